@@ -1,0 +1,222 @@
+"""CPU restatement of the TrackNetV3 heatmap -> coordinate post-process.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Reference lines followed:
+* get_ensemble_weight                     test.py:25-50
+* predict_location                        test.py:52-79   (cv2.findContours + cv2.boundingRect)
+* generate_inpaint_mask                   test.py:223-258
+* to_img                                  utils/general.py:110-122
+* predict                                 predict.py:14-69
+* heat-map temporal ensemble loop         predict.py:163-209
+* coordinate temporal ensemble loop       predict.py:243-301
+* COOR_TH etc.                            utils/general.py:15-19
+
+PARITY UNPINNED at one boundary: ``predict_location`` calls into OpenCV
+(opencv_python==4.4.0.46, requirements.txt:3), which is not vendored in the
+reference and not installed in this image, and the reference ships no tests or
+golden vectors for it.  The restatement follows OpenCV's documented semantics
+(8-connected foreground components, RETR_EXTERNAL outer borders only,
+boundingRect = (min_x, min_y, max_x-min_x+1, max_y-min_y+1)); contour order is
+"last discovered in raster scan first", which together with the strict ``>`` at
+test.py:74 means: among equal-area boxes the component whose first raster
+pixel comes LAST wins.  That tie rule is a single switch (``TIE_LAST_WINS``).
+``scipy.ndimage.label`` is used as an independent cross-check of the
+component / bounding-box part in tests/.
+"""
+import math
+
+import numpy as np
+
+HEIGHT = 288
+WIDTH = 512
+SIGMA = 2.5
+DELTA_T = 1 / math.sqrt(HEIGHT ** 2 + WIDTH ** 2)
+COOR_TH = DELTA_T * 50
+
+TIE_LAST_WINS = True   # see module docstring
+
+
+def get_ensemble_weight(seq_len, eval_mode):
+    """test.py:39-50."""
+    if eval_mode == "average":
+        w = np.ones(seq_len, dtype=np.float32) / np.float32(seq_len)
+    elif eval_mode == "weight":
+        w = np.ones(seq_len, dtype=np.float32)
+        for i in range(math.ceil(seq_len / 2)):
+            w[i] = i + 1
+            w[seq_len - i - 1] = i + 1
+        w = w / w.sum(dtype=np.float32)
+    else:
+        raise ValueError("Invalid mode")
+    return w.astype(np.float32)
+
+
+def to_img(image):
+    """utils/general.py:120-122."""
+    return (image * 255).astype("uint8")
+
+
+def connected_boxes(binary):
+    """8-connected foreground components in raster discovery order.
+
+    Returns [(x, y, w, h, first_pixel_linear_index)] -- what cv2.findContours(RETR_EXTERNAL)
+    + cv2.boundingRect yield for outer borders.  (Components nested inside another
+    component's hole are also listed here; their boxes are strictly inside the outer
+    box so they can never win or tie on area -- SURVEY 8c.)
+    """
+    h, w = binary.shape
+    fg = binary != 0
+    seen = np.zeros((h, w), dtype=bool)
+    boxes = []
+    ys, xs = np.nonzero(fg)
+    for y0, x0 in zip(ys.tolist(), xs.tolist()):
+        if seen[y0, x0]:
+            continue
+        stack = [(y0, x0)]
+        seen[y0, x0] = True
+        x_min = x_max = x0
+        y_min = y_max = y0
+        while stack:
+            y, x = stack.pop()
+            x_min, x_max = min(x_min, x), max(x_max, x)
+            y_min, y_max = min(y_min, y), max(y_max, y)
+            for dy in (-1, 0, 1):
+                yy = y + dy
+                if yy < 0 or yy >= h:
+                    continue
+                for dx in (-1, 0, 1):
+                    xx = x + dx
+                    if xx < 0 or xx >= w or seen[yy, xx] or not fg[yy, xx]:
+                        continue
+                    seen[yy, xx] = True
+                    stack.append((yy, xx))
+        boxes.append((x_min, y_min, x_max - x_min + 1, y_max - y_min + 1, y0 * w + x0))
+    return boxes
+
+
+def predict_location(heatmap):
+    """test.py:52-79 on a uint8 (H, W) map -> (x, y, w, h) of the max-area bounding box."""
+    if np.amax(heatmap) == 0:
+        return 0, 0, 0, 0
+    rects = connected_boxes(heatmap)
+    if TIE_LAST_WINS:
+        rects = rects[::-1]          # cv2 contour order: last discovered first
+    max_area_idx = 0
+    max_area = rects[0][2] * rects[0][3]
+    for i in range(1, len(rects)):
+        area = rects[i][2] * rects[i][3]
+        if area > max_area:
+            max_area_idx = i
+            max_area = area
+    x, y, w, h, _ = rects[max_area_idx]
+    return x, y, w, h
+
+
+def predict(indices, y_pred=None, c_pred=None, img_scaler=(1, 1)):
+    """predict.py:28-69.  indices (N, L, 2) ints; y_pred (N, L, H, W) float; c_pred (N, L, 2)."""
+    pred_dict = {"Frame": [], "X": [], "Y": [], "Visibility": []}
+    indices = np.asarray(indices)
+    batch_size, seq_len = indices.shape[0], indices.shape[1]
+    if y_pred is not None:
+        y_pred = np.asarray(y_pred) > 0.5
+    if c_pred is not None:
+        c_pred = np.asarray(c_pred)
+    prev_f_i = -1
+    for n in range(batch_size):
+        for f in range(seq_len):
+            f_i = indices[n][f][1]
+            if f_i != prev_f_i:
+                if c_pred is not None:
+                    c_p = c_pred[n][f]
+                    cx_pred = int(c_p[0] * WIDTH * img_scaler[0])
+                    cy_pred = int(c_p[1] * HEIGHT * img_scaler[1])
+                elif y_pred is not None:
+                    bbox = predict_location(to_img(y_pred[n][f]))
+                    cx_pred, cy_pred = int(bbox[0] + bbox[2] / 2), int(bbox[1] + bbox[3] / 2)
+                    cx_pred, cy_pred = int(cx_pred * img_scaler[0]), int(cy_pred * img_scaler[1])
+                else:
+                    raise ValueError("Invalid input")
+                vis_pred = 0 if cx_pred == 0 and cy_pred == 0 else 1
+                pred_dict["Frame"].append(int(f_i))
+                pred_dict["X"].append(cx_pred)
+                pred_dict["Y"].append(cy_pred)
+                pred_dict["Visibility"].append(vis_pred)
+                prev_f_i = f_i
+            else:
+                break
+    return pred_dict
+
+
+def generate_inpaint_mask(pred_dict, th_h=30):
+    """test.py:234-258."""
+    y = np.array(pred_dict["Y"])
+    vis_pred = np.array(pred_dict["Visibility"])
+    inpaint_mask = np.zeros_like(y)
+    i = 0
+    j = 0
+    threshold = th_h
+    while j < len(vis_pred):
+        while i < len(vis_pred) - 1 and vis_pred[i] == 1:
+            i += 1
+        j = i
+        while j < len(vis_pred) - 1 and vis_pred[j] == 0:
+            j += 1
+        if j == i:
+            break
+        elif i == 0 and y[j] > threshold:
+            inpaint_mask[:j] = 1
+        elif (i > 1 and y[i - 1] > threshold) and (j < len(vis_pred) and y[j] > threshold):
+            inpaint_mask[i:j] = 1
+        else:
+            pass
+        i = j
+    return inpaint_mask.tolist()
+
+
+def ensemble_stream(window_batches, seq_len, eval_mode, num_sample):
+    """Literal restatement of the buffer loop predict.py:163-209 (heat maps) and
+    predict.py:245-301 (coordinates): ``window_batches`` is an iterable of float32 arrays
+    (B, L, *tail) -- the per-window network outputs in sliding-step-1 order.  Yields one
+    array per batch: the ensembled per-frame predictions (n_frames_in_batch, *tail),
+    including the tail flush after the last window.
+    """
+    weight = get_ensemble_weight(seq_len, eval_mode)
+    buffer_size = seq_len - 1
+    batch_i = np.arange(seq_len)
+    frame_i = np.arange(seq_len - 1, -1, -1)
+    buf = None
+    sample_count = 0
+    for y_pred in window_batches:
+        y_pred = np.asarray(y_pred, dtype=np.float32)
+        tail = y_pred.shape[2:]
+        if buf is None:
+            buf = np.zeros((buffer_size, seq_len) + tail, dtype=np.float32)
+        b_size = y_pred.shape[0]
+        buf = np.concatenate((buf, y_pred), axis=0)
+        out = []
+        wb = weight.reshape((seq_len,) + (1,) * len(tail))
+        for b in range(b_size):
+            if sample_count < buffer_size:
+                e = buf[batch_i + b, frame_i].sum(0, dtype=np.float32) / np.float32(sample_count + 1)
+            else:
+                e = (buf[batch_i + b, frame_i] * wb).sum(0, dtype=np.float32)
+            out.append(e.astype(np.float32))
+            sample_count += 1
+            if sample_count == num_sample:
+                pad = np.zeros((buffer_size, seq_len) + tail, dtype=np.float32)
+                buf = np.concatenate((buf, pad), axis=0)
+                for f in range(1, seq_len):
+                    e = buf[batch_i + b + f, frame_i].sum(0, dtype=np.float32) / np.float32(seq_len - f)
+                    out.append(e.astype(np.float32))
+        yield np.stack(out, axis=0)
+        buf = buf[-buffer_size:]
+
+
+def inpaint_blend_threshold(coor_inpaint, coor_pred, inpaint_mask):
+    """predict.py:225-232: out*m + in*(1-m); zero where both x,y < COOR_TH."""
+    out = coor_inpaint * inpaint_mask + coor_pred * (1 - inpaint_mask)
+    th = (out[:, :, 0] < COOR_TH) & (out[:, :, 1] < COOR_TH)
+    out = out.copy()
+    out[th] = 0.0
+    return out
