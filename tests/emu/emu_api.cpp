@@ -1,0 +1,22 @@
+// emu_api.cpp -- the C ABI of include/tracknetv3_hip.h built on the host SIMT emulator (hip_emu.h).
+// TEST TOOL: lets the CPU test-suite run the unchanged kernel headers and the unchanged dispatch code
+// (tnv3_impl.h) on host memory.  Never loaded by the product package on its own.
+// Build: clang++ -std=c++17 -O2 -shared -fPIC -include tests/emu/hip_emu.h tests/emu/emu_api.cpp
+#include "../../include/tracknetv3_hip.h"
+#include "../../tracknetv3_amd/csrc/tnv3_impl.h"
+
+namespace {
+struct Launcher {
+  template <class... KArgs, class... Args>
+  int launch(void (*kernel)(KArgs...), int grid, int block, Args... args) {
+    emu::launch(emu_dim3{(unsigned)grid, 1, 1}, emu_dim3{(unsigned)block, 1, 1},
+                [=]() { kernel(static_cast<KArgs>(args)...); });
+    return TNV3_OK;
+  }
+};
+inline Launcher make_launcher(tnv3_stream_t) { return Launcher{}; }
+}  // namespace
+
+#include "../../tracknetv3_amd/csrc/tnv3_capi_body.inc"
+
+extern "C" int tnv3_is_emulator(void) { return 1; }

@@ -1,0 +1,265 @@
+// hip_emu.h -- a tiny host-side SIMT emulator for gfx950 HIP kernels.  TEST TOOL ONLY.
+//
+// The build container has no GPU.  This header lets the UNCHANGED kernel headers under
+// tracknetv3_amd/csrc/kernels/ be compiled by the host clang (-include hip_emu.h) and executed
+// lane-by-lane, so that tile/lane/LDS index arithmetic and the MFMA fragment mapping are checked
+// against the oracle by the CPU test-suite before any GPU minute is spent.  It is never part of
+// the product: the shipped library is built by hipcc from the same kernel headers.
+//
+// Model: one workgroup at a time; each work-item is a ucontext fiber; fibers yield at
+// __syncthreads() and at wave-level exchanges (shuffles, MFMA).  The MFMA emulation implements the
+// documented gfx950 fragment layouts (guide: cdna_hip_programming.md section 3):
+//   32x32x2 f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D reg r -> row=(r&3)+8*(r>>2)+4*(l>>5), col=l&31
+//   16x16x4 f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D reg r -> row=4*(l>>4)+r,            col=l&15
+// and computes each output as the k-ordered fmaf chain the hardware produces.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define TNV3_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct emu_dim3 { unsigned x, y, z; };
+static emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+
+enum { WAVE = 64, MAX_WAVES = 16 };
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  bool wait_block = false;
+  unsigned wait_gen = 0;
+  emu_dim3 tid{};
+};
+
+struct State {
+  ucontext_t main_ctx;
+  std::vector<Fiber> fibers;
+  Fiber* cur = nullptr;
+  unsigned nthreads = 0;
+  unsigned block_gen = 0, block_count = 0;
+  unsigned wave_gen[MAX_WAVES], wave_count[MAX_WAVES], wave_size[MAX_WAVES];
+  uint64_t xchg[MAX_WAVES][4][WAVE];   // per-wave exchange scratch
+  std::function<void()> body;
+};
+inline State& S() { static State s; return s; }
+
+inline unsigned flat_tid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
+inline unsigned lane_id() { return flat_tid() % WAVE; }
+inline unsigned wave_id() { return flat_tid() / WAVE; }
+
+inline void yield() {
+  State& s = S();
+  Fiber* f = s.cur;
+  swapcontext(&f->ctx, &s.main_ctx);
+  threadIdx = f->tid;
+}
+
+inline void block_barrier() {
+  State& s = S();
+  Fiber* f = s.cur;
+  unsigned g = s.block_gen;
+  if (++s.block_count == s.nthreads) { s.block_count = 0; ++s.block_gen; return; }
+  f->wait_block = true; f->wait_gen = g;
+  while (s.block_gen == g) yield();
+  f->wait_block = false;
+}
+
+inline void wave_barrier() {
+  State& s = S();
+  unsigned w = wave_id();
+  unsigned g = s.wave_gen[w];
+  if (++s.wave_count[w] == s.wave_size[w]) { s.wave_count[w] = 0; ++s.wave_gen[w]; return; }
+  while (s.wave_gen[w] == g) yield();
+}
+
+inline void fiber_entry() {
+  State& s = S();
+  threadIdx = s.cur->tid;
+  s.body();
+  s.cur->done = true;
+  swapcontext(&s.cur->ctx, &s.main_ctx);
+}
+
+// Run `body` for every work-item of a grid.
+inline void launch(emu_dim3 grid, emu_dim3 block, std::function<void()> body) {
+  State& s = S();
+  const size_t STACK = 256 * 1024;
+  s.nthreads = block.x * block.y * block.z;
+  if (s.nthreads > MAX_WAVES * WAVE) { fprintf(stderr, "emu: block too large\n"); abort(); }
+  gridDim = grid; blockDim = block;
+  s.body = std::move(body);
+  if (s.fibers.size() < s.nthreads) s.fibers.resize(s.nthreads);
+  for (unsigned i = 0; i < s.nthreads; ++i)
+    if (!s.fibers[i].stack) s.fibers[i].stack = (char*)malloc(STACK);
+  unsigned nwaves = (s.nthreads + WAVE - 1) / WAVE;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+  for (unsigned by = 0; by < grid.y; ++by)
+  for (unsigned bx = 0; bx < grid.x; ++bx) {
+    blockIdx = {bx, by, bz};
+    s.block_gen = 0; s.block_count = 0;
+    for (unsigned w = 0; w < nwaves; ++w) {
+      s.wave_gen[w] = 0; s.wave_count[w] = 0;
+      unsigned rem = s.nthreads - w * WAVE; s.wave_size[w] = rem < WAVE ? rem : WAVE;
+    }
+    for (unsigned i = 0; i < s.nthreads; ++i) {
+      Fiber& f = s.fibers[i];
+      f.done = false; f.wait_block = false;
+      f.tid = {i % block.x, (i / block.x) % block.y, i / (block.x * block.y)};
+      getcontext(&f.ctx);
+      f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
+      makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    unsigned remaining = s.nthreads;
+    unsigned long guard = 0;
+    while (remaining) {
+      for (unsigned w = 0; w < nwaves; ++w) {
+        for (;;) {   // run this wave until all its lanes are done or parked at a block barrier
+          bool any = false;
+          for (unsigned l = 0; l < s.wave_size[w]; ++l) {
+            Fiber& f = s.fibers[w * WAVE + l];
+            if (f.done) continue;
+            if (f.wait_block && f.wait_gen == s.block_gen) continue;
+            s.cur = &f; threadIdx = f.tid;
+            swapcontext(&s.main_ctx, &f.ctx);
+            any = true;
+            if (f.done) --remaining;
+          }
+          if (!any) break;
+          if (++guard > (1ul << 34)) { fprintf(stderr, "emu: livelock (divergent barrier?)\n"); abort(); }
+        }
+      }
+    }
+  }
+}
+
+template <class T> inline uint64_t to_bits(T v) { uint64_t b = 0; memcpy(&b, &v, sizeof(T)); return b; }
+template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
+
+// generic "read value of lane src" with all lanes participating
+template <class T> inline T wave_read(T v, unsigned src_lane) {
+  State& s = S(); unsigned w = wave_id(), l = lane_id();
+  s.xchg[w][0][l] = to_bits(v);
+  wave_barrier();
+  T r = (src_lane < s.wave_size[w]) ? from_bits<T>(s.xchg[w][0][src_lane]) : v;
+  wave_barrier();
+  return r;
+}
+}  // namespace emu
+
+// ------------------------------------------------------------------ HIP surface used by the kernels
+inline void __syncthreads() { emu::block_barrier(); }
+inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __threadfence() {}
+
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+  unsigned l = emu::lane_id(); unsigned base = l - (l % width);
+  return emu::wave_read(v, base + (unsigned(src) % width));
+}
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
+  unsigned l = emu::lane_id(); unsigned t = l ^ unsigned(mask);
+  if ((t / width) != (l / width)) t = l;
+  return emu::wave_read(v, t);
+}
+template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
+  unsigned l = emu::lane_id(); unsigned t = l + d;
+  if ((t / width) != (l / width)) t = l;
+  return emu::wave_read(v, t);
+}
+template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
+  unsigned l = emu::lane_id(); int t = int(l) - int(d);
+  if (t < 0 || (unsigned(t) / width) != (l / width)) t = l;
+  return emu::wave_read(v, unsigned(t));
+}
+inline unsigned long long __ballot(int pred) {
+  emu::State& s = emu::S(); unsigned w = emu::wave_id(), l = emu::lane_id();
+  s.xchg[w][0][l] = pred ? 1 : 0;
+  emu::wave_barrier();
+  unsigned long long m = 0;
+  for (unsigned i = 0; i < s.wave_size[w]; ++i) if (s.xchg[w][0][i]) m |= 1ull << i;
+  emu::wave_barrier();
+  return m;
+}
+inline int __any(int p) { return __ballot(p) != 0; }
+inline int __all(int p) { emu::State& s = emu::S(); unsigned n = s.wave_size[emu::wave_id()];
+  unsigned long long full = n == 64 ? ~0ull : ((1ull << n) - 1); return __ballot(p) == full; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __builtin_amdgcn_readfirstlane(int v) { return emu::wave_read(v, 0); }
+
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+
+inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
+  emu::State& s = emu::S(); unsigned w = emu::wave_id(), l = emu::lane_id();
+  if (s.wave_size[w] != 64) { fprintf(stderr, "emu: MFMA needs a full wave\n"); abort(); }
+  s.xchg[w][1][l] = emu::to_bits(a); s.xchg[w][2][l] = emu::to_bits(b);
+  emu::wave_barrier();
+  emu_f32x16 d;
+  for (int r = 0; r < 16; ++r) {
+    unsigned row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    float acc = c[r];
+    for (unsigned k = 0; k < 2; ++k)
+      acc = fmaf(emu::from_bits<float>(s.xchg[w][1][row + 32 * k]), emu::from_bits<float>(s.xchg[w][2][col + 32 * k]), acc);
+    d[r] = acc;
+  }
+  emu::wave_barrier();
+  return d;
+}
+inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
+  emu::State& s = emu::S(); unsigned w = emu::wave_id(), l = emu::lane_id();
+  if (s.wave_size[w] != 64) { fprintf(stderr, "emu: MFMA needs a full wave\n"); abort(); }
+  s.xchg[w][1][l] = emu::to_bits(a); s.xchg[w][2][l] = emu::to_bits(b);
+  emu::wave_barrier();
+  emu_f32x4 d;
+  for (int r = 0; r < 4; ++r) {
+    unsigned row = 4 * (l >> 4) + r, col = l & 15;
+    float acc = c[r];
+    for (unsigned k = 0; k < 4; ++k)
+      acc = fmaf(emu::from_bits<float>(s.xchg[w][1][row + 16 * k]), emu::from_bits<float>(s.xchg[w][2][col + 16 * k]), acc);
+    d[r] = acc;
+  }
+  emu::wave_barrier();
+  return d;
+}
+
+// atomics (the emulator is single-threaded: plain read-modify-write)
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+
+inline float __expf(float x) { return expf(x); }
+inline float __logf(float x) { return logf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float __frcp_rn(float a) { return 1.0f / a; }
+inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
+inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
+template <class T> inline T __ldg(const T* p) { return *p; }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
+inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }

@@ -1,0 +1,128 @@
+"""ctypes binding of libtnv3_hip.so (C ABI: include/tracknetv3_hip.h).
+
+The product path has NO fallback: if the HIP library cannot be loaded, every op raises.  The only other
+library this module will ever bind is the CPU SIMT emulator built by the test-suite, and only when a test
+calls ``use_library()`` explicitly (it is never searched for or loaded implicitly).
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _build
+
+_c = ctypes
+_f32p = _c.c_void_p
+_lib = None
+_is_emulator = False
+
+
+class Tnv3Error(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    def sig(name, restype, *argtypes):
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+
+    i, p, f, sz, lg = _c.c_int, _c.c_void_p, _c.c_float, _c.c_size_t, _c.c_long
+    ip = _c.POINTER(_c.c_int)
+    sig("tnv3_abi_version", i)
+    sig("tnv3_last_error", _c.c_char_p)
+    sig("tnv3_conv3x3_num_configs", i)
+    sig("tnv3_conv3x3_config_info", i, i, ip, ip, ip, ip, ip, ip)
+    sig("tnv3_conv3x3_packed_floats", sz, i, i, i)
+    sig("tnv3_pack_conv3x3_weights", i, p, p, i, i, i, p)
+    sig("tnv3_bn_fold", i, p, p, p, p, f, p, p, i, p)
+    sig("tnv3_conv3x3_forward", i, p, p, p, p, p, p, i, i, i, i, i, i, i, i, i, p)
+    sig("tnv3_head1x1_sigmoid", i, p, p, p, p, i, i, i, i, i, p)
+    sig("tnv3_maxpool2x2", i, p, p, lg, i, i, p)
+    for name, spec in _OPTIONAL.items():
+        if hasattr(lib, name):
+            sig(name, *spec)
+
+
+_OPTIONAL = {}   # later entry points register here: name -> (restype, *argtypes)
+
+EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "tnv3_conv3x3_config_info",
+           "tnv3_conv3x3_packed_floats", "tnv3_pack_conv3x3_weights", "tnv3_bn_fold", "tnv3_conv3x3_forward",
+           "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2"]
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building first if sources are newer and hipcc exists) the HIP library.  Raises if impossible."""
+    global _lib, _is_emulator
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            raise Tnv3Error(f"libtnv3_hip.so is missing and could not be built: {e}") from e
+    try:
+        lib = _c.CDLL(path)
+    except OSError as e:
+        raise Tnv3Error(f"cannot load {path}: {e}") from e
+    _declare(lib)
+    if lib.tnv3_abi_version() != 1:
+        raise Tnv3Error("libtnv3_hip.so ABI version mismatch")
+    _lib, _is_emulator = lib, False
+    return lib
+
+
+def use_library(path):
+    """TEST HOOK: bind an explicitly given library (the CPU SIMT emulator of tests/emu)."""
+    global _lib, _is_emulator
+    lib = _c.CDLL(path)
+    _declare(lib)
+    _lib = lib
+    _is_emulator = hasattr(lib, "tnv3_is_emulator")
+    return lib
+
+
+def reset_library():
+    global _lib, _is_emulator
+    _lib, _is_emulator = None, False
+
+
+def is_emulator():
+    return _is_emulator
+
+
+def check(rc):
+    if rc != 0:
+        raise Tnv3Error(f"tnv3 error {rc}: {load().tnv3_last_error().decode()}")
+
+
+def stream_ptr(t):
+    if t.is_cuda:
+        return _c.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return _c.c_void_p(0)
+
+
+def dev_check(*tensors):
+    """All tensors: fp32 (or stated), contiguous, on one device; device must be a GPU unless the emulator is bound."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_contiguous():
+            raise Tnv3Error("tnv3 ops need contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise Tnv3Error(f"tensors on different devices: {t.device} vs {dev}")
+    if dev is not None and not dev.type == "cuda" and not _is_emulator:
+        raise Tnv3Error("tnv3 ops run on the GPU only (tensor is on %s); there is no CPU fallback" % dev)
+    return dev
+
+
+def ptr(t):
+    return _c.c_void_p(t.data_ptr()) if t is not None else _c.c_void_p(0)

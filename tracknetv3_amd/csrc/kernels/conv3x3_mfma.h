@@ -1,0 +1,304 @@
+// conv3x3_mfma.h -- direct 3x3 convolution (stride 1, zero pad 1, NCHW fp32) as an implicit GEMM on
+// the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain).
+//
+// Replaces the implicit ATen/cuDNN kernels behind the reference's
+//   Conv2DBlock  = nn.Conv2d(k=3, padding='same', bias=False) -> BatchNorm2d -> ReLU   (model.py:4-16)
+// and, through the dual-source loader, `torch.cat([nn.Upsample(scale_factor=2)(x), skip], dim=1)`
+// (model.py:65,67,69) without ever materialising the upsampled / concatenated tensor.
+//
+// GEMM view per workgroup:  D[co, pix] = sum_{ci,kh,kw} Wp[ci,kh,kw,co] * X[ci, h+kh-1, w+kw-1]
+//   M = MB output channels, N = TR x TC output pixels, K = Cin*9 walked in chunks of CC channels.
+//   MFMA 32x32x2:  lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+//                  D reg r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
+//   j = 32 consecutive pixels of one image row, so the B operand of lane l for tap (kh,kw) is one
+//   ds_read_b32 at  lane_base + const  from the LDS-staged halo tile -- conflict free (each 32-lane half
+//   reads 32 consecutive dwords).  The two K slots of one MFMA are two consecutive input channels at the
+//   same tap, so all LDS addresses in the main loop are `per-lane base + immediate`.
+//   Weights are pre-packed [Cin_pad][3][3][Cout] so the A operand is also a 32-consecutive-dword read.
+//
+// Pipeline: 2 LDS buffers; global loads of chunk k+1 are issued before the MFMA block of chunk k and
+// written to the other LDS buffer after it (register staging), one barrier per chunk.
+//
+// Roofline: every layer here has fp32 arithmetic intensity >= 85 FLOP/B, so the kernel is
+// bound by the 157.3 TFLOP/s fp32 MFMA rate, not by HBM.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tnv3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Conv3x3Args {
+  const float* src0;    // [N][C0][H0][W0]   H0,W0 = H,W (up0 == 0) or H/2,W/2 (up0 == 1: nearest 2x upsample on load)
+  const float* src1;    // [N][C1][H][W] or nullptr; its channels follow src0's (cat([up(src0), src1], dim=1))
+  const float* wpack;   // [Cin_pad][9][Cout], Cin_pad = roundup(C0+C1, CC), padding rows zero
+  const float* scale;   // [Cout] or nullptr  -> y = acc*scale + shift   (eval-mode BN folded to an affine)
+  const float* shift;   // [Cout] or nullptr
+  float* dst;           // [N][Cout][H][W]
+  int N, C0, C1, Cout, H, W;
+  int up0;              // 1: src0 is stored at (H/2, W/2) and read as out[h][w] = src0[h>>1][w>>1]
+  int relu;             // 1: y = max(y, 0)
+};
+
+template <int MT_, int NTW_, int WM_, int WN_, int TR_, int TC_, int CC_, int MINW_ = 1>
+struct ConvCfg {
+  static constexpr int MT = MT_, NTW = NTW_, WM = WM_, WN = WN_, TR = TR_, TC = TC_, CC = CC_;
+  static constexpr int MINW = MINW_;                 // __launch_bounds__ 2nd argument: waves per SIMD to fit
+  static constexpr int NT = WM * WN * 64;            // threads per workgroup
+  static constexpr int MB = MT * 32 * WM;            // output channels per workgroup
+  static constexpr int CS = TC / 32;                 // 32-pixel column segments per tile row
+  static_assert(TC % 32 == 0, "tile width must be a multiple of the MFMA N (32)");
+  static_assert(TR * CS == NTW * WN, "pixel tile must equal waves x N-tiles");
+  static_assert(NTW % CS == 0, "each wave must own whole tile rows");
+  static_assert(CC % 2 == 0 && CC <= 32, "channel chunk must be even (one MFMA = 2 channels)");
+  static constexpr int TRp = TR + 2, TCp = TC + 2, PLANE = TRp * TCp;
+  static constexpr int E_IN = CC * PLANE;                       // halo-tile elements per chunk
+  static constexpr int NIN = (E_IN + NT - 1) / NT;              // staged elements per thread
+  static constexpr int IN_FLOATS = NIN * NT;                    // LDS floats (padded so every thread stores)
+  static constexpr int KROWS = CC * 9;
+  static constexpr int W_FLOATS = KROWS * MB;
+  static constexpr int E_W4 = W_FLOATS / 4;
+  static constexpr int NW4 = (E_W4 + NT - 1) / NT;
+  static constexpr int BUF_FLOATS = W_FLOATS + IN_FLOATS;       // one pipeline stage
+  static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+};
+
+// Block index -> (output-channel block, pixel tile).  Workgroup b is observed to run on XCD b % 8 (speed
+// only, never correctness): XCDs are split into nMB groups so that one XCD's L2 holds one weight panel, and
+// each XCD walks a contiguous range of pixel tiles so vertical halo rows are L2 hits.
+__device__ __forceinline__ bool conv_block_map(int b, int nMB, int nPT, int& mb, int& pt) {
+  if (nMB <= 8 && (8 % nMB) == 0) {
+    const int G = 8 / nMB;                      // XCDs per channel block
+    const int per = (nPT + G - 1) / G;          // pixel tiles per XCD
+    const int xcd = b & 7, q = b >> 3;
+    mb = xcd % nMB;
+    pt = (xcd / nMB) * per + q;
+    return q < per && pt < nPT;
+  }
+  mb = b % nMB;
+  pt = b / nMB;
+  return pt < nPT;
+}
+
+__host__ __device__ inline int conv_grid_blocks(int nMB, int nPT) {
+  if (nMB <= 8 && (8 % nMB) == 0) {
+    const int G = 8 / nMB;
+    return 8 * ((nPT + G - 1) / G);
+  }
+  return nMB * nPT;
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const Conv3x3Args a) {
+  constexpr int MT = Cfg::MT, NTW = Cfg::NTW, WN = Cfg::WN, TR = Cfg::TR, TC = Cfg::TC, CC = Cfg::CC;
+  constexpr int NT = Cfg::NT, MB = Cfg::MB, CS = Cfg::CS, TRp = Cfg::TRp, TCp = Cfg::TCp, PLANE = Cfg::PLANE;
+  constexpr int NIN = Cfg::NIN, NW4 = Cfg::NW4, KROWS = Cfg::KROWS;
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int half = lane >> 5, bl = lane & 31;
+
+  const int H = a.H, W = a.W, Cout = a.Cout, C0 = a.C0, C1 = a.C1;
+  const int Cin = C0 + C1;
+  const int tilesH = (H + TR - 1) / TR, tilesW = (W + TC - 1) / TC;
+  const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
+  int mb, pt;
+  if (!conv_block_map(blockIdx.x, nMB, nPT, mb, pt)) return;   // whole workgroup leaves together
+  const int n = pt / (tilesH * tilesW);
+  const int trem = pt - n * (tilesH * tilesW);
+  const int h0 = (trem / tilesW) * TR, w0 = (trem % tilesW) * TC;
+  const int m0 = mb * MB;
+
+  const int HW = H * W;
+  const int H0 = a.up0 ? (H >> 1) : H, W0 = a.up0 ? (W >> 1) : W;
+  const int HW0 = H0 * W0;
+
+  // ---- per-thread staging slots: element e = tid + i*NT of the [CC][TRp][TCp] halo tile
+  // packed as c<<26 | gh<<13 | gw, or -1 when the slot is outside the image (zero padding) / unused
+  int sp[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int e = tid + i * NT;
+    const int c = e / PLANE, r = e - c * PLANE;
+    const int tr = r / TCp, tc = r - tr * TCp;
+    const int gh = h0 - 1 + tr, gw = w0 - 1 + tc;
+    const bool ok = (e < Cfg::E_IN) && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    sp[i] = ok ? ((c << 26) | (gh << 13) | gw) : -1;
+  }
+
+  float rin[NIN];
+  f32x4 rw[NW4];
+
+  // Validity of slot i for chunk k (zero padding outside the image / beyond the last input channel).
+  auto slot_ok = [&](int i, int k) -> bool {
+    const int s = sp[i];
+    const int cbeg = k * CC;
+    const int climit = (cbeg < C0 ? C0 : Cin) - cbeg;
+    return (s != -1) && ((int)((unsigned)s >> 26) < climit);
+  };
+
+  // Issue the global loads of chunk k into registers.  Nothing here consumes a loaded value, so the loads
+  // stay in flight across the MFMA block that follows; the zero-padding select happens in store_stage.
+  auto load_stage = [&](int k) {
+    const int cbeg = k * CC;
+    const bool from0 = cbeg < C0;
+    const float* base = from0 ? a.src0 + ((size_t)n * C0 + cbeg) * HW0
+                              : a.src1 + ((size_t)n * C1 + (cbeg - C0)) * HW;
+    if (from0 && a.up0) {
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) {
+        const int s = sp[i];
+        const int c = (int)((unsigned)s >> 26), gh = (s >> 13) & 8191, gw = s & 8191;
+        const int off = slot_ok(i, k) ? (c * HW0 + (gh >> 1) * W0 + (gw >> 1)) : 0;
+        rin[i] = base[off];
+      }
+    } else {
+      const int hw = from0 ? HW0 : HW;   // == HW when not upsampled
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) {
+        const int s = sp[i];
+        const int c = (int)((unsigned)s >> 26), gh = (s >> 13) & 8191, gw = s & 8191;
+        const int off = slot_ok(i, k) ? (c * hw + gh * W + gw) : 0;
+        rin[i] = base[off];
+      }
+    }
+    const float* wsrc = a.wpack + (size_t)k * KROWS * Cout + m0;
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+      const int e4 = tid + i * NT;
+      const int krow = e4 / (MB / 4), m4 = e4 - krow * (MB / 4);
+      if ((i + 1) * NT <= Cfg::E_W4 || e4 < Cfg::E_W4)
+        rw[i] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)krow * Cout + m4 * 4);
+    }
+  };
+
+  auto store_stage = [&](int buf, int k) {
+    float* lw = lds + buf * Cfg::BUF_FLOATS;
+    float* li = lw + Cfg::W_FLOATS;
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+      const int e4 = tid + i * NT;
+      if ((i + 1) * NT <= Cfg::E_W4 || e4 < Cfg::E_W4) *reinterpret_cast<f32x4*>(lw + e4 * 4) = rw[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) li[tid + i * NT] = slot_ok(i, k) ? rin[i] : 0.0f;
+  };
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.0f;
+
+  // per-lane LDS bases (floats) inside one stage
+  const int a_off = half * 9 * MB + wm * (MT * 32) + bl;
+  const int b_off = Cfg::W_FLOATS + (half * TRp + wn * (NTW / CS)) * TCp + bl;
+
+  const int nChunks = (Cin + CC - 1) / CC;
+  load_stage(0);
+  store_stage(0, 0);
+  __syncthreads();
+
+  for (int k = 0; k < nChunks; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < nChunks) load_stage(k + 1);
+
+    const float* A = lds + buf * Cfg::BUF_FLOATS + a_off;
+    const float* B = lds + buf * Cfg::BUF_FLOATS + b_off;
+    // K-steps of this chunk: step s = (channel pair cp, tap); operands of step s+1 are read from LDS before
+    // the MFMAs of step s are issued (static double buffer), so LDS latency hides under the matrix pipe.
+    constexpr int NSTEP = (CC / 2) * 9;
+    float av[2][MT], bv[2][NTW];
+    auto read_step = [&](int s, float (&ar)[MT], float (&br)[NTW]) {
+      const int cp = s / 9, tap = s - 9 * cp;
+      const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) ar[mt] = A[(2 * cp * 9 + tap) * MB + mt * 32];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) br[j] = B[(2 * cp * TRp + kh + j / CS) * TCp + kw + (j % CS) * 32];
+    };
+    read_step(0, av[0], bv[0]);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + 1 < NSTEP) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mt], bv[s & 1][j], acc[mt][j], 0, 0, 0);
+      // pin the order "LDS reads of step s+1, then the MFMAs of step s" in the machine scheduler
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NTW, 0);   // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);   // MFMA
+    }
+
+    if (k + 1 < nChunks) store_stage(buf ^ 1, k + 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: affine (folded eval-mode BN) + ReLU, 128-byte row segments per half-wave
+  const bool has_affine = a.scale != nullptr;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float sc = 1.0f, sh = 0.0f;
+      if (has_affine) { sc = a.scale[co]; sh = a.shift[co]; }
+      float* drow = a.dst + ((size_t)n * Cout + co) * HW;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int oh = h0 + wn * (NTW / CS) + j / CS;
+        const int ow = w0 + (j % CS) * 32 + bl;
+        float v = acc[mt][j][r];
+        if (has_affine) v = v * sc + sh;
+        if (a.relu) v = v > 0.0f ? v : 0.0f;
+        if (oh < H && ow < W) drow[oh * W + ow] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight packing:  W[Cout][Cin][3][3]  ->  Wp[Cin_pad][3][3][Cout]              (forward)
+//                  W[Cout][Cin][3][3]  ->  Wp[Cout_pad][3][3][Cin] with taps flipped  (dgrad: dX = conv(dY, W^T flipped))
+// One thread per packed element; rows >= the real K extent are zero.
+__global__ void pack_conv3x3_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                            int Cout, int Cin, int Kpad, int transpose_flip) {
+  const int M = transpose_flip ? Cin : Cout;     // packed inner (GEMM M) extent
+  const int Kc = transpose_flip ? Cout : Cin;    // packed outer (GEMM K channels) extent
+  const long total = (long)Kpad * 9 * M;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(e % M);
+    const long t = e / M;
+    const int tap = (int)(t % 9);
+    const int kc = (int)(t / 9);
+    float v = 0.0f;
+    if (kc < Kc) {
+      if (transpose_flip) v = w[((long)kc * Cin + m) * 9 + (8 - tap)];
+      else v = w[((long)m * Cin + kc) * 9 + tap];
+    }
+    wp[e] = v;
+  }
+}
+
+// Eval-mode BatchNorm2d as a per-channel affine (model.py:9):
+//   scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rmean, const float* __restrict__ rvar,
+                               float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float s = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - rmean[c] * s;
+  }
+}
+
+}  // namespace tnv3

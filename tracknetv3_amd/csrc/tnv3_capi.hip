@@ -1,0 +1,22 @@
+// tnv3_capi.hip -- libtnv3_hip.so: gfx950 kernels + C ABI (include/tracknetv3_hip.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see tracknetv3_amd/_build.py).
+#include <hip/hip_runtime.h>
+
+#include "../../include/tracknetv3_hip.h"
+#include "tnv3_impl.h"
+
+namespace {
+struct Launcher {
+  hipStream_t stream;
+  template <class... KArgs, class... Args>
+  int launch(void (*kernel)(KArgs...), int grid, int block, Args... args) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, static_cast<KArgs>(args)...);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) TNV3_FAIL(TNV3_E_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+    return TNV3_OK;
+  }
+};
+inline Launcher make_launcher(tnv3_stream_t s) { return Launcher{static_cast<hipStream_t>(s)}; }
+}  // namespace
+
+#include "tnv3_capi_body.inc"

@@ -1,0 +1,175 @@
+"""TrackNet / InpaintNet with the reference's module tree and ``state_dict`` layout, computed by libtnv3_hip.so.
+
+Drop-in for the reference's ``model.py`` (TrackNet: model.py:45-73, InpaintNet: model.py:100-129): same
+constructor arguments, same attribute names (including the misspelt ``buttleneck``), therefore the same 104 / 18
+``state_dict`` keys, shapes and dtypes, so reference checkpoints load with
+``load_state_dict(ckpt['model'])`` and ``torch.optim`` / ``clip_grad_norm_`` see ordinary leaf Parameters.
+
+The sub-modules below are parameter containers only: they never run a torch convolution.  ``forward`` enqueues
+hand-written gfx950 kernels through the C ABI (``ops``).  There is no CPU or ATen fallback: on a non-GPU tensor, or
+without the HIP library, the call raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import tuning
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _Conv3x3Params(nn.Module):
+    """Holds the filter of ``nn.Conv2d(in, out, 3, padding='same', bias=False)`` (model.py:8); default PyTorch init."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.weight = nn.Parameter(torch.empty(out_dim, in_dim, 3, 3))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+
+class _BatchNormParams(nn.Module):
+    """Holds the state of ``nn.BatchNorm2d(out)`` (model.py:9): weight, bias, running stats, step counter."""
+
+    def __init__(self, dim, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.register_buffer("running_mean", torch.zeros(dim))
+        self.register_buffer("running_var", torch.ones(dim))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class Conv2DBlock(nn.Module):
+    """Conv3x3 + BN + ReLU (model.py:4-16) as ONE fused kernel in eval mode."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.conv = _Conv3x3Params(in_dim, out_dim)
+        self.bn = _BatchNormParams(out_dim)
+        self._cache = {}
+
+    def _versions(self, names):
+        out = []
+        for n in names:
+            t = getattr(self.bn, n) if n != "conv" else self.conv.weight
+            out.append((t.data_ptr(), t._version))
+        return tuple(out)
+
+    def packed_weight(self, transpose_flip=False):
+        key = ("wd" if transpose_flip else "wf")
+        ver = self._versions(["conv"])
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_conv3x3_weights(self.conv.weight.detach(), transpose_flip=transpose_flip))
+            self._cache[key] = hit
+        return hit[1]
+
+    def folded_affine(self):
+        ver = self._versions(["weight", "bias", "running_mean", "running_var"])
+        hit = self._cache.get("aff")
+        if hit is None or hit[0] != ver:
+            bn = self.bn
+            hit = (ver, ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps))
+            self._cache["aff"] = hit
+        return hit[1]
+
+    def forward_eval(self, x, skip=None, up=False, layer_key=None):
+        scale, shift = self.folded_affine()
+        n = x.shape[0]
+        h = x.shape[2] * (2 if up else 1)
+        w = x.shape[3] * (2 if up else 1)
+        cfg = tuning.conv_config(self.conv.out_dim, self.conv.in_dim, n, h, w)
+        return ops.conv3x3(x, self.packed_weight(), self.conv.out_dim, src1=skip, scale=scale, shift=shift,
+                           up0=up, relu=True, cfg=cfg)
+
+    def forward(self, x):
+        if self.training:
+            from . import autograd_ops
+            return autograd_ops.conv_bn_relu_train(self, x)
+        return self.forward_eval(x)
+
+
+class Double2DConv(nn.Module):
+    """Conv2DBlock x 2 (model.py:18-28)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.conv_1 = Conv2DBlock(in_dim, out_dim)
+        self.conv_2 = Conv2DBlock(out_dim, out_dim)
+
+    def blocks(self):
+        return [self.conv_1, self.conv_2]
+
+
+class Triple2DConv(nn.Module):
+    """Conv2DBlock x 3 (model.py:30-42)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.conv_1 = Conv2DBlock(in_dim, out_dim)
+        self.conv_2 = Conv2DBlock(out_dim, out_dim)
+        self.conv_3 = Conv2DBlock(out_dim, out_dim)
+
+    def blocks(self):
+        return [self.conv_1, self.conv_2, self.conv_3]
+
+
+class _Conv1x1Params(nn.Module):
+    """Holds ``nn.Conv2d(64, out_dim, (1, 1))`` (model.py:54): weight (L,64,1,1) + bias (L,), default init."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_dim, in_dim, 1, 1))
+        self.bias = nn.Parameter(torch.empty(out_dim))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_dim)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class TrackNet(nn.Module):
+    """VGG-style U-Net heat-map network (model.py:45-73).  in: (N, in_dim, H, W) -> out: (N, out_dim, H, W)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.down_block_1 = Double2DConv(in_dim, 64)
+        self.down_block_2 = Double2DConv(64, 128)
+        self.down_block_3 = Triple2DConv(128, 256)
+        self.bottleneck = Triple2DConv(256, 512)
+        self.up_block_1 = Triple2DConv(768, 256)
+        self.up_block_2 = Double2DConv(384, 128)
+        self.up_block_3 = Double2DConv(192, 64)
+        self.predictor = _Conv1x1Params(64, out_dim)
+
+    # -- eval: 17 fused conv+BN+ReLU kernels, 3 pools, 1 head; upsample+concat folded into the consumer's loader
+    @staticmethod
+    def _chain_eval(blocks, x, skip=None, up=False):
+        x = blocks[0].forward_eval(x, skip=skip, up=up)
+        for b in blocks[1:]:
+            x = b.forward_eval(x)
+        return x
+
+    def _forward_eval(self, x):
+        x1 = self._chain_eval(self.down_block_1.blocks(), x)
+        x2 = self._chain_eval(self.down_block_2.blocks(), ops.maxpool2x2(x1))
+        x3 = self._chain_eval(self.down_block_3.blocks(), ops.maxpool2x2(x2))
+        x = self._chain_eval(self.bottleneck.blocks(), ops.maxpool2x2(x3))
+        x = self._chain_eval(self.up_block_1.blocks(), x, skip=x3, up=True)
+        x = self._chain_eval(self.up_block_2.blocks(), x, skip=x2, up=True)
+        x = self._chain_eval(self.up_block_3.blocks(), x, skip=x1, up=True)
+        return ops.head1x1_sigmoid(x, self.predictor.weight.detach(), self.predictor.bias.detach())
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_dim:
+            raise ValueError(f"TrackNet expects (N, {self.in_dim}, H, W), got {tuple(x.shape)}")
+        if (x.shape[2] % 8) or (x.shape[3] % 8):
+            raise ValueError("TrackNet needs H and W divisible by 8 (three 2x2 poolings)")
+        x = x.contiguous()
+        if self.training:
+            from . import autograd_ops
+            return autograd_ops.tracknet_forward_train(self, x)
+        with torch.no_grad():
+            return self._forward_eval(x)

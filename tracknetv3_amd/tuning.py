@@ -1,0 +1,32 @@
+"""Per-layer tile-configuration table for the MFMA conv kernel.
+
+``conv_tuning.json`` is produced on an MI355X by ``python bench.py --tune`` (it times every compiled tile
+configuration on every distinct conv shape of the workload and keeps the fastest).  Without an entry the library's
+own heuristic (cfg = -1) is used.  Keys: "cout,cin,n,h,w".
+"""
+import json
+import os
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning.json")
+_table = None
+
+
+def _load():
+    global _table
+    if _table is None:
+        _table = {}
+        if os.path.exists(_PATH):
+            with open(_PATH) as f:
+                _table = {k: int(v) for k, v in json.load(f).get("configs", {}).items()}
+    return _table
+
+
+def conv_config(cout, cin, n, h, w):
+    return _load().get(f"{cout},{cin},{n},{h},{w}", -1)
+
+
+def save(configs, meta=None):
+    global _table
+    with open(_PATH, "w") as f:
+        json.dump({"meta": meta or {}, "configs": configs}, f, indent=1, sort_keys=True)
+    _table = None
