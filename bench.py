@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- TrackNetV3 hot-path benchmark on MI355X (contract: see the build brief / DESIGN.md section 6).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A *step* is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+BASELINE.json configs[1] -- TrackNet(seq_len=8, bg_mode='concat').eval() forward, batch 10 per GPU, 288x512 --
+i.e. 80 output heat-map frames per GPU-step.  Weak scaling: every rank runs its own batch; inference windows are
+independent, so there is no data-path collective.  Rank 0 prints ONE JSON line.
+
+Extra modes:  --tune  (time every compiled conv tile configuration per layer shape, write conv_tuning.json)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+SEQ_LEN, BG_MODE, H, W = 8, "concat", 288, 512
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (= fp32 vector peak)
+PEAK_HBM_GBPS = 8000.0
+ALG_BYTES_PER_SAMPLE = 693.55e6    # ideal-fusion fp32 bytes of one 27->8 forward
+
+
+def conv_layer_table(in_dim, h, w):
+    """[(name, c0, c1, cout, H, W, up)] -- the 17 Conv2DBlocks of TrackNet.forward (model.py:57-73)."""
+    t = [("down_block_1.conv_1", in_dim, 0, 64, h, w, False), ("down_block_1.conv_2", 64, 0, 64, h, w, False),
+         ("down_block_2.conv_1", 64, 0, 128, h // 2, w // 2, False), ("down_block_2.conv_2", 128, 0, 128, h // 2, w // 2, False),
+         ("down_block_3.conv_1", 128, 0, 256, h // 4, w // 4, False), ("down_block_3.conv_2", 256, 0, 256, h // 4, w // 4, False),
+         ("down_block_3.conv_3", 256, 0, 256, h // 4, w // 4, False),
+         ("bottleneck.conv_1", 256, 0, 512, h // 8, w // 8, False), ("bottleneck.conv_2", 512, 0, 512, h // 8, w // 8, False),
+         ("bottleneck.conv_3", 512, 0, 512, h // 8, w // 8, False),
+         ("up_block_1.conv_1", 512, 256, 256, h // 4, w // 4, True), ("up_block_1.conv_2", 256, 0, 256, h // 4, w // 4, False),
+         ("up_block_1.conv_3", 256, 0, 256, h // 4, w // 4, False),
+         ("up_block_2.conv_1", 256, 128, 128, h // 2, w // 2, True), ("up_block_2.conv_2", 128, 0, 128, h // 2, w // 2, False),
+         ("up_block_3.conv_1", 128, 64, 64, h, w, True), ("up_block_3.conv_2", 64, 0, 64, h, w, False)]
+    return t
+
+
+def conv_flops(c0, c1, cout, h, w):
+    return 2.0 * 9 * (c0 + c1) * cout * h * w
+
+
+def tune(dev, batch, out_paths):
+    """Time every compiled tile configuration on every distinct conv shape of the workload; keep the fastest."""
+    from tracknetv3_amd import ops, tuning
+    in_dim = (SEQ_LEN + 1) * 3
+    ncfg = ops.conv3x3_num_configs()
+    infos = [ops.conv3x3_config_info(c) for c in range(ncfg)]
+    best, report, seen = {}, [], set()
+    for name, c0, c1, cout, h, w, up in conv_layer_table(in_dim, H, W):
+        key = f"{cout},{c0 + c1},{batch},{h},{w}"
+        if key in seen:
+            continue
+        seen.add(key)
+        wt = torch.empty(cout, c0 + c1, 3, 3, device=dev).uniform_(-0.05, 0.05)
+        wp = ops.pack_conv3x3_weights(wt)
+        s0 = torch.rand((batch, c0, h // 2, w // 2) if up else (batch, c0, h, w), device=dev)
+        s1 = torch.rand((batch, c1, h, w), device=dev) if c1 else None
+        sc, sh = torch.rand(cout, device=dev) + 0.5, torch.rand(cout, device=dev) - 0.5
+        out = torch.empty((batch, cout, h, w), device=dev)
+        fl = conv_flops(c0, c1, cout, h, w) * batch
+        row = {"layer": name, "key": key, "tflops": {}}
+        for cfg in range(ncfg):
+            if cout % infos[cfg]["m_block"] or (c1 and c0 % infos[cfg]["chan_chunk"]):
+                continue
+            for _ in range(2):
+                ops.conv3x3(s0, wp, cout, src1=s1, scale=sc, shift=sh, up0=up, relu=True, cfg=cfg, out=out)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            e0.record()
+            for _ in range(reps):
+                ops.conv3x3(s0, wp, cout, src1=s1, scale=sc, shift=sh, up0=up, relu=True, cfg=cfg, out=out)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / reps
+            row["tflops"][str(cfg)] = round(fl / ms / 1e9, 2)
+        cfg_best = max(row["tflops"], key=lambda k: row["tflops"][k])
+        best[key] = int(cfg_best)
+        row["best"] = int(cfg_best)
+        report.append(row)
+        print(f"[tune] {name:22s} {key:24s} best cfg {cfg_best}: {row['tflops']}", file=sys.stderr, flush=True)
+        del wt, wp, s0, s1, out
+    meta = {"device": torch.cuda.get_device_name(dev), "batch": batch, "configs": infos}
+    tuning.save(best, meta)
+    for p in out_paths:
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            json.dump({"meta": meta, "configs": best, "report": report}, f, indent=1)
+    return best
+
+
+def cpu_baseline(budget_s=15.0):
+    """The oracle's PyTorch-CPU restatement of the same forward, on the host cores, bounded sample (N=2)."""
+    from oracle import nets
+    in_dim = (SEQ_LEN + 1) * 3
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, SEQ_LEN), 31, calibrated=True)
+    n = 2
+    x = nets.synth_input((n, in_dim, H, W), 4242)
+    with torch.no_grad():
+        nets.tracknet_forward(sd, x, training=False)     # warm-up
+        times, t_all = [], time.time()
+        while len(times) < 3 or (time.time() - t_all < budget_s and len(times) < 40):
+            t = time.time()
+            nets.tracknet_forward(sd, x, training=False)
+            times.append(time.time() - t)
+    med = float(np.median(times))
+    return {"value": round(n * SEQ_LEN / med, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement) eval forward, batch {n} x 288x512, median of {len(times)} runs",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=10, help="windows per GPU per step (BASELINE configs[1]: 10)")
+    ap.add_argument("--tune", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers-out", default=os.path.join(ROOT, "gpurun_out", "bench_layers.json"))
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n_gpus = world
+
+    from tracknetv3_amd import _lib, ops
+    from tracknetv3_amd.utils.general import get_model
+    from oracle import nets
+    _lib.load()
+    assert not _lib.is_emulator()
+
+    if args.tune and rank == 0:
+        tune(dev, args.batch, [os.path.join(ROOT, "gpurun_out", "conv_tuning.json")])
+    if world > 1:
+        dist.barrier()
+
+    in_dim = (SEQ_LEN + 1) * 3
+    model = get_model("TrackNet", SEQ_LEN, BG_MODE)
+    model.load_state_dict(nets.synth_state(nets.tracknet_state_shapes(in_dim, SEQ_LEN), 31, calibrated=True), strict=True)
+    model = model.to(dev).eval()
+    x = torch.rand((args.batch, in_dim, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+
+    # per-launch timing of the dominant kernel family (conv3x3_mfma_kernel<*>): HIP events on the launch stream
+    layers = conv_layer_table(in_dim, H, W)
+    events = []
+    ops_conv = ops.conv3x3
+
+    def timed_conv(*a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = ops_conv(*a, **kw)
+        e1.record()
+        events.append((e0, e1))
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        model(x)
+    barrier()
+    ops.conv3x3 = timed_conv
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = model(x)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.conv3x3 = ops_conv
+
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        assert len(events) == 17 * args.steps, len(events)
+        per_layer_ms = np.zeros(17)
+        for k, (e0, e1) in enumerate(events):
+            per_layer_ms[k % 17] += e0.elapsed_time(e1)
+        per_layer_ms /= args.steps
+        fl = np.array([conv_flops(c0, c1, co, h, w) * args.batch for (_, c0, c1, co, h, w, _) in layers])
+        conv_ms = float(per_layer_ms.sum())
+        achieved = float(fl.sum() / conv_ms / 1e9)
+        frames = n_gpus * args.batch * SEQ_LEN * args.steps
+        ms_per_step = dt / args.steps * 1e3
+        layer_rows = [{"layer": layers[k][0], "ms": round(float(per_layer_ms[k]), 4),
+                       "tflops": round(float(fl[k] / per_layer_ms[k] / 1e9), 2)} for k in range(17)]
+        try:
+            os.makedirs(os.path.dirname(args.layers_out), exist_ok=True)
+            with open(args.layers_out, "w") as f:
+                json.dump({"ms_per_step": ms_per_step, "conv_ms_per_step": conv_ms, "layers": layer_rows}, f, indent=1)
+        except OSError:
+            pass
+        for r in layer_rows:
+            print(f"[layer] {r['layer']:22s} {r['ms']:8.3f} ms  {r['tflops']:7.2f} TFLOP/s", file=sys.stderr)
+        out = {
+            "metric": "frames/sec (288x512, seq_len=8) TrackNet inference", "value": round(frames / dt, 2), "unit": "frames/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: TrackNet seq_len=8 bg_mode=concat eval forward, batch 10 per GPU, "
+                                   "288x512 synthetic frames, synthetic (PRNG) weights", "batch_per_gpu": args.batch,
+                       "frames_per_step": n_gpus * args.batch * SEQ_LEN, "parallelism": f"replicated windows x{n_gpus} (no collective)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv3x3_mfma_kernel<*> (17 launches/step, fp32 MFMA 32x32x2)",
+                         "avg_launch_ms": round(conv_ms / 17, 4), "conv_ms_per_step": round(conv_ms, 4),
+                         "algorithmic_gflop_per_step": round(float(fl.sum()) / 1e9, 3),
+                         "hbm_view": {"algorithmic_GB_per_step": round(ALG_BYTES_PER_SAMPLE * args.batch / 1e9, 3),
+                                      "achieved_GBps": round(ALG_BYTES_PER_SAMPLE * args.batch / (ms_per_step * 1e-3) / 1e9, 1),
+                                      "peak_GBps": PEAK_HBM_GBPS}},
+        }
+        if not args.no_cpu_baseline and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""CPU: the UNCHANGED HIP kernel headers + dispatch code, executed by the host SIMT emulator (tests/emu), against
+the oracle.  This validates tile / lane / LDS indexing and the MFMA fragment mapping without a GPU; the `-m gpu`
+tests repeat the same comparisons on the real library."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+from oracle import nets, prng
+
+
+def T(shape, seed, lo=-1.0, hi=1.0):
+    return torch.from_numpy(prng.uniform(shape, seed, lo, hi))
+
+
+def conv_ref(s0, s1, wt, sc, sh, up0, relu):
+    x = s0.repeat_interleave(2, 2).repeat_interleave(2, 3) if up0 else s0
+    if s1 is not None:
+        x = torch.cat([x, s1], 1)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    if sc is not None:
+        ref = ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    return ref.relu() if relu else ref
+
+
+CONV_CASES = [
+    # cfg, n, c0, c1, cout, h, w, up0, relu, affine
+    (0, 1, 6, 0, 64, 8, 32, False, False, False),
+    (0, 2, 9, 0, 64, 12, 40, False, True, True),      # ragged tile edges, odd Cin, 2 samples
+    (7, 1, 32, 16, 64, 8, 16, True, True, True),       # two sources, first one nearest-upsampled
+    (4, 1, 8, 0, 128, 6, 32, False, False, True),
+    (2, 1, 5, 0, 128, 8, 32, False, True, False),
+    (3, 1, 4, 0, 128, 8, 32, False, False, False),
+    (5, 1, 8, 0, 64, 4, 64, False, False, False),
+    (1, 1, 10, 0, 64, 16, 32, False, False, False),
+    (6, 1, 8, 0, 256, 8, 32, False, False, False),     # several channel blocks -> XCD block map
+    (-1, 1, 32, 32, 192, 4, 8, True, True, True),      # 3 channel blocks -> fallback block map, auto config
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "cfg%d_c%d+%d_o%d_%dx%d_up%d" % (c[0], c[2], c[3], c[4], c[5], c[6], c[7]))
+def test_conv3x3_mfma_emulated(emu, case):
+    from tracknetv3_amd import ops
+    cfg, n, c0, c1, cout, h, w, up0, relu, affine = case
+    seed = 100 + CONV_CASES.index(case) * 10
+    wt = T((cout, c0 + c1, 3, 3), seed)
+    s0 = T((n, c0, h // 2, w // 2) if up0 else (n, c0, h, w), seed + 1)
+    s1 = T((n, c1, h, w), seed + 2) if c1 else None
+    sc = T((cout,), seed + 3, 0.5, 1.5) if affine else None
+    sh = T((cout,), seed + 4, -0.5, 0.5) if affine else None
+    y = ops.conv3x3(s0, ops.pack_conv3x3_weights(wt), cout, src1=s1, scale=sc, shift=sh, up0=up0, relu=relu, cfg=cfg)
+    ref = conv_ref(s0, s1, wt, sc, sh, up0, relu)
+    assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6
+
+
+def test_weight_packing_layouts(emu):
+    from tracknetv3_amd import ops
+    w = T((64, 5, 3, 3), 7)
+    p = ops.pack_conv3x3_weights(w).reshape(32, 9, 64)
+    assert torch.equal(p[:5], w.permute(1, 2, 3, 0).reshape(5, 9, 64))
+    assert p[5:].abs().max() == 0
+    pt = ops.pack_conv3x3_weights(w, transpose_flip=True).reshape(64, 9, 5)      # dgrad: K = Cout, M = Cin, taps flipped
+    assert torch.equal(pt, w.flip(2, 3).permute(0, 2, 3, 1).reshape(64, 9, 5))
+
+
+def test_bn_fold_pool_head_emulated(emu):
+    from tracknetv3_amd import ops
+    g, b, rm, rv = T((70,), 1, 0.5, 1.5), T((70,), 2), T((70,), 3), T((70,), 4, 0.5, 2.0)
+    sc, sh = ops.bn_fold(g, b, rm, rv)
+    ref_sc = g / torch.sqrt(rv + 1e-5)
+    assert torch.allclose(sc, ref_sc, rtol=1e-6) and torch.allclose(sh, b - rm * ref_sc, rtol=1e-5, atol=1e-6)
+    x = T((2, 3, 8, 16), 5)
+    assert torch.equal(ops.maxpool2x2(x), F.max_pool2d(x, 2, 2))
+    x = T((2, 64, 4, 8), 6)
+    for L in (3, 8, 11):
+        w, bias = T((L, 64, 1, 1), 8 + L, -0.3, 0.3), T((L,), 9 + L)
+        y = ops.head1x1_sigmoid(x, w, bias)
+        ref = torch.sigmoid(F.conv2d(x.double(), w.double(), bias.double()))
+        assert (y.double() - ref).abs().max() <= 1e-6
+        z = ops.head1x1_sigmoid(x, w, bias, apply_sigmoid=False)
+        assert (z.double() - F.conv2d(x.double(), w.double(), bias.double())).abs().max() <= 1e-5
+
+
+def test_argument_errors_are_reported(emu):
+    from tracknetv3_amd import ops, _lib
+    w = ops.pack_conv3x3_weights(T((64, 4, 3, 3), 1))
+    with pytest.raises(_lib.Tnv3Error, match="multiple of 64"):
+        ops.conv3x3(T((1, 4, 8, 32), 2), T((32 * 9 * 40,), 3), 40)
+    with pytest.raises(_lib.Tnv3Error, match="unknown config"):
+        ops.conv3x3(T((1, 4, 8, 32), 2), w, 64, cfg=99)
+    with pytest.raises(_lib.Tnv3Error, match="channel block"):
+        ops.conv3x3(T((1, 4, 8, 32), 2), w, 64, cfg=2)          # 128-channel config on Cout = 64
+    with pytest.raises(_lib.Tnv3Error):
+        ops.maxpool2x2(T((1, 1, 3, 6), 4))
+
+
+@pytest.mark.slow
+def test_tracknet_eval_forward_emulated_vs_golden(emu):
+    """Whole TrackNet(9,3).eval() through the product's host code + emulated kernels vs the reference golden."""
+    from tracknetv3_amd.model import TrackNet
+    g = np.load(os.path.join(GOLDEN, "tracknet_9_3_32x64.npz"))
+    in_dim, out_dim, n, h, w, seed, cal = (int(v) for v in g["meta"])
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=bool(cal))
+    m = TrackNet(in_dim, out_dim)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    x = nets.synth_input((n, in_dim, h, w), seed + 1000)[:1, :, :16, :32].contiguous()   # a crop keeps the emulator fast
+    with torch.no_grad():
+        ref = nets.tracknet_forward(sd, x, training=False)
+    y = m(x)
+    assert (y - ref).abs().max().item() <= 1e-5

@@ -1,0 +1,124 @@
+"""GPU (-m gpu): parity of the HIP path (through the C ABI) with the oracle / the reference goldens.
+Tolerance: heat-map values within 1e-4 (BASELINE.json north_star); most checks are far tighter."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+from oracle import nets, prng
+from test_emu_kernels import CONV_CASES, T, conv_ref
+
+pytestmark = pytest.mark.gpu
+HEATMAP_TOL = 1e-4
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "cfg%d_c%d+%d_o%d_%dx%d_up%d" % (c[0], c[2], c[3], c[4], c[5], c[6], c[7]))
+def test_conv3x3_small_cases(gpu_device, case):
+    from tracknetv3_amd import ops
+    cfg, n, c0, c1, cout, h, w, up0, relu, affine = case
+    seed = 100 + CONV_CASES.index(case) * 10
+    wt = T((cout, c0 + c1, 3, 3), seed)
+    s0 = T((n, c0, h // 2, w // 2) if up0 else (n, c0, h, w), seed + 1)
+    s1 = T((n, c1, h, w), seed + 2) if c1 else None
+    sc = T((cout,), seed + 3, 0.5, 1.5) if affine else None
+    sh = T((cout,), seed + 4, -0.5, 0.5) if affine else None
+    d = gpu_device
+    g = lambda t: None if t is None else t.to(d)
+    y = ops.conv3x3(g(s0), ops.pack_conv3x3_weights(g(wt)), cout, src1=g(s1), scale=g(sc), shift=g(sh), up0=up0,
+                    relu=relu, cfg=cfg).cpu()
+    ref = conv_ref(s0, s1, wt, sc, sh, up0, relu)
+    assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("cfg", list(range(8)))
+def test_conv3x3_every_config_on_network_shapes(gpu_device, cfg):
+    """Each compiled tile configuration on mid-sized shapes incl. a two-source decoder-entry layer."""
+    from tracknetv3_amd import ops
+    info = ops.conv3x3_config_info(cfg)
+    cout = 2 * info["m_block"]
+    d = gpu_device
+    for (c0, c1, h, w, up0) in ((64, 0, 72, 128, False), (128, 64, 36, 64, True), (27, 0, 40, 96, False)):
+        wt = T((cout, c0 + c1, 3, 3), 5, -0.1, 0.1)
+        s0 = T((2, c0, h // 2, w // 2) if up0 else (2, c0, h, w), 6)
+        s1 = T((2, c1, h, w), 7) if c1 else None
+        sc, sh = T((cout,), 8, 0.5, 1.5), T((cout,), 9, -0.5, 0.5)
+        y = ops.conv3x3(s0.to(d), ops.pack_conv3x3_weights(wt.to(d)), cout, src1=None if s1 is None else s1.to(d),
+                        scale=sc.to(d), shift=sh.to(d), up0=up0, relu=True, cfg=cfg).cpu()
+        ref = conv_ref(s0, s1, wt, sc, sh, up0, True)
+        assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6, (cfg, c0, c1)
+
+
+def test_pool_head_pack(gpu_device):
+    from tracknetv3_amd import ops
+    d = gpu_device
+    x = T((3, 64, 72, 128), 5)
+    assert torch.equal(ops.maxpool2x2(x.to(d)).cpu(), F.max_pool2d(x, 2, 2))
+    for L in (3, 8):
+        w, b = T((L, 64, 1, 1), 8 + L, -0.3, 0.3), T((L,), 9 + L)
+        y = ops.head1x1_sigmoid(x.to(d), w.to(d), b.to(d)).cpu()
+        ref = torch.sigmoid(F.conv2d(x.double(), w.double(), b.double()))
+        assert (y.double() - ref).abs().max() <= 1e-6
+    w = T((128, 70, 3, 3), 7)
+    p = ops.pack_conv3x3_weights(w.to(d)).cpu().reshape(96, 9, 128)
+    assert torch.equal(p[:70], w.permute(1, 2, 3, 0).reshape(70, 9, 128)) and p[70:].abs().max() == 0
+
+
+def _load_model(g, device):
+    from tracknetv3_amd.model import TrackNet
+    in_dim, out_dim, n, h, w, seed, cal = (int(v) for v in g["meta"])
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=bool(cal))
+    m = TrackNet(in_dim, out_dim)
+    m.load_state_dict(sd, strict=True)
+    x = nets.synth_input((n, in_dim, h, w), seed + 1000)
+    return m.to(device).eval(), x, sd
+
+
+@pytest.mark.parametrize("name", ["tracknet_9_3_32x64.npz", "tracknet_27_8_32x64_cal.npz"])
+def test_tracknet_eval_vs_reference_golden_full_tensor(gpu_device, name):
+    g = np.load(os.path.join(GOLDEN, name))
+    m, x, _ = _load_model(g, gpu_device)
+    y = m(x.to(gpu_device)).cpu().numpy()
+    err = np.abs(y - g["eval_out"]).max()
+    assert err <= 1e-5, err
+
+
+def test_tracknet_eval_vs_reference_golden_probes_64x128(gpu_device):
+    g = np.load(os.path.join(GOLDEN, "tracknet_9_3_64x128_cal.npz"))
+    m, x, _ = _load_model(g, gpu_device)
+    y = m(x.to(gpu_device)).cpu()
+    assert np.abs(y.numpy().reshape(-1)[g["eval_probe_idx"]] - g["eval_probe_val"]).max() <= 2e-5
+    np.testing.assert_allclose(y.double().sum(dim=(2, 3)).numpy(), g["eval_chan_sum64"], rtol=2e-5)
+
+
+def test_tracknet_full_size_288x512_vs_reference_golden(gpu_device):
+    """Config-2 geometry (27->8 channels, 288x512): 8192 reference probes, per-channel sums, range."""
+    g = np.load(os.path.join(GOLDEN, "tracknet_27_8_288x512.npz"))
+    m, x, sd = _load_model(g, gpu_device)
+    y = m(x.to(gpu_device)).cpu()
+    err = np.abs(y.numpy().reshape(-1)[g["eval_probe_idx"]] - g["eval_probe_val"]).max()
+    assert err <= HEATMAP_TOL / 4, err
+    np.testing.assert_allclose(y.double().sum(dim=(2, 3)).numpy(), g["eval_chan_sum"], rtol=2e-5)
+    assert abs(y.min().item() - float(g["eval_min"])) <= 1e-5 and abs(y.max().item() - float(g["eval_max"])) <= 1e-5
+    # full-tensor comparison with the oracle computed here on the host CPU
+    with torch.no_grad():
+        ref = nets.tracknet_forward(sd, x, training=False)
+    assert (y - ref).abs().max().item() <= HEATMAP_TOL / 4
+
+
+def test_tracknet_batch10_properties(gpu_device):
+    """BASELINE config 2 size (N=10): determinism and sample independence (eval mode has no cross-sample term)."""
+    g = np.load(os.path.join(GOLDEN, "tracknet_27_8_288x512.npz"))
+    m, x1, _ = _load_model(g, gpu_device)
+    x = torch.cat([x1] + [nets.synth_input(tuple(x1.shape), 900 + k) for k in range(9)], 0).to(gpu_device)
+    y_a = m(x)
+    y_b = m(x)
+    assert torch.equal(y_a, y_b)
+    y_1 = m(x[:1].contiguous())
+    assert (y_a[:1] - y_1).abs().max().item() <= 1e-6
+    perm = torch.tensor([3, 1, 4, 0, 9, 2, 6, 5, 8, 7], device=gpu_device)
+    assert torch.equal(m(x[perm].contiguous()), y_a[perm])
+    err = np.abs(y_a[0].cpu().numpy().reshape(-1)[g["eval_probe_idx"]] - g["eval_probe_val"]).max()
+    assert err <= HEATMAP_TOL / 4

@@ -1,0 +1,142 @@
+"""CPU: the oracle (oracle/) reproduces every committed golden vector (which were produced by importing the
+reference -- tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import nets, postproc, prng
+
+
+def _g(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", ["tracknet_9_3_32x64.npz", "tracknet_27_8_32x64_cal.npz"])
+def test_tracknet_eval_and_train_forward(name):
+    g = _g(name)
+    in_dim, out_dim, n, h, w, seed, cal = (int(v) for v in g["meta"])
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=bool(cal))
+    x = nets.synth_input((n, in_dim, h, w), seed + 1000)
+    y = nets.disc_heatmaps(n, out_dim, h, w, seed + 2000)
+    with torch.no_grad():
+        p = nets.tracknet_forward(sd, x, training=False)
+    assert np.abs(p.numpy() - g["eval_out"]).max() <= 2e-6
+    assert abs(nets.wbce_loss(p, y).item() - float(g["eval_loss"])) <= 1e-6
+    stats = {}
+    with torch.no_grad():
+        pt = nets.tracknet_forward(sd, x, training=True, stats_out=stats)
+    assert np.abs(pt.numpy() - g["train_out"]).max() <= 5e-5
+    assert abs(nets.wbce_loss(pt, y).item() - float(g["train_loss"])) <= 2e-6
+    got = np.concatenate([stats[k].numpy().ravel() for k in g["bn_names"]])
+    np.testing.assert_allclose(got, g["bn_after"], rtol=1e-4, atol=1e-6)
+
+
+def test_tracknet_grads_fp64_oracle_vs_golden():
+    g = _g("tracknet_9_3_32x64.npz")
+    in_dim, out_dim, n, h, w, seed, cal = (int(v) for v in g["meta"])
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=bool(cal))
+    x = nets.synth_input((n, in_dim, h, w), seed + 1000)
+    y = nets.disc_heatmaps(n, out_dim, h, w, seed + 2000)
+    loss, _, grads, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float64)
+    assert abs(loss.item() - float(g["train_loss64"])) < 1e-10
+    for k, name in enumerate(g["grad_names"]):
+        gr = grads[str(name)].numpy()
+        st = g["grad_stats64"][k]
+        np.testing.assert_allclose([gr.sum(), np.abs(gr).sum(), np.abs(gr).max()], st[:3], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(gr.reshape(-1)[g["grad_probe_idx"][k]], st[3:], rtol=1e-7, atol=1e-14)
+
+
+def test_wbce_edge_cases_and_closed_form_gradient():
+    g = _g("wbce_edge.npz")
+    p, y = torch.from_numpy(g["p"]).requires_grad_(True), torch.from_numpy(g["y"])
+    loss = nets.wbce_loss(p, y)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6
+    np.testing.assert_allclose(p.grad.numpy(), g["grad"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(nets.wbce_grad_closed_form(p.detach(), y).numpy(), g["grad"], rtol=1e-5, atol=1e-9)
+    assert nets.wbce_loss(p.detach(), y, reduce=False).shape == (1,)
+
+
+def test_inpaintnet_forward():
+    g = _g("inpaintnet_6x16.npz")
+    sd = nets.synth_state(nets.inpaintnet_state_shapes(), 77)
+    n, L = 6, 16
+    coor = nets.synth_input((n, L, 2), 501)
+    vis = (nets.synth_input((n, L, 1), 502) > 0.2).float()
+    coor = coor * vis
+    mask = ((nets.synth_input((n, L, 1), 503) < 0.3).float() * vis)
+    with torch.no_grad():
+        o = nets.inpaintnet_forward(sd, coor * (1 - mask), mask)
+    assert np.abs(o.numpy() - g["out"]).max() <= 1e-6
+
+
+def test_host_logic_goldens():
+    g = _g("host_logic.npz")
+    plan, k = g["get_model_plan"], 0
+    for bg in ("", "subtract", "subtract_concat", "concat", None, "zzz"):
+        for L in (1, 3, 8):
+            assert tuple(plan[k][1:]) == nets.tracknet_dims(L, bg)
+            k += 1
+    for L in (1, 2, 3, 5, 8, 16):
+        for mode in ("average", "weight"):
+            assert np.array_equal(postproc.get_ensemble_weight(L, mode), g[f"ens_w_{mode}_{L}"])
+    vis, yy, out = g["inpaint_mask_vis"], g["inpaint_mask_y"], g["inpaint_mask_out"]
+    r = 0
+    for c in range(vis.shape[0]):
+        n = int((vis[c] >= 0).sum())
+        for th in (30, 14.4):
+            got = postproc.generate_inpaint_mask({"Y": yy[c][:n].tolist(), "Visibility": vis[c][:n].tolist()}, th_h=th)
+            assert got == out[r][:n].tolist()
+            r += 1
+    xm, ym = nets.mixup_injected(nets.synth_input((4, 3, 8, 16), 11), nets.synth_input((4, 2, 8, 16), 12),
+                                 g["mixup_lam"], g["mixup_perm"])
+    assert np.array_equal(xm.numpy(), g["mixup_x"]) and np.array_equal(ym.numpy(), g["mixup_y"])
+    a = postproc.predict(g["predict_c_idx"], c_pred=g["predict_c_in"], img_scaler=(3.75, 3.75))
+    assert np.array_equal(np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]]), g["predict_c_out"])
+    hm = np.zeros((3, 4, 288, 512), dtype=np.float32)
+    hm[0, 0, 100:105, 200:207] = 0.9
+    hm[0, 1, 10:12, 10:12] = 0.7
+    hm[0, 1, 50:53, 300:303] = 0.8
+    hm[1, 2, 0:3, 0:2] = 0.51
+    hm[2, 0, 287, 511] = 1.0
+    a = postproc.predict(g["predict_c_idx"], y_pred=hm, img_scaler=(3.75, 3.75))
+    assert np.array_equal(np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]]), g["predict_h_out"])
+
+
+def test_ensemble_goldens():
+    g = _g("ensemble.npz")
+    k = 0
+    while f"heat_{k}_meta" in g:
+        L, wmode, n_win, batch, seed = (int(v) for v in g[f"heat_{k}_meta"])
+        win = prng.uniform((n_win, L, 4, 8), seed)
+        mine = np.concatenate(list(postproc.ensemble_stream([win[s:s + batch] for s in range(0, n_win, batch)], L,
+                                                            "weight" if wmode else "average", n_win)), 0)
+        assert np.abs(mine - g[f"heat_{k}_ens"]).max() <= 1.2e-7
+        k += 1
+    assert k == 24
+
+
+def test_predict_location_against_scipy_label():
+    """Independent cross-check of the component / bounding-box part (cv2 is not available: parity unpinned)."""
+    from scipy import ndimage
+    rng = np.random.RandomState(3)
+    for trial in range(30):
+        dens = [0.02, 0.2, 0.5, 0.8][trial % 4]
+        img = (rng.rand(24, 40) < dens).astype(np.uint8) * 255
+        lab, n = ndimage.label(img, structure=np.ones((3, 3)))
+        boxes = sorted((sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start)
+                       for sl in ndimage.find_objects(lab))
+        mine = sorted(b[:4] for b in postproc.connected_boxes(img))
+        assert mine == boxes
+        if n:
+            x, y, w, h = postproc.predict_location(img)
+            assert w * h == max(b[2] * b[3] for b in boxes)
+    assert postproc.predict_location(np.zeros((8, 8), np.uint8)) == (0, 0, 0, 0)
+    # tie rule: equal areas -> the component discovered LAST in raster order wins (cv2 contour order)
+    img = np.zeros((10, 10), np.uint8)
+    img[1:3, 1:3] = 255
+    img[6:8, 5:7] = 255
+    assert postproc.predict_location(img) == (5, 6, 2, 2)

@@ -173,3 +173,61 @@ class TrackNet(nn.Module):
             return autograd_ops.tracknet_forward_train(self, x)
         with torch.no_grad():
             return self._forward_eval(x)
+
+
+# --------------------------------------------------------------------------- InpaintNet
+class _Conv1dParams(nn.Module):
+    """Holds ``nn.Conv1d(in, out, kernel_size=3, padding='same', bias=True)`` (model.py:80,110); default init."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.weight = nn.Parameter(torch.empty(out_dim, in_dim, 3))
+        self.bias = nn.Parameter(torch.empty(out_dim))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_dim * 3)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class Conv1DBlock(nn.Module):
+    """Conv1D + LeakyReLU (model.py:76-87); container only."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.conv = _Conv1dParams(in_dim, out_dim)
+
+
+class Double1DConv(nn.Module):
+    """Conv1DBlock x 2 (model.py:89-98)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.conv_1 = Conv1DBlock(in_dim, out_dim)
+        self.conv_2 = Conv1DBlock(out_dim, out_dim)
+
+
+class InpaintNet(nn.Module):
+    """1-D trajectory rectification network (model.py:100-129).  x (N,L,2), m (N,L,1) -> (N,L,2)."""
+
+    def __init__(self):
+        super().__init__()
+        self.down_1 = Conv1DBlock(3, 32)
+        self.down_2 = Conv1DBlock(32, 64)
+        self.down_3 = Conv1DBlock(64, 128)
+        self.buttleneck = Double1DConv(128, 256)
+        self.up_1 = Conv1DBlock(384, 128)
+        self.up_2 = Conv1DBlock(192, 64)
+        self.up_3 = Conv1DBlock(96, 32)
+        self.predictor = _Conv1dParams(32, 2)
+
+    def conv_params(self):
+        """[(weight, bias)] in forward order."""
+        mods = [self.down_1.conv, self.down_2.conv, self.down_3.conv, self.buttleneck.conv_1.conv,
+                self.buttleneck.conv_2.conv, self.up_1.conv, self.up_2.conv, self.up_3.conv, self.predictor]
+        return [(m.weight, m.bias) for m in mods]
+
+    def forward(self, x, m):
+        if x.dim() != 3 or x.shape[2] != 2 or m.shape[:2] != x.shape[:2] or m.shape[2] != 1:
+            raise ValueError(f"InpaintNet expects x (N,L,2) and m (N,L,1), got {tuple(x.shape)} / {tuple(m.shape)}")
+        from . import inpaint_ops
+        return inpaint_ops.inpaintnet_forward(self, x, m)

@@ -1,0 +1,47 @@
+"""Model factory and constants -- the drop-in for the hot-path part of the reference's ``utils/general.py``
+(get_model: utils/general.py:46-80; HEIGHT/WIDTH/SIGMA/DELTA_T/COOR_TH: utils/general.py:15-19;
+ResumeArgumentParser: utils/general.py:23-42)."""
+import math
+
+from ..model import InpaintNet, TrackNet
+
+HEIGHT = 288
+WIDTH = 512
+SIGMA = 2.5
+DELTA_T = 1 / math.sqrt(HEIGHT ** 2 + WIDTH ** 2)
+COOR_TH = DELTA_T * 50
+IMG_FORMAT = 'png'
+
+
+class ResumeArgumentParser():
+    """Rebuilds the argument namespace from a checkpoint's ``param_dict`` (same keys as the reference)."""
+
+    _KEYS = ('model_name', 'seq_len', 'epochs', 'batch_size', 'optim', 'learning_rate', 'lr_scheduler', 'bg_mode',
+             'alpha', 'frame_alpha', 'mask_ratio', 'tolerance', 'resume_training', 'seed', 'save_dir', 'debug',
+             'verbose')
+
+    def __init__(self, param_dict):
+        for k in self._KEYS:
+            setattr(self, k, param_dict[k])
+
+
+def get_model(model_name, seq_len=None, bg_mode=None):
+    """Create a model by name; same channel plan and error behaviour as the reference.
+
+    'TrackNet': bg_mode 'subtract' -> (L, L); 'subtract_concat' -> (4L, L); 'concat' -> (3(L+1), L);
+    anything else -> (3L, L).  'InpaintNet' -> InpaintNet().  Otherwise ValueError('Invalid model name.').
+    """
+    if model_name == 'TrackNet':
+        if bg_mode == 'subtract':
+            model = TrackNet(in_dim=seq_len, out_dim=seq_len)
+        elif bg_mode == 'subtract_concat':
+            model = TrackNet(in_dim=seq_len * 4, out_dim=seq_len)
+        elif bg_mode == 'concat':
+            model = TrackNet(in_dim=(seq_len + 1) * 3, out_dim=seq_len)
+        else:
+            model = TrackNet(in_dim=seq_len * 3, out_dim=seq_len)
+    elif model_name == 'InpaintNet':
+        model = InpaintNet()
+    else:
+        raise ValueError('Invalid model name.')
+    return model
