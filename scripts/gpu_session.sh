@@ -11,7 +11,7 @@ echo "== device" | tee $OUT/session.log
 echo "== smoke" | tee -a $OUT/session.log
 timeout 600 python __graft_entry__.py smoke >> $OUT/session.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/session.log
 echo "== pytest -m gpu" | tee -a $OUT/session.log
-timeout 900 python -m pytest tests -m gpu -q -x --no-header -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/session.log
+timeout 900 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/session.log
 tail -15 $OUT/pytest_gpu.log | tee -a $OUT/session.log
 echo "== bench (tune)" | tee -a $OUT/session.log
 timeout 900 python bench.py --tune --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/session.log
