@@ -98,25 +98,42 @@ def tune(dev, batch, out_paths):
     return best
 
 
-def cpu_baseline(budget_s=15.0):
-    """The oracle's PyTorch-CPU restatement of the same forward, on the host cores, bounded sample (N=2)."""
+def cpu_baseline(budget_s=25.0):
+    """The oracle's PyTorch-CPU restatement of the same forward on the host cores, bounded sample (batch 2).
+    Thread count: a short scan picks the fastest of {32, 64, physical cores, all hardware threads} -- using every
+    SMT thread of a 2-socket host is several times SLOWER for this batch size, which would flatter the GPU."""
     from oracle import nets
     in_dim = (SEQ_LEN + 1) * 3
-    torch.set_num_threads(os.cpu_count() or 1)
     sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, SEQ_LEN), 31, calibrated=True)
     n = 2
     x = nets.synth_input((n, in_dim, H, W), 4242)
-    with torch.no_grad():
-        nets.tracknet_forward(sd, x, training=False)     # warm-up
-        times, t_all = [], time.time()
-        while len(times) < 3 or (time.time() - t_all < budget_s and len(times) < 40):
-            t = time.time()
+    ncpu = os.cpu_count() or 1
+    cands = sorted({min(32, ncpu), min(64, ncpu), max(1, ncpu // 2), ncpu})
+    t_all = time.time()
+
+    def run():
+        t = time.time()
+        with torch.no_grad():
             nets.tracknet_forward(sd, x, training=False)
-            times.append(time.time() - t)
+        return time.time() - t
+
+    scan = {}
+    for th in cands:
+        if time.time() - t_all > budget_s * 0.6 and scan:
+            break
+        torch.set_num_threads(th)
+        run()                                   # warm-up (thread pool, oneDNN primitive cache)
+        scan[th] = run()
+    best = min(scan, key=scan.get)
+    torch.set_num_threads(best)
+    times = [run()]
+    while len(times) < 3 or (time.time() - t_all < budget_s and len(times) < 20):
+        times.append(run())
     med = float(np.median(times))
-    return {"value": round(n * SEQ_LEN / med, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch-CPU fp32 restatement) eval forward, batch {n} x 288x512, median of {len(times)} runs",
-            "host_cpus": os.cpu_count()}
+    return {"value": round(n * SEQ_LEN / med, 2), "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement) eval forward, batch {n} x 288x512, median of {len(times)} runs; "
+                      f"thread scan s/fwd: {{{', '.join(f'{k}: {v:.2f}' for k, v in scan.items())}}}",
+            "host_cpus": ncpu}
 
 
 def main():

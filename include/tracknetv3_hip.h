@@ -74,6 +74,16 @@ int tnv3_head1x1_sigmoid(const float* x, const float* w, const float* b, float* 
 /* nn.MaxPool2d((2,2), stride=(2,2)) over nc planes of h x w (h % 2 == 0, w % 4 == 0). */
 int tnv3_maxpool2x2(const float* x, float* y, long nc, int h, int w, tnv3_stream_t stream);
 
+/* ---- InpaintNet 1-D convolution (Conv1DBlock: model.py:76-87; InpaintNet.forward: model.py:113-129) ------- */
+
+/* dst = act( conv1d_k3_same( cat([src0, src1], channel dim), w ) + b )
+ *   src0/src1: [N][C][L] (or [N][L][C] when src_nlc != 0: the network input cat([coor (N,L,2), mask (N,L,1)], 2));
+ *   src1 may be NULL (c1 = 0);  w: [Cout][C0+C1][3] exactly as in the state_dict;  b: [Cout]
+ *   dst: [N][Cout][L], or [N][L][Cout] when dst_nlc != 0 (the network output after the final permute)
+ *   act: 0 none, 1 LeakyReLU(0.01), 2 sigmoid */
+int tnv3_conv1d_k3_forward(const float* src0, const float* src1, const float* w, const float* b, float* dst, int n,
+                           int c0, int c1, int cout, int l, int src_nlc, int dst_nlc, int act, tnv3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,11 @@ namespace {
 struct Launcher {
   template <class... KArgs, class... Args>
   int launch(void (*kernel)(KArgs...), int grid, int block, Args... args) {
-    emu::launch(emu_dim3{(unsigned)grid, 1, 1}, emu_dim3{(unsigned)block, 1, 1},
+    return launch3(kernel, grid, 1, 1, block, args...);
+  }
+  template <class... KArgs, class... Args>
+  int launch3(void (*kernel)(KArgs...), int gx, int gy, int gz, int block, Args... args) {
+    emu::launch(emu_dim3{(unsigned)gx, (unsigned)gy, (unsigned)gz}, emu_dim3{(unsigned)block, 1, 1},
                 [=]() { kernel(static_cast<KArgs>(args)...); });
     return TNV3_OK;
   }

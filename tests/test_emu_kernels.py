@@ -112,3 +112,26 @@ def test_tracknet_eval_forward_emulated_vs_golden(emu):
         ref = nets.tracknet_forward(sd, x, training=False)
     y = m(x)
     assert (y - ref).abs().max().item() <= 1e-5
+
+
+def test_inpaintnet_forward_emulated_vs_golden(emu):
+    from tracknetv3_amd.model import InpaintNet
+    g = np.load(os.path.join(GOLDEN, "inpaintnet_6x16.npz"))
+    sd = nets.synth_state(nets.inpaintnet_state_shapes(), 77)
+    net = InpaintNet()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    n, L = 6, 16
+    coor = nets.synth_input((n, L, 2), 501)
+    vis = (nets.synth_input((n, L, 1), 502) > 0.2).float()
+    coor = coor * vis
+    mask = ((nets.synth_input((n, L, 1), 503) < 0.3).float() * vis)
+    out = net(coor * (1 - mask), mask)
+    assert out.shape == (n, L, 2)
+    assert np.abs(out.numpy() - g["out"]).max() <= 2e-6
+    # other sequence lengths / ragged batch (positions tiled by 16, sequences by 8)
+    for (n2, L2) in ((3, 5), (9, 24)):
+        c2, m2 = nets.synth_input((n2, L2, 2), 9), (nets.synth_input((n2, L2, 1), 10) < 0.5).float()
+        with torch.no_grad():
+            ref = nets.inpaintnet_forward(sd, c2, m2)
+        assert (net(c2, m2) - ref).abs().max().item() <= 2e-6

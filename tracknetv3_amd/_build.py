@@ -1,7 +1,9 @@
 """Build libtnv3_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and on first import
 when the library is missing but hipcc is available."""
 import os
-import shutil
+import shutil  # noqa: I001
+
+import torch  # noqa: F401  (loaded first so that libtnv3_hip.so binds to torch's HIP runtime, not a second copy)
 import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))

@@ -39,6 +39,7 @@ def _declare(lib):
     sig("tnv3_conv3x3_forward", i, p, p, p, p, p, p, i, i, i, i, i, i, i, i, i, p)
     sig("tnv3_head1x1_sigmoid", i, p, p, p, p, i, i, i, i, i, p)
     sig("tnv3_maxpool2x2", i, p, p, lg, i, i, p)
+    sig("tnv3_conv1d_k3_forward", i, p, p, p, p, p, i, i, i, i, i, i, i, i, p)
     for name, spec in _OPTIONAL.items():
         if hasattr(lib, name):
             sig(name, *spec)
@@ -48,7 +49,7 @@ _OPTIONAL = {}   # later entry points register here: name -> (restype, *argtypes
 
 EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "tnv3_conv3x3_config_info",
            "tnv3_conv3x3_packed_floats", "tnv3_pack_conv3x3_weights", "tnv3_bn_fold", "tnv3_conv3x3_forward",
-           "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2"]
+           "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2", "tnv3_conv1d_k3_forward"]
 
 
 def library_path():

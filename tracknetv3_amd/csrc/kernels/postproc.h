@@ -1,0 +1,162 @@
+// postproc.h -- heat-map -> coordinates on the device, so that only (x, y, w, h) integers leave HBM.
+//
+//  * ensemble_frames_kernel: the temporal ensemble of predict.py:163-209 (heat maps) / 243-301 (coordinates) in
+//    closed form.  Frame t is covered by windows s in [t-L+1, t] at in-window position t-s; with the reference's
+//    zero-prefilled buffer this is
+//        t <  num_sample, t <  L-1 : sum_s win[s][t-s] / (t+1)                  ("incomplete buffer", all modes)
+//        t <  num_sample, t >= L-1 : sum_k weight[k] * win[t-L+1+k][L-1-k]      (get_ensemble_weight, test.py:25-50)
+//        t >= num_sample           : sum_s win[s][t-s] / (L - (t - num_sample + 1))   (tail after the last window)
+//    Windows outside [0, num_sample) contribute zero.  HBM-bound gather-FMA: L reads + 1 write per output element.
+//
+//  * peak-find = predict.py:35 (`> 0.5`) + predict_location (test.py:52-79): cv2.findContours(RETR_EXTERNAL) +
+//    cv2.boundingRect + largest box.  Integer work, restated as 8-connected component labelling by lock-free
+//    union-find (label = smallest linear pixel index of the component = its first pixel in raster order),
+//    per-root bounding boxes by atomic min/max, and ONE 64-bit atomicMax per root on (area << 32 | order) where
+//    `order` encodes the tie rule (equal areas: the component discovered last in raster order wins -- OpenCV's
+//    contour list order combined with the strict '>' at test.py:74; see oracle/postproc.py).  Bit-exact integers.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tnv3 {
+
+typedef float pp_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) ensemble_frames_kernel(const float* __restrict__ win, int n_local, long s_base,
+                                                              int L, int E, const float* __restrict__ weight, long t0,
+                                                              int n_frames, long num_sample, float* __restrict__ out) {
+  // win: [n_local][L][E] (window s_base + i at row i), E = elements per position (H*W, or 2 for coordinates)
+  const long total = (long)n_frames * E;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int fi = (int)(idx / E);
+    const int e = (int)(idx - (long)fi * E);
+    const long t = t0 + fi;
+    float acc = 0.0f;
+    const bool general = (t < num_sample) && (t >= L - 1);
+    for (int k = 0; k < L; ++k) {
+      const long s = t - (L - 1) + k;            // window index; in-window position L-1-k
+      if (s < 0 || s >= num_sample) continue;
+      const long i = s - s_base;
+      if (i < 0 || i >= n_local) continue;       // caller guarantees residency of all needed windows
+      const float v = win[((size_t)i * L + (L - 1 - k)) * E + e];
+      acc = general ? fmaf(weight[k], v, acc) : acc + v;
+    }
+    if (!general) {
+      const float div = (t < num_sample) ? (float)(t + 1) : (float)(L - (t - num_sample + 1));
+      acc = acc / div;
+    }
+    out[idx] = acc;
+  }
+}
+
+// ---- connected components --------------------------------------------------------------------------------------
+// workspace per frame: int label[HW]; int box[4][HW] (min x, min y, max x, max y at root pixels); unsigned long long best
+struct PeakWs {
+  int* label;
+  int* box;                      // 4 planes of HW
+  unsigned long long* best;      // one per frame
+};
+
+__device__ __forceinline__ int ccl_load(const int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+
+__device__ __forceinline__ int ccl_find(const int* lab, int x) {
+  int p = ccl_load(lab + x);
+  while (p != x) { x = p; p = ccl_load(lab + x); }
+  return x;
+}
+
+__device__ __forceinline__ void ccl_union(int* lab, int a, int b) {
+  for (;;) {
+    a = ccl_find(lab, a);
+    b = ccl_find(lab, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }          // a > b: hang root a under b
+    const int old = atomicMin(lab + a, b);
+    if (old == a) return;                                   // a was still a root: linked
+    a = old;                                                // somebody re-parented a meanwhile: retry from there
+  }
+}
+
+__global__ void __launch_bounds__(256) ccl_init_kernel(const float* __restrict__ heat, float thr, int* __restrict__ label,
+                                                       int* __restrict__ box, unsigned long long* __restrict__ best,
+                                                       int H, int W) {
+  const int HW = H * W;
+  const int f = blockIdx.y;
+  const float* hm = heat + (size_t)f * HW;
+  int* lab = label + (size_t)f * HW;
+  int* bx = box + (size_t)f * 4 * HW;
+  if (blockIdx.x == 0 && threadIdx.x == 0) best[f] = 0ull;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const bool fg = hm[p] > thr;
+    lab[p] = fg ? p : -1;
+    if (fg) {
+      const int y = p / W, x = p - y * W;
+      bx[p] = x; bx[HW + p] = y; bx[2 * HW + p] = x; bx[3 * HW + p] = y;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) ccl_merge_kernel(int* __restrict__ label, int H, int W) {
+  const int HW = H * W;
+  int* lab = label + (size_t)blockIdx.y * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    if (ccl_load(lab + p) < 0) continue;
+    const int y = p / W, x = p - y * W;
+    // 8-connectivity: link with the already-visited half of the neighbourhood (W, NW, N, NE)
+    if (x > 0 && ccl_load(lab + p - 1) >= 0) ccl_union(lab, p, p - 1);
+    if (y > 0) {
+      if (ccl_load(lab + p - W) >= 0) ccl_union(lab, p, p - W);
+      if (x > 0 && ccl_load(lab + p - W - 1) >= 0) ccl_union(lab, p, p - W - 1);
+      if (x + 1 < W && ccl_load(lab + p - W + 1) >= 0) ccl_union(lab, p, p - W + 1);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) ccl_box_kernel(int* __restrict__ label, int* __restrict__ box, int H, int W) {
+  const int HW = H * W;
+  int* lab = label + (size_t)blockIdx.y * HW;
+  int* bx = box + (size_t)blockIdx.y * 4 * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    if (lab[p] < 0) continue;
+    const int r = ccl_find(lab, p);
+    if (r == p) continue;                                   // the root carries its own pixel already
+    const int y = p / W, x = p - y * W;
+    atomicMin(bx + r, x); atomicMin(bx + HW + r, y);
+    atomicMax(bx + 2 * HW + r, x); atomicMax(bx + 3 * HW + r, y);
+    lab[p] = r;                                             // flatten (only this thread writes lab[p] in this pass)
+  }
+}
+
+__global__ void __launch_bounds__(256) ccl_select_kernel(const int* __restrict__ label, const int* __restrict__ box,
+                                                         unsigned long long* __restrict__ best, int H, int W,
+                                                         int tie_last_wins) {
+  const int HW = H * W;
+  const int* lab = label + (size_t)blockIdx.y * HW;
+  const int* bx = box + (size_t)blockIdx.y * 4 * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    if (lab[p] != p) continue;                              // roots only
+    const unsigned area = (unsigned)(bx[2 * HW + p] - bx[p] + 1) * (unsigned)(bx[3 * HW + p] - bx[HW + p] + 1);
+    const unsigned order = tie_last_wins ? (unsigned)p + 1u : 0xFFFFFFFFu - (unsigned)p;
+    atomicMax(best + blockIdx.y, ((unsigned long long)area << 32) | order);
+  }
+}
+
+// out[f] = (x, y, w, h) of the winning box, or (0,0,0,0) when the thresholded map is empty (test.py:60-62)
+__global__ void ccl_emit_kernel(const int* __restrict__ box, const unsigned long long* __restrict__ best,
+                                int* __restrict__ out, int frames, int H, int W, int tie_last_wins) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= frames) return;
+  const int HW = H * W;
+  const unsigned long long k = best[f];
+  int x = 0, y = 0, w = 0, h = 0;
+  if (k != 0ull) {
+    const unsigned order = (unsigned)(k & 0xFFFFFFFFull);
+    const int p = tie_last_wins ? (int)(order - 1u) : (int)(0xFFFFFFFFu - order);
+    const int* bx = box + (size_t)f * 4 * HW;
+    x = bx[p]; y = bx[HW + p];
+    w = bx[2 * HW + p] - x + 1; h = bx[3 * HW + p] - y + 1;
+  }
+  out[4 * f] = x; out[4 * f + 1] = y; out[4 * f + 2] = w; out[4 * f + 3] = h;
+}
+
+}  // namespace tnv3

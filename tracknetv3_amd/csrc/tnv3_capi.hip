@@ -10,7 +10,11 @@ struct Launcher {
   hipStream_t stream;
   template <class... KArgs, class... Args>
   int launch(void (*kernel)(KArgs...), int grid, int block, Args... args) {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, static_cast<KArgs>(args)...);
+    return launch3(kernel, grid, 1, 1, block, args...);
+  }
+  template <class... KArgs, class... Args>
+  int launch3(void (*kernel)(KArgs...), int gx, int gy, int gz, int block, Args... args) {
+    hipLaunchKernelGGL(kernel, dim3(gx, gy, gz), dim3(block), 0, stream, static_cast<KArgs>(args)...);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) TNV3_FAIL(TNV3_E_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
     return TNV3_OK;

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "kernels/conv3x3_mfma.h"
+#include "kernels/conv1d_k3.h"
 #include "kernels/pointwise.h"
 
 namespace tnv3 {
@@ -50,18 +51,9 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Library default when the caller passes cfg = -1 (overridden per layer by the tuned table on the Python
-// side).  Prefers 128-channel blocks when Cout allows, falls back to smaller pixel tiles when the grid would
-// not cover the 256 CUs twice.
-inline int conv_auto_config(int N, int Cout, int H, int W) {
-  const long px = (long)N * H * W;
-  if (Cout % 128 == 0) {
-    const long blocks = (Cout / 128) * ((px + 255) / 256);
-    return blocks >= 512 ? 2 : 4;
-  }
-  const long blocks = (Cout / 64) * ((px + 511) / 512);
-  if (blocks >= 1024) return 1;
-  return ((Cout / 64) * ((px + 255) / 256) >= 512) ? 0 : 7;
-}
+// side).  Measured on MI355X (profiles/r01_*): the small 4x32-pixel tiles win on every TrackNet layer because
+// they run 3 waves per SIMD; 128-channel blocks are marginally better when Cout allows.
+inline int conv_auto_config(int /*N*/, int Cout, int /*H*/, int /*W*/) { return (Cout % 128 == 0) ? 4 : 7; }
 
 template <class Cfg, class Launcher>
 int launch_conv_cfg(Launcher& L, const Conv3x3Args& a) {
@@ -139,6 +131,19 @@ int maxpool2x2_impl(Launcher& L, const float* x, float* y, long nc, int h, int w
   const long total = nc * (h / 2) * (w / 4);
   const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   return L.launch(maxpool2x2_kernel, grid, 256, x, y, nc, h, w);
+}
+
+template <class Launcher>
+int conv1d_k3_impl(Launcher& L, const float* src0, const float* src1, const float* w, const float* b, float* dst, int n,
+                   int c0, int c1, int cout, int l, int src_nlc, int dst_nlc, int act) {
+  if (!src0 || !w || !b || !dst || n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || l <= 0) TNV3_FAIL(-1, "conv1d_k3: bad argument");
+  if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv1d_k3: src1 / c1 mismatch");
+  if (act < 0 || act > 2) TNV3_FAIL(-1, "conv1d_k3: unknown activation %d", act);
+  constexpr int S = 8, COB = 32, CK = 32, LT = 16;
+  Conv1dArgs a{src0, src1, w, b, dst, n, c0, c1, cout, l, src_nlc ? 1 : 0, dst_nlc ? 1 : 0, act};
+  const long gx = (n + S - 1) / S;
+  if (gx > 0x7fffffffl) TNV3_FAIL(-1, "conv1d_k3: batch too large");
+  return L.launch3(conv1d_k3_kernel<S, COB, CK, LT>, (int)gx, (cout + COB - 1) / COB, (l + LT - 1) / LT, S * COB, a);
 }
 
 }  // namespace tnv3

@@ -103,3 +103,27 @@ def maxpool2x2(x, out=None):
         out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
     _lib.check(lib.tnv3_maxpool2x2(_lib.ptr(x), _lib.ptr(out), n * c, h, w, _lib.stream_ptr(x)))
     return out
+
+
+ACT_NONE, ACT_LEAKY_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def conv1d_k3(src0, weight, bias, src1=None, src_nlc=False, dst_nlc=False, act=ACT_LEAKY_RELU):
+    """act(conv1d_k3_same(cat([src0, src1], channels), weight) + bias) -- see tnv3_conv1d_k3_forward."""
+    lib = _lib.load()
+    _f32(src0, src1, weight, bias)
+    _lib.dev_check(src0, src1, weight, bias)
+    if src_nlc:
+        n, l, c0 = (int(v) for v in src0.shape)
+        c1 = int(src1.shape[2]) if src1 is not None else 0
+    else:
+        n, c0, l = (int(v) for v in src0.shape)
+        c1 = int(src1.shape[1]) if src1 is not None else 0
+    cout = int(weight.shape[0])
+    if tuple(weight.shape) != (cout, c0 + c1, 3) or bias.numel() != cout:
+        raise _lib.Tnv3Error(f"conv1d_k3: weight {tuple(weight.shape)} does not match {c0}+{c1} input channels")
+    out = torch.empty((n, l, cout) if dst_nlc else (n, cout, l), dtype=torch.float32, device=src0.device)
+    _lib.check(lib.tnv3_conv1d_k3_forward(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out),
+                                          n, c0, c1, cout, l, int(bool(src_nlc)), int(bool(dst_nlc)), int(act),
+                                          _lib.stream_ptr(src0)))
+    return out
