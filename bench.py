@@ -136,12 +136,69 @@ def cpu_baseline(budget_s=25.0):
             "host_cpus": ncpu}
 
 
+TRAIN_FLOPS_PER_SAMPLE = 678.2e9    # fwd + dgrad + wgrad (no dgrad for the first layer)
+
+
+def bench_train(args, dev, rank, world):
+    """BASELINE configs[2] shard: TrackNet(27,8) train step, batch 10 per GPU, mixup alpha 0.5, Adam, DP all-reduce."""
+    import torch.distributed as dist
+    from oracle import nets
+    from tracknetv3_amd.parallel import TrackNetTrainer
+    from tracknetv3_amd.utils.general import get_model
+    in_dim = (SEQ_LEN + 1) * 3
+    model = get_model("TrackNet", SEQ_LEN, BG_MODE)
+    model.load_state_dict(nets.synth_state(nets.tracknet_state_shapes(in_dim, SEQ_LEN), 31, calibrated=False), strict=True)
+    model = model.to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    trainer = TrackNetTrainer(model, opt, alpha=0.5, seed=13)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.rand((args.batch, in_dim, H, W), device=dev, generator=gen)
+    y = nets.disc_heatmaps(args.batch, SEQ_LEN, H, W, 77 + rank).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        frames = world * args.batch * SEQ_LEN * args.steps
+        ms = dt / args.steps * 1e3
+        tf = TRAIN_FLOPS_PER_SAMPLE * args.batch / (ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "frames/sec (288x512, seq_len=8) TrackNet training", "value": round(frames / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] shard: TrackNet seq_len=8 bg_mode=concat, batch 10 per GPU, mixup alpha=0.5, "
+                                   "WBCE, backward, Adam(lr=1e-3); DP gradient all-reduce over RCCL when n_gpus > 1",
+                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "whole step (conv fwd + dgrad + wgrad MFMA kernels + HBM-bound BN/pool/head passes)"},
+            "cpu_baseline": None, "final_loss": round(float(loss.item()), 6)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=10, help="windows per GPU per step (BASELINE configs[1]: 10)")
+    ap.add_argument("--mode", choices=("infer", "train"), default="infer",
+                    help="infer: BASELINE configs[1] (headline); train: configs[2] shard -- mixup + fwd + WBCE + bwd + Adam")
     ap.add_argument("--tune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers-out", default=os.path.join(ROOT, "gpurun_out", "bench_layers.json"))
@@ -170,6 +227,9 @@ def main():
         tune(dev, args.batch, [os.path.join(ROOT, "gpurun_out", "conv_tuning.json")])
     if world > 1:
         dist.barrier()
+
+    if args.mode == "train":
+        return bench_train(args, dev, rank, world)
 
     in_dim = (SEQ_LEN + 1) * 3
     model = get_model("TrackNet", SEQ_LEN, BG_MODE)

@@ -84,6 +84,80 @@ int tnv3_maxpool2x2(const float* x, float* y, long nc, int h, int w, tnv3_stream
 int tnv3_conv1d_k3_forward(const float* src0, const float* src1, const float* w, const float* b, float* dst, int n,
                            int c0, int c1, int cout, int l, int src_nlc, int dst_nlc, int act, tnv3_stream_t stream);
 
+/* ---- heat-map post-process (predict.py:14-69,163-209; test.py:25-79) ------------------------------------- */
+
+/* Temporal ensemble in closed form (predict.py:163-209 heat maps, 243-301 coordinates).
+ *   win    : [n_local][L][E] window outputs; row i is global window s_base + i (sliding step 1)
+ *   weight : [L] from get_ensemble_weight (test.py:25-50)
+ *   out    : [n_frames][E] ensembled predictions of global frames t0 .. t0+n_frames-1
+ *   num_sample = total number of windows of the video (frames - L + 1).  Every window a requested frame needs
+ *   (s in [max(0,t-L+1), min(t,num_sample-1)]) must be resident in `win`. */
+int tnv3_ensemble_frames(const float* win, int n_local, long s_base, int l, int e, const float* weight, long t0,
+                         int n_frames, long num_sample, float* out, tnv3_stream_t stream);
+
+/* Bytes of scratch tnv3_heatmap_peakfind needs for `frames` maps of h x w. */
+size_t tnv3_peakfind_workspace_bytes(int frames, int h, int w);
+
+/* predict.py:35 (`y_pred > 0.5`) + predict_location (test.py:52-79; cv2.findContours(RETR_EXTERNAL) +
+ * cv2.boundingRect + largest box), batched: out_bbox[f] = (x, y, w, h) int32, or (0,0,0,0) for an empty map.
+ *   heat : [frames][h][w] fp32;  a pixel is foreground iff heat > threshold
+ *   tie_last_wins != 0: among equal-area boxes the component found last in raster order wins (OpenCV order) */
+int tnv3_heatmap_peakfind(const float* heat, float threshold, int tie_last_wins, int32_t* out_bbox, void* workspace,
+                          size_t workspace_bytes, int frames, int h, int w, tnv3_stream_t stream);
+
+/* ---- training step (train.py:84-96: forward in train mode, WBCELoss, loss.backward()) -------------------- */
+
+/* nn.BatchNorm2d in training mode (model.py:9) + nn.ReLU (model.py:10) on the raw convolution output z[N][C][HW]:
+ * batch mean / biased variance over (N,H,W), a = max((z-mean)*invstd*gamma+beta, 0), running stats updated in
+ * place with momentum and the UNBIASED variance; (mean, invstd) saved for backward.  HW % 4 == 0. */
+size_t tnv3_bn_workspace_bytes(int channels);
+int tnv3_bn_train_forward(const float* z, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float eps, float momentum, float* a, float* save_mean,
+                          float* save_invstd, void* workspace, size_t workspace_bytes, int n, int c, int hw,
+                          tnv3_stream_t stream);
+
+/* Backward of the same: given dA (gradient w.r.t. a), a, z and the saved statistics, writes dZ (may alias dA),
+ * dgamma[C], dbeta[C]. */
+int tnv3_bn_relu_backward(const float* da, const float* a, const float* z, const float* gamma, const float* save_mean,
+                          const float* save_invstd, float* dz, float* dgamma, float* dbeta, void* workspace,
+                          size_t workspace_bytes, int n, int c, int hw, tnv3_stream_t stream);
+
+/* Data gradient of Conv2DBlock's convolution: dX = conv3x3(dZ, W^T with flipped taps).  wpack_t comes from
+ * tnv3_pack_conv3x3_weights(..., transpose_flip = 1).  The first c0 input-channel gradients go to dx0
+ * [N][c0][H][W], the remaining c1 to dx1 [N][c1][H][W] (the two operands of torch.cat at model.py:65,67,69);
+ * c1 = 0 / dx1 = NULL for an ordinary layer.  (c0 + c1) % 64 == 0. */
+int tnv3_conv3x3_dgrad(const float* dz, const float* wpack_t, float* dx0, float* dx1, int n, int cout, int c0, int c1,
+                       int h, int w, int cfg, tnv3_stream_t stream);
+
+/* Weight gradient dW[Cout][C0+C1][3][3] = sum_pixels dZ * X, X = cat([up2x?(src0), src1]) as in the forward. */
+size_t tnv3_conv3x3_wgrad_workspace_bytes(int n, int c0, int c1, int cout, int h, int w);
+int tnv3_conv3x3_wgrad(const float* src0, const float* src1, const float* dz, float* dw, void* workspace,
+                       size_t workspace_bytes, int n, int c0, int c1, int cout, int h, int w, int up0,
+                       tnv3_stream_t stream);
+
+/* WBCELoss(y_pred, y, reduce) (utils/metric.py:3-20): out[0] (reduce != 0) or out[N] per-sample means. */
+size_t tnv3_wbce_workspace_bytes(int n);
+int tnv3_wbce_forward(const float* p, const float* y, float* out, void* workspace, size_t workspace_bytes, int n,
+                      long per_sample, int reduce, tnv3_stream_t stream);
+/* dL/dp in closed form; upstream: gradient of the scalar (reduce != 0: 1 value) or of the N per-sample losses. */
+int tnv3_wbce_backward(const float* p, const float* y, const float* upstream, float* dp, int n, long per_sample,
+                       int reduce, tnv3_stream_t stream);
+
+/* Backward of the head p = sigmoid(conv1x1(a) + b) (model.py:71-72): dA[N][64][HW], dW[L][64], db[L]. */
+size_t tnv3_head_backward_workspace_bytes(int l);
+int tnv3_head_backward(const float* dp, const float* p, const float* a, const float* w, float* da, float* dw,
+                       float* db, void* workspace, size_t workspace_bytes, int n, int l, int hw,
+                       tnv3_stream_t stream);
+
+/* MaxPool2d(2,2) backward fused with the skip-connection gradient add: dx = dskip + route(dpool). dskip may be NULL. */
+int tnv3_maxpool2x2_backward_add(const float* x, const float* dpool, const float* dskip, float* dx, long nc, int h,
+                                 int w, tnv3_stream_t stream);
+/* nn.Upsample(scale_factor=2) backward: d_lo = 2x2 block sums of d_hi [nc][2*hl][2*wl]. */
+int tnv3_upsample2x_backward(const float* d_hi, float* d_lo, long nc, int hl, int wl, tnv3_stream_t stream);
+/* Sample mixup (train.py:32-40): out[n] = x[n]*lam[n] + x[perm[n]]*(1-lam[n]); per_sample % 4 == 0. */
+int tnv3_mixup(const float* x, const float* lam, const int32_t* perm, float* out, int n, long per_sample,
+               tnv3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

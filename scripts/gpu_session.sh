@@ -1,27 +1,39 @@
 #!/bin/bash
-# One GPU-box session: smoke, GPU parity tests, tile-config tuning + bench, rocprofv3 kernel trace.
+# One GPU-box session: smoke, GPU parity tests, benches, rocprofv3 kernel trace + PMC passes.
 # Everything that must come back is written under gpurun_out/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-OUT=gpurun_out
+OUT=$PWD/gpurun_out
 mkdir -p $OUT
-echo "== device" | tee $OUT/session.log
-(rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8; nproc; lscpu | grep -E "Model name|^CPU\(s\)|Socket|Core") >> $OUT/session.log 2>&1
-echo "== smoke" | tee -a $OUT/session.log
-timeout 600 python __graft_entry__.py smoke >> $OUT/session.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/session.log
-echo "== pytest -m gpu" | tee -a $OUT/session.log
-timeout 900 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/session.log
-tail -15 $OUT/pytest_gpu.log | tee -a $OUT/session.log
-echo "== bench (tune)" | tee -a $OUT/session.log
-timeout 900 python bench.py --tune --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/session.log
-cat $OUT/bench.json | tee -a $OUT/session.log
-grep -E "^\[layer\]|^\[tune\]" $OUT/bench.err | tee -a $OUT/session.log
-echo "== rocprofv3 kernel trace" | tee -a $OUT/session.log
-cp $OUT/conv_tuning.json tracknetv3_amd/conv_tuning.json.session 2>/dev/null
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof_bench.err); echo "rocprof rc=$?" | tee -a $OUT/session.log
-find $OUT/prof -name "*stats*" | head | tee -a $OUT/session.log
-for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -25 $f | cut -c1-220 | tee -a $OUT/session.log; done
-# keep only the small summaries (the raw trace can be large)
-find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
-echo "== done" | tee -a $OUT/session.log
+LOG=$OUT/session.log
+: > $LOG
+echo "== smoke" | tee -a $LOG
+timeout 600 python __graft_entry__.py smoke >> $LOG 2>&1; echo "smoke rc=$?" | tee -a $LOG
+echo "== pytest -m gpu" | tee -a $LOG
+timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $LOG
+tail -40 $OUT/pytest_gpu.log | tee -a $LOG
+echo "== bench infer" | tee -a $LOG
+timeout 600 python bench.py ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $LOG
+cat $OUT/bench.json | tee -a $LOG; grep -E "^\[layer\]|^\[tune\]" $OUT/bench.err | tee -a $LOG
+echo "== bench train" | tee -a $LOG
+timeout 600 python bench.py --mode train --steps 10 --warmup 2 > $OUT/bench_train.json 2> $OUT/bench_train.err; echo "bench train rc=$?" | tee -a $LOG
+cat $OUT/bench_train.json | tee -a $LOG; tail -5 $OUT/bench_train.err | tee -a $LOG
+echo "== microbench" | tee -a $LOG
+timeout 600 python scripts/microbench.py > $OUT/microbench.json 2> $OUT/microbench.err; echo "microbench rc=$?" | tee -a $LOG
+cat $OUT/microbench.json | tee -a $LOG; tail -5 $OUT/microbench.err | tee -a $LOG
+echo "== rocprofv3 kernel trace (infer, then train)" | tee -a $LOG
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_infer -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_infer.json 2> $OUT/prof_infer.err; echo "rocprof infer rc=$?" | tee -a $LOG
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_train -o trace -- python $OLDPWD/bench.py --mode train --steps 3 --warmup 1 > $OUT/prof_train.json 2> $OUT/prof_train.err; echo "rocprof train rc=$?" | tee -a $LOG
+echo "== rocprofv3 PMC passes (separate runs; counters only with --kernel-trace)" | tee -a $LOG
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err; echo "pmc fetch rc=$?" | tee -a $LOG
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err; echo "pmc write rc=$?" | tee -a $LOG
+cd $OLDPWD
+for d in prof_infer prof_train pmc_fetch pmc_write; do
+  for f in $(find $OUT/$d -name "*.db"); do python scripts/rocpd_summary.py $f $OUT/${d}_kernel_stats.csv >> $LOG 2>&1; python scripts/rocpd_pmc.py $f $OUT/${d}_pmc.csv >> $LOG 2>&1; done
+done
+du -sh $OUT/* | tee -a $LOG
+# raw databases can be large: keep the summaries, drop dbs above 15 MB
+find $OUT -name "*.db" -size +15M -delete
+echo "== done" | tee -a $LOG

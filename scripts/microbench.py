@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Secondary measurements on one MI355X (BASELINE configs[3] and the post-process of configs[4]):
+InpaintNet forward latency/throughput, batched peak-find, temporal ensemble.  Prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def timeit(fn, reps, dev):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    from tracknetv3_amd import ops, postprocess as pp
+    from tracknetv3_amd.utils.general import get_model
+    dev = torch.device("cuda:0")
+    out = {}
+    net = get_model("InpaintNet").to(dev).eval()
+    for n in (32, 4096, 65536):
+        x, m = torch.rand(n, 16, 2, device=dev), (torch.rand(n, 16, 1, device=dev) < 0.3).float()
+        ms = timeit(lambda: net(x, m), 5 if n > 4096 else 20, dev)
+        out[f"inpaintnet_fwd_n{n}"] = {"ms": round(ms, 4), "seq_per_s": round(n / ms * 1e3, 1), "tflops": round(16.63e6 * n / ms / 1e9, 2)}
+    hm = torch.zeros(80, 288, 512, device=dev)
+    hm[:, 100:106, 200:207] = 0.9
+    hm[::3, 20:23, 400:404] = 0.8
+    out["peakfind_80x288x512_sparse"] = {"ms": round(timeit(lambda: ops.heatmap_peakfind(hm, 0.5), 20, dev), 4)}
+    hd = (torch.rand(80, 288, 512, device=dev) < 0.5).float()
+    out["peakfind_80x288x512_dense_noise"] = {"ms": round(timeit(lambda: ops.heatmap_peakfind(hd, 0.5), 5, dev), 4)}
+    win = torch.rand(17, 8, 288, 512, device=dev)
+    w = pp.get_ensemble_weight(8, "weight").to(dev)
+    ms = timeit(lambda: ops.ensemble_frames(win, 0, w, 7, 10, 1000), 20, dev)
+    out["ensemble_10frames_L8"] = {"ms": round(ms, 4), "GBps": round((10 * 9) * 288 * 512 * 4 / ms / 1e6, 1)}
+    x = torch.rand(10, 27, 288, 512, device=dev)
+    lam, perm = torch.rand(10, device=dev), torch.randperm(10, device=dev).int()
+    ms = timeit(lambda: ops.mixup(x, lam, perm), 20, dev)
+    out["mixup_10x27x288x512"] = {"ms": round(ms, 4), "GBps": round(3 * x.numel() * 4 / ms / 1e6, 1)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

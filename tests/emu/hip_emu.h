@@ -13,7 +13,6 @@
 //   16x16x4 f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D reg r -> row=4*(l>>4)+r,            col=l&15
 // and computes each output as the k-ordered fmaf chain the hardware produces.
 #pragma once
-#include <ucontext.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -34,12 +33,38 @@
 struct emu_dim3 { unsigned x, y, z; };
 static emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+// Minimal x86-64 SysV context switch (callee-saved registers + stack pointer).  glibc's swapcontext makes a
+// sigprocmask system call per switch, which dominated the emulator's run time.
+extern "C" void tnv3_emu_swap(void** save_sp, void* load_sp);
+__asm__(R"ASM(
+.text
+.globl tnv3_emu_swap
+.type tnv3_emu_swap,@function
+tnv3_emu_swap:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size tnv3_emu_swap,.-tnv3_emu_swap
+)ASM");
+
 namespace emu {
 
 enum { WAVE = 64, MAX_WAVES = 16 };
 
 struct Fiber {
-  ucontext_t ctx;
+  void* sp = nullptr;
   char* stack = nullptr;
   bool done = false;
   bool wait_block = false;
@@ -48,7 +73,7 @@ struct Fiber {
 };
 
 struct State {
-  ucontext_t main_ctx;
+  void* main_sp = nullptr;
   std::vector<Fiber> fibers;
   Fiber* cur = nullptr;
   unsigned nthreads = 0;
@@ -66,7 +91,7 @@ inline unsigned wave_id() { return flat_tid() / WAVE; }
 inline void yield() {
   State& s = S();
   Fiber* f = s.cur;
-  swapcontext(&f->ctx, &s.main_ctx);
+  tnv3_emu_swap(&f->sp, s.main_sp);
   threadIdx = f->tid;
 }
 
@@ -93,7 +118,8 @@ inline void fiber_entry() {
   threadIdx = s.cur->tid;
   s.body();
   s.cur->done = true;
-  swapcontext(&s.cur->ctx, &s.main_ctx);
+  tnv3_emu_swap(&s.cur->sp, s.main_sp);
+  abort();   // a finished fiber is never resumed
 }
 
 // Run `body` for every work-item of a grid.
@@ -121,9 +147,14 @@ inline void launch(emu_dim3 grid, emu_dim3 block, std::function<void()> body) {
       Fiber& f = s.fibers[i];
       f.done = false; f.wait_block = false;
       f.tid = {i % block.x, (i / block.x) % block.y, i / (block.x * block.y)};
-      getcontext(&f.ctx);
-      f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
-      makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+      // initial frame: six zeroed callee-saved registers, then the entry address that `ret` jumps to;
+      // after that `ret`, rsp % 16 == 8 as the ABI requires at a function entry.
+      uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+      void** frame = (void**)(top - 64);
+      for (int q = 0; q < 6; ++q) frame[q] = nullptr;
+      frame[6] = (void*)&fiber_entry;
+      frame[7] = nullptr;
+      f.sp = (void*)frame;
     }
     unsigned remaining = s.nthreads;
     unsigned long guard = 0;
@@ -136,7 +167,7 @@ inline void launch(emu_dim3 grid, emu_dim3 block, std::function<void()> body) {
             if (f.done) continue;
             if (f.wait_block && f.wait_gen == s.block_gen) continue;
             s.cur = &f; threadIdx = f.tid;
-            swapcontext(&s.main_ctx, &f.ctx);
+            tnv3_emu_swap(&s.main_sp, f.sp);
             any = true;
             if (f.done) --remaining;
           }

@@ -1,0 +1,127 @@
+"""GPU (-m gpu): post-process (ensemble, peak-find) and InpaintNet through the C ABI vs the oracle / goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import nets, prng
+from oracle import postproc as opp
+from test_emu_postproc import _blob_maps
+
+pytestmark = pytest.mark.gpu
+
+
+def test_peakfind_designed_maps_bit_exact(gpu_device):
+    from tracknetv3_amd import ops
+    maps = _blob_maps()
+    for tie in (True, False):
+        got = ops.heatmap_peakfind(torch.from_numpy(maps).to(gpu_device), 0.5, tie_last_wins=tie).cpu().numpy()
+        opp.TIE_LAST_WINS = tie
+        try:
+            want = np.array([opp.predict_location(opp.to_img(m > 0.5)) for m in maps])
+        finally:
+            opp.TIE_LAST_WINS = True
+        assert np.array_equal(got, want), (tie, got.tolist(), want.tolist())
+
+
+def test_peakfind_full_size_batch_bit_exact_and_concurrent_unions(gpu_device):
+    """288x512 maps, 80 per call (config-2 batch): sparse discs, dense noise (long union chains across workgroups),
+    a full frame, a serpentine -- repeated to catch union-find races."""
+    from tracknetv3_amd import ops
+    rng = np.random.RandomState(5)
+    maps = np.zeros((80, 288, 512), np.float32)
+    ii, jj = np.meshgrid(np.arange(288), np.arange(512), indexing="ij")
+    for f in range(60):
+        for _ in range(f % 4):
+            cy, cx, r = rng.randint(0, 288), rng.randint(0, 512), rng.uniform(1.5, 6)
+            maps[f][(ii - cy) ** 2 + (jj - cx) ** 2 <= r * r] = 0.9
+    for f in range(60, 70):
+        maps[f] = (rng.rand(288, 512) < [0.3, 0.45, 0.55, 0.6, 0.7][f % 5]).astype(np.float32)
+    maps[70] = 1.0
+    maps[71, ::2, :] = 1.0
+    maps[71, 1::4, 511] = 1.0
+    maps[71, 3::4, 0] = 1.0                       # one serpentine component spanning the whole frame
+    maps[72, ::2, ::2] = 1.0                      # 36864 isolated pixels: all ties
+    for f in range(73, 80):
+        maps[f] = (rng.rand(288, 512) < 0.5).astype(np.float32) * (rng.rand(288, 512) + 0.01)
+    hm = torch.from_numpy(maps).to(gpu_device)
+    got = ops.heatmap_peakfind(hm, 0.5).cpu().numpy()
+    for _ in range(3):
+        assert np.array_equal(ops.heatmap_peakfind(hm, 0.5).cpu().numpy(), got)
+    from scipy import ndimage
+    for f in range(80):
+        fg = maps[f] > 0.5
+        lab, n = ndimage.label(fg, structure=np.ones((3, 3)))
+        if n == 0:
+            assert got[f].tolist() == [0, 0, 0, 0]
+            continue
+        sl = ndimage.find_objects(lab)
+        boxes = [(s[1].start, s[0].start, s[1].stop - s[1].start, s[0].stop - s[0].start) for s in sl]
+        firsts = ndimage.minimum(np.arange(fg.size).reshape(fg.shape), lab, index=np.arange(1, n + 1))
+        best = max(range(n), key=lambda k: (boxes[k][2] * boxes[k][3], firsts[k]))     # tie: last discovered wins
+        assert tuple(got[f].tolist()) == boxes[best], f
+    sel = [0, 1, 2, 3, 61, 70, 71]                                                      # oracle's own BFS on a subset
+    want = np.array([opp.predict_location(opp.to_img(maps[f] > 0.5)) for f in sel])
+    assert np.array_equal(got[sel], want)
+
+
+def test_predict_matches_reference_golden(gpu_device):
+    from tracknetv3_amd import postprocess as pp
+    g = np.load(os.path.join(GOLDEN, "host_logic.npz"))
+    idx = g["predict_c_idx"]
+    hm = np.zeros((3, 4, 288, 512), dtype=np.float32)
+    hm[0, 0, 100:105, 200:207] = 0.9
+    hm[0, 1, 10:12, 10:12] = 0.7
+    hm[0, 1, 50:53, 300:303] = 0.8
+    hm[1, 2, 0:3, 0:2] = 0.51
+    hm[2, 0, 287, 511] = 1.0
+    a = pp.predict(torch.from_numpy(idx), y_pred=torch.from_numpy(hm).to(gpu_device), img_scaler=(3.75, 3.75))
+    assert np.array_equal(np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]]), g["predict_h_out"])
+    a = pp.predict(torch.from_numpy(idx), c_pred=torch.from_numpy(g["predict_c_in"]).to(gpu_device), img_scaler=(3.75, 3.75))
+    assert np.array_equal(np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]]), g["predict_c_out"])
+
+
+def test_ensemble_stream_vs_reference_goldens_and_full_size(gpu_device):
+    from tracknetv3_amd import postprocess as pp
+    g = np.load(os.path.join(GOLDEN, "ensemble.npz"))
+    k = 0
+    while f"heat_{k}_meta" in g:
+        L, wmode, n_win, batch, seed = (int(v) for v in g[f"heat_{k}_meta"])
+        win = prng.uniform((n_win, L, 4, 8), seed)
+        es = pp.EnsembleStream(L, "weight" if wmode else "average", n_win)
+        mine = torch.cat([es.push(torch.from_numpy(win[s:s + batch]).to(gpu_device)) for s in range(0, n_win, batch)], 0)
+        assert np.abs(mine.cpu().numpy() - g[f"heat_{k}_ens"]).max() <= 2.5e-7, k
+        k += 1
+    assert k == 24
+    # full-size heat maps: the literal buffer-loop restatement (oracle) vs the device stream
+    L, n_win, batch = 8, 21, 10
+    win = prng.uniform((n_win, L, 288, 512), 99)
+    want = np.concatenate(list(opp.ensemble_stream([win[s:s + batch] for s in range(0, n_win, batch)], L, "weight", n_win)), 0)
+    es = pp.EnsembleStream(L, "weight", n_win)
+    mine = torch.cat([es.push(torch.from_numpy(win[s:s + batch]).to(gpu_device)) for s in range(0, n_win, batch)], 0)
+    assert mine.shape[0] == n_win + L - 1 and np.abs(mine.cpu().numpy() - want).max() <= 2.5e-7
+
+
+def test_inpaintnet_forward(gpu_device):
+    from tracknetv3_amd.model import InpaintNet
+    g = np.load(os.path.join(GOLDEN, "inpaintnet_6x16.npz"))
+    sd = nets.synth_state(nets.inpaintnet_state_shapes(), 77)
+    net = InpaintNet()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(gpu_device).eval()
+    n, L = 6, 16
+    coor = nets.synth_input((n, L, 2), 501)
+    vis = (nets.synth_input((n, L, 1), 502) > 0.2).float()
+    coor = coor * vis
+    mask = ((nets.synth_input((n, L, 1), 503) < 0.3).float() * vis)
+    out = net((coor * (1 - mask)).to(gpu_device), mask.to(gpu_device)).cpu()
+    assert np.abs(out.numpy() - g["out"]).max() <= 2e-6
+    for (n2, L2) in ((3, 5), (9, 24), (4099, 16)):
+        c2, m2 = nets.synth_input((n2, L2, 2), 9), (nets.synth_input((n2, L2, 1), 10) < 0.5).float()
+        with torch.no_grad():
+            ref = nets.inpaintnet_forward(sd, c2, m2)
+        assert (net(c2.to(gpu_device), m2.to(gpu_device)).cpu() - ref).abs().max().item() <= 2e-6
+    # int mask as produced by train.py:153 (`.int()`) is accepted like torch.cat's type promotion
+    assert (net(c2.to(gpu_device), m2.int().to(gpu_device)).cpu() - ref).abs().max().item() <= 2e-6

@@ -1,0 +1,181 @@
+"""GPU (-m gpu): training-path parity through the C ABI -- per-kernel against torch autograd on the fp64 oracle,
+whole train step against the reference-derived goldens and the fp64 oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+from oracle import nets
+from test_emu_training import T, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bn_train_forward_backward(gpu_device):
+    from tracknetv3_amd import ops
+    d = gpu_device
+    n, c, h, w = 4, 128, 36, 64
+    z = T((n, c, h, w), 1, -2, 3)
+    g, b = T((c,), 2, 0.5, 1.5), T((c,), 3)
+    rm0, rv0 = T((c,), 4), T((c,), 5, 0.5, 2.0)
+    rm, rv = rm0.clone().to(d), rv0.clone().to(d)
+    a, mean, invstd = ops.bn_train_forward(z.to(d), g.to(d), b.to(d), rm, rv)
+    zd = z.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    sd = {"bn.weight": gd, "bn.bias": bd, "bn.running_mean": rm0, "bn.running_var": rv0, "bn.num_batches_tracked": torch.tensor(0)}
+    st = {}
+    ref = torch.relu(nets.batchnorm2d(zd, sd, "bn", True, st))
+    assert (a.cpu().double() - ref).abs().max().item() <= 5e-6
+    assert torch.allclose(rm.cpu().double(), st["bn.running_mean"], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(rv.cpu().double(), st["bn.running_var"], rtol=1e-6, atol=1e-7)
+    da = T((n, c, h, w), 6)
+    ref.backward(da.double())
+    dz, dgamma, dbeta = ops.bn_relu_backward(da.to(d), a, z.to(d), g.to(d), mean, invstd)
+    assert rel_err(dz.cpu(), zd.grad) <= 1e-5 and rel_err(dgamma.cpu(), gd.grad) <= 1e-5 and rel_err(dbeta.cpu(), bd.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 27, 0, 64, 40, 96, False), (2, 64, 0, 64, 32, 64, False), (1, 128, 64, 64, 32, 64, True),
+                                  (2, 512, 256, 256, 8, 32, True), (2, 256, 0, 512, 12, 32, False), (1, 128, 0, 256, 18, 50, False)],
+                         ids=["27to64", "64to64", "dual192to64", "dual768to256", "256to512", "128to256_ragged"])
+def test_wgrad_and_dgrad(gpu_device, case):
+    from tracknetv3_amd import ops
+    d = gpu_device
+    n, c0, c1, cout, h, w, up = case
+    s0 = T((n, c0, h // 2, w // 2) if up else (n, c0, h, w), 11)
+    s1 = T((n, c1, h, w), 12) if c1 else None
+    wt = T((cout, c0 + c1, 3, 3), 13, -0.1, 0.1)
+    dz = T((n, cout, h, w), 14)
+    x = s0.repeat_interleave(2, 2).repeat_interleave(2, 3) if up else s0
+    if c1:
+        x = torch.cat([x, s1], 1)
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    F.conv2d(xd, wd, padding=1).backward(dz.double())
+    dw = ops.conv3x3_wgrad(s0.to(d), dz.to(d), src1=None if s1 is None else s1.to(d), up0=up)
+    assert rel_err(dw.cpu(), wd.grad) <= 3e-6
+    dw2 = ops.conv3x3_wgrad(s0.to(d), dz.to(d), src1=None if s1 is None else s1.to(d), up0=up)
+    assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
+    if (c0 + c1) % 64 == 0:
+        dx0, dx1 = ops.conv3x3_dgrad(dz.to(d), ops.pack_conv3x3_weights(wt.to(d), transpose_flip=True), c0, c1)
+        assert rel_err(dx0.cpu(), xd.grad[:, :c0]) <= 3e-6
+        if c1:
+            assert rel_err(dx1.cpu(), xd.grad[:, c0:]) <= 3e-6
+
+
+def test_wbce_head_pool_upsample_mixup(gpu_device):
+    from tracknetv3_amd import ops
+    from tracknetv3_amd.utils.metric import WBCELoss
+    d = gpu_device
+    g = np.load(os.path.join(GOLDEN, "wbce_edge.npz"))
+    p = torch.from_numpy(g["p"]).to(d).requires_grad_(True)
+    y = torch.from_numpy(g["y"]).to(d)
+    loss = WBCELoss(p, y)
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6
+    loss.backward()
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad"], rtol=2e-5, atol=1e-8)
+    assert WBCELoss(p.detach(), y, reduce=False).shape == (1,)
+    # full-size maps (config-3 shard shape): loss value + gradient vs fp64 autograd
+    pp = T((10, 8, 288, 512), 5, 0.001, 0.999)
+    yy = nets.disc_heatmaps(10, 8, 288, 512, 77)
+    pg = pp.to(d).requires_grad_(True)
+    lg = WBCELoss(pg, yy.to(d))
+    lg.backward()
+    pd = pp.double().requires_grad_(True)
+    lr = nets.wbce_loss(pd, yy.double())
+    lr.backward()
+    assert abs(lg.item() - lr.item()) <= 1e-6 * abs(lr.item()) + 1e-9
+    assert rel_err(pg.grad.cpu(), pd.grad) <= 1e-5
+    # head backward
+    n, L, h, w = 2, 8, 24, 100
+    a = T((n, 64, h, w), 1)
+    wt, b = T((L, 64, 1, 1), 2, -0.3, 0.3), T((L,), 3)
+    ad, wd, bd = a.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    pref = torch.sigmoid(F.conv2d(ad, wd, bd))
+    dp = T((n, L, h, w), 4)
+    pref.backward(dp.double())
+    pq = ops.head1x1_sigmoid(a.to(d), wt.to(d), b.to(d))
+    da, dw, db = ops.head_backward(dp.to(d), pq, a.to(d), wt.to(d))
+    assert rel_err(da.cpu(), ad.grad) <= 1e-5 and rel_err(dw.cpu(), wd.grad) <= 1e-5 and rel_err(db.cpu(), bd.grad) <= 1e-5
+    # pool / upsample backward
+    x = torch.relu(T((2, 16, 24, 40), 5))
+    xd = x.double().requires_grad_(True)
+    dpool, dskip = T((2, 16, 12, 20), 6), T((2, 16, 24, 40), 7)
+    F.max_pool2d(xd, 2, 2).backward(dpool.double())
+    got = ops.maxpool2x2_backward_add(x.to(d), dpool.to(d), dskip.to(d)).cpu()
+    assert (got.double() - (xd.grad + dskip.double())).abs().max().item() <= 1e-6
+    dhi = T((2, 16, 24, 40), 8)
+    lo = torch.zeros((2, 16, 12, 20), dtype=torch.float64, requires_grad=True)
+    nets.upsample2x_nearest(lo).backward(dhi.double())
+    assert (ops.upsample2x_backward(dhi.to(d)).cpu().double() - lo.grad).abs().max().item() <= 1e-6
+    # mixup
+    gg = np.load(os.path.join(GOLDEN, "host_logic.npz"))
+    xm = nets.synth_input((4, 3, 8, 16), 11)
+    lam = np.maximum(gg["mixup_lam"], 1 - gg["mixup_lam"]).astype(np.float32)
+    out = ops.mixup(xm.to(d), torch.from_numpy(lam).to(d), torch.from_numpy(gg["mixup_perm"].astype(np.int32)).to(d))
+    assert np.abs(out.cpu().numpy() - gg["mixup_x"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["tracknet_9_3_32x64.npz", "tracknet_27_8_32x64_cal.npz"])
+def test_tracknet_train_step_vs_reference_golden(gpu_device, name):
+    """forward(train) + WBCELoss + backward: loss / heat maps / BN buffers vs the reference golden, gradients vs the
+    fp64 oracle with a tolerance tied to the fp32 reference's own deviation from fp64."""
+    from tracknetv3_amd.model import TrackNet
+    from tracknetv3_amd.utils.metric import WBCELoss
+    g = np.load(os.path.join(GOLDEN, name))
+    in_dim, out_dim, n, h, w, seed, cal = (int(v) for v in g["meta"])
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=bool(cal))
+    m = TrackNet(in_dim, out_dim)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu_device).train()
+    x = nets.synth_input((n, in_dim, h, w), seed + 1000)
+    y = nets.disc_heatmaps(n, out_dim, h, w, seed + 2000)
+    p = m(x.to(gpu_device))
+    loss = WBCELoss(p, y.to(gpu_device))
+    loss.backward()
+    assert abs(loss.item() - float(g["train_loss"])) <= 2e-5
+    assert np.abs(p.detach().cpu().numpy() - g["train_out"]).max() <= 1e-4
+    after = m.state_dict()
+    got = np.concatenate([after[str(k)].cpu().numpy().ravel() for k in g["bn_names"]])
+    np.testing.assert_allclose(got, g["bn_after"], rtol=2e-4, atol=2e-6)
+    assert all(int(after[k]) == 1 for k in after if k.endswith("num_batches_tracked"))
+    _, _, g64, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float64)
+    _, _, g32, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float32)
+    names = [str(s) for s in g["grad_names"]]
+    params = dict(m.named_parameters())
+    for k, name_ in enumerate(names):
+        gr = params[name_].grad.cpu()
+        assert rel_err(gr, g64[name_]) <= 3 * rel_err(g32[name_], g64[name_]) + 2e-4, name_
+        st = g["grad_stats64"][k]                       # golden: fp64 oracle statistics captured with the reference
+        assert abs(gr.double().abs().max().item() - st[2]) <= 0.1 * st[2] + 1e-12
+
+
+def test_train_then_eval_and_optimizer_step(gpu_device):
+    """Adam on the module's leaf parameters (train.py:85-96 protocol) changes the loss the right way and the eval path
+    picks up the new weights / running stats (cache invalidation)."""
+    from tracknetv3_amd.utils.general import get_model
+    from tracknetv3_amd.utils.metric import WBCELoss
+    torch.manual_seed(0)
+    m = get_model("TrackNet", 3, "").to(gpu_device)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x = nets.synth_input((2, 9, 32, 64), 5).to(gpu_device)
+    y = nets.disc_heatmaps(2, 3, 32, 64, 6).to(gpu_device)
+    m.eval()
+    e0 = m(x).clone()
+    m.train()
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = WBCELoss(m(x), y)
+        losses.append(loss.item())
+        loss.backward()
+        opt.step()
+    assert losses[-1] < losses[0]
+    m.eval()
+    e1 = m(x)
+    assert (e1 - e0).abs().max().item() > 1e-4
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = nets.tracknet_forward(sd, x.cpu(), training=False)
+    assert (e1.cpu() - ref).abs().max().item() <= 1e-4

@@ -1,0 +1,84 @@
+"""CPU, world_size 2 over gloo: the data-parallel machinery -- gradient bucketing in ready order, averaging,
+hook -> view replacement, shard ranges, per-rank mixup draws.  (The kernels themselves are rank-local and are
+covered by the emulator / GPU suites; RCCL replaces gloo on the GPUs with the same torch.distributed calls.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tracknetv3_amd import autograd_ops, parallel
+        from tracknetv3_amd.utils.general import get_model
+        torch.manual_seed(100 + rank)                      # replicas start DIFFERENT on purpose
+        net = get_model("TrackNet", 3, "")
+        parallel.broadcast_module(net, 0)
+        w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        order = autograd_ops.grad_ready_order(net)
+        assert len(order) == 53 and len({id(p) for p in order}) == 53
+        assert order[0] is net.predictor.weight and order[-1] is net.down_block_1.conv_1.conv.weight
+        red = parallel.GradAllReducer(order, bucket_bytes=12 << 20)
+        assert 3 <= red.num_buckets() <= 8
+        gen = torch.Generator().manual_seed(7 + rank)
+        grads, views = {}, {}
+        for p in order:                                     # what backward does, in the same order
+            g = torch.randn(p.shape, generator=gen)
+            grads[id(p)] = g.clone()
+            views[id(p)] = red.on_grad(p, g)
+        red.on_backward_end()
+        # every rank must now hold the mean over ranks
+        for p in order:
+            mine = grads[id(p)]
+            other = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(other, mine)
+            want = sum(other) / world
+            assert torch.allclose(views[id(p)], want, atol=1e-6), "bucket average mismatch"
+        # second step reuses the buckets
+        for p in order:
+            red.on_grad(p, torch.ones(p.shape) * (rank + 1))
+        red.on_backward_end()
+        assert torch.allclose(views[id(order[5])], torch.full(order[5].shape, (1 + world) / 2.0))
+        lo, hi = parallel.shard_range(80, rank, world)
+        lam, perm = parallel.draw_mixup(hi - lo, 0.5, np.random.RandomState(13 + 1000 * rank))
+        out[rank] = dict(w0=w0[:1000].clone(), shard=(lo, hi), lam=lam, perm=perm)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_and_sharding():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+        assert torch.equal(r0["w0"], r1["w0"]), "broadcast_module must make replicas identical"
+        assert r0["shard"] == (0, 40) and r1["shard"] == (40, 80)
+        assert (r0["lam"] >= 0.5).all() and sorted(r0["perm"].tolist()) == list(range(40))
+        assert not np.array_equal(r0["lam"], r1["lam"]), "each rank draws its own mixup lambdas"
+
+
+def test_shard_range_covers_batch():
+    from tracknetv3_amd.parallel import shard_range
+    for gb in (1, 7, 10, 80, 81):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(gb, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -40,6 +40,23 @@ def _declare(lib):
     sig("tnv3_head1x1_sigmoid", i, p, p, p, p, i, i, i, i, i, p)
     sig("tnv3_maxpool2x2", i, p, p, lg, i, i, p)
     sig("tnv3_conv1d_k3_forward", i, p, p, p, p, p, i, i, i, i, i, i, i, i, p)
+    sig("tnv3_ensemble_frames", i, p, i, lg, i, i, p, lg, i, lg, p, p)
+    sig("tnv3_peakfind_workspace_bytes", sz, i, i, i)
+    sig("tnv3_heatmap_peakfind", i, p, f, i, p, p, sz, i, i, i, p)
+    sig("tnv3_bn_workspace_bytes", sz, i)
+    sig("tnv3_bn_train_forward", i, p, p, p, p, p, f, f, p, p, p, p, sz, i, i, i, p)
+    sig("tnv3_bn_relu_backward", i, p, p, p, p, p, p, p, p, p, p, sz, i, i, i, p)
+    sig("tnv3_conv3x3_dgrad", i, p, p, p, p, i, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wgrad_workspace_bytes", sz, i, i, i, i, i, i)
+    sig("tnv3_conv3x3_wgrad", i, p, p, p, p, p, sz, i, i, i, i, i, i, i, p)
+    sig("tnv3_wbce_workspace_bytes", sz, i)
+    sig("tnv3_wbce_forward", i, p, p, p, p, sz, i, lg, i, p)
+    sig("tnv3_wbce_backward", i, p, p, p, p, i, lg, i, p)
+    sig("tnv3_head_backward_workspace_bytes", sz, i)
+    sig("tnv3_head_backward", i, p, p, p, p, p, p, p, p, sz, i, i, i, p)
+    sig("tnv3_maxpool2x2_backward_add", i, p, p, p, p, lg, i, i, p)
+    sig("tnv3_upsample2x_backward", i, p, p, lg, i, i, p)
+    sig("tnv3_mixup", i, p, p, p, p, i, lg, p)
     for name, spec in _OPTIONAL.items():
         if hasattr(lib, name):
             sig(name, *spec)
@@ -49,7 +66,11 @@ _OPTIONAL = {}   # later entry points register here: name -> (restype, *argtypes
 
 EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "tnv3_conv3x3_config_info",
            "tnv3_conv3x3_packed_floats", "tnv3_pack_conv3x3_weights", "tnv3_bn_fold", "tnv3_conv3x3_forward",
-           "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2", "tnv3_conv1d_k3_forward"]
+           "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2", "tnv3_conv1d_k3_forward", "tnv3_ensemble_frames",
+           "tnv3_peakfind_workspace_bytes", "tnv3_heatmap_peakfind", "tnv3_bn_workspace_bytes", "tnv3_bn_train_forward",
+           "tnv3_bn_relu_backward", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",
+           "tnv3_wbce_workspace_bytes", "tnv3_wbce_forward", "tnv3_wbce_backward", "tnv3_head_backward_workspace_bytes",
+           "tnv3_head_backward", "tnv3_maxpool2x2_backward_add", "tnv3_upsample2x_backward", "tnv3_mixup"]
 
 
 def library_path():

@@ -1,0 +1,187 @@
+"""Training-mode forward/backward of TrackNet as ONE torch.autograd.Function over HIP kernels.
+
+The reference relies on PyTorch autograd through ~60 ATen ops (train.py:92-95).  Here the whole network is a single
+autograd node: ``forward`` runs conv (fp32 MFMA) -> BN batch-stats -> normalise+ReLU per Conv2DBlock and keeps what the
+backward needs (raw conv outputs z, activations a, saved mean/invstd); ``backward`` receives dL/dp from the loss
+node (``WBCELoss`` below, or any torch op) and runs head-backward, then per block in reverse: BN+ReLU backward ->
+data gradient (the forward MFMA kernel on transposed/flipped filters) -> weight gradient (MFMA split-K), with the
+pool / upsample / concat gradients folded into three small kernels.  Parameters stay ordinary leaf tensors, so
+``torch.optim`` and ``state_dict`` work unchanged.  Optional ``grad_ready`` hook: called with (param, grad) as soon as
+a gradient is final, which is what the data-parallel wrapper uses to overlap RCCL all-reduce with the rest of backward.
+"""
+import torch
+
+from . import ops
+from . import tuning
+
+_grad_ready_hook = None
+_backward_end_hook = None
+
+
+def set_grad_ready_hook(fn, end_fn=None):
+    """fn(param, grad) -> grad-or-replacement is called inside backward as soon as `grad` is final; end_fn() runs
+    once after the last gradient of the step (None disables both)."""
+    global _grad_ready_hook, _backward_end_hook
+    _grad_ready_hook, _backward_end_hook = fn, end_fn
+
+
+def grad_ready_order(net):
+    """Parameters in the order their gradients become final inside backward (head first, first conv last)."""
+    order = [net.predictor.weight, net.predictor.bias]
+    for blks in reversed(_blocks(net)):
+        for blk in reversed(blks):
+            order += [blk.bn.weight, blk.bn.bias, blk.conv.weight]
+    return order
+
+
+def _blocks(net):
+    return (net.down_block_1.blocks(), net.down_block_2.blocks(), net.down_block_3.blocks(), net.bottleneck.blocks(),
+            net.up_block_1.blocks(), net.up_block_2.blocks(), net.up_block_3.blocks())
+
+
+def _cfg(blk, n, h, w):
+    return tuning.conv_config(blk.conv.out_dim, blk.conv.in_dim, n, h, w)
+
+
+class _TrackNetTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        # params are listed only so that autograd routes their gradients; values are read from the module.
+        saved = []          # per block: dict(x0, x1, up, z, a, mean, invstd)
+        n = x.shape[0]
+
+        def block_fwd(blk, src0, src1=None, up=False):
+            h = src0.shape[2] * (2 if up else 1)
+            w = src0.shape[3] * (2 if up else 1)
+            z = ops.conv3x3(src0, blk.packed_weight(), blk.conv.out_dim, src1=src1, up0=up, relu=False, cfg=_cfg(blk, n, h, w))
+            bn = blk.bn
+            a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                   bn.eps, bn.momentum)
+            bn.num_batches_tracked.add_(1)
+            saved.append(dict(blk=blk, x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd))
+            return a
+
+        def chain(blks, src0, src1=None, up=False):
+            y = block_fwd(blks[0], src0, src1, up)
+            for b in blks[1:]:
+                y = block_fwd(b, y)
+            return y
+
+        d1, d2, d3, bt, u1, u2, u3 = _blocks(net)
+        x1 = chain(d1, x)
+        x2 = chain(d2, ops.maxpool2x2(x1))
+        x3 = chain(d3, ops.maxpool2x2(x2))
+        y = chain(bt, ops.maxpool2x2(x3))
+        y = chain(u1, y, x3, True)
+        y = chain(u2, y, x2, True)
+        y = chain(u3, y, x1, True)
+        p = ops.head1x1_sigmoid(y, net.predictor.weight.detach(), net.predictor.bias.detach())
+        ctx.net, ctx.saved, ctx.p, ctx.head_in = net, saved, p, y
+        ctx.skips = (x1, x2, x3)
+        ctx.need_dx = x.requires_grad
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        net, saved = ctx.net, ctx.saved
+        hook = _grad_ready_hook
+        grads = {}
+
+        def done(param, g):
+            if hook is not None:
+                r = hook(param, g)
+                if r is not None:
+                    g = r
+            grads[id(param)] = g
+
+        dp = dp.contiguous()
+        da, dw_head, db_head = ops.head_backward(dp, ctx.p, ctx.head_in, net.predictor.weight.detach())
+        done(net.predictor.weight, dw_head)
+        done(net.predictor.bias, db_head)
+
+        def block_bwd(rec, da, need_dx=True):
+            blk = rec["blk"]
+            dz, dgamma, dbeta = ops.bn_relu_backward(da, rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"], rec["invstd"])
+            done(blk.bn.weight, dgamma)
+            done(blk.bn.bias, dbeta)
+            dw = ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
+            done(blk.conv.weight, dw)
+            if not need_dx:
+                return None, None
+            c0 = int(rec["x0"].shape[1])
+            c1 = int(rec["x1"].shape[1]) if rec["x1"] is not None else 0
+            n, _, h, w = dz.shape
+            cfg = tuning.conv_config(c0 + c1, blk.conv.out_dim, int(n), int(h), int(w))
+            return ops.conv3x3_dgrad(dz, blk.packed_weight(transpose_flip=True), c0, c1, cfg=cfg)
+
+        x1, x2, x3 = ctx.skips
+        idx = len(saved) - 1
+
+        def chain_bwd(count, da, first_needs_dx=True):
+            nonlocal idx
+            d_skip = None
+            for k in range(count):
+                rec = saved[idx]
+                idx -= 1
+                last = (k == count - 1)
+                da, d_skip = block_bwd(rec, da, need_dx=(first_needs_dx or not last))
+            return da, d_skip
+
+        # up_block_3 (2) -> dUp(128ch, full res), dSkip(x1)
+        d_up, d_x1 = chain_bwd(2, da)
+        da = ops.upsample2x_backward(d_up)
+        d_up, d_x2 = chain_bwd(2, da)                      # up_block_2
+        da = ops.upsample2x_backward(d_up)
+        d_up, d_x3 = chain_bwd(3, da)                      # up_block_1
+        da = ops.upsample2x_backward(d_up)
+        d_pool3, _ = chain_bwd(3, da)                      # bottleneck -> gradient of pool(x3)
+        da = ops.maxpool2x2_backward_add(x3, d_pool3, d_x3)
+        d_pool2, _ = chain_bwd(3, da)                      # down_block_3
+        da = ops.maxpool2x2_backward_add(x2, d_pool2, d_x2)
+        d_pool1, _ = chain_bwd(2, da)                      # down_block_2
+        da = ops.maxpool2x2_backward_add(x1, d_pool1, d_x1)
+        dx, _ = chain_bwd(2, da, first_needs_dx=ctx.need_dx)   # down_block_1
+        ctx.saved = None
+        if _backward_end_hook is not None:
+            _backward_end_hook()
+        out = [None, dx if ctx.need_dx else None]
+        out.extend(grads.get(id(p)) for p in net._train_params)
+        return tuple(out)
+
+
+def tracknet_forward_train(net, x):
+    params = [p for p in net.parameters()]
+    net._train_params = params
+    if not torch.is_grad_enabled() or not any(p.requires_grad for p in params):
+        # train-mode forward without autograd (e.g. under no_grad): still uses batch statistics / updates buffers
+        class _Ctx:
+            pass
+        return _TrackNetTrain.forward(_Ctx(), net, x, *params)
+    return _TrackNetTrain.apply(net, x, *params)
+
+
+def conv_bn_relu_train(blk, x):
+    raise NotImplementedError("Conv2DBlock is trained through TrackNet.forward (one autograd node for the whole network)")
+
+
+class _WBCELoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_pred, y, reduce):
+        y_pred, y = y_pred.contiguous(), y.contiguous()
+        out = ops.wbce_forward(y_pred, y, reduce)
+        ctx.save_for_backward(y_pred, y)
+        ctx.reduce = reduce
+        return out.reshape(()) if reduce else out
+
+    @staticmethod
+    def backward(ctx, g):
+        y_pred, y = ctx.saved_tensors
+        return ops.wbce_backward(y_pred, y, g.reshape(-1).contiguous().float(), ctx.reduce), None, None
+
+
+def wbce_loss(y_pred, y, reduce=True):
+    return _WBCELoss.apply(y_pred, y.to(y_pred.dtype), bool(reduce))
+
+
+def inpaintnet_forward_train(net, x, m):
+    raise NotImplementedError("InpaintNet training kernels are not built yet (round 2); inference is supported")

@@ -36,7 +36,9 @@ struct Conv3x3Args {
   const float* wpack;   // [Cin_pad][9][Cout], Cin_pad = roundup(C0+C1, CC), padding rows zero
   const float* scale;   // [Cout] or nullptr  -> y = acc*scale + shift   (eval-mode BN folded to an affine)
   const float* shift;   // [Cout] or nullptr
-  float* dst;           // [N][Cout][H][W]
+  float* dst;           // [N][Cout][H][W]   (or [N][csplit][H][W] when dst1 is set)
+  float* dst1;          // optional second destination for output channels >= csplit: [N][Cout-csplit][H][W]
+  int csplit;           //   (data gradient of a concat layer: d(up) and d(skip) land in separate tensors)
   int N, C0, C1, Cout, H, W;
   int up0;              // 1: src0 is stored at (H/2, W/2) and read as out[h][w] = src0[h>>1][w>>1]
   int relu;             // 1: y = max(y, 0)
@@ -251,7 +253,9 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
       const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       float sc = 1.0f, sh = 0.0f;
       if (has_affine) { sc = a.scale[co]; sh = a.shift[co]; }
-      float* drow = a.dst + ((size_t)n * Cout + co) * HW;
+      float* drow = (a.dst1 == nullptr || co < a.csplit)
+                        ? a.dst + ((size_t)n * (a.dst1 ? a.csplit : Cout) + co) * HW
+                        : a.dst1 + ((size_t)n * (Cout - a.csplit) + (co - a.csplit)) * HW;
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int oh = h0 + wn * (NTW / CS) + j / CS;

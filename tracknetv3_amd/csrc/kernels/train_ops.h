@@ -1,0 +1,358 @@
+// train_ops.h -- the HBM-bound kernels of one TrackNet training step (train.py:84-96):
+//   BatchNorm2d in training mode (model.py:9): batch statistics, running-stat update, normalise+ReLU, backward
+//   WBCELoss forward + closed-form backward (utils/metric.py:3-20)
+//   head (1x1 conv + sigmoid) backward, 2x2 max-pool backward (+ skip-gradient add), nearest-upsample backward,
+//   sample mixup (train.py:32-40).
+// All reductions are two-stage and deterministic: fixed-shape partials (fp64) written by the first kernel,
+// summed in a fixed order by a finalize kernel -- no atomics, no zero-initialised accumulators.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tnv3 {
+
+typedef float t_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRedSplit = 64;   // partial sums per channel / per sample
+
+// Sum `v` over the 256 threads of a workgroup; result valid in thread 0.
+__device__ __forceinline__ double block_sum_256(double v, double* red /* [4] LDS */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- BatchNorm (training) forward ------------------------------------------------------------------------------
+// partial[c][s] = (sum, sumsq) of z[:, c, :] over the s-th slice of the N*HW elements.  grid = (kRedSplit, C)
+__global__ void __launch_bounds__(256) bn_stats_partial_kernel(const float* __restrict__ z, double* __restrict__ partial,
+                                                               int N, int C, int HW) {
+  __shared__ double red[4];
+  const int c = blockIdx.y, s = blockIdx.x;
+  const int hw4 = HW >> 2;
+  const long total4 = (long)N * hw4;
+  double s1 = 0.0, s2 = 0.0;
+  for (long t = (long)s * 256 + threadIdx.x; t < total4; t += (long)kRedSplit * 256) {
+    const int n = (int)(t / hw4);
+    const int p = (int)(t - (long)n * hw4) << 2;
+    const t_f32x4 v = *reinterpret_cast<const t_f32x4*>(z + ((size_t)n * C + c) * HW + p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1 += (double)v[k]; s2 += (double)v[k] * (double)v[k]; }
+  }
+  const double a = block_sum_256(s1, red);
+  const double b = block_sum_256(s2, red);
+  if (threadIdx.x == 0) { partial[((size_t)c * kRedSplit + s) * 2] = a; partial[((size_t)c * kRedSplit + s) * 2 + 1] = b; }
+}
+
+// mean / biased var -> (scale, shift) for the normalise pass, saved (mean, invstd) for backward, running-stat update
+// with the UNBIASED variance.  One thread per channel.
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var, float eps, float momentum, long count,
+                                         float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                         float* __restrict__ save_invstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < kRedSplit; ++s) { s1 += partial[((size_t)c * kRedSplit + s) * 2]; s2 += partial[((size_t)c * kRedSplit + s) * 2 + 1]; }
+  const double n = (double)count;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * invstd;
+  scale[c] = (float)sc;
+  shift[c] = (float)((double)beta[c] - mean * sc);
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)invstd;
+  const double unbiased = count > 1 ? var * (n / (n - 1.0)) : var;
+  running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+  running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+}
+
+// a = max(z*scale[c] + shift[c], 0)
+__global__ void __launch_bounds__(256) bn_apply_relu_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ a,
+                                                            long NC, int C, int HW) {
+  const int hw4 = HW >> 2;
+  const long total4 = NC * hw4;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (long)gridDim.x * blockDim.x) {
+    const long nc = t / hw4;
+    const int c = (int)(nc % C);
+    const float sc = scale[c], sh = shift[c];
+    t_f32x4 v = *reinterpret_cast<const t_f32x4*>(z + t * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float y = fmaf(v[k], sc, sh); v[k] = y > 0.0f ? y : 0.0f; }
+    *reinterpret_cast<t_f32x4*>(a + t * 4) = v;
+  }
+}
+
+// ---- BatchNorm + ReLU backward ---------------------------------------------------------------------------------
+// g = dA * (a > 0);  partial[c][s] = (sum g, sum g*xhat), xhat = (z - mean) * invstd.      grid = (kRedSplit, C)
+__global__ void __launch_bounds__(256) bn_relu_bwd_partial_kernel(const float* __restrict__ dA, const float* __restrict__ a,
+                                                                  const float* __restrict__ z, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, double* __restrict__ partial,
+                                                                  int N, int C, int HW) {
+  __shared__ double red[4];
+  const int c = blockIdx.y, s = blockIdx.x;
+  const int hw4 = HW >> 2;
+  const long total4 = (long)N * hw4;
+  const float mu = mean[c], is = invstd[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (long t = (long)s * 256 + threadIdx.x; t < total4; t += (long)kRedSplit * 256) {
+    const int n = (int)(t / hw4);
+    const int p = (int)(t - (long)n * hw4) << 2;
+    const size_t off = ((size_t)n * C + c) * HW + p;
+    const t_f32x4 g = *reinterpret_cast<const t_f32x4*>(dA + off);
+    const t_f32x4 av = *reinterpret_cast<const t_f32x4*>(a + off);
+    const t_f32x4 zv = *reinterpret_cast<const t_f32x4*>(z + off);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = av[k] > 0.0f ? g[k] : 0.0f;
+      s1 += (double)gk;
+      s2 += (double)gk * (double)((zv[k] - mu) * is);
+    }
+  }
+  const double r1 = block_sum_256(s1, red);
+  const double r2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) { partial[((size_t)c * kRedSplit + s) * 2] = r1; partial[((size_t)c * kRedSplit + s) * 2 + 1] = r2; }
+}
+
+// dbeta = sum g, dgamma = sum g*xhat; coefficients of the apply pass:  dZ = k0*g - k1 - k2*xhat
+__global__ void bn_relu_bwd_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+                                            const float* __restrict__ invstd, long count, float* __restrict__ dgamma,
+                                            float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < kRedSplit; ++s) { s1 += partial[((size_t)c * kRedSplit + s) * 2]; s2 += partial[((size_t)c * kRedSplit + s) * 2 + 1]; }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  const double k0 = (double)gamma[c] * (double)invstd[c];
+  coef[c] = (float)k0;
+  coef[C + c] = (float)(k0 * s1 / (double)count);
+  coef[2 * C + c] = (float)(k0 * s2 / (double)count);
+}
+
+// dZ = k0*g - k1 - k2*xhat  (written over dA's buffer is allowed: dZ may alias dA)
+__global__ void __launch_bounds__(256) bn_relu_bwd_apply_kernel(const float* dA, const float* __restrict__ a,
+                                                                const float* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                                float* dZ, long NC, int C, int HW) {
+  const int hw4 = HW >> 2;
+  const long total4 = NC * hw4;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (long)gridDim.x * blockDim.x) {
+    const long nc = t / hw4;
+    const int c = (int)(nc % C);
+    const float mu = mean[c], is = invstd[c], k0 = coef[c], k1 = coef[C + c], k2 = coef[2 * C + c];
+    const t_f32x4 g = *reinterpret_cast<const t_f32x4*>(dA + t * 4);
+    const t_f32x4 av = *reinterpret_cast<const t_f32x4*>(a + t * 4);
+    const t_f32x4 zv = *reinterpret_cast<const t_f32x4*>(z + t * 4);
+    t_f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = av[k] > 0.0f ? g[k] : 0.0f;
+      o[k] = k0 * gk - k1 - k2 * ((zv[k] - mu) * is);
+    }
+    *reinterpret_cast<t_f32x4*>(dZ + t * 4) = o;
+  }
+}
+
+// ---- WBCE (utils/metric.py:15-20) -------------------------------------------------------------------------------
+__device__ __forceinline__ float wbce_elem(float p, float y) {
+  const float q = 1.0f - p;
+  const float pc = fminf(fmaxf(p, 1e-7f), 1.0f), qc = fminf(fmaxf(q, 1e-7f), 1.0f);
+  return -(q * q * y * logf(pc) + p * p * (1.0f - y) * logf(qc));
+}
+
+// partial[n][s] = sum of the element losses of sample n over slice s.     grid = (kRedSplit, N)
+__global__ void __launch_bounds__(256) wbce_partial_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                           double* __restrict__ partial, long per_sample) {
+  __shared__ double red[4];
+  const int n = blockIdx.y, s = blockIdx.x;
+  const float* pp = p + (size_t)n * per_sample;
+  const float* yy = y + (size_t)n * per_sample;
+  double acc = 0.0;
+  for (long t = (long)s * 256 + threadIdx.x; t < per_sample; t += (long)kRedSplit * 256) acc += (double)wbce_elem(pp[t], yy[t]);
+  const double r = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)n * kRedSplit + s] = r;
+}
+
+// reduce != 0: out[0] = mean over everything; else out[n] = per-sample mean   (utils/metric.py:17-20)
+__global__ void wbce_finalize_kernel(const double* __restrict__ partial, float* __restrict__ out, int N, long per_sample, int reduce) {
+  if (reduce) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      double t = 0.0;
+      for (int n = 0; n < N; ++n) for (int s = 0; s < kRedSplit; ++s) t += partial[(size_t)n * kRedSplit + s];
+      out[0] = (float)(t / ((double)N * (double)per_sample));
+    }
+  } else {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) {
+      double t = 0.0;
+      for (int s = 0; s < kRedSplit; ++s) t += partial[(size_t)n * kRedSplit + s];
+      out[n] = (float)(t / (double)per_sample);
+    }
+  }
+}
+
+// dL/dp = upstream[n or 0] * d(elem)/dp / denom      (closed form; clamp gradient is 0 outside [1e-7, 1])
+__global__ void __launch_bounds__(256) wbce_backward_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                            const float* __restrict__ upstream, int upstream_per_sample,
+                                                            float inv_denom, float* __restrict__ dp, long per_sample, long total) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const float pv = p[t], yv = y[t];
+    const float q = 1.0f - pv;
+    const float pc = fminf(fmaxf(pv, 1e-7f), 1.0f), qc = fminf(fmaxf(q, 1e-7f), 1.0f);
+    const float in_p = (pv >= 1e-7f && pv <= 1.0f) ? 1.0f : 0.0f;
+    const float in_q = (q >= 1e-7f && q <= 1.0f) ? 1.0f : 0.0f;
+    const float g = -(-2.0f * q * yv * logf(pc) + q * q * yv * in_p / pc + 2.0f * pv * (1.0f - yv) * logf(qc) - pv * pv * (1.0f - yv) * in_q / qc);
+    const float up = upstream[upstream_per_sample ? (int)(t / per_sample) : 0];
+    dp[t] = g * up * inv_denom;
+  }
+}
+
+// ---- head backward: p = sigmoid(W a + b) ------------------------------------------------------------------------
+// dz = dP * p * (1-p);  dA[c] = sum_l W[l][c] dz[l];  dW[l][c] = sum dz[l]*a[c];  db[l] = sum dz[l]
+// One workgroup walks pixel tiles of P = 128; partial dW/db per workgroup -> finalize.   L <= 16, C == 64.
+constexpr int kHeadP = 128, kHeadC = 64, kHeadLMax = 16;
+__global__ void __launch_bounds__(256) head_backward_kernel(const float* __restrict__ dP, const float* __restrict__ p,
+                                                            const float* __restrict__ a, const float* __restrict__ w,
+                                                            float* __restrict__ dA, float* __restrict__ part /* [grid][L*C + L] */,
+                                                            int N, int L, int HW) {
+  __shared__ float dz_s[kHeadLMax * kHeadP];
+  __shared__ float a_s[kHeadC * (kHeadP + 1)];
+  __shared__ float w_s[kHeadLMax * kHeadC];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < L * kHeadC; i += 256) w_s[i] = w[i];
+  const int tilesPer = (HW + kHeadP - 1) / kHeadP;
+  const long nTiles = (long)N * tilesPer;
+  const int c_own = tid & 63, lq = tid >> 6;           // dW ownership: channel c_own, outputs l = lq, lq+4, ...
+  float accW[kHeadLMax / 4];
+#pragma unroll
+  for (int k = 0; k < kHeadLMax / 4; ++k) accW[k] = 0.0f;
+  float accB = 0.0f;                                     // thread tid < L owns db[tid]
+  for (long tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    const int n = (int)(tile / tilesPer);
+    const int p0 = (int)(tile - (long)n * tilesPer) * kHeadP;
+    __syncthreads();
+    for (int i = tid; i < L * kHeadP; i += 256) {
+      const int l = i / kHeadP, px = i - l * kHeadP;
+      float v = 0.0f;
+      if (p0 + px < HW) { const size_t o = ((size_t)n * L + l) * HW + p0 + px; const float pv = p[o]; v = dP[o] * pv * (1.0f - pv); }
+      dz_s[i] = v;
+    }
+    for (int i = tid; i < kHeadC * kHeadP; i += 256) {
+      const int c = i / kHeadP, px = i - c * kHeadP;
+      a_s[c * (kHeadP + 1) + px] = (p0 + px < HW) ? a[((size_t)n * kHeadC + c) * HW + p0 + px] : 0.0f;
+    }
+    __syncthreads();
+    // dA: thread -> pixel px = tid % 128, channels c = (tid/128) + 2k
+    {
+      const int px = tid & (kHeadP - 1);
+      if (p0 + px < HW) {
+        for (int c = tid >> 7; c < kHeadC; c += 2) {
+          float s = 0.0f;
+          for (int l = 0; l < L; ++l) s = fmaf(w_s[l * kHeadC + c], dz_s[l * kHeadP + px], s);
+          dA[((size_t)n * kHeadC + c) * HW + p0 + px] = s;
+        }
+      }
+    }
+    // dW / db partials
+#pragma unroll
+    for (int k = 0; k < kHeadLMax / 4; ++k) {
+      const int l = lq + 4 * k;
+      if (l < L) {
+        float s = accW[k];
+        for (int px = 0; px < kHeadP; ++px) s = fmaf(dz_s[l * kHeadP + px], a_s[c_own * (kHeadP + 1) + px], s);
+        accW[k] = s;
+      }
+    }
+    if (tid < L) { float s = accB; for (int px = 0; px < kHeadP; ++px) s += dz_s[tid * kHeadP + px]; accB = s; }
+  }
+  float* out = part + (size_t)blockIdx.x * (L * kHeadC + L);
+#pragma unroll
+  for (int k = 0; k < kHeadLMax / 4; ++k) { const int l = lq + 4 * k; if (l < L) out[l * kHeadC + c_own] = accW[k]; }
+  if (tid < L) out[L * kHeadC + tid] = accB;
+}
+
+// out[i] = sum_b part[b][i] in fixed order (double accumulate).  Used for head dW/db and the wgrad split-K slabs.
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nparts) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < nparts; ++b) s += (double)part[(size_t)b * n + i];
+    out[i] = (float)s;
+  }
+}
+
+// out[i] = sum_b part[b*stride + offset + i]  (fixed order, double accumulate)
+__global__ void __launch_bounds__(256) sum_partials_strided_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+                                                                   int nparts, long stride, long offset) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < nparts; ++b) s += (double)part[(size_t)b * stride + offset + i];
+    out[i] = (float)s;
+  }
+}
+
+// ---- pooling / upsampling backward ------------------------------------------------------------------------------
+// dx = dskip + route(dpool): the FIRST maximum of each 2x2 window (row-major, strict '>') receives the pooled gradient.
+__global__ void __launch_bounds__(256) maxpool2x2_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dpool,
+                                                                 const float* __restrict__ dskip, float* __restrict__ dx,
+                                                                 long NC, int H, int W) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long total = NC * Ho * Wo;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ow = (int)(t % Wo);
+    const long u = t / Wo;
+    const int oh = (int)(u % Ho);
+    const long nc = u / Ho;
+    const size_t i00 = ((size_t)nc * H + 2 * oh) * W + 2 * ow;
+    const float v0 = x[i00], v1 = x[i00 + 1], v2 = x[i00 + W], v3 = x[i00 + W + 1];
+    int am = 0; float m = v0;
+    if (v1 > m || v1 != v1) { m = v1; am = 1; }
+    if (v2 > m || v2 != v2) { m = v2; am = 2; }
+    if (v3 > m || v3 != v3) { m = v3; am = 3; }
+    const float g = dpool[t];
+    const bool has = dskip != nullptr;
+    dx[i00] = (has ? dskip[i00] : 0.0f) + (am == 0 ? g : 0.0f);
+    dx[i00 + 1] = (has ? dskip[i00 + 1] : 0.0f) + (am == 1 ? g : 0.0f);
+    dx[i00 + W] = (has ? dskip[i00 + W] : 0.0f) + (am == 2 ? g : 0.0f);
+    dx[i00 + W + 1] = (has ? dskip[i00 + W + 1] : 0.0f) + (am == 3 ? g : 0.0f);
+  }
+}
+
+// nearest 2x upsample backward: d_lo[h][w] = sum of the 2x2 block of d_hi
+__global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __restrict__ d_hi, float* __restrict__ d_lo,
+                                                             long NC, int Hl, int Wl) {
+  const long total = NC * Hl * Wl;
+  const int Wh = 2 * Wl;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(t % Wl);
+    const long u = t / Wl;
+    const int h = (int)(u % Hl);
+    const long nc = u / Hl;
+    const size_t i = ((size_t)nc * 2 * Hl + 2 * h) * Wh + 2 * w;
+    d_lo[t] = (d_hi[i] + d_hi[i + 1]) + (d_hi[i + Wh] + d_hi[i + Wh + 1]);
+  }
+}
+
+// ---- mixup (train.py:32-40): out[n] = x[n]*lam[n] + x[perm[n]]*(1-lam[n]) -----------------------------------------
+__global__ void __launch_bounds__(256) mixup_kernel(const float* __restrict__ x, const float* __restrict__ lam,
+                                                    const int* __restrict__ perm, float* __restrict__ out, int N, long per_sample) {
+  const long per4 = per_sample >> 2;
+  const long total4 = (long)N * per4;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(t / per4);
+    const long o = (t - (long)n * per4) << 2;
+    const float l = lam[n];
+    const t_f32x4 a = *reinterpret_cast<const t_f32x4*>(x + (size_t)n * per_sample + o);
+    const t_f32x4 b = *reinterpret_cast<const t_f32x4*>(x + (size_t)perm[n] * per_sample + o);
+    *reinterpret_cast<t_f32x4*>(out + (size_t)n * per_sample + o) = a * l + b * (1.0f - l);
+  }
+}
+
+}  // namespace tnv3

@@ -8,6 +8,9 @@
 #include "kernels/conv3x3_mfma.h"
 #include "kernels/conv1d_k3.h"
 #include "kernels/pointwise.h"
+#include "kernels/postproc.h"
+#include "kernels/train_ops.h"
+#include "kernels/wgrad3x3_mfma.h"
 
 namespace tnv3 {
 
@@ -69,7 +72,7 @@ int launch_conv_cfg(Launcher& L, const Conv3x3Args& a) {
 template <class Launcher>
 int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, const float* wpack, const float* scale,
                          const float* shift, float* dst, int n, int c0, int c1, int cout, int h, int w, int up0,
-                         int relu, int cfg) {
+                         int relu, int cfg, float* dst1 = nullptr, int csplit = 0) {
   if (!src0 || !wpack || !dst) TNV3_FAIL(-1, "conv3x3: null pointer");
   if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "conv3x3: non-positive dimension");
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3: src1 / c1 mismatch");
@@ -79,7 +82,8 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
   if (c1 > 0 && (c0 % 32)) TNV3_FAIL(-1, "conv3x3: two-source input needs C0 %% 32 == 0 (got %d)", c0);
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3: upsampled source needs even H,W");
   if (cfg < 0) cfg = conv_auto_config(n, cout, h, w);
-  Conv3x3Args a{src0, src1, wpack, scale, shift, dst, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0};
+  if (dst1 && (csplit <= 0 || csplit >= cout)) TNV3_FAIL(-1, "conv3x3: bad output split %d of %d", csplit, cout);
+  Conv3x3Args a{src0, src1, wpack, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0};
   switch (cfg) {
     case 0: return launch_conv_cfg<ConvC0>(L, a);
     case 1: return launch_conv_cfg<ConvC1>(L, a);
@@ -144,6 +148,202 @@ int conv1d_k3_impl(Launcher& L, const float* src0, const float* src1, const floa
   const long gx = (n + S - 1) / S;
   if (gx > 0x7fffffffl) TNV3_FAIL(-1, "conv1d_k3: batch too large");
   return L.launch3(conv1d_k3_kernel<S, COB, CK, LT>, (int)gx, (cout + COB - 1) / COB, (l + LT - 1) / LT, S * COB, a);
+}
+
+template <class Launcher>
+int ensemble_frames_impl(Launcher& L, const float* win, int n_local, long s_base, int l, int e, const float* weight, long t0,
+                         int n_frames, long num_sample, float* out) {
+  if (!win || !weight || !out || n_local <= 0 || l <= 0 || e <= 0 || n_frames <= 0 || num_sample <= 0)
+    TNV3_FAIL(-1, "ensemble_frames: bad argument");
+  for (long t = t0; t < t0 + n_frames; t += (n_frames > 1 ? n_frames - 1 : 1)) {   // first and last frame bound the need
+    const long lo = t - l + 1 > 0 ? t - l + 1 : 0, hi = t < num_sample - 1 ? t : num_sample - 1;
+    if (lo <= hi && (lo < s_base || hi >= s_base + n_local))
+      TNV3_FAIL(-1, "ensemble_frames: frame %ld needs windows [%ld,%ld] but [%ld,%ld) are resident", t, lo, hi, s_base, s_base + n_local);
+  }
+  const long total = (long)n_frames * e;
+  const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  return L.launch(ensemble_frames_kernel, grid, 256, win, n_local, s_base, l, e, weight, t0, n_frames, num_sample, out);
+}
+
+inline size_t peakfind_workspace_bytes(int frames, int h, int w) {
+  if (frames <= 0 || h <= 0 || w <= 0) return 0;
+  const size_t hw = (size_t)h * w;
+  return (size_t)((frames + 7) / 8) * 8 * sizeof(unsigned long long) + (size_t)frames * 5 * hw * sizeof(int);
+}
+
+template <class Launcher>
+int heatmap_peakfind_impl(Launcher& L, const float* heat, float thr, int tie_last_wins, int32_t* out_bbox, void* ws,
+                          size_t ws_bytes, int frames, int h, int w) {
+  if (!heat || !out_bbox || !ws || frames <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "heatmap_peakfind: bad argument");
+  if ((long)h * w >= (1l << 31) - 2) TNV3_FAIL(-1, "heatmap_peakfind: map too large");
+  if (frames > 65535) TNV3_FAIL(-1, "heatmap_peakfind: at most 65535 maps per call");
+  if (ws_bytes < peakfind_workspace_bytes(frames, h, w)) TNV3_FAIL(-1, "heatmap_peakfind: workspace too small");
+  if (((uintptr_t)ws) & 7) TNV3_FAIL(-1, "heatmap_peakfind: workspace must be 8-byte aligned");
+  const size_t hw = (size_t)h * w;
+  unsigned long long* best = (unsigned long long*)ws;
+  int* label = (int*)(best + ((frames + 7) / 8) * 8);
+  int* box = label + (size_t)frames * hw;
+  const int gx = (int)((hw + 255) / 256 > 1024 ? 1024 : (hw + 255) / 256);
+  int rc;
+  if ((rc = L.launch3(ccl_init_kernel, gx, frames, 1, 256, heat, thr, label, box, best, h, w))) return rc;
+  if ((rc = L.launch3(ccl_merge_kernel, gx, frames, 1, 256, label, h, w))) return rc;
+  if ((rc = L.launch3(ccl_box_kernel, gx, frames, 1, 256, label, box, h, w))) return rc;
+  if ((rc = L.launch3(ccl_select_kernel, gx, frames, 1, 256, (const int*)label, (const int*)box, best, h, w, tie_last_wins ? 1 : 0))) return rc;
+  return L.launch(ccl_emit_kernel, (frames + 63) / 64, 64, (const int*)box, (const unsigned long long*)best, (int*)out_bbox, frames, h, w,
+                  tie_last_wins ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------ training entry points
+inline int grid_for(long items, int per_block = 256, int cap = 65536) {
+  const long g = (items + per_block - 1) / per_block;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+inline size_t bn_workspace_bytes(int c) { return c <= 0 ? 0 : (size_t)c * kRedSplit * 2 * sizeof(double) + (size_t)c * 3 * sizeof(float); }
+
+template <class Launcher>
+int bn_train_forward_impl(Launcher& L, const float* z, const float* gamma, const float* beta, float* rm, float* rv, float eps,
+                          float momentum, float* a, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, int n,
+                          int c, int hw) {
+  if (!z || !gamma || !beta || !rm || !rv || !a || !save_mean || !save_invstd || !ws || n <= 0 || c <= 0 || hw <= 0)
+    TNV3_FAIL(-1, "bn_train_forward: bad argument");
+  if (hw % 4) TNV3_FAIL(-1, "bn_train_forward: H*W must be a multiple of 4");
+  if (ws_bytes < bn_workspace_bytes(c) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "bn_train_forward: workspace too small / misaligned");
+  double* partial = (double*)ws;
+  float* scale = (float*)(partial + (size_t)c * kRedSplit * 2);
+  float* shift = scale + c;
+  int rc;
+  if ((rc = L.launch3(bn_stats_partial_kernel, kRedSplit, c, 1, 256, z, partial, n, c, hw))) return rc;
+  if ((rc = L.launch(bn_stats_finalize_kernel, (c + 63) / 64, 64, (const double*)partial, gamma, beta, rm, rv, eps, momentum,
+                     (long)n * hw, scale, shift, save_mean, save_invstd, c))) return rc;
+  return L.launch(bn_apply_relu_kernel, grid_for((long)n * c * (hw / 4)), 256, z, (const float*)scale, (const float*)shift, a,
+                  (long)n * c, c, hw);
+}
+
+template <class Launcher>
+int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const float* z, const float* gamma, const float* mean,
+                          const float* invstd, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int n, int c,
+                          int hw) {
+  if (!da || !a || !z || !gamma || !mean || !invstd || !dz || !dgamma || !dbeta || !ws || n <= 0 || c <= 0 || hw <= 0)
+    TNV3_FAIL(-1, "bn_relu_backward: bad argument");
+  if (hw % 4) TNV3_FAIL(-1, "bn_relu_backward: H*W must be a multiple of 4");
+  if (ws_bytes < bn_workspace_bytes(c) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "bn_relu_backward: workspace too small / misaligned");
+  double* partial = (double*)ws;
+  float* coef = (float*)(partial + (size_t)c * kRedSplit * 2);
+  int rc;
+  if ((rc = L.launch3(bn_relu_bwd_partial_kernel, kRedSplit, c, 1, 256, da, a, z, mean, invstd, partial, n, c, hw))) return rc;
+  if ((rc = L.launch(bn_relu_bwd_finalize_kernel, (c + 63) / 64, 64, (const double*)partial, gamma, invstd, (long)n * hw, dgamma,
+                     dbeta, coef, c))) return rc;
+  return L.launch(bn_relu_bwd_apply_kernel, grid_for((long)n * c * (hw / 4)), 256, da, a, z, mean, invstd, (const float*)coef, dz,
+                  (long)n * c, c, hw);
+}
+
+template <class Launcher>
+int conv3x3_dgrad_impl(Launcher& L, const float* dz, const float* wpack_t, float* dx0, float* dx1, int n, int cout, int c0,
+                       int c1, int h, int w, int cfg) {
+  if (c1 < 0 || (c1 > 0) != (dx1 != nullptr)) TNV3_FAIL(-1, "conv3x3_dgrad: dx1 / c1 mismatch");
+  return conv3x3_forward_impl(L, dz, (const float*)nullptr, wpack_t, (const float*)nullptr, (const float*)nullptr, dx0, n, cout,
+                              0, c0 + c1, h, w, 0, 0, cfg, dx1, c1 > 0 ? c0 : 0);
+}
+
+using WgradA = WgradCfg<4, 1>;   // 128 co x 32 ci per workgroup
+using WgradB = WgradCfg<2, 2>;   //  64 co x 64 ci per workgroup
+
+struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
+inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
+  WgradPlan p;
+  p.use_b = (cout % 128) != 0;
+  const int MB = p.use_b ? WgradB::MB : WgradA::MB, CB = p.use_b ? WgradB::CB : WgradA::CB;
+  p.nMB = (cout + MB - 1) / MB;
+  p.nCB = (cin + CB - 1) / CB;
+  p.nTiles = n * ((h + 1) / 2) * ((w + 31) / 32);
+  int sk = (2048 + p.nMB * p.nCB - 1) / (p.nMB * p.nCB);          // ~2048 workgroups: 4 per CU x 2 resident
+  const int max_by_work = (p.nTiles + 7) / 8;                       // at least ~8 pixel tiles per workgroup
+  if (sk > max_by_work) sk = max_by_work;
+  if (sk < 1) sk = 1;
+  if (sk > 4096) sk = 4096;
+  p.splitK = sk;
+  return p;
+}
+inline size_t wgrad_workspace_bytes(int n, int c0, int c1, int cout, int h, int w) {
+  if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+  const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
+  return (size_t)p.splitK * cout * (c0 + c1) * 9 * sizeof(float);
+}
+
+template <class Launcher>
+int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const float* dz, float* dw, void* ws, size_t ws_bytes,
+                       int n, int c0, int c1, int cout, int h, int w, int up0) {
+  if (!src0 || !dz || !dw || !ws || n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "conv3x3_wgrad: bad argument");
+  if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3_wgrad: src1 / c1 mismatch");
+  if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3_wgrad: upsampled source needs even H,W");
+  if (ws_bytes < wgrad_workspace_bytes(n, c0, c1, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad: workspace too small");
+  const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
+  WgradArgs a{src0, src1, dz, (float*)ws, n, c0, c1, cout, h, w, up0 ? 1 : 0, p.splitK};
+  const int grid = p.nMB * p.nCB * p.splitK;
+  int rc = p.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB>, grid, WgradB::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA>, grid, WgradA::NT, a);
+  if (rc) return rc;
+  const long nel = (long)cout * (c0 + c1) * 9;
+  return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)ws, dw, nel, p.splitK);
+}
+
+inline size_t wbce_workspace_bytes(int n) { return n <= 0 ? 0 : (size_t)n * kRedSplit * sizeof(double); }
+
+template <class Launcher>
+int wbce_forward_impl(Launcher& L, const float* p, const float* y, float* out, void* ws, size_t ws_bytes, int n, long per_sample,
+                      int reduce) {
+  if (!p || !y || !out || !ws || n <= 0 || per_sample <= 0 || n > 65535) TNV3_FAIL(-1, "wbce_forward: bad argument");
+  if (ws_bytes < wbce_workspace_bytes(n) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "wbce_forward: workspace too small / misaligned");
+  int rc;
+  if ((rc = L.launch3(wbce_partial_kernel, kRedSplit, n, 1, 256, p, y, (double*)ws, per_sample))) return rc;
+  return L.launch(wbce_finalize_kernel, reduce ? 1 : (n + 63) / 64, 64, (const double*)ws, out, n, per_sample, reduce ? 1 : 0);
+}
+
+template <class Launcher>
+int wbce_backward_impl(Launcher& L, const float* p, const float* y, const float* upstream, float* dp, int n, long per_sample,
+                       int reduce) {
+  if (!p || !y || !upstream || !dp || n <= 0 || per_sample <= 0) TNV3_FAIL(-1, "wbce_backward: bad argument");
+  const long total = (long)n * per_sample;
+  const float inv = reduce ? (float)(1.0 / ((double)n * (double)per_sample)) : (float)(1.0 / (double)per_sample);
+  return L.launch(wbce_backward_kernel, grid_for(total), 256, p, y, upstream, reduce ? 0 : 1, inv, dp, per_sample, total);
+}
+
+constexpr int kHeadGrid = 1024;
+inline size_t head_backward_workspace_bytes(int l) { return l <= 0 ? 0 : (size_t)kHeadGrid * (l * kHeadC + l) * sizeof(float); }
+
+template <class Launcher>
+int head_backward_impl(Launcher& L, const float* dp, const float* p, const float* a, const float* w, float* da, float* dw, float* db,
+                       void* ws, size_t ws_bytes, int n, int l, int hw) {
+  if (!dp || !p || !a || !w || !da || !dw || !db || !ws || n <= 0 || l <= 0 || hw <= 0) TNV3_FAIL(-1, "head_backward: bad argument");
+  if (l > kHeadLMax) TNV3_FAIL(-1, "head_backward: at most %d output maps", kHeadLMax);
+  if (ws_bytes < head_backward_workspace_bytes(l)) TNV3_FAIL(-1, "head_backward: workspace too small");
+  const long nTiles = (long)n * ((hw + kHeadP - 1) / kHeadP);
+  const int grid = (int)(nTiles < kHeadGrid ? nTiles : kHeadGrid);
+  int rc;
+  if ((rc = L.launch(head_backward_kernel, grid, 256, dp, p, a, w, da, (float*)ws, n, l, hw))) return rc;
+  // partial layout per workgroup: [L*64 dW | L db]; dW and db are contiguous slices of one reduction
+  const long nel = (long)l * kHeadC + l;
+  // reduce into a temporary tail of the workspace is avoided: sum directly into dw / db with two launches
+  if ((rc = L.launch(sum_partials_strided_kernel, grid_for((long)l * kHeadC, 256, 64), 256, (const float*)ws, dw, (long)l * kHeadC, grid, nel, 0l))) return rc;
+  return L.launch(sum_partials_strided_kernel, 1, 64, (const float*)ws, db, (long)l, grid, nel, (long)l * kHeadC);
+}
+
+template <class Launcher>
+int maxpool2x2_backward_add_impl(Launcher& L, const float* x, const float* dpool, const float* dskip, float* dx, long nc, int h, int w) {
+  if (!x || !dpool || !dx || nc <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1)) TNV3_FAIL(-1, "maxpool2x2_backward_add: bad argument");
+  return L.launch(maxpool2x2_bwd_add_kernel, grid_for(nc * (h / 2) * (w / 2)), 256, x, dpool, dskip, dx, nc, h, w);
+}
+
+template <class Launcher>
+int upsample2x_backward_impl(Launcher& L, const float* d_hi, float* d_lo, long nc, int hl, int wl) {
+  if (!d_hi || !d_lo || nc <= 0 || hl <= 0 || wl <= 0) TNV3_FAIL(-1, "upsample2x_backward: bad argument");
+  return L.launch(upsample2x_bwd_kernel, grid_for(nc * hl * wl), 256, d_hi, d_lo, nc, hl, wl);
+}
+
+template <class Launcher>
+int mixup_impl(Launcher& L, const float* x, const float* lam, const int32_t* perm, float* out, int n, long per_sample) {
+  if (!x || !lam || !perm || !out || n <= 0 || per_sample <= 0 || (per_sample % 4)) TNV3_FAIL(-1, "mixup: bad argument");
+  return L.launch(mixup_kernel, grid_for((long)n * (per_sample / 4)), 256, x, lam, (const int*)perm, out, n, per_sample);
 }
 
 }  // namespace tnv3

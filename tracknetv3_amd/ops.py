@@ -127,3 +127,184 @@ def conv1d_k3(src0, weight, bias, src1=None, src_nlc=False, dst_nlc=False, act=A
                                           n, c0, c1, cout, l, int(bool(src_nlc)), int(bool(dst_nlc)), int(act),
                                           _lib.stream_ptr(src0)))
     return out
+
+
+def ensemble_frames(win, s_base, weight, t0, n_frames, num_sample):
+    """Temporal ensemble of global frames t0..t0+n_frames-1 from resident windows win[i] = window s_base+i.
+    win: (n_local, L, *tail) -> out: (n_frames, *tail).  See tnv3_ensemble_frames."""
+    lib = _lib.load()
+    _f32(win, weight)
+    _lib.dev_check(win, weight)
+    n_local, l = int(win.shape[0]), int(win.shape[1])
+    tail = tuple(win.shape[2:])
+    e = 1
+    for v in tail:
+        e *= int(v)
+    out = torch.empty((n_frames,) + tail, dtype=torch.float32, device=win.device)
+    _lib.check(lib.tnv3_ensemble_frames(_lib.ptr(win), n_local, int(s_base), l, e, _lib.ptr(weight), int(t0), int(n_frames),
+                                        int(num_sample), _lib.ptr(out), _lib.stream_ptr(win)))
+    return out
+
+
+def heatmap_peakfind(heat, threshold=0.5, tie_last_wins=True):
+    """(frames, H, W) fp32 heat maps -> (frames, 4) int32 boxes (x, y, w, h); zeros for an empty map."""
+    lib = _lib.load()
+    _f32(heat)
+    _lib.dev_check(heat)
+    if heat.dim() != 3:
+        raise _lib.Tnv3Error("heatmap_peakfind: expected (frames, H, W)")
+    frames, h, w = (int(v) for v in heat.shape)
+    out = torch.empty((frames, 4), dtype=torch.int32, device=heat.device)
+    step = 4096
+    for f0 in range(0, frames, step):
+        nf = min(step, frames - f0)
+        nbytes = lib.tnv3_peakfind_workspace_bytes(nf, h, w)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=heat.device)
+        _lib.check(lib.tnv3_heatmap_peakfind(_lib.ptr(heat[f0:f0 + nf]), float(threshold), int(bool(tie_last_wins)),
+                                             _lib.ptr(out[f0:f0 + nf]), _lib.ptr(ws), ws.numel() * 8, nf, h, w,
+                                             _lib.stream_ptr(heat)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- training ops
+def _workspace(nbytes, device):
+    return torch.empty((int(nbytes) + 7) // 8, dtype=torch.int64, device=device)
+
+
+def bn_train_forward(z, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=0.1):
+    """Training-mode BatchNorm2d + ReLU on the raw conv output; updates running stats in place.
+    Returns (a, save_mean, save_invstd)."""
+    lib = _lib.load()
+    _f32(z, gamma, beta, running_mean, running_var)
+    _lib.dev_check(z, gamma, beta, running_mean, running_var)
+    n, c, h, w = (int(v) for v in z.shape)
+    a = torch.empty_like(z)
+    mean = torch.empty(c, dtype=torch.float32, device=z.device)
+    invstd = torch.empty_like(mean)
+    ws = _workspace(lib.tnv3_bn_workspace_bytes(c), z.device)
+    _lib.check(lib.tnv3_bn_train_forward(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                         _lib.ptr(running_var), float(eps), float(momentum), _lib.ptr(a), _lib.ptr(mean),
+                                         _lib.ptr(invstd), _lib.ptr(ws), ws.numel() * 8, n, c, h * w, _lib.stream_ptr(z)))
+    return a, mean, invstd
+
+
+def bn_relu_backward(da, a, z, gamma, mean, invstd, inplace=True):
+    """Returns (dz, dgamma, dbeta); dz overwrites da when inplace."""
+    lib = _lib.load()
+    _f32(da, a, z, gamma, mean, invstd)
+    _lib.dev_check(da, a, z, gamma, mean, invstd)
+    n, c, h, w = (int(v) for v in z.shape)
+    dz = da if inplace else torch.empty_like(da)
+    dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _workspace(lib.tnv3_bn_workspace_bytes(c), z.device)
+    _lib.check(lib.tnv3_bn_relu_backward(_lib.ptr(da), _lib.ptr(a), _lib.ptr(z), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(invstd),
+                                         _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel() * 8, n, c,
+                                         h * w, _lib.stream_ptr(z)))
+    return dz, dgamma, dbeta
+
+
+def conv3x3_dgrad(dz, wpack_t, c0, c1=0, cfg=-1):
+    """dX = conv3x3(dZ, W^T flipped); returns (dx0 [N,c0,H,W], dx1 [N,c1,H,W] or None)."""
+    lib = _lib.load()
+    _f32(dz, wpack_t)
+    _lib.dev_check(dz, wpack_t)
+    n, cout, h, w = (int(v) for v in dz.shape)
+    if wpack_t.numel() != lib.tnv3_conv3x3_packed_floats(cout, c0 + c1, 1):
+        raise _lib.Tnv3Error("conv3x3_dgrad: packed (transposed) filter has the wrong size")
+    dx0 = torch.empty((n, c0, h, w), dtype=torch.float32, device=dz.device)
+    dx1 = torch.empty((n, c1, h, w), dtype=torch.float32, device=dz.device) if c1 else None
+    _lib.check(lib.tnv3_conv3x3_dgrad(_lib.ptr(dz), _lib.ptr(wpack_t), _lib.ptr(dx0), _lib.ptr(dx1), n, cout, c0, c1, h, w,
+                                      int(cfg), _lib.stream_ptr(dz)))
+    return dx0, dx1
+
+
+def conv3x3_wgrad(src0, dz, src1=None, up0=False):
+    """dW[Cout][C0+C1][3][3] for X = cat([up2x?(src0), src1], 1)."""
+    lib = _lib.load()
+    _f32(src0, src1, dz)
+    _lib.dev_check(src0, src1, dz)
+    n, cout, h, w = (int(v) for v in dz.shape)
+    c0 = int(src0.shape[1])
+    c1 = int(src1.shape[1]) if src1 is not None else 0
+    dw = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dz.device)
+    ws = _workspace(lib.tnv3_conv3x3_wgrad_workspace_bytes(n, c0, c1, cout, h, w), dz.device)
+    _lib.check(lib.tnv3_conv3x3_wgrad(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8,
+                                      n, c0, c1, cout, h, w, int(bool(up0)), _lib.stream_ptr(dz)))
+    return dw
+
+
+def wbce_forward(p, y, reduce=True):
+    lib = _lib.load()
+    _f32(p, y)
+    _lib.dev_check(p, y)
+    n = int(p.shape[0])
+    per = p.numel() // n
+    out = torch.empty(1 if reduce else n, dtype=torch.float32, device=p.device)
+    ws = _workspace(lib.tnv3_wbce_workspace_bytes(n), p.device)
+    _lib.check(lib.tnv3_wbce_forward(_lib.ptr(p), _lib.ptr(y), _lib.ptr(out), _lib.ptr(ws), ws.numel() * 8, n, per,
+                                     int(bool(reduce)), _lib.stream_ptr(p)))
+    return out
+
+
+def wbce_backward(p, y, upstream, reduce=True):
+    lib = _lib.load()
+    _f32(p, y, upstream)
+    _lib.dev_check(p, y, upstream)
+    n = int(p.shape[0])
+    per = p.numel() // n
+    dp = torch.empty_like(p)
+    _lib.check(lib.tnv3_wbce_backward(_lib.ptr(p), _lib.ptr(y), _lib.ptr(upstream), _lib.ptr(dp), n, per, int(bool(reduce)),
+                                      _lib.stream_ptr(p)))
+    return dp
+
+
+def head_backward(dp, p, a, weight):
+    """Backward of p = sigmoid(conv1x1(a) + b): returns (da, dW (L,64,1,1), db (L,))."""
+    lib = _lib.load()
+    _f32(dp, p, a, weight)
+    _lib.dev_check(dp, p, a, weight)
+    n, l, h, w = (int(v) for v in p.shape)
+    if int(a.shape[1]) != 64:
+        raise _lib.Tnv3Error("head_backward: expects 64 input channels")
+    da = torch.empty_like(a)
+    dw = torch.empty((l, 64, 1, 1), dtype=torch.float32, device=p.device)
+    db = torch.empty(l, dtype=torch.float32, device=p.device)
+    ws = _workspace(lib.tnv3_head_backward_workspace_bytes(l), p.device)
+    _lib.check(lib.tnv3_head_backward(_lib.ptr(dp), _lib.ptr(p), _lib.ptr(a), _lib.ptr(weight), _lib.ptr(da), _lib.ptr(dw),
+                                      _lib.ptr(db), _lib.ptr(ws), ws.numel() * 8, n, l, h * w, _lib.stream_ptr(p)))
+    return da, dw, db
+
+
+def maxpool2x2_backward_add(x, dpool, dskip=None):
+    lib = _lib.load()
+    _f32(x, dpool, dskip)
+    _lib.dev_check(x, dpool, dskip)
+    n, c, h, w = (int(v) for v in x.shape)
+    dx = torch.empty_like(x)
+    _lib.check(lib.tnv3_maxpool2x2_backward_add(_lib.ptr(x), _lib.ptr(dpool), _lib.ptr(dskip), _lib.ptr(dx), n * c, h, w,
+                                                _lib.stream_ptr(x)))
+    return dx
+
+
+def upsample2x_backward(d_hi):
+    lib = _lib.load()
+    _f32(d_hi)
+    _lib.dev_check(d_hi)
+    n, c, h, w = (int(v) for v in d_hi.shape)
+    d_lo = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=d_hi.device)
+    _lib.check(lib.tnv3_upsample2x_backward(_lib.ptr(d_hi), _lib.ptr(d_lo), n * c, h // 2, w // 2, _lib.stream_ptr(d_hi)))
+    return d_lo
+
+
+def mixup(x, lam, perm):
+    """out[n] = x[n]*lam[n] + x[perm[n]]*(1-lam[n]); lam float32 (N,), perm int32 (N,)."""
+    lib = _lib.load()
+    _f32(x, lam)
+    _lib.dev_check(x, lam, perm)
+    if perm.dtype != torch.int32:
+        raise _lib.Tnv3Error("mixup: perm must be int32")
+    n = int(x.shape[0])
+    out = torch.empty_like(x)
+    _lib.check(lib.tnv3_mixup(_lib.ptr(x), _lib.ptr(lam), _lib.ptr(perm), _lib.ptr(out), n, x.numel() // n, _lib.stream_ptr(x)))
+    return out
