@@ -64,7 +64,7 @@ def tune(dev, batch, out_paths):
         wp = ops.pack_conv3x3_weights(wt)
         s0 = torch.rand((batch, c0, h // 2, w // 2) if up else (batch, c0, h, w), device=dev)
         s1 = torch.rand((batch, c1, h, w), device=dev) if c1 else None
-        sc, sh = torch.rand(cout, device=dev) + 0.5, torch.rand(cout, device=dev) - 0.5
+        sc, sh, mu = torch.rand(cout, device=dev) + 0.5, torch.rand(cout, device=dev) - 0.5, torch.rand(cout, device=dev) - 0.5
         out = torch.empty((batch, cout, h, w), device=dev)
         fl = conv_flops(c0, c1, cout, h, w) * batch
         row = {"layer": name, "key": key, "tflops": {}}
@@ -72,13 +72,13 @@ def tune(dev, batch, out_paths):
             if cout % infos[cfg]["m_block"] or (c1 and c0 % infos[cfg]["chan_chunk"]):
                 continue
             for _ in range(2):
-                ops.conv3x3(s0, wp, cout, src1=s1, scale=sc, shift=sh, up0=up, relu=True, cfg=cfg, out=out)
+                ops.conv3x3(s0, wp, cout, src1=s1, mean=mu, scale=sc, shift=sh, up0=up, relu=True, cfg=cfg, out=out)
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 5
             e0.record()
             for _ in range(reps):
-                ops.conv3x3(s0, wp, cout, src1=s1, scale=sc, shift=sh, up0=up, relu=True, cfg=cfg, out=out)
+                ops.conv3x3(s0, wp, cout, src1=s1, mean=mu, scale=sc, shift=sh, up0=up, relu=True, cfg=cfg, out=out)
             e1.record()
             torch.cuda.synchronize(dev)
             ms = e0.elapsed_time(e1) / reps
@@ -100,7 +100,7 @@ def tune(dev, batch, out_paths):
 
 def cpu_baseline(budget_s=25.0):
     """The oracle's PyTorch-CPU restatement of the same forward on the host cores, bounded sample (batch 2).
-    Thread count: a short scan picks the fastest of {32, 64, physical cores, all hardware threads} -- using every
+    Thread count: a short upward scan over {8, 16, 32, 64, physical cores, all hardware threads} keeps the fastest -- using every
     SMT thread of a 2-socket host is several times SLOWER for this batch size, which would flatter the GPU."""
     from oracle import nets
     in_dim = (SEQ_LEN + 1) * 3
@@ -108,7 +108,7 @@ def cpu_baseline(budget_s=25.0):
     n = 2
     x = nets.synth_input((n, in_dim, H, W), 4242)
     ncpu = os.cpu_count() or 1
-    cands = sorted({min(32, ncpu), min(64, ncpu), max(1, ncpu // 2), ncpu})
+    cands = sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu), max(1, ncpu // 2), ncpu})
     t_all = time.time()
 
     def run():
@@ -119,8 +119,8 @@ def cpu_baseline(budget_s=25.0):
 
     scan = {}
     for th in cands:
-        if time.time() - t_all > budget_s * 0.6 and scan:
-            break
+        if scan and (time.time() - t_all > budget_s * 0.6 or scan[max(scan)] > 2.0 * min(scan.values())):
+            break                               # out of budget, or clearly past the sweet spot (more threads = slower)
         torch.set_num_threads(th)
         run()                                   # warm-up (thread pool, oneDNN primitive cache)
         scan[th] = run()
@@ -292,6 +292,12 @@ def main():
             pass
         for r in layer_rows:
             print(f"[layer] {r['layer']:22s} {r['ms']:8.3f} ms  {r['tflops']:7.2f} TFLOP/s", file=sys.stderr)
+        traffic = None
+        try:        # HBM bytes per conv launch from the PMC passes (profiles/conv_traffic.json; rocprofv3 cannot wrap itself)
+            with open(os.path.join(ROOT, "profiles", "conv_traffic.json")) as f:
+                traffic = float(json.load(f)["traffic_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "frames/sec (288x512, seq_len=8) TrackNet inference", "value": round(frames / dt, 2), "unit": "frames/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -300,7 +306,8 @@ def main():
                                    "288x512 synthetic frames, synthetic (PRNG) weights", "batch_per_gpu": args.batch,
                        "frames_per_step": n_gpus * args.batch * SEQ_LEN, "parallelism": f"replicated windows x{n_gpus} (no collective)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/conv_traffic.json)",
                          "kernel": "conv3x3_mfma_kernel<*> (17 launches/step, fp32 MFMA 32x32x2)",
                          "avg_launch_ms": round(conv_ms / 17, 4), "conv_ms_per_step": round(conv_ms, 4),
                          "algorithmic_gflop_per_step": round(float(fl.sum()) / 1e9, 3),

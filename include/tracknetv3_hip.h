@@ -50,20 +50,23 @@ size_t tnv3_conv3x3_packed_floats(int cout, int cin, int transpose_flip);
 int tnv3_pack_conv3x3_weights(const float* w, float* wpack, int cout, int cin, int transpose_flip,
                               tnv3_stream_t stream);
 
-/* Eval-mode nn.BatchNorm2d (model.py:9) as y = x*scale + shift per channel. */
-int tnv3_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                 float eps, float* scale, float* shift, int channels, tnv3_stream_t stream);
+/* Eval-mode nn.BatchNorm2d (model.py:9): scale[c] = gamma[c] / sqrt(running_var[c] + eps).  The conv epilogue then
+ * computes (x - running_mean) * scale + beta in the reference's operation order (the mean is deliberately not
+ * folded into the shift: that form cancels catastrophically when |mean| >> std). */
+int tnv3_bn_eval_scale(const float* gamma, const float* running_var, float eps, float* scale, int channels,
+                       tnv3_stream_t stream);
 
-/* dst[N][Cout][H][W] = act( conv3x3( cat([up2x?(src0), src1], dim=1), W ) * scale + shift )
+/* dst[N][Cout][H][W] = act( (conv3x3( cat([up2x?(src0), src1], dim=1), W ) - mean) * scale + shift )
  *   src0 : [N][C0][H][W], or [N][C0][H/2][W/2] when up0 != 0 (nn.Upsample(scale_factor=2), nearest)
  *   src1 : [N][C1][H][W] or NULL (C1 = 0); its channels follow src0's, as torch.cat([up, skip], dim=1)
  *   wpack: from tnv3_pack_conv3x3_weights for Cin = C0 + C1
- *   scale/shift: [Cout] or both NULL (raw convolution);  relu != 0 applies max(.,0)
+ *   mean/scale/shift: [Cout]; scale and shift both NULL = raw convolution; mean may be NULL (= 0);
+ *   relu != 0 applies max(.,0)
  *   cfg  : tile configuration index, or -1 to let the library choose
  * Requirements: Cout % 64 == 0; H,W < 8192; when C1 > 0, C0 % 32 == 0.  */
-int tnv3_conv3x3_forward(const float* src0, const float* src1, const float* wpack, const float* scale,
-                         const float* shift, float* dst, int n, int c0, int c1, int cout, int h, int w,
-                         int up0, int relu, int cfg, tnv3_stream_t stream);
+int tnv3_conv3x3_forward(const float* src0, const float* src1, const float* wpack, const float* mean,
+                         const float* scale, const float* shift, float* dst, int n, int c0, int c1, int cout,
+                         int h, int w, int up0, int relu, int cfg, tnv3_stream_t stream);
 
 /* ---- head + pooling (model.py:54-55,59,61,63,71-72) ----------------------------------------------------- */
 

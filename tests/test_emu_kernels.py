@@ -16,12 +16,14 @@ def T(shape, seed, lo=-1.0, hi=1.0):
     return torch.from_numpy(prng.uniform(shape, seed, lo, hi))
 
 
-def conv_ref(s0, s1, wt, sc, sh, up0, relu):
+def conv_ref(s0, s1, wt, sc, sh, up0, relu, mu=None):
     x = s0.repeat_interleave(2, 2).repeat_interleave(2, 3) if up0 else s0
     if s1 is not None:
         x = torch.cat([x, s1], 1)
     ref = F.conv2d(x.double(), wt.double(), padding=1)
     if sc is not None:
+        if mu is not None:
+            ref = ref - mu.double()[None, :, None, None]
         ref = ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
     return ref.relu() if relu else ref
 
@@ -51,8 +53,9 @@ def test_conv3x3_mfma_emulated(emu, case):
     s1 = T((n, c1, h, w), seed + 2) if c1 else None
     sc = T((cout,), seed + 3, 0.5, 1.5) if affine else None
     sh = T((cout,), seed + 4, -0.5, 0.5) if affine else None
-    y = ops.conv3x3(s0, ops.pack_conv3x3_weights(wt), cout, src1=s1, scale=sc, shift=sh, up0=up0, relu=relu, cfg=cfg)
-    ref = conv_ref(s0, s1, wt, sc, sh, up0, relu)
+    mu = T((cout,), seed + 5, -2.0, 2.0) if (affine and cfg % 2 == 0) else None      # mean is optional
+    y = ops.conv3x3(s0, ops.pack_conv3x3_weights(wt), cout, src1=s1, mean=mu, scale=sc, shift=sh, up0=up0, relu=relu, cfg=cfg)
+    ref = conv_ref(s0, s1, wt, sc, sh, up0, relu, mu)
     assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6
 
 
@@ -66,12 +69,11 @@ def test_weight_packing_layouts(emu):
     assert torch.equal(pt, w.flip(2, 3).permute(0, 2, 3, 1).reshape(64, 9, 5))
 
 
-def test_bn_fold_pool_head_emulated(emu):
+def test_bn_scale_pool_head_emulated(emu):
     from tracknetv3_amd import ops
     g, b, rm, rv = T((70,), 1, 0.5, 1.5), T((70,), 2), T((70,), 3), T((70,), 4, 0.5, 2.0)
-    sc, sh = ops.bn_fold(g, b, rm, rv)
-    ref_sc = g / torch.sqrt(rv + 1e-5)
-    assert torch.allclose(sc, ref_sc, rtol=1e-6) and torch.allclose(sh, b - rm * ref_sc, rtol=1e-5, atol=1e-6)
+    sc = ops.bn_eval_scale(g, rv)
+    assert torch.allclose(sc, g / torch.sqrt(rv + 1e-5), rtol=1e-6)
     x = T((2, 3, 8, 16), 5)
     assert torch.equal(ops.maxpool2x2(x), F.max_pool2d(x, 2, 2))
     x = T((2, 64, 4, 8), 6)

@@ -25,11 +25,12 @@ def test_conv3x3_small_cases(gpu_device, case):
     s1 = T((n, c1, h, w), seed + 2) if c1 else None
     sc = T((cout,), seed + 3, 0.5, 1.5) if affine else None
     sh = T((cout,), seed + 4, -0.5, 0.5) if affine else None
+    mu = T((cout,), seed + 5, -2.0, 2.0) if (affine and cfg % 2 == 0) else None
     d = gpu_device
     g = lambda t: None if t is None else t.to(d)
-    y = ops.conv3x3(g(s0), ops.pack_conv3x3_weights(g(wt)), cout, src1=g(s1), scale=g(sc), shift=g(sh), up0=up0,
+    y = ops.conv3x3(g(s0), ops.pack_conv3x3_weights(g(wt)), cout, src1=g(s1), mean=g(mu), scale=g(sc), shift=g(sh), up0=up0,
                     relu=relu, cfg=cfg).cpu()
-    ref = conv_ref(s0, s1, wt, sc, sh, up0, relu)
+    ref = conv_ref(s0, s1, wt, sc, sh, up0, relu, mu)
     assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6
 
 
@@ -44,10 +45,10 @@ def test_conv3x3_every_config_on_network_shapes(gpu_device, cfg):
         wt = T((cout, c0 + c1, 3, 3), 5, -0.1, 0.1)
         s0 = T((2, c0, h // 2, w // 2) if up0 else (2, c0, h, w), 6)
         s1 = T((2, c1, h, w), 7) if c1 else None
-        sc, sh = T((cout,), 8, 0.5, 1.5), T((cout,), 9, -0.5, 0.5)
+        sc, sh, mu = T((cout,), 8, 0.5, 1.5), T((cout,), 9, -0.5, 0.5), T((cout,), 10, -1.0, 1.0)
         y = ops.conv3x3(s0.to(d), ops.pack_conv3x3_weights(wt.to(d)), cout, src1=None if s1 is None else s1.to(d),
-                        scale=sc.to(d), shift=sh.to(d), up0=up0, relu=True, cfg=cfg).cpu()
-        ref = conv_ref(s0, s1, wt, sc, sh, up0, True)
+                        mean=mu.to(d), scale=sc.to(d), shift=sh.to(d), up0=up0, relu=True, cfg=cfg).cpu()
+        ref = conv_ref(s0, s1, wt, sc, sh, up0, True, mu)
         assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6, (cfg, c0, c1)
 
 

@@ -35,8 +35,8 @@ def _declare(lib):
     sig("tnv3_conv3x3_config_info", i, i, ip, ip, ip, ip, ip, ip)
     sig("tnv3_conv3x3_packed_floats", sz, i, i, i)
     sig("tnv3_pack_conv3x3_weights", i, p, p, i, i, i, p)
-    sig("tnv3_bn_fold", i, p, p, p, p, f, p, p, i, p)
-    sig("tnv3_conv3x3_forward", i, p, p, p, p, p, p, i, i, i, i, i, i, i, i, i, p)
+    sig("tnv3_bn_eval_scale", i, p, p, f, p, i, p)
+    sig("tnv3_conv3x3_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, i, i, p)
     sig("tnv3_head1x1_sigmoid", i, p, p, p, p, i, i, i, i, i, p)
     sig("tnv3_maxpool2x2", i, p, p, lg, i, i, p)
     sig("tnv3_conv1d_k3_forward", i, p, p, p, p, p, i, i, i, i, i, i, i, i, p)
@@ -65,7 +65,7 @@ def _declare(lib):
 _OPTIONAL = {}   # later entry points register here: name -> (restype, *argtypes)
 
 EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "tnv3_conv3x3_config_info",
-           "tnv3_conv3x3_packed_floats", "tnv3_pack_conv3x3_weights", "tnv3_bn_fold", "tnv3_conv3x3_forward",
+           "tnv3_conv3x3_packed_floats", "tnv3_pack_conv3x3_weights", "tnv3_bn_eval_scale", "tnv3_conv3x3_forward",
            "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2", "tnv3_conv1d_k3_forward", "tnv3_ensemble_frames",
            "tnv3_peakfind_workspace_bytes", "tnv3_heatmap_peakfind", "tnv3_bn_workspace_bytes", "tnv3_bn_train_forward",
            "tnv3_bn_relu_backward", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",

@@ -34,7 +34,8 @@ struct Conv3x3Args {
   const float* src0;    // [N][C0][H0][W0]   H0,W0 = H,W (up0 == 0) or H/2,W/2 (up0 == 1: nearest 2x upsample on load)
   const float* src1;    // [N][C1][H][W] or nullptr; its channels follow src0's (cat([up(src0), src1], dim=1))
   const float* wpack;   // [Cin_pad][9][Cout], Cin_pad = roundup(C0+C1, CC), padding rows zero
-  const float* scale;   // [Cout] or nullptr  -> y = acc*scale + shift   (eval-mode BN folded to an affine)
+  const float* mean;    // [Cout] or nullptr  -> y = (acc - mean)*scale + shift: eval-mode BatchNorm in the reference's
+  const float* scale;   // [Cout] or nullptr     own operation order (subtract first: no cancellation when |mean| >> std)
   const float* shift;   // [Cout] or nullptr
   float* dst;           // [N][Cout][H][W]   (or [N][csplit][H][W] when dst1 is set)
   float* dst1;          // optional second destination for output channels >= csplit: [N][Cout-csplit][H][W]
@@ -251,8 +252,8 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float sc = 1.0f, sh = 0.0f;
-      if (has_affine) { sc = a.scale[co]; sh = a.shift[co]; }
+      float mu = 0.0f, sc = 1.0f, sh = 0.0f;
+      if (has_affine) { mu = a.mean ? a.mean[co] : 0.0f; sc = a.scale[co]; sh = a.shift[co]; }
       float* drow = (a.dst1 == nullptr || co < a.csplit)
                         ? a.dst + ((size_t)n * (a.dst1 ? a.csplit : Cout) + co) * HW
                         : a.dst1 + ((size_t)n * (Cout - a.csplit) + (co - a.csplit)) * HW;
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
         const int oh = h0 + wn * (NTW / CS) + j / CS;
         const int ow = w0 + (j % CS) * 32 + bl;
         float v = acc[mt][j][r];
-        if (has_affine) v = v * sc + sh;
+        if (has_affine) v = (v - mu) * sc + sh;
         if (a.relu) v = v > 0.0f ? v : 0.0f;
         if (oh < H && ow < W) drow[oh * W + ow] = v;
       }
@@ -292,17 +293,12 @@ __global__ void pack_conv3x3_weights_kernel(const float* __restrict__ w, float* 
   }
 }
 
-// Eval-mode BatchNorm2d as a per-channel affine (model.py:9):
-//   scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
-__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
-                               const float* __restrict__ rmean, const float* __restrict__ rvar,
-                               float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+// Eval-mode BatchNorm2d (model.py:9): y = (x - running_mean) * scale + beta with
+//   scale = gamma / sqrt(running_var + eps)      (the mean is NOT folded into the shift: see the epilogue note)
+__global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ rvar, float eps,
+                                     float* __restrict__ scale, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
-    const float s = gamma[c] / sqrtf(rvar[c] + eps);
-    scale[c] = s;
-    shift[c] = beta[c] - rmean[c] * s;
-  }
+  if (c < C) scale[c] = gamma[c] / sqrtf(rvar[c] + eps);
 }
 
 }  // namespace tnv3

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const float* __re
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, float* __restrict__ running_mean,
                                          float* __restrict__ running_var, float eps, float momentum, long count,
-                                         float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                         float* __restrict__ scale, float* __restrict__ save_mean,
                                          float* __restrict__ save_invstd, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -63,9 +63,8 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, con
   double var = s2 / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
-  const double sc = (double)gamma[c] * invstd;
-  scale[c] = (float)sc;
-  shift[c] = (float)((double)beta[c] - mean * sc);
+  scale[c] = (float)((double)gamma[c] * invstd);
+  (void)beta;
   save_mean[c] = (float)mean;
   save_invstd[c] = (float)invstd;
   const double unbiased = count > 1 ? var * (n / (n - 1.0)) : var;
@@ -73,19 +72,19 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, con
   running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
 }
 
-// a = max(z*scale[c] + shift[c], 0)
-__global__ void __launch_bounds__(256) bn_apply_relu_kernel(const float* __restrict__ z, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, float* __restrict__ a,
-                                                            long NC, int C, int HW) {
+// a = max((z - mean[c])*scale[c] + beta[c], 0)  -- subtract first, like the reference: no cancellation when |mean| >> std
+__global__ void __launch_bounds__(256) bn_apply_relu_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ a, long NC, int C, int HW) {
   const int hw4 = HW >> 2;
   const long total4 = NC * hw4;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (long)gridDim.x * blockDim.x) {
     const long nc = t / hw4;
     const int c = (int)(nc % C);
-    const float sc = scale[c], sh = shift[c];
+    const float mu = mean[c], sc = scale[c], sh = shift[c];
     t_f32x4 v = *reinterpret_cast<const t_f32x4*>(z + t * 4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const float y = fmaf(v[k], sc, sh); v[k] = y > 0.0f ? y : 0.0f; }
+    for (int k = 0; k < 4; ++k) { const float y = fmaf(v[k] - mu, sc, sh); v[k] = y > 0.0f ? y : 0.0f; }
     *reinterpret_cast<t_f32x4*>(a + t * 4) = v;
   }
 }

@@ -70,20 +70,21 @@ int launch_conv_cfg(Launcher& L, const Conv3x3Args& a) {
 }
 
 template <class Launcher>
-int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, const float* wpack, const float* scale,
-                         const float* shift, float* dst, int n, int c0, int c1, int cout, int h, int w, int up0,
+int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, const float* wpack, const float* mean,
+                         const float* scale, const float* shift, float* dst, int n, int c0, int c1, int cout, int h, int w, int up0,
                          int relu, int cfg, float* dst1 = nullptr, int csplit = 0) {
   if (!src0 || !wpack || !dst) TNV3_FAIL(-1, "conv3x3: null pointer");
   if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "conv3x3: non-positive dimension");
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3: src1 / c1 mismatch");
   if ((scale == nullptr) != (shift == nullptr)) TNV3_FAIL(-1, "conv3x3: scale and shift must both be given or both be NULL");
+  if (mean && !scale) TNV3_FAIL(-1, "conv3x3: mean given without scale/shift");
   if (cout % 64) TNV3_FAIL(-1, "conv3x3: Cout=%d must be a multiple of 64", cout);
   if (h >= 8192 || w >= 8192) TNV3_FAIL(-1, "conv3x3: H,W must be < 8192");
   if (c1 > 0 && (c0 % 32)) TNV3_FAIL(-1, "conv3x3: two-source input needs C0 %% 32 == 0 (got %d)", c0);
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3: upsampled source needs even H,W");
   if (cfg < 0) cfg = conv_auto_config(n, cout, h, w);
   if (dst1 && (csplit <= 0 || csplit >= cout)) TNV3_FAIL(-1, "conv3x3: bad output split %d of %d", csplit, cout);
-  Conv3x3Args a{src0, src1, wpack, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0};
+  Conv3x3Args a{src0, src1, wpack, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0};
   switch (cfg) {
     case 0: return launch_conv_cfg<ConvC0>(L, a);
     case 1: return launch_conv_cfg<ConvC1>(L, a);
@@ -112,10 +113,9 @@ int pack_conv3x3_weights_impl(Launcher& L, const float* w, float* wpack, int cou
 }
 
 template <class Launcher>
-int bn_fold_impl(Launcher& L, const float* g, const float* b, const float* rm, const float* rv, float eps, float* scale,
-                 float* shift, int c) {
-  if (!g || !b || !rm || !rv || !scale || !shift || c <= 0) TNV3_FAIL(-1, "bn_fold: bad argument");
-  return L.launch(bn_fold_kernel, (c + 255) / 256, 256, g, b, rm, rv, eps, scale, shift, c);
+int bn_eval_scale_impl(Launcher& L, const float* g, const float* rv, float eps, float* scale, int c) {
+  if (!g || !rv || !scale || c <= 0) TNV3_FAIL(-1, "bn_eval_scale: bad argument");
+  return L.launch(bn_eval_scale_kernel, (c + 255) / 256, 256, g, rv, eps, scale, c);
 }
 
 template <class Launcher>
@@ -211,12 +211,11 @@ int bn_train_forward_impl(Launcher& L, const float* z, const float* gamma, const
   if (ws_bytes < bn_workspace_bytes(c) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "bn_train_forward: workspace too small / misaligned");
   double* partial = (double*)ws;
   float* scale = (float*)(partial + (size_t)c * kRedSplit * 2);
-  float* shift = scale + c;
   int rc;
   if ((rc = L.launch3(bn_stats_partial_kernel, kRedSplit, c, 1, 256, z, partial, n, c, hw))) return rc;
   if ((rc = L.launch(bn_stats_finalize_kernel, (c + 63) / 64, 64, (const double*)partial, gamma, beta, rm, rv, eps, momentum,
-                     (long)n * hw, scale, shift, save_mean, save_invstd, c))) return rc;
-  return L.launch(bn_apply_relu_kernel, grid_for((long)n * c * (hw / 4)), 256, z, (const float*)scale, (const float*)shift, a,
+                     (long)n * hw, scale, save_mean, save_invstd, c))) return rc;
+  return L.launch(bn_apply_relu_kernel, grid_for((long)n * c * (hw / 4)), 256, z, (const float*)save_mean, (const float*)scale, beta, a,
                   (long)n * c, c, hw);
 }
 
@@ -242,7 +241,7 @@ template <class Launcher>
 int conv3x3_dgrad_impl(Launcher& L, const float* dz, const float* wpack_t, float* dx0, float* dx1, int n, int cout, int c0,
                        int c1, int h, int w, int cfg) {
   if (c1 < 0 || (c1 > 0) != (dx1 != nullptr)) TNV3_FAIL(-1, "conv3x3_dgrad: dx1 / c1 mismatch");
-  return conv3x3_forward_impl(L, dz, (const float*)nullptr, wpack_t, (const float*)nullptr, (const float*)nullptr, dx0, n, cout,
+  return conv3x3_forward_impl(L, dz, (const float*)nullptr, wpack_t, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dx0, n, cout,
                               0, c0 + c1, h, w, 0, 0, cfg, dx1, c1 > 0 ? c0 : 0);
 }
 

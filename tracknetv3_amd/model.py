@@ -67,23 +67,24 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
-    def folded_affine(self):
-        ver = self._versions(["weight", "bias", "running_mean", "running_var"])
+    def eval_scale(self):
+        """gamma / sqrt(running_var + eps), recomputed when gamma or running_var change."""
+        ver = self._versions(["weight", "running_var"])
         hit = self._cache.get("aff")
         if hit is None or hit[0] != ver:
             bn = self.bn
-            hit = (ver, ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps))
+            hit = (ver, ops.bn_eval_scale(bn.weight.detach(), bn.running_var, bn.eps))
             self._cache["aff"] = hit
         return hit[1]
 
     def forward_eval(self, x, skip=None, up=False, layer_key=None):
-        scale, shift = self.folded_affine()
+        bn = self.bn
         n = x.shape[0]
         h = x.shape[2] * (2 if up else 1)
         w = x.shape[3] * (2 if up else 1)
         cfg = tuning.conv_config(self.conv.out_dim, self.conv.in_dim, n, h, w)
-        return ops.conv3x3(x, self.packed_weight(), self.conv.out_dim, src1=skip, scale=scale, shift=shift,
-                           up0=up, relu=True, cfg=cfg)
+        return ops.conv3x3(x, self.packed_weight(), self.conv.out_dim, src1=skip, mean=bn.running_mean, scale=self.eval_scale(),
+                           shift=bn.bias.detach(), up0=up, relu=True, cfg=cfg)
 
     def forward(self, x):
         if self.training:

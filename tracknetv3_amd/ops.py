@@ -41,23 +41,23 @@ def pack_conv3x3_weights(w, transpose_flip=False, out=None):
     return out
 
 
-def bn_fold(gamma, beta, running_mean, running_var, eps=BN_EPS):
+def bn_eval_scale(gamma, running_var, eps=BN_EPS):
+    """scale = gamma / sqrt(running_var + eps) (eval-mode BatchNorm2d; mean and beta are passed to the conv as they are)."""
     lib = _lib.load()
-    _f32(gamma, beta, running_mean, running_var)
-    _lib.dev_check(gamma, beta, running_mean, running_var)
+    _f32(gamma, running_var)
+    _lib.dev_check(gamma, running_var)
     c = gamma.numel()
     scale = torch.empty(c, dtype=torch.float32, device=gamma.device)
-    shift = torch.empty_like(scale)
-    _lib.check(lib.tnv3_bn_fold(_lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
-                                float(eps), _lib.ptr(scale), _lib.ptr(shift), c, _lib.stream_ptr(gamma)))
-    return scale, shift
+    _lib.check(lib.tnv3_bn_eval_scale(_lib.ptr(gamma), _lib.ptr(running_var), float(eps), _lib.ptr(scale), c,
+                                      _lib.stream_ptr(gamma)))
+    return scale
 
 
-def conv3x3(src0, wpack, cout, src1=None, scale=None, shift=None, up0=False, relu=False, cfg=-1, out=None):
-    """act(conv3x3(cat([up2x?(src0), src1], 1), W) * scale + shift) -- see tnv3_conv3x3_forward."""
+def conv3x3(src0, wpack, cout, src1=None, mean=None, scale=None, shift=None, up0=False, relu=False, cfg=-1, out=None):
+    """act((conv3x3(cat([up2x?(src0), src1], 1), W) - mean) * scale + shift) -- see tnv3_conv3x3_forward."""
     lib = _lib.load()
-    _f32(src0, src1, wpack, scale, shift, out)
-    _lib.dev_check(src0, src1, wpack, scale, shift, out)
+    _f32(src0, src1, wpack, mean, scale, shift, out)
+    _lib.dev_check(src0, src1, wpack, mean, scale, shift, out)
     n, c0, h0, w0 = (int(v) for v in src0.shape)
     h, w = (2 * h0, 2 * w0) if up0 else (h0, w0)
     c1 = 0
@@ -72,7 +72,7 @@ def conv3x3(src0, wpack, cout, src1=None, scale=None, shift=None, up0=False, rel
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=src0.device)
     elif tuple(out.shape) != (n, cout, h, w):
         raise _lib.Tnv3Error("conv3x3: wrong output shape")
-    _lib.check(lib.tnv3_conv3x3_forward(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(wpack), _lib.ptr(scale), _lib.ptr(shift),
+    _lib.check(lib.tnv3_conv3x3_forward(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(wpack), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(shift),
                                         _lib.ptr(out), n, c0, c1, cout, h, w, int(bool(up0)), int(bool(relu)), int(cfg),
                                         _lib.stream_ptr(src0)))
     return out
