@@ -40,9 +40,12 @@ struct WgradCfg {
 };
 
 template <class Cfg>
-__global__ void __launch_bounds__(Cfg::NT, 2) wgrad3x3_mfma_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs a) {
   constexpr int WC = Cfg::WC, TR = Cfg::TR, TC = Cfg::TC, NT = Cfg::NT, MB = Cfg::MB, CB = Cfg::CB;
   constexpr int PIX = Cfg::PIX, PIXP = Cfg::PIXP, TRp = Cfg::TRp, TCp = Cfg::TCp, PLANE = Cfg::PLANE, PLANEP = Cfg::PLANEP;
+  constexpr int NDZ4 = (MB * PIX / 4 + NT - 1) / NT;     // 16-byte dZ loads per thread per tile
+  constexpr int NX = (CB * PLANE + NT - 1) / NT;         // X halo elements per thread per tile
+  static_assert((MB * PIX / 4) % NT == 0, "dZ tile must divide evenly over the workgroup");
   __shared__ float lds[Cfg::DZ_FLOATS + Cfg::X_FLOATS];
   float* dz_s = lds;
   float* x_s = lds + Cfg::DZ_FLOATS;
@@ -63,6 +66,75 @@ __global__ void __launch_bounds__(Cfg::NT, 2) wgrad3x3_mfma_kernel(const WgradAr
   const int tilesH = (H + TR - 1) / TR, tilesW = (W + TC - 1) / TC;
   const int nTiles = a.N * tilesH * tilesW;
 
+  // ---- per-thread staging slots (tile independent)
+  // dZ: 16-byte group g = tid + i*NT of [MB][TR][TC/4]; X: element e = tid + i*NT of [CB][TR+2][TC+2]
+  int xs[NX];                                   // ci_l << 16 | tr << 8 | tc, or -1
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int e = tid + i * NT;
+    const int ci_l = e / PLANE, rr = e - ci_l * PLANE;
+    const int tr = rr / TCp, tc = rr - tr * TCp;
+    xs[i] = (e < CB * PLANE && ci0 + ci_l < Cin) ? ((ci_l << 16) | (tr << 8) | tc) : -1;
+  }
+
+  f32x4 rdz[NDZ4];
+  float rx[NX];
+  unsigned long long dz_ok = 0, x_ok = 0;       // validity bits of the tile currently held in registers
+  static_assert(NDZ4 <= 64 && NX <= 64, "validity masks are 64-bit");
+
+  auto load_tile = [&](int tile) {
+    const int n = tile / (tilesH * tilesW);
+    const int trem = tile - n * (tilesH * tilesW);
+    const int h0 = (trem / tilesW) * TR, w0 = (trem % tilesW) * TC;
+    const float* dzn = a.dz + (size_t)n * Cout * HW;
+    dz_ok = 0; x_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NDZ4; ++i) {
+      const int g = tid + i * NT;
+      const int c4 = g % (TC / 4), t2 = g / (TC / 4);
+      const int r = t2 % TR, co_l = t2 / TR;
+      const int co = co0 + co_l, gh = h0 + r, gw = w0 + 4 * c4;
+      const bool ok = co < Cout && gh < H && gw < W;            // W % 4 == 0: a 16-byte group is all-in or all-out
+      const size_t off = ok ? ((size_t)co * HW + gh * W + gw) : 0;
+      rdz[i] = *reinterpret_cast<const f32x4*>(dzn + off);
+      dz_ok |= ok ? (1ull << i) : 0ull;
+    }
+    const float* s0n = a.src0 + (size_t)n * C0 * HW0;
+    const float* s1n = a.src1 ? a.src1 + (size_t)n * C1 * HW : a.src0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int s = xs[i];
+      const int ci = ci0 + (s >> 16), gh = h0 - 1 + ((s >> 8) & 255), gw = w0 - 1 + (s & 255);
+      const bool ok = s != -1 && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      const bool from0 = ci < C0;
+      const int off0 = a.up0 ? (ci * HW0 + (gh >> 1) * W0 + (gw >> 1)) : (ci * HW + gh * W + gw);
+      const int off1 = (ci - C0) * HW + gh * W + gw;
+      const float* ptr = from0 ? s0n + (ok ? off0 : 0) : s1n + (ok ? off1 : 0);
+      rx[i] = *ptr;
+      x_ok |= ok ? (1ull << i) : 0ull;
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NDZ4; ++i) {
+      const int g = tid + i * NT;
+      const int c4 = g % (TC / 4), t2 = g / (TC / 4);
+      const int r = t2 % TR, co_l = t2 / TR;
+      float* d = dz_s + co_l * PIXP + r * TC + 4 * c4;          // odd row stride: four scalar stores
+      const bool ok = (dz_ok >> i) & 1ull;
+      d[0] = ok ? rdz[i][0] : 0.0f; d[1] = ok ? rdz[i][1] : 0.0f; d[2] = ok ? rdz[i][2] : 0.0f; d[3] = ok ? rdz[i][3] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * NT;
+      if ((i + 1) * NT <= CB * PLANE || e < CB * PLANE) {
+        const int ci_l = e / PLANE, rr = e - ci_l * PLANE;
+        x_s[ci_l * PLANEP + rr] = ((x_ok >> i) & 1ull) ? rx[i] : 0.0f;
+      }
+    }
+  };
+
   f32x16 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -72,48 +144,33 @@ __global__ void __launch_bounds__(Cfg::NT, 2) wgrad3x3_mfma_kernel(const WgradAr
   const int a_off = (wm * 32 + bl) * PIXP + half;
   const int b_off = (wc * 32 + bl) * PLANEP + half;
 
+  if (ks < nTiles) load_tile(ks);
   for (int tile = ks; tile < nTiles; tile += a.splitK) {
-    const int n = tile / (tilesH * tilesW);
-    const int trem = tile - n * (tilesH * tilesW);
-    const int h0 = (trem / tilesW) * TR, w0 = (trem % tilesW) * TC;
+    __syncthreads();                            // every wave is done reading the previous tile
+    store_tile();
     __syncthreads();
-    // ---- stage dZ tile [MB][TR][TC]
-    for (int idx = tid; idx < MB * PIX; idx += NT) {
-      const int col = idx % TC, t2 = idx / TC;
-      const int r = t2 % TR, co_l = t2 / TR;
-      const int co = co0 + co_l, gh = h0 + r, gw = w0 + col;
-      float v = 0.0f;
-      if (co < Cout && gh < H && gw < W) v = a.dz[((size_t)n * Cout + co) * HW + gh * W + gw];
-      dz_s[co_l * PIXP + r * TC + col] = v;
-    }
-    // ---- stage X halo tile [CB][TR+2][TC+2]
-    for (int idx = tid; idx < CB * PLANE; idx += NT) {
-      const int ci_l = idx / PLANE, rr = idx - ci_l * PLANE;
-      const int tr = rr / TCp, tc = rr - tr * TCp;
-      const int ci = ci0 + ci_l, gh = h0 - 1 + tr, gw = w0 - 1 + tc;
-      float v = 0.0f;
-      if (ci < Cin && gh >= 0 && gh < H && gw >= 0 && gw < W) {
-        if (ci < C0) v = a.up0 ? a.src0[((size_t)n * C0 + ci) * HW0 + (gh >> 1) * W0 + (gw >> 1)]
-                               : a.src0[((size_t)n * C0 + ci) * HW + gh * W + gw];
-        else v = a.src1[((size_t)n * C1 + (ci - C0)) * HW + gh * W + gw];
-      }
-      x_s[ci_l * PLANEP + tr * TCp + tc] = v;
-    }
-    __syncthreads();
+    if (tile + a.splitK < nTiles) load_tile(tile + a.splitK);   // in flight during the MFMA block below
     // ---- MFMA: K-step = two horizontally adjacent pixels of one tile row
     const float* A = dz_s + a_off;
     const float* B = x_s + b_off;
+    // operands of K-step s+1 are read before the nine MFMAs of step s (static double buffer), as in the forward kernel
+    constexpr int NSTEP = TR * (TC / 2);
+    float av[2], bv[2][9];
+    auto read_step = [&](int s, float& ar, float (&br)[9]) {
+      const int r = s / (TC / 2), j = s - r * (TC / 2);
+      ar = A[r * TC + 2 * j];
 #pragma unroll
-    for (int r = 0; r < TR; ++r) {
+      for (int tap = 0; tap < 9; ++tap) br[tap] = B[(r + tap / 3) * TCp + 2 * j + (tap % 3)];
+    };
+    read_step(0, av[0], bv[0]);
 #pragma unroll
-      for (int j = 0; j < TC / 2; ++j) {
-        const float av = A[r * TC + 2 * j];
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + 1 < NSTEP) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int kh = tap / 3, kw = tap - 3 * kh;
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B[(r + kh) * TCp + 2 * j + kw], acc[tap], 0, 0, 0);
-        }
-      }
+      for (int tap = 0; tap < 9; ++tap)
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][tap], acc[tap], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // DS reads of step s+1
+      __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);    // MFMAs of step s
     }
   }
 

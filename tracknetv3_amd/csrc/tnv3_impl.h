@@ -256,7 +256,7 @@ inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
   p.nMB = (cout + MB - 1) / MB;
   p.nCB = (cin + CB - 1) / CB;
   p.nTiles = n * ((h + 1) / 2) * ((w + 31) / 32);
-  int sk = (2048 + p.nMB * p.nCB - 1) / (p.nMB * p.nCB);          // ~2048 workgroups: 4 per CU x 2 resident
+  int sk = (1024 + p.nMB * p.nCB - 1) / (p.nMB * p.nCB);          // ~1024 workgroups: two rounds of 2 resident per CU
   const int max_by_work = (p.nTiles + 7) / 8;                       // at least ~8 pixel tiles per workgroup
   if (sk > max_by_work) sk = max_by_work;
   if (sk < 1) sk = 1;
@@ -276,6 +276,8 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   if (!src0 || !dz || !dw || !ws || n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "conv3x3_wgrad: bad argument");
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3_wgrad: src1 / c1 mismatch");
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3_wgrad: upsampled source needs even H,W");
+  if (w % 4) TNV3_FAIL(-1, "conv3x3_wgrad: W must be a multiple of 4 (16-byte dZ loads)");
+  if (h > 250 * 2 * 1024 || c0 + c1 > 32767) TNV3_FAIL(-1, "conv3x3_wgrad: dimension too large");
   if (ws_bytes < wgrad_workspace_bytes(n, c0, c1, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad: workspace too small");
   const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
   WgradArgs a{src0, src1, dz, (float*)ws, n, c0, c1, cout, h, w, up0 ? 1 : 0, p.splitK};
