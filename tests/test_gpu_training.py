@@ -38,7 +38,7 @@ def test_bn_train_forward_backward(gpu_device):
 
 
 @pytest.mark.parametrize("case", [(2, 27, 0, 64, 40, 96, False), (2, 64, 0, 64, 32, 64, False), (1, 128, 64, 64, 32, 64, True),
-                                  (2, 512, 256, 256, 8, 32, True), (2, 256, 0, 512, 12, 32, False), (1, 128, 0, 256, 18, 50, False)],
+                                  (2, 512, 256, 256, 8, 32, True), (2, 256, 0, 512, 12, 32, False), (1, 128, 0, 256, 18, 52, False)],
                          ids=["27to64", "64to64", "dual192to64", "dual768to256", "256to512", "128to256_ragged"])
 def test_wgrad_and_dgrad(gpu_device, case):
     from tracknetv3_amd import ops
