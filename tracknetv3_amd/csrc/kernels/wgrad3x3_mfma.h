@@ -27,7 +27,7 @@ struct WgradArgs {
   int N, C0, C1, Cout, H, W, up0, splitK;
 };
 
-template <int WM_, int WC_, int TR_ = 2, int TC_ = 32>
+template <int WM_, int WC_, int TR_ = 4, int TC_ = 32>
 struct WgradCfg {
   static constexpr int WM = WM_, WC = WC_, TR = TR_, TC = TC_;
   static constexpr int NT = WM * WC * 64;
@@ -82,6 +82,14 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
   unsigned long long dz_ok = 0, x_ok = 0;       // validity bits of the tile currently held in registers
   static_assert(NDZ4 <= 64 && NX <= 64, "validity masks are 64-bit");
 
+  // The whole ci block comes from ONE source (host guarantees C0 % CB == 0 for a two-source input), so the source,
+  // its plane geometry and the upsample flag are workgroup-uniform: one branch per tile, none per element.
+  const bool blk0 = ci0 < C0;
+  const bool up = blk0 && a.up0;
+  const float* xsrc = blk0 ? a.src0 : a.src1;
+  const int Cs = blk0 ? C0 : C1, cib = blk0 ? ci0 : ci0 - C0;
+  const int Ws = up ? W0 : W, HWs = up ? HW0 : HW;
+
   auto load_tile = [&](int tile) {
     const int n = tile / (tilesH * tilesW);
     const int trem = tile - n * (tilesH * tilesW);
@@ -95,23 +103,31 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
       const int r = t2 % TR, co_l = t2 / TR;
       const int co = co0 + co_l, gh = h0 + r, gw = w0 + 4 * c4;
       const bool ok = co < Cout && gh < H && gw < W;            // W % 4 == 0: a 16-byte group is all-in or all-out
-      const size_t off = ok ? ((size_t)co * HW + gh * W + gw) : 0;
+      const int off = ok ? (co * HW + gh * W + gw) : 0;
       rdz[i] = *reinterpret_cast<const f32x4*>(dzn + off);
       dz_ok |= ok ? (1ull << i) : 0ull;
     }
-    const float* s0n = a.src0 + (size_t)n * C0 * HW0;
-    const float* s1n = a.src1 ? a.src1 + (size_t)n * C1 * HW : a.src0;
+    const float* xn = xsrc + ((size_t)n * Cs + cib) * HWs;
+    if (up) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int s = xs[i];
-      const int ci = ci0 + (s >> 16), gh = h0 - 1 + ((s >> 8) & 255), gw = w0 - 1 + (s & 255);
-      const bool ok = s != -1 && gh >= 0 && gh < H && gw >= 0 && gw < W;
-      const bool from0 = ci < C0;
-      const int off0 = a.up0 ? (ci * HW0 + (gh >> 1) * W0 + (gw >> 1)) : (ci * HW + gh * W + gw);
-      const int off1 = (ci - C0) * HW + gh * W + gw;
-      const float* ptr = from0 ? s0n + (ok ? off0 : 0) : s1n + (ok ? off1 : 0);
-      rx[i] = *ptr;
-      x_ok |= ok ? (1ull << i) : 0ull;
+      for (int i = 0; i < NX; ++i) {
+        const int s = xs[i];
+        const int gh = h0 - 1 + ((s >> 8) & 255), gw = w0 - 1 + (s & 255);
+        const bool ok = s != -1 && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        const int off = ok ? ((s >> 16) * HWs + (gh >> 1) * Ws + (gw >> 1)) : 0;
+        rx[i] = xn[off];
+        x_ok |= ok ? (1ull << i) : 0ull;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int s = xs[i];
+        const int gh = h0 - 1 + ((s >> 8) & 255), gw = w0 - 1 + (s & 255);
+        const bool ok = s != -1 && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        const int off = ok ? ((s >> 16) * HWs + gh * Ws + gw) : 0;
+        rx[i] = xn[off];
+        x_ok |= ok ? (1ull << i) : 0ull;
+      }
     }
   };
 

@@ -245,8 +245,8 @@ int conv3x3_dgrad_impl(Launcher& L, const float* dz, const float* wpack_t, float
                               0, c0 + c1, h, w, 0, 0, cfg, dx1, c1 > 0 ? c0 : 0);
 }
 
-using WgradA = WgradCfg<4, 1>;   // 128 co x 32 ci per workgroup
-using WgradB = WgradCfg<2, 2>;   //  64 co x 64 ci per workgroup
+using WgradA = WgradCfg<4, 1, 4, 32>;   // 128 co x 32 ci per workgroup, 4x32-pixel K tiles
+using WgradB = WgradCfg<2, 2, 2, 32>;   //  64 co x 64 ci per workgroup, 2x32-pixel K tiles (register budget)
 
 struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
 inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
@@ -255,9 +255,10 @@ inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
   const int MB = p.use_b ? WgradB::MB : WgradA::MB, CB = p.use_b ? WgradB::CB : WgradA::CB;
   p.nMB = (cout + MB - 1) / MB;
   p.nCB = (cin + CB - 1) / CB;
-  p.nTiles = n * ((h + 1) / 2) * ((w + 31) / 32);
+  const int TR = p.use_b ? WgradB::TR : WgradA::TR;
+  p.nTiles = n * ((h + TR - 1) / TR) * ((w + 31) / 32);
   int sk = (1024 + p.nMB * p.nCB - 1) / (p.nMB * p.nCB);          // ~1024 workgroups: two rounds of 2 resident per CU
-  const int max_by_work = (p.nTiles + 7) / 8;                       // at least ~8 pixel tiles per workgroup
+  const int max_by_work = (p.nTiles * TR + 23) / 24;                // at least ~768 pixels of K per workgroup
   if (sk > max_by_work) sk = max_by_work;
   if (sk < 1) sk = 1;
   if (sk > 4096) sk = 4096;
@@ -277,6 +278,11 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3_wgrad: src1 / c1 mismatch");
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3_wgrad: upsampled source needs even H,W");
   if (w % 4) TNV3_FAIL(-1, "conv3x3_wgrad: W must be a multiple of 4 (16-byte dZ loads)");
+  {
+    const int cb = (cout % 128) ? WgradB::CB : WgradA::CB;     // a channel block must come from one source
+    if (c1 > 0 && (c0 % cb)) TNV3_FAIL(-1, "conv3x3_wgrad: two-source input needs C0 %% %d == 0 (got %d)", cb, c0);
+  }
+  if ((long)cout * h * w >= (1l << 31) || (long)(c0 > c1 ? c0 : c1) * h * w >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad: sample too large");
   if (h > 250 * 2 * 1024 || c0 + c1 > 32767) TNV3_FAIL(-1, "conv3x3_wgrad: dimension too large");
   if (ws_bytes < wgrad_workspace_bytes(n, c0, c1, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad: workspace too small");
   const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
