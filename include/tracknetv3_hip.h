@@ -161,6 +161,22 @@ int tnv3_upsample2x_backward(const float* d_hi, float* d_lo, long nc, int hl, in
 int tnv3_mixup(const float* x, const float* lam, const int32_t* perm, float* out, int n, long per_sample,
                tnv3_stream_t stream);
 
+/* ---- InpaintNet backward (train.py:156-164: autograd through Conv1DBlock / predictor) ------------------------ */
+
+/* dPre[N][C][L] = dOut * act'(out); act as in tnv3_conv1d_k3_forward; nlc != 0: dOut/out are [N][L][C]. */
+int tnv3_conv1d_act_backward(const float* dout, const float* out, float* dpre, int n, int c, int l, int act, int nlc,
+                             tnv3_stream_t stream);
+/* dX = conv1d_k3(dPre [N][cout][L], W^T flipped), W = the layer's forward filter [cout][c0+c1][3].  The first c0
+ * channel gradients go to dx0 [N][c0][L], the other c1 to dx1 (NULL when c1 = 0).  accumulate bit 0 / bit 1: add to
+ * dx0 / dx1 instead of overwriting (a skip tensor receives two gradients). */
+int tnv3_conv1d_k3_dgrad(const float* dpre, const float* w, float* dx0, float* dx1, int n, int cout, int c0, int c1,
+                         int l, int accumulate, tnv3_stream_t stream);
+/* dW[cout][c0+c1][3] and db[cout] for X = cat([src0, src1]) ([N][C][L], or [N][L][C] when src_nlc); L <= 64. */
+size_t tnv3_conv1d_k3_wgrad_workspace_bytes(int n, int c0, int c1, int cout);
+int tnv3_conv1d_k3_wgrad(const float* src0, const float* src1, const float* dpre, float* dw, float* db, void* workspace,
+                         size_t workspace_bytes, int n, int c0, int c1, int cout, int l, int src_nlc,
+                         tnv3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

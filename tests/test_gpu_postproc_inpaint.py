@@ -125,3 +125,48 @@ def test_inpaintnet_forward(gpu_device):
         assert (net(c2.to(gpu_device), m2.to(gpu_device)).cpu() - ref).abs().max().item() <= 2e-6
     # int mask as produced by train.py:153 (`.int()`) is accepted like torch.cat's type promotion
     assert (net(c2.to(gpu_device), m2.int().to(gpu_device)).cpu() - ref).abs().max().item() <= 2e-6
+
+
+def test_inpaintnet_train_step_vs_reference_golden(gpu_device):
+    """forward(train) + masked MSE (train.py:159-161) + backward + clip_grad_norm_ + Adam step (train.py:164-166)."""
+    from tracknetv3_amd.model import InpaintNet
+    g = np.load(os.path.join(GOLDEN, "inpaintnet_6x16.npz"))
+    sd = nets.synth_state(nets.inpaintnet_state_shapes(), 77)
+    net = InpaintNet()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(gpu_device).train()
+    n, L = 6, 16
+    coor = nets.synth_input((n, L, 2), 501)
+    vis = (nets.synth_input((n, L, 1), 502) > 0.2).float()
+    coor = coor * vis
+    mask = ((nets.synth_input((n, L, 1), 503) < 0.3).float() * vis).to(gpu_device)
+    gt = nets.synth_input((n, L, 2), 504).to(gpu_device)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt.zero_grad()
+    out = net((coor.to(gpu_device) * (1 - mask)), mask.int())          # train.py:153 passes an int mask
+    loss = torch.nn.MSELoss()(out * mask, gt * mask)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-7
+    params = dict(net.named_parameters())
+    for k, name in enumerate(g["grad_names"]):
+        gr = params[str(name)].grad.double().cpu()
+        assert abs(gr.sum().item() - g["grad_sums"][k]) <= 2e-4 * g["grad_abs"][k] + 1e-9, name
+        assert abs(gr.abs().sum().item() - g["grad_abs"][k]) <= 2e-4 * g["grad_abs"][k] + 1e-9, name
+    d = (params["predictor.weight"].grad.cpu() - torch.from_numpy(g["grad_pred_w"])).abs().max().item()
+    assert d <= 2e-5 * np.abs(g["grad_pred_w"]).max()
+    torch.nn.utils.clip_grad_norm_(net.parameters(), 1)
+    opt.step()
+    # bigger, ragged batch vs fp64 autograd on the oracle
+    n2 = 67
+    c2, m2, g2 = nets.synth_input((n2, L, 2), 9), (nets.synth_input((n2, L, 1), 10) < 0.5).float(), nets.synth_input((n2, L, 2), 11)
+    net2 = InpaintNet()
+    net2.load_state_dict(sd, strict=True)
+    net2 = net2.to(gpu_device).train()
+    o2 = net2(c2.to(gpu_device), m2.to(gpu_device))
+    torch.nn.MSELoss()(o2 * m2.to(gpu_device), (g2 * m2).to(gpu_device)).backward()
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    o64 = nets.inpaintnet_forward(sd64, c2.double(), m2.double())
+    (((o64 - g2.double()) * m2.double()) ** 2).mean().backward()
+    for name, prm in net2.named_parameters():
+        ref = sd64[name].grad
+        assert (prm.grad.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-10, name

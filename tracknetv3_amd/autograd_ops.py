@@ -183,5 +183,73 @@ def wbce_loss(y_pred, y, reduce=True):
     return _WBCELoss.apply(y_pred, y.to(y_pred.dtype), bool(reduce))
 
 
+class _InpaintNetTrain(torch.autograd.Function):
+    """InpaintNet.forward (model.py:113-129) + its backward as one autograd node over the conv1d HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, net, x, m, *params):
+        p = [(w.detach(), b.detach()) for w, b in net.conv_params()]
+        x1 = ops.conv1d_k3(x, *p[0], src1=m, src_nlc=True)
+        x2 = ops.conv1d_k3(x1, *p[1])
+        x3 = ops.conv1d_k3(x2, *p[2])
+        b1 = ops.conv1d_k3(x3, *p[3])
+        b2 = ops.conv1d_k3(b1, *p[4])
+        u1 = ops.conv1d_k3(b2, *p[5], src1=x3)
+        u2 = ops.conv1d_k3(u1, *p[6], src1=x2)
+        u3 = ops.conv1d_k3(u2, *p[7], src1=x1)
+        out = ops.conv1d_k3(u3, *p[8], dst_nlc=True, act=ops.ACT_SIGMOID)
+        ctx.net, ctx.acts, ctx.inp = net, (x1, x2, x3, b1, b2, u1, u2, u3, out), (x, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        net = ctx.net
+        x1, x2, x3, b1, b2, u1, u2, u3, out = ctx.acts
+        x, m = ctx.inp
+        w = [wb[0].detach() for wb in net.conv_params()]
+        g = {}
+
+        def layer(i, dpre, src0, src1=None, src_nlc=False):
+            dw, db = ops.conv1d_k3_wgrad(src0, dpre, src1=src1, src_nlc=src_nlc)
+            g[i] = (dw, db)
+
+        L = ops.ACT_LEAKY_RELU
+        d = ops.conv1d_act_backward(dout.contiguous(), out, ops.ACT_SIGMOID, nlc=True)        # predictor
+        layer(8, d, u3)
+        d_u3, _ = ops.conv1d_k3_dgrad(d, w[8], 32)
+        d = ops.conv1d_act_backward(d_u3, u3, L)                                               # up_3: cat([u2, x1])
+        layer(7, d, u2, x1)
+        d_u2, d_x1 = ops.conv1d_k3_dgrad(d, w[7], 64, 32)
+        d = ops.conv1d_act_backward(d_u2, u2, L)                                               # up_2: cat([u1, x2])
+        layer(6, d, u1, x2)
+        d_u1, d_x2 = ops.conv1d_k3_dgrad(d, w[6], 128, 64)
+        d = ops.conv1d_act_backward(d_u1, u1, L)                                               # up_1: cat([b2, x3])
+        layer(5, d, b2, x3)
+        d_b2, d_x3 = ops.conv1d_k3_dgrad(d, w[5], 256, 128)
+        d = ops.conv1d_act_backward(d_b2, b2, L)                                               # buttleneck.conv_2
+        layer(4, d, b1)
+        d_b1, _ = ops.conv1d_k3_dgrad(d, w[4], 256)
+        d = ops.conv1d_act_backward(d_b1, b1, L)                                               # buttleneck.conv_1
+        layer(3, d, x3)
+        ops.conv1d_k3_dgrad(d, w[3], 128, dx0=d_x3)                                            # += skip gradient of x3
+        d = ops.conv1d_act_backward(d_x3, x3, L)                                               # down_3
+        layer(2, d, x2)
+        ops.conv1d_k3_dgrad(d, w[2], 64, dx0=d_x2)
+        d = ops.conv1d_act_backward(d_x2, x2, L)                                               # down_2
+        layer(1, d, x1)
+        ops.conv1d_k3_dgrad(d, w[1], 32, dx0=d_x1)
+        d = ops.conv1d_act_backward(d_x1, x1, L)                                               # down_1 (inputs need no grad)
+        layer(0, d, x, m, src_nlc=True)
+        out_g = [None, None, None]
+        for i in range(9):
+            out_g.extend(g[i])
+        return tuple(out_g)
+
+
 def inpaintnet_forward_train(net, x, m):
-    raise NotImplementedError("InpaintNet training kernels are not built yet (round 2); inference is supported")
+    x = x.contiguous().float()
+    m = m.contiguous().to(torch.float32)
+    flat = []
+    for wt, b in net.conv_params():
+        flat += [wt, b]
+    return _InpaintNetTrain.apply(net, x, m, *flat)

@@ -144,7 +144,7 @@ int conv1d_k3_impl(Launcher& L, const float* src0, const float* src1, const floa
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv1d_k3: src1 / c1 mismatch");
   if (act < 0 || act > 2) TNV3_FAIL(-1, "conv1d_k3: unknown activation %d", act);
   constexpr int S = 8, COB = 32, CK = 32, LT = 16;
-  Conv1dArgs a{src0, src1, w, b, dst, n, c0, c1, cout, l, src_nlc ? 1 : 0, dst_nlc ? 1 : 0, act};
+  Conv1dArgs a{src0, src1, w, b, dst, n, c0, c1, cout, l, src_nlc ? 1 : 0, dst_nlc ? 1 : 0, act, 0, nullptr, 0, 0};
   const long gx = (n + S - 1) / S;
   if (gx > 0x7fffffffl) TNV3_FAIL(-1, "conv1d_k3: batch too large");
   return L.launch3(conv1d_k3_kernel<S, COB, CK, LT>, (int)gx, (cout + COB - 1) / COB, (l + LT - 1) / LT, S * COB, a);
@@ -351,6 +351,54 @@ template <class Launcher>
 int mixup_impl(Launcher& L, const float* x, const float* lam, const int32_t* perm, float* out, int n, long per_sample) {
   if (!x || !lam || !perm || !out || n <= 0 || per_sample <= 0 || (per_sample % 4)) TNV3_FAIL(-1, "mixup: bad argument");
   return L.launch(mixup_kernel, grid_for((long)n * (per_sample / 4)), 256, x, lam, (const int*)perm, out, n, per_sample);
+}
+
+// ---- InpaintNet backward
+template <class Launcher>
+int conv1d_act_backward_impl(Launcher& L, const float* dout, const float* out, float* dpre, int n, int c, int l, int act, int nlc) {
+  if (!dout || !out || !dpre || n <= 0 || c <= 0 || l <= 0 || act < 0 || act > 2) TNV3_FAIL(-1, "conv1d_act_backward: bad argument");
+  return L.launch(conv1d_act_bwd_kernel, grid_for((long)n * c * l), 256, dout, out, dpre, n, c, l, act, nlc ? 1 : 0);
+}
+
+// dX = conv1d(dPre [N][cout][L], W^T flipped): first c0 input-channel gradients -> dx0, remaining c1 -> dx1
+template <class Launcher>
+int conv1d_k3_dgrad_impl(Launcher& L, const float* dpre, const float* w, float* dx0, float* dx1, int n, int cout, int c0, int c1,
+                         int l, int accumulate) {
+  if (!dpre || !w || !dx0 || n <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || l <= 0) TNV3_FAIL(-1, "conv1d_k3_dgrad: bad argument");
+  if ((c1 > 0) != (dx1 != nullptr)) TNV3_FAIL(-1, "conv1d_k3_dgrad: dx1 / c1 mismatch");
+  constexpr int S = 8, COB = 32, CK = 32, LT = 16;
+  Conv1dArgs a{dpre, nullptr, w, nullptr, dx0, n, cout, 0, c0 + c1, l, 0, 0, 0, 1, dx1, c1 > 0 ? c0 : 0, accumulate};
+  return L.launch3(conv1d_k3_kernel<S, COB, CK, LT>, (n + S - 1) / S, (c0 + c1 + COB - 1) / COB, (l + LT - 1) / LT, S * COB, a);
+}
+
+constexpr int kConv1dLMax = 64;
+inline int conv1d_wgrad_nsplit(int n, int c0, int c1, int cout) {
+  const int blocks = ((c0 + c1 + 31) / 32) * ((cout + 31) / 32);
+  int ns = (1024 + blocks - 1) / blocks;
+  const int by_work = (n + 7) / 8;
+  if (ns > by_work) ns = by_work;
+  return ns < 1 ? 1 : (ns > 256 ? 256 : ns);
+}
+inline size_t conv1d_wgrad_workspace_bytes(int n, int c0, int c1, int cout) {
+  if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0) return 0;
+  return (size_t)conv1d_wgrad_nsplit(n, c0, c1, cout) * ((size_t)cout * (c0 + c1) * 3 + cout) * sizeof(float);
+}
+
+template <class Launcher>
+int conv1d_k3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const float* dpre, float* dw, float* db, void* ws,
+                         size_t ws_bytes, int n, int c0, int c1, int cout, int l, int src_nlc) {
+  if (!src0 || !dpre || !dw || !db || !ws || n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || l <= 0) TNV3_FAIL(-1, "conv1d_k3_wgrad: bad argument");
+  if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv1d_k3_wgrad: src1 / c1 mismatch");
+  if (l > kConv1dLMax) TNV3_FAIL(-1, "conv1d_k3_wgrad: sequence length %d > %d", l, kConv1dLMax);
+  if (ws_bytes < conv1d_wgrad_workspace_bytes(n, c0, c1, cout)) TNV3_FAIL(-1, "conv1d_k3_wgrad: workspace too small");
+  const int ns = conv1d_wgrad_nsplit(n, c0, c1, cout);
+  const long nw = (long)cout * (c0 + c1) * 3, slab = nw + cout;
+  int rc;
+  if (l <= 16) rc = L.launch3(conv1d_wgrad_kernel<8, 16>, (c0 + c1 + 31) / 32, (cout + 31) / 32, ns, 256, src0, src1, dpre, (float*)ws, n, c0, c1, cout, l, src_nlc ? 1 : 0);
+  else rc = L.launch3(conv1d_wgrad_kernel<2, kConv1dLMax>, (c0 + c1 + 31) / 32, (cout + 31) / 32, ns, 256, src0, src1, dpre, (float*)ws, n, c0, c1, cout, l, src_nlc ? 1 : 0);
+  if (rc) return rc;
+  if ((rc = L.launch(sum_partials_strided_kernel, grid_for(nw, 256, 1024), 256, (const float*)ws, dw, nw, ns, slab, 0l))) return rc;
+  return L.launch(sum_partials_strided_kernel, 1, 256, (const float*)ws, db, (long)cout, ns, slab, nw);
 }
 
 }  // namespace tnv3

@@ -308,3 +308,53 @@ def mixup(x, lam, perm):
     out = torch.empty_like(x)
     _lib.check(lib.tnv3_mixup(_lib.ptr(x), _lib.ptr(lam), _lib.ptr(perm), _lib.ptr(out), n, x.numel() // n, _lib.stream_ptr(x)))
     return out
+
+
+# ------------------------------------------------------------------------------------------------- InpaintNet backward
+def conv1d_act_backward(dout, out, act, nlc=False):
+    """dPre[N][C][L] = dOut * act'(out); nlc: dOut/out are (N, L, C)."""
+    lib = _lib.load()
+    _f32(dout, out)
+    _lib.dev_check(dout, out)
+    if nlc:
+        n, l, c = (int(v) for v in out.shape)
+    else:
+        n, c, l = (int(v) for v in out.shape)
+    dpre = torch.empty((n, c, l), dtype=torch.float32, device=out.device)
+    _lib.check(lib.tnv3_conv1d_act_backward(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(dpre), n, c, l, int(act), int(bool(nlc)),
+                                            _lib.stream_ptr(out)))
+    return dpre
+
+
+def conv1d_k3_dgrad(dpre, weight, c0, c1=0, dx0=None, dx1=None):
+    """dX = conv1d(dPre, W^T flipped) split into the two concat operands; pass existing dx0/dx1 to ACCUMULATE into them."""
+    lib = _lib.load()
+    _f32(dpre, weight, dx0, dx1)
+    _lib.dev_check(dpre, weight, dx0, dx1)
+    n, cout, l = (int(v) for v in dpre.shape)
+    if tuple(weight.shape) != (cout, c0 + c1, 3):
+        raise _lib.Tnv3Error("conv1d_k3_dgrad: weight shape mismatch")
+    acc = (1 if dx0 is not None else 0) | (2 if (dx1 is not None and c1) else 0)
+    if dx0 is None:
+        dx0 = torch.empty((n, c0, l), dtype=torch.float32, device=dpre.device)
+    if dx1 is None and c1:
+        dx1 = torch.empty((n, c1, l), dtype=torch.float32, device=dpre.device)
+    _lib.check(lib.tnv3_conv1d_k3_dgrad(_lib.ptr(dpre), _lib.ptr(weight), _lib.ptr(dx0), _lib.ptr(dx1 if c1 else None), n, cout,
+                                        c0, c1, l, acc, _lib.stream_ptr(dpre)))
+    return dx0, (dx1 if c1 else None)
+
+
+def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
+    """(dW [Cout][C0+C1][3], db [Cout]) for X = cat([src0, src1])."""
+    lib = _lib.load()
+    _f32(src0, src1, dpre)
+    _lib.dev_check(src0, src1, dpre)
+    n, cout, l = (int(v) for v in dpre.shape)
+    c0 = int(src0.shape[2] if src_nlc else src0.shape[1])
+    c1 = 0 if src1 is None else int(src1.shape[2] if src_nlc else src1.shape[1])
+    dw = torch.empty((cout, c0 + c1, 3), dtype=torch.float32, device=dpre.device)
+    db = torch.empty(cout, dtype=torch.float32, device=dpre.device)
+    ws = _workspace(lib.tnv3_conv1d_k3_wgrad_workspace_bytes(n, c0, c1, cout), dpre.device)
+    _lib.check(lib.tnv3_conv1d_k3_wgrad(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(dpre), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
+                                        ws.numel() * 8, n, c0, c1, cout, l, int(bool(src_nlc)), _lib.stream_ptr(dpre)))
+    return dw, db
