@@ -48,6 +48,29 @@ def main():
     lam, perm = torch.rand(10, device=dev), torch.randperm(10, device=dev).int()
     ms = timeit(lambda: ops.mixup(x, lam, perm), 20, dev)
     out["mixup_10x27x288x512"] = {"ms": round(ms, 4), "GBps": round(3 * x.numel() * 4 / ms / 1e6, 1)}
+    # ---- BASELINE configs[4]: end-to-end predict.py path on a synthetic stream (frames already resized to 288x512;
+    #      video decode / bicubic resize / median are outside the path)
+    from oracle import nets
+    from tracknetv3_amd.pipeline import predict_video
+    tn = get_model("TrackNet", 8, "concat")
+    tn.load_state_dict(nets.synth_state(nets.tracknet_state_shapes(27, 8), 31, calibrated=True), strict=True)
+    tn = tn.to(dev).eval()
+    t_frames = 264
+    frames = torch.rand(t_frames, 3, 288, 512, device=dev) * 0.2
+    for f in range(t_frames):
+        cx, cy = 20 + f, 60 + (f * 3) % 150
+        frames[f, :, cy - 2:cy + 3, cx - 2:cx + 3] = 1.0
+    med = frames.median(dim=0).values
+    for mode in ("nonoverlap", "weight"):
+        predict_video(frames[:40], tn, net, 8, 16, "concat", mode, 16, (1920, 1080), median=med)      # warm-up
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pd = predict_video(frames, tn, net, 8, 16, "concat", mode, 16, (1920, 1080), median=med)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        assert len(pd["Frame"]) == t_frames
+        out[f"e2e_predict_video_{mode}"] = {"frames": t_frames, "s": round(dt, 4), "fps": round(t_frames / dt, 1),
+                                            "note": "TrackNet(8,concat)+InpaintNet(16), batch 16, frames resident at 288x512"}
     print(json.dumps(out))
 
 

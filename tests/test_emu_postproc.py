@@ -110,3 +110,10 @@ def test_ensemble_stream_emulated_vs_reference_goldens(emu):
         assert np.abs(mine.numpy() - g[f"coor_{j}_ens"]).max() <= 2.5e-7
         j += 1
     assert j == 3
+
+
+def test_predict_video_pipeline_emulated_vs_oracle_flow(emu):
+    """predict.py's whole flow (windows -> net -> ensemble -> peak-find -> inpaint mask -> InpaintNet -> ensemble ->
+    coordinates) on small maps with a synthetic heat-map stub in place of TrackNet."""
+    from pipeline_common import check_pipeline
+    check_pipeline(torch.device("cpu"), 24, 40, 31, 5, "weight")

@@ -170,3 +170,9 @@ def test_inpaintnet_train_step_vs_reference_golden(gpu_device):
     for name, prm in net2.named_parameters():
         ref = sd64[name].grad
         assert (prm.grad.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-10, name
+
+
+@pytest.mark.parametrize("eval_mode", ["weight", "average"])
+def test_predict_video_pipeline_vs_oracle_flow(gpu_device, eval_mode):
+    from pipeline_common import check_pipeline
+    check_pipeline(gpu_device, 288, 512, 45, 10, eval_mode)

@@ -1,0 +1,135 @@
+"""End-to-end trajectory prediction on a frame stream: the `__main__` of the reference's predict.py (predict.py:120-301)
+with every arithmetic stage on the device -- window assembly, TrackNet, temporal ensemble, threshold + peak-find,
+inpaint-mask scan, InpaintNet, blend + COOR_TH threshold, coordinate ensemble, final coordinates.
+
+What stays outside (SURVEY 8f "next"): video decoding, the 1080p -> 288x512 bicubic resize and the median background
+estimate -- `frames` are expected already resized, float in [0, 1], shape (T, 3, 288, 512), resident on the device.
+"""
+import torch
+
+from . import postprocess as pp
+from .utils.general import HEIGHT, WIDTH
+
+
+def _windows(num_frames, seq_len, step, padding):
+    """Frame indices of every input window, as dataset.py:329-354 builds them (padding repeats the last frame)."""
+    out = []
+    last = -1
+    for i in range(0, num_frames, step):
+        idx = []
+        for f in range(seq_len):
+            if i + f < num_frames:
+                idx.append(i + f)
+                last = i + f
+            elif padding:
+                idx.append(last)
+            else:
+                break
+        if len(idx) == seq_len:
+            out.append(idx)
+    return torch.tensor(out, dtype=torch.long).reshape(-1, seq_len)
+
+
+def _assemble(frames, median, widx, bg_mode):
+    """(B, L) frame indices -> network input (B, C, H, W): 'concat' puts the median image first (dataset.py:455-456)."""
+    b, l = widx.shape
+    x = frames[widx.to(frames.device)].reshape(b, l * 3, frames.shape[-2], frames.shape[-1])
+    if bg_mode == "concat":
+        x = torch.cat((median.unsqueeze(0).expand(b, -1, -1, -1), x), dim=1)
+    elif bg_mode not in ("", None):
+        raise NotImplementedError(f"bg_mode '{bg_mode}' needs the difference-frame preprocessing (SURVEY 8f, not built yet)")
+    return x.contiguous()
+
+
+def _index_tensor(widx):
+    i = torch.zeros(widx.shape + (2,), dtype=torch.long)
+    i[..., 1] = widx
+    return i
+
+
+@torch.no_grad()
+def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaintnet_seq_len=16, bg_mode="concat",
+                  eval_mode="weight", batch_size=16, img_shape=None, median=None):
+    """Returns the reference's pred_dict {'Frame','X','Y','Visibility'} (+ 'Inpaint_Mask' when InpaintNet runs)
+    for a (T, 3, 288, 512) frame tensor.  img_shape = (w, h) of the source video (default: the network resolution)."""
+    if eval_mode not in ("nonoverlap", "average", "weight"):
+        raise ValueError("Invalid mode")
+    t = int(frames.shape[0])
+    w_src, h_src = img_shape if img_shape is not None else (WIDTH, HEIGHT)
+    img_scaler = (w_src / WIDTH, h_src / HEIGHT)
+    if bg_mode == "concat" and median is None:
+        median = frames.median(dim=0).values
+    tracknet.eval()
+    pred = {"Frame": [], "X": [], "Y": [], "Visibility": []}
+    seq_len = tracknet_seq_len
+
+    if eval_mode == "nonoverlap":
+        widx = _windows(t, seq_len, seq_len, padding=True)
+        for s in range(0, widx.shape[0], batch_size):
+            wi = widx[s:s + batch_size]
+            y = tracknet(_assemble(frames, median, wi, bg_mode))
+            tmp = pp.predict(_index_tensor(wi), y_pred=y, img_scaler=img_scaler)
+            for k in pred:
+                pred[k].extend(tmp[k])
+    else:
+        widx = _windows(t, seq_len, 1, padding=False)
+        num_sample = int(widx.shape[0])
+        stream = pp.EnsembleStream(seq_len, eval_mode, num_sample)
+        frame_id = 0
+        for s in range(0, num_sample, batch_size):
+            wi = widx[s:s + batch_size]
+            ens = stream.push(tracknet(_assemble(frames, median, wi, bg_mode)))        # (n_frames, H, W), on device
+            n = int(ens.shape[0])
+            ids = torch.zeros((n, 1, 2), dtype=torch.long)
+            ids[:, 0, 1] = torch.arange(frame_id, frame_id + n)
+            frame_id += n
+            tmp = pp.predict(ids, y_pred=ens.unsqueeze(1), img_scaler=img_scaler)
+            for k in pred:
+                pred[k].extend(tmp[k])
+
+    if inpaintnet is None:
+        return pred
+
+    # ---- TrackNetV3 = TrackNet + InpaintNet (predict.py:213-301)
+    inpaintnet.eval()
+    dev = frames.device
+    pred["Inpaint_Mask"] = pp.generate_inpaint_mask(pred, th_h=h_src * 0.05)
+    seq_len = inpaintnet_seq_len
+    n_pts = len(pred["Frame"])
+    coor_all = torch.tensor([pred["X"], pred["Y"]], dtype=torch.float32).t().contiguous()      # source-pixel units
+    coor_all[:, 0] /= w_src
+    coor_all[:, 1] /= h_src
+    mask_all = torch.tensor(pred["Inpaint_Mask"], dtype=torch.float32).reshape(-1, 1)
+    out = {"Frame": [], "X": [], "Y": [], "Visibility": []}
+
+    if eval_mode == "nonoverlap":
+        widx = _windows(n_pts, seq_len, seq_len, padding=True)
+        for s in range(0, widx.shape[0], batch_size):
+            wi = widx[s:s + batch_size]
+            c, m = coor_all[wi].to(dev), mask_all[wi].to(dev)
+            ci = pp.inpaint_blend_threshold(inpaintnet(c, m), c, m)
+            tmp = pp.predict(_index_tensor(wi), c_pred=ci, img_scaler=img_scaler)
+            for k in out:
+                out[k].extend(tmp[k])
+    else:
+        widx = _windows(n_pts, seq_len, 1, padding=False)
+        num_sample = int(widx.shape[0])
+        stream = pp.EnsembleStream(seq_len, eval_mode, num_sample)
+        frame_id = 0
+        for s in range(0, num_sample, batch_size):
+            wi = widx[s:s + batch_size]
+            c, m = coor_all[wi].to(dev), mask_all[wi].to(dev)
+            ci = pp.inpaint_blend_threshold(inpaintnet(c, m), c, m)
+            ens = stream.push(ci)                                                               # (n_frames, 2)
+            th = (ens[:, 0] < pp.COOR_TH) & (ens[:, 1] < pp.COOR_TH)
+            ens = ens.clone()
+            ens[th] = 0.0
+            n = int(ens.shape[0])
+            ids = torch.zeros((n, 1, 2), dtype=torch.long)
+            ids[:, 0, 1] = torch.arange(frame_id, frame_id + n)
+            frame_id += n
+            tmp = pp.predict(ids, c_pred=ens.unsqueeze(1), img_scaler=img_scaler)
+            for k in out:
+                out[k].extend(tmp[k])
+    out["Inpaint_Mask"] = pred["Inpaint_Mask"]
+    return out
