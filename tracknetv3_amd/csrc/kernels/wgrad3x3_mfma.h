@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
   constexpr int WC = Cfg::WC, TR = Cfg::TR, TC = Cfg::TC, NT = Cfg::NT, MB = Cfg::MB, CB = Cfg::CB;
   constexpr int PIX = Cfg::PIX, PIXP = Cfg::PIXP, TRp = Cfg::TRp, TCp = Cfg::TCp, PLANE = Cfg::PLANE, PLANEP = Cfg::PLANEP;
   constexpr int NDZ4 = (MB * PIX / 4 + NT - 1) / NT;     // 16-byte dZ loads per thread per tile
-  constexpr int NX = (CB * PLANE + NT - 1) / NT;         // X halo elements per thread per tile
+  constexpr int NX = CB;                                 // X halo elements per thread per tile (one per channel)
   static_assert((MB * PIX / 4) % NT == 0, "dZ tile must divide evenly over the workgroup");
   __shared__ float lds[Cfg::DZ_FLOATS + Cfg::X_FLOATS];
   float* dz_s = lds;
@@ -66,21 +66,18 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
   const int tilesH = (H + TR - 1) / TR, tilesW = (W + TC - 1) / TC;
   const int nTiles = a.N * tilesH * tilesW;
 
-  // ---- per-thread staging slots (tile independent)
-  // dZ: 16-byte group g = tid + i*NT of [MB][TR][TC/4]; X: element e = tid + i*NT of [CB][TR+2][TC+2]
-  int xs[NX];                                   // ci_l << 16 | tr << 8 | tc, or -1
-#pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int e = tid + i * NT;
-    const int ci_l = e / PLANE, rr = e - ci_l * PLANE;
-    const int tr = rr / TCp, tc = rr - tr * TCp;
-    xs[i] = (e < CB * PLANE && ci0 + ci_l < Cin) ? ((ci_l << 16) | (tr << 8) | tc) : -1;
-  }
+  // ---- per-thread staging roles (tile independent)
+  // dZ: 16-byte group g = tid + i*NT of [MB][TR][TC/4].   X: thread tid < PLANE owns ONE (row, col) of the halo plane and
+  // walks the CB channels (i = channel): no per-slot coordinates to keep, two instructions per element.
+  static_assert(PLANE <= NT, "one thread per halo-plane element");
+  const int x_tr = tid / TCp, x_tc = tid - x_tr * TCp;
+  const bool x_thread = tid < PLANE;
 
   f32x4 rdz[NDZ4];
   float rx[NX];
-  unsigned long long dz_ok = 0, x_ok = 0;       // validity bits of the tile currently held in registers
-  static_assert(NDZ4 <= 64 && NX <= 64, "validity masks are 64-bit");
+  unsigned dz_ok = 0;                           // validity bits of the dZ groups currently held in registers
+  bool x_ok = false;                            // this thread's halo position is inside the image
+  static_assert(NDZ4 <= 32, "validity mask is 32-bit");
 
   // The whole ci block comes from ONE source (host guarantees C0 % CB == 0 for a two-source input), so the source,
   // its plane geometry and the upsample flag are workgroup-uniform: one branch per tile, none per element.
@@ -95,7 +92,7 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
     const int trem = tile - n * (tilesH * tilesW);
     const int h0 = (trem / tilesW) * TR, w0 = (trem % tilesW) * TC;
     const float* dzn = a.dz + (size_t)n * Cout * HW;
-    dz_ok = 0; x_ok = 0;
+    dz_ok = 0;
 #pragma unroll
     for (int i = 0; i < NDZ4; ++i) {
       const int g = tid + i * NT;
@@ -105,30 +102,15 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
       const bool ok = co < Cout && gh < H && gw < W;            // W % 4 == 0: a 16-byte group is all-in or all-out
       const int off = ok ? (co * HW + gh * W + gw) : 0;
       rdz[i] = *reinterpret_cast<const f32x4*>(dzn + off);
-      dz_ok |= ok ? (1ull << i) : 0ull;
+      dz_ok |= ok ? (1u << i) : 0u;
     }
-    const float* xn = xsrc + ((size_t)n * Cs + cib) * HWs;
-    if (up) {
+    const int gh = h0 - 1 + x_tr, gw = w0 - 1 + x_tc;
+    x_ok = x_thread && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+    const int sp_off = x_ok ? (up ? (gh >> 1) * Ws + (gw >> 1) : gh * Ws + gw) : 0;
+    const float* xn = xsrc + ((size_t)n * Cs + cib) * HWs + sp_off;
+    const int nch = Cs - cib;                                    // channels of this source from cib on (>= 1)
 #pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        const int s = xs[i];
-        const int gh = h0 - 1 + ((s >> 8) & 255), gw = w0 - 1 + (s & 255);
-        const bool ok = s != -1 && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        const int off = ok ? ((s >> 16) * HWs + (gh >> 1) * Ws + (gw >> 1)) : 0;
-        rx[i] = xn[off];
-        x_ok |= ok ? (1ull << i) : 0ull;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        const int s = xs[i];
-        const int gh = h0 - 1 + ((s >> 8) & 255), gw = w0 - 1 + (s & 255);
-        const bool ok = s != -1 && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        const int off = ok ? ((s >> 16) * HWs + gh * Ws + gw) : 0;
-        rx[i] = xn[off];
-        x_ok |= ok ? (1ull << i) : 0ull;
-      }
-    }
+    for (int i = 0; i < NX; ++i) rx[i] = xn[(size_t)(i < nch ? i : 0) * HWs];
   };
 
   auto store_tile = [&]() {
@@ -138,16 +120,13 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
       const int c4 = g % (TC / 4), t2 = g / (TC / 4);
       const int r = t2 % TR, co_l = t2 / TR;
       float* d = dz_s + co_l * PIXP + r * TC + 4 * c4;          // odd row stride: four scalar stores
-      const bool ok = (dz_ok >> i) & 1ull;
+      const bool ok = (dz_ok >> i) & 1u;
       d[0] = ok ? rdz[i][0] : 0.0f; d[1] = ok ? rdz[i][1] : 0.0f; d[2] = ok ? rdz[i][2] : 0.0f; d[3] = ok ? rdz[i][3] : 0.0f;
     }
+    if (x_thread) {
+      const int nch = Cs - cib;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int e = tid + i * NT;
-      if ((i + 1) * NT <= CB * PLANE || e < CB * PLANE) {
-        const int ci_l = e / PLANE, rr = e - ci_l * PLANE;
-        x_s[ci_l * PLANEP + rr] = ((x_ok >> i) & 1ull) ? rx[i] : 0.0f;
-      }
+      for (int i = 0; i < NX; ++i) x_s[i * PLANEP + tid] = (x_ok && i < nch) ? rx[i] : 0.0f;
     }
   };
 

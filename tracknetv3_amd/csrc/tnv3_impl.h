@@ -246,7 +246,7 @@ int conv3x3_dgrad_impl(Launcher& L, const float* dz, const float* wpack_t, float
 }
 
 using WgradA = WgradCfg<4, 1, 4, 32>;   // 128 co x 32 ci per workgroup, 4x32-pixel K tiles
-using WgradB = WgradCfg<2, 2, 2, 32>;   //  64 co x 64 ci per workgroup, 2x32-pixel K tiles (register budget)
+using WgradB = WgradCfg<2, 2, 4, 32>;   //  64 co x 64 ci per workgroup, 4x32-pixel K tiles
 
 struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
 inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
