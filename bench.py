@@ -55,7 +55,10 @@ def tune(dev, batch, out_paths):
     ncfg = ops.conv3x3_num_configs()
     infos = [ops.conv3x3_config_info(c) for c in range(ncfg)]
     best, report, seen = {}, [], set()
-    for name, c0, c1, cout, h, w, up in conv_layer_table(in_dim, H, W):
+    shapes = list(conv_layer_table(in_dim, H, W))
+    # data-gradient convolutions of the training step: dX = conv(dZ, W^T): Cout' = Cin, Cin' = Cout, single source
+    shapes += [(name + ":dgrad", cout, 0, c0 + c1, h, w, False) for (name, c0, c1, cout, h, w, up) in shapes[1:]]
+    for name, c0, c1, cout, h, w, up in shapes:
         key = f"{cout},{c0 + c1},{batch},{h},{w}"
         if key in seen:
             continue

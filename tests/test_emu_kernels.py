@@ -40,6 +40,8 @@ CONV_CASES = [
     (1, 1, 10, 0, 64, 16, 32, False, False, False),
     (6, 1, 8, 0, 256, 8, 32, False, False, False),     # several channel blocks -> XCD block map
     (-1, 1, 32, 32, 192, 4, 8, True, True, True),      # 3 channel blocks -> fallback block map, auto config
+    (8, 1, 7, 0, 64, 12, 40, False, True, True),       # 512-thread workgroups
+    (9, 1, 32, 32, 128, 6, 32, True, False, True),
 ]
 
 

@@ -32,8 +32,10 @@ using ConvC3 = ConvCfg<2, 4, 2, 2, 8, 32, 4>;    // 128 ch x ( 8x32 px), wave = 
 using ConvC4 = ConvCfg<2, 2, 2, 2, 4, 32, 4>;    // 128 ch x ( 4x32 px)
 using ConvC5 = ConvCfg<2, 2, 1, 4, 4, 64, 8>;    // 64 ch x ( 4x64 px)
 using ConvC6 = ConvCfg<4, 2, 1, 4, 8, 32, 8>;    // 128 ch x ( 8x32 px), CC = 8
-using ConvC7 = ConvCfg<2, 1, 1, 4, 4, 32, 8>;    // 64 ch x ( 4x32 px)  (small images)
-constexpr int kNumConvConfigs = 8;
+using ConvC7 = ConvCfg<2, 1, 1, 4, 4, 32, 8>;    // 64 ch x ( 4x32 px): 3 waves/SIMD
+using ConvC8 = ConvCfg<2, 1, 1, 8, 8, 32, 8>;    // 64 ch x ( 8x32 px), 512 threads: cfg 7's wave tile, weight panel shared by 8 waves
+using ConvC9 = ConvCfg<2, 1, 2, 4, 4, 32, 4>;    // 128 ch x ( 4x32 px), 512 threads: input tile shared by two channel halves
+constexpr int kNumConvConfigs = 10;
 
 struct ConvCfgInfo { int MB, TR, TC, CC, NT, LDS; };
 template <class C> constexpr ConvCfgInfo cfg_info() { return {C::MB, C::TR, C::TC, C::CC, C::NT, C::LDS_BYTES}; }
@@ -47,6 +49,8 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
     case 5: return cfg_info<ConvC5>();
     case 6: return cfg_info<ConvC6>();
     case 7: return cfg_info<ConvC7>();
+    case 8: return cfg_info<ConvC8>();
+    case 9: return cfg_info<ConvC9>();
     default: return {0, 0, 0, 0, 0, 0};
   }
 }
@@ -94,6 +98,8 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
     case 5: return launch_conv_cfg<ConvC5>(L, a);
     case 6: return launch_conv_cfg<ConvC6>(L, a);
     case 7: return launch_conv_cfg<ConvC7>(L, a);
+    case 8: return launch_conv_cfg<ConvC8>(L, a);
+    case 9: return launch_conv_cfg<ConvC9>(L, a);
     default: TNV3_FAIL(-1, "conv3x3: unknown config %d", cfg);
   }
 }
