@@ -177,6 +177,13 @@ int tnv3_conv1d_k3_wgrad(const float* src0, const float* src1, const float* dpre
                          size_t workspace_bytes, int n, int c0, int c1, int cout, int l, int src_nlc,
                          tnv3_stream_t stream);
 
+/* ---- diagnostics ----------------------------------------------------------------------------------------- */
+
+/* Register-only v_mfma_f32_32x32x2_f32 loop: `blocks` workgroups of 256 threads, each wave issuing iters*8 MFMAs
+ * (2*32*32*2 FLOP each).  out: blocks*256 floats (keeps the work observable).  Measures the sustained fp32 matrix
+ * rate of the chip as clocked under load, to set next to the conv kernels' TFLOP/s. */
+int tnv3_mfma_f32_probe(float* out, int blocks, int iters, tnv3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

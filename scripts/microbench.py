@@ -29,6 +29,15 @@ def main():
     from tracknetv3_amd.utils.general import get_model
     dev = torch.device("cuda:0")
     out = {}
+    # sustained fp32 MFMA rate of this chip under load (register-only probe): the practical ceiling of the conv kernels
+    from tracknetv3_amd import _lib
+    lib = _lib.load()
+    for blocks, label in ((256 * 1, "1wg_per_cu"), (256 * 3, "3wg_per_cu"), (256 * 8, "8wg_per_cu")):
+        buf = torch.empty(blocks * 256, device=dev)
+        iters = 4000
+        ms = timeit(lambda: _lib.check(lib.tnv3_mfma_f32_probe(_lib.ptr(buf), blocks, iters, _lib.stream_ptr(buf))), 5, dev)
+        flops = blocks * 4 * iters * 8 * (2.0 * 32 * 32 * 2)
+        out[f"mfma_f32_probe_{label}"] = {"ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 1)}
     net = get_model("InpaintNet").to(dev).eval()
     for n in (32, 4096, 65536):
         x, m = torch.rand(n, 16, 2, device=dev), (torch.rand(n, 16, 1, device=dev) < 0.3).float()

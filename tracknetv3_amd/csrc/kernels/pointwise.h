@@ -74,4 +74,28 @@ __global__ void __launch_bounds__(256) maxpool2x2_kernel(const float* __restrict
   }
 }
 
+// Diagnostic: sustained v_mfma_f32_32x32x2_f32 rate of the chip as it is clocked under load -- every wave issues
+// `iters` x 8 independent accumulator chains from registers only (no LDS, no global traffic in the loop).  Used by
+// scripts/microbench.py to put the conv kernels' TFLOP/s next to what the matrix pipe delivers at the same time.
+__global__ void __launch_bounds__(256) mfma_f32_probe_kernel(float* __restrict__ out, int iters, float a0, float b0) {
+  typedef float pf32x16 __attribute__((ext_vector_type(16)));
+  pf32x16 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+  float a = a0 + (float)(threadIdx.x & 7) * 1e-3f, b = b0 - (float)(threadIdx.x & 3) * 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[k], 0, 0, 0);
+    a += 1e-6f;
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[k][r];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 }  // namespace tnv3

@@ -199,6 +199,12 @@ int heatmap_peakfind_impl(Launcher& L, const float* heat, float thr, int tie_las
                   tie_last_wins ? 1 : 0);
 }
 
+template <class Launcher>
+int mfma_probe_impl(Launcher& L, float* out, int blocks, int iters) {
+  if (!out || blocks <= 0 || iters <= 0) TNV3_FAIL(-1, "mfma_probe: bad argument");
+  return L.launch(mfma_f32_probe_kernel, blocks, 256, out, iters, 0.5f, 0.25f);
+}
+
 // ------------------------------------------------------------------------------------------ training entry points
 inline int grid_for(long items, int per_block = 256, int cap = 65536) {
   const long g = (items + per_block - 1) / per_block;
