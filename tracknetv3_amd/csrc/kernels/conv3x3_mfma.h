@@ -45,10 +45,14 @@ struct Conv3x3Args {
   int relu;             // 1: y = max(y, 0)
 };
 
-template <int MT_, int NTW_, int WM_, int WN_, int TR_, int TC_, int CC_, int MINW_ = 1>
+template <int MT_, int NTW_, int WM_, int WN_, int TR_, int TC_, int CC_, int MINW_ = 1, int PF_ = 1, int PRIO_ = 0>
 struct ConvCfg {
   static constexpr int MT = MT_, NTW = NTW_, WM = WM_, WN = WN_, TR = TR_, TC = TC_, CC = CC_;
   static constexpr int MINW = MINW_;                 // __launch_bounds__ 2nd argument: waves per SIMD to fit
+  static constexpr int PF = PF_;                     // K-steps of operand prefetch (LDS reads run PF steps ahead of the MFMAs)
+  static constexpr int PRIO = PRIO_;                 // 1: s_setprio(1) around the MFMA block (co-resident workgroups are
+                                                     //    in different phases; favour the wave that can feed the matrix pipe)
+  static_assert(PF == 1 || PF == 2, "prefetch distance");
   static constexpr int NT = WM * WN * 64;            // threads per workgroup
   static constexpr int MB = MT * 32 * WM;            // output channels per workgroup
   static constexpr int CS = TC / 32;                 // 32-pixel column segments per tile row
@@ -218,7 +222,8 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
     // K-steps of this chunk: step s = (channel pair cp, tap); operands of step s+1 are read from LDS before
     // the MFMAs of step s are issued (static double buffer), so LDS latency hides under the matrix pipe.
     constexpr int NSTEP = (CC / 2) * 9;
-    float av[2][MT], bv[2][NTW];
+    constexpr int RING = Cfg::PF + 1;
+    float av[RING][MT], bv[RING][NTW];
     auto read_step = [&](int s, float (&ar)[MT], float (&br)[NTW]) {
       const int cp = s / 9, tap = s - 9 * cp;
       const int kh = tap / 3, kw = tap - 3 * kh;
@@ -227,19 +232,22 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
 #pragma unroll
       for (int j = 0; j < NTW; ++j) br[j] = B[(2 * cp * TRp + kh + j / CS) * TCp + kw + (j % CS) * 32];
     };
+    if (Cfg::PRIO) __builtin_amdgcn_s_setprio(1);
     read_step(0, av[0], bv[0]);
+    if (Cfg::PF == 2) read_step(1, av[1], bv[1]);
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-      if (s + 1 < NSTEP) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+      if (s + Cfg::PF < NSTEP) read_step(s + Cfg::PF, av[(s + Cfg::PF) % RING], bv[(s + Cfg::PF) % RING]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
-          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mt], bv[s & 1][j], acc[mt][j], 0, 0, 0);
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING][mt], bv[s % RING][j], acc[mt][j], 0, 0, 0);
       // pin the order "LDS reads of step s+1, then the MFMAs of step s" in the machine scheduler
       __builtin_amdgcn_sched_group_barrier(0x100, MT + NTW, 0);   // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);   // MFMA
     }
+    if (Cfg::PRIO) __builtin_amdgcn_s_setprio(0);
 
     if (k + 1 < nChunks) store_stage(buf ^ 1, k + 1);
     __syncthreads();

@@ -35,7 +35,12 @@ using ConvC6 = ConvCfg<4, 2, 1, 4, 8, 32, 8>;    // 128 ch x ( 8x32 px), CC = 8
 using ConvC7 = ConvCfg<2, 1, 1, 4, 4, 32, 8>;    // 64 ch x ( 4x32 px): 3 waves/SIMD
 using ConvC8 = ConvCfg<2, 1, 1, 8, 8, 32, 8>;    // 64 ch x ( 8x32 px), 512 threads: cfg 7's wave tile, weight panel shared by 8 waves
 using ConvC9 = ConvCfg<2, 1, 2, 4, 4, 32, 4>;    // 128 ch x ( 4x32 px), 512 threads: input tile shared by two channel halves
-constexpr int kNumConvConfigs = 10;
+using ConvC10 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 1, 1>;   // cfg 8 + setprio
+using ConvC11 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 0>;   // cfg 8 + 2-step operand prefetch
+using ConvC12 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1>;   // cfg 8 + both
+using ConvC13 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1>;   // cfg 9 + both
+using ConvC14 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1>;   // cfg 7 + both
+constexpr int kNumConvConfigs = 15;
 
 struct ConvCfgInfo { int MB, TR, TC, CC, NT, LDS; };
 template <class C> constexpr ConvCfgInfo cfg_info() { return {C::MB, C::TR, C::TC, C::CC, C::NT, C::LDS_BYTES}; }
@@ -51,6 +56,11 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
     case 7: return cfg_info<ConvC7>();
     case 8: return cfg_info<ConvC8>();
     case 9: return cfg_info<ConvC9>();
+    case 10: return cfg_info<ConvC10>();
+    case 11: return cfg_info<ConvC11>();
+    case 12: return cfg_info<ConvC12>();
+    case 13: return cfg_info<ConvC13>();
+    case 14: return cfg_info<ConvC14>();
     default: return {0, 0, 0, 0, 0, 0};
   }
 }
@@ -100,6 +110,11 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
     case 7: return launch_conv_cfg<ConvC7>(L, a);
     case 8: return launch_conv_cfg<ConvC8>(L, a);
     case 9: return launch_conv_cfg<ConvC9>(L, a);
+    case 10: return launch_conv_cfg<ConvC10>(L, a);
+    case 11: return launch_conv_cfg<ConvC11>(L, a);
+    case 12: return launch_conv_cfg<ConvC12>(L, a);
+    case 13: return launch_conv_cfg<ConvC13>(L, a);
+    case 14: return launch_conv_cfg<ConvC14>(L, a);
     default: TNV3_FAIL(-1, "conv3x3: unknown config %d", cfg);
   }
 }
