@@ -42,8 +42,9 @@ CONV_CASES = [
     (-1, 1, 32, 32, 192, 4, 8, True, True, True),      # 3 channel blocks -> fallback block map, auto config
     (8, 1, 7, 0, 64, 12, 40, False, True, True),       # 512-thread workgroups
     (9, 1, 32, 32, 128, 6, 32, True, False, True),
-    (12, 1, 6, 0, 64, 8, 32, False, True, True),       # 2-step operand prefetch ring
-    (13, 1, 8, 0, 128, 5, 33, False, False, False),
+    (10, 1, 6, 0, 64, 8, 32, False, True, True),       # 2-step operand prefetch ring
+    (11, 1, 8, 0, 128, 5, 33, False, False, False),
+    (12, 2, 3, 0, 64, 4, 32, False, True, True),
 ]
 
 

@@ -35,12 +35,10 @@ using ConvC6 = ConvCfg<4, 2, 1, 4, 8, 32, 8>;    // 128 ch x ( 8x32 px), CC = 8
 using ConvC7 = ConvCfg<2, 1, 1, 4, 4, 32, 8>;    // 64 ch x ( 4x32 px): 3 waves/SIMD
 using ConvC8 = ConvCfg<2, 1, 1, 8, 8, 32, 8>;    // 64 ch x ( 8x32 px), 512 threads: cfg 7's wave tile, weight panel shared by 8 waves
 using ConvC9 = ConvCfg<2, 1, 2, 4, 4, 32, 4>;    // 128 ch x ( 4x32 px), 512 threads: input tile shared by two channel halves
-using ConvC10 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 1, 1>;   // cfg 8 + setprio
-using ConvC11 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 0>;   // cfg 8 + 2-step operand prefetch
-using ConvC12 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1>;   // cfg 8 + both
-using ConvC13 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1>;   // cfg 9 + both
-using ConvC14 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1>;   // cfg 7 + both
-constexpr int kNumConvConfigs = 15;
+using ConvC10 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1>;   // cfg 8 + 2-step operand prefetch + setprio around the MFMA block
+using ConvC11 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1>;   // cfg 9 + both (+1.5 % measured)
+using ConvC12 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1>;   // cfg 7 + both
+constexpr int kNumConvConfigs = 13;
 
 struct ConvCfgInfo { int MB, TR, TC, CC, NT, LDS; };
 template <class C> constexpr ConvCfgInfo cfg_info() { return {C::MB, C::TR, C::TC, C::CC, C::NT, C::LDS_BYTES}; }
@@ -59,8 +57,6 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
     case 10: return cfg_info<ConvC10>();
     case 11: return cfg_info<ConvC11>();
     case 12: return cfg_info<ConvC12>();
-    case 13: return cfg_info<ConvC13>();
-    case 14: return cfg_info<ConvC14>();
     default: return {0, 0, 0, 0, 0, 0};
   }
 }
@@ -70,7 +66,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // Library default when the caller passes cfg = -1 (overridden per layer by the tuned table on the Python
 // side).  Measured on MI355X (profiles/r01_*): the small 4x32-pixel tiles win on every TrackNet layer because
 // they run 3 waves per SIMD; 128-channel blocks are marginally better when Cout allows.
-inline int conv_auto_config(int /*N*/, int Cout, int /*H*/, int /*W*/) { return (Cout % 128 == 0) ? 4 : 7; }
+inline int conv_auto_config(int /*N*/, int Cout, int /*H*/, int /*W*/) { return (Cout % 128 == 0) ? 11 : 12; }
 
 template <class Cfg, class Launcher>
 int launch_conv_cfg(Launcher& L, const Conv3x3Args& a) {
@@ -113,8 +109,6 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
     case 10: return launch_conv_cfg<ConvC10>(L, a);
     case 11: return launch_conv_cfg<ConvC11>(L, a);
     case 12: return launch_conv_cfg<ConvC12>(L, a);
-    case 13: return launch_conv_cfg<ConvC13>(L, a);
-    case 14: return launch_conv_cfg<ConvC14>(L, a);
     default: TNV3_FAIL(-1, "conv3x3: unknown config %d", cfg);
   }
 }
