@@ -148,24 +148,30 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
     // ---- MFMA: K-step = two horizontally adjacent pixels of one tile row
     const float* A = dz_s + a_off;
     const float* B = x_s + b_off;
-    // operands of K-step s+1 are read before the nine MFMAs of step s (static double buffer), as in the forward kernel
-    constexpr int NSTEP = TR * (TC / 2);
-    float av[2], bv[2][9];
-    auto read_step = [&](int s, float& ar, float (&br)[9]) {
-      const int r = s / (TC / 2), j = s - r * (TC / 2);
-      ar = A[r * TC + 2 * j];
+    // Per tile row: 16 K-steps (two adjacent pixels each), fully unrolled; operands of step s+1 are read before the
+    // nine MFMAs of step s (static double buffer), as in the forward kernel.  The row loop stays rolled (code size /
+    // compile time); the one-step pipeline refill per row costs ~1 %.
+    constexpr int NSTEP = TC / 2;
+#pragma unroll 1
+    for (int r = 0; r < TR; ++r) {
+      const float* Ar = A + r * TC;
+      const float* Br = B + r * TCp;
+      float av[2], bv[2][9];
+      auto read_step = [&](int s, float& ar, float (&br)[9]) {
+        ar = Ar[2 * s];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) br[tap] = B[(r + tap / 3) * TCp + 2 * j + (tap % 3)];
-    };
-    read_step(0, av[0], bv[0]);
+        for (int tap = 0; tap < 9; ++tap) br[tap] = Br[(tap / 3) * TCp + 2 * s + (tap % 3)];
+      };
+      read_step(0, av[0], bv[0]);
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      if (s + 1 < NSTEP) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+      for (int s = 0; s < NSTEP; ++s) {
+        if (s + 1 < NSTEP) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][tap], acc[tap], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // DS reads of step s+1
-      __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);    // MFMAs of step s
+        for (int tap = 0; tap < 9; ++tap)
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][tap], acc[tap], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // DS reads of step s+1
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);    // MFMAs of step s
+      }
     }
   }
 
