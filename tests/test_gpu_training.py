@@ -185,3 +185,35 @@ def test_train_then_eval_and_optimizer_step(gpu_device):
     with torch.no_grad():
         ref = nets.tracknet_forward(sd, x.cpu(), training=False)
     assert (e1.cpu() - ref).abs().max().item() <= 1e-4
+
+
+def test_mixup_with_reference_rng_protocol(gpu_device):
+    """train_utils.mixup draws lambda / permutation exactly like train.py:33-36 (numpy Beta, torch.randperm on the host);
+    with the same seeds the result equals the oracle's mixup on those draws."""
+    from tracknetv3_amd.train_utils import mixup
+    x, y = nets.synth_input((6, 27, 32, 64), 1), nets.synth_input((6, 8, 32, 64), 2)
+    np.random.seed(13)
+    torch.manual_seed(13)
+    xm, ym = mixup(x.to(gpu_device), y.to(gpu_device), 0.5)
+    np.random.seed(13)
+    torch.manual_seed(13)
+    lamb = np.random.beta(0.5, 0.5, size=6)
+    index = torch.randperm(6)
+    xo, yo = nets.mixup_injected(x, y, lamb, index)
+    assert (xm.cpu() - xo).abs().max().item() <= 1e-6 and (ym.cpu() - yo).abs().max().item() <= 1e-6
+
+
+def test_tracknet_trainer_single_rank(gpu_device):
+    """parallel.TrackNetTrainer without torch.distributed: mixup + step protocol of train.py:84-96, device-scalar loss."""
+    from tracknetv3_amd.parallel import TrackNetTrainer
+    from tracknetv3_amd.utils.general import get_model
+    torch.manual_seed(1)
+    net = get_model("TrackNet", 3, "concat").to(gpu_device)
+    tr = TrackNetTrainer(net, torch.optim.Adam(net.parameters(), lr=1e-3), alpha=0.5, seed=13)
+    x = nets.synth_input((4, 12, 32, 64), 5).to(gpu_device)
+    y = nets.disc_heatmaps(4, 3, 32, 64, 6).to(gpu_device)
+    losses = [tr.step(x, y) for _ in range(5)]
+    assert all(l.is_cuda and l.dim() == 0 for l in losses)
+    vals = [l.item() for l in losses]
+    assert np.isfinite(vals).all() and min(vals[1:]) < vals[0]
+    assert int(net.down_block_1.conv_1.bn.num_batches_tracked) == 5

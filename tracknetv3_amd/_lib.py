@@ -62,12 +62,7 @@ def _declare(lib):
     sig("tnv3_conv1d_k3_dgrad", i, p, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_conv1d_k3_wgrad_workspace_bytes", sz, i, i, i, i)
     sig("tnv3_conv1d_k3_wgrad", i, p, p, p, p, p, p, sz, i, i, i, i, i, i, p)
-    for name, spec in _OPTIONAL.items():
-        if hasattr(lib, name):
-            sig(name, *spec)
 
-
-_OPTIONAL = {}   # later entry points register here: name -> (restype, *argtypes)
 
 EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "tnv3_conv3x3_config_info",
            "tnv3_conv3x3_packed_floats", "tnv3_pack_conv3x3_weights", "tnv3_bn_eval_scale", "tnv3_conv3x3_forward",

@@ -160,10 +160,6 @@ def tracknet_forward_train(net, x):
     return _TrackNetTrain.apply(net, x, *params)
 
 
-def conv_bn_relu_train(blk, x):
-    raise NotImplementedError("Conv2DBlock is trained through TrackNet.forward (one autograd node for the whole network)")
-
-
 class _WBCELoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y_pred, y, reduce):

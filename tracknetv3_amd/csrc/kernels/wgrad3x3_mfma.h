@@ -150,26 +150,26 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
     const float* B = x_s + b_off;
     // Per tile row: 16 K-steps (two adjacent pixels each), fully unrolled; operands of step s+1 are read before the
     // nine MFMAs of step s (static double buffer), as in the forward kernel.  The row loop stays rolled (code size /
-    // compile time); the one-step pipeline refill per row costs ~1 %.
+    // compile time) and the operand pipeline is carried across it: the last step of row r prefetches step 0 of row r+1.
     constexpr int NSTEP = TC / 2;
+    static_assert(NSTEP % 2 == 0, "ring slot of the carried prefetch");
+    float av[2], bv[2][9];
+    auto read_step = [&](int r, int s, float& ar, float (&br)[9]) {
+      ar = A[r * TC + 2 * s];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) br[tap] = B[(r + tap / 3) * TCp + 2 * s + (tap % 3)];
+    };
+    read_step(0, 0, av[0], bv[0]);
 #pragma unroll 1
     for (int r = 0; r < TR; ++r) {
-      const float* Ar = A + r * TC;
-      const float* Br = B + r * TCp;
-      float av[2], bv[2][9];
-      auto read_step = [&](int s, float& ar, float (&br)[9]) {
-        ar = Ar[2 * s];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) br[tap] = Br[(tap / 3) * TCp + 2 * s + (tap % 3)];
-      };
-      read_step(0, av[0], bv[0]);
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
-        if (s + 1 < NSTEP) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+        if (s + 1 < NSTEP) read_step(r, s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+        else if (r + 1 < TR) read_step(r + 1, 0, av[0], bv[0]);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][tap], acc[tap], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // DS reads of step s+1
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // DS reads of the next step
         __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);    // MFMAs of step s
       }
     }

@@ -77,7 +77,7 @@ class Conv2DBlock(nn.Module):
             self._cache["aff"] = hit
         return hit[1]
 
-    def forward_eval(self, x, skip=None, up=False, layer_key=None):
+    def forward_eval(self, x, skip=None, up=False):
         bn = self.bn
         n = x.shape[0]
         h = x.shape[2] * (2 if up else 1)
@@ -88,9 +88,10 @@ class Conv2DBlock(nn.Module):
 
     def forward(self, x):
         if self.training:
-            from . import autograd_ops
-            return autograd_ops.conv_bn_relu_train(self, x)
-        return self.forward_eval(x)
+            raise RuntimeError("a Conv2DBlock is trained through TrackNet.forward (the whole network is one autograd node); "
+                               "call the block directly only in eval mode")
+        with torch.no_grad():
+            return self.forward_eval(x.contiguous())
 
 
 class Double2DConv(nn.Module):
