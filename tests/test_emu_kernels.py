@@ -142,3 +142,20 @@ def test_inpaintnet_forward_emulated_vs_golden(emu):
         with torch.no_grad():
             ref = nets.inpaintnet_forward(sd, c2, m2)
         assert (net(c2, m2) - ref).abs().max().item() <= 2e-6
+
+
+def test_empty_batches_are_accepted(emu):
+    """N = 0 flows through the reference's torch ops; the boundary accepts it too (no launch, empty result)."""
+    from tracknetv3_amd import ops
+    from tracknetv3_amd.model import InpaintNet, TrackNet
+    m = TrackNet(9, 3).eval()
+    assert m(torch.zeros((0, 9, 16, 32))).shape == (0, 3, 16, 32)
+    net = InpaintNet().eval()
+    assert net(torch.zeros((0, 16, 2)), torch.zeros((0, 16, 1))).shape == (0, 16, 2)
+    assert ops.heatmap_peakfind(torch.zeros((0, 8, 16))).shape == (0, 4)
+    with pytest.raises(ValueError):
+        m(torch.zeros((1, 8, 16, 32)))                # wrong channel count
+    with pytest.raises(ValueError):
+        m(torch.zeros((1, 9, 12, 32)))                # H not divisible by 8
+    with pytest.raises(ValueError):
+        net(torch.zeros((2, 16, 3)), torch.zeros((2, 16, 1)))

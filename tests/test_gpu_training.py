@@ -217,3 +217,28 @@ def test_tracknet_trainer_single_rank(gpu_device):
     vals = [l.item() for l in losses]
     assert np.isfinite(vals).all() and min(vals[1:]) < vals[0]
     assert int(net.down_block_1.conv_1.bn.num_batches_tracked) == 5
+
+
+def test_baseline_config1_train_forward_wbce_288x512(gpu_device):
+    """BASELINE configs[0]: TrackNet seq_len=3 bg_mode='' batch 2, 288x512, train-mode forward + WBCE (the reference's
+    CPU-runnable plumbing case) -- GPU path vs the oracle evaluated here on the host CPU, plus backward sanity."""
+    from tracknetv3_amd.utils.general import get_model
+    from tracknetv3_amd.utils.metric import WBCELoss
+    seed = 13                                                        # the reference's default seed (train.py:195)
+    sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), seed, calibrated=False)
+    m = get_model("TrackNet", 3, "")
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu_device).train()
+    x = nets.synth_input((2, 9, 288, 512), seed + 1000)
+    y = nets.disc_heatmaps(2, 3, 288, 512, seed + 2000)
+    p = m(x.to(gpu_device))
+    loss = WBCELoss(p, y.to(gpu_device))
+    with torch.no_grad():
+        p_ref = nets.tracknet_forward(sd, x, training=True)
+        l_ref = nets.wbce_loss(p_ref, y)
+    assert (p.detach().cpu() - p_ref).abs().max().item() <= 1e-4
+    assert abs(loss.item() - l_ref.item()) <= 1e-5
+    assert 0.05 < loss.item() < 1.0                                   # SURVEY 8d: "expected order: loss ~ 0.2 at init"
+    loss.backward()
+    gsum = sum(float(q.grad.abs().sum()) for q in m.parameters())
+    assert np.isfinite(gsum) and gsum > 0

@@ -72,6 +72,8 @@ def conv3x3(src0, wpack, cout, src1=None, mean=None, scale=None, shift=None, up0
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=src0.device)
     elif tuple(out.shape) != (n, cout, h, w):
         raise _lib.Tnv3Error("conv3x3: wrong output shape")
+    if n == 0:
+        return out                                   # empty batch: nothing to launch (torch ops accept N = 0 too)
     _lib.check(lib.tnv3_conv3x3_forward(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(wpack), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(shift),
                                         _lib.ptr(out), n, c0, c1, cout, h, w, int(bool(up0)), int(bool(relu)), int(cfg),
                                         _lib.stream_ptr(src0)))
@@ -89,6 +91,8 @@ def head1x1_sigmoid(x, weight, bias, apply_sigmoid=True, out=None):
         raise _lib.Tnv3Error("head1x1: weight/bias shape mismatch")
     if out is None:
         out = torch.empty((n, l, h, w), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out
     _lib.check(lib.tnv3_head1x1_sigmoid(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), n, c, l, h * w,
                                         int(bool(apply_sigmoid)), _lib.stream_ptr(x)))
     return out
@@ -101,6 +105,8 @@ def maxpool2x2(x, out=None):
     n, c, h, w = (int(v) for v in x.shape)
     if out is None:
         out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out
     _lib.check(lib.tnv3_maxpool2x2(_lib.ptr(x), _lib.ptr(out), n * c, h, w, _lib.stream_ptr(x)))
     return out
 
@@ -123,6 +129,8 @@ def conv1d_k3(src0, weight, bias, src1=None, src_nlc=False, dst_nlc=False, act=A
     if tuple(weight.shape) != (cout, c0 + c1, 3) or bias.numel() != cout:
         raise _lib.Tnv3Error(f"conv1d_k3: weight {tuple(weight.shape)} does not match {c0}+{c1} input channels")
     out = torch.empty((n, l, cout) if dst_nlc else (n, cout, l), dtype=torch.float32, device=src0.device)
+    if n == 0:
+        return out
     _lib.check(lib.tnv3_conv1d_k3_forward(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out),
                                           n, c0, c1, cout, l, int(bool(src_nlc)), int(bool(dst_nlc)), int(act),
                                           _lib.stream_ptr(src0)))
@@ -141,6 +149,8 @@ def ensemble_frames(win, s_base, weight, t0, n_frames, num_sample):
     for v in tail:
         e *= int(v)
     out = torch.empty((n_frames,) + tail, dtype=torch.float32, device=win.device)
+    if n_frames == 0:
+        return out
     _lib.check(lib.tnv3_ensemble_frames(_lib.ptr(win), n_local, int(s_base), l, e, _lib.ptr(weight), int(t0), int(n_frames),
                                         int(num_sample), _lib.ptr(out), _lib.stream_ptr(win)))
     return out
@@ -155,6 +165,8 @@ def heatmap_peakfind(heat, threshold=0.5, tie_last_wins=True):
         raise _lib.Tnv3Error("heatmap_peakfind: expected (frames, H, W)")
     frames, h, w = (int(v) for v in heat.shape)
     out = torch.empty((frames, 4), dtype=torch.int32, device=heat.device)
+    if frames == 0:
+        return out
     step = 4096
     for f0 in range(0, frames, step):
         nf = min(step, frames - f0)
