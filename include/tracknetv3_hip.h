@@ -177,6 +177,23 @@ int tnv3_conv1d_k3_wgrad(const float* src0, const float* src1, const float* dpre
                          size_t workspace_bytes, int n, int c0, int c1, int cout, int l, int src_nlc,
                          tnv3_stream_t stream);
 
+/* ---- frame preprocessing in front of the network (dataset.py:101-105, 427-461) --------------- */
+
+/* PIL `Image.resize((ow, oh))` (default BICUBIC, 8-bit two-pass fixed-point resample) of `frames` images
+ * src[frames][h][w][c] (uint8, HWC) -- bit-exact -- fused with np.moveaxis(img, -1, 0) and `/= 255.`:
+ *   dst_f32[frames][c][oh][ow] = lut[resized u8]   (lut: 256 floats = float32(float64(v) / 255.0)), and/or
+ *   dst_u8 [frames][oh][ow][c]                     (either may be NULL)
+ *   tmp: frames*h*ow*c bytes of scratch (the horizontally resized intermediate)
+ *   xmin/xcnt/kkx[ow][ksize_x], ymin/ycnt/kky[oh][ksize_y]: Pillow's precompute_coeffs + normalize_coeffs_8bpc tables
+ *   (int32, device memory) for the two axes; they depend only on (w, ow) and (h, oh). */
+int tnv3_resample_bicubic_u8(const unsigned char* src, unsigned char* tmp, float* dst_f32, unsigned char* dst_u8,
+                             const int32_t* xmin, const int32_t* xcnt, const int32_t* kkx, int ksize_x,
+                             const int32_t* ymin, const int32_t* ycnt, const int32_t* kky, int ksize_y, const float* lut,
+                             int frames, int h, int w, int c, int oh, int ow, tnv3_stream_t stream);
+
+/* np.median(frame_arr, 0).astype('uint8') over t frames of bytes_per_frame bytes each (uint8): the background image. */
+int tnv3_median_u8(const unsigned char* frames, unsigned char* median, int t, long bytes_per_frame, tnv3_stream_t stream);
+
 /* ---- diagnostics ----------------------------------------------------------------------------------------- */
 
 /* Register-only v_mfma_f32_32x32x2_f32 loop: `blocks` workgroups of 256 threads, each wave issuing iters*8 MFMAs

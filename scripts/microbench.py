@@ -80,6 +80,27 @@ def main():
         assert len(pd["Frame"]) == t_frames
         out[f"e2e_predict_video_{mode}"] = {"frames": t_frames, "s": round(dt, 4), "fps": round(t_frames / dt, 1),
                                             "note": "TrackNet(8,concat)+InpaintNet(16), batch 16, frames resident at 288x512"}
+    # ---- device-side preprocessing and the end-to-end path from 1080p uint8 frames
+    from tracknetv3_amd import preprocess as pre
+    src = torch.randint(0, 256, (64, 1080, 1920, 3), dtype=torch.uint8, device=dev)
+    ms = timeit(lambda: pre.resize_frames(src), 5, dev)
+    out["resize_1080p_to_288x512_64frames"] = {"ms": round(ms, 3), "frames_per_s": round(64 / ms * 1e3, 1),
+                                                "GBps_read": round(src.numel() / ms / 1e6, 1)}
+    ms = timeit(lambda: pre.median_background(src), 3, dev)
+    out["median_1080p_T64"] = {"ms": round(ms, 3), "GBps_read": round(src.numel() / ms / 1e6, 1)}
+    big = src.repeat(4, 1, 1, 1)[:256]
+    for f in range(256):
+        cx, cy = 100 + 6 * f, 300 + (f * 7) % 500
+        big[f, cy - 8:cy + 9, cx - 8:cx + 9] = 255
+    for mode in ("nonoverlap", "weight"):
+        predict_video(big[:40], tn, net, 8, 16, "concat", mode, 16)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pd = predict_video(big, tn, net, 8, 16, "concat", mode, 16)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out[f"e2e_from_1080p_u8_{mode}"] = {"frames": 256, "s": round(dt, 4), "fps": round(256 / dt, 1),
+                                             "note": "median + bicubic resize + TrackNet + ensemble + peak-find + InpaintNet; frames resident as uint8 1080p"}
     print(json.dumps(out))
 
 

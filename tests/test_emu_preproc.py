@@ -1,0 +1,67 @@
+"""CPU: frame-preprocessing kernels through the emulator vs the oracle restatement, and the oracle vs LIVE Pillow."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import preproc as opre
+
+
+def test_oracle_resize_is_bit_exact_with_installed_pillow():
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(0)
+    for (h, w, oh, ow) in ((270, 480, 72, 128), (108, 192, 72, 128), (72, 128, 72, 128), (50, 75, 72, 128), (1080, 1920, 288, 512)):
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        img[: h // 4, : w // 3] = 255
+        img[h // 2:, w // 2:] = 0
+        assert np.array_equal(opre.resize_bicubic_u8(img, ow, oh), np.array(Image.fromarray(img).resize(size=(ow, oh))))
+    g = rng.randint(0, 256, (100, 160)).astype(np.uint8)
+    assert np.array_equal(opre.resize_bicubic_u8(g[..., None], 64, 36)[..., 0], np.array(Image.fromarray(g).resize(size=(64, 36))))
+
+
+def test_product_coefficient_tables_equal_oracle():
+    from tracknetv3_amd.preprocess import resample_coeffs
+    for (a, b) in ((1920, 512), (1080, 288), (480, 128), (75, 128), (128, 128)):
+        for x, y in zip(resample_coeffs(a, b), opre.resample_coeffs(a, b)):
+            assert np.array_equal(x, y)
+
+
+def test_resize_and_median_emulated_vs_oracle(emu):
+    from tracknetv3_amd import preprocess as pre
+    rng = np.random.RandomState(1)
+    for (h, w, oh, ow) in ((54, 96, 16, 32), (20, 30, 16, 32), (16, 32, 16, 32)):
+        fr = rng.randint(0, 256, (3, h, w, 3)).astype(np.uint8)
+        fr[0, :5] = 255
+        f32, u8 = pre.resize_frames(torch.from_numpy(fr), oh, ow, want_f32=True, want_u8=True)
+        for k in range(3):
+            want = opre.resize_bicubic_u8(fr[k], ow, oh)
+            assert np.array_equal(u8[k].numpy(), want)
+            assert np.array_equal(f32[k].numpy(), opre.normalise_u8(np.moveaxis(want, -1, 0)))
+    for t in (1, 2, 7, 16, 33):
+        fr = rng.randint(0, 256, (t, 6, 10, 3)).astype(np.uint8)
+        fr[:, 0, 0] = 200                                            # constant pixel
+        fr[: t // 2, 0, 1] = 0
+        fr[t // 2:, 0, 1] = 255                                      # bimodal: even T averages 0 and 255 -> 127
+        got = pre.median_background(torch.from_numpy(fr)).numpy()
+        assert np.array_equal(got, opre.median_u8(fr)), t
+
+
+def test_preprocess_video_matches_reference_dataset_layout(emu):
+    """median first for 'concat', frame channels RGB-major, /255 -- vs the oracle's restatement of dataset.py:427-461."""
+    from tracknetv3_amd import preprocess as pre
+    from tracknetv3_amd.pipeline import _assemble, _windows
+    rng = np.random.RandomState(2)
+    fr = rng.randint(0, 256, (6, 40, 64, 3)).astype(np.uint8)
+    import tracknetv3_amd.preprocess as p
+    frames, med = None, None
+    old = (p.HEIGHT, p.WIDTH)
+    try:
+        frames = torch.cat([pre.resize_frames(torch.from_numpy(fr), 16, 32)], 0)
+        med = pre.resize_frames(pre.median_background(torch.from_numpy(fr)).unsqueeze(0), 16, 32)[0]
+    finally:
+        p.HEIGHT, p.WIDTH = old
+    widx = _windows(6, 3, 1, padding=False)
+    x = _assemble(frames, med, widx, "concat").numpy()
+    want = opre.tracknet_input_from_frames(fr, [0, 1, 2, 3], 3, "concat", height=16, width=32)
+    assert x.shape == want.shape == (4, 12, 16, 32) and np.array_equal(x, want)
+    x0 = _assemble(frames, None, widx, "").numpy()
+    assert np.array_equal(x0, opre.tracknet_input_from_frames(fr, [0, 1, 2, 3], 3, "", height=16, width=32))

@@ -176,3 +176,33 @@ def test_inpaintnet_train_step_vs_reference_golden(gpu_device):
 def test_predict_video_pipeline_vs_oracle_flow(gpu_device, eval_mode):
     from pipeline_common import check_pipeline
     check_pipeline(gpu_device, 288, 512, 45, 10, eval_mode)
+
+
+def test_preprocessing_1080p_bit_exact_vs_pillow_and_numpy(gpu_device):
+    """median background + PIL BICUBIC resize + CHW + /255 on the device, at the real geometry."""
+    from oracle import preproc as opre
+    from tracknetv3_amd import preprocess as pre
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(3)
+    t = 9
+    fr = rng.randint(0, 256, (t, 1080, 1920, 3)).astype(np.uint8)
+    fr[:, 100:300, 200:800] = 255
+    fr[:, 500:700, 1000:1500] = 0
+    fr[::2, 900:1000, 100:300] = 17                                   # bimodal over time
+    d = torch.from_numpy(fr).to(gpu_device)
+    f32, u8 = pre.resize_frames(d[:3], want_f32=True, want_u8=True)
+    for k in range(3):
+        ref = np.array(Image.fromarray(fr[k]).resize(size=(512, 288)))          # live Pillow on this box
+        assert np.array_equal(u8[k].cpu().numpy(), ref)
+        assert np.array_equal(f32[k].cpu().numpy(), (np.moveaxis(ref, -1, 0).astype(np.float64) / 255.0).astype(np.float32))
+    assert np.array_equal(u8[0].cpu().numpy(), opre.resize_bicubic_u8(fr[0], 512, 288))
+    med = pre.median_background(d).cpu().numpy()
+    assert np.array_equal(med, np.median(fr, 0).astype("uint8"))
+    med8 = pre.median_background(d[:8]).cpu().numpy()                  # even T: mean of the two middle values, truncated
+    assert np.array_equal(med8, np.median(fr[:8], 0).astype("uint8"))
+    frames, medf = pre.preprocess_video(d, "concat")
+    assert frames.shape == (t, 3, 288, 512) and medf.shape == (3, 288, 512)
+    want = opre.tracknet_input_from_frames(fr, [0], 8, "concat")
+    from tracknetv3_amd.pipeline import _assemble, _windows
+    x = _assemble(frames, medf, _windows(t, 8, 1, False)[:1], "concat").cpu().numpy()
+    assert np.array_equal(x, want)

@@ -9,6 +9,7 @@
 #include "kernels/conv1d_k3.h"
 #include "kernels/pointwise.h"
 #include "kernels/postproc.h"
+#include "kernels/preproc.h"
 #include "kernels/train_ops.h"
 #include "kernels/wgrad3x3_mfma.h"
 
@@ -372,6 +373,30 @@ template <class Launcher>
 int mixup_impl(Launcher& L, const float* x, const float* lam, const int32_t* perm, float* out, int n, long per_sample) {
   if (!x || !lam || !perm || !out || n <= 0 || per_sample <= 0 || (per_sample % 4)) TNV3_FAIL(-1, "mixup: bad argument");
   return L.launch(mixup_kernel, grid_for((long)n * (per_sample / 4)), 256, x, lam, (const int*)perm, out, n, per_sample);
+}
+
+// ---- frame preprocessing
+template <class Launcher>
+int resample_bicubic_u8_impl(Launcher& L, const unsigned char* src, unsigned char* tmp, float* dst_f32, unsigned char* dst_u8,
+                             const int* xmin, const int* xcnt, const int* kkx, int ksx, const int* ymin, const int* ycnt,
+                             const int* kky, int ksy, const float* lut, int frames, int h, int w, int c, int oh, int ow) {
+  if (!src || !tmp || (!dst_f32 && !dst_u8) || !xmin || !xcnt || !kkx || !ymin || !ycnt || !kky || frames <= 0 || h <= 0 || w <= 0 ||
+      c <= 0 || oh <= 0 || ow <= 0 || ksx <= 0 || ksy <= 0)
+    TNV3_FAIL(-1, "resample_bicubic_u8: bad argument");
+  if (dst_f32 && !lut) TNV3_FAIL(-1, "resample_bicubic_u8: fp32 output needs the 256-entry lookup table");
+  if ((long)w * c > kResampleMaxRowBytes) TNV3_FAIL(-1, "resample_bicubic_u8: source row of %ld bytes exceeds %d", (long)w * c, kResampleMaxRowBytes);
+  if ((long)frames * h >= (1l << 31) || (long)frames * oh >= (1l << 31)) TNV3_FAIL(-1, "resample_bicubic_u8: too many rows");
+  int rc;
+  if ((rc = L.launch(resample_h_u8_kernel, frames * h, 256, src, tmp, xmin, xcnt, kkx, ksx, h, w, c, ow))) return rc;
+  return L.launch(resample_v_u8_kernel, frames * oh, 256, (const unsigned char*)tmp, dst_f32, dst_u8, ymin, ycnt, kky, ksy, lut, h, ow, c, oh);
+}
+
+template <class Launcher>
+int median_u8_impl(Launcher& L, const unsigned char* frames, unsigned char* med, int t, long p) {
+  if (!frames || !med || t <= 0 || p <= 0) TNV3_FAIL(-1, "median_u8: bad argument");
+  const long blocks = (p + 127) / 128;
+  if (blocks >= (1l << 31)) TNV3_FAIL(-1, "median_u8: frame too large");
+  return L.launch(median_u8_kernel, (int)blocks, 128, frames, med, t, p);
 }
 
 // ---- InpaintNet backward

@@ -2,8 +2,9 @@
 with every arithmetic stage on the device -- window assembly, TrackNet, temporal ensemble, threshold + peak-find,
 inpaint-mask scan, InpaintNet, blend + COOR_TH threshold, coordinate ensemble, final coordinates.
 
-What stays outside (SURVEY 8f "next"): video decoding, the 1080p -> 288x512 bicubic resize and the median background
-estimate -- `frames` are expected already resized, float in [0, 1], shape (T, 3, 288, 512), resident on the device.
+`frames` is either the source-resolution stream as uint8 (T, H, W, 3) RGB -- then the median background, the
+Pillow-exact bicubic resize to 288x512 and the `/255` normalisation run on the device too (`preprocess.py`) -- or
+already-resized float frames (T, 3, 288, 512) in [0, 1].  Video decoding stays outside.
 """
 import torch
 
@@ -54,6 +55,13 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
     for a (T, 3, 288, 512) frame tensor.  img_shape = (w, h) of the source video (default: the network resolution)."""
     if eval_mode not in ("nonoverlap", "average", "weight"):
         raise ValueError("Invalid mode")
+    if frames.dtype == torch.uint8:                      # source-resolution (T, H, W, 3) stream: preprocess on the device
+        from . import preprocess
+        if img_shape is None:
+            img_shape = (int(frames.shape[2]), int(frames.shape[1]))
+        frames, med = preprocess.preprocess_video(frames, bg_mode)
+        if median is None:
+            median = med
     t = int(frames.shape[0])
     w_src, h_src = img_shape if img_shape is not None else (WIDTH, HEIGHT)
     img_scaler = (w_src / WIDTH, h_src / HEIGHT)

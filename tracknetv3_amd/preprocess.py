@@ -1,0 +1,112 @@
+"""Frame preprocessing in front of TrackNet on the device: what Shuttlecock_Trajectory_Dataset does on
+CPU workers for `frame_arr` inputs (dataset.py:101-109, 427-461) -- temporal median background, Pillow-exact BICUBIC
+resize to 288x512, HWC->CHW, `/255.` -- as three HIP kernels.  Source frames stay uint8 in HBM; the network input is
+assembled from the resized fp32 frames by `pipeline.predict_video`.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils.general import HEIGHT, WIDTH
+
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x, a=-0.5):
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def resample_coeffs(in_size, out_size):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) for the BICUBIC filter over the full
+    source range, in float64 like the C code: (xmin[out], xcount[out], coeff[out][ksize]) int32.  Host-side table: it
+    depends only on the two sizes."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    xmin = np.zeros(out_size, dtype=np.int32)
+    xcnt = np.zeros(out_size, dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.float64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        lo = max(int(center - support + 0.5), 0)
+        hi = min(int(center + support + 0.5), in_size)
+        ww = 0.0
+        for x in range(hi - lo):
+            w = _bicubic((x + lo - center + 0.5) * ss)
+            kk[xx, x] = w
+            ww += w
+        if ww != 0.0:
+            kk[xx, :hi - lo] /= ww
+        xmin[xx], xcnt[xx] = lo, hi - lo
+    scaled = kk * (1 << _PRECISION_BITS)
+    return xmin, xcnt, np.where(kk < 0, np.trunc(-0.5 + scaled), np.trunc(0.5 + scaled)).astype(np.int32)
+
+
+_tables = {}
+
+
+def _device_tables(h, w, oh, ow, device):
+    key = (h, w, oh, ow, str(device))
+    if key not in _tables:
+        xs = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in resample_coeffs(w, ow)]
+        ys = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in resample_coeffs(h, oh)]
+        lut = torch.from_numpy((np.arange(256, dtype=np.float64) / 255.0).astype(np.float32)).to(device)   # `/= 255.` then .float()
+        _tables[key] = (xs, ys, lut)
+    return _tables[key]
+
+
+def resize_frames(frames_u8, out_h=HEIGHT, out_w=WIDTH, want_f32=True, want_u8=False):
+    """(F, H, W, C) uint8 -> fp32 (F, C, out_h, out_w) in [0, 1] (and/or uint8 (F, out_h, out_w, C)); bit-exact with
+    `np.moveaxis(np.array(Image.fromarray(img).resize((out_w, out_h))), -1, 0) / 255.`"""
+    lib = _lib.load()
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
+        raise _lib.Tnv3Error("resize_frames: expected a (F, H, W, C) uint8 tensor")
+    _lib.dev_check(frames_u8)
+    f, h, w, c = (int(v) for v in frames_u8.shape)
+    dev = frames_u8.device
+    (xmin, xcnt, kkx), (ymin, ycnt, kky), lut = _device_tables(h, w, out_h, out_w, dev)
+    out_f = torch.empty((f, c, out_h, out_w), dtype=torch.float32, device=dev) if want_f32 else None
+    out_u = torch.empty((f, out_h, out_w, c), dtype=torch.uint8, device=dev) if want_u8 else None
+    if f == 0:
+        return (out_f, out_u) if (want_f32 and want_u8) else (out_f if want_f32 else out_u)
+    tmp = torch.empty((f, h, out_w, c), dtype=torch.uint8, device=dev)
+    _lib.check(lib.tnv3_resample_bicubic_u8(_lib.ptr(frames_u8), _lib.ptr(tmp), _lib.ptr(out_f), _lib.ptr(out_u), _lib.ptr(xmin),
+                                            _lib.ptr(xcnt), _lib.ptr(kkx), int(kkx.shape[1]), _lib.ptr(ymin), _lib.ptr(ycnt),
+                                            _lib.ptr(kky), int(kky.shape[1]), _lib.ptr(lut), f, h, w, c, out_h, out_w,
+                                            _lib.stream_ptr(frames_u8)))
+    return (out_f, out_u) if (want_f32 and want_u8) else (out_f if want_f32 else out_u)
+
+
+def median_background(frames_u8):
+    """np.median(frame_arr, 0).astype('uint8') of a (T, H, W, C) uint8 stack -> (H, W, C) uint8."""
+    lib = _lib.load()
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
+        raise _lib.Tnv3Error("median_background: expected a (T, H, W, C) uint8 tensor")
+    _lib.dev_check(frames_u8)
+    t = int(frames_u8.shape[0])
+    med = torch.empty(tuple(frames_u8.shape[1:]), dtype=torch.uint8, device=frames_u8.device)
+    _lib.check(lib.tnv3_median_u8(_lib.ptr(frames_u8), _lib.ptr(med), t, med.numel(), _lib.stream_ptr(frames_u8)))
+    return med
+
+
+def preprocess_video(frames_u8, bg_mode="concat", median_u8=None, chunk=64):
+    """Source-resolution uint8 frames (T, H, W, 3) on the device -> (frames fp32 (T, 3, 288, 512), median fp32 (3, 288, 512)
+    or None), as the reference's dataset produces them for bg_mode '' / 'concat'."""
+    med = None
+    if bg_mode == "concat":
+        if median_u8 is None:
+            median_u8 = median_background(frames_u8)
+        med = resize_frames(median_u8.unsqueeze(0))[0]
+    elif bg_mode not in ("", None):
+        raise NotImplementedError(f"bg_mode '{bg_mode}': difference-frame preprocessing is not built yet")
+    outs = [resize_frames(frames_u8[s:s + chunk]) for s in range(0, int(frames_u8.shape[0]), chunk)]
+    return torch.cat(outs, 0), med
