@@ -201,6 +201,12 @@ int tnv3_median_u8(const unsigned char* frames, unsigned char* median, int t, lo
  * rate of the chip as clocked under load, to set next to the conv kernels' TFLOP/s. */
 int tnv3_mfma_f32_probe(float* out, int blocks, int iters, tnv3_stream_t stream);
 
+/* The conv kernel with parts of its pipeline switched off (results are WRONG by design): diag 1 = stage only the first
+ * channel chunk (no global loads / LDS stores afterwards), diag 2 = additionally no workgroup barriers.  Timing these
+ * against the production launch attributes the matrix-pipe idle time to staging / synchronisation / the MFMA loop. */
+int tnv3_conv3x3_forward_diag(const float* src0, const float* wpack, float* dst, int n, int c0, int cout, int h, int w,
+                              int cfg, int diag, tnv3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

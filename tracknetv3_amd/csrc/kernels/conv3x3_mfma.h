@@ -43,6 +43,8 @@ struct Conv3x3Args {
   int N, C0, C1, Cout, H, W;
   int up0;              // 1: src0 is stored at (H/2, W/2) and read as out[h][w] = src0[h>>1][w>>1]
   int relu;             // 1: y = max(y, 0)
+  int diag;             // 0 in production.  Diagnostics only (WRONG results): 1 = stage the first chunk only (no global
+                        // loads / LDS stores afterwards), 2 = additionally no barriers: isolates the MFMA + LDS-read loop.
 };
 
 template <int MT_, int NTW_, int WM_, int WN_, int TR_, int TC_, int CC_, int MINW_ = 1, int PF_ = 1, int PRIO_ = 0>
@@ -214,8 +216,8 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
   __syncthreads();
 
   for (int k = 0; k < nChunks; ++k) {
-    const int buf = k & 1;
-    if (k + 1 < nChunks) load_stage(k + 1);
+    const int buf = a.diag ? 0 : (k & 1);
+    if (k + 1 < nChunks && !a.diag) load_stage(k + 1);
 
     const float* A = lds + buf * Cfg::BUF_FLOATS + a_off;
     const float* B = lds + buf * Cfg::BUF_FLOATS + b_off;
@@ -249,8 +251,8 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
     }
     if (Cfg::PRIO) __builtin_amdgcn_s_setprio(0);
 
-    if (k + 1 < nChunks) store_stage(buf ^ 1, k + 1);
-    __syncthreads();
+    if (k + 1 < nChunks && !a.diag) store_stage(buf ^ 1, k + 1);
+    if (a.diag < 2) __syncthreads();
   }
 
   // ---- epilogue: affine (folded eval-mode BN) + ReLU, 128-byte row segments per half-wave

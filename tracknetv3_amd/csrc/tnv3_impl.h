@@ -83,7 +83,7 @@ int launch_conv_cfg(Launcher& L, const Conv3x3Args& a) {
 template <class Launcher>
 int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, const float* wpack, const float* mean,
                          const float* scale, const float* shift, float* dst, int n, int c0, int c1, int cout, int h, int w, int up0,
-                         int relu, int cfg, float* dst1 = nullptr, int csplit = 0) {
+                         int relu, int cfg, float* dst1 = nullptr, int csplit = 0, int diag = 0) {
   if (!src0 || !wpack || !dst) TNV3_FAIL(-1, "conv3x3: null pointer");
   if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "conv3x3: non-positive dimension");
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3: src1 / c1 mismatch");
@@ -95,7 +95,7 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3: upsampled source needs even H,W");
   if (cfg < 0) cfg = conv_auto_config(n, cout, h, w);
   if (dst1 && (csplit <= 0 || csplit >= cout)) TNV3_FAIL(-1, "conv3x3: bad output split %d of %d", csplit, cout);
-  Conv3x3Args a{src0, src1, wpack, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0};
+  Conv3x3Args a{src0, src1, wpack, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0, diag};
   switch (cfg) {
     case 0: return launch_conv_cfg<ConvC0>(L, a);
     case 1: return launch_conv_cfg<ConvC1>(L, a);
