@@ -273,6 +273,13 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
   return d;
 }
 
+// LDS DMA: LDS[base + lane*size] <- *gsrc (per-lane source, wave-uniform LDS base = lane 0's argument)
+inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(1))) void* g, __attribute__((address_space(3))) void* l,
+                                             unsigned size, int offset, unsigned) {
+  const uintptr_t base = emu::wave_read((uintptr_t)l, 0);
+  memcpy((void*)(base + (uintptr_t)emu::lane_id() * size + offset), (const void*)((uintptr_t)g + offset), size);
+}
+
 // atomics (the emulator is single-threaded: plain read-modify-write)
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }

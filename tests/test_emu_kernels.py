@@ -45,6 +45,9 @@ CONV_CASES = [
     (10, 1, 6, 0, 64, 8, 32, False, True, True),       # 2-step operand prefetch ring
     (11, 1, 8, 0, 128, 5, 33, False, False, False),
     (12, 2, 3, 0, 64, 4, 32, False, True, True),
+    (13, 2, 9, 0, 64, 12, 40, False, True, True),      # LDS-DMA staging: ragged edges, odd Cin (zero-tail padding)
+    (14, 1, 32, 16, 64, 8, 16, True, True, True),      # LDS-DMA + two sources + upsample
+    (15, 1, 8, 0, 128, 6, 32, False, False, True),
 ]
 
 
@@ -67,10 +70,12 @@ def test_conv3x3_mfma_emulated(emu, case):
 def test_weight_packing_layouts(emu):
     from tracknetv3_amd import ops
     w = T((64, 5, 3, 3), 7)
-    p = ops.pack_conv3x3_weights(w).reshape(32, 9, 64)
+    p = ops.pack_conv3x3_weights(w)
+    assert p[-64:].abs().max() == 0                     # zero tail (padding source of the LDS-DMA loader)
+    p = p[:-64].reshape(32, 9, 64)
     assert torch.equal(p[:5], w.permute(1, 2, 3, 0).reshape(5, 9, 64))
     assert p[5:].abs().max() == 0
-    pt = ops.pack_conv3x3_weights(w, transpose_flip=True).reshape(64, 9, 5)      # dgrad: K = Cout, M = Cin, taps flipped
+    pt = ops.pack_conv3x3_weights(w, transpose_flip=True)[:-64].reshape(64, 9, 5)     # dgrad: K = Cout, M = Cin, taps flipped
     assert torch.equal(pt, w.flip(2, 3).permute(0, 2, 3, 1).reshape(64, 9, 5))
 
 
@@ -95,7 +100,7 @@ def test_argument_errors_are_reported(emu):
     from tracknetv3_amd import ops, _lib
     w = ops.pack_conv3x3_weights(T((64, 4, 3, 3), 1))
     with pytest.raises(_lib.Tnv3Error, match="multiple of 64"):
-        ops.conv3x3(T((1, 4, 8, 32), 2), T((32 * 9 * 40,), 3), 40)
+        ops.conv3x3(T((1, 4, 8, 32), 2), T((32 * 9 * 40 + 64,), 3), 40)
     with pytest.raises(_lib.Tnv3Error, match="unknown config"):
         ops.conv3x3(T((1, 4, 8, 32), 2), w, 64, cfg=99)
     with pytest.raises(_lib.Tnv3Error, match="channel block"):

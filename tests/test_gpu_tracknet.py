@@ -34,7 +34,7 @@ def test_conv3x3_small_cases(gpu_device, case):
     assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6
 
 
-@pytest.mark.parametrize("cfg", list(range(13)))
+@pytest.mark.parametrize("cfg", list(range(16)))
 def test_conv3x3_every_config_on_network_shapes(gpu_device, cfg):
     """Each compiled tile configuration on mid-sized shapes incl. a two-source decoder-entry layer."""
     from tracknetv3_amd import ops
@@ -63,7 +63,7 @@ def test_pool_head_pack(gpu_device):
         ref = torch.sigmoid(F.conv2d(x.double(), w.double(), b.double()))
         assert (y.double() - ref).abs().max() <= 1e-6
     w = T((128, 70, 3, 3), 7)
-    p = ops.pack_conv3x3_weights(w.to(d)).cpu().reshape(96, 9, 128)
+    p = ops.pack_conv3x3_weights(w.to(d)).cpu()[:-64].reshape(96, 9, 128)
     assert torch.equal(p[:70], w.permute(1, 2, 3, 0).reshape(70, 9, 128)) and p[70:].abs().max() == 0
 
 

@@ -33,7 +33,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct Conv3x3Args {
   const float* src0;    // [N][C0][H0][W0]   H0,W0 = H,W (up0 == 0) or H/2,W/2 (up0 == 1: nearest 2x upsample on load)
   const float* src1;    // [N][C1][H][W] or nullptr; its channels follow src0's (cat([up(src0), src1], dim=1))
-  const float* wpack;   // [Cin_pad][9][Cout], Cin_pad = roundup(C0+C1, CC), padding rows zero
+  const float* wpack;   // [Cin_pad][9][Cout], Cin_pad = roundup(C0+C1, 32), padding rows zero, then kPackZeroTail zeros
+  const float* zeros;   // -> the zero tail of wpack (source of padded elements for the LDS-DMA path)
   const float* mean;    // [Cout] or nullptr  -> y = (acc - mean)*scale + shift: eval-mode BatchNorm in the reference's
   const float* scale;   // [Cout] or nullptr     own operation order (subtract first: no cancellation when |mean| >> std)
   const float* shift;   // [Cout] or nullptr
@@ -47,8 +48,10 @@ struct Conv3x3Args {
                         // loads / LDS stores afterwards), 2 = additionally no barriers: isolates the MFMA + LDS-read loop.
 };
 
-template <int MT_, int NTW_, int WM_, int WN_, int TR_, int TC_, int CC_, int MINW_ = 1, int PF_ = 1, int PRIO_ = 0>
+template <int MT_, int NTW_, int WM_, int WN_, int TR_, int TC_, int CC_, int MINW_ = 1, int PF_ = 1, int PRIO_ = 0, int GLDS_ = 0>
 struct ConvCfg {
+  static constexpr int GLDS = GLDS_;                 // 1: stage through the LDS-DMA path (global_load_lds): no staging VGPRs,
+                                                     //    no ds_write; zero padding is read from the filter's zero tail
   static constexpr int MT = MT_, NTW = NTW_, WM = WM_, WN = WN_, TR = TR_, TC = TC_, CC = CC_;
   static constexpr int MINW = MINW_;                 // __launch_bounds__ 2nd argument: waves per SIMD to fit
   static constexpr int PF = PF_;                     // K-steps of operand prefetch (LDS reads run PF steps ahead of the MFMAs)
@@ -97,6 +100,20 @@ __host__ __device__ inline int conv_grid_blocks(int nMB, int nPT) {
     return 8 * ((nPT + G - 1) / G);
   }
   return nMB * nPT;
+}
+
+constexpr int kPackZeroTail = 64;      // floats of zeros appended to every packed filter
+
+// global -> LDS DMA: LDS[lds_base + lane*BYTES] <- *gsrc (per-lane source, wave-uniform LDS base; the builtin puts the base
+// in M0).  Completion is tracked by vmcnt; the compiler drains it before the workgroup barrier that publishes the stage.
+// (the size operand of the builtin must be a literal, hence two helpers)
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_dma4(const float* gsrc, float* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
 }
 
 template <class Cfg>
@@ -198,6 +215,36 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
     for (int i = 0; i < NIN; ++i) li[tid + i * NT] = slot_ok(i, k) ? rin[i] : 0.0f;
   };
 
+  // LDS-DMA staging of chunk k straight into stage `buf` (Cfg::GLDS): one 16-byte piece per lane for the weight panel,
+  // one dword per lane for the halo tile; padded / out-of-image elements are fetched from the filter's zero tail.
+  auto dma_stage = [&](int k, int buf) {
+    float* lw = lds + buf * Cfg::BUF_FLOATS;
+    float* li = lw + Cfg::W_FLOATS;
+    const int wbase = wave * 64;                     // wave-uniform part of the element index
+    const float* wsrc = a.wpack + (size_t)k * KROWS * Cout + m0;
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+      const int e4 = tid + i * NT;
+      const int krow = e4 / (MB / 4), m4 = e4 - krow * (MB / 4);
+      if ((i + 1) * NT <= Cfg::E_W4 || e4 < Cfg::E_W4)
+        lds_dma16(wsrc + (size_t)krow * Cout + m4 * 4, lw + (i * NT + wbase) * 4);
+    }
+    const int cbeg = k * CC;
+    const bool from0 = cbeg < C0;
+    const float* base = from0 ? a.src0 + ((size_t)n * C0 + cbeg) * HW0
+                              : a.src1 + ((size_t)n * C1 + (cbeg - C0)) * HW;
+    const bool up = from0 && a.up0;
+    const int hw = from0 ? HW0 : HW, wrow = up ? W0 : W;
+    const int sh = up ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int s = sp[i];
+      const int c = (int)((unsigned)s >> 26), gh = (s >> 13) & 8191, gw = s & 8191;
+      const float* src = slot_ok(i, k) ? base + (c * hw + (gh >> sh) * wrow + (gw >> sh)) : a.zeros;
+      lds_dma4(src, li + i * NT + wbase);
+    }
+  };
+
   f32x16 acc[MT][NTW];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -211,13 +258,20 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
   const int b_off = Cfg::W_FLOATS + (half * TRp + wn * (NTW / CS)) * TCp + bl;
 
   const int nChunks = (Cin + CC - 1) / CC;
-  load_stage(0);
-  store_stage(0, 0);
+  if (Cfg::GLDS) {
+    dma_stage(0, 0);
+  } else {
+    load_stage(0);
+    store_stage(0, 0);
+  }
   __syncthreads();
 
   for (int k = 0; k < nChunks; ++k) {
     const int buf = a.diag ? 0 : (k & 1);
-    if (k + 1 < nChunks && !a.diag) load_stage(k + 1);
+    if (k + 1 < nChunks && !a.diag) {
+      if (Cfg::GLDS) dma_stage(k + 1, buf ^ 1);      // the other stage was last read before the previous barrier
+      else load_stage(k + 1);
+    }
 
     const float* A = lds + buf * Cfg::BUF_FLOATS + a_off;
     const float* B = lds + buf * Cfg::BUF_FLOATS + b_off;
@@ -251,7 +305,7 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
     }
     if (Cfg::PRIO) __builtin_amdgcn_s_setprio(0);
 
-    if (k + 1 < nChunks && !a.diag) store_stage(buf ^ 1, k + 1);
+    if (k + 1 < nChunks && !a.diag && !Cfg::GLDS) store_stage(buf ^ 1, k + 1);
     if (a.diag < 2) __syncthreads();
   }
 
@@ -288,8 +342,9 @@ __global__ void pack_conv3x3_weights_kernel(const float* __restrict__ w, float* 
                                             int Cout, int Cin, int Kpad, int transpose_flip) {
   const int M = transpose_flip ? Cin : Cout;     // packed inner (GEMM M) extent
   const int Kc = transpose_flip ? Cout : Cin;    // packed outer (GEMM K channels) extent
-  const long total = (long)Kpad * 9 * M;
+  const long body = (long)Kpad * 9 * M, total = body + kPackZeroTail;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    if (e >= body) { wp[e] = 0.0f; continue; }        // zero tail: padding source of the LDS-DMA loader
     const int m = (int)(e % M);
     const long t = e / M;
     const int tap = (int)(t % 9);

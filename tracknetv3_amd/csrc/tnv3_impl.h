@@ -39,7 +39,10 @@ using ConvC9 = ConvCfg<2, 1, 2, 4, 4, 32, 4>;    // 128 ch x ( 4x32 px), 512 thr
 using ConvC10 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1>;   // cfg 8 + 2-step operand prefetch + setprio around the MFMA block
 using ConvC11 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1>;   // cfg 9 + both (+1.5 % measured)
 using ConvC12 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1>;   // cfg 7 + both
-constexpr int kNumConvConfigs = 13;
+using ConvC13 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1, 1>;   // cfg 12 with LDS-DMA staging
+using ConvC14 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1, 1>;   // cfg 10 with LDS-DMA staging
+using ConvC15 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1, 1>;   // cfg 11 with LDS-DMA staging
+constexpr int kNumConvConfigs = 16;
 
 struct ConvCfgInfo { int MB, TR, TC, CC, NT, LDS; };
 template <class C> constexpr ConvCfgInfo cfg_info() { return {C::MB, C::TR, C::TC, C::CC, C::NT, C::LDS_BYTES}; }
@@ -58,6 +61,9 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
     case 10: return cfg_info<ConvC10>();
     case 11: return cfg_info<ConvC11>();
     case 12: return cfg_info<ConvC12>();
+    case 13: return cfg_info<ConvC13>();
+    case 14: return cfg_info<ConvC14>();
+    case 15: return cfg_info<ConvC15>();
     default: return {0, 0, 0, 0, 0, 0};
   }
 }
@@ -95,7 +101,8 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3: upsampled source needs even H,W");
   if (cfg < 0) cfg = conv_auto_config(n, cout, h, w);
   if (dst1 && (csplit <= 0 || csplit >= cout)) TNV3_FAIL(-1, "conv3x3: bad output split %d of %d", csplit, cout);
-  Conv3x3Args a{src0, src1, wpack, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0, diag};
+  const float* zeros = wpack + (size_t)round_up(c0 + c1, 32) * 9 * cout;       // the packed filter's zero tail
+  Conv3x3Args a{src0, src1, wpack, zeros, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0, diag};
   switch (cfg) {
     case 0: return launch_conv_cfg<ConvC0>(L, a);
     case 1: return launch_conv_cfg<ConvC1>(L, a);
@@ -110,13 +117,16 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
     case 10: return launch_conv_cfg<ConvC10>(L, a);
     case 11: return launch_conv_cfg<ConvC11>(L, a);
     case 12: return launch_conv_cfg<ConvC12>(L, a);
+    case 13: return launch_conv_cfg<ConvC13>(L, a);
+    case 14: return launch_conv_cfg<ConvC14>(L, a);
+    case 15: return launch_conv_cfg<ConvC15>(L, a);
     default: TNV3_FAIL(-1, "conv3x3: unknown config %d", cfg);
   }
 }
 
 inline size_t conv3x3_packed_floats(int cout, int cin, int transpose_flip) {
   const int K = transpose_flip ? cout : cin, M = transpose_flip ? cin : cout;
-  return (size_t)round_up(K, 32) * 9 * M;
+  return (size_t)round_up(K, 32) * 9 * M + kPackZeroTail;
 }
 
 template <class Launcher>
