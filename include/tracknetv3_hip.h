@@ -191,8 +191,16 @@ int tnv3_resample_bicubic_u8(const unsigned char* src, unsigned char* tmp, float
                              const int32_t* ymin, const int32_t* ycnt, const int32_t* kky, int ksize_y, const float* lut,
                              int frames, int h, int w, int c, int oh, int ow, tnv3_stream_t stream);
 
-/* np.median(frame_arr, 0).astype('uint8') over t frames of bytes_per_frame bytes each (uint8): the background image. */
-int tnv3_median_u8(const unsigned char* frames, unsigned char* median, int t, long bytes_per_frame, tnv3_stream_t stream);
+/* np.median(frame_arr, 0) over t frames of bytes_per_frame bytes each (uint8).  median (may be NULL): the value cast
+ * `.astype('uint8')` (bg_mode 'concat'); median_x2 (may be NULL): TWICE the float64 median as uint16 (an even count gives
+ * x.5 medians), which is what the difference-frame modes subtract. */
+int tnv3_median_u8(const unsigned char* frames, unsigned char* median, uint16_t* median_x2, int t, long bytes_per_frame,
+                   tnv3_stream_t stream);
+
+/* Difference frame of bg_mode 'subtract' / 'subtract_concat' (dataset.py:439, 443):
+ * out[f][p] = uint8(sum_c |frames[f][p][c] - median[p][c]|) with the float median (truncate, wrap mod 256), 3 channels. */
+int tnv3_absdiff_sum_u8(const unsigned char* frames, const uint16_t* median_x2, unsigned char* out, int frames_n,
+                        long pixels, tnv3_stream_t stream);
 
 /* ---- diagnostics ----------------------------------------------------------------------------------------- */
 

@@ -101,20 +101,33 @@ def normalise_u8(img_u8):
     return (img_u8.astype(np.float64) / 255.0).astype(np.float32)
 
 
+def diff_frame_u8(img_u8, median_f64):
+    """`np.sum(np.absolute(img - median_img), 2).astype('uint8')` (dataset.py:439, 443): the median stays FLOAT64 here
+    (np.median result, halves possible), the channel sum can reach 765 and the uint8 cast truncates then wraps mod 256."""
+    return np.sum(np.absolute(img_u8 - median_f64), 2).astype("uint8")
+
+
 def tracknet_input_from_frames(frame_arr, starts, seq_len, bg_mode, height=288, width=512, median=None):
     """frame_arr (T, H, W, 3) uint8 RGB -> float32 (B, C, height, width) exactly as Shuttlecock_Trajectory_Dataset
-    .__getitem__ does for frame_arr inputs (dataset.py:427-461) with bg_mode '' or 'concat'."""
-    if bg_mode not in ("", None, "concat"):
-        raise NotImplementedError(bg_mode)
+    .__getitem__ does for frame_arr inputs (dataset.py:427-461), all four bg_mode values."""
+    if bg_mode not in ("", None, "concat", "subtract", "subtract_concat"):
+        raise ValueError(bg_mode)
     med = None
+    if bg_mode and median is None:
+        median = np.median(frame_arr, 0)                     # float64 (dataset.py:103-104)
     if bg_mode == "concat":
-        if median is None:
-            median = np.median(frame_arr, 0)
         med = np.moveaxis(resize_bicubic_u8(median.astype("uint8"), width, height), -1, 0)
     out = []
     for s in starts:
         chans = [] if med is None else [med]
         for f in range(seq_len):
-            chans.append(np.moveaxis(resize_bicubic_u8(frame_arr[s + f], width, height), -1, 0))
+            img = frame_arr[s + f]
+            if bg_mode == "subtract":
+                chans.append(resize_bicubic_u8(diff_frame_u8(img, median)[..., None], width, height)[None, ..., 0])
+            elif bg_mode == "subtract_concat":
+                chans.append(np.moveaxis(resize_bicubic_u8(img, width, height), -1, 0))
+                chans.append(resize_bicubic_u8(diff_frame_u8(img, median)[..., None], width, height)[None, ..., 0])
+            else:
+                chans.append(np.moveaxis(resize_bicubic_u8(img, width, height), -1, 0))
         out.append(normalise_u8(np.concatenate(chans, 0)))
     return np.stack(out, 0)

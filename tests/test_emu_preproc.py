@@ -65,3 +65,34 @@ def test_preprocess_video_matches_reference_dataset_layout(emu):
     assert x.shape == want.shape == (4, 12, 16, 32) and np.array_equal(x, want)
     x0 = _assemble(frames, None, widx, "").numpy()
     assert np.array_equal(x0, opre.tracknet_input_from_frames(fr, [0, 1, 2, 3], 3, "", height=16, width=32))
+
+
+def test_difference_frame_modes_emulated_vs_oracle(emu):
+    """bg_mode 'subtract' / 'subtract_concat' (dataset.py:439-446): float median (halves), channel sum up to 765,
+    uint8 truncation + wrap -- bit-exact in integer arithmetic; odd and even frame counts."""
+    from tracknetv3_amd import preprocess as pre
+    from tracknetv3_amd.pipeline import _assemble, _windows
+    rng = np.random.RandomState(4)
+    for t in (6, 7):
+        fr = rng.randint(0, 256, (t, 20, 24, 3)).astype(np.uint8)
+        fr[: t // 2, 2:6, 2:6] = 0
+        fr[t // 2:, 2:6, 2:6] = 255                                   # big differences: sums above 255 wrap
+        med64 = np.median(fr, 0)
+        m2 = pre.median_background(torch.from_numpy(fr), doubled=True).numpy()
+        assert np.array_equal(m2.astype(np.float64) / 2.0, med64)
+        d = pre.difference_frames(torch.from_numpy(fr), torch.from_numpy(m2)).numpy()[..., 0]
+        for k in range(t):
+            assert np.array_equal(d[k], opre.diff_frame_u8(fr[k], med64)), (t, k)
+    import tracknetv3_amd.preprocess as p
+    fr = rng.randint(0, 256, (6, 40, 64, 3)).astype(np.uint8)
+    for mode, c in (("subtract", 1), ("subtract_concat", 4)):
+        med2 = pre.median_background(torch.from_numpy(fr), doubled=True)
+        planes = []
+        if mode != "subtract":
+            planes.append(pre.resize_frames(torch.from_numpy(fr), 16, 32))
+        planes.append(pre.resize_frames(pre.difference_frames(torch.from_numpy(fr), med2), 16, 32))
+        frames = planes[0] if len(planes) == 1 else torch.cat(planes, 1)
+        assert frames.shape == (6, c, 16, 32)
+        x = _assemble(frames, None, _windows(6, 3, 1, False), mode).numpy()
+        want = opre.tracknet_input_from_frames(fr, [0, 1, 2, 3], 3, mode, height=16, width=32)
+        assert x.shape == want.shape == (4, 3 * c, 16, 32) and np.array_equal(x, want), mode

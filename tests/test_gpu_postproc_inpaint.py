@@ -206,3 +206,24 @@ def test_preprocessing_1080p_bit_exact_vs_pillow_and_numpy(gpu_device):
     from tracknetv3_amd.pipeline import _assemble, _windows
     x = _assemble(frames, medf, _windows(t, 8, 1, False)[:1], "concat").cpu().numpy()
     assert np.array_equal(x, want)
+
+
+def test_difference_frame_modes_1080p_bit_exact(gpu_device):
+    from oracle import preproc as opre
+    from tracknetv3_amd import preprocess as pre
+    from tracknetv3_amd.pipeline import _assemble, _windows
+    rng = np.random.RandomState(5)
+    fr = rng.randint(0, 256, (8, 1080, 1920, 3)).astype(np.uint8)
+    fr[:4, 100:400, 100:900] = 0
+    fr[4:, 100:400, 100:900] = 255                                    # channel sums above 255: wrap path
+    d = torch.from_numpy(fr).to(gpu_device)
+    med64 = np.median(fr, 0)
+    m2 = pre.median_background(d, doubled=True)
+    assert np.array_equal(m2.cpu().numpy().astype(np.float64) / 2.0, med64)
+    diff = pre.difference_frames(d[:2], m2).cpu().numpy()[..., 0]
+    assert np.array_equal(diff[0], opre.diff_frame_u8(fr[0], med64)) and np.array_equal(diff[1], opre.diff_frame_u8(fr[1], med64))
+    for mode, c in (("subtract", 1), ("subtract_concat", 4)):
+        frames, med = pre.preprocess_video(d, mode)
+        assert med is None and frames.shape == (8, c, 288, 512)
+        x = _assemble(frames, None, _windows(8, 8, 1, False), mode).cpu().numpy()
+        assert np.array_equal(x, opre.tracknet_input_from_frames(fr, [0], 8, mode))

@@ -60,7 +60,8 @@ def _declare(lib):
     sig("tnv3_mfma_f32_probe", i, p, i, i, p)
     sig("tnv3_conv3x3_forward_diag", i, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_resample_bicubic_u8", i, p, p, p, p, p, p, p, i, p, p, p, i, p, i, i, i, i, i, i, p)
-    sig("tnv3_median_u8", i, p, p, i, lg, p)
+    sig("tnv3_median_u8", i, p, p, p, i, lg, p)
+    sig("tnv3_absdiff_sum_u8", i, p, p, p, i, lg, p)
     sig("tnv3_conv1d_act_backward", i, p, p, p, i, i, i, i, i, p)
     sig("tnv3_conv1d_k3_dgrad", i, p, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_conv1d_k3_wgrad_workspace_bytes", sz, i, i, i, i)
@@ -74,7 +75,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_bn_relu_backward", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",
            "tnv3_wbce_workspace_bytes", "tnv3_wbce_forward", "tnv3_wbce_backward", "tnv3_head_backward_workspace_bytes",
            "tnv3_head_backward", "tnv3_maxpool2x2_backward_add", "tnv3_upsample2x_backward", "tnv3_mixup",
-           "tnv3_mfma_f32_probe", "tnv3_conv3x3_forward_diag", "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad"]
+           "tnv3_mfma_f32_probe", "tnv3_conv3x3_forward_diag", "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_absdiff_sum_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad"]
 
 
 def library_path():

@@ -60,8 +60,10 @@ __global__ void __launch_bounds__(256) resample_v_u8_kernel(const unsigned char*
 
 // Median over T frames of P bytes each: frames [T][P] u8 -> med [P] u8 = floor((v[(T-1)/2] + v[T/2]) / 2).
 // 128 threads x 256 32-bit bins = 128 KB of LDS; bin-major layout keeps the 32 lanes of a half-wave on 32 banks.
+// med2 (optional): a + b as uint16 = twice the float median (np.median of an even count ends in .5): what the
+// difference-frame modes subtract (dataset.py:439) without leaving integer arithmetic.
 __global__ void __launch_bounds__(128) median_u8_kernel(const unsigned char* __restrict__ frames, unsigned char* __restrict__ med,
-                                                        int T, long P) {
+                                                        unsigned short* __restrict__ med2, int T, long P) {
   __shared__ unsigned int hist_s[256 * 128];          // [bin][thread]: 128 KB of the CU's 160 KB
   const int tid = threadIdx.x;
   const long p = (long)blockIdx.x * 128 + tid;
@@ -85,7 +87,26 @@ __global__ void __launch_bounds__(128) median_u8_kernel(const unsigned char* __r
       if (a < 0 && cum > r0) a = b;
       if (b2 < 0 && cum > r1) { b2 = b; break; }
     }
-    med[p] = (unsigned char)((a + b2) >> 1);
+    if (med) med[p] = (unsigned char)((a + b2) >> 1);
+    if (med2) med2[p] = (unsigned short)(a + b2);
+  }
+}
+
+// Difference frame of bg_mode 'subtract' / 'subtract_concat' (dataset.py:439, 443):
+//   out[f][p] = uint8( sum_c |frame[f][p][c] - median[p][c]| )   with a float64 median -> truncate, then wrap mod 256.
+// In integers: s2 = sum_c |2*v - med2|,  out = (s2 >> 1) & 255.   frames [F][P][3] u8, med2 [P][3] u16 -> out [F][P] u8.
+__global__ void __launch_bounds__(256) absdiff_sum_u8_kernel(const unsigned char* __restrict__ frames,
+                                                             const unsigned short* __restrict__ med2,
+                                                             unsigned char* __restrict__ out, int F, long P) {
+  const long total = (long)F * P;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long p = t % P;
+    const unsigned char* v = frames + t * 3;
+    const unsigned short* m = med2 + p * 3;
+    int s2 = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const int d = 2 * (int)v[c] - (int)m[c]; s2 += d < 0 ? -d : d; }
+    out[t] = (unsigned char)((s2 >> 1) & 255);
   }
 }
 

@@ -402,11 +402,17 @@ int resample_bicubic_u8_impl(Launcher& L, const unsigned char* src, unsigned cha
 }
 
 template <class Launcher>
-int median_u8_impl(Launcher& L, const unsigned char* frames, unsigned char* med, int t, long p) {
-  if (!frames || !med || t <= 0 || p <= 0) TNV3_FAIL(-1, "median_u8: bad argument");
+int median_u8_impl(Launcher& L, const unsigned char* frames, unsigned char* med, unsigned short* med2, int t, long p) {
+  if (!frames || (!med && !med2) || t <= 0 || p <= 0) TNV3_FAIL(-1, "median_u8: bad argument");
   const long blocks = (p + 127) / 128;
   if (blocks >= (1l << 31)) TNV3_FAIL(-1, "median_u8: frame too large");
-  return L.launch(median_u8_kernel, (int)blocks, 128, frames, med, t, p);
+  return L.launch(median_u8_kernel, (int)blocks, 128, frames, med, med2, t, p);
+}
+
+template <class Launcher>
+int absdiff_sum_u8_impl(Launcher& L, const unsigned char* frames, const unsigned short* med2, unsigned char* out, int f, long p) {
+  if (!frames || !med2 || !out || f <= 0 || p <= 0) TNV3_FAIL(-1, "absdiff_sum_u8: bad argument");
+  return L.launch(absdiff_sum_u8_kernel, grid_for((long)f * p), 256, frames, med2, out, f, p);
 }
 
 // ---- InpaintNet backward

@@ -34,11 +34,9 @@ def _windows(num_frames, seq_len, step, padding):
 def _assemble(frames, median, widx, bg_mode):
     """(B, L) frame indices -> network input (B, C, H, W): 'concat' puts the median image first (dataset.py:455-456)."""
     b, l = widx.shape
-    x = frames[widx.to(frames.device)].reshape(b, l * 3, frames.shape[-2], frames.shape[-1])
+    x = frames[widx.to(frames.device)].reshape(b, l * frames.shape[1], frames.shape[-2], frames.shape[-1])
     if bg_mode == "concat":
         x = torch.cat((median.unsqueeze(0).expand(b, -1, -1, -1), x), dim=1)
-    elif bg_mode not in ("", None):
-        raise NotImplementedError(f"bg_mode '{bg_mode}' needs the difference-frame preprocessing (SURVEY 8f, not built yet)")
     return x.contiguous()
 
 

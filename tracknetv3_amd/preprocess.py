@@ -86,27 +86,56 @@ def resize_frames(frames_u8, out_h=HEIGHT, out_w=WIDTH, want_f32=True, want_u8=F
     return (out_f, out_u) if (want_f32 and want_u8) else (out_f if want_f32 else out_u)
 
 
-def median_background(frames_u8):
-    """np.median(frame_arr, 0).astype('uint8') of a (T, H, W, C) uint8 stack -> (H, W, C) uint8."""
+def median_background(frames_u8, doubled=False):
+    """np.median(frame_arr, 0) of a (T, H, W, C) uint8 stack.  Default: `.astype('uint8')` -> (H, W, C) uint8 (bg_mode
+    'concat').  doubled=True: twice the float median as int16-range uint16 (exact, halves included) for the
+    difference-frame modes."""
     lib = _lib.load()
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
         raise _lib.Tnv3Error("median_background: expected a (T, H, W, C) uint8 tensor")
     _lib.dev_check(frames_u8)
     t = int(frames_u8.shape[0])
-    med = torch.empty(tuple(frames_u8.shape[1:]), dtype=torch.uint8, device=frames_u8.device)
-    _lib.check(lib.tnv3_median_u8(_lib.ptr(frames_u8), _lib.ptr(med), t, med.numel(), _lib.stream_ptr(frames_u8)))
+    shape = tuple(frames_u8.shape[1:])
+    med = torch.empty(shape, dtype=torch.int16 if doubled else torch.uint8, device=frames_u8.device)
+    _lib.check(lib.tnv3_median_u8(_lib.ptr(frames_u8), None if doubled else _lib.ptr(med), _lib.ptr(med) if doubled else None, t,
+                                  med.numel(), _lib.stream_ptr(frames_u8)))
     return med
 
 
+def difference_frames(frames_u8, median_x2):
+    """(F, H, W, 3) uint8 and the doubled median (H, W, 3) -> (F, H, W, 1) uint8 = uint8(sum_c |frame - median|)."""
+    lib = _lib.load()
+    _lib.dev_check(frames_u8, median_x2)
+    f, h, w, c = (int(v) for v in frames_u8.shape)
+    if c != 3 or median_x2.dtype != torch.int16 or tuple(median_x2.shape) != (h, w, 3):
+        raise _lib.Tnv3Error("difference_frames: expected RGB frames and an int16 (H, W, 3) doubled median")
+    out = torch.empty((f, h, w, 1), dtype=torch.uint8, device=frames_u8.device)
+    if f:
+        _lib.check(lib.tnv3_absdiff_sum_u8(_lib.ptr(frames_u8), _lib.ptr(median_x2), _lib.ptr(out), f, h * w, _lib.stream_ptr(frames_u8)))
+    return out
+
+
 def preprocess_video(frames_u8, bg_mode="concat", median_u8=None, chunk=64):
-    """Source-resolution uint8 frames (T, H, W, 3) on the device -> (frames fp32 (T, 3, 288, 512), median fp32 (3, 288, 512)
-    or None), as the reference's dataset produces them for bg_mode '' / 'concat'."""
-    med = None
+    """Source-resolution uint8 frames (T, H, W, 3) on the device -> (per-frame fp32 planes (T, C, 288, 512), median fp32
+    (3, 288, 512) or None) as the reference's dataset produces them (dataset.py:427-461):
+    bg_mode '' / 'concat': C = 3 (RGB; 'concat' also returns the resized median image that goes first in every window);
+    'subtract': C = 1 (difference frame); 'subtract_concat': C = 4 (RGB + difference frame)."""
+    if bg_mode not in ("", None, "concat", "subtract", "subtract_concat"):
+        raise ValueError(f"unknown bg_mode '{bg_mode}'")
+    med, med2 = None, None
     if bg_mode == "concat":
         if median_u8 is None:
             median_u8 = median_background(frames_u8)
         med = resize_frames(median_u8.unsqueeze(0))[0]
-    elif bg_mode not in ("", None):
-        raise NotImplementedError(f"bg_mode '{bg_mode}': difference-frame preprocessing is not built yet")
-    outs = [resize_frames(frames_u8[s:s + chunk]) for s in range(0, int(frames_u8.shape[0]), chunk)]
+    elif bg_mode in ("subtract", "subtract_concat"):
+        med2 = median_background(frames_u8, doubled=True)
+    outs = []
+    for s in range(0, int(frames_u8.shape[0]), chunk):
+        part = frames_u8[s:s + chunk]
+        planes = []
+        if bg_mode != "subtract":
+            planes.append(resize_frames(part))
+        if med2 is not None:
+            planes.append(resize_frames(difference_frames(part, med2)))
+        outs.append(planes[0] if len(planes) == 1 else torch.cat(planes, 1))
     return torch.cat(outs, 0), med
