@@ -18,11 +18,11 @@ def main():
         y = torch.empty(n, cout, h, w, device=dev)
         fl = 2.0 * 9 * cin * cout * h * w * n
         row = {}
-        for cfg in (12, 13, 10, 14, 11, 15):
+        for cfg in (12, 10, 11):
             info = ops.conv3x3_config_info(cfg)
             if cout % info["m_block"]:
                 continue
-            for diag in (0, 1):
+            for diag in (0, 1, 2):
                 f = lambda: _lib.check(lib.tnv3_conv3x3_forward_diag(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), n, cin, cout, h, w, cfg, diag, _lib.stream_ptr(x)))
                 for _ in range(2): f()
                 torch.cuda.synchronize(dev)

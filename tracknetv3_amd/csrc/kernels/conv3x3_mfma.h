@@ -44,12 +44,15 @@ struct Conv3x3Args {
   int N, C0, C1, Cout, H, W;
   int up0;              // 1: src0 is stored at (H/2, W/2) and read as out[h][w] = src0[h>>1][w>>1]
   int relu;             // 1: y = max(y, 0)
-  int diag;             // 0 in production.  Diagnostics only (WRONG results): 1 = stage the first chunk only (no global
-                        // loads / LDS stores afterwards), 2 = additionally no barriers: isolates the MFMA + LDS-read loop.
+  int diag;             // honoured only by ConvCfg<..., DIAG = 1> instantiations (WRONG results by design): 1 = stage the first
+                        // chunk only (no global loads / LDS stores afterwards), 2 = additionally no barriers.
 };
 
-template <int MT_, int NTW_, int WM_, int WN_, int TR_, int TC_, int CC_, int MINW_ = 1, int PF_ = 1, int PRIO_ = 0, int GLDS_ = 0>
+template <int MT_, int NTW_, int WM_, int WN_, int TR_, int TC_, int CC_, int MINW_ = 1, int PF_ = 1, int PRIO_ = 0, int GLDS_ = 0,
+          int DIAG_ = 0>
 struct ConvCfg {
+  static constexpr int DIAG = DIAG_;                 // 1: diagnostic instantiation that honours Conv3x3Args::diag (a runtime
+                                                     //    flag in the production kernels cost 15 VGPRs = one workgroup per CU)
   static constexpr int GLDS = GLDS_;                 // 1: stage through the LDS-DMA path (global_load_lds): no staging VGPRs,
                                                      //    no ds_write; zero padding is read from the filter's zero tail
   static constexpr int MT = MT_, NTW = NTW_, WM = WM_, WN = WN_, TR = TR_, TC = TC_, CC = CC_;
@@ -267,8 +270,9 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
   __syncthreads();
 
   for (int k = 0; k < nChunks; ++k) {
-    const int buf = a.diag ? 0 : (k & 1);
-    if (k + 1 < nChunks && !a.diag) {
+    const int diag = Cfg::DIAG ? a.diag : 0;          // folds to 0 in production instantiations
+    const int buf = diag ? 0 : (k & 1);
+    if (k + 1 < nChunks && !diag) {
       if (Cfg::GLDS) dma_stage(k + 1, buf ^ 1);      // the other stage was last read before the previous barrier
       else load_stage(k + 1);
     }
@@ -305,8 +309,8 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
     }
     if (Cfg::PRIO) __builtin_amdgcn_s_setprio(0);
 
-    if (k + 1 < nChunks && !a.diag && !Cfg::GLDS) store_stage(buf ^ 1, k + 1);
-    if (a.diag < 2) __syncthreads();
+    if (k + 1 < nChunks && !diag && !Cfg::GLDS) store_stage(buf ^ 1, k + 1);
+    if (diag < 2) __syncthreads();
   }
 
   // ---- epilogue: affine (folded eval-mode BN) + ReLU, 128-byte row segments per half-wave

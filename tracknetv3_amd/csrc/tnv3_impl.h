@@ -43,6 +43,10 @@ using ConvC13 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1, 1>;   // cfg 12 with LDS-
 using ConvC14 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1, 1>;   // cfg 10 with LDS-DMA staging
 using ConvC15 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1, 1>;   // cfg 11 with LDS-DMA staging
 constexpr int kNumConvConfigs = 16;
+// diagnostic twins (tnv3_conv3x3_forward_diag only): same geometry, runtime `diag` honoured
+using ConvD10 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1, 0, 1>;
+using ConvD11 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1, 0, 1>;
+using ConvD12 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1, 0, 1>;
 
 struct ConvCfgInfo { int MB, TR, TC, CC, NT, LDS; };
 template <class C> constexpr ConvCfgInfo cfg_info() { return {C::MB, C::TR, C::TC, C::CC, C::NT, C::LDS_BYTES}; }
@@ -103,6 +107,14 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
   if (dst1 && (csplit <= 0 || csplit >= cout)) TNV3_FAIL(-1, "conv3x3: bad output split %d of %d", csplit, cout);
   const float* zeros = wpack + (size_t)round_up(c0 + c1, 32) * 9 * cout;       // the packed filter's zero tail
   Conv3x3Args a{src0, src1, wpack, zeros, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0, diag};
+  if (diag) {
+    switch (cfg) {
+      case 10: return launch_conv_cfg<ConvD10>(L, a);
+      case 11: return launch_conv_cfg<ConvD11>(L, a);
+      case 12: return launch_conv_cfg<ConvD12>(L, a);
+      default: TNV3_FAIL(-1, "conv3x3 diagnostics exist for configs 10, 11, 12 only (got %d)", cfg);
+    }
+  }
   switch (cfg) {
     case 0: return launch_conv_cfg<ConvC0>(L, a);
     case 1: return launch_conv_cfg<ConvC1>(L, a);
