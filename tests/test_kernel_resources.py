@@ -1,0 +1,62 @@
+"""CPU: register / occupancy budget of the hot kernels, read from hipcc's -Rpass-analysis=kernel-resource-usage remarks.
+A runtime flag added to the conv kernel once cost 15 VGPRs = one resident workgroup per CU (-4 % end to end) without any
+test noticing; this pins the budgets the tuned table relies on."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def resources(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("res") / "capi.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+                        "-Rpass-analysis=kernel-resource-usage", "-o", str(out),
+                        os.path.join(ROOT, "tracknetv3_amd", "csrc", "tnv3_capi.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur:
+            kernels[cur][m.group(1).strip()] = int(m.group(2))
+    assert len(kernels) > 30
+    return kernels
+
+
+def _find(kernels, *needles):
+    hits = [v for k, v in kernels.items() if all(n in k for n in needles)]
+    assert len(hits) == 1, (needles, len(hits))
+    return hits[0]
+
+
+def test_no_vgpr_spills_anywhere(resources):
+    bad = {k: v for k, v in resources.items() if v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)}
+    assert not bad, list(bad)
+
+
+def test_conv_and_wgrad_budgets(resources):
+    cfg = "conv3x3_mfma_kernelINS_7ConvCfgI"
+    # (template arguments, minimum waves per SIMD) of the configurations the tuned table uses
+    for args, occ in (("Li2ELi1ELi1ELi8ELi8ELi32ELi8ELi1ELi2ELi1ELi0ELi0E", 4),     # cfg 10
+                      ("Li2ELi1ELi2ELi4ELi4ELi32ELi4ELi1ELi2ELi1ELi0ELi0E", 6),     # cfg 11
+                      ("Li2ELi1ELi1ELi4ELi4ELi32ELi8ELi1ELi2ELi1ELi0ELi0E", 3),     # cfg 12
+                      ("Li2ELi1ELi1ELi4ELi4ELi32ELi8ELi1ELi1ELi0ELi0ELi0E", 3),     # cfg 7
+                      ("Li2ELi1ELi1ELi8ELi8ELi32ELi8ELi1ELi1ELi0ELi0ELi0E", 4),     # cfg 8
+                      ("Li2ELi1ELi2ELi4ELi4ELi32ELi4ELi1ELi1ELi0ELi0ELi0E", 6)):    # cfg 9
+        k = _find(resources, cfg + args)
+        assert k["Occupancy [waves/SIMD]"] >= occ, (args, k)
+    for args in ("WgradCfgILi4ELi1ELi4ELi32E", "WgradCfgILi2ELi2ELi4ELi32E"):
+        k = _find(resources, "wgrad3x3_mfma_kernel", args)
+        assert k["VGPRs"] + k.get("AGPRs", 0) <= 512 and k["Occupancy [waves/SIMD]"] >= 1
