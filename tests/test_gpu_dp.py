@@ -1,0 +1,82 @@
+"""GPU (-m gpu): data-parallel semantics end to end with the REAL kernels -- two ranks (both on cuda:0, gloo transport;
+RCCL replaces it on a multi-GPU node with the same torch.distributed calls) run TrackNetTrainer.step on their shards;
+the result must equal the survey's DP definition: the CPU oracle runs the shards sequentially through the
+reference arithmetic with LOCAL BatchNorm statistics, averages the gradient sets and applies one optimiser step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tracknetv3_amd.parallel import TrackNetTrainer, shard_range
+        from tracknetv3_amd.utils.general import get_model
+        dev = torch.device("cuda:0")
+        sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 13, calibrated=True)
+        net = get_model("TrackNet", 3, "")
+        if rank == 0:
+            net.load_state_dict(sd, strict=True)           # rank 1 starts from random init: broadcast must fix it
+        net = net.to(dev)
+        opt = torch.optim.SGD(net.parameters(), lr=1.0)    # lr 1, no momentum: parameter delta == -averaged gradient
+        tr = TrackNetTrainer(net, opt, alpha=0.0, bucket_bytes=4 << 20)
+        assert tr.reducer is not None and tr.reducer.num_buckets() >= 8
+        x = nets.synth_input((4, 9, 32, 64), 1013)
+        y = nets.disc_heatmaps(4, 3, 32, 64, 2013)
+        lo, hi = shard_range(4, rank, world)
+        loss = tr.step(x[lo:hi].to(dev), y[lo:hi].to(dev))
+        torch.cuda.synchronize()
+        out[rank] = dict(loss=float(loss), params={k: v.detach().cpu() for k, v in net.named_parameters()},
+                         bn={k: v.detach().cpu() for k, v in net.state_dict().items() if "running_" in k})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_train_step_equals_sequential_shard_oracle(gpu_device):
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 13, calibrated=True)
+    x = nets.synth_input((4, 9, 32, 64), 1013)
+    y = nets.disc_heatmaps(4, 3, 32, 64, 2013)
+    g64, g32, losses, stats = [], [], [], []
+    for lo, hi in ((0, 2), (2, 4)):                          # the DP definition: shards one after the other, local BN
+        l, _, g, st = nets.tracknet_train_step_grads(sd, x[lo:hi], y[lo:hi], torch.float64)
+        _, _, gf, _ = nets.tracknet_train_step_grads(sd, x[lo:hi], y[lo:hi], torch.float32)
+        g64.append(g); g32.append(gf); losses.append(l.item()); stats.append(st)
+    assert abs(r0["loss"] - losses[0]) <= 2e-5 and abs(r1["loss"] - losses[1]) <= 2e-5
+    mine, ref = [], []
+    for name in g64[0]:
+        want = sd[name].double() - 0.5 * (g64[0][name] + g64[1][name])          # one SGD step with the averaged gradient
+        want32 = sd[name].double() - 0.5 * (g32[0][name].double() + g32[1][name].double())
+        assert torch.equal(r0["params"][name], r1["params"][name]), f"replicas diverged on {name}"
+        scale = (0.5 * (g64[0][name] + g64[1][name])).abs().max().item() + 1e-30
+        mine.append((r0["params"][name].double() - want).abs().max().item() / scale)
+        ref.append((want32 - want).abs().max().item() / scale)
+    mine, ref = np.array(mine), np.array(ref)
+    assert mine.max() <= 3 * ref.max() + 5e-4 and np.median(mine) <= 3 * np.median(ref) + 2e-4, (mine.max(), ref.max())
+    # BatchNorm running statistics stay LOCAL to each rank (no SyncBN): rank r holds the stats of shard r
+    for r, got in ((0, r0["bn"]), (1, r1["bn"])):
+        for k, v in got.items():
+            assert torch.allclose(v.double(), stats[r][k], rtol=2e-4, atol=2e-6), (r, k)
