@@ -199,6 +199,7 @@ inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_s_waitcnt(int) {}   // the emulated LDS DMA is synchronous
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline void __threadfence() {}
 

@@ -48,6 +48,10 @@ CONV_CASES = [
     (13, 2, 9, 0, 64, 12, 40, False, True, True),      # LDS-DMA staging: ragged edges, odd Cin (zero-tail padding)
     (14, 1, 32, 16, 64, 8, 16, True, True, True),      # LDS-DMA + two sources + upsample
     (15, 1, 8, 0, 128, 6, 32, False, False, True),
+    (16, 2, 9, 0, 64, 12, 40, False, True, True),      # 3-stage LDS-DMA pipeline: 2 chunks (short pipeline)
+    (16, 1, 40, 0, 64, 4, 32, False, False, False),    #                           5 chunks
+    (17, 1, 32, 16, 128, 8, 16, True, True, True),     #                           12 chunks, two sources
+    (18, 1, 8, 0, 64, 8, 32, False, False, True),      #                           1 chunk
 ]
 
 

@@ -34,7 +34,7 @@ def test_conv3x3_small_cases(gpu_device, case):
     assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6
 
 
-@pytest.mark.parametrize("cfg", list(range(16)))
+@pytest.mark.parametrize("cfg", list(range(19)))
 def test_conv3x3_every_config_on_network_shapes(gpu_device, cfg):
     """Each compiled tile configuration on mid-sized shapes incl. a two-source decoder-entry layer."""
     from tracknetv3_amd import ops

@@ -55,6 +55,9 @@ struct ConvCfg {
                                                      //    flag in the production kernels cost 15 VGPRs = one workgroup per CU)
   static constexpr int GLDS = GLDS_;                 // 1: stage through the LDS-DMA path (global_load_lds): no staging VGPRs,
                                                      //    no ds_write; zero padding is read from the filter's zero tail
+                                                     // 2: same, THREE LDS stages and counted vmcnt: the DMA of chunk k+2 stays
+                                                     //    in flight across the barrier that publishes chunk k+1
+  static constexpr int STAGES = GLDS_ == 2 ? 3 : 2;
   static constexpr int MT = MT_, NTW = NTW_, WM = WM_, WN = WN_, TR = TR_, TC = TC_, CC = CC_;
   static constexpr int MINW = MINW_;                 // __launch_bounds__ 2nd argument: waves per SIMD to fit
   static constexpr int PF = PF_;                     // K-steps of operand prefetch (LDS reads run PF steps ahead of the MFMAs)
@@ -77,7 +80,12 @@ struct ConvCfg {
   static constexpr int E_W4 = W_FLOATS / 4;
   static constexpr int NW4 = (E_W4 + NT - 1) / NT;
   static constexpr int BUF_FLOATS = W_FLOATS + IN_FLOATS;       // one pipeline stage
-  static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+  static constexpr int LDS_BYTES = STAGES * BUF_FLOATS * 4;
+  // LDS-DMA instructions one wave issues per chunk (GLDS == 2 counts them in vmcnt): NIN input pieces, the full filter
+  // pieces, and -- for the waves below W_TAIL_WAVES -- the partial last filter piece (wave-uniform: E_W4 % 64 == 0).
+  static constexpr int DMA_PER_CHUNK = NIN + E_W4 / NT;
+  static constexpr int W_TAIL_WAVES = (E_W4 % NT) / 64;
+  static_assert(GLDS_ != 2 || E_W4 % 64 == 0, "filter pieces must split on wave boundaries");
 };
 
 // Block index -> (output-channel block, pixel tile).  Workgroup b is observed to run on XCD b % 8 (speed
@@ -107,6 +115,9 @@ __host__ __device__ inline int conv_grid_blocks(int nMB, int nPT) {
 
 constexpr int kPackZeroTail = 64;      // floats of zeros appended to every packed filter
 
+// s_waitcnt immediate that waits for vmcnt <= n only (gfx9+ encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14])
+__host__ __device__ constexpr int tnv3_vmcnt_only(int n) { return (n & 15) | (7 << 4) | (15 << 8) | (((n >> 4) & 3) << 14); }
+
 // global -> LDS DMA: LDS[lds_base + lane*BYTES] <- *gsrc (per-lane source, wave-uniform LDS base; the builtin puts the base
 // in M0).  Completion is tracked by vmcnt; the compiler drains it before the workgroup barrier that publishes the stage.
 // (the size operand of the builtin must be a literal, hence two helpers)
@@ -125,7 +136,7 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
   constexpr int NT = Cfg::NT, MB = Cfg::MB, CS = Cfg::CS, TRp = Cfg::TRp, TCp = Cfg::TCp, PLANE = Cfg::PLANE;
   constexpr int NIN = Cfg::NIN, NW4 = Cfg::NW4, KROWS = Cfg::KROWS;
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::STAGES * Cfg::BUF_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -261,6 +272,55 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
   const int b_off = Cfg::W_FLOATS + (half * TRp + wn * (NTW / CS)) * TCp + bl;
 
   const int nChunks = (Cin + CC - 1) / CC;
+  if (Cfg::GLDS == 2) {
+    // ---- 3-stage LDS-DMA pipeline with counted vmcnt (CDNA guide T3/T4): never drain to 0 inside the loop
+    const bool wtail = wave < Cfg::W_TAIL_WAVES;
+    auto wait_all_but_newest = [&](bool newest_in_flight) {
+      if (!newest_in_flight) __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+      else if (wtail) __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(Cfg::DMA_PER_CHUNK + 1));
+      else __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(Cfg::DMA_PER_CHUNK));
+    };
+    dma_stage(0, 0);
+    if (nChunks > 1) dma_stage(1, 1);
+    wait_all_but_newest(nChunks > 1);                          // chunk 0 landed, chunk 1 still in flight
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < nChunks; ++k) {
+      const int st = k % 3;
+      if (k + 2 < nChunks) dma_stage(k + 2, (k + 2) % 3);     // that stage was last read before the previous barrier
+      const float* A = lds + st * Cfg::BUF_FLOATS + a_off;
+      const float* B = lds + st * Cfg::BUF_FLOATS + b_off;
+      constexpr int NSTEP = (CC / 2) * 9;
+      constexpr int RING = Cfg::PF + 1;
+      float av[RING][MT], bv[RING][NTW];
+      auto read_step = [&](int s, float (&ar)[MT], float (&br)[NTW]) {
+        const int cp = s / 9, tap = s - 9 * cp;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ar[mt] = A[(2 * cp * 9 + tap) * MB + mt * 32];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) br[j] = B[(2 * cp * TRp + kh + j / CS) * TCp + kw + (j % CS) * 32];
+      };
+      if (Cfg::PRIO) __builtin_amdgcn_s_setprio(1);
+      read_step(0, av[0], bv[0]);
+      if (Cfg::PF == 2) read_step(1, av[1], bv[1]);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        if (s + Cfg::PF < NSTEP) read_step(s + Cfg::PF, av[(s + Cfg::PF) % RING], bv[(s + Cfg::PF) % RING]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j)
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING][mt], bv[s % RING][j], acc[mt][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + NTW, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);
+      }
+      if (Cfg::PRIO) __builtin_amdgcn_s_setprio(0);
+      // publish chunk k+1: this wave's DMAs of chunk k+1 have landed when at most the DMA_PER_CHUNK pieces of chunk k+2
+      // are still outstanding; the barrier extends that to every wave's pieces and retires all reads of stage `st`.
+      wait_all_but_newest(k + 2 < nChunks);
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
   if (Cfg::GLDS) {
     dma_stage(0, 0);
   } else {
@@ -312,6 +372,7 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
     if (k + 1 < nChunks && !diag && !Cfg::GLDS) store_stage(buf ^ 1, k + 1);
     if (diag < 2) __syncthreads();
   }
+  }   // 2-stage pipelines
 
   // ---- epilogue: affine (folded eval-mode BN) + ReLU, 128-byte row segments per half-wave
   const bool has_affine = a.scale != nullptr;

@@ -42,7 +42,10 @@ using ConvC12 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1>;   // cfg 7 + both
 using ConvC13 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1, 1>;   // cfg 12 with LDS-DMA staging
 using ConvC14 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1, 1>;   // cfg 10 with LDS-DMA staging
 using ConvC15 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1, 1>;   // cfg 11 with LDS-DMA staging
-constexpr int kNumConvConfigs = 16;
+using ConvC16 = ConvCfg<2, 1, 1, 4, 4, 32, 4, 1, 2, 1, 2>;   // cfg 12 tile, CC 4, 3-stage LDS-DMA + counted vmcnt
+using ConvC17 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1, 2>;   // cfg 11 tile,       3-stage LDS-DMA + counted vmcnt
+using ConvC18 = ConvCfg<2, 1, 1, 8, 8, 32, 4, 1, 2, 1, 2>;   // cfg 10 tile, CC 4, 3-stage LDS-DMA + counted vmcnt
+constexpr int kNumConvConfigs = 19;
 // diagnostic twins (tnv3_conv3x3_forward_diag only): same geometry, runtime `diag` honoured
 using ConvD10 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1, 0, 1>;
 using ConvD11 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1, 0, 1>;
@@ -68,6 +71,9 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
     case 13: return cfg_info<ConvC13>();
     case 14: return cfg_info<ConvC14>();
     case 15: return cfg_info<ConvC15>();
+    case 16: return cfg_info<ConvC16>();
+    case 17: return cfg_info<ConvC17>();
+    case 18: return cfg_info<ConvC18>();
     default: return {0, 0, 0, 0, 0, 0};
   }
 }
@@ -132,6 +138,9 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
     case 13: return launch_conv_cfg<ConvC13>(L, a);
     case 14: return launch_conv_cfg<ConvC14>(L, a);
     case 15: return launch_conv_cfg<ConvC15>(L, a);
+    case 16: return launch_conv_cfg<ConvC16>(L, a);
+    case 17: return launch_conv_cfg<ConvC17>(L, a);
+    case 18: return launch_conv_cfg<ConvC18>(L, a);
     default: TNV3_FAIL(-1, "conv3x3: unknown config %d", cfg);
   }
 }
