@@ -35,9 +35,23 @@ def _blob_maps():
     return np.stack(maps)
 
 
-def test_peakfind_emulated_vs_oracle(emu):
+def _wide_maps():
+    """Rows longer than a 64-pixel wave segment and not a multiple of it: runs cut by segment boundaries."""
+    rng = np.random.RandomState(12)
+    h, w = 14, 150
+    maps = [np.ones((h, w), np.float32)]
+    for dens in (0.02, 0.2, 0.5, 0.7, 0.95):
+        maps.append((rng.rand(h, w) < dens).astype(np.float32))
+    st = np.zeros((h, w), np.float32); st[::3, 5:140] = 1; st[1::3, 139] = 1; maps.append(st)     # long runs chained at one end
+    cb = np.zeros((h, w), np.float32); cb[::2, ::2] = 1; cb[1::2, 1::2] = 1; maps.append(cb)      # checkerboard: all diagonal links
+    vs = np.zeros((h, w), np.float32); vs[:, 63:66] = 1; vs[:, 127:129] = 1; maps.append(vs)      # columns across segment edges
+    return np.stack(maps)
+
+
+@pytest.mark.parametrize("maps_fn", [_blob_maps, _wide_maps])
+def test_peakfind_emulated_vs_oracle(emu, maps_fn):
     from tracknetv3_amd import ops
-    maps = _blob_maps()
+    maps = maps_fn()
     for tie in (True, False):
         got = ops.heatmap_peakfind(torch.from_numpy(maps), 0.5, tie_last_wins=tie).numpy()
         opp.TIE_LAST_WINS = tie

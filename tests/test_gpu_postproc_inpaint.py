@@ -13,6 +13,15 @@ from test_emu_postproc import _blob_maps
 pytestmark = pytest.mark.gpu
 
 
+def test_peakfind_wide_maps_bit_exact(gpu_device):
+    from tracknetv3_amd import ops
+    from test_emu_postproc import _wide_maps
+    maps = _wide_maps()
+    got = ops.heatmap_peakfind(torch.from_numpy(maps).to(gpu_device), 0.5).cpu().numpy()
+    want = np.array([opp.predict_location(opp.to_img(m > 0.5)) for m in maps])
+    assert np.array_equal(got, want)
+
+
 def test_peakfind_designed_maps_bit_exact(gpu_device):
     from tracknetv3_amd import ops
     maps = _blob_maps()

@@ -10,8 +10,9 @@
 //
 //  * peak-find = predict.py:35 (`> 0.5`) + predict_location (test.py:52-79): cv2.findContours(RETR_EXTERNAL) +
 //    cv2.boundingRect + largest box.  Integer work, restated as 8-connected component labelling by lock-free
-//    union-find (label = smallest linear pixel index of the component = its first pixel in raster order),
-//    per-root bounding boxes by atomic min/max, and ONE 64-bit atomicMax per root on (area << 32 | order) where
+//    union-find over horizontal RUNS (found with wave ballots, so a dense map costs one node per run, not per pixel;
+//    label = smallest linear pixel index of the component = its first pixel in raster order), per-root bounding boxes
+//    by atomic min/max of the run boxes, and ONE 64-bit atomicMax per root on (area << 32 | order) where
 //    `order` encodes the tie rule (equal areas: the component discovered last in raster order wins -- OpenCV's
 //    contour list order combined with the strict '>' at test.py:74; see oracle/postproc.py).  Bit-exact integers.
 #pragma once
@@ -77,6 +78,9 @@ __device__ __forceinline__ void ccl_union(int* lab, int a, int b) {
   }
 }
 
+// Pass 1 -- threshold + horizontal runs, no atomics: a wave owns 64 consecutive pixels; from the ballot of the
+// foreground bits every pixel gets the index of the first pixel of its run (within the 64-pixel segment and the image
+// row) as its label, and the run's first pixel records the run's box.  Dense maps collapse to one node per run.
 __global__ void __launch_bounds__(256) ccl_init_kernel(const float* __restrict__ heat, float thr, int* __restrict__ label,
                                                        int* __restrict__ box, unsigned long long* __restrict__ best,
                                                        int H, int W) {
@@ -86,44 +90,74 @@ __global__ void __launch_bounds__(256) ccl_init_kernel(const float* __restrict__
   int* lab = label + (size_t)f * HW;
   int* bx = box + (size_t)f * 4 * HW;
   if (blockIdx.x == 0 && threadIdx.x == 0) best[f] = 0ull;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-    const bool fg = hm[p] > thr;
-    lab[p] = fg ? p : -1;
+  const int lane = threadIdx.x & 63;
+  for (int p0 = blockIdx.x * 256; p0 < HW; p0 += gridDim.x * 256) {       // block-uniform trip count: ballots are full
+    const int p = p0 + threadIdx.x;
+    const bool valid = p < HW;
+    const int y = valid ? p / W : 0, x = p - y * W;
+    const bool fg = valid && hm[valid ? p : 0] > thr;
+    const unsigned long long M = __ballot(fg);
+    const unsigned long long R = __ballot(valid && x == 0);                 // lanes that begin an image row
     if (fg) {
-      const int y = p / W, x = p - y * W;
-      bx[p] = x; bx[HW + p] = y; bx[2 * HW + p] = x; bx[3 * HW + p] = y;
+      const unsigned long long S = M & (~(M << 1) | R);                     // run starts
+      const unsigned long long E = M & (~(M >> 1) | (R >> 1));              // run ends
+      const int s = 63 - __builtin_clzll(S & (~0ull >> (63 - lane)));
+      lab[p] = p - (lane - s);
+      if (s == lane) {
+        const int e = __builtin_ctzll(E & (~0ull << lane));
+        bx[p] = x; bx[HW + p] = y; bx[2 * HW + p] = x + (e - lane); bx[3 * HW + p] = y;
+      }
+    } else if (valid) {
+      lab[p] = -1;
     }
   }
 }
 
+__device__ __forceinline__ bool ccl_fg(const int* lab, int q) { return ccl_load(lab + q) >= 0; }
+
+// Pass 2 -- link runs (8-connectivity).  Only one pixel per pair of touching runs issues a union:
+//   * a run cut by a 64-pixel segment boundary is re-joined by its first pixel;
+//   * against the row above, the pixel under N links with N unless its left neighbour already sits under the same
+//     upper run (W and NW set); with N clear, NW is linked only by a run's first pixel and NE only when the right
+//     neighbour (which has NE as its N) is background.
 __global__ void __launch_bounds__(256) ccl_merge_kernel(int* __restrict__ label, int H, int W) {
   const int HW = H * W;
   int* lab = label + (size_t)blockIdx.y * HW;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-    if (ccl_load(lab + p) < 0) continue;
+    if (!ccl_fg(lab, p)) continue;
     const int y = p / W, x = p - y * W;
-    // 8-connectivity: link with the already-visited half of the neighbourhood (W, NW, N, NE)
-    if (x > 0 && ccl_load(lab + p - 1) >= 0) ccl_union(lab, p, p - 1);
+    const bool Wf = x > 0 && ccl_fg(lab, p - 1);
+    if ((p & 63) == 0 && Wf) ccl_union(lab, p, p - 1);
     if (y > 0) {
-      if (ccl_load(lab + p - W) >= 0) ccl_union(lab, p, p - W);
-      if (x > 0 && ccl_load(lab + p - W - 1) >= 0) ccl_union(lab, p, p - W - 1);
-      if (x + 1 < W && ccl_load(lab + p - W + 1) >= 0) ccl_union(lab, p, p - W + 1);
+      const bool N = ccl_fg(lab, p - W);
+      const bool NW = x > 0 && ccl_fg(lab, p - W - 1);
+      if (N) {
+        if (!(Wf && NW)) ccl_union(lab, p, p - W);
+      } else {
+        if (NW && !Wf) ccl_union(lab, p, p - W - 1);
+        if (x + 1 < W && ccl_fg(lab, p - W + 1) && !ccl_fg(lab, p + 1)) ccl_union(lab, p, p - W + 1);
+      }
     }
   }
 }
 
+// Pass 3 -- one node per run: resolve the root, fold the run's box into the root's box (atomics only when they would
+// change the value; min-y needs none: the root is the component's first pixel in raster order), flatten the label.
 __global__ void __launch_bounds__(256) ccl_box_kernel(int* __restrict__ label, int* __restrict__ box, int H, int W) {
   const int HW = H * W;
   int* lab = label + (size_t)blockIdx.y * HW;
   int* bx = box + (size_t)blockIdx.y * 4 * HW;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-    if (lab[p] < 0) continue;
-    const int r = ccl_find(lab, p);
-    if (r == p) continue;                                   // the root carries its own pixel already
+    if (!ccl_fg(lab, p)) continue;
     const int y = p / W, x = p - y * W;
-    atomicMin(bx + r, x); atomicMin(bx + HW + r, y);
-    atomicMax(bx + 2 * HW + r, x); atomicMax(bx + 3 * HW + r, y);
-    lab[p] = r;                                             // flatten (only this thread writes lab[p] in this pass)
+    if (!(x == 0 || (p & 63) == 0 || !ccl_fg(lab, p - 1))) continue;      // not the first pixel of a run
+    const int r = ccl_find(lab, p);
+    if (r == p) continue;                                                  // the root carries its own run already
+    const int x1 = bx[2 * HW + p];
+    if (x < ccl_load(bx + r)) atomicMin(bx + r, x);
+    if (x1 > ccl_load(bx + 2 * HW + r)) atomicMax(bx + 2 * HW + r, x1);
+    if (y > ccl_load(bx + 3 * HW + r)) atomicMax(bx + 3 * HW + r, y);
+    __atomic_store_n(lab + p, r, __ATOMIC_RELAXED);                        // flatten: r is a root, paths only get shorter
   }
 }
 
