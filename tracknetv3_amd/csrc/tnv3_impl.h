@@ -302,6 +302,7 @@ using WgradA = WgradCfg<4, 1, 4, 32>;   // 128 co x 32 ci per workgroup, 4x32-pi
 using WgradB = WgradCfg<2, 2, 4, 32>;   //  64 co x 64 ci per workgroup, 4x32-pixel K tiles
 
 struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
+constexpr int kNumCU = 256;   // MI355X: 8 XCDs x 32 CUs
 inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
   WgradPlan p;
   p.use_b = (cout % 128) != 0;
@@ -310,12 +311,22 @@ inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
   p.nCB = (cin + CB - 1) / CB;
   const int TR = p.use_b ? WgradB::TR : WgradA::TR;
   p.nTiles = n * ((h + TR - 1) / TR) * ((w + 31) / 32);
-  int sk = (1024 + p.nMB * p.nCB - 1) / (p.nMB * p.nCB);          // ~1024 workgroups: two rounds of 2 resident per CU
-  const int max_by_work = (p.nTiles * TR + 23) / 24;                // at least ~768 pixels of K per workgroup
-  if (sk > max_by_work) sk = max_by_work;
-  if (sk < 1) sk = 1;
-  if (sk > 4096) sk = 4096;
-  p.splitK = sk;
+  // One workgroup is resident per CU (LDS), all workgroups of a launch do the same work, so the launch runs in
+  // ceil(workgroups / kNumCU) rounds of ceil(nTiles / splitK) tiles (+ ~0.6 tile of prologue / slab write each).
+  // Pick the split that minimises rounds x tiles; ties go to the smaller split (fewer slabs to write and re-read).
+  const int nb = p.nMB * p.nCB;
+  int cap = (p.nTiles * TR + 23) / 24;                               // at least ~768 pixels of K per workgroup
+  if (cap > 4096) cap = 4096;
+  if (cap < 1) cap = 1;
+  int best_sk = 1;
+  double best = 1e300;
+  for (int sk = 1; sk <= cap; ++sk) {
+    const long blocks = (long)nb * sk;
+    if (sk > 1 && blocks > 16l * kNumCU) break;
+    const double cost = (double)((blocks + kNumCU - 1) / kNumCU) * ((double)((p.nTiles + sk - 1) / sk) + 0.6);
+    if (cost < best - 1e-9) { best = cost; best_sk = sk; }
+  }
+  p.splitK = best_sk;
   return p;
 }
 inline size_t wgrad_workspace_bytes(int n, int c0, int c1, int cout, int h, int w) {
@@ -344,6 +355,8 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   int rc = p.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB>, grid, WgradB::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA>, grid, WgradA::NT, a);
   if (rc) return rc;
   const long nel = (long)cout * (c0 + c1) * 9;
+  if ((nel & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dw) & 15) == 0)
+    return L.launch(sum_partials_vec4_kernel, grid_for(nel / 4, 256, 8192), 256, (const float*)ws, dw, nel / 4, p.splitK);
   return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)ws, dw, nel, p.splitK);
 }
 
