@@ -153,6 +153,29 @@ def test_inpaintnet_forward_emulated_vs_golden(emu):
         assert (net(c2, m2) - ref).abs().max().item() <= 2e-6
 
 
+CONV1D_MFMA_CASES = [   # (n, c0, c1, cout, act): every tile configuration of conv1d_mfma.h, ragged batches, two sources
+    (19, 32, 0, 64, 1), (5, 64, 0, 128, 1), (9, 128, 0, 256, 0), (3, 256, 128, 128, 1), (17, 64, 32, 32, 2), (1, 8, 8, 32, 1),
+]
+
+
+def _conv1d_case(n, c0, c1, cout, act, device):
+    import torch.nn.functional as F
+    from tracknetv3_amd import ops
+    x0 = nets.synth_input((n, c0, 16), 40 + n) - 0.5
+    x1 = (nets.synth_input((n, c1, 16), 41 + n) - 0.5) if c1 else None
+    w = (nets.synth_input((cout, c0 + c1, 3), 42 + cout) - 0.5) * (2.0 / (3 * (c0 + c1)) ** 0.5)
+    b = nets.synth_input((cout,), 43) - 0.5
+    z = F.conv1d(torch.cat([x0, x1], 1).double() if c1 else x0.double(), w.double(), b.double(), padding=1)
+    ref = {0: z, 1: F.leaky_relu(z, 0.01), 2: torch.sigmoid(z)}[act].float()
+    got = ops.conv1d_k3(x0.to(device), w.to(device), b.to(device), src1=None if x1 is None else x1.to(device), act=act).cpu()
+    return (got - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("case", CONV1D_MFMA_CASES)
+def test_conv1d_mfma_emulated_vs_torch(emu, case):
+    assert _conv1d_case(*case, "cpu") <= 3e-6
+
+
 def test_empty_batches_are_accepted(emu):
     """N = 0 flows through the reference's torch ops; the boundary accepts it too (no launch, empty result)."""
     from tracknetv3_amd import ops

@@ -9,6 +9,7 @@ from conftest import GOLDEN
 from oracle import nets, prng
 from oracle import postproc as opp
 from test_emu_postproc import _blob_maps
+from test_emu_kernels import CONV1D_MFMA_CASES, _conv1d_case
 
 pytestmark = pytest.mark.gpu
 
@@ -134,6 +135,11 @@ def test_inpaintnet_forward(gpu_device):
         assert (net(c2.to(gpu_device), m2.to(gpu_device)).cpu() - ref).abs().max().item() <= 2e-6
     # int mask as produced by train.py:153 (`.int()`) is accepted like torch.cat's type promotion
     assert (net(c2.to(gpu_device), m2.int().to(gpu_device)).cpu() - ref).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("case", CONV1D_MFMA_CASES + [(4099, 256, 128, 128, 1), (70000, 32, 0, 64, 1)])
+def test_conv1d_mfma_vs_torch(gpu_device, case):
+    assert _conv1d_case(*case, gpu_device) <= 3e-6
 
 
 def test_inpaintnet_train_step_vs_reference_golden(gpu_device):

@@ -7,6 +7,7 @@
 
 #include "kernels/conv3x3_mfma.h"
 #include "kernels/conv1d_k3.h"
+#include "kernels/conv1d_mfma.h"
 #include "kernels/pointwise.h"
 #include "kernels/postproc.h"
 #include "kernels/preproc.h"
@@ -184,6 +185,10 @@ int maxpool2x2_impl(Launcher& L, const float* x, float* y, long nc, int h, int w
   return L.launch(maxpool2x2_kernel, grid, 256, x, y, nc, h, w);
 }
 
+using Conv1dM128 = Conv1dMfmaCfg<2, 2, 2, 2>;   // 128 channels x 8 sequences
+using Conv1dM64 = Conv1dMfmaCfg<2, 2, 1, 4>;    //  64 channels x 16 sequences
+using Conv1dM32 = Conv1dMfmaCfg<1, 2, 1, 4>;    //  32 channels x 16 sequences
+
 template <class Launcher>
 int conv1d_k3_impl(Launcher& L, const float* src0, const float* src1, const float* w, const float* b, float* dst, int n,
                    int c0, int c1, int cout, int l, int src_nlc, int dst_nlc, int act) {
@@ -192,6 +197,19 @@ int conv1d_k3_impl(Launcher& L, const float* src0, const float* src1, const floa
   if (act < 0 || act > 2) TNV3_FAIL(-1, "conv1d_k3: unknown activation %d", act);
   constexpr int S = 8, COB = 32, CK = 32, LT = 16;
   Conv1dArgs a{src0, src1, w, b, dst, n, c0, c1, cout, l, src_nlc ? 1 : 0, dst_nlc ? 1 : 0, act, 0, nullptr, 0, 0};
+  // The dense layers (L = 16, channel counts in multiples of 8 / 32, channel-major tensors) go to the matrix cores.
+  if (l == 16 && !src_nlc && !dst_nlc && cout % 32 == 0 && c0 % 8 == 0 && c1 % 8 == 0 &&
+      (((uintptr_t)src0 | (uintptr_t)src1 | (uintptr_t)w) & 15) == 0) {
+    auto go = [&](auto cfg) -> int {
+      using Cfg = decltype(cfg);
+      const long blocks = ((long)n + Cfg::SB - 1) / Cfg::SB * ((cout + Cfg::MB - 1) / Cfg::MB);
+      if (blocks > 0x7fffffffl) TNV3_FAIL(-1, "conv1d_k3: batch too large");
+      return L.launch(conv1d_k3_mfma_kernel<Cfg>, (int)blocks, Cfg::NT, a);
+    };
+    if (cout % 128 == 0) return go(Conv1dM128{});
+    if (cout % 64 == 0) return go(Conv1dM64{});
+    return go(Conv1dM32{});
+  }
   const long gx = (n + S - 1) / S;
   if (gx > 0x7fffffffl) TNV3_FAIL(-1, "conv1d_k3: batch too large");
   return L.launch3(conv1d_k3_kernel<S, COB, CK, LT>, (int)gx, (cout + COB - 1) / COB, (l + LT - 1) / LT, S * COB, a);
