@@ -108,6 +108,12 @@ size_t tnv3_peakfind_workspace_bytes(int frames, int h, int w);
 int tnv3_heatmap_peakfind(const float* heat, float threshold, int tie_last_wins, int32_t* out_bbox, void* workspace,
                           size_t workspace_bytes, int frames, int h, int w, tnv3_stream_t stream);
 
+/* Per-map maximum inside a box: out[f] = max heat[f][y:y+h, x:x+w] with (x, y, w, h) = boxes[f] (int32, clipped to the
+ * map; 0 for an empty box), or the maximum of the whole map when boxes == NULL.  Replaces the detection confidence
+ * `np.amax(y_p[bbox...])` of evaluate() (test.py:164-167) and its `np.amax(y_t) > 0` ground-truth test (test.py:170-178),
+ * so validation never copies heat maps to the host.  NaN propagates as in numpy. */
+int tnv3_heatmap_box_max(const float* heat, const int32_t* boxes, float* out, int frames, int h, int w, tnv3_stream_t stream);
+
 /* ---- training step (train.py:84-96: forward in train mode, WBCELoss, loss.backward()) -------------------- */
 
 /* nn.BatchNorm2d in training mode (model.py:9) + nn.ReLU (model.py:10) on the raw convolution output z[N][C][HW]:

@@ -148,6 +148,93 @@ def predict(indices, y_pred=None, c_pred=None, img_scaler=(1, 1)):
     return pred_dict
 
 
+PRED_TYPES = ("TP", "TN", "FP1", "FP2", "FN")          # test.py:20-21: Type is the index into this list
+
+
+def _classify(pred_present, true_present, pred_xy, true_xy, tolerance):
+    """The five-way typing of test.py:136-156 / 170-190 given 'is there a ball' on both sides and integer centres."""
+    if not pred_present and not true_present:
+        return PRED_TYPES.index("TN")
+    if pred_present and not true_present:
+        return PRED_TYPES.index("FP2")
+    if not pred_present and true_present:
+        return PRED_TYPES.index("FN")
+    dist = math.sqrt((pred_xy[0] - true_xy[0]) ** 2 + (pred_xy[1] - true_xy[1]) ** 2)
+    return PRED_TYPES.index("FP1") if dist > tolerance else PRED_TYPES.index("TP")
+
+
+def evaluate(indices, y_true=None, y_pred=None, c_true=None, c_pred=None, tolerance=4., img_scaler=(1, 1),
+             output_bbox=False, output_gt=False):
+    """test.py:81-221 restated.  indices (N, L, 2); heat maps (N, L, H, W) or normalised coordinates (N, L, 2).
+    Unlike predict(), the repeated-index stop is per sample and compares the whole (rally, frame) pair."""
+    out = {k: [] for k in ("Frame", "X", "Y", "Visibility", "Type", "BBox", "Confidence", "X_GT", "Y_GT", "Visibility_GT")}
+    indices = np.asarray(indices)
+    n_samples, seq_len = indices.shape[0], indices.shape[1]
+    heat = y_true is not None and y_pred is not None
+    coor = c_true is not None and c_pred is not None
+    if heat:
+        assert c_true is None and c_pred is None, "Invalid input"
+        y_true, y_pred = np.asarray(y_true), np.asarray(y_pred)
+        h_pred = y_pred > 0.5
+    if coor:
+        assert y_true is None and y_pred is None, "Invalid input"
+        assert not output_bbox, "Coordinate prediction cannot output detection"
+        c_true, c_pred = np.array(c_true, copy=True), np.array(c_pred, copy=True)     # test.py:119-122, in the input's dtype
+        for c in (c_true, c_pred):
+            c[..., 0] = c[..., 0] * WIDTH
+            c[..., 1] = c[..., 1] * HEIGHT
+    if not heat and not coor:
+        raise ValueError("Invalid input")
+    for n in range(n_samples):
+        prev = (-1, -1)
+        for f in range(seq_len):
+            d_i = (int(indices[n][f][0]), int(indices[n][f][1]))
+            if d_i == prev:
+                break
+            if coor:
+                c_t, c_p = c_true[n][f], c_pred[n][f]
+                true_xy = (int(c_t[0]), int(c_t[1]))
+                pred_xy = (int(c_p[0]), int(c_p[1]))
+                typ = _classify(np.amax(c_p) > 0, np.amax(c_t) > 0, pred_xy, true_xy, tolerance)
+            else:
+                bt = predict_location(to_img(y_true[n][f]))
+                true_xy = (int(bt[0] + bt[2] / 2), int(bt[1] + bt[3] / 2))
+                bp = predict_location(to_img(h_pred[n][f]))
+                pred_xy = (int(bp[0] + bp[2] / 2), int(bp[1] + bp[3] / 2))
+                conf = np.amax(y_pred[n][f][bp[1]:bp[1] + bp[3], bp[0]:bp[0] + bp[2]]) if max(bp) > 0 else 0.
+                typ = _classify(bool(np.amax(h_pred[n][f]) > 0), bool(np.amax(y_true[n][f]) > 0), pred_xy, true_xy, tolerance)
+            out["Type"].append(typ)
+            out["Frame"].append(d_i[1])
+            out["X"].append(int(pred_xy[0] * img_scaler[0]))
+            out["Y"].append(int(pred_xy[1] * img_scaler[1]))
+            out["Visibility"].append(0 if pred_xy == (0, 0) else 1)
+            if output_bbox:
+                out["BBox"].append([int(bp[0] * img_scaler[0]), int(bp[1] * img_scaler[1]),
+                                    int(bp[2] * img_scaler[0]), int(bp[3] * img_scaler[1])])
+                out["Confidence"].append(float(conf))
+            if output_gt:
+                out["X_GT"].append(int(true_xy[0] * img_scaler[0]))
+                out["Y_GT"].append(int(true_xy[1] * img_scaler[1]))
+                out["Visibility_GT"].append(0 if true_xy == (0, 0) else 1)
+            prev = d_i
+    if not output_bbox:
+        del out["BBox"], out["Confidence"]
+    if not output_gt:
+        del out["X_GT"], out["Y_GT"], out["Visibility_GT"]
+    return out
+
+
+def get_metric(TP, TN, FP1, FP2, FN):
+    """utils/metric.py:22-46: accuracy, precision, recall, F1, miss rate (0 where a denominator is 0)."""
+    total = TP + TN + FP1 + FP2 + FN
+    accuracy = (TP + TN) / total if total > 0 else 0
+    precision = TP / (TP + FP1 + FP2) if (TP + FP1 + FP2) > 0 else 0
+    recall = TP / (TP + FN) if (TP + FN) > 0 else 0
+    f1 = 2 * precision * recall / (precision + recall) if (precision + recall) > 0 else 0
+    miss_rate = FN / (TP + FN) if (TP + FN) > 0 else 0
+    return accuracy, precision, recall, f1, miss_rate
+
+
 def generate_inpaint_mask(pred_dict, th_h=30):
     """test.py:234-258."""
     y = np.array(pred_dict["Y"])

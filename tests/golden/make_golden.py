@@ -31,6 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, REF)
 
 import model as ref_model                      # noqa: E402  (reference)
@@ -73,6 +74,14 @@ ref_predict = extract_function(
     "predict.py", "predict",
     {"torch": torch, "np": np, "WIDTH": 512, "HEIGHT": 288, "to_img": ref_to_img,
      "to_img_format": ref_to_img_format, "predict_location": postproc.predict_location})
+
+
+ref_evaluate = extract_function(
+    "test.py", "evaluate",
+    {"torch": torch, "np": np, "math": math, "WIDTH": 512, "HEIGHT": 288, "to_img": ref_to_img,
+     "to_img_format": ref_to_img_format, "predict_location": postproc.predict_location,
+     "pred_types_map": {t: i for i, t in enumerate(["TP", "TN", "FP1", "FP2", "FN"])}})
+ref_get_metric = extract_function("utils/metric.py", "get_metric", {})
 
 
 def extract_ensemble_loops():
@@ -463,6 +472,44 @@ def host_logic_cases():
     print("[host] get_model / ensemble weights / inpaint mask / mixup / predict pinned")
 
 
+from pipeline_common import evaluate_inputs   # noqa: E402  (deterministic inputs shared with the tests)
+
+
+def _pack_eval(d):
+    keys = ["Frame", "X", "Y", "Visibility", "Type"]
+    out = {k: np.array(d[k]) for k in keys}
+    for k in ("BBox", "Confidence", "X_GT", "Y_GT", "Visibility_GT"):
+        if k in d:
+            out[k] = np.array(d[k])
+    return out
+
+
+def evaluate_cases():
+    idx, y_true, y_pred, c_true, c_pred = evaluate_inputs()
+    out = {}
+    for name, kw in (("h_plain", dict(tolerance=4.)), ("h_full", dict(tolerance=4., img_scaler=(3.75, 3.75), output_bbox=True, output_gt=True)),
+                     ("h_tol1", dict(tolerance=1.))):
+        a = ref_evaluate(torch.from_numpy(idx), y_true=torch.from_numpy(y_true.copy()), y_pred=torch.from_numpy(y_pred.copy()), **kw)
+        b = postproc.evaluate(idx, y_true=y_true, y_pred=y_pred, **kw)
+        assert a == b, name
+        for k, v in _pack_eval(a).items():
+            out[f"{name}_{k}"] = v
+    for name, kw in (("c_plain", dict(tolerance=4.)), ("c_gt", dict(tolerance=4., img_scaler=(3.75, 3.75), output_gt=True))):
+        a = ref_evaluate(torch.from_numpy(idx), c_true=torch.from_numpy(c_true.copy()), c_pred=torch.from_numpy(c_pred.copy()), **kw)
+        b = postproc.evaluate(idx, c_true=c_true, c_pred=c_pred, **kw)
+        assert a == b, name
+        for k, v in _pack_eval(a).items():
+            out[f"{name}_{k}"] = v
+    rows = []
+    for tp, tn, fp1, fp2, fn in ((0, 0, 0, 0, 0), (10, 5, 1, 2, 3), (0, 7, 0, 0, 0), (3, 0, 0, 0, 9), (0, 0, 4, 4, 0), (977, 13, 8, 14, 6)):
+        a = ref_get_metric(tp, tn, fp1, fp2, fn)
+        assert a == postproc.get_metric(tp, tn, fp1, fp2, fn)
+        rows.append([tp, tn, fp1, fp2, fn, *a])
+    out["get_metric"] = np.array(rows, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "evaluate.npz"), **out)
+    print("[host] evaluate / get_metric pinned:", {k: v.tolist() for k, v in out.items() if k.endswith("_Type")})
+
+
 def ensemble_cases():
     out = {}
     k = 0
@@ -506,6 +553,7 @@ def ensemble_cases():
 
 if __name__ == "__main__":
     host_logic_cases()
+    evaluate_cases()
     ensemble_cases()
     wbce_case()
     inpaint_case()

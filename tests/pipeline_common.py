@@ -3,7 +3,7 @@ frame ids carried in the frames, and the oracle-side restatement of predict.py's
 import numpy as np
 import torch
 
-from oracle import nets
+from oracle import nets, prng
 from oracle import postproc as opp
 
 
@@ -123,3 +123,60 @@ def check_pipeline(device, h, w, t, batch, eval_mode):
     # the non-overlap mode covers every frame exactly once as well
     no = predict_video(frames.to(device), stub, net, seq_len, inp_len, "concat", "nonoverlap", batch, img_shape)
     assert no["Frame"] == list(range(t))
+
+
+def evaluate_inputs():
+    """Deterministic evaluate() inputs, shared with the tests (rebuilt there from the portable PRNG)."""
+    n, L = 5, 4
+    idx = np.zeros((n, L, 2), dtype=np.int64)
+    idx[:, :, 0] = np.arange(n)[:, None] % 2
+    idx[:, :, 1] = np.arange(n * L).reshape(n, L)
+    idx[4, 2:, 1] = idx[4, 1, 1]                                   # padded tail: stops after the first repeat
+    y_true = np.zeros((n, L, 288, 512), dtype=np.float32)
+    y_pred = (prng.uniform((n, L, 288, 512), 4100) * 0.4).astype(np.float32)
+    cen = (prng.uniform((n, L, 2), 4101) * np.array([480, 260]) + 12).astype(int)
+    for i in range(n):
+        for f in range(L):
+            cx, cy = cen[i, f]
+            kind = (i * L + f) % 6
+            if kind != 1 and kind != 4:                                # GT present (disc r=2.5)
+                yy, xx = np.ogrid[:288, :512]
+                y_true[i, f][(yy - cy) ** 2 + (xx - cx) ** 2 <= 6.25] = 1.0
+            if kind in (0, 1):                                         # prediction near the centre -> TP / FP2
+                y_pred[i, f, cy - 2:cy + 3, cx - 1:cx + 4] = 0.6 + 0.05 * f
+            elif kind == 2:                                            # prediction far away -> FP1
+                y_pred[i, f, (cy + 40) % 280:(cy + 40) % 280 + 3, (cx + 60) % 500:(cx + 60) % 500 + 3] = 0.9
+            elif kind == 3:                                            # exactly `tolerance` = 4 px away (dist > tol is strict)
+                y_pred[i, f, cy - 2:cy + 3, cx + 2:cx + 7] = 0.7
+            # kind 4: neither (TN), kind 5: GT only (FN)
+    c_true = prng.uniform((n, L, 2), 4102).astype(np.float32)
+    c_pred = (c_true + (prng.uniform((n, L, 2), 4103).astype(np.float32) - 0.5) * 0.02).astype(np.float32)
+    c_true[0, 1] = 0; c_pred[0, 1] = 0                                 # TN
+    c_true[1, 0] = 0                                                   # FP2
+    c_pred[1, 2] = 0                                                   # FN
+    c_pred[2, 3] = c_true[2, 3] + 0.3                                  # FP1
+    return idx, y_true, y_pred, c_true, c_pred
+
+
+EVAL_CASES = {   # name -> evaluate() keyword arguments; expected dicts live in tests/golden/evaluate.npz
+    "h_plain": dict(tolerance=4.), "h_full": dict(tolerance=4., img_scaler=(3.75, 3.75), output_bbox=True, output_gt=True),
+    "h_tol1": dict(tolerance=1.), "c_plain": dict(tolerance=4.), "c_gt": dict(tolerance=4., img_scaler=(3.75, 3.75), output_gt=True),
+}
+
+
+def check_evaluate_against_golden(evaluate_fn, golden, to_dev=lambda a: a):
+    """Run evaluate_fn on the shared inputs for every case and compare each list of the result with the golden."""
+    idx, y_true, y_pred, c_true, c_pred = evaluate_inputs()
+    for name, kw in EVAL_CASES.items():
+        if name.startswith("h_"):
+            got = evaluate_fn(torch.from_numpy(idx), y_true=to_dev(torch.from_numpy(y_true)), y_pred=to_dev(torch.from_numpy(y_pred)), **kw)
+        else:
+            got = evaluate_fn(torch.from_numpy(idx), c_true=torch.from_numpy(c_true.copy()), c_pred=torch.from_numpy(c_pred.copy()), **kw)
+        want_keys = [k[len(name) + 1:] for k in golden.files if k.startswith(name + "_")]
+        assert sorted(got.keys()) == sorted(want_keys), (name, sorted(got.keys()), sorted(want_keys))
+        for k in want_keys:
+            want = golden[f"{name}_{k}"]
+            if k == "Confidence":
+                assert np.array_equal(np.array(got[k], dtype=np.float32), want.astype(np.float32)), (name, k)
+            else:
+                assert np.array_equal(np.array(got[k]), want), (name, k, got[k], want.tolist())

@@ -131,3 +131,27 @@ def test_predict_video_pipeline_emulated_vs_oracle_flow(emu):
     coordinates) on small maps with a synthetic heat-map stub in place of TrackNet."""
     from pipeline_common import check_pipeline
     check_pipeline(torch.device("cpu"), 24, 40, 31, 5, "weight")
+
+
+def test_evaluate_emulated_vs_reference_golden(emu):
+    """postprocess.evaluate (device peak-finds + box maxima, host typing) reproduces the reference's evaluate() dicts."""
+    from pipeline_common import check_evaluate_against_golden
+    from tracknetv3_amd import postprocess as pp
+    from tracknetv3_amd.utils.metric import get_metric
+    g = np.load(os.path.join(GOLDEN, "evaluate.npz"))
+    check_evaluate_against_golden(pp.evaluate, g)
+    for row in g["get_metric"]:
+        assert np.array_equal(np.array(get_metric(*(int(v) for v in row[:5])), dtype=np.float64), row[5:])
+
+
+def test_box_max_emulated(emu):
+    from tracknetv3_amd import ops
+    rng = np.random.RandomState(2)
+    heat = rng.rand(6, 20, 70).astype(np.float32)
+    boxes = np.array([[0, 0, 70, 20], [3, 4, 5, 6], [69, 19, 1, 1], [0, 0, 0, 0], [10, 0, 60, 1], [64, 5, 30, 30]], dtype=np.int32)
+    got = ops.heatmap_box_max(torch.from_numpy(heat), torch.from_numpy(boxes)).numpy()
+    want = [heat[f, y:y + h, x:x + w].max() if w > 0 and h > 0 else 0.0 for f, (x, y, w, h) in enumerate(boxes)]
+    assert np.array_equal(got, np.array(want, dtype=np.float32))
+    assert np.array_equal(ops.heatmap_box_max(torch.from_numpy(heat)).numpy(), heat.reshape(6, -1).max(1))
+    heat[1, 5, 4] = np.nan
+    assert np.isnan(ops.heatmap_box_max(torch.from_numpy(heat), torch.from_numpy(boxes)).numpy()[1])

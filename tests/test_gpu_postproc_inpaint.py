@@ -242,3 +242,10 @@ def test_difference_frame_modes_1080p_bit_exact(gpu_device):
         assert med is None and frames.shape == (8, c, 288, 512)
         x = _assemble(frames, None, _windows(8, 8, 1, False), mode).cpu().numpy()
         assert np.array_equal(x, opre.tracknet_input_from_frames(fr, [0], 8, mode))
+
+
+def test_evaluate_vs_reference_golden(gpu_device):
+    from pipeline_common import check_evaluate_against_golden
+    from tracknetv3_amd import postprocess as pp
+    g = np.load(os.path.join(GOLDEN, "evaluate.npz"))
+    check_evaluate_against_golden(pp.evaluate, g, to_dev=lambda a: a.to(gpu_device))

@@ -140,3 +140,15 @@ def test_predict_location_against_scipy_label():
     img[1:3, 1:3] = 255
     img[6:8, 5:7] = 255
     assert postproc.predict_location(img) == (5, 6, 2, 2)
+
+
+def test_evaluate_and_get_metric_vs_reference_golden():
+    """oracle.postproc.evaluate / get_metric against the dicts the reference's own evaluate() (test.py:81-221) and
+    get_metric (utils/metric.py:22-46) produced in the golden generator."""
+    from pipeline_common import check_evaluate_against_golden
+    from oracle import postproc as opp
+    g = np.load(os.path.join(GOLDEN, "evaluate.npz"))
+    check_evaluate_against_golden(lambda idx, **kw: opp.evaluate(idx.numpy(), **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in kw.items()}), g)
+    for row in g["get_metric"]:
+        got = opp.get_metric(*(int(v) for v in row[:5]))
+        assert np.array_equal(np.array(got, dtype=np.float64), row[5:])

@@ -43,6 +43,7 @@ def _declare(lib):
     sig("tnv3_ensemble_frames", i, p, i, lg, i, i, p, lg, i, lg, p, p)
     sig("tnv3_peakfind_workspace_bytes", sz, i, i, i)
     sig("tnv3_heatmap_peakfind", i, p, f, i, p, p, sz, i, i, i, p)
+    sig("tnv3_heatmap_box_max", i, p, p, p, i, i, i, p)
     sig("tnv3_bn_workspace_bytes", sz, i)
     sig("tnv3_bn_train_forward", i, p, p, p, p, p, f, f, p, p, p, p, sz, i, i, i, p)
     sig("tnv3_bn_relu_backward", i, p, p, p, p, p, p, p, p, p, p, sz, i, i, i, p)
@@ -75,7 +76,8 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_bn_relu_backward", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",
            "tnv3_wbce_workspace_bytes", "tnv3_wbce_forward", "tnv3_wbce_backward", "tnv3_head_backward_workspace_bytes",
            "tnv3_head_backward", "tnv3_maxpool2x2_backward_add", "tnv3_upsample2x_backward", "tnv3_mixup",
-           "tnv3_mfma_f32_probe", "tnv3_conv3x3_forward_diag", "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_absdiff_sum_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad"]
+           "tnv3_mfma_f32_probe", "tnv3_conv3x3_forward_diag", "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_absdiff_sum_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad",
+           "tnv3_heatmap_box_max"]
 
 
 def library_path():

@@ -175,6 +175,40 @@ __global__ void __launch_bounds__(256) ccl_select_kernel(const int* __restrict__
   }
 }
 
+// out[f] = max of heat[f] over the box (x, y, w, h) = boxes[f] (the whole map when boxes == nullptr); 0 for an empty box.
+// test.py:164-167: the detection confidence `np.amax(y_p[y:y+h, x:x+w])`; with boxes == nullptr: the `np.amax(y_t) > 0`
+// "ground truth has a ball" test of test.py:170-178.  One workgroup per map, fixed-shape tree reduction (max is exact).
+__global__ void __launch_bounds__(256) heatmap_box_max_kernel(const float* __restrict__ heat, const int* __restrict__ boxes,
+                                                              float* __restrict__ out, int H, int W) {
+  __shared__ float red[256];
+  const int f = blockIdx.x;
+  int x0 = 0, y0 = 0, bw = W, bh = H;
+  if (boxes) { x0 = boxes[4 * f]; y0 = boxes[4 * f + 1]; bw = boxes[4 * f + 2]; bh = boxes[4 * f + 3]; }
+  if (x0 < 0) { bw += x0; x0 = 0; }
+  if (y0 < 0) { bh += y0; y0 = 0; }
+  if (x0 + bw > W) bw = W - x0;
+  if (y0 + bh > H) bh = H - y0;
+  const float* hm = heat + (size_t)f * H * W;
+  const int n = (bw > 0 && bh > 0) ? bw * bh : 0;
+  float m = -__builtin_inff();
+  bool nan = false;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = hm[(size_t)(y0 + i / bw) * W + x0 + i % bw];
+    nan |= v != v;
+    m = v > m ? v : m;
+  }
+  red[threadIdx.x] = nan ? __builtin_nanf("") : m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const float a = red[threadIdx.x], b = red[threadIdx.x + s];
+      red[threadIdx.x] = (a != a || b != b) ? __builtin_nanf("") : (b > a ? b : a);     // NaN propagates like np.amax
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[f] = n > 0 ? red[0] : 0.0f;
+}
+
 // out[f] = (x, y, w, h) of the winning box, or (0,0,0,0) when the thresholded map is empty (test.py:60-62)
 __global__ void ccl_emit_kernel(const int* __restrict__ box, const unsigned long long* __restrict__ best,
                                 int* __restrict__ out, int frames, int H, int W, int tie_last_wins) {

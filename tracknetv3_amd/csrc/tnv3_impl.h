@@ -259,6 +259,13 @@ int heatmap_peakfind_impl(Launcher& L, const float* heat, float thr, int tie_las
 }
 
 template <class Launcher>
+int heatmap_box_max_impl(Launcher& L, const float* heat, const int32_t* boxes, float* out, int frames, int h, int w) {
+  if (!heat || !out || frames <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "heatmap_box_max: bad argument");
+  if ((long)h * w >= (1l << 31)) TNV3_FAIL(-1, "heatmap_box_max: map too large");
+  return L.launch(heatmap_box_max_kernel, frames, 256, heat, (const int*)boxes, out, h, w);
+}
+
+template <class Launcher>
 int mfma_probe_impl(Launcher& L, float* out, int blocks, int iters) {
   if (!out || blocks <= 0 || iters <= 0) TNV3_FAIL(-1, "mfma_probe: bad argument");
   return L.launch(mfma_f32_probe_kernel, blocks, 256, out, iters, 0.5f, 0.25f);

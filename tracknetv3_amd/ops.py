@@ -178,6 +178,22 @@ def heatmap_peakfind(heat, threshold=0.5, tie_last_wins=True):
     return out
 
 
+def heatmap_box_max(heat, boxes=None):
+    """(frames, H, W) fp32 maps [+ (frames, 4) int32 boxes (x, y, w, h)] -> (frames,) maxima (0 for an empty box)."""
+    lib = _lib.load()
+    _f32(heat)
+    _lib.dev_check(heat, boxes)
+    if heat.dim() != 3:
+        raise _lib.Tnv3Error("heatmap_box_max: expected (frames, H, W)")
+    frames, h, w = (int(v) for v in heat.shape)
+    if boxes is not None and (boxes.dtype != torch.int32 or tuple(boxes.shape) != (frames, 4) or not boxes.is_contiguous()):
+        raise _lib.Tnv3Error("heatmap_box_max: boxes must be contiguous int32 (frames, 4)")
+    out = torch.empty(frames, dtype=torch.float32, device=heat.device)
+    if frames:
+        _lib.check(lib.tnv3_heatmap_box_max(_lib.ptr(heat), _lib.ptr(boxes), _lib.ptr(out), frames, h, w, _lib.stream_ptr(heat)))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------- training ops
 def _workspace(nbytes, device):
     return torch.empty((int(nbytes) + 7) // 8, dtype=torch.int64, device=device)

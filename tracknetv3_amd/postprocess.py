@@ -93,6 +93,99 @@ def predict(indices, y_pred=None, c_pred=None, img_scaler=(1, 1)):
     return pred_dict
 
 
+pred_types = ['TP', 'TN', 'FP1', 'FP2', 'FN']                      # test.py:20-21
+pred_types_map = {pred_type: i for i, pred_type in enumerate(pred_types)}
+
+
+def _pred_type(pred_ball, true_ball, cx_pred, cy_pred, cx_true, cy_true, tolerance):
+    if not pred_ball and not true_ball:
+        return pred_types_map['TN']
+    if pred_ball and not true_ball:
+        return pred_types_map['FP2']
+    if not pred_ball and true_ball:
+        return pred_types_map['FN']
+    dist = math.sqrt(pow(cx_pred - cx_true, 2) + pow(cy_pred - cy_true, 2))
+    return pred_types_map['FP1'] if dist > tolerance else pred_types_map['TP']
+
+
+def evaluate(indices, y_true=None, y_pred=None, c_true=None, c_pred=None, tolerance=4., img_scaler=(1, 1),
+             output_bbox=False, output_gt=False):
+    """Per-frame TP / TN / FP1 / FP2 / FN typing with the reference's signature and result dict (test.py:81-221).
+
+    Heat-map inputs (N, L, H, W), values in [0, 1], stay on the device: both peak-finds (ground truth through
+    `to_img`, prediction through `> 0.5`), the "is there a ball" maxima and the detection confidence are computed by
+    libtnv3_hip.so; only (N*L) x 4 integers and N*L floats reach the host.  Coordinate inputs (N, L, 2) are typed on the
+    host as in the reference.  The inputs are not modified (the reference scales c_true / c_pred in place)."""
+    pred_dict = {'Frame': [], 'X': [], 'Y': [], 'Visibility': [], 'Type': [], 'BBox': [], 'Confidence': [],
+                 'X_GT': [], 'Y_GT': [], 'Visibility_GT': []}
+    batch_size, seq_len = indices.shape[0], indices.shape[1]
+    indices = indices.detach().cpu().numpy().tolist() if torch.is_tensor(indices) else np.asarray(indices).tolist()
+    heat = y_true is not None and y_pred is not None
+    coor = c_true is not None and c_pred is not None
+    if heat:
+        assert c_true is None and c_pred is None, 'Invalid input'
+        y_pred = torch.as_tensor(y_pred)
+        dev = _device_of(y_pred)
+        h, w = int(y_pred.shape[-2]), int(y_pred.shape[-1])
+        yp = y_pred.to(device=dev, dtype=torch.float32).reshape(batch_size * seq_len, h, w).contiguous()
+        yt = torch.as_tensor(y_true).to(device=dev, dtype=torch.float32).reshape(batch_size * seq_len, h, w).contiguous()
+        # to_img(y_t) = (y_t * 255).astype('uint8') is non-zero iff the fp32 product reaches 1
+        box_t = ops.heatmap_peakfind(yt * 255.0, threshold=float(np.nextafter(np.float32(1), np.float32(0))),
+                                     tie_last_wins=TIE_LAST_WINS)
+        box_p = ops.heatmap_peakfind(yp, threshold=0.5, tie_last_wins=TIE_LAST_WINS)
+        true_ball = (ops.heatmap_box_max(yt) > 0).cpu().numpy().reshape(batch_size, seq_len)
+        conf = ops.heatmap_box_max(yp, box_p).cpu().numpy().reshape(batch_size, seq_len) if output_bbox else None
+        box_t = box_t.cpu().numpy().reshape(batch_size, seq_len, 4)
+        box_p = box_p.cpu().numpy().reshape(batch_size, seq_len, 4)
+    if coor:
+        assert y_true is None and y_pred is None, 'Invalid input'
+        assert output_bbox == False, 'Coordinate prediction cannot output detection'  # noqa: E712
+        c_true = np.array(c_true.detach().cpu().numpy() if torch.is_tensor(c_true) else c_true, copy=True)
+        c_pred = np.array(c_pred.detach().cpu().numpy() if torch.is_tensor(c_pred) else c_pred, copy=True)
+        for c in (c_true, c_pred):
+            c[..., 0] = c[..., 0] * WIDTH
+            c[..., 1] = c[..., 1] * HEIGHT
+
+    for n in range(batch_size):
+        prev_d_i = [-1, -1]
+        for f in range(seq_len):
+            d_i = indices[n][f]
+            if d_i == prev_d_i:
+                break
+            if coor:
+                c_t, c_p = c_true[n][f], c_pred[n][f]
+                cx_true, cy_true = int(c_t[0]), int(c_t[1])
+                cx_pred, cy_pred = int(c_p[0]), int(c_p[1])
+                typ = _pred_type(np.amax(c_p) > 0, np.amax(c_t) > 0, cx_pred, cy_pred, cx_true, cy_true, tolerance)
+            elif heat:
+                bt = [int(v) for v in box_t[n][f]]
+                bp = [int(v) for v in box_p[n][f]]
+                cx_true, cy_true = int(bt[0] + bt[2] / 2), int(bt[1] + bt[3] / 2)
+                cx_pred, cy_pred = int(bp[0] + bp[2] / 2), int(bp[1] + bp[3] / 2)
+                typ = _pred_type(bp[2] > 0, bool(true_ball[n][f]), cx_pred, cy_pred, cx_true, cy_true, tolerance)
+            else:
+                raise ValueError('Invalid input')
+            pred_dict['Type'].append(typ)
+            pred_dict['Frame'].append(int(d_i[1]))
+            pred_dict['X'].append(int(cx_pred * img_scaler[0]))
+            pred_dict['Y'].append(int(cy_pred * img_scaler[1]))
+            pred_dict['Visibility'].append(0 if cx_pred == 0 and cy_pred == 0 else 1)
+            if output_bbox:
+                pred_dict['BBox'].append([int(bp[0] * img_scaler[0]), int(bp[1] * img_scaler[1]),
+                                          int(bp[2] * img_scaler[0]), int(bp[3] * img_scaler[1])])
+                pred_dict['Confidence'].append(float(conf[n][f]))
+            if output_gt:
+                pred_dict['X_GT'].append(int(cx_true * img_scaler[0]))
+                pred_dict['Y_GT'].append(int(cy_true * img_scaler[1]))
+                pred_dict['Visibility_GT'].append(0 if cx_true == 0 and cy_true == 0 else 1)
+            prev_d_i = d_i
+    if not output_bbox:
+        del pred_dict['BBox'], pred_dict['Confidence']
+    if not output_gt:
+        del pred_dict['X_GT'], pred_dict['Y_GT'], pred_dict['Visibility_GT']
+    return pred_dict
+
+
 def generate_inpaint_mask(pred_dict, th_h=30):
     """Mask the invisible runs whose neighbours are both below the height threshold (host integer scan)."""
     y = np.array(pred_dict['Y'])
