@@ -108,6 +108,11 @@ size_t tnv3_peakfind_workspace_bytes(int frames, int h, int w);
 int tnv3_heatmap_peakfind(const float* heat, float threshold, int tie_last_wins, int32_t* out_bbox, void* workspace,
                           size_t workspace_bytes, int frames, int h, int w, tnv3_stream_t stream);
 
+/* Tuning / diagnostic knob: selects the weight-gradient kernel family for the whole process and returns the previous
+ * value.  0 (default): register-staged 4x32-pixel tiles;  1: LDS-DMA staged, double-buffered 2x32-pixel tiles.  Any other
+ * value only queries.  Call tnv3_conv3x3_wgrad_workspace_bytes again after switching (the split-K plan follows). */
+int tnv3_conv3x3_wgrad_variant(int variant);
+
 /* Per-map maximum inside a box: out[f] = max heat[f][y:y+h, x:x+w] with (x, y, w, h) = boxes[f] (int32, clipped to the
  * map; 0 for an empty box), or the maximum of the whole map when boxes == NULL.  Replaces the detection confidence
  * `np.amax(y_p[bbox...])` of evaluate() (test.py:164-167) and its `np.amax(y_t) > 0` ground-truth test (test.py:170-178),

@@ -46,8 +46,17 @@ def test_bn_train_forward_backward_emulated(emu):
 @pytest.mark.parametrize("case", [(2, 5, 0, 64, 6, 40, False), (1, 32, 16, 128, 4, 16, True), (2, 64, 0, 192, 4, 8, False),
                                   (1, 27, 0, 64, 5, 36, False)],
                          ids=["b_5to64", "a_dual_up_48to128", "b_64to192", "b_27to64_ragged"])
-def test_wgrad_mfma_and_dgrad_emulated(emu, case):
+@pytest.mark.parametrize("variant", [0, 1], ids=["regstaged", "ldsdma"])
+def test_wgrad_mfma_and_dgrad_emulated(emu, case, variant):
     from tracknetv3_amd import ops
+    old = ops.wgrad_variant(variant)
+    try:
+        _wgrad_case(case, ops)
+    finally:
+        ops.wgrad_variant(old)
+
+
+def _wgrad_case(case, ops):
     n, c0, c1, cout, h, w, up = case
     s0 = T((n, c0, h // 2, w // 2) if up else (n, c0, h, w), 11)
     s1 = T((n, c1, h, w), 12) if c1 else None

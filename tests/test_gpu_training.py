@@ -40,9 +40,17 @@ def test_bn_train_forward_backward(gpu_device):
 @pytest.mark.parametrize("case", [(2, 27, 0, 64, 40, 96, False), (2, 64, 0, 64, 32, 64, False), (1, 128, 64, 64, 32, 64, True),
                                   (2, 512, 256, 256, 8, 32, True), (2, 256, 0, 512, 12, 32, False), (1, 128, 0, 256, 18, 52, False)],
                          ids=["27to64", "64to64", "dual192to64", "dual768to256", "256to512", "128to256_ragged"])
-def test_wgrad_and_dgrad(gpu_device, case):
+@pytest.mark.parametrize("variant", [0, 1], ids=["regstaged", "ldsdma"])
+def test_wgrad_and_dgrad(gpu_device, case, variant):
     from tracknetv3_amd import ops
-    d = gpu_device
+    old = ops.wgrad_variant(variant)
+    try:
+        _wgrad_case(case, ops, gpu_device)
+    finally:
+        ops.wgrad_variant(old)
+
+
+def _wgrad_case(case, ops, d):
     n, c0, c1, cout, h, w, up = case
     s0 = T((n, c0, h // 2, w // 2) if up else (n, c0, h, w), 11)
     s1 = T((n, c1, h, w), 12) if c1 else None

@@ -44,6 +44,7 @@ def _declare(lib):
     sig("tnv3_peakfind_workspace_bytes", sz, i, i, i)
     sig("tnv3_heatmap_peakfind", i, p, f, i, p, p, sz, i, i, i, p)
     sig("tnv3_heatmap_box_max", i, p, p, p, i, i, i, p)
+    sig("tnv3_conv3x3_wgrad_variant", i, i)
     sig("tnv3_bn_workspace_bytes", sz, i)
     sig("tnv3_bn_train_forward", i, p, p, p, p, p, f, f, p, p, p, p, sz, i, i, i, p)
     sig("tnv3_bn_relu_backward", i, p, p, p, p, p, p, p, p, p, p, sz, i, i, i, p)
@@ -77,7 +78,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_wbce_workspace_bytes", "tnv3_wbce_forward", "tnv3_wbce_backward", "tnv3_head_backward_workspace_bytes",
            "tnv3_head_backward", "tnv3_maxpool2x2_backward_add", "tnv3_upsample2x_backward", "tnv3_mixup",
            "tnv3_mfma_f32_probe", "tnv3_conv3x3_forward_diag", "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_absdiff_sum_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad",
-           "tnv3_heatmap_box_max"]
+           "tnv3_heatmap_box_max", "tnv3_conv3x3_wgrad_variant"]
 
 
 def library_path():
@@ -103,6 +104,8 @@ def load():
     if lib.tnv3_abi_version() != 1:
         raise Tnv3Error("libtnv3_hip.so ABI version mismatch")
     _lib, _is_emulator = lib, False
+    if os.environ.get("TNV3_WGRAD_VARIANT", "") in ("0", "1"):       # diagnostic: pick the weight-gradient kernel family
+        lib.tnv3_conv3x3_wgrad_variant(int(os.environ["TNV3_WGRAD_VARIANT"]))
     return lib
 
 

@@ -287,6 +287,10 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restri
   }
 }
 
+__global__ void __launch_bounds__(256) fill_zero_kernel(float* __restrict__ p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.0f;
+}
+
 // Same sum (same order, so the same bits), 16 bytes per lane and four slabs in flight: n % 4 == 0, 16-byte aligned.
 typedef float to_f32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) sum_partials_vec4_kernel(const float* __restrict__ part, float* __restrict__ out, long n4,

@@ -15,6 +15,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "conv3x3_mfma.h"
 
 namespace tnv3 {
@@ -25,6 +27,7 @@ struct WgradArgs {
   const float* dz;     // [N][Cout][H][W]
   float* part;         // [splitK][Cout][C0+C1][9]
   int N, C0, C1, Cout, H, W, up0, splitK;
+  const float* zeros;  // >= 64 zero floats (source of the padding for the LDS-DMA kernel)
 };
 
 template <int WM_, int WC_, int TR_ = 4, int TC_ = 32>
@@ -176,6 +179,171 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
   }
 
   // ---- partial slab: part[ks][co][ci][tap]
+  float* slab = a.part + (size_t)ks * Cout * Cin * 9;
+  const int ci = ci0 + wc * 32 + bl;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (co < Cout && ci < Cin) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) slab[((size_t)co * Cin + ci) * 9 + tap] = acc[tap][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant.  With one wave per SIMD (144 accumulator registers) nothing hides the instructions of a wave but its
+// own MFMAs: the register-staged kernel above issues the ~800 address / load / ds_write instructions of a tile in two
+// bursts during which the matrix pipe idles.  Here both tiles go global -> LDS by DMA (no staging registers, no
+// ds_write), the LDS is double-buffered, and the DMAs of tile t+1 are issued two per K-step inside the fully unrolled
+// MFMA stream of tile t, i.e. in the shadow of the 64-cycle MFMAs.  Tiles are TR = 2 rows (two 50 KB stages fit).
+//   work item = one wave-wide DMA of 64 floats:  dZ row (co, 64 pixels)   -> dz_s[co][0..63]
+//                                                X plane third (ci, g)    -> x_s[ci][64g .. 64g+63]   (halo plane 4x34 = 136)
+//   items are dealt to the waves round-robin with a static (item -> kind, group) map, so no branch splits the MFMA block.
+template <int WM_, int WC_>
+struct WgradDmaCfg {
+  static constexpr int WM = WM_, WC = WC_, TR = 2, TC = 32;
+  static constexpr int NW = WM * WC, NT = NW * 64;
+  static constexpr int MB = WM * 32, CB = WC * 32;
+  static constexpr int PIX = TR * TC, PIXP = PIX + 1;
+  static constexpr int TRp = TR + 2, TCp = TC + 2, PLANE = TRp * TCp, XG = (PLANE + 63) / 64, PLANEP = XG * 64 + 1;
+  static constexpr int DZ_FLOATS = MB * PIXP, X_FLOATS = CB * PLANEP;
+  static constexpr int BUF_FLOATS = DZ_FLOATS + X_FLOATS;
+  static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+  static constexpr int DZ_IPW = MB / NW, X_IPW = XG * CB / NW, IPW = DZ_IPW + X_IPW;    // DMA items per wave per tile
+  static constexpr int KSTEPS = PIX / 2, SLOTS = (IPW + KSTEPS - 1) / KSTEPS;
+  static_assert(PIX == 64, "one dZ row of the tile = one wave-wide DMA");
+  static_assert(MB % NW == 0 && CB % NW == 0, "items must deal evenly");
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT) wgrad3x3_dma_kernel(const WgradArgs a) {
+  constexpr int WC = Cfg::WC, TR = Cfg::TR, TC = Cfg::TC, MB = Cfg::MB, CB = Cfg::CB, NW = Cfg::NW;
+  constexpr int PIXP = Cfg::PIXP, TCp = Cfg::TCp, PLANE = Cfg::PLANE, PLANEP = Cfg::PLANEP, XG = Cfg::XG;
+  __shared__ float lds[2 * Cfg::BUF_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave % WC, wm = wave / WC;
+  const int half = lane >> 5, bl = lane & 31;
+  const int H = a.H, W = a.W, Cout = a.Cout, C0 = a.C0, C1 = a.C1, Cin = C0 + C1;
+  const int HW = H * W;
+  const int H0 = a.up0 ? (H >> 1) : H, W0 = a.up0 ? (W >> 1) : W, HW0 = H0 * W0;
+
+  const int nCB = (Cin + CB - 1) / CB;
+  int b = blockIdx.x;
+  const int ks = b % a.splitK; b /= a.splitK;
+  const int cb = b % nCB, mb = b / nCB;
+  const int co0 = mb * MB, ci0 = cb * CB;
+  const int tilesH = (H + TR - 1) / TR, tilesW = (W + TC - 1) / TC;
+  const int nTiles = a.N * tilesH * tilesW;
+
+  const bool blk0 = ci0 < C0;                     // the ci block comes from one source (host: C0 % CB == 0)
+  const bool up = blk0 && a.up0;
+  const float* xsrc = blk0 ? a.src0 : a.src1;
+  const int Cs = blk0 ? C0 : C1, cib = blk0 ? ci0 : ci0 - C0;
+  const int Ws = up ? W0 : W, HWs = up ? HW0 : HW;
+  const int nch = Cs - cib;                       // channels this source still has from cib on
+  const float* zsrc = a.zeros + lane;
+
+  // tile-independent lane roles: pixel (lane>>5, lane&31) of a dZ row; element g*64+lane of the halo plane
+  const int dz_rel = (lane >> 5) * W + (lane & 31);
+  int x_tr[XG], x_tc[XG];
+#pragma unroll
+  for (int g = 0; g < XG; ++g) { const int e = g * 64 + lane; x_tr[g] = e / TCp; x_tc[g] = e - x_tr[g] * TCp; }
+
+  // per-tile staging state (of the tile being fetched)
+  const float* dzt = nullptr;
+  const float* xt = nullptr;
+  bool dz_ok = false;
+  int x_off[XG];
+  auto prepare = [&](int tile) {
+    const int n = tile / (tilesH * tilesW);
+    const int trem = tile - n * (tilesH * tilesW);
+    const int h0 = (trem / tilesW) * TR, w0 = (trem % tilesW) * TC;
+    dzt = a.dz + ((size_t)n * Cout + co0) * HW + (size_t)h0 * W + w0 + dz_rel;
+    dz_ok = (h0 + (lane >> 5) < H) && (w0 + (lane & 31) < W);
+    xt = xsrc + ((size_t)n * Cs + cib) * HWs;
+#pragma unroll
+    for (int g = 0; g < XG; ++g) {
+      const int gh = h0 - 1 + x_tr[g], gw = w0 - 1 + x_tc[g];
+      const bool ok = g * 64 + lane < PLANE && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+      x_off[g] = ok ? (up ? (gh >> 1) * Ws + (gw >> 1) : gh * Ws + gw) : -1;
+    }
+  };
+  // item j of this wave (static j -> static kind / plane third)
+  auto issue = [&](int j, float* stage) {
+    if (j < Cfg::DZ_IPW) {
+      const int co_l = j * NW + wave;
+      const bool ok = dz_ok && co0 + co_l < Cout;
+      lds_dma4(ok ? dzt + (size_t)co_l * HW : zsrc, stage + co_l * PIXP);
+    } else {
+      const int k = j - Cfg::DZ_IPW;
+      const int g = k % XG, ci_l = (k / XG) * NW + wave;
+      const bool ok = x_off[g] >= 0 && ci_l < nch;
+      lds_dma4(ok ? xt + (size_t)ci_l * HWs + x_off[g] : zsrc, stage + Cfg::DZ_FLOATS + ci_l * PLANEP + g * 64);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const int a_off = (wm * 32 + bl) * PIXP + half;
+  const int b_off = Cfg::DZ_FLOATS + (wc * 32 + bl) * PLANEP + half;
+
+  // One tile: 32 K-steps (two adjacent pixels each) x 9 taps, fully unrolled; the operands of step s+1 are read before
+  // the MFMAs of step s; with FETCH the DMAs of the next tile ride along, SLOTS per K-step.
+  auto tile_mfma = [&](const float* cur, float* nxt, auto fetch) {
+    constexpr bool FETCH = decltype(fetch)::value;
+    const float* A = cur + a_off;
+    const float* B = cur + b_off;
+    constexpr int NSTEP = Cfg::KSTEPS, SPR = TC / 2;
+    float av[2], bv[2][9];
+    auto read_step = [&](int st, float& ar, float (&br)[9]) {
+      const int r = st / SPR, s = st - r * SPR;
+      ar = A[r * TC + 2 * s];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) br[tap] = B[(r + tap / 3) * TCp + 2 * s + (tap % 3)];
+    };
+    read_step(0, av[0], bv[0]);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      if (st + 1 < NSTEP) read_step(st + 1, av[(st + 1) & 1], bv[(st + 1) & 1]);
+      if (FETCH) {
+#pragma unroll
+        for (int q = 0; q < Cfg::SLOTS; ++q)
+          if (st * Cfg::SLOTS + q < Cfg::IPW) issue(st * Cfg::SLOTS + q, nxt);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1], bv[st & 1][tap], acc[tap], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);             // DS reads of the next step
+      if (FETCH) __builtin_amdgcn_sched_group_barrier(0x020, Cfg::SLOTS, 0);   // the DMAs riding on this step
+      __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);              // MFMAs of this step
+    }
+  };
+
+  if (ks < nTiles) {
+    prepare(ks);
+#pragma unroll
+    for (int j = 0; j < Cfg::IPW; ++j) issue(j, lds);
+  }
+  int buf = 0;
+  for (int tile = ks; tile < nTiles; tile += a.splitK) {
+    __syncthreads();          // this stage has landed (vmcnt drained) for every wave; the other stage is no longer read
+    float* cur = lds + buf * Cfg::BUF_FLOATS;
+    float* nxt = lds + (buf ^ 1) * Cfg::BUF_FLOATS;
+    if (tile + a.splitK < nTiles) {
+      prepare(tile + a.splitK);
+      tile_mfma(cur, nxt, std::true_type{});
+    } else {
+      tile_mfma(cur, nxt, std::false_type{});
+    }
+    buf ^= 1;
+  }
+
   float* slab = a.part + (size_t)ks * Cout * Cin * 9;
   const int ci = ci0 + wc * 32 + bl;
 #pragma unroll

@@ -326,6 +326,16 @@ int conv3x3_dgrad_impl(Launcher& L, const float* dz, const float* wpack_t, float
 using WgradA = WgradCfg<4, 1, 4, 32>;   // 128 co x 32 ci per workgroup, 4x32-pixel K tiles
 using WgradB = WgradCfg<2, 2, 4, 32>;   //  64 co x 64 ci per workgroup, 4x32-pixel K tiles
 
+using WgradDmaA = WgradDmaCfg<4, 1>;    // the same blocks, 2x32-pixel K tiles staged by LDS DMA, double-buffered
+using WgradDmaB = WgradDmaCfg<2, 2>;
+static_assert(WgradDmaA::MB == WgradA::MB && WgradDmaA::CB == WgradA::CB && WgradDmaB::MB == WgradB::MB && WgradDmaB::CB == WgradB::CB,
+              "both kernel families share the (co, ci) blocking");
+
+// 0: register-staged kernels (WgradA/B, default: measured 8 % faster), 1: LDS-DMA kernels (WgradDmaA/B).
+// A tuning / diagnostic knob, process-wide.
+inline int& wgrad_variant() { static int v = 0; return v; }
+constexpr size_t kWgradZeroBytes = 1024;     // zero prefix of the workspace: padding source of the LDS-DMA kernels
+
 struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
 constexpr int kNumCU = 256;   // MI355X: 8 XCDs x 32 CUs
 inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
@@ -334,7 +344,7 @@ inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
   const int MB = p.use_b ? WgradB::MB : WgradA::MB, CB = p.use_b ? WgradB::CB : WgradA::CB;
   p.nMB = (cout + MB - 1) / MB;
   p.nCB = (cin + CB - 1) / CB;
-  const int TR = p.use_b ? WgradB::TR : WgradA::TR;
+  const int TR = wgrad_variant() == 1 ? WgradDmaA::TR : (p.use_b ? WgradB::TR : WgradA::TR);
   p.nTiles = n * ((h + TR - 1) / TR) * ((w + 31) / 32);
   // One workgroup is resident per CU (LDS), all workgroups of a launch do the same work, so the launch runs in
   // ceil(workgroups / kNumCU) rounds of ceil(nTiles / splitK) tiles (+ ~0.6 tile of prologue / slab write each).
@@ -357,7 +367,7 @@ inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
 inline size_t wgrad_workspace_bytes(int n, int c0, int c1, int cout, int h, int w) {
   if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
   const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
-  return (size_t)p.splitK * cout * (c0 + c1) * 9 * sizeof(float);
+  return kWgradZeroBytes + (size_t)p.splitK * cout * (c0 + c1) * 9 * sizeof(float);
 }
 
 template <class Launcher>
@@ -375,14 +385,22 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   if (h > 250 * 2 * 1024 || c0 + c1 > 32767) TNV3_FAIL(-1, "conv3x3_wgrad: dimension too large");
   if (ws_bytes < wgrad_workspace_bytes(n, c0, c1, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad: workspace too small");
   const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
-  WgradArgs a{src0, src1, dz, (float*)ws, n, c0, c1, cout, h, w, up0 ? 1 : 0, p.splitK};
+  if (((uintptr_t)ws) & 15) TNV3_FAIL(-1, "conv3x3_wgrad: workspace must be 16-byte aligned");
+  float* slabs = (float*)((char*)ws + kWgradZeroBytes);
+  WgradArgs a{src0, src1, dz, slabs, n, c0, c1, cout, h, w, up0 ? 1 : 0, p.splitK, (const float*)ws};
   const int grid = p.nMB * p.nCB * p.splitK;
-  int rc = p.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB>, grid, WgradB::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA>, grid, WgradA::NT, a);
+  int rc;
+  if (wgrad_variant() == 1) {
+    if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
+    rc = p.use_b ? L.launch(wgrad3x3_dma_kernel<WgradDmaB>, grid, WgradDmaB::NT, a) : L.launch(wgrad3x3_dma_kernel<WgradDmaA>, grid, WgradDmaA::NT, a);
+  } else {
+    rc = p.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB>, grid, WgradB::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA>, grid, WgradA::NT, a);
+  }
   if (rc) return rc;
   const long nel = (long)cout * (c0 + c1) * 9;
   if ((nel & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dw) & 15) == 0)
-    return L.launch(sum_partials_vec4_kernel, grid_for(nel / 4, 256, 8192), 256, (const float*)ws, dw, nel / 4, p.splitK);
-  return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)ws, dw, nel, p.splitK);
+    return L.launch(sum_partials_vec4_kernel, grid_for(nel / 4, 256, 8192), 256, (const float*)slabs, dw, nel / 4, p.splitK);
+  return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)slabs, dw, nel, p.splitK);
 }
 
 inline size_t wbce_workspace_bytes(int n) { return n <= 0 ? 0 : (size_t)n * kRedSplit * sizeof(double); }

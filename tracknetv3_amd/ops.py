@@ -178,6 +178,11 @@ def heatmap_peakfind(heat, threshold=0.5, tie_last_wins=True):
     return out
 
 
+def wgrad_variant(variant=-1):
+    """Select (0: register-staged, 1: LDS-DMA staged) or query (-1) the weight-gradient kernel family; returns the old one."""
+    return int(_lib.load().tnv3_conv3x3_wgrad_variant(int(variant)))
+
+
 def heatmap_box_max(heat, boxes=None):
     """(frames, H, W) fp32 maps [+ (frames, 4) int32 boxes (x, y, w, h)] -> (frames,) maxima (0 for an empty box)."""
     lib = _lib.load()
