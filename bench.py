@@ -171,10 +171,31 @@ def bench_train(args, dev, rank, world):
         loss = trainer.step(x, y)
     barrier()
     dt = time.perf_counter() - t0
+    # Extra (reported beside, never instead of, `value`): the same K steps on independent batches issued round-robin on two
+    # HIP streams.  Windows are independent, so the second stream's launches fill the CUs that the 45/48 tail of every
+    # batch-10 conv launch leaves idle (profiles/r01_conv_batch32_vs_batch10.md); pipeline.predict_video runs this way.
+    dt2 = None
+    if args.overlap_streams > 1:
+        side = [torch.cuda.Stream(dev) for _ in range(args.overlap_streams)]
+        xs = [x] + [torch.rand_like(x) for _ in range(args.overlap_streams - 1)]
+        model.prepare_eval()
+        barrier()
+        for k in range(2 * len(side)):
+            with torch.cuda.stream(side[k % len(side)]):
+                model(xs[k % len(side)])
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            with torch.cuda.stream(side[k % len(side)]):
+                model(xs[k % len(side)])
+        barrier()
+        dt2 = time.perf_counter() - t0
+
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt, dt2 if dt2 is not None else 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax[0].item())
+        dt2 = float(tmax[1].item()) if dt2 is not None else None
     if rank == 0:
         frames = world * args.batch * SEQ_LEN * args.steps
         ms = dt / args.steps * 1e3
@@ -204,6 +225,8 @@ def main():
                     help="infer: BASELINE configs[1] (headline); train: configs[2] shard -- mixup + fwd + WBCE + bwd + Adam")
     ap.add_argument("--tune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-streams", type=int, default=2,
+                    help="also time the K steps round-robin on this many HIP streams (reported as `overlap`; 0/1 = skip)")
     ap.add_argument("--layers-out", default=os.path.join(ROOT, "gpurun_out", "bench_layers.json"))
     args = ap.parse_args()
 
@@ -318,6 +341,10 @@ def main():
                                       "achieved_GBps": round(ALG_BYTES_PER_SAMPLE * args.batch / (ms_per_step * 1e-3) / 1e9, 1),
                                       "peak_GBps": PEAK_HBM_GBPS}},
         }
+        out["overlap"] = None if dt2 is None else {
+            "streams": args.overlap_streams, "value": round(frames / dt2, 2), "unit": "frames/s",
+            "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+            "note": "same K steps, independent batches round-robin on HIP streams; not used for `value` or `roofline`"}
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline()
         else:

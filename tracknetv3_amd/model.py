@@ -164,6 +164,16 @@ class TrackNet(nn.Module):
         x = self._chain_eval(self.up_block_3.blocks(), x, skip=x1, up=True)
         return ops.head1x1_sigmoid(x, self.predictor.weight.detach(), self.predictor.bias.detach())
 
+    def prepare_eval(self):
+        """Build (on the current stream) every cached eval-mode operand -- packed filters, folded BN scales -- so that
+        forwards issued afterwards on several streams only read them."""
+        with torch.no_grad():
+            for blk in (self.down_block_1, self.down_block_2, self.down_block_3, self.bottleneck, self.up_block_1,
+                        self.up_block_2, self.up_block_3):
+                for b in blk.blocks():
+                    b.packed_weight()
+                    b.eval_scale()
+
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_dim:
             raise ValueError(f"TrackNet expects (N, {self.in_dim}, H, W), got {tuple(x.shape)}")
