@@ -171,31 +171,10 @@ def bench_train(args, dev, rank, world):
         loss = trainer.step(x, y)
     barrier()
     dt = time.perf_counter() - t0
-    # Extra (reported beside, never instead of, `value`): the same K steps on independent batches issued round-robin on two
-    # HIP streams.  Windows are independent, so the second stream's launches fill the CUs that the 45/48 tail of every
-    # batch-10 conv launch leaves idle (profiles/r01_conv_batch32_vs_batch10.md); pipeline.predict_video runs this way.
-    dt2 = None
-    if args.overlap_streams > 1:
-        side = [torch.cuda.Stream(dev) for _ in range(args.overlap_streams)]
-        xs = [x] + [torch.rand_like(x) for _ in range(args.overlap_streams - 1)]
-        model.prepare_eval()
-        barrier()
-        for k in range(2 * len(side)):
-            with torch.cuda.stream(side[k % len(side)]):
-                model(xs[k % len(side)])
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            with torch.cuda.stream(side[k % len(side)]):
-                model(xs[k % len(side)])
-        barrier()
-        dt2 = time.perf_counter() - t0
-
     if world > 1:
-        tmax = torch.tensor([dt, dt2 if dt2 is not None else 0.0], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax[0].item())
-        dt2 = float(tmax[1].item()) if dt2 is not None else None
+        dt = float(tmax.item())
     if rank == 0:
         frames = world * args.batch * SEQ_LEN * args.steps
         ms = dt / args.steps * 1e3
@@ -292,10 +271,31 @@ def main():
     dt = time.perf_counter() - t0
     ops.conv3x3 = ops_conv
 
+    # Extra (reported beside, never instead of, `value`): the same K steps on independent batches issued round-robin on two
+    # HIP streams.  Windows are independent, so the second stream's launches fill the CUs that the 45/48 tail of every
+    # batch-10 conv launch leaves idle (profiles/r01_conv_batch32_vs_batch10.md); pipeline.predict_video runs this way.
+    dt2 = None
+    if args.overlap_streams > 1:
+        side = [torch.cuda.Stream(dev) for _ in range(args.overlap_streams)]
+        xs = [x] + [torch.rand_like(x) for _ in range(args.overlap_streams - 1)]
+        model.prepare_eval()
+        barrier()
+        for k in range(2 * len(side)):
+            with torch.cuda.stream(side[k % len(side)]):
+                model(xs[k % len(side)])
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            with torch.cuda.stream(side[k % len(side)]):
+                model(xs[k % len(side)])
+        barrier()
+        dt2 = time.perf_counter() - t0
+
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt, dt2 if dt2 is not None else 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax[0].item())
+        dt2 = float(tmax[1].item()) if dt2 is not None else None
 
     if rank == 0:
         assert len(events) == 17 * args.steps, len(events)
