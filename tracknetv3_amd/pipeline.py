@@ -46,6 +46,19 @@ def _index_tensor(widx):
     return i
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, n):
+    """Side streams are kept per device: the caching allocator pools memory per stream, so fresh streams on every call
+    would pay a hipMalloc for each activation of the first forwards."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    have = _SIDE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(dev))
+    return have[:n]
+
+
 def _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, n_streams=2):
     """Yields (window-index batch, heat maps) in order, keeping up to `n_streams` TrackNet forwards in flight on side
     HIP streams: windows are independent, so the next batch's launches fill the CUs that the 45/48 tail of every
@@ -61,7 +74,7 @@ def _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, n_str
     main = torch.cuda.current_stream(dev)
     if hasattr(tracknet, "prepare_eval"):
         tracknet.prepare_eval()                          # cached operands are built here, before the side streams read them
-    side = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    side = _side_streams(dev, n_streams)
     ready = torch.cuda.Event()
     ready.record(main)                                   # frames / median were produced on the consumer's stream
     pending = []
