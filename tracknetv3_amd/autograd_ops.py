@@ -9,6 +9,8 @@ pool / upsample / concat gradients folded into three small kernels.  Parameters 
 ``torch.optim`` and ``state_dict`` work unchanged.  Optional ``grad_ready`` hook: called with (param, grad) as soon as
 a gradient is final, which is what the data-parallel wrapper uses to overlap RCCL all-reduce with the rest of backward.
 """
+import os
+
 import torch
 
 from . import ops
@@ -16,6 +18,37 @@ from . import tuning
 
 _grad_ready_hook = None
 _backward_end_hook = None
+
+# Weight gradients on a side HIP stream: wgrad(L) depends only on dZ(L), while the main chain continues with
+# dgrad(L) -> BN backward(L-1) -> ...  Two independent chains in flight let the HBM-bound BN passes and the tails of
+# the batch-10 conv launches hide under the other chain's MFMA work.
+_wgrad_overlap = os.environ.get("TNV3_WGRAD_OVERLAP", "1") != "0"
+_WGRAD_STREAMS = {}
+
+
+def set_wgrad_overlap(enabled):
+    """Enable / disable the side-stream weight gradients (default on for GPU tensors); returns the previous setting."""
+    global _wgrad_overlap
+    old, _wgrad_overlap = _wgrad_overlap, bool(enabled)
+    return old
+
+
+_BACKWARD_STREAMS = {}
+
+
+def backward_streams(dev):
+    """Streams the running (or last) backward on `dev` produces gradients on: [main] or [main, weight-gradient stream]."""
+    return _BACKWARD_STREAMS.get(dev.index if dev.index is not None else 0, [])
+
+
+def wgrad_stream(dev):
+    """The persistent side stream weight gradients are launched on (None when the overlap is off or `dev` is no GPU)."""
+    if not _wgrad_overlap or dev.type != "cuda":
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(dev)
+    return _WGRAD_STREAMS[key]
 
 
 def set_grad_ready_hook(fn, end_fn=None):
@@ -95,6 +128,11 @@ class _TrackNetTrain(torch.autograd.Function):
             grads[id(param)] = g
 
         dp = dp.contiguous()
+        side = wgrad_stream(dp.device)
+        main = torch.cuda.current_stream(dp.device) if side is not None else None
+        if dp.device.type == "cuda":
+            _BACKWARD_STREAMS[dp.device.index if dp.device.index is not None else 0] = \
+                [torch.cuda.current_stream(dp.device)] + ([side] if side is not None else [])
         da, dw_head, db_head = ops.head_backward(dp, ctx.p, ctx.head_in, net.predictor.weight.detach())
         done(net.predictor.weight, dw_head)
         done(net.predictor.bias, db_head)
@@ -104,8 +142,19 @@ class _TrackNetTrain(torch.autograd.Function):
             dz, dgamma, dbeta = ops.bn_relu_backward(da, rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"], rec["invstd"])
             done(blk.bn.weight, dgamma)
             done(blk.bn.bias, dbeta)
-            dw = ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
-            done(blk.conv.weight, dw)
+            if side is None:
+                dw = ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
+                done(blk.conv.weight, dw)
+            else:
+                ready = torch.cuda.Event()
+                ready.record(main)                                   # dZ (and, first time round, the activations) are final
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    dw = ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
+                    done(blk.conv.weight, dw)                        # the hook's bucket copy is ordered on the side stream
+                for t in (dz, rec["x0"], rec["x1"]):
+                    if t is not None:
+                        t.record_stream(side)                        # freed on the main stream while the side stream may read
             if not need_dx:
                 return None, None
             c0 = int(rec["x0"].shape[1])
@@ -141,6 +190,8 @@ class _TrackNetTrain(torch.autograd.Function):
         d_pool1, _ = chain_bwd(2, da)                      # down_block_2
         da = ops.maxpool2x2_backward_add(x1, d_pool1, d_x1)
         dx, _ = chain_bwd(2, da, first_needs_dx=ctx.need_dx)   # down_block_1
+        if side is not None:
+            main.wait_stream(side)                                   # every weight gradient is final for whoever comes next
         ctx.saved = None
         if _backward_end_hook is not None:
             _backward_end_hook()

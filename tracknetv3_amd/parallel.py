@@ -75,6 +75,8 @@ class GradAllReducer:
             return
         if self.use_stream:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
+            for s in autograd_ops.backward_streams(self.device):     # a bucket mixes gradients made on the main and the
+                self.side.wait_stream(s)                             # weight-gradient stream: wait for both
             with torch.cuda.stream(self.side):
                 flat.div_(self.world)
                 self.pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
