@@ -19,6 +19,7 @@ struct Launcher {
   }
 };
 inline Launcher make_launcher(tnv3_stream_t) { return Launcher{}; }
+inline void init_cu_count() {}   // the emulator plans for the default 256 CUs
 }  // namespace
 
 #include "../../tracknetv3_amd/csrc/tnv3_capi_body.inc"

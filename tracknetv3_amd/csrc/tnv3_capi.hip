@@ -21,6 +21,16 @@ struct Launcher {
   }
 };
 inline Launcher make_launcher(tnv3_stream_t s) { return Launcher{static_cast<hipStream_t>(s)}; }
+
+// One-time device query behind the split-K planner (a partitioned GPU exposes fewer CUs).
+struct CuCountInit {
+  CuCountInit() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      tnv3::num_cus() = n;
+  }
+};
+inline void init_cu_count() { static CuCountInit once; (void)once; }
 }  // namespace
 
 #include "tnv3_capi_body.inc"

@@ -337,7 +337,9 @@ inline int& wgrad_variant() { static int v = 0; return v; }
 constexpr size_t kWgradZeroBytes = 1024;     // zero prefix of the workspace: padding source of the LDS-DMA kernels
 
 struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
-constexpr int kNumCU = 256;   // MI355X: 8 XCDs x 32 CUs
+// Compute units of the current device (256 on an unpartitioned MI355X: 8 XCDs x 32 CUs); the C-ABI translation unit
+// sets it once from hipDeviceGetAttribute, the emulator keeps the default.
+inline int& num_cus() { static int n = 256; return n; }
 inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
   WgradPlan p;
   p.use_b = (cout % 128) != 0;
@@ -347,9 +349,10 @@ inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
   const int TR = wgrad_variant() == 1 ? WgradDmaA::TR : (p.use_b ? WgradB::TR : WgradA::TR);
   p.nTiles = n * ((h + TR - 1) / TR) * ((w + 31) / 32);
   // One workgroup is resident per CU (LDS), all workgroups of a launch do the same work, so the launch runs in
-  // ceil(workgroups / kNumCU) rounds of ceil(nTiles / splitK) tiles (+ ~0.6 tile of prologue / slab write each).
+  // ceil(workgroups / CUs) rounds of ceil(nTiles / splitK) tiles (+ ~0.6 tile of prologue / slab write each).
   // Pick the split that minimises rounds x tiles; ties go to the smaller split (fewer slabs to write and re-read).
   const int nb = p.nMB * p.nCB;
+  const int kNumCU = num_cus();
   int cap = (p.nTiles * TR + 23) / 24;                               // at least ~768 pixels of K per workgroup
   if (cap > 4096) cap = 4096;
   if (cap < 1) cap = 1;
