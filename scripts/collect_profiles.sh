@@ -1,0 +1,19 @@
+#!/bin/bash
+# Copies the summaries of the last scripts/gpu_session.sh run from gpurun_out/ (scratch) into profiles/ (tracked).
+set -eu
+cd "$(dirname "$0")/.."
+R=${ROUND:-r01}
+O=gpurun_out
+P=profiles
+cp $O/bench.json $P/${R}_bench_n1.json
+cp $O/bench_layers.json $P/${R}_bench_layers.json
+cp $O/bench_train.json $P/${R}_bench_train_n1.json
+cp $O/microbench.json $P/${R}_microbench.json
+cp $O/prof_infer.json $P/${R}_bench_n1_under_rocprof.json
+cp $O/prof_infer_kernel_stats.csv $P/${R}_infer_kernel_stats.csv
+cp $O/prof_train_kernel_stats.csv $P/${R}_train_kernel_stats.csv
+cp $O/pmc_fetch_pmc.csv $P/${R}_infer_pmc_fetch_size.csv
+cp $O/pmc_write_pmc.csv $P/${R}_infer_pmc_write_size.csv
+python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json
+cp $O/session.log $P/${R}_session_final.log
+echo "profiles/ refreshed from $O"
