@@ -41,10 +41,10 @@ def build_emulator():
 
 @pytest.fixture(scope="session")
 def emu_lib_path():
-    try:
-        return build_emulator()
-    except Exception as e:  # noqa: BLE001
-        pytest.skip(f"host clang unavailable for the SIMT emulator: {e}")
+    import shutil
+    if not os.path.exists(HOST_CLANG) and shutil.which("clang++") is None:
+        pytest.skip("no host clang++ for the SIMT emulator")
+    return build_emulator()          # a compile error of the kernel headers must FAIL the suite, not skip it
 
 
 @pytest.fixture()

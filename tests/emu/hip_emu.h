@@ -31,6 +31,7 @@
 #define __restrict__ __restrict
 
 struct emu_dim3 { unsigned x, y, z; };
+struct uint4 { unsigned x, y, z, w; };
 static emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 // Minimal x86-64 SysV context switch (callee-saved registers + stack pointer).  glibc's swapcontext makes a

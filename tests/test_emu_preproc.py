@@ -36,13 +36,17 @@ def test_resize_and_median_emulated_vs_oracle(emu):
             want = opre.resize_bicubic_u8(fr[k], ow, oh)
             assert np.array_equal(u8[k].numpy(), want)
             assert np.array_equal(f32[k].numpy(), opre.normalise_u8(np.moveaxis(want, -1, 0)))
-    for t in (1, 2, 7, 16, 33):
-        fr = rng.randint(0, 256, (t, 6, 10, 3)).astype(np.uint8)
+    for t, (mh, mw) in ((1, (6, 10)), (2, (6, 10)), (7, (5, 7)), (16, (6, 10)), (33, (6, 10)), (100, (4, 6)), (46, (5, 7))):
+        fr = rng.randint(0, 256, (t, mh, mw, 3)).astype(np.uint8)   # 6x10x3 bytes: radix-select kernel; 5x7x3: LDS-histogram kernel
         fr[:, 0, 0] = 200                                            # constant pixel
         fr[: t // 2, 0, 1] = 0
         fr[t // 2:, 0, 1] = 255                                      # bimodal: even T averages 0 and 255 -> 127
+        fr[:, 1, 0] = rng.randint(96, 112, (t, 3))                   # all values inside one high nibble
+        fr[:, 1, 1] = rng.randint(110, 114, (t, 3))                  # straddling a high-nibble boundary (111 | 112)
         got = pre.median_background(torch.from_numpy(fr)).numpy()
         assert np.array_equal(got, opre.median_u8(fr)), t
+        m2 = pre.median_background(torch.from_numpy(fr), doubled=True).numpy()
+        assert np.array_equal(m2.astype(np.float64) / 2, np.median(fr, 0)), t
 
 
 def test_preprocess_video_matches_reference_dataset_layout(emu):

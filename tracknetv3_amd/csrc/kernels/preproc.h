@@ -58,6 +58,78 @@ __global__ void __launch_bounds__(256) resample_v_u8_kernel(const unsigned char*
   }
 }
 
+// RGB fast path of the horizontal pass: a workgroup stages RPB source rows with 16-byte loads; a thread owns ONE output
+// column (all three channels) so its <= KMAX coefficients are fetched once into registers and reused for 3 x RPB outputs,
+// and every LDS read is `per-thread base + immediate`.  Same arithmetic, same bits as the generic kernel.
+template <int KMAX, int RPB>
+__global__ void __launch_bounds__(256) resample_h_rgb_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                             const int* __restrict__ xmin, const int* __restrict__ xcnt,
+                                                             const int* __restrict__ kk, int ksize, long rows, int W, int OW) {
+  constexpr int C = 3;
+  constexpr int kRowStride = kResampleMaxRowBytes / RPB;          // bytes reserved per staged row (incl. tail slack)
+  __shared__ __attribute__((aligned(16))) unsigned char row_s[kResampleMaxRowBytes];
+  const long r0 = (long)blockIdx.x * RPB;
+  const int rowb = W * C;                                          // host guarantees rowb % 16 == 0, rowb + KMAX*C <= kRowStride
+  const int vec_per_row = rowb / 16;
+  for (int i = threadIdx.x; i < RPB * vec_per_row; i += 256) {
+    const int r = i / vec_per_row, v = i - r * vec_per_row;
+    if (r0 + r < rows)
+      *reinterpret_cast<uint4*>(row_s + r * kRowStride + 16 * v) = *reinterpret_cast<const uint4*>(src + (r0 + r) * (size_t)rowb + 16 * v);
+  }
+  __syncthreads();
+  for (int xx = threadIdx.x; xx < OW; xx += 256) {
+    const int x0 = xmin[xx], n = xcnt[xx];
+    int k[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) k[j] = j < n ? kk[(size_t)xx * ksize + j] : 0;
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) {
+      if (r0 + r >= rows) break;
+      const unsigned char* p = row_s + r * kRowStride + x0 * C;
+      int a0 = 1 << (kResampleBits - 1), a1 = a0, a2 = a0;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {                             // taps beyond n carry a zero coefficient (reads stay inside the slack)
+        a0 += (int)p[j * C] * k[j];
+        a1 += (int)p[j * C + 1] * k[j];
+        a2 += (int)p[j * C + 2] * k[j];
+      }
+      unsigned char* d = dst + ((r0 + r) * (size_t)OW + xx) * C;
+      d[0] = resample_clip8(a0); d[1] = resample_clip8(a1); d[2] = resample_clip8(a2);
+    }
+  }
+}
+
+// Vertical pass, four consecutive output bytes per thread (32-bit loads of the intermediate rows); (OW*C) % 4 == 0.
+__global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst_f32,
+                                                              unsigned char* __restrict__ dst_u8, const int* __restrict__ ymin,
+                                                              const int* __restrict__ ycnt, const int* __restrict__ kk, int ksize,
+                                                              const float* __restrict__ lut, int H, int OW, int C, int OH) {
+  const int f = blockIdx.x / OH, yy = blockIdx.x - f * OH;
+  const int y0 = ymin[yy], n = ycnt[yy];
+  const int* k = kk + (size_t)yy * ksize;
+  const int rowb = OW * C;
+  const unsigned char* s = src + ((size_t)f * H + y0) * rowb;
+  for (int q = threadIdx.x; q < rowb / 4; q += 256) {
+    int a0 = 1 << (kResampleBits - 1), a1 = a0, a2 = a0, a3 = a0;
+    for (int y = 0; y < n; ++y) {
+      const unsigned v = *reinterpret_cast<const unsigned int*>(s + (size_t)y * rowb + 4 * q);
+      const int ky = k[y];
+      a0 += (int)(v & 255u) * ky; a1 += (int)((v >> 8) & 255u) * ky; a2 += (int)((v >> 16) & 255u) * ky; a3 += (int)(v >> 24) * ky;
+    }
+    const unsigned char o[4] = {resample_clip8(a0), resample_clip8(a1), resample_clip8(a2), resample_clip8(a3)};
+    if (dst_u8)
+      *reinterpret_cast<unsigned int*>(dst_u8 + ((size_t)f * OH + yy) * rowb + 4 * q) =
+          (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16) | ((unsigned)o[3] << 24);
+    if (dst_f32) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int oidx = 4 * q + e, xx = oidx / C, c = oidx - xx * C;
+        dst_f32[(((size_t)f * C + c) * OH + yy) * OW + xx] = lut[o[e]];
+      }
+    }
+  }
+}
+
 // Median over T frames of P bytes each: frames [T][P] u8 -> med [P] u8 = floor((v[(T-1)/2] + v[T/2]) / 2).
 // 128 threads x 256 32-bit bins = 128 KB of LDS; bin-major layout keeps the 32 lanes of a half-wave on 32 banks.
 // med2 (optional): a + b as uint16 = twice the float median (np.median of an even count ends in .5): what the
@@ -89,6 +161,111 @@ __global__ void __launch_bounds__(128) median_u8_kernel(const unsigned char* __r
     }
     if (med) med[p] = (unsigned char)((a + b2) >> 1);
     if (med2) med2[p] = (unsigned short)(a + b2);
+  }
+}
+
+// The same median as a two-pass 4-bit radix select, registers only (no LDS -> full occupancy, 4-byte loads):
+//   pass A histograms the HIGH nibble of every frame's byte into 16 bins and finds the bins holding the two middle
+//   ranks; pass B re-reads the stack and histograms the LOW nibble of the bytes that fall into those bins.
+// Each thread owns 4 consecutive byte positions.  Counting is SWAR: one 64-bit word of sixteen 4-bit counters takes
+// `1 << 4n` per byte and is spilled into 16-bit counters every 15 frames, i.e. ~6 integer instructions per byte
+// instead of an LDS read-modify-write.  HBM traffic 2 x T x P bytes (the stack does not fit the L2).  T <= 65535, P % 4 == 0.
+struct NibbleHist {
+  unsigned long long swar;       // 16 x 4-bit counters (at most 15 increments between spills)
+  unsigned int c[8];             // 16 x 16-bit counters: bins 2j (low half) and 2j+1 (high half)
+  __device__ __forceinline__ void clear() { swar = 0ull; for (int j = 0; j < 8; ++j) c[j] = 0u; }
+  __device__ __forceinline__ void add(unsigned n) { swar += 1ull << (4u * n); }
+  __device__ __forceinline__ void add_if(unsigned n, bool take) { swar += (take ? 1ull : 0ull) << (4u * n); }
+  __device__ __forceinline__ void spill() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned b = (unsigned)(swar >> (8 * j)) & 255u;
+      c[j] += (b & 15u) | ((b >> 4) << 16);
+    }
+    swar = 0ull;
+  }
+  // smallest bin whose cumulative count exceeds `rank`; `before` = count of all smaller bins
+  __device__ __forceinline__ void select(unsigned rank, unsigned& bin, unsigned& before) const {
+    unsigned cum = 0, found = 16u, bef = 0u;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const unsigned n = (c[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu;
+      const bool hit = found == 16u && cum + n > rank;
+      bef = hit ? cum : bef;
+      found = hit ? (unsigned)b : found;
+      cum += n;
+    }
+    bin = found; before = bef;
+  }
+};
+
+__global__ void __launch_bounds__(256) median_u8_radix_kernel(const unsigned int* __restrict__ frames4, unsigned char* __restrict__ med,
+                                                              unsigned short* __restrict__ med2, int T, long P4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P4) return;
+  const unsigned r0 = (unsigned)((T - 1) / 2), r1 = (unsigned)(T / 2);
+  const unsigned int* f = frames4 + i;
+  NibbleHist h[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) h[b].clear();
+  // ---- pass A: high nibbles
+  for (int t0 = 0; t0 < T; t0 += 15) {
+    const int tn = T - t0 < 15 ? T - t0 : 15;
+    if (tn == 15) {
+      unsigned v[15];
+#pragma unroll
+      for (int u = 0; u < 15; ++u) v[u] = f[(size_t)(t0 + u) * P4];
+#pragma unroll
+      for (int u = 0; u < 15; ++u)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) h[b].add((v[u] >> (8 * b + 4)) & 15u);
+    } else {
+      for (int u = 0; u < tn; ++u) {
+        const unsigned v = f[(size_t)(t0 + u) * P4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) h[b].add((v >> (8 * b + 4)) & 15u);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) h[b].spill();
+  }
+  unsigned hiA[4], hiB[4], befA[4], befB[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { h[b].select(r0, hiA[b], befA[b]); h[b].select(r1, hiB[b], befB[b]); }
+  // ---- pass B: low nibbles of the bytes whose high nibble is hiA (rank r0) / hiB (rank r1)
+  NibbleHist la[4], lb[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { la[b].clear(); lb[b].clear(); }
+  for (int t0 = 0; t0 < T; t0 += 15) {
+    const int tn = T - t0 < 15 ? T - t0 : 15;
+    for (int u = 0; u < tn; ++u) {
+      const unsigned v = f[(size_t)(t0 + u) * P4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned byte = (v >> (8 * b)) & 255u;
+        la[b].add_if(byte & 15u, (byte >> 4) == hiA[b]);
+        lb[b].add_if(byte & 15u, (byte >> 4) == hiB[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { la[b].spill(); lb[b].spill(); }
+  }
+  unsigned outm = 0u;
+  unsigned short o2[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    unsigned lo, bef;
+    la[b].select(r0 - befA[b], lo, bef);
+    const unsigned va = hiA[b] * 16u + lo;
+    lb[b].select(r1 - befB[b], lo, bef);
+    const unsigned vb = hiB[b] * 16u + lo;
+    outm |= ((va + vb) >> 1) << (8 * b);
+    o2[b] = (unsigned short)(va + vb);
+  }
+  if (med) reinterpret_cast<unsigned int*>(med)[i] = outm;
+  if (med2) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) med2[4 * i + b] = o2[b];
   }
 }
 

@@ -477,13 +477,26 @@ int resample_bicubic_u8_impl(Launcher& L, const unsigned char* src, unsigned cha
   if ((long)w * c > kResampleMaxRowBytes) TNV3_FAIL(-1, "resample_bicubic_u8: source row of %ld bytes exceeds %d", (long)w * c, kResampleMaxRowBytes);
   if ((long)frames * h >= (1l << 31) || (long)frames * oh >= (1l << 31)) TNV3_FAIL(-1, "resample_bicubic_u8: too many rows");
   int rc;
-  if ((rc = L.launch(resample_h_u8_kernel, frames * h, 256, src, tmp, xmin, xcnt, kkx, ksx, h, w, c, ow))) return rc;
+  constexpr int KMAX = 20, RPB = 4;                // fast RGB path: <= 20 taps (down-scales up to 4.5x), 4 rows per workgroup
+  const long rows = (long)frames * h;
+  const bool fast_h = c == 3 && ksx <= KMAX && (w * c) % 16 == 0 && w * c + KMAX * 3 <= kResampleMaxRowBytes / RPB &&
+                      (((uintptr_t)src) & 15) == 0;
+  if (fast_h) rc = L.launch(resample_h_rgb_kernel<KMAX, RPB>, (int)((rows + RPB - 1) / RPB), 256, src, tmp, xmin, xcnt, kkx, ksx, rows, w, ow);
+  else rc = L.launch(resample_h_u8_kernel, frames * h, 256, src, tmp, xmin, xcnt, kkx, ksx, h, w, c, ow);
+  if (rc) return rc;
+  if ((ow * c) % 4 == 0 && (((uintptr_t)tmp | (uintptr_t)dst_u8) & 3) == 0)
+    return L.launch(resample_v_u8x4_kernel, frames * oh, 256, (const unsigned char*)tmp, dst_f32, dst_u8, ymin, ycnt, kky, ksy, lut, h, ow, c, oh);
   return L.launch(resample_v_u8_kernel, frames * oh, 256, (const unsigned char*)tmp, dst_f32, dst_u8, ymin, ycnt, kky, ksy, lut, h, ow, c, oh);
 }
 
 template <class Launcher>
 int median_u8_impl(Launcher& L, const unsigned char* frames, unsigned char* med, unsigned short* med2, int t, long p) {
   if (!frames || (!med && !med2) || t <= 0 || p <= 0) TNV3_FAIL(-1, "median_u8: bad argument");
+  if ((p & 3) == 0 && t <= 65535 && (((uintptr_t)frames | (uintptr_t)med) & 3) == 0 && (((uintptr_t)med2) & 1) == 0) {
+    const long p4 = p / 4, blocks4 = (p4 + 255) / 256;          // radix select in registers: 4 byte positions per thread
+    if (blocks4 >= (1l << 31)) TNV3_FAIL(-1, "median_u8: frame too large");
+    return L.launch(median_u8_radix_kernel, (int)blocks4, 256, (const unsigned int*)frames, med, med2, t, p4);
+  }
   const long blocks = (p + 127) / 128;
   if (blocks >= (1l << 31)) TNV3_FAIL(-1, "median_u8: frame too large");
   return L.launch(median_u8_kernel, (int)blocks, 128, frames, med, med2, t, p);
