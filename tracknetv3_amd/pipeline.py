@@ -154,6 +154,7 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
     dev = frames.device
     pred["Inpaint_Mask"] = pp.generate_inpaint_mask(pred, th_h=h_src * 0.05)
     seq_len = inpaintnet_seq_len
+    batch_size = max(batch_size, 1024)       # trajectory windows are 48 floats each: the reference's batch only bounds launch count
     n_pts = len(pred["Frame"])
     coor_all = torch.tensor([pred["X"], pred["Y"]], dtype=torch.float32).t().contiguous()      # source-pixel units
     coor_all[:, 0] /= w_src
