@@ -174,6 +174,26 @@ def test_tracknet_train_step_emulated_vs_fp64_oracle(emu):
             assert torch.allclose(after[k].double(), v, rtol=1e-4, atol=1e-6), k
 
 
+def test_train_step_releases_its_activations_without_the_cyclic_gc(emu):
+    """The autograd nodes must not form reference cycles with their outputs: with the cyclic collector disabled, the
+    network output (and with it every saved activation of the step) has to die with the last user reference.
+    (InpaintNet here; the TrackNet node is checked on the GPU, a whole emulated TrackNet step takes minutes.)"""
+    import gc
+    import weakref
+    from tracknetv3_amd.model import InpaintNet
+    gc.collect()
+    gc.disable()
+    try:
+        net = InpaintNet().train()
+        out = net(nets.synth_input((2, 16, 2), 7), (nets.synth_input((2, 16, 1), 8) > 0.5).float())
+        out.sum().backward()
+        alive = weakref.ref(out)
+        del out
+        assert alive() is None, "InpaintNet output survived: ctx <-> output reference cycle"
+    finally:
+        gc.enable()
+
+
 def test_inpaintnet_train_step_emulated_vs_reference_golden(emu):
     """InpaintNet forward(train) + masked MSE (train.py:159-161) + backward through the product's autograd node."""
     from tracknetv3_amd.model import InpaintNet

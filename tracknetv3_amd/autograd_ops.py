@@ -109,7 +109,11 @@ class _TrackNetTrain(torch.autograd.Function):
         y = chain(u2, y, x2, True)
         y = chain(u3, y, x1, True)
         p = ops.head1x1_sigmoid(y, net.predictor.weight.detach(), net.predictor.bias.detach())
-        ctx.net, ctx.saved, ctx.p, ctx.head_in = net, saved, p, y
+        # The OUTPUT goes through save_for_backward: an output kept as a plain ctx attribute is a reference cycle
+        # (p.grad_fn -> ctx -> p) that pins every activation of the step until the cyclic GC runs (measured: +0.85 GB/step).
+        if hasattr(ctx, "save_for_backward"):
+            ctx.save_for_backward(p)
+        ctx.net, ctx.saved, ctx.head_in = net, saved, y
         ctx.skips = (x1, x2, x3)
         ctx.need_dx = x.requires_grad
         return p
@@ -119,6 +123,7 @@ class _TrackNetTrain(torch.autograd.Function):
         net, saved = ctx.net, ctx.saved
         hook = _grad_ready_hook
         grads = {}
+        keep = []
 
         def done(param, g):
             if hook is not None:
@@ -133,7 +138,8 @@ class _TrackNetTrain(torch.autograd.Function):
         if dp.device.type == "cuda":
             _BACKWARD_STREAMS[dp.device.index if dp.device.index is not None else 0] = \
                 [torch.cuda.current_stream(dp.device)] + ([side] if side is not None else [])
-        da, dw_head, db_head = ops.head_backward(dp, ctx.p, ctx.head_in, net.predictor.weight.detach())
+        (p_out,) = ctx.saved_tensors
+        da, dw_head, db_head = ops.head_backward(dp, p_out, ctx.head_in, net.predictor.weight.detach())
         done(net.predictor.weight, dw_head)
         done(net.predictor.bias, db_head)
 
@@ -152,9 +158,8 @@ class _TrackNetTrain(torch.autograd.Function):
                     side.wait_event(ready)
                     dw = ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
                     done(blk.conv.weight, dw)                        # the hook's bucket copy is ordered on the side stream
-                for t in (dz, rec["x0"], rec["x1"]):
-                    if t is not None:
-                        t.record_stream(side)                        # freed on the main stream while the side stream may read
+                keep.append(dz)      # read by the side stream: stays alive until the main stream has joined it (below), so the
+                                     # allocator can never hand its memory to later main-stream work too early
             if not need_dx:
                 return None, None
             c0 = int(rec["x0"].shape[1])
@@ -192,7 +197,8 @@ class _TrackNetTrain(torch.autograd.Function):
         dx, _ = chain_bwd(2, da, first_needs_dx=ctx.need_dx)   # down_block_1
         if side is not None:
             main.wait_stream(side)                                   # every weight gradient is final for whoever comes next
-        ctx.saved = None
+        keep.clear()
+        ctx.saved = ctx.skips = ctx.head_in = None
         if _backward_end_hook is not None:
             _backward_end_hook()
         out = [None, dx if ctx.need_dx else None]
@@ -245,13 +251,16 @@ class _InpaintNetTrain(torch.autograd.Function):
         u2 = ops.conv1d_k3(u1, *p[6], src1=x2)
         u3 = ops.conv1d_k3(u2, *p[7], src1=x1)
         out = ops.conv1d_k3(u3, *p[8], dst_nlc=True, act=ops.ACT_SIGMOID)
-        ctx.net, ctx.acts, ctx.inp = net, (x1, x2, x3, b1, b2, u1, u2, u3, out), (x, m)
+        if hasattr(ctx, "save_for_backward"):
+            ctx.save_for_backward(out)                   # the output: never as a plain attribute (reference cycle)
+        ctx.net, ctx.acts, ctx.inp = net, (x1, x2, x3, b1, b2, u1, u2, u3), (x, m)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         net = ctx.net
-        x1, x2, x3, b1, b2, u1, u2, u3, out = ctx.acts
+        x1, x2, x3, b1, b2, u1, u2, u3 = ctx.acts
+        (out,) = ctx.saved_tensors
         x, m = ctx.inp
         w = [wb[0].detach() for wb in net.conv_params()]
         g = {}
