@@ -155,6 +155,8 @@ def test_inpaintnet_forward_emulated_vs_golden(emu):
 
 CONV1D_MFMA_CASES = [   # (n, c0, c1, cout, act): every tile configuration of conv1d_mfma.h, ragged batches, two sources
     (19, 32, 0, 64, 1), (5, 64, 0, 128, 1), (9, 128, 0, 256, 0), (3, 256, 128, 128, 1), (17, 64, 32, 32, 2), (1, 8, 8, 32, 1),
+    # channel counts that are multiples of 8 but not of 32 take the 8-channel-stage (throughput) configurations at any batch
+    (5, 40, 0, 128, 1), (11, 40, 24, 64, 1), (3, 24, 0, 32, 0),
 ]
 
 

@@ -18,21 +18,28 @@
 
 namespace tnv3 {
 
-template <int MT_, int NTW_, int WM_, int WN_>
+template <int MT_, int NTW_, int WM_, int WN_, int CC_ = 8, int WK_ = 1>
 struct Conv1dMfmaCfg {
   static constexpr int MT = MT_, NTW = NTW_, WM = WM_, WN = WN_;
-  static constexpr int NT = WM * WN * 64;
+  static constexpr int WK = WK_;                     // waves that split the K range of a stage (small batches: a 32 x 32 tile per
+                                                     // workgroup spreads few sequences over many CUs, its four waves share the chain)
+  static constexpr int NT = WM * WN * WK * 64;
   static constexpr int MB = MT * 32 * WM;            // output channels per workgroup
   static constexpr int NB = NTW * 32 * WN;           // positions per workgroup
   static constexpr int SB = NB / 16;                 // sequences per workgroup
-  static constexpr int CC = 8;                       // input channels per pipeline stage
+  static constexpr int CC = CC_;                     // input channels per pipeline stage (8: throughput; 32: few workgroups,
+                                                     // where the chain of load -> barrier -> MFMA stages is the latency)
   static constexpr int WROW = CC * 3 + 1;            // padded filter row
   static constexpr int INP = NB + 8;                 // padded input row: 4 floats of slack on both sides
   static constexpr int W_FLOATS = MB * WROW, IN_FLOATS = CC * INP;
   static constexpr int BUF_FLOATS = ((W_FLOATS + 3) / 4) * 4 + IN_FLOATS;
-  static constexpr int NW4 = (MB * 6 + NT - 1) / NT; // 16-byte filter loads per thread per stage
+  static constexpr int WQ = CC * 3 / 4;              // 16-byte pieces per filter row and stage
+  static constexpr int NW4 = (MB * WQ + NT - 1) / NT; // 16-byte filter loads per thread per stage
   static constexpr int NI4 = (CC * SB * 4 + NT - 1) / NT;
   static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+  static constexpr int CW = CC / WK;                 // channels of a stage one wave contracts
+  static_assert(CC % (2 * WK) == 0, "each K-split wave needs whole channel pairs");
+  static_assert(WK == 1 || WK * WM * WN * MT * NTW * 16 * 64 <= 2 * BUF_FLOATS, "the K-split reduction reuses the stage buffers");
 };
 
 template <class Cfg>
@@ -43,7 +50,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv1d_k3_mfma_kernel(const Conv1dArg
   __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave % WN, wm = wave / WN;
+  const int wn = wave % WN, wm = (wave / WN) % Cfg::WM, wk = wave / (WN * Cfg::WM);
   const int half = lane >> 5, bl = lane & 31;
   const int Cin = a.C0 + a.C1, Cout = a.Cout;
   const int nMB = (Cout + MB - 1) / MB;
@@ -57,8 +64,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv1d_k3_mfma_kernel(const Conv1dArg
 #pragma unroll
     for (int i = 0; i < Cfg::NW4; ++i) {
       const int idx = tid + i * NT;
-      const int q = idx % 6, co_l = idx / 6;
-      const bool ok = idx < MB * 6 && co0 + co_l < Cout;
+      const int q = idx % Cfg::WQ, co_l = idx / Cfg::WQ;
+      const bool ok = idx < MB * Cfg::WQ && co0 + co_l < Cout;
       const float* src = a.w + ((size_t)(ok ? co0 + co_l : 0) * Cin + c0) * 3 + 4 * q;
       rw[i] = *reinterpret_cast<const f32x4*>(src);
       if (!ok) rw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -82,8 +89,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv1d_k3_mfma_kernel(const Conv1dArg
 #pragma unroll
     for (int i = 0; i < Cfg::NW4; ++i) {
       const int idx = tid + i * NT;
-      if (idx < MB * 6) {
-        float* d = w_s + (idx / 6) * WROW + 4 * (idx % 6);
+      if (idx < MB * Cfg::WQ) {
+        float* d = w_s + (idx / Cfg::WQ) * WROW + 4 * (idx % Cfg::WQ);
         d[0] = rw[i][0]; d[1] = rw[i][1]; d[2] = rw[i][2]; d[3] = rw[i][3];
       }
     }
@@ -106,8 +113,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv1d_k3_mfma_kernel(const Conv1dArg
       for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.0f;
 
   const bool z_first = (bl & 15) == 0, z_last = (bl & 15) == 15;
-  const int a_off = (wm * MT * 32 + bl) * WROW + half * 3;
-  const int b_off = IN_OFF + half * INP + 4 + wn * NTW * 32 + bl - 1;
+  const int a_off = (wm * MT * 32 + bl) * WROW + (wk * Cfg::CW + half) * 3;
+  const int b_off = IN_OFF + (wk * Cfg::CW + half) * INP + 4 + wn * NTW * 32 + bl - 1;
 
   const int nChunks = Cin / CC;
   load_stage(0);
@@ -118,7 +125,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv1d_k3_mfma_kernel(const Conv1dArg
     if (k + 1 < nChunks) load_stage(k + 1);
     const float* A = lds + buf * Cfg::BUF_FLOATS + a_off;
     const float* B = lds + buf * Cfg::BUF_FLOATS + b_off;
-    constexpr int NSTEP = (CC / 2) * 3;
+    constexpr int NSTEP = (Cfg::CW / 2) * 3;
     float av[2][MT], bv[2][NTW];
     auto read_step = [&](int s, float (&ar)[MT], float (&br)[NTW]) {
       const int cp = s / 3, tap = s - 3 * cp;
@@ -142,6 +149,32 @@ __global__ void __launch_bounds__(Cfg::NT) conv1d_k3_mfma_kernel(const Conv1dArg
     }
     if (k + 1 < nChunks) store_stage(buf ^ 1);
     __syncthreads();
+  }
+
+  // ---- K-split waves: fold the partial accumulators through LDS (fixed order wk = 1, 2, ...: deterministic)
+  if (Cfg::WK > 1) {
+    constexpr int TILE = MT * NTW * 16 * 64;                       // floats one wave holds
+    float* red = lds;                                              // stage buffers are free after the last barrier
+    const int slot = ((wk * Cfg::WM + wm) * WN + wn) * TILE + lane;
+    if (wk > 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[slot + ((mt * NTW + j) * 16 + r) * 64] = acc[mt][j][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int q = 1; q < Cfg::WK; ++q)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[mt][j][r] += red[((q * Cfg::WM + wm) * WN + wn) * TILE + lane + ((mt * NTW + j) * 16 + r) * 64];
   }
 
   // ---- epilogue: bias + activation, [N][Cout][16]

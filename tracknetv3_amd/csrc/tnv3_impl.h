@@ -185,9 +185,14 @@ int maxpool2x2_impl(Launcher& L, const float* x, float* y, long nc, int h, int w
   return L.launch(maxpool2x2_kernel, grid, 256, x, y, nc, h, w);
 }
 
+// Compute units of the current device (256 on an unpartitioned MI355X: 8 XCDs x 32 CUs); the C-ABI translation unit
+// sets it once from hipDeviceGetAttribute, the emulator keeps the default.
+inline int& num_cus() { static int n = 256; return n; }
+
 using Conv1dM128 = Conv1dMfmaCfg<2, 2, 2, 2>;   // 128 channels x 8 sequences
 using Conv1dM64 = Conv1dMfmaCfg<2, 2, 1, 4>;    //  64 channels x 16 sequences
 using Conv1dM32 = Conv1dMfmaCfg<1, 2, 1, 4>;    //  32 channels x 16 sequences
+using Conv1dLat = Conv1dMfmaCfg<1, 1, 1, 1, 32, 4>; // small batches: 32 channels x 2 sequences per workgroup, four waves split K
 
 template <class Launcher>
 int conv1d_k3_impl(Launcher& L, const float* src0, const float* src1, const float* w, const float* b, float* dst, int n,
@@ -206,6 +211,9 @@ int conv1d_k3_impl(Launcher& L, const float* src0, const float* src1, const floa
       if (blocks > 0x7fffffffl) TNV3_FAIL(-1, "conv1d_k3: batch too large");
       return L.launch(conv1d_k3_mfma_kernel<Cfg>, (int)blocks, Cfg::NT, a);
     };
+    // Few sequences: the big tiles would occupy a handful of CUs for K/2 x 64 cycles each (61 us for the 384 -> 128 layer);
+    // 32 x 32 tiles with the K range split over four waves put the same work on up to 4 x num_cus() SIMDs.
+    if (c0 % 32 == 0 && c1 % 32 == 0 && ((long)n + 1) / 2 * (cout / 32) <= 4l * num_cus()) return go(Conv1dLat{});
     if (cout % 128 == 0) return go(Conv1dM128{});
     if (cout % 64 == 0) return go(Conv1dM64{});
     return go(Conv1dM32{});
@@ -337,9 +345,6 @@ inline int& wgrad_variant() { static int v = 0; return v; }
 constexpr size_t kWgradZeroBytes = 1024;     // zero prefix of the workspace: padding source of the LDS-DMA kernels
 
 struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
-// Compute units of the current device (256 on an unpartitioned MI355X: 8 XCDs x 32 CUs); the C-ABI translation unit
-// sets it once from hipDeviceGetAttribute, the emulator keeps the default.
-inline int& num_cus() { static int n = 256; return n; }
 inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
   WgradPlan p;
   p.use_b = (cout % 128) != 0;
