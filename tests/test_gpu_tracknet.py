@@ -86,6 +86,26 @@ def test_tracknet_eval_vs_reference_golden_full_tensor(gpu_device, name):
     assert err <= 1e-5, err
 
 
+@pytest.mark.parametrize("seq_len,bg_mode", [(1, ""), (1, "subtract"), (3, "subtract"), (3, "subtract_concat"), (2, "concat"), (8, "")])
+def test_every_get_model_channel_plan_runs_and_matches_the_oracle(gpu_device, seq_len, bg_mode):
+    """get_model's channel plans (utils/general.py:46-80): in_dim 3 / 1 / 3 / 12 / 9 / 24 -- odd, tiny and non-multiple-of-8
+    input widths go through the same kernels (K padded with zero filter rows); eval and train-mode forward vs the oracle."""
+    from tracknetv3_amd.utils.general import get_model
+    m = get_model("TrackNet", seq_len, bg_mode)
+    in_dim, out_dim = nets.tracknet_dims(seq_len, bg_mode)
+    assert m.in_dim == in_dim and m.out_dim == out_dim
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), 50 + in_dim, calibrated=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu_device)
+    x = nets.synth_input((2, in_dim, 16, 32), 77)
+    with torch.no_grad():
+        ref_eval = nets.tracknet_forward(sd, x, training=False)
+        ref_train = nets.tracknet_forward({k: v.clone() for k, v in sd.items()}, x, training=True)
+    assert (m.eval()(x.to(gpu_device)).cpu() - ref_eval).abs().max().item() <= 1e-5
+    with torch.no_grad():
+        assert (m.train()(x.to(gpu_device)).cpu() - ref_train).abs().max().item() <= 5e-5
+
+
 def test_tracknet_eval_vs_reference_golden_probes_64x128(gpu_device):
     g = np.load(os.path.join(GOLDEN, "tracknet_9_3_64x128_cal.npz"))
     m, x, _ = _load_model(g, gpu_device)
