@@ -81,10 +81,32 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// Library default when the caller passes cfg = -1 (overridden per layer by the tuned table on the Python
-// side).  Measured on MI355X (profiles/r01_*): the small 4x32-pixel tiles win on every TrackNet layer because
-// they run 3 waves per SIMD; 128-channel blocks are marginally better when Cout allows.
-inline int conv_auto_config(int /*N*/, int Cout, int /*H*/, int /*W*/) { return (Cout % 128 == 0) ? 11 : 12; }
+// Compute units of the current device (256 on an unpartitioned MI355X: 8 XCDs x 32 CUs); the C-ABI translation unit
+// sets it once from hipDeviceGetAttribute, the emulator keeps the default.
+inline int& num_cus() { static int n = 256; return n; }
+
+// Library default when the caller passes cfg = -1 (overridden per layer by the tuned table on the Python side, which
+// holds the measured winners for batch 10).  For every other batch size the choice follows the launch-tail model that
+// the sweeps at batch 1 / 5 / 16 / 32 confirmed (profiles/r01_conv_tile_sweep_batch_1_5_16.md): a launch of B equal
+// workgroups keeps the CUs busy for (B/CUs)/ceil(B/CUs) of its time (B/CUs when there are fewer workgroups than CUs);
+// the 128-channel tile (cfg 11) is ~4.5 % more efficient per FLOP than the 64-channel one (cfg 12) and loses whenever
+// halving the tile wins more than that back.
+inline double conv_tail_factor(long blocks, int cus) {
+  if (blocks < cus) return (double)blocks / cus;
+  const long rounds = (blocks + cus - 1) / cus;
+  return (double)blocks / ((double)rounds * cus);
+}
+inline int conv_auto_config(int N, int Cin, int Cout, int H, int W) {
+  const int cus = num_cus();
+  if (Cin <= 32 && Cout % 64 == 0) return 16;                 // stem: K = 9 * Cin is short, the 3-stage LDS-DMA pipeline wins
+  if (Cout % 128 == 0) {
+    const long b11 = (long)N * ((H + 3) / 4) * ((W + 31) / 32) * (Cout / 128);
+    if (b11 < 2l * cus) return 12;
+    return 0.955 * conv_tail_factor(2 * b11, cus) > conv_tail_factor(b11, cus) ? 12 : 11;
+  }
+  const long b14 = (long)N * ((H + 7) / 8) * ((W + 31) / 32) * ((Cout + 63) / 64);
+  return b14 >= 2l * cus ? 14 : 12;                           // 64-channel layers: 8x32-pixel tiles once they fill the chip
+}
 
 template <class Cfg, class Launcher>
 int launch_conv_cfg(Launcher& L, const Conv3x3Args& a) {
@@ -110,7 +132,7 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
   if (h >= 8192 || w >= 8192) TNV3_FAIL(-1, "conv3x3: H,W must be < 8192");
   if (c1 > 0 && (c0 % 32)) TNV3_FAIL(-1, "conv3x3: two-source input needs C0 %% 32 == 0 (got %d)", c0);
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3: upsampled source needs even H,W");
-  if (cfg < 0) cfg = conv_auto_config(n, cout, h, w);
+  if (cfg < 0) cfg = conv_auto_config(n, c0 + c1, cout, h, w);
   if (dst1 && (csplit <= 0 || csplit >= cout)) TNV3_FAIL(-1, "conv3x3: bad output split %d of %d", csplit, cout);
   const float* zeros = wpack + (size_t)round_up(c0 + c1, 32) * 9 * cout;       // the packed filter's zero tail
   Conv3x3Args a{src0, src1, wpack, zeros, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0, diag};
@@ -185,9 +207,6 @@ int maxpool2x2_impl(Launcher& L, const float* x, float* y, long nc, int h, int w
   return L.launch(maxpool2x2_kernel, grid, 256, x, y, nc, h, w);
 }
 
-// Compute units of the current device (256 on an unpartitioned MI355X: 8 XCDs x 32 CUs); the C-ABI translation unit
-// sets it once from hipDeviceGetAttribute, the emulator keeps the default.
-inline int& num_cus() { static int n = 256; return n; }
 
 using Conv1dM128 = Conv1dMfmaCfg<2, 2, 2, 2>;   // 128 channels x 8 sequences
 using Conv1dM64 = Conv1dMfmaCfg<2, 2, 1, 4>;    //  64 channels x 16 sequences
