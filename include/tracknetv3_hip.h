@@ -68,6 +68,27 @@ int tnv3_conv3x3_forward(const float* src0, const float* src1, const float* wpac
                          const float* scale, const float* shift, float* dst, int n, int c0, int c1, int cout,
                          int h, int w, int up0, int relu, int cfg, tnv3_stream_t stream);
 
+/* The same kernel with an ADDEND: dst = act(((conv3x3(...) + addend) - mean) * scale + shift), addend [N][Cout][H][W] or NULL.
+ * Used for the skip half of a decoder-entry layer, whose upsampled half comes from tnv3_conv_up2x_forward. */
+int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* wpack, const float* addend, const float* mean,
+                             const float* scale, const float* shift, float* dst, int n, int c0, int c1, int cout, int h, int w,
+                             int up0, int relu, int cfg, tnv3_stream_t stream);
+
+/* Decoder-entry layers (model.py:65,67,69: Conv2DBlock on torch.cat([nn.Upsample(scale_factor=2)(x), skip], dim=1)):
+ * the contribution of the UPSAMPLED channels computed at the low resolution.  A 3x3 'same' convolution over a nearest-2x
+ * upsampled tensor reads only 2x2 distinct source pixels per output pixel, so with the taps that coincide pre-summed
+ * (four class filters, one per output parity) it costs 4/9 of the multiply-adds and reads the low-res tensor once.
+ *   tnv3_conv_up2x_packed_floats : size of the class-filter buffer for c0 upsampled channels
+ *   tnv3_pack_up2x_weights       : w [cout][cin][3][3] (the layer's nn.Conv2d weight; its first c0 input channels are the
+ *                                  upsampled ones) -> wq
+ *   tnv3_conv_up2x_forward       : src_low [n][c0][h_low][w_low], wq -> dst [n][cout][2*h_low][2*w_low] partial sums (no
+ *                                  BN / activation); feed it to tnv3_conv3x3_forward_add as `addend` together with the skip
+ *                                  tensor and the packed filter of input channels c0.. of the same weight. */
+size_t tnv3_conv_up2x_packed_floats(int c0, int cout);
+int tnv3_pack_up2x_weights(const float* w, float* wq, int cout, int cin, int c0, tnv3_stream_t stream);
+int tnv3_conv_up2x_forward(const float* src_low, const float* wq, float* dst, int n, int c0, int cout, int h_low, int w_low,
+                           tnv3_stream_t stream);
+
 /* ---- head + pooling (model.py:54-55,59,61,63,71-72) ----------------------------------------------------- */
 
 /* y[N][L][HW] = sigmoid?( b[l] + sum_c w[l][c] * x[N][C][HW] ); HW % 4 == 0. */

@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import GOLDEN
+from test_emu_kernels import UP2X_CASES, _up2x_case
 from oracle import nets, prng
 from test_emu_kernels import CONV_CASES, T, conv_ref
 
@@ -50,6 +51,13 @@ def test_conv3x3_every_config_on_network_shapes(gpu_device, cfg):
                         mean=mu.to(d), scale=sc.to(d), shift=sh.to(d), up0=up0, relu=True, cfg=cfg).cpu()
         ref = conv_ref(s0, s1, wt, sc, sh, up0, True, mu)
         assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6, (cfg, c0, c1)
+
+
+@pytest.mark.parametrize("case", UP2X_CASES + [(2, 512, 256, 36, 64), (1, 128, 64, 144, 256), (2, 256, 128, 9, 40)])
+def test_conv_up2x_vs_torch(gpu_device, case):
+    n, c0, cout, hl, wl = case
+    e_up, e_full = _up2x_case(n, c0, cout, hl, wl, gpu_device, c1=c0 // 2 if c0 >= 64 else 16)
+    assert e_up <= 3e-6 and e_full <= 3e-6, (e_up, e_full)
 
 
 def test_pool_head_pack(gpu_device):

@@ -86,7 +86,10 @@ class _TrackNetTrain(torch.autograd.Function):
         def block_fwd(blk, src0, src1=None, up=False):
             h = src0.shape[2] * (2 if up else 1)
             w = src0.shape[3] * (2 if up else 1)
-            z = ops.conv3x3(src0, blk.packed_weight(), blk.conv.out_dim, src1=src1, up0=up, relu=False, cfg=_cfg(blk, n, h, w))
+            if up and src1 is not None:
+                z = blk.conv_up_skip(src0, src1, int(n), relu=False, affine=False)
+            else:
+                z = ops.conv3x3(src0, blk.packed_weight(), blk.conv.out_dim, src1=src1, up0=up, relu=False, cfg=_cfg(blk, n, h, w))
             bn = blk.bn
             a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                    bn.eps, bn.momentum)

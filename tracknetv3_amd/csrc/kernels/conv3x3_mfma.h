@@ -44,6 +44,8 @@ struct Conv3x3Args {
   int N, C0, C1, Cout, H, W;
   int up0;              // 1: src0 is stored at (H/2, W/2) and read as out[h][w] = src0[h>>1][w>>1]
   int relu;             // 1: y = max(y, 0)
+  const float* addend;  // optional [N][Cout][H][W]: added to the accumulator before the affine / ReLU (the low-resolution half of a
+                        // decoder-entry layer, conv_up2x_mfma.h); not combined with dst1
   int diag;             // honoured only by ConvCfg<..., DIAG = 1> instantiations (WRONG results by design): 1 = stage the first
                         // chunk only (no global loads / LDS stores afterwards), 2 = additionally no barriers.
 };
@@ -390,10 +392,13 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
       for (int j = 0; j < NTW; ++j) {
         const int oh = h0 + wn * (NTW / CS) + j / CS;
         const int ow = w0 + (j % CS) * 32 + bl;
-        float v = acc[mt][j][r];
-        if (has_affine) v = (v - mu) * sc + sh;
-        if (a.relu) v = v > 0.0f ? v : 0.0f;
-        if (oh < H && ow < W) drow[oh * W + ow] = v;
+        if (oh < H && ow < W) {
+          float v = acc[mt][j][r];
+          if (a.addend) v += a.addend[((size_t)n * Cout + co) * HW + oh * W + ow];
+          if (has_affine) v = (v - mu) * sc + sh;
+          if (a.relu) v = v > 0.0f ? v : 0.0f;
+          drow[oh * W + ow] = v;
+        }
       }
     }
   }

@@ -1,0 +1,211 @@
+// conv_up2x_mfma.h -- the upsampled half of a decoder-entry layer (model.py:65,67,69: Conv2DBlock applied to
+// torch.cat([nn.Upsample(scale_factor=2)(x), skip], dim=1)) computed AT THE LOW RESOLUTION.
+//
+// A 3x3 'same' convolution over a nearest-2x-upsampled tensor only ever sees 2x2 distinct source pixels per output
+// pixel: for output row h = 2i + ph the taps kh = 0,1,2 read low-res rows {i-1, i, i} (ph = 0) or {i, i, i+1} (ph = 1),
+// and likewise for columns.  Summing the filter taps that hit the same source pixel,
+//     Wq[cls = 2ph+pw][a][b] = sum_{kh in R[ph][a]} sum_{kw in R[pw][b]} W[kh][kw],   R[0] = {{0},{1,2}},  R[1] = {{0,1},{2}},
+// turns the upsampled part of the layer into four 2x2 correlations on the low-res tensor (one per output parity class):
+//     P[co][2i+ph][2j+pw] = sum_{ci,a,b} Wq[cls][ci][a][b][co] * Xlow[ci][i + a + ph - 1][j + b + pw - 1]
+// i.e. 4/9 of the multiply-adds, and the low-res tensor is read once instead of four times.  The skip half of the layer
+// stays a regular 3x3 convolution (conv3x3_mfma_kernel) that takes P as its `addend` and applies BN + ReLU.
+// Same algebra as the reference in exact arithmetic; in fp32 the pre-summed taps differ from the tap-by-tap chain by
+// ordinary rounding (a few 1e-7 relative), far inside the 1e-4 heat-map bar.
+//
+// MFMA 32x32x2 mapping: an N-tile is 32 output pixels of one full-res row with the SAME column parity (w = 2j + pw,
+// j = 32 consecutive low-res columns), so all its lanes share the class filter and the B operand is 32 consecutive
+// low-res floats of the LDS halo tile; a wave owns both column parities of its rows and stores (pw = 0, pw = 1) as one
+// 8-byte pair per lane -> contiguous 256-byte row segments per half-wave.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "conv3x3_mfma.h"
+
+namespace tnv3 {
+
+struct ConvUp2xArgs {
+  const float* src;     // [N][C0][HL][WL]   low-resolution tensor (the operand of nn.Upsample)
+  const float* wq;      // [C0_pad][4][4][Cout]  pre-summed class filters (pack_up2x_weights_kernel), C0_pad = roundup(C0, CC)
+  float* dst;           // [N][Cout][2*HL][2*WL]  partial sums P (no bias / BN / activation)
+  int N, C0, Cout, HL, WL;
+};
+
+template <int MT_, int WM_, int WN_, int TRL_, int CC_>
+struct ConvUp2xCfg {
+  static constexpr int MT = MT_, WM = WM_, WN = WN_, TRL = TRL_, CC = CC_;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int MB = MT * 32 * WM;
+  static constexpr int NTILES = 4 * TRL;                 // (full-res row, column parity) pairs of a 2*TRL x 64 output tile
+  static constexpr int NTW = NTILES / WN;                // per wave: whole rows, both parities
+  static_assert(NTILES % WN == 0 && NTW % 2 == 0, "a wave owns both column parities of its rows");
+  static_assert(CC % 2 == 0, "one MFMA = 2 channels");
+  static constexpr int TRp = TRL + 2, TCp = 34, PLANE = TRp * TCp;
+  static constexpr int E_IN = CC * PLANE, NIN = (E_IN + NT - 1) / NT, IN_FLOATS = NIN * NT;
+  static constexpr int KROWS = CC * 16;                  // (channel, class, tap) rows of one stage
+  static constexpr int W_FLOATS = KROWS * MB, E_W4 = W_FLOATS / 4, NW4 = (E_W4 + NT - 1) / NT;
+  static_assert(E_W4 % NT == 0, "the filter panel must deal evenly");
+  static constexpr int BUF_FLOATS = W_FLOATS + IN_FLOATS;
+  static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT) conv_up2x_mfma_kernel(const ConvUp2xArgs a) {
+  constexpr int MT = Cfg::MT, WN = Cfg::WN, TRL = Cfg::TRL, CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, NTW = Cfg::NTW;
+  constexpr int TCp = Cfg::TCp, PLANE = Cfg::PLANE, NIN = Cfg::NIN, NW4 = Cfg::NW4, KROWS = Cfg::KROWS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int half = lane >> 5, bl = lane & 31;
+  const int HL = a.HL, WL = a.WL, C0 = a.C0, Cout = a.Cout;
+  const int tilesH = (HL + TRL - 1) / TRL, tilesW = (WL + 31) / 32;
+  const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
+  int mb, pt;
+  if (!conv_block_map(blockIdx.x, nMB, nPT, mb, pt)) return;
+  const int n = pt / (tilesH * tilesW);
+  const int trem = pt - n * (tilesH * tilesW);
+  const int i0 = (trem / tilesW) * TRL, j0 = (trem % tilesW) * 32;
+  const int m0 = mb * MB;
+  const int HWL = HL * WL;
+
+  // staging slots of the [CC][TRL+2][34] halo tile: offset inside one low-res plane, or -1 (zero padding / unused)
+  int so[NIN], sc[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int e = tid + i * NT;
+    const int c = e / PLANE, r = e - c * PLANE;
+    const int tr = r / TCp, tc = r - tr * TCp;
+    const int gi = i0 - 1 + tr, gj = j0 - 1 + tc;
+    const bool ok = e < Cfg::E_IN && gi >= 0 && gi < HL && gj >= 0 && gj < WL;
+    so[i] = ok ? gi * WL + gj : -1;
+    sc[i] = c;
+  }
+  float rin[NIN];
+  f32x4 rw[NW4];
+  auto load_stage = [&](int k) {
+    const int cbeg = k * CC;
+    const float* base = a.src + ((size_t)n * C0 + cbeg) * HWL;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const bool ok = so[i] >= 0 && cbeg + sc[i] < C0;
+      rin[i] = base[ok ? sc[i] * HWL + so[i] : 0];
+    }
+    const float* wsrc = a.wq + (size_t)k * KROWS * Cout + m0;
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+      const int e4 = tid + i * NT;
+      const int krow = e4 / (MB / 4), m4 = e4 - krow * (MB / 4);
+      rw[i] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)krow * Cout + m4 * 4);
+    }
+  };
+  auto store_stage = [&](int buf, int k) {
+    float* lw = lds + buf * Cfg::BUF_FLOATS;
+    float* li = lw + Cfg::W_FLOATS;
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) *reinterpret_cast<f32x4*>(lw + (tid + i * NT) * 4) = rw[i];
+    const int cbeg = k * CC;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) li[tid + i * NT] = (so[i] >= 0 && cbeg + sc[i] < C0) ? rin[i] : 0.0f;
+  };
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.0f;
+
+  // N-tile t of the workgroup = (full-res row rf = t >> 1 of the tile, column parity pw = t & 1); wave wn owns
+  // t = wn*NTW .. wn*NTW + NTW-1.  Row rf = 2*il + ph reads halo rows il + ph + a and columns bl + pw + b (a, b = tap bits),
+  // with the class filter (ph, pw).  Per N-tile that is one wave-uniform offset on each side, the rest are immediates.
+  int aoff[NTW], boff[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int t = wn * NTW + j;
+    const int rf = t >> 1, pw = t & 1, il = rf >> 1, ph = rf & 1;
+    aoff[j] = half * 16 * MB + ((ph * 2 + pw) * 4) * MB + wm * (MT * 32) + bl;
+    boff[j] = Cfg::W_FLOATS + half * PLANE + (il + ph) * TCp + pw + bl;
+  }
+
+  const int nChunks = (C0 + CC - 1) / CC;
+  load_stage(0);
+  store_stage(0, 0);
+  __syncthreads();
+  for (int k = 0; k < nChunks; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < nChunks) load_stage(k + 1);
+    const float* S = lds + buf * Cfg::BUF_FLOATS;
+    constexpr int NSTEP = (CC / 2) * 4;                  // (channel pair, tap) steps of this stage
+    float av[2][MT][NTW], bv[2][NTW];
+    auto read_step = [&](int s, float (&ar)[MT][NTW], float (&br)[NTW]) {
+      const int cp = s >> 2, tap = s & 3;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        br[j] = S[boff[j] + (2 * cp) * PLANE + (tap >> 1) * TCp + (tap & 1)];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ar[mt][j] = S[aoff[j] + ((2 * cp) * 16 + tap) * MB + mt * 32];
+      }
+    };
+    read_step(0, av[0], bv[0]);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + 1 < NSTEP) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mt][j], bv[s & 1][j], acc[mt][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (MT + 1) * NTW, 0);   // DS reads of the next step
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);         // MFMAs of this step
+    }
+    if (k + 1 < nChunks) store_stage(buf ^ 1, k + 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: the two column parities of a row are interleaved into 8-byte pairs
+  const int H = 2 * HL, W = 2 * WL;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float* dplane = a.dst + ((size_t)n * Cout + co) * H * W;
+#pragma unroll
+      for (int jp = 0; jp < NTW / 2; ++jp) {
+        const int rf = (wn * NTW) / 2 + jp;              // full-res row inside the tile
+        const int oh = 2 * i0 + rf, ow = 2 * (j0 + bl);
+        if (oh < H && ow < W) {
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          f32x2_t v; v[0] = acc[mt][2 * jp][r]; v[1] = acc[mt][2 * jp + 1][r];
+          *reinterpret_cast<f32x2_t*>(dplane + (size_t)oh * W + ow) = v;
+        }
+      }
+    }
+  }
+}
+
+// Wq[C0_pad][cls][a*2+b][Cout] from the layer's nn.Conv2d weight W[Cout][Cin][3][3] (first C0 input channels), + zero rows.
+__global__ void pack_up2x_weights_kernel(const float* __restrict__ w, float* __restrict__ wq, int Cout, int Cin, int C0, int C0pad) {
+  const long total = (long)C0pad * 16 * Cout;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(e % Cout);
+    const long t = e / Cout;
+    const int tap = (int)(t & 3), cls = (int)((t >> 2) & 3);
+    const int ci = (int)(t >> 4);
+    float v = 0.0f;
+    if (ci < C0) {
+      const int ph = cls >> 1, pw = cls & 1, ta = tap >> 1, tb = tap & 1;
+      // rows kh hitting low-res row offset `ta` for output parity ph:  ph=0: {0} | {1,2};  ph=1: {0,1} | {2}
+      const int kh0 = ph == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), kh1 = ph == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+      const int kw0 = pw == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kw1 = pw == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+      const float* wk = w + ((long)co * Cin + ci) * 9;
+      for (int kh = kh0; kh <= kh1; ++kh)
+        for (int kw = kw0; kw <= kw1; ++kw) v += wk[kh * 3 + kw];
+    }
+    wq[e] = v;
+  }
+}
+
+}  // namespace tnv3

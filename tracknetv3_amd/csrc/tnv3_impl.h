@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "kernels/conv3x3_mfma.h"
+#include "kernels/conv_up2x_mfma.h"
 #include "kernels/conv1d_k3.h"
 #include "kernels/conv1d_mfma.h"
 #include "kernels/pointwise.h"
@@ -122,7 +123,7 @@ int launch_conv_cfg(Launcher& L, const Conv3x3Args& a) {
 template <class Launcher>
 int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, const float* wpack, const float* mean,
                          const float* scale, const float* shift, float* dst, int n, int c0, int c1, int cout, int h, int w, int up0,
-                         int relu, int cfg, float* dst1 = nullptr, int csplit = 0, int diag = 0) {
+                         int relu, int cfg, float* dst1 = nullptr, int csplit = 0, int diag = 0, const float* addend = nullptr) {
   if (!src0 || !wpack || !dst) TNV3_FAIL(-1, "conv3x3: null pointer");
   if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "conv3x3: non-positive dimension");
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3: src1 / c1 mismatch");
@@ -134,8 +135,9 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3: upsampled source needs even H,W");
   if (cfg < 0) cfg = conv_auto_config(n, c0 + c1, cout, h, w);
   if (dst1 && (csplit <= 0 || csplit >= cout)) TNV3_FAIL(-1, "conv3x3: bad output split %d of %d", csplit, cout);
+  if (dst1 && addend) TNV3_FAIL(-1, "conv3x3: addend cannot be combined with a split destination");
   const float* zeros = wpack + (size_t)round_up(c0 + c1, 32) * 9 * cout;       // the packed filter's zero tail
-  Conv3x3Args a{src0, src1, wpack, zeros, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0, diag};
+  Conv3x3Args a{src0, src1, wpack, zeros, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0, addend, diag};
   if (diag) {
     switch (cfg) {
       case 10: return launch_conv_cfg<ConvD10>(L, a);
@@ -340,6 +342,39 @@ int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const fl
                      dbeta, coef, c))) return rc;
   return L.launch(bn_relu_bwd_apply_kernel, grid_for((long)n * c * (hw / 4)), 256, da, a, z, mean, invstd, (const float*)coef, dz,
                   (long)n * c, c, hw);
+}
+
+// ---- the upsampled half of a decoder-entry layer at the low resolution (kernels/conv_up2x_mfma.h)
+using UpA = ConvUp2xCfg<2, 2, 4, 2, 4>;      // 128 channels x (4 x 64) full-res pixels, 512 threads
+using UpB = ConvUp2xCfg<2, 1, 4, 2, 4>;      //  64 channels x (4 x 64) full-res pixels, 256 threads
+inline int up2x_chunk(int cout) { return cout % 128 == 0 ? UpA::CC : UpB::CC; }
+inline size_t conv_up2x_packed_floats(int c0, int cout) {
+  if (c0 <= 0 || cout <= 0) return 0;
+  return (size_t)round_up(c0, 8) * 16 * cout;          // padded to the larger chunk so either configuration can read it
+}
+
+template <class Launcher>
+int pack_up2x_weights_impl(Launcher& L, const float* w, float* wq, int cout, int cin, int c0) {
+  if (!w || !wq || cout <= 0 || cin <= 0 || c0 <= 0 || c0 > cin) TNV3_FAIL(-1, "pack_up2x_weights: bad argument");
+  const int c0pad = round_up(c0, 8);
+  const long total = (long)c0pad * 16 * cout;
+  return L.launch(pack_up2x_weights_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, wq, cout, cin, c0, c0pad);
+}
+
+template <class Launcher>
+int conv_up2x_forward_impl(Launcher& L, const float* src, const float* wq, float* dst, int n, int c0, int cout, int hl, int wl) {
+  if (!src || !wq || !dst || n <= 0 || c0 <= 0 || cout <= 0 || hl <= 0 || wl <= 0) TNV3_FAIL(-1, "conv_up2x: bad argument");
+  if (cout % 64) TNV3_FAIL(-1, "conv_up2x: Cout=%d must be a multiple of 64", cout);
+  if (hl >= 4096 || wl >= 4096) TNV3_FAIL(-1, "conv_up2x: low-resolution H,W must be < 4096");
+  if (((uintptr_t)dst) & 7) TNV3_FAIL(-1, "conv_up2x: destination must be 8-byte aligned");
+  ConvUp2xArgs a{src, wq, dst, n, c0, cout, hl, wl};
+  auto go = [&](auto cfg) -> int {
+    using Cfg = decltype(cfg);
+    const long npt = (long)n * ((hl + Cfg::TRL - 1) / Cfg::TRL) * ((wl + 31) / 32);
+    if (npt > (1l << 28)) TNV3_FAIL(-1, "conv_up2x: too many pixel tiles");
+    return L.launch(conv_up2x_mfma_kernel<Cfg>, conv_grid_blocks(cout / Cfg::MB, (int)npt), Cfg::NT, a);
+  };
+  return cout % 128 == 0 ? go(UpA{}) : go(UpB{});
 }
 
 template <class Launcher>

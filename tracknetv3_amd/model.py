@@ -67,6 +67,31 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
+    def packed_up2x(self, c0):
+        """(class filters of the first c0 = upsampled input channels, packed 3x3 filter of the remaining skip channels):
+        the two operands of the decoder-entry formulation (ops.conv_up2x + ops.conv3x3(..., addend=...))."""
+        key = ("up2x", int(c0))
+        ver = self._versions(["conv"])
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            w = self.conv.weight.detach()
+            hit = (ver, (ops.pack_up2x_weights(w, c0), ops.pack_conv3x3_weights(w[:, c0:].contiguous())))
+            self._cache[key] = hit
+        return hit[1]
+
+    def conv_up_skip(self, x_low, skip, n, relu, affine):
+        """conv3x3(cat([upsample2x(x_low), skip], 1)) with the upsampled half computed at the low resolution."""
+        c0, c1 = int(x_low.shape[1]), int(skip.shape[1])
+        wq, wskip = self.packed_up2x(c0)
+        part = ops.conv_up2x(x_low, wq, self.conv.out_dim)
+        h, w = int(skip.shape[2]), int(skip.shape[3])
+        cfg = tuning.conv_config(self.conv.out_dim, c1, n, h, w)
+        bn = self.bn
+        if affine:
+            return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, mean=bn.running_mean, scale=self.eval_scale(),
+                               shift=bn.bias.detach(), relu=relu, cfg=cfg)
+        return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, relu=relu, cfg=cfg)
+
     def eval_scale(self):
         """gamma / sqrt(running_var + eps), recomputed when gamma or running_var change."""
         ver = self._versions(["weight", "running_var"])
@@ -80,6 +105,8 @@ class Conv2DBlock(nn.Module):
     def forward_eval(self, x, skip=None, up=False):
         bn = self.bn
         n = x.shape[0]
+        if up and skip is not None:
+            return self.conv_up_skip(x, skip, int(n), relu=True, affine=True)
         h = x.shape[2] * (2 if up else 1)
         w = x.shape[3] * (2 if up else 1)
         cfg = tuning.conv_config(self.conv.out_dim, self.conv.in_dim, n, h, w)
@@ -170,8 +197,11 @@ class TrackNet(nn.Module):
         with torch.no_grad():
             for blk in (self.down_block_1, self.down_block_2, self.down_block_3, self.bottleneck, self.up_block_1,
                         self.up_block_2, self.up_block_3):
-                for b in blk.blocks():
-                    b.packed_weight()
+                for i, b in enumerate(blk.blocks()):
+                    if i == 0 and blk in (self.up_block_1, self.up_block_2, self.up_block_3):
+                        b.packed_up2x(b.conv.in_dim * 2 // 3)      # decoder entry: 2/3 of the inputs are the upsampled tensor
+                    else:
+                        b.packed_weight()
                     b.eval_scale()
 
     def forward(self, x):

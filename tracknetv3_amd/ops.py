@@ -53,11 +53,37 @@ def bn_eval_scale(gamma, running_var, eps=BN_EPS):
     return scale
 
 
-def conv3x3(src0, wpack, cout, src1=None, mean=None, scale=None, shift=None, up0=False, relu=False, cfg=-1, out=None):
-    """act((conv3x3(cat([up2x?(src0), src1], 1), W) - mean) * scale + shift) -- see tnv3_conv3x3_forward."""
+def pack_up2x_weights(weight, c0):
+    """nn.Conv2d weight (Cout, Cin, 3, 3) -> pre-summed class filters of its first c0 (upsampled) input channels."""
     lib = _lib.load()
-    _f32(src0, src1, wpack, mean, scale, shift, out)
-    _lib.dev_check(src0, src1, wpack, mean, scale, shift, out)
+    _f32(weight)
+    _lib.dev_check(weight)
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    wq = torch.empty(lib.tnv3_conv_up2x_packed_floats(int(c0), cout), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.tnv3_pack_up2x_weights(_lib.ptr(weight), _lib.ptr(wq), cout, cin, int(c0), _lib.stream_ptr(weight)))
+    return wq
+
+
+def conv_up2x(src_low, wq, cout):
+    """Partial sums of conv3x3 over the nearest-2x upsampling of src_low, computed at the low resolution (tnv3_conv_up2x_forward)."""
+    lib = _lib.load()
+    _f32(src_low, wq)
+    _lib.dev_check(src_low, wq)
+    n, c0, hl, wl = (int(v) for v in src_low.shape)
+    if wq.numel() != lib.tnv3_conv_up2x_packed_floats(c0, int(cout)):
+        raise _lib.Tnv3Error("conv_up2x: class-filter buffer does not match the channel counts")
+    out = torch.empty((n, int(cout), 2 * hl, 2 * wl), dtype=torch.float32, device=src_low.device)
+    if n:
+        _lib.check(lib.tnv3_conv_up2x_forward(_lib.ptr(src_low), _lib.ptr(wq), _lib.ptr(out), n, c0, int(cout), hl, wl,
+                                              _lib.stream_ptr(src_low)))
+    return out
+
+
+def conv3x3(src0, wpack, cout, src1=None, mean=None, scale=None, shift=None, up0=False, relu=False, cfg=-1, out=None, addend=None):
+    """act((conv3x3(cat([up2x?(src0), src1], 1), W) + addend - mean) * scale + shift) -- see tnv3_conv3x3_forward(_add)."""
+    lib = _lib.load()
+    _f32(src0, src1, wpack, mean, scale, shift, out, addend)
+    _lib.dev_check(src0, src1, wpack, mean, scale, shift, out, addend)
     n, c0, h0, w0 = (int(v) for v in src0.shape)
     h, w = (2 * h0, 2 * w0) if up0 else (h0, w0)
     c1 = 0
@@ -74,9 +100,11 @@ def conv3x3(src0, wpack, cout, src1=None, mean=None, scale=None, shift=None, up0
         raise _lib.Tnv3Error("conv3x3: wrong output shape")
     if n == 0:
         return out                                   # empty batch: nothing to launch (torch ops accept N = 0 too)
-    _lib.check(lib.tnv3_conv3x3_forward(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(wpack), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(shift),
-                                        _lib.ptr(out), n, c0, c1, cout, h, w, int(bool(up0)), int(bool(relu)), int(cfg),
-                                        _lib.stream_ptr(src0)))
+    if addend is not None and tuple(addend.shape) != (n, cout, h, w):
+        raise _lib.Tnv3Error("conv3x3: addend must have the output's shape")
+    _lib.check(lib.tnv3_conv3x3_forward_add(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(wpack), _lib.ptr(addend), _lib.ptr(mean),
+                                            _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(out), n, c0, c1, cout, h, w, int(bool(up0)),
+                                            int(bool(relu)), int(cfg), _lib.stream_ptr(src0)))
     return out
 
 
