@@ -89,6 +89,14 @@ int tnv3_pack_up2x_weights(const float* w, float* wq, int cout, int cin, int c0,
 int tnv3_conv_up2x_forward(const float* src_low, const float* wq, float* dst, int n, int c0, int cout, int h_low, int w_low,
                            tnv3_stream_t stream);
 
+/* Data gradient of that half-layer (autograd of nn.Upsample(scale_factor=2) -> Conv2d w.r.t. the low-res tensor), also at
+ * the low resolution: dx_low[n][c0][h_low][w_low] = 4x4 stride-2 correlation of dz[n][cout][2*h_low][2*w_low] with the
+ * pre-summed filters g (tnv3_pack_dgrad_up2x_weights from the same nn.Conv2d weight).  Replaces "3x3 data gradient at full
+ * resolution + sum over 2x2 blocks" at 4/9 of the multiply-adds; c0 % 4 == 0. */
+size_t tnv3_dgrad_up2x_packed_floats(int c0, int cout);
+int tnv3_pack_dgrad_up2x_weights(const float* w, float* g, int cout, int cin, int c0, tnv3_stream_t stream);
+int tnv3_dgrad_up2x(const float* dz, const float* g, float* dx_low, int n, int c0, int cout, int h_low, int w_low, tnv3_stream_t stream);
+
 /* ---- head + pooling (model.py:54-55,59,61,63,71-72) ----------------------------------------------------- */
 
 /* y[N][L][HW] = sigmoid?( b[l] + sum_c w[l][c] * x[N][C][HW] ); HW % 4 == 0. */

@@ -118,6 +118,24 @@ def _up2x_case(n, c0, cout, hl, wl, device, c1=16):
     return e_up, ((full.cpu().double() - ref).abs().max() / ref.abs().max()).item()
 
 
+def _dgrad_up2x_case(n, c0, cout, hl, wl, device):
+    """autograd of conv2d(upsample2x(x_low), W[:, :c0]) w.r.t. x_low in fp64 vs ops.dgrad_up2x."""
+    from tracknetv3_amd import ops
+    c0 = (c0 + 3) // 4 * 4
+    xl = T((n, c0, hl, wl), 81).double().requires_grad_(True)
+    w = T((cout, c0 + 8, 3, 3), 82, -0.3, 0.3)
+    dz = T((n, cout, 2 * hl, 2 * wl), 83)
+    up = xl.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    F.conv2d(up, w[:, :c0].double(), padding=1).backward(dz.double())
+    got = ops.dgrad_up2x(dz.to(device), ops.pack_dgrad_up2x_weights(w.to(device), c0), c0)
+    return ((got.cpu().double() - xl.grad).abs().max() / xl.grad.abs().max()).item()
+
+
+@pytest.mark.parametrize("case", UP2X_CASES)
+def test_dgrad_up2x_emulated_vs_autograd(emu, case):
+    assert _dgrad_up2x_case(*case, "cpu") <= 2e-6
+
+
 @pytest.mark.parametrize("case", UP2X_CASES)
 def test_conv_up2x_emulated_vs_torch(emu, case):
     e_up, e_full = _up2x_case(*case, "cpu")

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import GOLDEN
-from test_emu_kernels import UP2X_CASES, _up2x_case
+from test_emu_kernels import UP2X_CASES, _dgrad_up2x_case, _up2x_case
 from oracle import nets, prng
 from test_emu_kernels import CONV_CASES, T, conv_ref
 
@@ -58,6 +58,11 @@ def test_conv_up2x_vs_torch(gpu_device, case):
     n, c0, cout, hl, wl = case
     e_up, e_full = _up2x_case(n, c0, cout, hl, wl, gpu_device, c1=c0 // 2 if c0 >= 64 else 16)
     assert e_up <= 3e-6 and e_full <= 3e-6, (e_up, e_full)
+
+
+@pytest.mark.parametrize("case", UP2X_CASES + [(2, 512, 256, 36, 64), (1, 128, 64, 144, 256), (2, 256, 128, 9, 40)])
+def test_dgrad_up2x_vs_autograd(gpu_device, case):
+    assert _dgrad_up2x_case(*case, gpu_device) <= 3e-6
 
 
 def test_pool_head_pack(gpu_device):

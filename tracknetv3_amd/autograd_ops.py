@@ -168,6 +168,14 @@ class _TrackNetTrain(torch.autograd.Function):
             c0 = int(rec["x0"].shape[1])
             c1 = int(rec["x1"].shape[1]) if rec["x1"] is not None else 0
             n, _, h, w = dz.shape
+            if rec["up"] and c1:
+                # decoder entry: the gradient of the upsampled operand straight at the low resolution (4x4 stride-2
+                # correlation of dZ, 4/9 of the MACs, no full-resolution intermediate), the skip half as a plain 3x3 dgrad
+                g_low, w_skip_t = blk.packed_dgrad_up2x(c0)
+                d_low = ops.dgrad_up2x(dz, g_low, c0)
+                cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))
+                d_skip, _ = ops.conv3x3_dgrad(dz, w_skip_t, c1, 0, cfg=cfg)
+                return d_low, d_skip
             cfg = tuning.conv_config(c0 + c1, blk.conv.out_dim, int(n), int(h), int(w))
             return ops.conv3x3_dgrad(dz, blk.packed_weight(transpose_flip=True), c0, c1, cfg=cfg)
 
@@ -185,12 +193,9 @@ class _TrackNetTrain(torch.autograd.Function):
             return da, d_skip
 
         # up_block_3 (2) -> dUp(128ch, full res), dSkip(x1)
-        d_up, d_x1 = chain_bwd(2, da)
-        da = ops.upsample2x_backward(d_up)
-        d_up, d_x2 = chain_bwd(2, da)                      # up_block_2
-        da = ops.upsample2x_backward(d_up)
-        d_up, d_x3 = chain_bwd(3, da)                      # up_block_1
-        da = ops.upsample2x_backward(d_up)
+        da, d_x1 = chain_bwd(2, da)                        # (the first block of each chain returns the gradient of the
+        da, d_x2 = chain_bwd(2, da)                        # up_block_2      low-resolution operand of nn.Upsample directly)
+        da, d_x3 = chain_bwd(3, da)                        # up_block_1
         d_pool3, _ = chain_bwd(3, da)                      # bottleneck -> gradient of pool(x3)
         da = ops.maxpool2x2_backward_add(x3, d_pool3, d_x3)
         d_pool2, _ = chain_bwd(3, da)                      # down_block_3

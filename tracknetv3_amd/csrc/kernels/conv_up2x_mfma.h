@@ -208,4 +208,194 @@ __global__ void pack_up2x_weights_kernel(const float* __restrict__ w, float* __r
   }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Data gradient of the same half-layer, also at the low resolution.  Transposing
+//     P[co][2i+ph][2j+pw] = sum Wq[cls][ci][a][b][co] * Xlow[ci][i+a+ph-1][j+b+pw-1]
+// gives        dXlow[ci][u][v] = sum_{co} sum_{dr,dc in {-1,0,1,2}} G[co][dr][dc][ci] * dZ[co][2u+dr][2v+dc]
+// with G[co][dr][dc][ci] = Wq[(ph,pw)][ci][a][b][co] for dr = 2 - 2a - ph, dc = 2 - 2b - pw: a 4x4, stride-2 correlation of
+// the full-resolution dZ -- 4/9 of the multiply-adds of "3x3 data gradient at full resolution, then sum the 2x2 blocks"
+// (autograd of nn.Upsample + Conv2d), and the full-resolution gradient of the upsampled tensor is never written.
+// The dZ halo tile is staged de-interleaved by column parity, so the stride-2 B operand is 32 consecutive floats again.
+struct DgradUp2xArgs {
+  const float* dz;      // [N][Cout][2*HL][2*WL]
+  const float* g;       // [Cout_pad][16][C0]   (pack_dgrad_up2x_weights_kernel), Cout_pad = roundup(Cout, CC)
+  float* dst;           // [N][C0][HL][WL]
+  int N, C0, Cout, HL, WL;
+};
+
+template <int MT_, int WM_, int WN_, int NTW_, int CC_>
+struct DgradUp2xCfg {
+  static constexpr int MT = MT_, WM = WM_, WN = WN_, NTW = NTW_, CC = CC_;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int MB = MT * 32 * WM;                // input channels (ci) per workgroup
+  static constexpr int TRL = WN * NTW;                   // low-res output rows per workgroup (32 columns wide)
+  static constexpr int ROWS = 2 * TRL + 2, HALF = 34, ROWF = 2 * HALF, PLANE = ROWS * ROWF;   // dZ tile: [row][parity][34]
+  static constexpr int COLS = 66;                        // full-res columns 2*v0-1 .. 2*v0+64
+  static constexpr int E_IN = CC * ROWS * COLS, NIN = (E_IN + NT - 1) / NT;
+  static constexpr int IN_FLOATS = CC * PLANE;
+  static constexpr int KROWS = CC * 16;
+  static constexpr int W_FLOATS = KROWS * MB, E_W4 = W_FLOATS / 4, NW4 = (E_W4 + NT - 1) / NT;
+  static_assert(E_W4 % NT == 0, "the filter panel must deal evenly");
+  static_assert(CC % 2 == 0, "one MFMA = 2 channels");
+  static constexpr int BUF_FLOATS = W_FLOATS + IN_FLOATS;
+  static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT) dgrad_up2x_mfma_kernel(const DgradUp2xArgs a) {
+  constexpr int MT = Cfg::MT, WN = Cfg::WN, NTW = Cfg::NTW, CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TRL = Cfg::TRL;
+  constexpr int ROWS = Cfg::ROWS, HALF = Cfg::HALF, ROWF = Cfg::ROWF, PLANE = Cfg::PLANE, COLS = Cfg::COLS;
+  constexpr int NIN = Cfg::NIN, NW4 = Cfg::NW4, KROWS = Cfg::KROWS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int half = lane >> 5, bl = lane & 31;
+  const int HL = a.HL, WL = a.WL, C0 = a.C0, Cout = a.Cout;
+  const int H = 2 * HL, W = 2 * WL, HW = H * W;
+  const int tilesH = (HL + TRL - 1) / TRL, tilesW = (WL + 31) / 32;
+  const int nPT = a.N * tilesH * tilesW, nMB = (C0 + MB - 1) / MB;
+  int mb, pt;
+  if (!conv_block_map(blockIdx.x, nMB, nPT, mb, pt)) return;
+  const int n = pt / (tilesH * tilesW);
+  const int trem = pt - n * (tilesH * tilesW);
+  const int u0 = (trem / tilesW) * TRL, v0 = (trem % tilesW) * 32;
+  const int m0 = mb * MB;
+
+  // staging slots: element e of [CC][ROWS][66 full-res columns] -> global offset inside one dZ plane (or -1) and LDS slot
+  int so[NIN], sl[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int e = tid + i * NT;
+    const int c = e / (ROWS * COLS), r = e - c * (ROWS * COLS);
+    const int tr = r / COLS, cc = r - tr * COLS;
+    const int gr = 2 * u0 - 1 + tr, gc = 2 * v0 - 1 + cc;
+    const bool ok = e < Cfg::E_IN && gr >= 0 && gr < H && gc >= 0 && gc < W;
+    so[i] = ok ? gr * W + gc : -1;
+    // cc even -> odd full-res column (plane 1), index cc/2;  cc odd -> even column (plane 0), index (cc-1)/2
+    sl[i] = e < Cfg::E_IN ? (c * PLANE + tr * ROWF + ((cc & 1) ? 0 : HALF) + (cc >> 1)) | (c << 24) : -1;
+  }
+  float rin[NIN];
+  f32x4 rw[NW4];
+  auto load_stage = [&](int k) {
+    const int cbeg = k * CC;
+    const float* base = a.dz + ((size_t)n * Cout + cbeg) * HW;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int c = sl[i] >> 24;
+      const bool ok = so[i] >= 0 && cbeg + c < Cout;
+      rin[i] = base[ok ? (size_t)c * HW + so[i] : 0];
+    }
+    const float* wsrc = a.g + (size_t)k * KROWS * C0 + m0;
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+      const int e4 = tid + i * NT;
+      const int krow = e4 / (MB / 4), m4 = e4 - krow * (MB / 4);
+      const bool ok = m0 + m4 * 4 < C0;                         // C0 % 4 == 0: a 16-byte group is all-in or all-out
+      rw[i] = *reinterpret_cast<const f32x4*>(wsrc + (ok ? (size_t)krow * C0 + m4 * 4 : 0));
+      if (!ok) rw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_stage = [&](int buf, int k) {
+    float* lw = lds + buf * Cfg::BUF_FLOATS;
+    float* li = lw + Cfg::W_FLOATS;
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) *reinterpret_cast<f32x4*>(lw + (tid + i * NT) * 4) = rw[i];
+    const int cbeg = k * CC;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      if (sl[i] >= 0) li[sl[i] & 0xFFFFFF] = (so[i] >= 0 && cbeg + (sl[i] >> 24) < Cout) ? rin[i] : 0.0f;
+    }
+  };
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.0f;
+
+  // tap (dri, dci) = (dr + 1, dc + 1): tile row 2*(u - u0) + dri, plane (dci even -> odd columns: plane 1), index (v - v0) + (dci >> 1)
+  const int a_off = half * 16 * MB + wm * (MT * 32) + bl;
+  const int b_off = Cfg::W_FLOATS + half * PLANE + bl;
+
+  const int nChunks = (Cout + CC - 1) / CC;
+  load_stage(0);
+  store_stage(0, 0);
+  __syncthreads();
+  for (int k = 0; k < nChunks; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < nChunks) load_stage(k + 1);
+    const float* S = lds + buf * Cfg::BUF_FLOATS;
+    constexpr int NSTEP = (CC / 2) * 16;
+    float av[2][MT], bv[2][NTW];
+    auto read_step = [&](int s, float (&ar)[MT], float (&br)[NTW]) {
+      const int cp = s >> 4, tap = s & 15;
+      const int dri = tap >> 2, dci = tap & 3;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) ar[mt] = S[a_off + ((2 * cp) * 16 + tap) * MB + mt * 32];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int ul = wn * NTW + j;                                 // low-res row of this N-tile inside the workgroup tile
+        br[j] = S[b_off + (2 * cp) * PLANE + (2 * ul + dri) * ROWF + ((dci & 1) ? 0 : HALF) + (dci >> 1)];
+      }
+    };
+    read_step(0, av[0], bv[0]);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + 1 < NSTEP) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mt], bv[s & 1][j], acc[mt][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NTW, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);
+    }
+    if (k + 1 < nChunks) store_stage(buf ^ 1, k + 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = m0 + wm * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (ci >= C0) continue;
+      float* dplane = a.dst + ((size_t)n * C0 + ci) * HL * WL;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int u = u0 + wn * NTW + j, v = v0 + bl;
+        if (u < HL && v < WL) dplane[(size_t)u * WL + v] = acc[mt][j][r];
+      }
+    }
+  }
+}
+
+// G[Cout_pad][dri*4+dci][C0] from W[Cout][Cin][3][3] (first C0 input channels): dr = dri - 1 = 2 - 2a - ph, dc likewise.
+__global__ void pack_dgrad_up2x_weights_kernel(const float* __restrict__ w, float* __restrict__ g, int Cout, int Cin, int C0, int CoutPad) {
+  const long total = (long)CoutPad * 16 * C0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(e % C0);
+    const long t = e / C0;
+    const int tap = (int)(t & 15), co = (int)(t >> 4);
+    float v = 0.0f;
+    if (co < Cout) {
+      const int dri = tap >> 2, dci = tap & 3;
+      // dri 0..3  <->  (a, ph) = (1,1), (1,0), (0,1), (0,0);  kernel rows kh in R[ph][a]:  R[0] = {{0},{1,2}},  R[1] = {{0,1},{2}}
+      const int ta = dri < 2 ? 1 : 0, ph = (dri & 1) ? 0 : 1;
+      const int tb = dci < 2 ? 1 : 0, pw = (dci & 1) ? 0 : 1;
+      const int kh0 = ph == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), kh1 = ph == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+      const int kw0 = pw == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kw1 = pw == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+      const float* wk = w + ((long)co * Cin + ci) * 9;
+      for (int kh = kh0; kh <= kh1; ++kh)
+        for (int kw = kw0; kw <= kw1; ++kw) v += wk[kh * 3 + kw];
+    }
+    g[e] = v;
+  }
+}
+
 }  // namespace tnv3

@@ -377,6 +377,31 @@ int conv_up2x_forward_impl(Launcher& L, const float* src, const float* wq, float
   return cout % 128 == 0 ? go(UpA{}) : go(UpB{});
 }
 
+using DUpA = DgradUp2xCfg<2, 2, 4, 1, 2>;    // 128 input channels x (4 x 32) low-res pixels, 512 threads
+inline size_t dgrad_up2x_packed_floats(int c0, int cout) {
+  if (c0 <= 0 || cout <= 0) return 0;
+  return (size_t)round_up(cout, DUpA::CC) * 16 * c0;
+}
+
+template <class Launcher>
+int pack_dgrad_up2x_weights_impl(Launcher& L, const float* w, float* g, int cout, int cin, int c0) {
+  if (!w || !g || cout <= 0 || cin <= 0 || c0 <= 0 || c0 > cin) TNV3_FAIL(-1, "pack_dgrad_up2x_weights: bad argument");
+  const int cpad = round_up(cout, DUpA::CC);
+  const long total = (long)cpad * 16 * c0;
+  return L.launch(pack_dgrad_up2x_weights_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, g, cout, cin, c0, cpad);
+}
+
+template <class Launcher>
+int dgrad_up2x_impl(Launcher& L, const float* dz, const float* g, float* dx_low, int n, int c0, int cout, int hl, int wl) {
+  if (!dz || !g || !dx_low || n <= 0 || c0 <= 0 || cout <= 0 || hl <= 0 || wl <= 0) TNV3_FAIL(-1, "dgrad_up2x: bad argument");
+  if (c0 % 4) TNV3_FAIL(-1, "dgrad_up2x: C0=%d must be a multiple of 4", c0);
+  if (hl >= 4096 || wl >= 4096) TNV3_FAIL(-1, "dgrad_up2x: low-resolution H,W must be < 4096");
+  DgradUp2xArgs a{dz, g, dx_low, n, c0, cout, hl, wl};
+  const long npt = (long)n * ((hl + DUpA::TRL - 1) / DUpA::TRL) * ((wl + 31) / 32);
+  if (npt > (1l << 28)) TNV3_FAIL(-1, "dgrad_up2x: too many pixel tiles");
+  return L.launch(dgrad_up2x_mfma_kernel<DUpA>, conv_grid_blocks((c0 + DUpA::MB - 1) / DUpA::MB, (int)npt), DUpA::NT, a);
+}
+
 template <class Launcher>
 int conv3x3_dgrad_impl(Launcher& L, const float* dz, const float* wpack_t, float* dx0, float* dx1, int n, int cout, int c0,
                        int c1, int h, int w, int cfg) {

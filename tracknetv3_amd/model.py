@@ -79,6 +79,18 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
+    def packed_dgrad_up2x(self, c0):
+        """(4x4 stride-2 filters of the low-resolution data gradient w.r.t. the first c0 inputs, transposed / flipped 3x3
+        filter of the remaining skip channels): the backward twins of packed_up2x."""
+        key = ("dup2x", int(c0))
+        ver = self._versions(["conv"])
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            w = self.conv.weight.detach()
+            hit = (ver, (ops.pack_dgrad_up2x_weights(w, c0), ops.pack_conv3x3_weights(w[:, c0:].contiguous(), transpose_flip=True)))
+            self._cache[key] = hit
+        return hit[1]
+
     def conv_up_skip(self, x_low, skip, n, relu, affine):
         """conv3x3(cat([upsample2x(x_low), skip], 1)) with the upsampled half computed at the low resolution."""
         c0, c1 = int(x_low.shape[1]), int(skip.shape[1])

@@ -79,6 +79,31 @@ def conv_up2x(src_low, wq, cout):
     return out
 
 
+def pack_dgrad_up2x_weights(weight, c0):
+    """nn.Conv2d weight (Cout, Cin, 3, 3) -> the 4x4 stride-2 filters of the low-resolution data gradient (first c0 inputs)."""
+    lib = _lib.load()
+    _f32(weight)
+    _lib.dev_check(weight)
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    g = torch.empty(lib.tnv3_dgrad_up2x_packed_floats(int(c0), cout), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.tnv3_pack_dgrad_up2x_weights(_lib.ptr(weight), _lib.ptr(g), cout, cin, int(c0), _lib.stream_ptr(weight)))
+    return g
+
+
+def dgrad_up2x(dz, g, c0):
+    """Gradient w.r.t. the low-res operand of nn.Upsample(2) -> conv3x3, straight at the low resolution (tnv3_dgrad_up2x)."""
+    lib = _lib.load()
+    _f32(dz, g)
+    _lib.dev_check(dz, g)
+    n, cout, h, w = (int(v) for v in dz.shape)
+    if (h | w) & 1 or g.numel() != lib.tnv3_dgrad_up2x_packed_floats(int(c0), cout):
+        raise _lib.Tnv3Error("dgrad_up2x: odd output size or filter buffer / channel mismatch")
+    out = torch.empty((n, int(c0), h // 2, w // 2), dtype=torch.float32, device=dz.device)
+    if n:
+        _lib.check(lib.tnv3_dgrad_up2x(_lib.ptr(dz), _lib.ptr(g), _lib.ptr(out), n, int(c0), cout, h // 2, w // 2, _lib.stream_ptr(dz)))
+    return out
+
+
 def conv3x3(src0, wpack, cout, src1=None, mean=None, scale=None, shift=None, up0=False, relu=False, cfg=-1, out=None, addend=None):
     """act((conv3x3(cat([up2x?(src0), src1], 1), W) + addend - mean) * scale + shift) -- see tnv3_conv3x3_forward(_add)."""
     lib = _lib.load()
