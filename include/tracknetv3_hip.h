@@ -97,6 +97,15 @@ size_t tnv3_dgrad_up2x_packed_floats(int c0, int cout);
 int tnv3_pack_dgrad_up2x_weights(const float* w, float* g, int cout, int cin, int c0, tnv3_stream_t stream);
 int tnv3_dgrad_up2x(const float* dz, const float* g, float* dx_low, int n, int c0, int cout, int h_low, int w_low, tnv3_stream_t stream);
 
+/* Weight gradient of a whole decoder-entry layer, dw[cout][c0+c1][3][3] for the nn.Conv2d applied to
+ * cat([Upsample(2)(x_low), skip], dim=1): the c0 upsampled channels through the four parity images of dz and 2x2 tap
+ * windows against x_low (16 instead of 36 taps per low-res pixel), the c1 skip channels as an ordinary 3x3 weight gradient.
+ *   x_low [n][c0][h_low][w_low], skip [n][c1][2*h_low][2*w_low], dz [n][cout][2*h_low][2*w_low];  w_low % 4 == 0.
+ * Deterministic (split-K slabs reduced in a fixed order); workspace from the _workspace_bytes query, 16-byte aligned. */
+size_t tnv3_conv3x3_wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int h_low, int w_low);
+int tnv3_conv3x3_wgrad_up2x(const float* x_low, const float* skip, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
+                            int n, int c0, int c1, int cout, int h_low, int w_low, tnv3_stream_t stream);
+
 /* ---- head + pooling (model.py:54-55,59,61,63,71-72) ----------------------------------------------------- */
 
 /* y[N][L][HW] = sigmoid?( b[l] + sum_c w[l][c] * x[N][C][HW] ); HW % 4 == 0. */

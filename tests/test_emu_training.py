@@ -76,6 +76,29 @@ def _wgrad_case(case, ops):
             assert rel_err(dx1, xd.grad[:, c0:]) <= 2e-6
 
 
+WGRAD_UP2X_CASES = [(1, 8, 16, 64, 4, 20), (2, 32, 32, 128, 3, 36), (1, 64, 32, 64, 6, 32)]   # (n, c0, c1, cout, h_low, w_low)
+
+
+def _wgrad_up2x_case(case, device):
+    from tracknetv3_amd import ops
+    n, c0, c1, cout, hl, wl = case
+    xl, skip = T((n, c0, hl, wl), 31), T((n, c1, 2 * hl, 2 * wl), 32)
+    dz = T((n, cout, 2 * hl, 2 * wl), 33)
+    wd = T((cout, c0 + c1, 3, 3), 34, -0.3, 0.3).double().requires_grad_(True)
+    x = torch.cat([xl.repeat_interleave(2, 2).repeat_interleave(2, 3), skip], 1)
+    F.conv2d(x.double(), wd, padding=1).backward(dz.double())
+    dw = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device))
+    dw2 = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device))
+    assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
+    return rel_err(dw.cpu(), wd.grad), rel_err(dw.cpu()[:, :c0], wd.grad[:, :c0])
+
+
+@pytest.mark.parametrize("case", WGRAD_UP2X_CASES)
+def test_wgrad_up2x_emulated_vs_autograd(emu, case):
+    e_all, e_up = _wgrad_up2x_case(case, "cpu")
+    assert e_all <= 3e-6 and e_up <= 3e-6, (e_all, e_up)
+
+
 def test_dgrad_split_destinations_emulated(emu):
     from tracknetv3_amd import ops
     n, c0, c1, cout, h, w = 1, 128, 64, 64, 4, 8          # shapes of up_block_3.conv_1's data gradient

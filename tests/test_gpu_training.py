@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from conftest import GOLDEN
 from oracle import nets
-from test_emu_training import T, rel_err
+from test_emu_training import T, WGRAD_UP2X_CASES, _wgrad_up2x_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,12 @@ def _wgrad_case(case, ops, d):
         assert rel_err(dx0.cpu(), xd.grad[:, :c0]) <= 3e-6
         if c1:
             assert rel_err(dx1.cpu(), xd.grad[:, c0:]) <= 3e-6
+
+
+@pytest.mark.parametrize("case", WGRAD_UP2X_CASES + [(2, 512, 256, 256, 8, 32), (1, 128, 64, 64, 32, 64)])
+def test_wgrad_up2x_vs_autograd(gpu_device, case):
+    e_all, e_up = _wgrad_up2x_case(case, gpu_device)
+    assert e_all <= 3e-6 and e_up <= 3e-6, (e_all, e_up)
 
 
 def test_wbce_head_pool_upsample_mixup(gpu_device):

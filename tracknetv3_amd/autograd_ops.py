@@ -151,15 +151,20 @@ class _TrackNetTrain(torch.autograd.Function):
             dz, dgamma, dbeta = ops.bn_relu_backward(da, rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"], rec["invstd"])
             done(blk.bn.weight, dgamma)
             done(blk.bn.bias, dbeta)
+            def wgrad():
+                if rec["up"] and rec["x1"] is not None:       # decoder entry: upsampled channels at the low resolution
+                    return ops.conv3x3_wgrad_up2x(rec["x0"], rec["x1"], dz)
+                return ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
+
             if side is None:
-                dw = ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
+                dw = wgrad()
                 done(blk.conv.weight, dw)
             else:
                 ready = torch.cuda.Event()
                 ready.record(main)                                   # dZ (and, first time round, the activations) are final
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    dw = ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
+                    dw = wgrad()
                     done(blk.conv.weight, dw)                        # the hook's bucket copy is ordered on the side stream
                 keep.append(dz)      # read by the side stream: stays alive until the main stream has joined it (below), so the
                                      # allocator can never hand its memory to later main-stream work too early

@@ -398,4 +398,61 @@ __global__ void pack_dgrad_up2x_weights_kernel(const float* __restrict__ w, floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the half-layer at the low resolution:
+//     D[co][ci][dr][dc] = sum_{n,u,v} dZ[co][2u+dr][2v+dc] * Xlow[ci][u][v],   dr, dc in {-1, 0, 1, 2}
+// (16 taps per low-res pixel instead of the 36 of "3x3 weight gradient over the upsampled tensor"), folded back with
+//     dW[co][ci][kh][kw] = sum_{dr in S(kh)} sum_{dc in S(kw)} D[co][ci][dr][dc],   S(0) = {2, 1}, S(1) = {0, 1}, S(2) = {0, -1}.
+// dZ is first split into its four parity images Z[pr][pc][..][i][j] = dZ[..][2i+pr][2j+pc] (one HBM pass); against the image
+// (pr, pc) the taps dr = 2 - pr - 2*th, dc = 2 - pc - 2*tw (th, tw in {0, 1}) are the 2x2 window (kh0, kw0) = (pr, pc) of an
+// ordinary 3x3 weight gradient of (Xlow, Z[pr][pc]) -- wgrad3x3_mfma_kernel<WgradCfg<.., NTAP = 4>>.
+
+// zp[(pr*2+pc)][plane][i][j] = dz[plane][2i+pr][2j+pc];  planes = N*Cout, W % 4 == 0
+__global__ void __launch_bounds__(256) space_to_depth2_kernel(const float* __restrict__ dz, float* __restrict__ zp, long planes, int H, int W) {
+  typedef float s2d_f2 __attribute__((ext_vector_type(2)));
+  const int HL = H >> 1, WL = W >> 1, W4 = W >> 2;
+  const long total = planes * H * W4;
+  const size_t img = (size_t)planes * HL * WL;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(t % W4);
+    const long u = t / W4;
+    const int h = (int)(u % H);
+    const long pl = u / H;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(dz + ((size_t)pl * H + h) * W + 4 * q);
+    const size_t o = ((size_t)pl * HL + (h >> 1)) * WL + 2 * q;
+    s2d_f2 e, d; e[0] = v[0]; e[1] = v[2]; d[0] = v[1]; d[1] = v[3];
+    *reinterpret_cast<s2d_f2*>(zp + ((h & 1) * 2 + 0) * img + o) = e;
+    *reinterpret_cast<s2d_f2*>(zp + ((h & 1) * 2 + 1) * img + o) = d;
+  }
+}
+
+// dW[Cout][C0+C1][3][3]: channels < C0 folded from D4[img = pr*2+pc][Cout][C0][th*2+tw], the rest copied from dw_skip[Cout][C1][9]
+__global__ void __launch_bounds__(256) wgrad_up2x_assemble_kernel(const float* __restrict__ d4, const float* __restrict__ dw_skip,
+                                                                  float* __restrict__ dw, int Cout, int C0, int C1) {
+  const int Cin = C0 + C1;
+  const long total = (long)Cout * Cin * 9;
+  const size_t img = (size_t)Cout * C0 * 4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(e % 9);
+    const long t = e / 9;
+    const int ci = (int)(t % Cin), co = (int)(t / Cin);
+    float v;
+    if (ci >= C0) {
+      v = dw_skip[((size_t)co * C1 + (ci - C0)) * 9 + tap];
+    } else {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      // S(k) as (parity image index p, window tap t) pairs: dr = 2 -> (0,0), 0 -> (0,1), 1 -> (1,0), -1 -> (1,1)
+      const int rp[2] = {kh == 0 ? 0 : (kh == 1 ? 0 : 0), kh == 0 ? 1 : (kh == 1 ? 1 : 1)};
+      const int rt[2] = {kh == 0 ? 0 : (kh == 1 ? 1 : 1), kh == 0 ? 0 : (kh == 1 ? 0 : 1)};
+      const int cp[2] = {0, 1};
+      const int ct[2] = {kw == 0 ? 0 : 1, kw == 0 ? 0 : (kw == 1 ? 0 : 1)};
+      v = 0.0f;
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+          v += d4[(size_t)(rp[i] * 2 + cp[j]) * img + ((size_t)co * C0 + ci) * 4 + rt[i] * 2 + ct[j]];
+    }
+    dw[e] = v;
+  }
+}
+
 }  // namespace tnv3

@@ -28,11 +28,15 @@ struct WgradArgs {
   float* part;         // [splitK][Cout][C0+C1][9]
   int N, C0, C1, Cout, H, W, up0, splitK;
   const float* zeros;  // >= 64 zero floats (source of the padding for the LDS-DMA kernel)
+  int kh0, kw0;        // WgradCfg<..., NTAP = 4> only: the 2x2 subset of taps {kh0, kh0+1} x {kw0, kw0+1} (slab [..][4])
 };
 
-template <int WM_, int WC_, int TR_ = 4, int TC_ = 32>
+template <int WM_, int WC_, int TR_ = 4, int TC_ = 32, int NTAP_ = 9>
 struct WgradCfg {
   static constexpr int WM = WM_, WC = WC_, TR = TR_, TC = TC_;
+  static constexpr int NTAP = NTAP_, TSIDE = NTAP_ == 9 ? 3 : 2;   // 9: the 3x3 filter; 4: a 2x2 window of it at (kh0, kw0) --
+                                                                  // the per-parity pieces of a decoder-entry layer's low-res wgrad
+  static_assert(NTAP_ == 9 || NTAP_ == 4, "tap sets");
   static constexpr int NT = WM * WC * 64;
   static constexpr int MB = WM * 32, CB = WC * 32;
   static constexpr int PIX = TR * TC, PIXP = PIX + 1;
@@ -133,14 +137,15 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
     }
   };
 
-  f32x16 acc[9];
+  constexpr int NTAP = Cfg::NTAP, TSIDE = Cfg::TSIDE;
+  f32x16 acc[NTAP];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   const int a_off = (wm * 32 + bl) * PIXP + half;
-  const int b_off = (wc * 32 + bl) * PLANEP + half;
+  const int b_off = (wc * 32 + bl) * PLANEP + half + (NTAP == 9 ? 0 : a.kh0 * TCp + a.kw0);
 
   if (ks < nTiles) load_tile(ks);
   for (int tile = ks; tile < nTiles; tile += a.splitK) {
@@ -156,11 +161,11 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
     // compile time) and the operand pipeline is carried across it: the last step of row r prefetches step 0 of row r+1.
     constexpr int NSTEP = TC / 2;
     static_assert(NSTEP % 2 == 0, "ring slot of the carried prefetch");
-    float av[2], bv[2][9];
-    auto read_step = [&](int r, int s, float& ar, float (&br)[9]) {
+    float av[2], bv[2][NTAP];
+    auto read_step = [&](int r, int s, float& ar, float (&br)[NTAP]) {
       ar = A[r * TC + 2 * s];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) br[tap] = B[(r + tap / 3) * TCp + 2 * s + (tap % 3)];
+      for (int tap = 0; tap < NTAP; ++tap) br[tap] = B[(r + tap / TSIDE) * TCp + 2 * s + (tap % TSIDE)];
     };
     read_step(0, 0, av[0], bv[0]);
 #pragma unroll 1
@@ -170,23 +175,23 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad3x3_mfma_kernel(const WgradArgs 
         if (s + 1 < NSTEP) read_step(r, s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
         else if (r + 1 < TR) read_step(r + 1, 0, av[0], bv[0]);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < NTAP; ++tap)
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][tap], acc[tap], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // DS reads of the next step
-        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);    // MFMAs of step s
+        __builtin_amdgcn_sched_group_barrier(0x100, NTAP + 1, 0);   // DS reads of the next step
+        __builtin_amdgcn_sched_group_barrier(0x008, NTAP, 0);       // MFMAs of step s
       }
     }
   }
 
   // ---- partial slab: part[ks][co][ci][tap]
-  float* slab = a.part + (size_t)ks * Cout * Cin * 9;
+  float* slab = a.part + (size_t)ks * Cout * Cin * NTAP;
   const int ci = ci0 + wc * 32 + bl;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
     if (co < Cout && ci < Cin) {
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) slab[((size_t)co * Cin + ci) * 9 + tap] = acc[tap][r];
+      for (int tap = 0; tap < NTAP; ++tap) slab[((size_t)co * Cin + ci) * NTAP + tap] = acc[tap][r];
     }
   }
 }

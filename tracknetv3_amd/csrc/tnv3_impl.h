@@ -474,7 +474,7 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
   if (((uintptr_t)ws) & 15) TNV3_FAIL(-1, "conv3x3_wgrad: workspace must be 16-byte aligned");
   float* slabs = (float*)((char*)ws + kWgradZeroBytes);
-  WgradArgs a{src0, src1, dz, slabs, n, c0, c1, cout, h, w, up0 ? 1 : 0, p.splitK, (const float*)ws};
+  WgradArgs a{src0, src1, dz, slabs, n, c0, c1, cout, h, w, up0 ? 1 : 0, p.splitK, (const float*)ws, 0, 0};
   const int grid = p.nMB * p.nCB * p.splitK;
   int rc;
   if (wgrad_variant() == 1) {
@@ -488,6 +488,70 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   if ((nel & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dw) & 15) == 0)
     return L.launch(sum_partials_vec4_kernel, grid_for(nel / 4, 256, 8192), 256, (const float*)slabs, dw, nel / 4, p.splitK);
   return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)slabs, dw, nel, p.splitK);
+}
+
+// ---- decoder-entry layer: weight gradient with the upsampled channels evaluated at the low resolution (conv_up2x_mfma.h)
+using WgradA4 = WgradCfg<4, 1, 4, 32, 4>;   // the same blocks with a 2x2 tap window (36 -> 16 taps per low-res pixel overall)
+using WgradB4 = WgradCfg<2, 2, 4, 32, 4>;
+struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; };
+inline size_t align16f(size_t floats) { return (floats + 3) / 4 * 4; }
+inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, int wl) {
+  WgradUpLayout l;
+  const int saved = wgrad_variant();
+  wgrad_variant() = 0;                                   // both halves use the register-staged family (4-row tiles)
+  l.up = wgrad_plan(n, c0, cout, hl, wl);
+  l.skip = wgrad_plan(n, c1, cout, 2 * hl, 2 * wl);
+  wgrad_variant() = saved;
+  size_t off = kWgradZeroBytes / 4;
+  l.zp = off;      off += align16f((size_t)4 * n * cout * hl * wl);
+  l.d4 = off;      off += align16f((size_t)4 * cout * c0 * 4);
+  l.dwskip = off;  off += align16f((size_t)cout * c1 * 9);
+  const size_t s_up = (size_t)l.up.splitK * cout * c0 * 4, s_skip = (size_t)l.skip.splitK * cout * c1 * 9;
+  l.slabs = off;   off += align16f(s_up > s_skip ? s_up : s_skip);
+  l.total = off * sizeof(float);
+  return l;
+}
+inline size_t wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int hl, int wl) {
+  if (n <= 0 || c0 <= 0 || c1 <= 0 || cout <= 0 || hl <= 0 || wl <= 0) return 0;
+  return wgrad_up2x_layout(n, c0, c1, cout, hl, wl).total;
+}
+
+template <class Launcher>
+int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, const float* dz, float* dw, void* ws, size_t ws_bytes,
+                            int n, int c0, int c1, int cout, int hl, int wl) {
+  if (!x_low || !skip || !dz || !dw || !ws || n <= 0 || c0 <= 0 || c1 <= 0 || cout <= 0 || hl <= 0 || wl <= 0)
+    TNV3_FAIL(-1, "conv3x3_wgrad_up2x: bad argument");
+  if (wl % 4) TNV3_FAIL(-1, "conv3x3_wgrad_up2x: the low-resolution width must be a multiple of 4");
+  if ((long)cout * 4 * hl * wl >= (1l << 31) || (long)(c0 > c1 ? c0 : c1) * 4 * hl * wl >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_up2x: sample too large");
+  if (((uintptr_t)ws) & 15) TNV3_FAIL(-1, "conv3x3_wgrad_up2x: workspace must be 16-byte aligned");
+  const WgradUpLayout l = wgrad_up2x_layout(n, c0, c1, cout, hl, wl);
+  if (ws_bytes < l.total) TNV3_FAIL(-1, "conv3x3_wgrad_up2x: workspace too small");
+  float* base = (float*)ws;
+  float *zp = base + l.zp, *d4 = base + l.d4, *dwskip = base + l.dwskip, *slabs = base + l.slabs;
+  const int h = 2 * hl, w = 2 * wl;
+  int rc;
+  const long s2d_items = (long)n * cout * h * (w / 4);
+  if ((rc = L.launch(space_to_depth2_kernel, grid_for(s2d_items, 256, 32768), 256, dz, zp, (long)n * cout, h, w))) return rc;
+  auto reduce = [&](float* out, long nel, int parts) -> int {
+    if ((nel & 3) == 0) return L.launch(sum_partials_vec4_kernel, grid_for(nel / 4, 256, 8192), 256, (const float*)slabs, out, nel / 4, parts);
+    return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)slabs, out, nel, parts);
+  };
+  const size_t img = (size_t)n * cout * hl * wl;
+  for (int im = 0; im < 4; ++im) {                              // parity image (pr, pc) = (im >> 1, im & 1): 2x2 window at (pr, pc)
+    WgradArgs a{x_low, (const float*)nullptr, zp + im * img, slabs, n, c0, 0, cout, hl, wl, 0, l.up.splitK, (const float*)ws, im >> 1, im & 1};
+    const int grid = l.up.nMB * l.up.nCB * l.up.splitK;
+    rc = l.up.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB4>, grid, WgradB4::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA4>, grid, WgradA4::NT, a);
+    if (rc) return rc;
+    if ((rc = reduce(d4 + (size_t)im * cout * c0 * 4, (long)cout * c0 * 4, l.up.splitK))) return rc;
+  }
+  {
+    WgradArgs a{skip, (const float*)nullptr, dz, slabs, n, c1, 0, cout, h, w, 0, l.skip.splitK, (const float*)ws, 0, 0};
+    const int grid = l.skip.nMB * l.skip.nCB * l.skip.splitK;
+    rc = l.skip.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB>, grid, WgradB::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA>, grid, WgradA::NT, a);
+    if (rc) return rc;
+    if ((rc = reduce(dwskip, (long)cout * c1 * 9, l.skip.splitK))) return rc;
+  }
+  return L.launch(wgrad_up2x_assemble_kernel, grid_for((long)cout * (c0 + c1) * 9, 256, 8192), 256, (const float*)d4, (const float*)dwskip, dw, cout, c0, c1);
 }
 
 inline size_t wbce_workspace_bytes(int n) { return n <= 0 ? 0 : (size_t)n * kRedSplit * sizeof(double); }

@@ -320,6 +320,23 @@ def conv3x3_wgrad(src0, dz, src1=None, up0=False):
     return dw
 
 
+def conv3x3_wgrad_up2x(x_low, skip, dz):
+    """dW[Cout][C0+C1][3][3] of a decoder-entry layer (X = cat([upsample2x(x_low), skip], 1)), its upsampled channels at the
+    low resolution -- see tnv3_conv3x3_wgrad_up2x."""
+    lib = _lib.load()
+    _f32(x_low, skip, dz)
+    _lib.dev_check(x_low, skip, dz)
+    n, cout, h, w = (int(v) for v in dz.shape)
+    c0, c1 = int(x_low.shape[1]), int(skip.shape[1])
+    if tuple(x_low.shape[2:]) != (h // 2, w // 2) or tuple(skip.shape[2:]) != (h, w):
+        raise _lib.Tnv3Error("conv3x3_wgrad_up2x: x_low must be half the size of skip / dz")
+    dw = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dz.device)
+    ws = _workspace(lib.tnv3_conv3x3_wgrad_up2x_workspace_bytes(n, c0, c1, cout, h // 2, w // 2), dz.device)
+    _lib.check(lib.tnv3_conv3x3_wgrad_up2x(_lib.ptr(x_low), _lib.ptr(skip), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8,
+                                           n, c0, c1, cout, h // 2, w // 2, _lib.stream_ptr(dz)))
+    return dw
+
+
 def wbce_forward(p, y, reduce=True):
     lib = _lib.load()
     _f32(p, y)
