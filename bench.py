@@ -140,6 +140,9 @@ def cpu_baseline(budget_s=25.0):
 
 
 TRAIN_FLOPS_PER_SAMPLE = 678.2e9    # fwd + dgrad + wgrad (no dgrad for the first layer)
+# what the matrix pipe executes: the upsampled halves of up_block_{1,2,3}.conv_1 (2*9*C0*Cout*H*W = 21.74 GFLOP each per sample)
+# cost 4/9 in each of the three passes
+TRAIN_FLOPS_EXECUTED_PER_SAMPLE = TRAIN_FLOPS_PER_SAMPLE - 3 * 3 * (5.0 / 9.0) * 2 * 9 * 512 * 256 * 72 * 128
 
 
 def bench_train(args, dev, rank, world):
@@ -188,7 +191,10 @@ def bench_train(args, dev, rank, world):
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "whole step (conv fwd + dgrad + wgrad MFMA kernels + HBM-bound BN/pool/head passes)"},
+                         "kernel": "whole step (conv fwd + dgrad + wgrad MFMA kernels + HBM-bound BN/pool/head passes)",
+                         "executed_tflops": round(TRAIN_FLOPS_EXECUTED_PER_SAMPLE * args.batch / (ms * 1e-3) / 1e12, 2),
+                         "note": "`achieved` counts the reference's algorithmic FLOPs (SURVEY 8d); the upsampled channels of the three "
+                                 "decoder-entry layers are evaluated at the low resolution in forward, dgrad and wgrad (4/9 of those MACs)"},
             "cpu_baseline": None, "final_loss": round(float(loss.item()), 6)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
