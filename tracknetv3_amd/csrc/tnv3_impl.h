@@ -424,10 +424,11 @@ inline int& wgrad_variant() { static int v = 0; return v; }
 constexpr size_t kWgradZeroBytes = 1024;     // zero prefix of the workspace: padding source of the LDS-DMA kernels
 
 struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
-inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w) {
+// cb_a: ci per workgroup of the 128-channel configuration in use (WgradA: 32; the 2x2-window WgradA4: 64)
+inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w, int cb_a = 32) {
   WgradPlan p;
   p.use_b = (cout % 128) != 0;
-  const int MB = p.use_b ? WgradB::MB : WgradA::MB, CB = p.use_b ? WgradB::CB : WgradA::CB;
+  const int MB = p.use_b ? WgradB::MB : WgradA::MB, CB = p.use_b ? WgradB::CB : cb_a;
   p.nMB = (cout + MB - 1) / MB;
   p.nCB = (cin + CB - 1) / CB;
   const int TR = wgrad_variant() == 1 ? WgradDmaA::TR : (p.use_b ? WgradB::TR : WgradA::TR);
@@ -491,7 +492,8 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
 }
 
 // ---- decoder-entry layer: weight gradient with the upsampled channels evaluated at the low resolution (conv_up2x_mfma.h)
-using WgradA4 = WgradCfg<4, 1, 4, 32, 4>;   // the same blocks with a 2x2 tap window (36 -> 16 taps per low-res pixel overall)
+using WgradA4 = WgradCfg<4, 2, 4, 32, 4>;   // 2x2 tap window: 128 co x 64 ci, 8 waves (4 taps reuse a staged tile less than 9 do,
+                                            // so the ci block is doubled to keep the flops per staged byte)
 using WgradB4 = WgradCfg<2, 2, 4, 32, 4>;
 struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; };
 inline size_t align16f(size_t floats) { return (floats + 3) / 4 * 4; }
@@ -499,7 +501,7 @@ inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, 
   WgradUpLayout l;
   const int saved = wgrad_variant();
   wgrad_variant() = 0;                                   // both halves use the register-staged family (4-row tiles)
-  l.up = wgrad_plan(n, c0, cout, hl, wl);
+  l.up = wgrad_plan(n, c0, cout, hl, wl, WgradA4::CB);
   l.skip = wgrad_plan(n, c1, cout, 2 * hl, 2 * wl);
   wgrad_variant() = saved;
   size_t off = kWgradZeroBytes / 4;
