@@ -326,6 +326,21 @@ __global__ void __launch_bounds__(256) sum_partials_strided_kernel(const float* 
   }
 }
 
+// The same strided sum for FEW outputs and MANY parts (head dW/db: 520 outputs x 1024 workgroup partials): one wave per
+// output, lane l adds parts l, l+64, ... in order, then the 64 lane sums are folded in lane order -- a fixed summation
+// tree, so the result is deterministic (it differs from the serial order above only in association).
+__global__ void __launch_bounds__(256) sum_partials_wave_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+                                                                int nparts, long stride, long offset) {
+  const int lane = threadIdx.x & 63;
+  const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= n) return;                                      // whole wave leaves together
+  double s = 0.0;
+  for (int b = lane; b < nparts; b += 64) s += (double)part[(size_t)b * stride + offset + o];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  if (lane == 0) out[o] = (float)s;
+}
+
 // ---- pooling / upsampling backward ------------------------------------------------------------------------------
 // dx = dskip + route(dpool): the FIRST maximum of each 2x2 window (row-major, strict '>') receives the pooled gradient.
 __global__ void __launch_bounds__(256) maxpool2x2_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dpool,

@@ -593,8 +593,8 @@ int head_backward_impl(Launcher& L, const float* dp, const float* p, const float
   // partial layout per workgroup: [L*64 dW | L db]; dW and db are contiguous slices of one reduction
   const long nel = (long)l * kHeadC + l;
   // reduce into a temporary tail of the workspace is avoided: sum directly into dw / db with two launches
-  if ((rc = L.launch(sum_partials_strided_kernel, grid_for((long)l * kHeadC, 256, 64), 256, (const float*)ws, dw, (long)l * kHeadC, grid, nel, 0l))) return rc;
-  return L.launch(sum_partials_strided_kernel, 1, 64, (const float*)ws, db, (long)l, grid, nel, (long)l * kHeadC);
+  if ((rc = L.launch(sum_partials_wave_kernel, (int)(((long)l * kHeadC + 3) / 4), 256, (const float*)ws, dw, (long)l * kHeadC, grid, nel, 0l))) return rc;
+  return L.launch(sum_partials_wave_kernel, (l + 3) / 4, 256, (const float*)ws, db, (long)l, grid, nel, (long)l * kHeadC);
 }
 
 template <class Launcher>
