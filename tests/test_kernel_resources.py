@@ -57,6 +57,12 @@ def test_conv_and_wgrad_budgets(resources):
                       ("Li2ELi1ELi2ELi4ELi4ELi32ELi4ELi1ELi1ELi0ELi0ELi0E", 6)):    # cfg 9
         k = _find(resources, cfg + args)
         assert k["Occupancy [waves/SIMD]"] >= occ, (args, k)
-    for args in ("WgradCfgILi4ELi1ELi4ELi32E", "WgradCfgILi2ELi2ELi4ELi32E"):
+    for args in ("WgradCfgILi4ELi1ELi4ELi32ELi9E", "WgradCfgILi2ELi2ELi4ELi32ELi9E", "WgradCfgILi2ELi2ELi4ELi32ELi4E"):
         k = _find(resources, "wgrad3x3_mfma_kernel", args)
         assert k["VGPRs"] + k.get("AGPRs", 0) <= 512 and k["Occupancy [waves/SIMD]"] >= 1
+    k = _find(resources, "wgrad3x3_mfma_kernel", "WgradCfgILi4ELi2ELi4ELi32ELi4E")        # 2x2-window, 8 waves: two per SIMD
+    assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs Spill"] == 0
+    for name, occ in (("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi2ELi4ELi2ELi4E", 4), ("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi1ELi4ELi2ELi4E", 4),
+                      ("dgrad_up2x_mfma_kernelINS_12DgradUp2xCfgILi2ELi2ELi4ELi1ELi2E", 4)):
+        k = _find(resources, name)
+        assert k["Occupancy [waves/SIMD]"] >= occ and k["VGPRs Spill"] == 0, (name, k)
