@@ -87,7 +87,7 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
 size_t tnv3_conv_up2x_packed_floats(int c0, int cout);
 int tnv3_pack_up2x_weights(const float* w, float* wq, int cout, int cin, int c0, tnv3_stream_t stream);
 int tnv3_conv_up2x_forward(const float* src_low, const float* wq, float* dst, int n, int c0, int cout, int h_low, int w_low,
-                           tnv3_stream_t stream);
+                           int cfg /* tile configuration 0..3, -1 = library default */, tnv3_stream_t stream);
 
 /* Data gradient of that half-layer (autograd of nn.Upsample(scale_factor=2) -> Conv2d w.r.t. the low-res tensor), also at
  * the low resolution: dx_low[n][c0][h_low][w_low] = 4x4 stride-2 correlation of dz[n][cout][2*h_low][2*w_low] with the

@@ -103,7 +103,7 @@ def test_bn_scale_pool_head_emulated(emu):
 UP2X_CASES = [(1, 8, 64, 4, 20), (2, 12, 128, 3, 34), (1, 32, 64, 5, 33), (1, 6, 128, 2, 8)]   # (n, c0, cout, h_low, w_low)
 
 
-def _up2x_case(n, c0, cout, hl, wl, device, c1=16):
+def _up2x_case(n, c0, cout, hl, wl, device, c1=16, cfg=-1):
     """Decoder-entry layer two ways: upsample + concat + 3x3 conv in fp64 torch vs conv_up2x (low-res half) + conv3x3(skip, addend)."""
     from tracknetv3_amd import ops
     xl = T((n, c0, hl, wl), 71)
@@ -112,7 +112,7 @@ def _up2x_case(n, c0, cout, hl, wl, device, c1=16):
     up = xl.repeat_interleave(2, 2).repeat_interleave(2, 3)
     ref_up = F.conv2d(up.double(), w[:, :c0].double(), padding=1)
     ref = F.conv2d(torch.cat([up, skip], 1).double(), w.double(), padding=1)
-    part = ops.conv_up2x(xl.to(device), ops.pack_up2x_weights(w.to(device), c0), cout)
+    part = ops.conv_up2x(xl.to(device), ops.pack_up2x_weights(w.to(device), c0), cout, cfg=cfg)
     e_up = ((part.cpu().double() - ref_up).abs().max() / ref_up.abs().max()).item()          # relative to the output scale
     full = ops.conv3x3(skip.to(device), ops.pack_conv3x3_weights(w[:, c0:].contiguous().to(device)), cout, addend=part)
     return e_up, ((full.cpu().double() - ref).abs().max() / ref.abs().max()).item()
@@ -139,6 +139,12 @@ def test_dgrad_up2x_emulated_vs_autograd(emu, case):
 @pytest.mark.parametrize("case", UP2X_CASES)
 def test_conv_up2x_emulated_vs_torch(emu, case):
     e_up, e_full = _up2x_case(*case, "cpu")
+    assert e_up <= 2e-6 and e_full <= 2e-6, (e_up, e_full)
+
+
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_conv_up2x_big_tile_configs_emulated(emu, cfg):
+    e_up, e_full = _up2x_case(1, 8, 128, 5, 36, "cpu", cfg=cfg)       # 8-row tiles: ragged in both directions
     assert e_up <= 2e-6 and e_full <= 2e-6, (e_up, e_full)
 
 

@@ -40,7 +40,7 @@ def _declare(lib):
     sig("tnv3_conv3x3_forward_add", i, p, p, p, p, p, p, p, p, i, i, i, i, i, i, i, i, i, p)
     sig("tnv3_conv_up2x_packed_floats", sz, i, i)
     sig("tnv3_pack_up2x_weights", i, p, p, i, i, i, p)
-    sig("tnv3_conv_up2x_forward", i, p, p, p, i, i, i, i, i, p)
+    sig("tnv3_conv_up2x_forward", i, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_dgrad_up2x_packed_floats", sz, i, i)
     sig("tnv3_pack_dgrad_up2x_weights", i, p, p, i, i, i, p)
     sig("tnv3_dgrad_up2x", i, p, p, p, i, i, i, i, i, p)

@@ -347,6 +347,8 @@ int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const fl
 // ---- the upsampled half of a decoder-entry layer at the low resolution (kernels/conv_up2x_mfma.h)
 using UpA = ConvUp2xCfg<2, 2, 4, 2, 4>;      // 128 channels x (4 x 64) full-res pixels, 512 threads
 using UpB = ConvUp2xCfg<2, 1, 4, 2, 4>;      //  64 channels x (4 x 64) full-res pixels, 256 threads
+using UpA2 = ConvUp2xCfg<2, 2, 8, 4, 4>;     // 128 channels x (8 x 64) full-res pixels, 1024 threads: half the filter traffic per FLOP
+using UpB2 = ConvUp2xCfg<2, 1, 8, 4, 4>;     //  64 channels x (8 x 64) full-res pixels, 512 threads
 inline int up2x_chunk(int cout) { return cout % 128 == 0 ? UpA::CC : UpB::CC; }
 inline size_t conv_up2x_packed_floats(int c0, int cout) {
   if (c0 <= 0 || cout <= 0) return 0;
@@ -362,7 +364,7 @@ int pack_up2x_weights_impl(Launcher& L, const float* w, float* wq, int cout, int
 }
 
 template <class Launcher>
-int conv_up2x_forward_impl(Launcher& L, const float* src, const float* wq, float* dst, int n, int c0, int cout, int hl, int wl) {
+int conv_up2x_forward_impl(Launcher& L, const float* src, const float* wq, float* dst, int n, int c0, int cout, int hl, int wl, int cfg = -1) {
   if (!src || !wq || !dst || n <= 0 || c0 <= 0 || cout <= 0 || hl <= 0 || wl <= 0) TNV3_FAIL(-1, "conv_up2x: bad argument");
   if (cout % 64) TNV3_FAIL(-1, "conv_up2x: Cout=%d must be a multiple of 64", cout);
   if (hl >= 4096 || wl >= 4096) TNV3_FAIL(-1, "conv_up2x: low-resolution H,W must be < 4096");
@@ -374,7 +376,14 @@ int conv_up2x_forward_impl(Launcher& L, const float* src, const float* wq, float
     if (npt > (1l << 28)) TNV3_FAIL(-1, "conv_up2x: too many pixel tiles");
     return L.launch(conv_up2x_mfma_kernel<Cfg>, conv_grid_blocks(cout / Cfg::MB, (int)npt), Cfg::NT, a);
   };
-  return cout % 128 == 0 ? go(UpA{}) : go(UpB{});
+  if (cfg < 0) cfg = 3;      // measured on the three TrackNet shapes (scripts/up2x_sweep.py): 64 channels x (8 x 64) pixels wins everywhere
+  switch (cfg) {
+    case 0: if (cout % 128) TNV3_FAIL(-1, "conv_up2x: config 0 needs Cout %% 128 == 0"); return go(UpA{});
+    case 1: return go(UpB{});
+    case 2: if (cout % 128) TNV3_FAIL(-1, "conv_up2x: config 2 needs Cout %% 128 == 0"); return go(UpA2{});
+    case 3: return go(UpB2{});
+    default: TNV3_FAIL(-1, "conv_up2x: unknown config %d", cfg);
+  }
 }
 
 using DUpA = DgradUp2xCfg<2, 2, 4, 1, 2>;    // 128 input channels x (4 x 32) low-res pixels, 512 threads

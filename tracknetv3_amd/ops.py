@@ -64,7 +64,7 @@ def pack_up2x_weights(weight, c0):
     return wq
 
 
-def conv_up2x(src_low, wq, cout):
+def conv_up2x(src_low, wq, cout, cfg=-1):
     """Partial sums of conv3x3 over the nearest-2x upsampling of src_low, computed at the low resolution (tnv3_conv_up2x_forward)."""
     lib = _lib.load()
     _f32(src_low, wq)
@@ -74,7 +74,7 @@ def conv_up2x(src_low, wq, cout):
         raise _lib.Tnv3Error("conv_up2x: class-filter buffer does not match the channel counts")
     out = torch.empty((n, int(cout), 2 * hl, 2 * wl), dtype=torch.float32, device=src_low.device)
     if n:
-        _lib.check(lib.tnv3_conv_up2x_forward(_lib.ptr(src_low), _lib.ptr(wq), _lib.ptr(out), n, c0, int(cout), hl, wl,
+        _lib.check(lib.tnv3_conv_up2x_forward(_lib.ptr(src_low), _lib.ptr(wq), _lib.ptr(out), n, c0, int(cout), hl, wl, int(cfg),
                                               _lib.stream_ptr(src_low)))
     return out
 
