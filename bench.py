@@ -251,7 +251,7 @@ def main():
     # per-launch timing of the dominant kernel family (conv3x3_mfma_kernel<*>): HIP events on the launch stream
     layers = conv_layer_table(in_dim, H, W)
     events = []
-    ops_conv, ops_up2x = ops.conv3x3, ops.conv_up2x
+    ops_conv, ops_up2x, ops_wino = ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino
 
     def timed(kind, fn):
         def wrap(*a, **kw):
@@ -263,7 +263,7 @@ def main():
             return out
         return wrap
 
-    timed_conv, timed_up2x = timed("conv", ops_conv), timed("up2x", ops_up2x)
+    timed_conv, timed_up2x, timed_wino = timed("conv", ops_conv), timed("up2x", ops_up2x), timed("conv", ops_wino)
 
     def barrier():
         if world > 1:
@@ -273,13 +273,13 @@ def main():
     for _ in range(args.warmup):
         model(x)
     barrier()
-    ops.conv3x3, ops.conv_up2x = timed_conv, timed_up2x
+    ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino = timed_conv, timed_up2x, timed_wino
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = model(x)
     barrier()
     dt = time.perf_counter() - t0
-    ops.conv3x3, ops.conv_up2x = ops_conv, ops_up2x
+    ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino = ops_conv, ops_up2x, ops_wino
 
     # Extra (reported beside, never instead of, `value`): the same K steps on independent batches issued round-robin on two
     # HIP streams.  Windows are independent, so the second stream's launches fill the CUs that the 45/48 tail of every
@@ -323,9 +323,16 @@ def main():
         per_layer_ms /= args.steps
         launches_per_step = n_launch // args.steps
         fl = np.array([conv_flops(c0, c1, co, h, w) * args.batch for (_, c0, c1, co, h, w, _) in layers])
-        # multiply-adds the device executes: the upsampled channels (c0 of an `up` layer) cost 4 taps instead of 9
-        fl_exec = np.array([(conv_flops(c0, c1, co, h, w) - (conv_flops(c0, 0, co, h, w) * 5 / 9 if up else 0.0)) * args.batch
-                            for (_, c0, c1, co, h, w, up) in layers])
+        # multiply-adds the device executes: the upsampled channels (c0 of an `up` layer) cost 4 taps instead of 9, and the
+        # plain halves that run in Winograd F(2x2,3x3) form cost 16 instead of 36 per 2x2 tile
+        from tracknetv3_amd import tuning as _tuning
+
+        def executed(c0, c1, co, h, w, up):
+            if up:
+                skip = conv_flops(c1, 0, co, h, w) * (16 / 36 if _tuning.use_winograd(c1, co, h, w) else 1.0)
+                return conv_flops(c0, 0, co, h, w) * 4 / 9 + skip
+            return conv_flops(c0, c1, co, h, w) * (16 / 36 if _tuning.use_winograd(c0, co, h, w) else 1.0)
+        fl_exec = np.array([executed(c0, c1, co, h, w, up) * args.batch for (_, c0, c1, co, h, w, up) in layers])
         conv_ms = float(per_layer_ms.sum())
         achieved = float(fl.sum() / conv_ms / 1e9)
         frames = n_gpus * args.batch * SEQ_LEN * args.steps
@@ -356,15 +363,16 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/conv_traffic.json)",
-                         "kernel": f"conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} launches/step for the 17 "
-                                   "conv layers, fp32 MFMA 32x32x2)",
+                         "kernel": f"conv3x3_wino_mfma_kernel<*> + conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} "
+                                   "launches/step for the 17 conv layers, fp32 MFMA 32x32x2)",
                          "avg_launch_ms": round(conv_ms / launches_per_step, 4), "conv_ms_per_step": round(conv_ms, 4),
                          "algorithmic_gflop_per_step": round(float(fl.sum()) / 1e9, 3),
                          "executed_gflop_per_step": round(float(fl_exec.sum()) / 1e9, 3),
                          "executed_tflops": round(float(fl_exec.sum() / conv_ms / 1e9), 2),
                          "note": "`achieved` counts the reference's algorithmic FLOPs (2*9*Cin*Cout*H*W per layer, SURVEY 8d); the "
                                  "three decoder-entry layers evaluate their upsampled channels at the low resolution with pre-summed "
-                                 "taps (4/9 of those multiply-adds), so the matrix pipe executes `executed_gflop_per_step`",
+                                 "taps (4/9 of those multiply-adds) and the 64..512-channel plain layers run in fused Winograd "
+                                 "F(2x2,3x3) form (16/36), so the matrix pipe executes `executed_gflop_per_step`",
                          "hbm_view": {"algorithmic_GB_per_step": round(ALG_BYTES_PER_SAMPLE * args.batch / 1e9, 3),
                                       "achieved_GBps": round(ALG_BYTES_PER_SAMPLE * args.batch / (ms_per_step * 1e-3) / 1e9, 1),
                                       "peak_GBps": PEAK_HBM_GBPS}},

@@ -74,6 +74,18 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
                              const float* scale, const float* shift, float* dst, int n, int c0, int c1, int cout, int h, int w,
                              int up0, int relu, int cfg, tnv3_stream_t stream);
 
+/* Winograd F(2x2, 3x3) form of the plain layer: dst = act(((conv3x3(src, W) + addend) - mean) * scale + shift), single source,
+ * 16 instead of 36 multiply-adds per (co, ci, 2x2 tile), transforms fused into the kernel.  Same function as
+ * tnv3_conv3x3_forward_add up to fp32 rounding (~6e-7 of the output scale per layer instead of ~2e-7).
+ *   tnv3_conv3x3_wino_supported     : 1 when the shape qualifies (Cout % 64 == 0, H % 4 == 0, W % 64 == 0)
+ *   tnv3_conv3x3_wino_packed_floats : size of the transformed-filter buffer
+ *   tnv3_conv3x3_wino_pack          : w [cout][cin][3][3] -> u = G w G^T, [cin_pad][16][cout] */
+size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
+int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
+int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, tnv3_stream_t stream);
+int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
+                              const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, tnv3_stream_t stream);
+
 /* Decoder-entry layers (model.py:65,67,69: Conv2DBlock on torch.cat([nn.Upsample(scale_factor=2)(x), skip], dim=1)):
  * the contribution of the UPSAMPLED channels computed at the low resolution.  A 3x3 'same' convolution over a nearest-2x
  * upsampled tensor reads only 2x2 distinct source pixels per output pixel, so with the taps that coincide pre-summed

@@ -148,6 +148,31 @@ def test_conv_up2x_big_tile_configs_emulated(emu, cfg):
     assert e_up <= 2e-6 and e_full <= 2e-6, (e_up, e_full)
 
 
+WINO_CASES = [(1, 8, 64, 4, 64), (2, 12, 128, 8, 64), (1, 70, 64, 4, 128)]   # (n, cin, cout, h, w)
+
+
+def _wino_case(n, cin, cout, h, w, device):
+    from tracknetv3_amd import ops
+    x, wt = torch.relu(T((n, cin, h, w), 91)), T((cout, cin, 3, 3), 92, -0.3, 0.3)
+    mean, scale, shift = T((cout,), 93), T((cout,), 94, 0.5, 1.5), T((cout,), 95)
+    add = T((n, cout, h, w), 96)
+    z = F.conv2d(x.double(), wt.double(), padding=1)
+    ref_plain = z
+    ref_full = torch.relu((z + add.double() - mean.double().view(1, -1, 1, 1)) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    u = ops.pack_wino_weights(wt.to(device))
+    got_plain = ops.conv3x3_wino(x.to(device), u, cout).cpu().double()
+    got_full = ops.conv3x3_wino(x.to(device), u, cout, mean=mean.to(device), scale=scale.to(device), shift=shift.to(device), relu=True,
+                                addend=add.to(device)).cpu().double()
+    s = ref_plain.abs().max()
+    return ((got_plain - ref_plain).abs().max() / s).item(), ((got_full - ref_full).abs().max() / s).item()
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_wino_emulated_vs_torch(emu, case):
+    e_plain, e_full = _wino_case(*case, "cpu")
+    assert e_plain <= 3e-6 and e_full <= 6e-6, (e_plain, e_full)
+
+
 def test_argument_errors_are_reported(emu):
     from tracknetv3_amd import ops, _lib
     w = ops.pack_conv3x3_weights(T((64, 4, 3, 3), 1))

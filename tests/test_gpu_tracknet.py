@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import GOLDEN
-from test_emu_kernels import UP2X_CASES, _dgrad_up2x_case, _up2x_case
+from test_emu_kernels import UP2X_CASES, WINO_CASES, _dgrad_up2x_case, _up2x_case, _wino_case
 from oracle import nets, prng
 from test_emu_kernels import CONV_CASES, T, conv_ref
 
@@ -63,6 +63,12 @@ def test_conv_up2x_vs_torch(gpu_device, case):
 @pytest.mark.parametrize("case", UP2X_CASES + [(2, 512, 256, 36, 64), (1, 128, 64, 144, 256), (2, 256, 128, 9, 40)])
 def test_dgrad_up2x_vs_autograd(gpu_device, case):
     assert _dgrad_up2x_case(*case, gpu_device) <= 3e-6
+
+
+@pytest.mark.parametrize("case", WINO_CASES + [(2, 256, 256, 72, 128), (1, 512, 512, 36, 64), (1, 64, 64, 288, 512)])
+def test_conv3x3_wino_vs_torch(gpu_device, case):
+    e_plain, e_full = _wino_case(*case, gpu_device)
+    assert e_plain <= 4e-6 and e_full <= 8e-6, (e_plain, e_full)
 
 
 def test_pool_head_pack(gpu_device):

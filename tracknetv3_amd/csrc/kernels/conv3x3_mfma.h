@@ -118,6 +118,8 @@ __host__ __device__ inline int conv_grid_blocks(int nMB, int nPT) {
 constexpr int kPackZeroTail = 64;      // floats of zeros appended to every packed filter
 
 // s_waitcnt immediate that waits for vmcnt <= n only (gfx9+ encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14])
+// ... and the one that waits for lgkmcnt <= n only (vmcnt = 63: no wait)
+__host__ __device__ constexpr int tnv3_lgkmcnt_only(int n) { return 15 | (7 << 4) | ((n & 15) << 8) | (3 << 14); }
 __host__ __device__ constexpr int tnv3_vmcnt_only(int n) { return (n & 15) | (7 << 4) | (15 << 8) | (((n >> 4) & 3) << 14); }
 
 // global -> LDS DMA: LDS[lds_base + lane*BYTES] <- *gsrc (per-lane source, wave-uniform LDS base; the builtin puts the base

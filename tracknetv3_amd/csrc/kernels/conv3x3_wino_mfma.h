@@ -1,0 +1,256 @@
+// conv3x3_wino_mfma.h -- Winograd F(2x2, 3x3) form of the plain 3x3 'same' convolution + eval-mode BN + ReLU
+// (model.py:4-16 in eval mode), fused in one kernel on the fp32 matrix cores.
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, d = its 4x4 input patch (Lavin & Gray 2015)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+// 16 multiply-adds per (co, ci, tile) instead of 36: the contraction becomes 16 independent GEMMs (one per transform
+// coefficient xi): M_xi[co][tile] = sum_ci U_xi[co][ci] * V_xi[ci][tile].  Same function as the reference in exact
+// arithmetic; in fp32 the +-1, 1/2 transforms cost ~3x the rounding noise of the direct chain (6e-7 vs 2e-7 of the
+// output scale per layer, measured) -- two orders below the 1e-4 heat-map bar.
+//
+// Mapping: MFMA 32x32x2 with M = 32 output channels, N = 32 tiles (2 tile rows x 16 tile columns = 4 x 32 pixels),
+// K = 2 input channels; a wave keeps ALL 16 xi of its 32 x 32 tile (256 accumulator registers, one wave per SIMD) so the
+// inverse transform happens in registers.  Per chunk of CC channels a workgroup stages the raw halo tile and the
+// pre-transformed filter panel U (conv3x3_wino_pack_kernel), transforms the patches cooperatively into the LDS operand
+// V[ci][xi][tile] (adds only), then runs CC/2 x 16 MFMAs per wave with both operands read as 32 consecutive floats.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "conv3x3_mfma.h"
+
+namespace tnv3 {
+
+struct WinoArgs {
+  const float* src;     // [N][Cin][H][W]
+  const float* u;       // [Cin_pad][16][Cout]   G g G^T per (ci, co), Cin_pad = roundup(Cin, CC), padding rows zero, then
+                        // kPackZeroTail zeros (`zeros` points there: the padding source of the LDS-DMA loader)
+  const float* zeros;
+  const float* addend;  // optional [N][Cout][H][W] added before the affine (decoder-entry layers) or nullptr
+  const float* mean;    // [Cout] or nullptr:  y = (acc - mean) * scale + shift  (eval-mode BN, reference's operation order)
+  const float* scale;
+  const float* shift;
+  float* dst;           // [N][Cout][H][W]
+  int N, Cin, Cout, H, W, relu;
+};
+
+template <int WM_, int WN_, int CC_>
+struct WinoCfg {
+  static constexpr int WM = WM_, WN = WN_, CC = CC_;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int MB = 32 * WM;                 // output channels per workgroup
+  static constexpr int TB = 32 * WN;                 // 2x2 tiles per workgroup: 2 tile rows x (16*WN) tile columns
+  static constexpr int PW = 32 * WN;                 // pixel columns per workgroup (4 pixel rows)
+  static constexpr int RW = PW + 2, RAWP = 6 * RW;   // raw halo tile per channel: 6 rows x (PW + 2)
+  static constexpr int RAW_FLOATS = CC * RAWP;
+  static constexpr int U_FLOATS = CC * 16 * MB, V_FLOATS = CC * 16 * TB;
+  static constexpr int NU4 = U_FLOATS / 4 / NT;      // 16-byte filter loads per thread and chunk
+  static constexpr int NRAW = (RAW_FLOATS + NT - 1) / NT;
+  static constexpr int NPAIR = (CC * TB + NT - 1) / NT;   // (channel, tile) patches each thread transforms per chunk
+  static_assert((U_FLOATS / 4) % NT == 0, "filter panel must deal evenly");
+  static_assert(CC % 2 == 0, "one MFMA = 2 channels");
+  // Staging is LDS DMA with a prefetch distance of TWO chunks: at one wave per SIMD (256 accumulator registers) nothing
+  // else hides the L2 / HBM latency, and one chunk of MFMAs (CC/2 x 16 x 64 cycles = 1.7 us) is shorter than it.
+  // Three filter stages, two raw stages (every wave issues the same number of DMAs per chunk: counted vmcnt), one V.
+  static constexpr int RAW_STAGE = NRAW * NT;        // padded so that all NRAW pieces of every wave land inside the stage
+  static constexpr int DMA_PER_CHUNK = NU4 + NRAW;
+  static constexpr int LDS_FLOATS = 3 * U_FLOATS + V_FLOATS + 2 * RAW_STAGE;
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_mfma_kernel(const WinoArgs a) {
+  constexpr int WN = Cfg::WN, CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, PW = Cfg::PW, RW = Cfg::RW, RAWP = Cfg::RAWP;
+  constexpr int NU4 = Cfg::NU4, NRAW = Cfg::NRAW, NPAIR = Cfg::NPAIR;
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  float* u_s = lds;                                   // three stages
+  float* v_s = lds + 3 * Cfg::U_FLOATS;
+  float* raw_s = v_s + Cfg::V_FLOATS;                 // two stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int half = lane >> 5, bl = lane & 31;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+  const int tilesH = H / 4, tilesW = W / PW;
+  const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
+  int mb, pt;
+  if (!conv_block_map(blockIdx.x, nMB, nPT, mb, pt)) return;
+  const int n = pt / (tilesH * tilesW);
+  const int trem = pt - n * (tilesH * tilesW);
+  const int h0 = (trem / tilesW) * 4, w0 = (trem % tilesW) * PW;
+  const int m0 = mb * MB;
+
+  // raw staging slots: element e of [CC][6][RW] -> offset in one input plane or -1 (zero padding / unused slot)
+  int so[NRAW];
+#pragma unroll
+  for (int i = 0; i < NRAW; ++i) {
+    const int e = tid + i * NT;
+    const int r = e % RAWP;
+    const int tr = r / RW, tc = r - tr * RW;
+    const int gh = h0 - 1 + tr, gw = w0 - 1 + tc;
+    so[i] = (e < Cfg::RAW_FLOATS && gh >= 0 && gh < H && gw >= 0 && gw < W) ? gh * W + gw : -1;
+  }
+  const float* zsrc = a.zeros + lane;
+  const int wbase = wave * 64;
+  // DMA of chunk k: filter panel -> u_s[ustage], raw halo tile -> raw_s[rstage]; NU4 + NRAW instructions per wave, always
+  auto dma_stage = [&](int k, int ustage, int rstage) {
+    float* us = u_s + ustage * Cfg::U_FLOATS;
+    const float* usrc = a.u + (size_t)k * CC * 16 * Cout + m0;
+#pragma unroll
+    for (int i = 0; i < NU4; ++i) {
+      const int e4 = tid + i * NT;
+      const int row = e4 / (MB / 4), m4 = e4 - row * (MB / 4);
+      lds_dma16(usrc + (size_t)row * Cout + m4 * 4, us + (i * NT + wbase) * 4);
+    }
+    float* rs = raw_s + rstage * Cfg::RAW_STAGE;
+    const float* base = a.src + ((size_t)n * Cin + k * CC) * HW;
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) {
+      const int c = (tid + i * NT) / RAWP;
+      const bool ok = so[i] >= 0 && k * CC + c < Cin;
+      lds_dma4(ok ? base + (size_t)c * HW + so[i] : zsrc, rs + i * NT + wbase);
+    }
+  };
+  // V[c][xi][t] = (B^T d B)[xi] for the 4x4 patch of tile t = (tr, tc): raw rows 2tr .. 2tr+3, columns 2tc .. 2tc+3
+  auto transform = [&](int rstage) {
+    const float* rs = raw_s + rstage * Cfg::RAW_STAGE;
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+      const int p = tid + i * NT;
+      if (p >= CC * TB) break;
+      const int c = p / TB, t = p - c * TB;
+      const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
+      const float* d = rs + c * RAWP + (2 * tr) * RW + 2 * tc;
+      float e[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = d[j], d1 = d[RW + j], d2 = d[2 * RW + j], d3 = d[3 * RW + j];
+        e[0][j] = d0 - d2; e[1][j] = d1 + d2; e[2][j] = d2 - d1; e[3][j] = d1 - d3;
+      }
+      float* v = v_s + (c * 16) * TB + t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[(r * 4 + 0) * TB] = e[r][0] - e[r][2];
+        v[(r * 4 + 1) * TB] = e[r][1] + e[r][2];
+        v[(r * 4 + 2) * TB] = e[r][2] - e[r][1];
+        v[(r * 4 + 3) * TB] = e[r][1] - e[r][3];
+      }
+    }
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+
+  const int a_off = half * 16 * MB + wm * 32 + bl;
+  const int b_off = half * 16 * TB + wn * 32 + bl;
+
+  const int nChunks = (Cin + CC - 1) / CC;
+  auto wait_landed = [&](bool newest_in_flight) {       // everything but (optionally) the newest chunk's DMAs has landed
+    if (newest_in_flight) __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(Cfg::DMA_PER_CHUNK));
+    else __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+  };
+  // Barriers are raw s_barrier: __syncthreads() would make the compiler drain vmcnt to 0 and with it the DMAs of the chunk
+  // that is supposed to stay in flight.  LDS writes of the transform are published with an explicit lgkmcnt(0).
+  auto publish_lds = [&]() {
+    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+  };
+  dma_stage(0, 0, 0);
+  if (nChunks > 1) dma_stage(1, 1, 1);
+  wait_landed(nChunks > 1);
+  __builtin_amdgcn_s_barrier();
+  transform(0);
+  publish_lds();
+  for (int k = 0; k < nChunks; ++k) {
+    // stage (k+2)%3 held the filters of chunk k-1 and raw stage k%2 the patches of chunk k: both were released by the barriers below
+    if (k + 2 < nChunks) dma_stage(k + 2, (k + 2) % 3, k & 1);
+    const float* A = u_s + (k % 3) * Cfg::U_FLOATS + a_off;
+    const float* B = v_s + b_off;
+    constexpr int NSTEP = (CC / 2) * 16;                 // (channel pair, xi): one MFMA each
+    // One MFMA (64 cycles) per step is shorter than the LDS round trip, so the operand reads run PF steps ahead (ring of
+    // PF + 1 register pairs); sched_group_barrier pins "two DS reads, one MFMA" so the compiler keeps that distance.
+    constexpr int PF = 4, RING = PF + 1;
+    float av[RING], bv[RING];
+    auto read_step = [&](int s) {
+      const int cp = s >> 4, xi = s & 15;
+      av[s % RING] = A[(2 * cp * 16 + xi) * MB];
+      bv[s % RING] = B[(2 * cp * 16 + xi) * TB];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) read_step(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + PF < NSTEP) read_step(s + PF);
+      acc[s & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s & 15], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    if (k + 1 < nChunks) {
+      wait_landed(k + 2 < nChunks);                      // chunk k+1 is in LDS (this wave's pieces) ...
+      __builtin_amdgcn_s_barrier();                      // ... and everybody's; V and filter stage k%3 are no longer read
+      transform((k + 1) & 1);
+      publish_lds();
+    }
+  }
+
+  // ---- inverse transform A^T M A in registers, affine + ReLU, two 8-byte stores per (channel, tile)
+  const bool has_affine = a.scale != nullptr;
+  const int t = wn * 32 + bl;
+  const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
+  const int oh = h0 + 2 * tr, ow = w0 + 2 * tc;
+  typedef float wf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    float tt[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float m0j = acc[j][r], m1j = acc[4 + j][r], m2j = acc[8 + j][r], m3j = acc[12 + j][r];
+      tt[0][j] = m0j + m1j + m2j;
+      tt[1][j] = m1j - m2j - m3j;
+    }
+    float mu = 0.0f, sc = 1.0f, sh = 0.0f;
+    if (has_affine) { mu = a.mean ? a.mean[co] : 0.0f; sc = a.scale[co]; sh = a.shift[co]; }
+    const size_t plane = ((size_t)n * Cout + co) * HW;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      wf2 v;
+      v[0] = tt[y][0] + tt[y][1] + tt[y][2];
+      v[1] = tt[y][1] - tt[y][2] - tt[y][3];
+      const size_t o = plane + (size_t)(oh + y) * W + ow;
+      if (a.addend) { const wf2 ad = *reinterpret_cast<const wf2*>(a.addend + o); v[0] += ad[0]; v[1] += ad[1]; }
+      if (has_affine) { v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh; }
+      if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
+      *reinterpret_cast<wf2*>(a.dst + o) = v;
+    }
+  }
+}
+
+// U[Cin_pad][xi = i*4+j][Cout] = (G g G^T)[i][j] from W[Cout][Cin][3][3]; rows ci >= Cin are zero
+__global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad) {
+  const long body = (long)CinPad * 16 * Cout, total = body + kPackZeroTail;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    if (e >= body) { u[e] = 0.0f; continue; }
+    const int co = (int)(e % Cout);
+    const long t = e / Cout;
+    const int xi = (int)(t & 15), ci = (int)(t >> 4);
+    float v = 0.0f;
+    if (ci < Cin) {
+      const float* g = w + ((long)co * Cin + ci) * 9;
+      const int i = xi >> 2, j = xi & 3;
+      // row i of G applied to the filter rows, then row j of G to the columns
+      float rowv[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+        rowv[c] = i == 0 ? g0 : (i == 1 ? 0.5f * (g0 + g1 + g2) : (i == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+      }
+      v = j == 0 ? rowv[0] : (j == 1 ? 0.5f * (rowv[0] + rowv[1] + rowv[2]) : (j == 2 ? 0.5f * (rowv[0] - rowv[1] + rowv[2]) : rowv[2]));
+    }
+    u[e] = v;
+  }
+}
+
+}  // namespace tnv3

@@ -67,6 +67,17 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
+    def packed_wino(self, c_from=0):
+        """Winograd-domain filters G w G^T of input channels c_from.. (the whole layer, or the skip half of a decoder entry)."""
+        key = ("wino", int(c_from))
+        ver = self._versions(["conv"])
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            w = self.conv.weight.detach()
+            hit = (ver, ops.pack_wino_weights(w if c_from == 0 else w[:, c_from:].contiguous()))
+            self._cache[key] = hit
+        return hit[1]
+
     def packed_up2x(self, c0):
         """(class filters of the first c0 = upsampled input channels, packed 3x3 filter of the remaining skip channels):
         the two operands of the decoder-entry formulation (ops.conv_up2x + ops.conv3x3(..., addend=...))."""
@@ -99,6 +110,10 @@ class Conv2DBlock(nn.Module):
         h, w = int(skip.shape[2]), int(skip.shape[3])
         cfg = tuning.conv_config(self.conv.out_dim, c1, n, h, w)
         bn = self.bn
+        if affine and c1 >= 128 and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # eval mode: the skip half in Winograd form
+            # (measured: with the addend read a 64-channel contraction is too short for the Winograd kernel to win)
+            return ops.conv3x3_wino(skip, self.packed_wino(c0), self.conv.out_dim, mean=bn.running_mean, scale=self.eval_scale(),
+                                    shift=bn.bias.detach(), relu=relu, addend=part)
         if affine:
             return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, mean=bn.running_mean, scale=self.eval_scale(),
                                shift=bn.bias.detach(), relu=relu, cfg=cfg)
@@ -121,6 +136,9 @@ class Conv2DBlock(nn.Module):
             return self.conv_up_skip(x, skip, int(n), relu=True, affine=True)
         h = x.shape[2] * (2 if up else 1)
         w = x.shape[3] * (2 if up else 1)
+        if skip is None and not up and tuning.use_winograd(self.conv.in_dim, self.conv.out_dim, int(h), int(w)):
+            return ops.conv3x3_wino(x, self.packed_wino(), self.conv.out_dim, mean=bn.running_mean, scale=self.eval_scale(),
+                                    shift=bn.bias.detach(), relu=True)
         cfg = tuning.conv_config(self.conv.out_dim, self.conv.in_dim, n, h, w)
         return ops.conv3x3(x, self.packed_weight(), self.conv.out_dim, src1=skip, mean=bn.running_mean, scale=self.eval_scale(),
                            shift=bn.bias.detach(), up0=up, relu=True, cfg=cfg)
@@ -211,9 +229,13 @@ class TrackNet(nn.Module):
                         self.up_block_2, self.up_block_3):
                 for i, b in enumerate(blk.blocks()):
                     if i == 0 and blk in (self.up_block_1, self.up_block_2, self.up_block_3):
-                        b.packed_up2x(b.conv.in_dim * 2 // 3)      # decoder entry: 2/3 of the inputs are the upsampled tensor
+                        c0 = b.conv.in_dim * 2 // 3               # decoder entry: 2/3 of the inputs are the upsampled tensor
+                        b.packed_up2x(c0)
+                        b.packed_wino(c0)
                     else:
                         b.packed_weight()
+                        if b.conv.in_dim >= tuning.WINOGRAD_MIN_CIN:
+                            b.packed_wino()
                     b.eval_scale()
 
     def forward(self, x):

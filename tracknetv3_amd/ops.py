@@ -53,6 +53,39 @@ def bn_eval_scale(gamma, running_var, eps=BN_EPS):
     return scale
 
 
+def wino_supported(cin, cout, h, w):
+    return bool(_lib.load().tnv3_conv3x3_wino_supported(int(cin), int(cout), int(h), int(w)))
+
+
+def pack_wino_weights(weight):
+    """nn.Conv2d weight (Cout, Cin, 3, 3) -> Winograd-domain filters G w G^T for tnv3_conv3x3_wino_forward."""
+    lib = _lib.load()
+    _f32(weight)
+    _lib.dev_check(weight)
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    u = torch.empty(lib.tnv3_conv3x3_wino_packed_floats(cin, cout), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.tnv3_conv3x3_wino_pack(_lib.ptr(weight.contiguous()), _lib.ptr(u), cout, cin, _lib.stream_ptr(weight)))
+    return u
+
+
+def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None):
+    """The plain eval-mode layer in Winograd F(2x2, 3x3) form (tnv3_conv3x3_wino_forward)."""
+    lib = _lib.load()
+    _f32(src, u, mean, scale, shift, addend)
+    _lib.dev_check(src, u, mean, scale, shift, addend)
+    n, cin, h, w = (int(v) for v in src.shape)
+    if u.numel() != lib.tnv3_conv3x3_wino_packed_floats(cin, int(cout)):
+        raise _lib.Tnv3Error("conv3x3_wino: transformed-filter buffer does not match the channel counts")
+    out = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=src.device)
+    if addend is not None and tuple(addend.shape) != tuple(out.shape):
+        raise _lib.Tnv3Error("conv3x3_wino: addend must have the output's shape")
+    if n:
+        _lib.check(lib.tnv3_conv3x3_wino_forward(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(mean), _lib.ptr(scale),
+                                                 _lib.ptr(shift), _lib.ptr(out), n, cin, int(cout), h, w, int(bool(relu)),
+                                                 _lib.stream_ptr(src)))
+    return out
+
+
 def pack_up2x_weights(weight, c0):
     """nn.Conv2d weight (Cout, Cin, 3, 3) -> pre-summed class filters of its first c0 (upsampled) input channels."""
     lib = _lib.load()

@@ -30,3 +30,17 @@ def save(configs, meta=None):
     with open(_PATH, "w") as f:
         json.dump({"meta": meta or {}, "configs": configs}, f, indent=1, sort_keys=True)
     _table = None
+
+
+# Eval-mode plain layers run in Winograd F(2x2, 3x3) form when the shape qualifies (ops.wino_supported) and the
+# contraction is deep enough for the transforms to pay: measured on MI355X at batch 10 (scripts/wino_sweep.py) it wins
+# 1.22-1.34x on every 64..512-channel layer.  The 27-channel stem stays on the direct kernel.
+WINOGRAD = True
+WINOGRAD_MIN_CIN = 64
+
+
+def use_winograd(cin, cout, h, w):
+    if not WINOGRAD or cin < WINOGRAD_MIN_CIN:
+        return False
+    from . import ops
+    return ops.wino_supported(cin, cout, h, w)
