@@ -88,6 +88,8 @@ class _TrackNetTrain(torch.autograd.Function):
             w = src0.shape[3] * (2 if up else 1)
             if up and src1 is not None:
                 z = blk.conv_up_skip(src0, src1, int(n), relu=False, affine=False)
+            elif src1 is None and not up and tuning.use_winograd(blk.conv.in_dim, blk.conv.out_dim, int(h), int(w)):
+                z = ops.conv3x3_wino(src0, blk.packed_wino(), blk.conv.out_dim)      # raw conv output in Winograd form
             else:
                 z = ops.conv3x3(src0, blk.packed_weight(), blk.conv.out_dim, src1=src1, up0=up, relu=False, cfg=_cfg(blk, n, h, w))
             bn = blk.bn
@@ -178,9 +180,15 @@ class _TrackNetTrain(torch.autograd.Function):
                 # correlation of dZ, 4/9 of the MACs, no full-resolution intermediate), the skip half as a plain 3x3 dgrad
                 g_low, w_skip_t = blk.packed_dgrad_up2x(c0)
                 d_low = ops.dgrad_up2x(dz, g_low, c0)
-                cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))
-                d_skip, _ = ops.conv3x3_dgrad(dz, w_skip_t, c1, 0, cfg=cfg)
+                if tuning.use_winograd(blk.conv.out_dim, c1, int(h), int(w)):
+                    d_skip = ops.conv3x3_wino(dz, blk.packed_wino_t(c0), c1)
+                else:
+                    cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))
+                    d_skip, _ = ops.conv3x3_dgrad(dz, w_skip_t, c1, 0, cfg=cfg)
                 return d_low, d_skip
+            if c1 == 0 and not rec["up"] and tuning.use_winograd(blk.conv.out_dim, c0, int(h), int(w)):
+                # plain layer: dX = conv3x3(dZ, W^T flipped) is itself a plain 3x3 convolution -> the Winograd kernel
+                return ops.conv3x3_wino(dz, blk.packed_wino_t(), c0), None
             cfg = tuning.conv_config(c0 + c1, blk.conv.out_dim, int(n), int(h), int(w))
             return ops.conv3x3_dgrad(dz, blk.packed_weight(transpose_flip=True), c0, c1, cfg=cfg)
 

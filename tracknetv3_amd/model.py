@@ -78,6 +78,17 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
+    def packed_wino_t(self, c_from=0):
+        """Winograd-domain filters of the data gradient: G w' G^T with w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw]."""
+        key = ("wino_t", int(c_from))
+        ver = self._versions(["conv"])
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            w = self.conv.weight.detach()
+            hit = (ver, ops.pack_wino_weights(w[:, c_from:].flip(2, 3).transpose(0, 1).contiguous()))
+            self._cache[key] = hit
+        return hit[1]
+
     def packed_up2x(self, c0):
         """(class filters of the first c0 = upsampled input channels, packed 3x3 filter of the remaining skip channels):
         the two operands of the decoder-entry formulation (ops.conv_up2x + ops.conv3x3(..., addend=...))."""
@@ -117,6 +128,8 @@ class Conv2DBlock(nn.Module):
         if affine:
             return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, mean=bn.running_mean, scale=self.eval_scale(),
                                shift=bn.bias.detach(), relu=relu, cfg=cfg)
+        if c1 >= 128 and tuning.use_winograd(c1, self.conv.out_dim, h, w):             # training forward: raw sums
+            return ops.conv3x3_wino(skip, self.packed_wino(c0), self.conv.out_dim, addend=part, relu=relu)
         return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, relu=relu, cfg=cfg)
 
     def eval_scale(self):
