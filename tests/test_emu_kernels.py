@@ -167,9 +167,15 @@ def _wino_case(n, cin, cout, h, w, device):
     return ((got_plain - ref_plain).abs().max() / s).item(), ((got_full - ref_full).abs().max() / s).item()
 
 
+@pytest.mark.parametrize("variant", [0, 1], ids=["phased", "interleaved"])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_conv3x3_wino_emulated_vs_torch(emu, case):
-    e_plain, e_full = _wino_case(*case, "cpu")
+def test_conv3x3_wino_emulated_vs_torch(emu, case, variant):
+    from tracknetv3_amd import ops
+    old = ops.wino_variant(variant)
+    try:
+        e_plain, e_full = _wino_case(*case, "cpu")
+    finally:
+        ops.wino_variant(old)
     assert e_plain <= 3e-6 and e_full <= 6e-6, (e_plain, e_full)
 
 

@@ -46,6 +46,7 @@ def _declare(lib):
     sig("tnv3_dgrad_up2x", i, p, p, p, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wgrad_up2x_workspace_bytes", sz, i, i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad_up2x", i, p, p, p, p, p, sz, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino_variant", i, i)
     sig("tnv3_conv3x3_wino_packed_floats", sz, i, i)
     sig("tnv3_conv3x3_wino_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wino_pack", i, p, p, i, i, p)
@@ -94,7 +95,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_heatmap_box_max", "tnv3_conv3x3_wgrad_variant", "tnv3_conv3x3_forward_add", "tnv3_conv_up2x_packed_floats",
            "tnv3_pack_up2x_weights", "tnv3_conv_up2x_forward", "tnv3_dgrad_up2x_packed_floats", "tnv3_pack_dgrad_up2x_weights",
            "tnv3_dgrad_up2x", "tnv3_conv3x3_wgrad_up2x_workspace_bytes", "tnv3_conv3x3_wgrad_up2x",
-           "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_forward"]
+           "tnv3_conv3x3_wino_variant", "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_forward"]
 
 
 def library_path():
@@ -120,6 +121,8 @@ def load():
     if lib.tnv3_abi_version() != 1:
         raise Tnv3Error("libtnv3_hip.so ABI version mismatch")
     _lib, _is_emulator = lib, False
+    if os.environ.get("TNV3_WINO_VARIANT", "") in ("0", "1"):         # diagnostic: Winograd kernel with / without interleaved transform
+        lib.tnv3_conv3x3_wino_variant(int(os.environ["TNV3_WINO_VARIANT"]))
     if os.environ.get("TNV3_WGRAD_VARIANT", "") in ("0", "1"):       # diagnostic: pick the weight-gradient kernel family
         lib.tnv3_conv3x3_wgrad_variant(int(os.environ["TNV3_WGRAD_VARIANT"]))
     return lib

@@ -347,9 +347,12 @@ int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const fl
 
 // ---- Winograd F(2x2, 3x3) form of the plain eval-mode layer (kernels/conv3x3_wino_mfma.h)
 using WinoA = WinoCfg<2, 2, 8>;              // 64 channels x 64 tiles (4 x 64 pixels), 256 threads, 8-channel chunks
+using WinoIl = WinoIlCfg<2, 2, 6>;           // same tile, 6-channel chunks, patch transform interleaved with the MFMAs
+constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
+inline int& wino_variant() { static int v = 0; return v; }   // 0: WinoA (default, measured faster), 1: WinoIl (diagnostic knob)
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
-  return (size_t)round_up(cin, WinoA::CC) * 16 * cout + kPackZeroTail;
+  return (size_t)round_up(cin, kWinoCinPad) * 16 * cout + kPackZeroTail;
 }
 inline bool conv3x3_wino_supported(int cin, int cout, int h, int w) {
   return cin > 0 && cout > 0 && cout % WinoA::MB == 0 && h % 4 == 0 && w % WinoA::PW == 0;
@@ -358,7 +361,7 @@ inline bool conv3x3_wino_supported(int cin, int cout, int h, int w) {
 template <class Launcher>
 int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin) {
   if (!w || !u || cout <= 0 || cin <= 0) TNV3_FAIL(-1, "conv3x3_wino_pack: bad argument");
-  const int cpad = round_up(cin, WinoA::CC);
+  const int cpad = round_up(cin, kWinoCinPad);
   const long total = (long)cpad * 16 * cout + kPackZeroTail;
   return L.launch(conv3x3_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, cpad);
 }
@@ -370,10 +373,12 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
   if (!conv3x3_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino: inconsistent affine arguments");
-  const float* zeros = u + (size_t)round_up(cin, WinoA::CC) * 16 * cout;
+  const float* zeros = u + (size_t)round_up(cin, kWinoCinPad) * 16 * cout;
   WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0};
   const long npt = (long)n * (h / 4) * (w / WinoA::PW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino: too many pixel tiles");
+  if (wino_variant() == 1)
+    return L.launch(conv3x3_wino_il_mfma_kernel<WinoIl>, conv_grid_blocks(cout / WinoIl::MB, (int)npt), WinoIl::NT, a);
   return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
 }
 

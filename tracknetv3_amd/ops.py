@@ -53,6 +53,11 @@ def bn_eval_scale(gamma, running_var, eps=BN_EPS):
     return scale
 
 
+def wino_variant(variant=-1):
+    """Select (1: transform interleaved with the MFMAs, 0: separate phase) or query (-1) the Winograd kernel; returns the old one."""
+    return int(_lib.load().tnv3_conv3x3_wino_variant(int(variant)))
+
+
 def wino_supported(cin, cout, h, w):
     return bool(_lib.load().tnv3_conv3x3_wino_supported(int(cin), int(cout), int(h), int(w)))
 
