@@ -1,0 +1,37 @@
+"""Where the Winograd kernel's time goes: the production kernel next to its timing twins (no DMA after the prologue /
++ no patch transform / + no barriers; results of the twins are wrong by design)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tracknetv3_amd import ops
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    out = {}
+    for cin, cout, h, w in ((512, 512, 36, 64), (256, 256, 72, 128), (64, 64, 288, 512)):
+        x = torch.relu(torch.randn(10, cin, h, w, device=dev))
+        u = ops.pack_wino_weights((torch.rand(cout, cin, 3, 3, device=dev) - 0.5) * 0.1)
+        gf = 2.0 * 16 * cin * cout * (h // 2) * (w // 2) * 10 / 1e9
+        row = {}
+        for name, v in (("production", 0), ("no_dma", 11), ("no_dma_no_transform", 12), ("no_dma_no_transform_no_barrier", 13)):
+            old = ops.wino_variant(v)
+            try:
+                for _ in range(3):
+                    ops.conv3x3_wino(x, u, cout)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    ops.conv3x3_wino(x, u, cout)
+                e1.record(); torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+            finally:
+                ops.wino_variant(old)
+            row[name] = {"ms": round(ms, 4), "executed_tflops": round(gf / ms, 1)}
+        out[f"{cout},{cin},10,{h},{w}"] = row
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -34,9 +34,10 @@ struct WinoArgs {
   int N, Cin, Cout, H, W, relu;
 };
 
-template <int WM_, int WN_, int CC_>
+template <int WM_, int WN_, int CC_, int DIAG_ = 0>
 struct WinoCfg {
   static constexpr int WM = WM_, WN = WN_, CC = CC_;
+  static constexpr int DIAG = DIAG_;   // timing twins (WRONG results): 1 = no DMA after the prologue, 2 = + no patch transform, 3 = + no barriers
   static constexpr int NT = WM * WN * 64;
   static constexpr int MB = 32 * WM;                 // output channels per workgroup
   static constexpr int TB = 32 * WN;                 // 2x2 tiles per workgroup: 2 tile rows x (16*WN) tile columns
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_mfma_kernel(const WinoAr
   publish_lds();
   for (int k = 0; k < nChunks; ++k) {
     // stage (k+2)%3 held the filters of chunk k-1 and raw stage k%2 the patches of chunk k: both were released by the barriers below
-    if (k + 2 < nChunks) dma_stage(k + 2, (k + 2) % 3, k & 1);
+    if (k + 2 < nChunks && Cfg::DIAG < 1) dma_stage(k + 2, (k + 2) % 3, k & 1);
     const float* A = u_s + (k % 3) * Cfg::U_FLOATS + a_off;
     const float* B = v_s + b_off;
     constexpr int NSTEP = (CC / 2) * 16;                 // (channel pair, xi): one MFMA each
@@ -188,10 +189,10 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_mfma_kernel(const WinoAr
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
     if (k + 1 < nChunks) {
-      wait_landed(k + 2 < nChunks);                      // chunk k+1 is in LDS (this wave's pieces) ...
-      __builtin_amdgcn_s_barrier();                      // ... and everybody's; V and filter stage k%3 are no longer read
-      transform((k + 1) & 1);
-      publish_lds();
+      if (Cfg::DIAG < 1) wait_landed(k + 2 < nChunks);   // chunk k+1 is in LDS (this wave's pieces) ...
+      if (Cfg::DIAG < 3) __builtin_amdgcn_s_barrier();   // ... and everybody's; V and filter stage k%3 are no longer read
+      if (Cfg::DIAG < 2) transform((k + 1) & 1);
+      if (Cfg::DIAG < 3) publish_lds();
     }
   }
 

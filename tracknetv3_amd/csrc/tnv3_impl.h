@@ -377,6 +377,12 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
   WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0};
   const long npt = (long)n * (h / 4) * (w / WinoA::PW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino: too many pixel tiles");
+  switch (wino_variant()) {          // 11..13: timing twins of WinoA (wrong results by design, scripts/wino_diag.py)
+    case 11: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 1>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
+    case 12: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 2>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
+    case 13: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 3>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
+    default: break;
+  }
   if (wino_variant() == 1)
     return L.launch(conv3x3_wino_il_mfma_kernel<WinoIl>, conv_grid_blocks(cout / WinoIl::MB, (int)npt), WinoIl::NT, a);
   return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
