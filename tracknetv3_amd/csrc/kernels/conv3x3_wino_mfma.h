@@ -42,18 +42,19 @@ struct WinoCfg {
   static constexpr int MB = 32 * WM;                 // output channels per workgroup
   static constexpr int TB = 32 * WN;                 // 2x2 tiles per workgroup: 2 tile rows x (16*WN) tile columns
   static constexpr int PW = 32 * WN;                 // pixel columns per workgroup (4 pixel rows)
-  static constexpr int RW = PW + 2, RAWP = 6 * RW;   // raw halo tile per channel: 6 rows x (PW + 2)
+  static constexpr int RW = PW + 8, RAWP = 6 * RW;   // raw halo tile per channel: 6 rows x (PW + 8): columns w0-4 .. w0+PW+3, staged
+                                                     // as 16-byte pieces (each fully inside or fully outside the image: W % 4 == 0)
   static constexpr int RAW_FLOATS = CC * RAWP;
   static constexpr int U_FLOATS = CC * 16 * MB, V_FLOATS = CC * 16 * TB;
   static constexpr int NU4 = U_FLOATS / 4 / NT;      // 16-byte filter loads per thread and chunk
-  static constexpr int NRAW = (RAW_FLOATS + NT - 1) / NT;
+  static constexpr int NRAW = (RAW_FLOATS / 4 + NT - 1) / NT;   // 16-byte raw pieces per thread and chunk
   static constexpr int NPAIR = (CC * TB + NT - 1) / NT;   // (channel, tile) patches each thread transforms per chunk
   static_assert((U_FLOATS / 4) % NT == 0, "filter panel must deal evenly");
   static_assert(CC % 2 == 0, "one MFMA = 2 channels");
   // Staging is LDS DMA with a prefetch distance of TWO chunks: at one wave per SIMD (256 accumulator registers) nothing
   // else hides the L2 / HBM latency, and one chunk of MFMAs (CC/2 x 16 x 64 cycles = 1.7 us) is shorter than it.
   // Three filter stages, two raw stages (every wave issues the same number of DMAs per chunk: counted vmcnt), one V.
-  static constexpr int RAW_STAGE = NRAW * NT;        // padded so that all NRAW pieces of every wave land inside the stage
+  static constexpr int RAW_STAGE = NRAW * NT * 4;    // padded so that all NRAW pieces of every wave land inside the stage
   static constexpr int DMA_PER_CHUNK = NU4 + NRAW;
   static constexpr int LDS_FLOATS = 3 * U_FLOATS + V_FLOATS + 2 * RAW_STAGE;
 };
@@ -80,17 +81,17 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_mfma_kernel(const WinoAr
   const int h0 = (trem / tilesW) * 4, w0 = (trem % tilesW) * PW;
   const int m0 = mb * MB;
 
-  // raw staging slots: element e of [CC][6][RW] -> offset in one input plane or -1 (zero padding / unused slot)
+  // raw staging slots: 16-byte piece e of [CC][6][RW/4] -> offset in one input plane or -1 (zero padding / unused slot)
   int so[NRAW];
 #pragma unroll
   for (int i = 0; i < NRAW; ++i) {
     const int e = tid + i * NT;
-    const int r = e % RAWP;
-    const int tr = r / RW, tc = r - tr * RW;
-    const int gh = h0 - 1 + tr, gw = w0 - 1 + tc;
-    so[i] = (e < Cfg::RAW_FLOATS && gh >= 0 && gh < H && gw >= 0 && gw < W) ? gh * W + gw : -1;
+    const int r = e % (RAWP / 4);
+    const int tr = r / (RW / 4), q = r - tr * (RW / 4);
+    const int gh = h0 - 1 + tr, gw = w0 - 4 + 4 * q;
+    so[i] = (e < Cfg::RAW_FLOATS / 4 && gh >= 0 && gh < H && gw >= 0 && gw < W) ? gh * W + gw : -1;
   }
-  const float* zsrc = a.zeros + lane;
+  const float* zsrc = a.zeros + (lane & 15) * 4;
   const int wbase = wave * 64;
   // DMA of chunk k: filter panel -> u_s[ustage], raw halo tile -> raw_s[rstage]; NU4 + NRAW instructions per wave, always
   auto dma_stage = [&](int k, int ustage, int rstage) {
@@ -106,9 +107,9 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_mfma_kernel(const WinoAr
     const float* base = a.src + ((size_t)n * Cin + k * CC) * HW;
 #pragma unroll
     for (int i = 0; i < NRAW; ++i) {
-      const int c = (tid + i * NT) / RAWP;
+      const int c = (tid + i * NT) / (RAWP / 4);
       const bool ok = so[i] >= 0 && k * CC + c < Cin;
-      lds_dma4(ok ? base + (size_t)c * HW + so[i] : zsrc, rs + i * NT + wbase);
+      lds_dma16(ok ? base + (size_t)c * HW + so[i] : zsrc, rs + (i * NT + wbase) * 4);
     }
   };
   // V[c][xi][t] = (B^T d B)[xi] for the 4x4 patch of tile t = (tr, tc): raw rows 2tr .. 2tr+3, columns 2tc .. 2tc+3
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_mfma_kernel(const WinoAr
       if (p >= CC * TB) break;
       const int c = p / TB, t = p - c * TB;
       const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
-      const float* d = rs + c * RAWP + (2 * tr) * RW + 2 * tc;
+      const float* d = rs + c * RAWP + (2 * tr) * RW + 2 * tc + 3;       // tile column 0 = image column w0-1 = staged column 3
       float e[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
