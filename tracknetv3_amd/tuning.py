@@ -34,9 +34,9 @@ def save(configs, meta=None):
 
 # Eval-mode plain layers run in Winograd F(2x2, 3x3) form when the shape qualifies (ops.wino_supported) and the
 # contraction is deep enough for the transforms to pay: measured on MI355X at batch 10 (scripts/wino_sweep.py) it wins
-# 1.22-1.34x on every 64..512-channel layer.  The 27-channel stem stays on the direct kernel.
+# 1.3-1.5x on every 64..512-channel layer and 1.2x on the 27-channel stem; thinner inputs stay on the direct kernel.
 WINOGRAD = os.environ.get("TNV3_WINOGRAD", "1") != "0"      # TNV3_WINOGRAD=0: direct 3x3 kernels everywhere (A/B knob)
-WINOGRAD_MIN_CIN = 64
+WINOGRAD_MIN_CIN = int(os.environ.get("TNV3_WINO_MIN_CIN", "24"))      # measured: the 27-channel stem gains too (0.52 -> 0.42 ms)
 
 
 def use_winograd(cin, cout, h, w):
