@@ -110,6 +110,15 @@ size_t tnv3_dgrad_up2x_packed_floats(int c0, int cout);
 int tnv3_pack_dgrad_up2x_weights(const float* w, float* g, int cout, int cin, int c0, tnv3_stream_t stream);
 int tnv3_dgrad_up2x(const float* dz, const float* g, float* dx_low, int n, int c0, int cout, int h_low, int w_low, tnv3_stream_t stream);
 
+/* Weight gradient of a plain layer (single source, no upsampling) in Winograd F(2x2, 3x3) form: dw[cout][cin][3][3] =
+ * G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- 16 instead of 36 multiply-adds per (co, ci, 2x2 tile); same gradient as
+ * tnv3_conv3x3_wgrad up to fp32 rounding; deterministic (fixed-order split-K sum).
+ *   supported: cin % 64 == 0, cout % 64 == 0, h % 2 == 0, w % 16 == 0;  workspace 16-byte aligned, size from the query. */
+int tnv3_conv3x3_wgrad_wino_supported(int cin, int cout, int h, int w);
+size_t tnv3_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w);
+int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes, int n, int cin, int cout,
+                            int h, int w, tnv3_stream_t stream);
+
 /* Weight gradient of a whole decoder-entry layer, dw[cout][c0+c1][3][3] for the nn.Conv2d applied to
  * cat([Upsample(2)(x_low), skip], dim=1): the c0 upsampled channels through the four parity images of dz and 2x2 tap
  * windows against x_low (16 instead of 36 taps per low-res pixel), the c1 skip channels as an ordinary 3x3 weight gradient.

@@ -76,7 +76,8 @@ def _wgrad_case(case, ops):
             assert rel_err(dx1, xd.grad[:, c0:]) <= 2e-6
 
 
-WGRAD_UP2X_CASES = [(1, 8, 16, 64, 4, 20), (2, 32, 32, 128, 3, 36), (1, 64, 32, 64, 6, 32)]   # (n, c0, c1, cout, h_low, w_low)
+WGRAD_UP2X_CASES = [(1, 8, 16, 64, 4, 20), (2, 32, 32, 128, 3, 36), (1, 64, 32, 64, 6, 32),    # (n, c0, c1, cout, h_low, w_low)
+                    (1, 64, 128, 128, 2, 16)]                                              # skip half on the Winograd-form kernel
 
 
 def _wgrad_up2x_case(case, device):
@@ -97,6 +98,25 @@ def _wgrad_up2x_case(case, device):
 def test_wgrad_up2x_emulated_vs_autograd(emu, case):
     e_all, e_up = _wgrad_up2x_case(case, "cpu")
     assert e_all <= 3e-6 and e_up <= 3e-6, (e_all, e_up)
+
+
+WGRAD_WINO_CASES = [(1, 64, 64, 4, 16), (2, 64, 128, 6, 32), (1, 128, 64, 2, 48)]   # (n, cin, cout, h, w)
+
+
+def _wgrad_wino_case(case, device):
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = case
+    x, dz = torch.relu(T((n, cin, h, w), 51)), T((n, cout, h, w), 52)
+    wd = T((cout, cin, 3, 3), 53, -0.3, 0.3).double().requires_grad_(True)
+    F.conv2d(x.double(), wd, padding=1).backward(dz.double())
+    dw = ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))
+    assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))), "split-K reduction must be deterministic"
+    return rel_err(dw.cpu(), wd.grad)
+
+
+@pytest.mark.parametrize("case", WGRAD_WINO_CASES)
+def test_wgrad_wino_emulated_vs_autograd(emu, case):
+    assert _wgrad_wino_case(case, "cpu") <= 4e-6
 
 
 def test_dgrad_split_destinations_emulated(emu):

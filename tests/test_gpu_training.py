@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from conftest import GOLDEN
 from oracle import nets
-from test_emu_training import T, WGRAD_UP2X_CASES, _wgrad_up2x_case, rel_err
+from test_emu_training import T, WGRAD_UP2X_CASES, WGRAD_WINO_CASES, _wgrad_up2x_case, _wgrad_wino_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -76,6 +76,11 @@ def _wgrad_case(case, ops, d):
 def test_wgrad_up2x_vs_autograd(gpu_device, case):
     e_all, e_up = _wgrad_up2x_case(case, gpu_device)
     assert e_all <= 3e-6 and e_up <= 3e-6, (e_all, e_up)
+
+
+@pytest.mark.parametrize("case", WGRAD_WINO_CASES + [(2, 256, 256, 72, 128), (1, 512, 512, 36, 64), (2, 128, 256, 18, 64)])
+def test_wgrad_wino_vs_autograd(gpu_device, case):
+    assert _wgrad_wino_case(case, gpu_device) <= 5e-6
 
 
 def test_wbce_head_pool_upsample_mixup(gpu_device):

@@ -51,6 +51,9 @@ def _declare(lib):
     sig("tnv3_conv3x3_wino_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wino_pack", i, p, p, i, i, p)
     sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wgrad_wino_supported", i, i, i, i, i)
+    sig("tnv3_conv3x3_wgrad_wino_workspace_bytes", sz, i, i, i, i, i)
+    sig("tnv3_conv3x3_wgrad_wino", i, p, p, p, p, sz, i, i, i, i, i, p)
     sig("tnv3_head1x1_sigmoid", i, p, p, p, p, i, i, i, i, i, p)
     sig("tnv3_maxpool2x2", i, p, p, lg, i, i, p)
     sig("tnv3_conv1d_k3_forward", i, p, p, p, p, p, i, i, i, i, i, i, i, i, p)
@@ -95,6 +98,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_heatmap_box_max", "tnv3_conv3x3_wgrad_variant", "tnv3_conv3x3_forward_add", "tnv3_conv_up2x_packed_floats",
            "tnv3_pack_up2x_weights", "tnv3_conv_up2x_forward", "tnv3_dgrad_up2x_packed_floats", "tnv3_pack_dgrad_up2x_weights",
            "tnv3_dgrad_up2x", "tnv3_conv3x3_wgrad_up2x_workspace_bytes", "tnv3_conv3x3_wgrad_up2x",
+           "tnv3_conv3x3_wgrad_wino_supported", "tnv3_conv3x3_wgrad_wino_workspace_bytes", "tnv3_conv3x3_wgrad_wino",
            "tnv3_conv3x3_wino_variant", "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_forward"]
 
 

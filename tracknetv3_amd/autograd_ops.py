@@ -156,6 +156,9 @@ class _TrackNetTrain(torch.autograd.Function):
             def wgrad():
                 if rec["up"] and rec["x1"] is not None:       # decoder entry: upsampled channels at the low resolution
                     return ops.conv3x3_wgrad_up2x(rec["x0"], rec["x1"], dz)
+                if rec["x1"] is None and not rec["up"] and tuning.use_winograd_wgrad(
+                        int(rec["x0"].shape[1]), blk.conv.out_dim, int(dz.shape[2]), int(dz.shape[3])):
+                    return ops.conv3x3_wgrad_wino(rec["x0"], dz)      # plain deep layer: Winograd-form weight gradient
                 return ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
 
             if side is None:

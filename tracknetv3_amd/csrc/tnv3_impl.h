@@ -15,6 +15,7 @@
 #include "kernels/preproc.h"
 #include "kernels/train_ops.h"
 #include "kernels/wgrad3x3_mfma.h"
+#include "kernels/wgrad_wino_mfma.h"
 
 namespace tnv3 {
 
@@ -544,11 +545,56 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)slabs, dw, nel, p.splitK);
 }
 
+// ---- weight gradient of a plain layer in Winograd F(2x2, 3x3) form (kernels/wgrad_wino_mfma.h)
+inline bool wgrad_wino_supported(int cin, int cout, int h, int w) {
+  return cin > 0 && cout > 0 && cin % 64 == 0 && cout % 64 == 0 && h % 2 == 0 && w % 16 == 0;
+}
+inline int wgrad_wino_splitk(int n, int cin, int cout, int h, int w) {
+  const int nb = (cout / 64) * (cin / 64);
+  const long chunks = (long)n * (h / 2) * (w / 16);
+  const int cus = num_cus();
+  int best_sk = 1;
+  double best = 1e300;
+  const long cap = chunks < 4096 ? chunks : 4096;
+  for (int sk = 1; sk <= cap; ++sk) {
+    const long blocks = (long)nb * sk;
+    if (sk > 1 && blocks > 16l * cus) break;
+    // one workgroup per CU; ~6 chunk-times of prologue + the 256-register slab write per workgroup
+    const double cost = (double)((blocks + cus - 1) / cus) * ((double)((chunks + sk - 1) / sk) + 6.0);
+    if (cost < best - 1e-9) { best = cost; best_sk = sk; }
+  }
+  return best_sk;
+}
+inline size_t wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w) {
+  if (n <= 0 || !wgrad_wino_supported(cin, cout, h, w)) return 0;
+  return kWgradZeroBytes + (size_t)wgrad_wino_splitk(n, cin, cout, h, w) * 16 * cout * cin * sizeof(float);
+}
+
+template <class Launcher>
+int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int n, int cin, int cout,
+                            int h, int w) {
+  if (!x || !dz || !dw || !ws || n <= 0) TNV3_FAIL(-1, "conv3x3_wgrad_wino: bad argument");
+  if (!wgrad_wino_supported(cin, cout, h, w))
+    TNV3_FAIL(-1, "conv3x3_wgrad_wino: needs Cin %% 64 == 0, Cout %% 64 == 0, H %% 2 == 0, W %% 16 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
+  if ((long)(cin > cout ? cin : cout) * h * w >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino: sample too large");
+  if (((uintptr_t)ws) & 15) TNV3_FAIL(-1, "conv3x3_wgrad_wino: workspace must be 16-byte aligned");
+  if (ws_bytes < wgrad_wino_workspace_bytes(n, cin, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad_wino: workspace too small");
+  const int sk = wgrad_wino_splitk(n, cin, cout, h, w);
+  float* slabs = (float*)((char*)ws + kWgradZeroBytes);
+  int rc;
+  if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
+  WgradWinoArgs a{x, dz, (const float*)ws, slabs, n, cin, cout, h, w, sk};
+  if ((rc = L.launch(wgrad_wino_mfma_kernel, (cout / 64) * (cin / 64) * sk, WgradWinoCfg::NT, a))) return rc;
+  return L.launch(wgrad_wino_fold_kernel, grid_for((long)cout * cin, 256, 4096), 256, (const float*)slabs, dw, cout, cin, sk);
+}
+
 // ---- decoder-entry layer: weight gradient with the upsampled channels evaluated at the low resolution (conv_up2x_mfma.h)
 using WgradA4 = WgradCfg<4, 2, 4, 32, 4>;   // 2x2 tap window: 128 co x 64 ci, 8 waves (4 taps reuse a staged tile less than 9 do,
                                             // so the ci block is doubled to keep the flops per staged byte)
 using WgradB4 = WgradCfg<2, 2, 4, 32, 4>;
 struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; };
+// the skip half (a plain layer of c1 -> cout channels at full resolution) takes the Winograd-form kernel where that one wins
+inline bool wgrad_up2x_skip_wino(int c1, int cout, int h, int w) { return c1 >= 128 && cout >= 128 && wgrad_wino_supported(c1, cout, h, w); }
 inline size_t align16f(size_t floats) { return (floats + 3) / 4 * 4; }
 inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, int wl) {
   WgradUpLayout l;
@@ -561,7 +607,8 @@ inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, 
   l.zp = off;      off += align16f((size_t)4 * n * cout * hl * wl);
   l.d4 = off;      off += align16f((size_t)4 * cout * c0 * 4);
   l.dwskip = off;  off += align16f((size_t)cout * c1 * 9);
-  const size_t s_up = (size_t)l.up.splitK * cout * c0 * 4, s_skip = (size_t)l.skip.splitK * cout * c1 * 9;
+  size_t s_up = (size_t)l.up.splitK * cout * c0 * 4, s_skip = (size_t)l.skip.splitK * cout * c1 * 9;
+  if (wgrad_up2x_skip_wino(c1, cout, 2 * hl, 2 * wl)) s_skip = (size_t)wgrad_wino_splitk(n, c1, cout, 2 * hl, 2 * wl) * 16 * cout * c1;
   l.slabs = off;   off += align16f(s_up > s_skip ? s_up : s_skip);
   l.total = off * sizeof(float);
   return l;
@@ -599,7 +646,13 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
     if (rc) return rc;
     if ((rc = reduce(d4 + (size_t)im * cout * c0 * 4, (long)cout * c0 * 4, l.up.splitK))) return rc;
   }
-  {
+  if (wgrad_up2x_skip_wino(c1, cout, h, w)) {
+    const int sk = wgrad_wino_splitk(n, c1, cout, h, w);
+    if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
+    WgradWinoArgs a{skip, dz, (const float*)ws, slabs, n, c1, cout, h, w, sk};
+    if ((rc = L.launch(wgrad_wino_mfma_kernel, (cout / 64) * (c1 / 64) * sk, WgradWinoCfg::NT, a))) return rc;
+    if ((rc = L.launch(wgrad_wino_fold_kernel, grid_for((long)cout * c1, 256, 4096), 256, (const float*)slabs, dwskip, cout, c1, sk))) return rc;
+  } else {
     WgradArgs a{skip, (const float*)nullptr, dz, slabs, n, c1, 0, cout, h, w, 0, l.skip.splitK, (const float*)ws, 0, 0};
     const int grid = l.skip.nMB * l.skip.nCB * l.skip.splitK;
     rc = l.skip.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB>, grid, WgradB::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA>, grid, WgradA::NT, a);

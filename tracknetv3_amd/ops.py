@@ -358,6 +358,26 @@ def conv3x3_wgrad(src0, dz, src1=None, up0=False):
     return dw
 
 
+def wgrad_wino_supported(cin, cout, h, w):
+    return bool(_lib.load().tnv3_conv3x3_wgrad_wino_supported(int(cin), int(cout), int(h), int(w)))
+
+
+def conv3x3_wgrad_wino(x, dz):
+    """dW[Cout][Cin][3][3] of a plain layer in Winograd F(2x2,3x3) form -- see tnv3_conv3x3_wgrad_wino."""
+    lib = _lib.load()
+    _f32(x, dz)
+    _lib.dev_check(x, dz)
+    n, cout, h, w = (int(v) for v in dz.shape)
+    cin = int(x.shape[1])
+    if tuple(x.shape) != (n, cin, h, w):
+        raise _lib.Tnv3Error("conv3x3_wgrad_wino: x and dz must share batch and spatial size")
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dz.device)
+    ws = _workspace(lib.tnv3_conv3x3_wgrad_wino_workspace_bytes(n, cin, cout, h, w), dz.device)
+    _lib.check(lib.tnv3_conv3x3_wgrad_wino(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8, n, cin, cout, h, w,
+                                           _lib.stream_ptr(dz)))
+    return dw
+
+
 def conv3x3_wgrad_up2x(x_low, skip, dz):
     """dW[Cout][C0+C1][3][3] of a decoder-entry layer (X = cat([upsample2x(x_low), skip], 1)), its upsampled channels at the
     low resolution -- see tnv3_conv3x3_wgrad_up2x."""

@@ -44,3 +44,16 @@ def use_winograd(cin, cout, h, w):
         return False
     from . import ops
     return ops.wino_supported(cin, cout, h, w)
+
+
+# The Winograd-form weight gradient wins where the (co, ci) block grid is at least 2 x 2 (both channel counts >= 128:
+# 1.1-1.4x, scripts/wgrad_wino_sweep.py); the 64-channel full-resolution layers stream their strips from HBM with no
+# reuse between workgroups and are faster on the direct kernel.
+WINOGRAD_WGRAD_MIN_CH = 128
+
+
+def use_winograd_wgrad(cin, cout, h, w):
+    if not WINOGRAD or cin < WINOGRAD_WGRAD_MIN_CH or cout < WINOGRAD_WGRAD_MIN_CH:
+        return False
+    from . import ops
+    return ops.wgrad_wino_supported(cin, cout, h, w)
