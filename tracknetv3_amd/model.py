@@ -121,14 +121,13 @@ class Conv2DBlock(nn.Module):
         h, w = int(skip.shape[2]), int(skip.shape[3])
         cfg = tuning.conv_config(self.conv.out_dim, c1, n, h, w)
         bn = self.bn
-        if affine and c1 >= 128 and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # eval mode: the skip half in Winograd form
-            # (measured: with the addend read a 64-channel contraction is too short for the Winograd kernel to win)
+        if affine and c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # eval mode: the skip half in Winograd form
             return ops.conv3x3_wino(skip, self.packed_wino(c0), self.conv.out_dim, mean=bn.running_mean, scale=self.eval_scale(),
                                     shift=bn.bias.detach(), relu=relu, addend=part)
         if affine:
             return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, mean=bn.running_mean, scale=self.eval_scale(),
                                shift=bn.bias.detach(), relu=relu, cfg=cfg)
-        if c1 >= 128 and tuning.use_winograd(c1, self.conv.out_dim, h, w):             # training forward: raw sums
+        if c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # training forward: raw sums
             return ops.conv3x3_wino(skip, self.packed_wino(c0), self.conv.out_dim, addend=part, relu=relu)
         return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, relu=relu, cfg=cfg)
 

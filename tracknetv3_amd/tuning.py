@@ -39,6 +39,9 @@ WINOGRAD = os.environ.get("TNV3_WINOGRAD", "1") != "0"      # TNV3_WINOGRAD=0: d
 WINOGRAD_MIN_CIN = int(os.environ.get("TNV3_WINO_MIN_CIN", "24"))      # measured: the 27-channel stem gains too (0.52 -> 0.42 ms)
 
 
+WINOGRAD_MIN_SKIP = int(os.environ.get("TNV3_WINO_MIN_SKIP", "64"))     # skip half of a decoder entry (addend read in the epilogue)
+
+
 def use_winograd(cin, cout, h, w):
     if not WINOGRAD or cin < WINOGRAD_MIN_CIN:
         return False
