@@ -143,8 +143,8 @@ TRAIN_FLOPS_PER_SAMPLE = 678.2e9    # fwd + dgrad + wgrad (no dgrad f
 # What the matrix pipe executes per sample (GFLOP): the upsampled halves of up_block_{1,2,3}.conv_1 cost 4/9 in all three
 # passes (conv_up2x / dgrad_up2x / 2x2-window wgrad); the plain halves with >= 24 input channels run in Winograd F(2x2,3x3)
 # form (16/36) in forward and data gradient, and those with >= 128 channels on both sides also in the weight gradient.
-#   forward 104.8 (of 227.6), data gradient 96.7 (of 223.0), weight gradient 119.4 (of 227.6)
-TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 320.9e9
+#   forward 98.8 (of 227.6), data gradient 96.7 (of 223.0), weight gradient 119.4 (of 227.6)
+TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 314.9e9
 
 
 def bench_train(args, dev, rank, world):
