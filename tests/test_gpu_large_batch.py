@@ -77,3 +77,59 @@ def test_train_step_beyond_2g_elements_equals_the_replicated_small_batch(gpu_dev
     # fp32 summation order differs (29x the terms per reduction; measured: worst 1.1e-3 on the first layer's filter,
     # median 2.9e-6); garbage from a wrapped offset would be O(1)
     assert errs[worst] <= 1e-2 and med <= 1e-4, (worst, errs[worst], med)
+
+
+N_SEQ = 600_000                  # 600 000 * 256 * 16 = 2.46e9 floats > 2^31 in the widest InpaintNet activation
+
+
+def _inpaintnet(device):
+    from tracknetv3_amd.model import InpaintNet
+    net = InpaintNet()
+    net.load_state_dict(nets.synth_state(nets.inpaintnet_state_shapes(), 77), strict=True)
+    return net.to(device)
+
+
+def test_inpaintnet_beyond_2g_elements(gpu_device):
+    """model.py:100-129 has no cross-sequence term: any slice of a huge batch equals the slice run alone; a training
+    step (train.py:153-164: masked MSE, mean over all elements) on k copies of a small batch has its loss and gradients."""
+    _need_memory(120)
+    d = gpu_device
+    net = _inpaintnet(d).eval()
+    gen = torch.Generator(device=d).manual_seed(9)
+    coor = torch.rand((N_SEQ, 16, 2), device=d, generator=gen)
+    mask = (torch.rand((N_SEQ, 16, 1), device=d, generator=gen) < 0.3).float()
+    with torch.no_grad():
+        out = net(coor, mask)
+        assert out.shape == (N_SEQ, 16, 2) and bool(torch.isfinite(out).all())
+        for lo in (0, 524_280, N_SEQ - 70):              # 524 288 * 256 * 16 = 2^31: the middle slice straddles it
+            part = net(coor[lo:lo + 70].contiguous(), mask[lo:lo + 70].contiguous())
+            assert (out[lo:lo + 70] - part).abs().max().item() <= 1e-6, lo
+    del out
+    torch.cuda.empty_cache()
+
+    n0 = 600
+    k = N_SEQ // n0
+    c0, m0 = coor[:n0].contiguous(), mask[:n0].contiguous()
+    gt0 = torch.rand((n0, 16, 2), device=d, generator=gen)
+
+    def step(c, m, gt):
+        net_t = _inpaintnet(d).train()
+        loss = torch.nn.MSELoss()(net_t(c * (1 - m), m.int()) * m, gt * m)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), {name: p.grad.detach().clone() for name, p in net_t.named_parameters()}
+
+    l_small, g_small = step(c0, m0, gt0)
+    try:
+        l_big, g_big = step(c0.repeat(k, 1, 1), m0.repeat(k, 1, 1), gt0.repeat(k, 1, 1))
+    except torch.cuda.OutOfMemoryError:
+        pytest.skip("the caching allocator could not fit the N=%d training step" % N_SEQ)
+    torch.cuda.empty_cache()
+    assert abs(l_big - l_small) <= 2e-6 * max(1e-3, abs(l_small)), (l_big, l_small)
+    worst = 0.0
+    for name, g in g_small.items():
+        ref = g.double()
+        e = ((g_big[name].double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+        worst = max(worst, e)
+        assert e <= 1e-3, (name, e)
+    print("InpaintNet large-batch gradient deviation: worst %.3e" % worst)
