@@ -367,7 +367,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/conv_traffic.json)",
-                         "kernel": f"conv3x3_wino_mfma_kernel<*> + conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} "
+                         "kernel": f"conv3x3_wino_split_mfma_kernel<*> + conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} "
                                    "launches/step for the 17 conv layers, fp32 MFMA 32x32x2)",
                          "avg_launch_ms": round(conv_ms / launches_per_step, 4), "conv_ms_per_step": round(conv_ms, 4),
                          "algorithmic_gflop_per_step": round(float(fl.sum()) / 1e9, 3),

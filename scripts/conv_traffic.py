@@ -6,7 +6,7 @@ import csv, json, sys
 def conv_sum(path, counter):
     tot, disp = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if any(k in r["kernel"] for k in ("conv3x3_mfma_kernel", "conv_up2x_mfma_kernel", "conv3x3_wino_mfma_kernel")) and r["counter"] == counter:
+        if any(k in r["kernel"] for k in ("conv3x3_mfma_kernel", "conv_up2x_mfma_kernel", "conv3x3_wino_mfma_kernel", "conv3x3_wino_split_mfma_kernel")) and r["counter"] == counter:
             tot += float(r["sum"]); disp += int(r["dispatches"])
     return tot, disp
 

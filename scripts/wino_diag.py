@@ -14,7 +14,9 @@ def main():
         u = ops.pack_wino_weights((torch.rand(cout, cin, 3, 3, device=dev) - 0.5) * 0.1)
         gf = 2.0 * 16 * cin * cout * (h // 2) * (w // 2) * 10 / 1e9
         row = {}
-        for name, v in (("production", 0), ("no_dma", 11), ("no_dma_no_transform", 12), ("no_dma_no_transform_no_barrier", 13)):
+        for name, v in (("production", 0), ("no_dma", 11), ("no_dma_no_transform", 12), ("no_dma_no_transform_no_barrier", 13),
+                        ("xisplit", 2), ("xisplit_dma_no_transform", 24), ("xisplit_dma_transform_no_writes", 25), ("xisplit_dma_transform_no_reads", 26), ("xisplit_no_dma", 21), ("xisplit_no_dma_no_transform", 22),
+                        ("xisplit_no_dma_no_transform_no_barrier", 23)):
             old = ops.wino_variant(v)
             try:
                 for _ in range(3):

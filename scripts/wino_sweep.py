@@ -33,10 +33,17 @@ def main():
         err = ((a - b).abs().max() / a.abs().max()).item()
         t_d = timeit(lambda: ops.conv3x3(x, wp, cout, mean=mu, scale=sc, shift=sh, relu=True, cfg=cfg))
         t_w = timeit(lambda: ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True))
+        other = 2 if ops.wino_variant() == 0 else 0                  # the other Winograd kernel (0: one wave / SIMD, 2: xi-split)
+        old = ops.wino_variant(other)
+        c = ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True)
+        t_o = timeit(lambda: ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True))
+        ops.wino_variant(old)
+        err_o = ((a - c).abs().max() / a.abs().max()).item()
         gf = 2.0 * 9 * cin * cout * h * w * n / 1e9
         out[f"{cout},{cin},{n},{h},{w}"] = {"direct_ms": round(t_d, 4), "wino_ms": round(t_w, 4), "direct_tflops": round(gf / t_d, 1),
                                            "wino_algorithmic_tflops": round(gf / t_w, 1), "wino_executed_tflops": round(gf * 16 / 36 / t_w, 1),
-                                           "rel_diff": float(f"{err:.2e}")}
+                                           "rel_diff": float(f"{err:.2e}"),
+                                           "variant%d_ms" % other: round(t_o, 4), "variant%d_rel_diff" % other: float(f"{err_o:.2e}")}
     print(json.dumps(out, indent=1))
 
 

@@ -167,7 +167,7 @@ def _wino_case(n, cin, cout, h, w, device):
     return ((got_plain - ref_plain).abs().max() / s).item(), ((got_full - ref_full).abs().max() / s).item()
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["phased", "interleaved"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["phased", "interleaved", "xisplit"])
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv3x3_wino_emulated_vs_torch(emu, case, variant):
     from tracknetv3_amd import ops

@@ -125,7 +125,7 @@ def load():
     if lib.tnv3_abi_version() != 1:
         raise Tnv3Error("libtnv3_hip.so ABI version mismatch")
     _lib, _is_emulator = lib, False
-    if os.environ.get("TNV3_WINO_VARIANT", "") in ("0", "1"):         # diagnostic: Winograd kernel with / without interleaved transform
+    if os.environ.get("TNV3_WINO_VARIANT", "") in ("0", "1", "2"):    # pick the Winograd forward kernel (ops.wino_variant; default 2)
         lib.tnv3_conv3x3_wino_variant(int(os.environ["TNV3_WINO_VARIANT"]))
     if os.environ.get("TNV3_WGRAD_VARIANT", "") in ("0", "1"):       # diagnostic: pick the weight-gradient kernel family
         lib.tnv3_conv3x3_wgrad_variant(int(os.environ["TNV3_WGRAD_VARIANT"]))

@@ -435,6 +435,237 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_il_mfma_kernel(const Win
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// xi-split kernel (the production one): the same 64-channel x 64-tile workgroup tile, but EIGHT waves.  Waves 0..3
+// ("group 0") accumulate the transform rows xi = 0..7 of their 32 x 32 sub-tile, waves 4..7 ("group 1") the rows
+// xi = 8..15: 128 accumulator registers per wave, so two waves share a SIMD.  Within a chunk the groups run in opposite
+// order -- group 0 issues the chunk's LDS DMAs, transforms its half of the next chunk's patches and THEN runs its 32
+// MFMAs; group 1 runs its MFMAs FIRST and transforms afterwards -- so on every SIMD one wave can feed the matrix pipe
+// while the other does the DMA bookkeeping, the adds and the LDS traffic of the patch transform.  The next chunk's V
+// goes to a second V stage (nobody waits for the current one to be drained), which leaves ONE barrier per chunk.
+// Everything a chunk issues by DMA (filters of chunk k+1, raw tile of chunk k+2) has the whole chunk to land: plain
+// vmcnt(0) before the barrier.
+// LDS: 2 filter stages + 2 V stages + 2 raw stages = 160 KB.  The two halves of A^T M A meet through LDS at the end:
+// group g finishes output row g of every 2 x 2 tile.
+// Measured (scripts/wino_diag.py, profiles/r01_wino_split_diag.json): 5-6 % faster than the one-wave-per-SIMD kernel
+// above, NOT the 1.4x a perfect overlap would give: its timing twins show that the DMA pieces and the transform still
+// cost (nearly) their full time next to another wave's MFMAs, additively, and neither a deeper operand ring nor wave
+// priorities change that -- consistent with the fp32 MFMA sharing issue / execution resources with the other
+// instruction classes of its SIMD, in which case the lever is the NUMBER of non-MFMA instructions, not their placement.
+template <int CC_, int DIAG_ = 0>
+struct WinoSplitCfg {
+  static constexpr int WM = 2, WN = 2, CC = CC_;
+  static constexpr int DIAG = DIAG_;   // timing twins (WRONG results): 1 = no DMA after the prologue, 2 = + no patch transform, 3 = + no barriers;
+                                       // with DMA: 4 = no patch transform, 5 = transform without its V writes, 6 = without its raw reads
+  static constexpr int NT = 2 * WM * WN * 64;
+  static constexpr int MB = 32 * WM, TB = 32 * WN, PW = 32 * WN;
+  static constexpr int RW = PW + 8, RAWP = 6 * RW;
+  static constexpr int RAW_FLOATS = CC * RAWP;
+  static constexpr int U_FLOATS = CC * 16 * MB, V_FLOATS = CC * 16 * TB;
+  static constexpr int NTD = NT / 2;                 // group 0 issues every DMA of a chunk (while group 1 is already in its MFMAs)
+  static constexpr int NU4 = U_FLOATS / 4 / NTD;
+  static constexpr int NRAW = (RAW_FLOATS / 4 + NTD - 1) / NTD;
+  static constexpr int RAW_STAGE = NRAW * NTD * 4;
+  static constexpr int LDS_FLOATS = 2 * U_FLOATS + 2 * V_FLOATS + 2 * RAW_STAGE;
+  static constexpr int XCH_FLOATS = (NT / 64) * 32 * 64;            // epilogue exchange: 32 floats per lane
+  static_assert((U_FLOATS / 4) % NTD == 0, "filter panel must deal evenly");
+  static_assert(CC * TB == NT, "one patch per thread and chunk");
+  static_assert(XCH_FLOATS <= 2 * U_FLOATS, "the exchange reuses the filter stages");
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_split_mfma_kernel(const WinoArgs a) {
+  constexpr int WN = Cfg::WN, CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, PW = Cfg::PW, RW = Cfg::RW, RAWP = Cfg::RAWP;
+  constexpr int NU4 = Cfg::NU4, NRAW = Cfg::NRAW, NTD = Cfg::NTD;
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  float* u_s = lds;                                   // two stages
+  float* v_s = lds + 2 * Cfg::U_FLOATS;               // two stages
+  float* raw_s = v_s + 2 * Cfg::V_FLOATS;             // two stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int wn = wq % WN, wm = wq / WN;
+  const int half = lane >> 5, bl = lane & 31;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+  const int tilesH = H / 4, tilesW = W / PW;
+  const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
+  int mb, pt;
+  if (!conv_block_map(blockIdx.x, nMB, nPT, mb, pt)) return;
+  const int n = pt / (tilesH * tilesW);
+  const int trem = pt - n * (tilesH * tilesW);
+  const int h0 = (trem / tilesW) * 4, w0 = (trem % tilesW) * PW;
+  const int m0 = mb * MB;
+
+  int so[NRAW];
+#pragma unroll
+  for (int i = 0; i < NRAW; ++i) {                    // DMA slots of group 0 (tid < NTD); group 1 never uses them
+    const int e = (tid & (NTD - 1)) + i * NTD;
+    const int r = e % (RAWP / 4);
+    const int tr = r / (RW / 4), q = r - tr * (RW / 4);
+    const int gh = h0 - 1 + tr, gw = w0 - 4 + 4 * q;
+    so[i] = (e < Cfg::RAW_FLOATS / 4 && gh >= 0 && gh < H && gw >= 0 && gw < W) ? gh * W + gw : -1;
+  }
+  const float* zsrc = a.zeros + (lane & 15) * 4;
+  const int wbase = wave * 64;
+  auto dma_u = [&](int k) {
+    float* us = u_s + (k & 1) * Cfg::U_FLOATS;
+    const float* usrc = a.u + (size_t)k * CC * 16 * Cout + m0;
+#pragma unroll
+    for (int i = 0; i < NU4; ++i) {
+      const int e4 = tid + i * NTD;
+      const int row = e4 / (MB / 4), m4 = e4 - row * (MB / 4);
+      lds_dma16(usrc + (size_t)row * Cout + m4 * 4, us + (i * NTD + wbase) * 4);
+    }
+  };
+  auto dma_raw = [&](int k) {
+    float* rs = raw_s + (k & 1) * Cfg::RAW_STAGE;
+    const float* base = a.src + ((size_t)n * Cin + k * CC) * HW;
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) {
+      const int c = (tid + i * NTD) / (RAWP / 4);
+      const bool ok = so[i] >= 0 && k * CC + c < Cin;
+      lds_dma16(ok ? base + (size_t)c * HW + so[i] : zsrc, rs + (i * NTD + wbase) * 4);
+    }
+  };
+  // this thread's patch of a chunk: channel tid / TB, tile tid % TB  (group 0 = channels 0..CC/2-1, group 1 the rest)
+  const int pc = tid / TB, ptile = tid - pc * TB;
+  const int ptr_ = ptile / (TB / 2), ptc = ptile - ptr_ * (TB / 2);
+  const int t_src = pc * RAWP + (2 * ptr_) * RW + 2 * ptc + 3;
+  const int t_dst = (pc * 16) * TB + ptile;
+  auto transform = [&](int stage) {                     // raw stage -> V stage of the same parity
+    const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src;
+    float e[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float d0, d1, d2, d3;
+      if (Cfg::DIAG == 6) { d0 = (float)(tid + j); d1 = (float)(tid - j); d2 = (float)(tid * j); d3 = (float)(stage + j); }
+      else { d0 = d[j]; d1 = d[RW + j]; d2 = d[2 * RW + j]; d3 = d[3 * RW + j]; }
+      e[0][j] = d0 - d2; e[1][j] = d1 + d2; e[2][j] = d2 - d1; e[3][j] = d1 - d3;
+    }
+    float* v = v_s + stage * Cfg::V_FLOATS + t_dst;
+    if (Cfg::DIAG == 5 && a.N > 0) {                    // keep the reads and adds alive without storing
+      float sum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += (e[r][0] - e[r][2]) * (e[r][1] + e[r][2]) + (e[r][2] - e[r][1]) * (e[r][1] - e[r][3]);
+      if (sum == 1234.5678f) v[0] = sum;
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[(r * 4 + 0) * TB] = e[r][0] - e[r][2];
+      v[(r * 4 + 1) * TB] = e[r][1] + e[r][2];
+      v[(r * 4 + 2) * TB] = e[r][2] - e[r][1];
+      v[(r * 4 + 3) * TB] = e[r][1] - e[r][3];
+    }
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+
+  const int a_off = (half * 16 + grp * 8) * MB + wm * 32 + bl;
+  const int b_off = (half * 16 + grp * 8) * TB + wn * 32 + bl;
+  auto mfma_chunk = [&](int k) {
+    const float* A = u_s + (k & 1) * Cfg::U_FLOATS + a_off;
+    const float* B = v_s + (k & 1) * Cfg::V_FLOATS + b_off;
+    constexpr int NSTEP = (CC / 2) * 8;                  // (channel pair, xi of this group): one MFMA each
+    constexpr int PF = 4, RING = PF + 1;                // deeper rings / raised wave priority measured: no effect
+    float av[RING], bv[RING];
+    auto read_step = [&](int s) {
+      const int cp = s >> 3, x = s & 7;
+      av[s % RING] = A[(2 * cp * 16 + x) * MB];
+      bv[s % RING] = B[(2 * cp * 16 + x) * TB];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) read_step(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + PF < NSTEP) read_step(s + PF);
+      acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s & 7], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+  auto chunk_barrier = [&]() {                          // DMAs landed, V writes visible, everybody done with the old stages
+    __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+  };
+
+  const int nChunks = (Cin + CC - 1) / CC;
+  if (grp == 0) {
+    dma_u(0);
+    dma_raw(0);
+    if (nChunks > 1) dma_raw(1);
+  }
+  chunk_barrier();
+  transform(0);
+  chunk_barrier();
+  for (int k = 0; k < nChunks; ++k) {
+    // free since the barrier that ended chunk k-1: filter stage (k+1)&1 (held chunk k-1) and raw stage k&1 (held chunk k,
+    // transformed during chunk k-1)
+    constexpr bool kDma = Cfg::DIAG < 1 || Cfg::DIAG > 3, kTransform = Cfg::DIAG < 2 || Cfg::DIAG > 4;
+    const bool more = k + 1 < nChunks && kTransform;
+    if (grp == 0) {
+      if (k + 1 < nChunks && kDma) dma_u(k + 1);
+      if (k + 2 < nChunks && kDma) dma_raw(k + 2);
+      if (more) transform((k + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_chunk(k);
+    } else {
+      mfma_chunk(k);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) transform((k + 1) & 1);
+    }
+    if (Cfg::DIAG != 3) chunk_barrier();
+  }
+
+  // ---- inverse transform: rows of A^T M (this group's two xi rows), columns, then the halves meet through LDS
+  float pv[16][2][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float tt[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = acc[j][r], hi = acc[4 + j][r];    // M rows 2*grp and 2*grp + 1
+      tt[0][j] = grp ? lo : lo + hi;                     // A^T row 0 = [1 1 1 0]
+      tt[1][j] = grp ? -lo - hi : hi;                    // A^T row 1 = [0 1 -1 -1]
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      pv[r][y][0] = tt[y][0] + tt[y][1] + tt[y][2];
+      pv[r][y][1] = tt[y][1] - tt[y][2] - tt[y][3];
+    }
+  }
+  float* xch = lds;                                      // all stages are free after the last chunk barrier
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) xch[(wave * 32 + r * 2 + x) * 64 + lane] = grp ? pv[r][0][x] : pv[r][1][x];
+  __syncthreads();
+  const bool has_affine = a.scale != nullptr;
+  const int t = wn * 32 + bl;
+  const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
+  const int oh = h0 + 2 * tr + grp, ow = w0 + 2 * tc;    // group g finishes output row g of the tile
+  typedef float wf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    wf2 v;
+    v[0] = (grp ? pv[r][1][0] : pv[r][0][0]) + xch[((wave ^ 4) * 32 + r * 2 + 0) * 64 + lane];
+    v[1] = (grp ? pv[r][1][1] : pv[r][0][1]) + xch[((wave ^ 4) * 32 + r * 2 + 1) * 64 + lane];
+    float mu = 0.0f, sc = 1.0f, sh = 0.0f;
+    if (has_affine) { mu = a.mean ? a.mean[co] : 0.0f; sc = a.scale[co]; sh = a.shift[co]; }
+    const size_t o = ((size_t)n * Cout + co) * HW + (size_t)oh * W + ow;
+    if (a.addend) { const wf2 ad = *reinterpret_cast<const wf2*>(a.addend + o); v[0] += ad[0]; v[1] += ad[1]; }
+    if (has_affine) { v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh; }
+    if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
+    *reinterpret_cast<wf2*>(a.dst + o) = v;
+  }
+}
+
 // U[Cin_pad][xi = i*4+j][Cout] = (G g G^T)[i][j] from W[Cout][Cin][3][3]; rows ci >= Cin are zero
 __global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad) {
   const long body = (long)CinPad * 16 * Cout, total = body + kPackZeroTail;

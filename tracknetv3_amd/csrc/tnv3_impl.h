@@ -348,9 +348,10 @@ int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const fl
 
 // ---- Winograd F(2x2, 3x3) form of the plain eval-mode layer (kernels/conv3x3_wino_mfma.h)
 using WinoA = WinoCfg<2, 2, 8>;              // 64 channels x 64 tiles (4 x 64 pixels), 256 threads, 8-channel chunks
+using WinoSplit = WinoSplitCfg<8>;          // same tile, 512 threads: two wave groups split the 16 transform rows (2 waves / SIMD)
 using WinoIl = WinoIlCfg<2, 2, 6>;           // same tile, 6-channel chunks, patch transform interleaved with the MFMAs
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
-inline int& wino_variant() { static int v = 0; return v; }   // 0: WinoA (default, measured faster), 1: WinoIl (diagnostic knob)
+inline int& wino_variant() { static int v = 2; return v; }   // 2: WinoSplit (default, fastest), 0: WinoA (one wave / SIMD), 1: WinoIl; 11.., 21..: timing twins
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
   return (size_t)round_up(cin, kWinoCinPad) * 16 * cout + kPackZeroTail;
@@ -378,12 +379,20 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
   WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0};
   const long npt = (long)n * (h / 4) * (w / WinoA::PW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino: too many pixel tiles");
-  switch (wino_variant()) {          // 11..13: timing twins of WinoA (wrong results by design, scripts/wino_diag.py)
+  switch (wino_variant()) {          // 11..13 / 21..26: timing twins of WinoA / WinoSplit (wrong results by design, scripts/wino_diag.py)
     case 11: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 1>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
     case 12: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 2>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
     case 13: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 3>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
+    case 21: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 1>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
+    case 22: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 2>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
+    case 23: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 3>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
+    case 24: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 4>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
+    case 25: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 5>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
+    case 26: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 6>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
     default: break;
   }
+  if (wino_variant() == 2)
+    return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplit>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
   if (wino_variant() == 1)
     return L.launch(conv3x3_wino_il_mfma_kernel<WinoIl>, conv_grid_blocks(cout / WinoIl::MB, (int)npt), WinoIl::NT, a);
   return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);

@@ -54,7 +54,9 @@ def bn_eval_scale(gamma, running_var, eps=BN_EPS):
 
 
 def wino_variant(variant=-1):
-    """Select (1: transform interleaved with the MFMAs, 0: separate phase) or query (-1) the Winograd kernel; returns the old one."""
+    """Select or query (-1) the Winograd forward kernel; returns the old value.  2: xi-split, two waves per SIMD (default);
+    0: one wave per SIMD, separate transform phase; 1: transform interleaved with the MFMAs; 11-13 / 21-26: timing twins
+    with wrong results (scripts/wino_diag.py)."""
     return int(_lib.load().tnv3_conv3x3_wino_variant(int(variant)))
 
 
