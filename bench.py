@@ -142,9 +142,10 @@ def cpu_baseline(budget_s=25.0):
 TRAIN_FLOPS_PER_SAMPLE = 678.2e9    # fwd + dgrad + wgrad (no dgrad for the first layer)
 # What the matrix pipe executes per sample (GFLOP): the upsampled halves of up_block_{1,2,3}.conv_1 cost 4/9 in all three
 # passes (conv_up2x / dgrad_up2x / 2x2-window wgrad); the plain halves with >= 24 input channels run in Winograd F(2x2,3x3)
-# form (16/36) in forward and data gradient, and those with >= 128 channels on both sides also in the weight gradient.
-#   forward 98.8 (of 227.6), data gradient 96.7 (of 223.0), weight gradient 119.4 (of 227.6)
-TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 314.9e9
+# form (16/36) in forward and data gradient, and those with >= 64 channels on both sides also in the weight gradient
+# (everything but the first layer).
+#   forward 98.7 (of 227.6), data gradient 96.6 (of 223.0), weight gradient 101.2 (of 227.6)
+TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 296.5e9
 
 
 def bench_train(args, dev, rank, world):
@@ -197,7 +198,7 @@ def bench_train(args, dev, rank, world):
                          "executed_tflops": round(TRAIN_FLOPS_EXECUTED_PER_SAMPLE * args.batch / (ms * 1e-3) / 1e12, 2),
                          "note": "`achieved` counts the reference's algorithmic FLOPs (SURVEY 8d); the upsampled channels of the three "
                                  "decoder-entry layers are evaluated at the low resolution in forward, dgrad and wgrad (4/9 of those MACs) "
-                                 "and the plain layers run in fused Winograd F(2x2,3x3) form (16/36) in forward, data gradient and -- from 128 "
+                                 "and the plain layers run in fused Winograd F(2x2,3x3) form (16/36) in forward, data gradient and -- from 64 "
                                  "channels -- weight gradient"},
             "cpu_baseline": None, "final_loss": round(float(loss.item()), 6)}), flush=True)
     if world > 1:

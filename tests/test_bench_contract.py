@@ -34,8 +34,7 @@ def test_training_flop_constants():
     plain = 9 * 10.872 + 4 * 5.436                                # the 13 plain layers with >= 64 channels
     fwd = 4.586 * 16 / 36 + plain * 16 / 36 + up * 4 / 9 + 3 * 10.872 * 16 / 36
     dgrad = plain * 16 / 36 + up * 4 / 9 + 3 * 10.872 * 16 / 36
-    wino_w = 10 * 10.872 + 2 * 5.436                              # >= 128 channels on both sides (incl. two skip halves)
-    wgrad = 4.586 + (plain - (wino_w - 2 * 10.872)) + wino_w * 16 / 36 + up * 4 / 9 + 10.872
+    wgrad = 4.586 + plain * 16 / 36 + up * 4 / 9 + 3 * 10.872 * 16 / 36      # only the first layer keeps the direct kernel
     assert abs((fwd + dgrad + wgrad) - b.TRAIN_FLOPS_EXECUTED_PER_SAMPLE / 1e9) < 1.5
 
 

@@ -196,34 +196,54 @@ __global__ void __launch_bounds__(WgradWinoCfg::NT) wgrad_wino_mfma_kernel(const
     }
 }
 
-// dW[co][ci][3][3] = G^T (sum_ks part[ks][.][co][ci]) G;  one thread per (co, ci); fixed summation order over ks (fp64 accumulate)
+// dW[co][ci][3][3] = G^T (sum_ks part[ks][.][co][ci]) G.
+// A block folds 16 (co, ci) elements: thread = (element el, xi row q, quarter p of the ks range) sums four xi over its
+// quarter in fp64; the quarters are combined in the fixed order p = 0..3 through LDS (deterministic), then 48 threads
+// apply G^T . G, three outputs each.  One thread per element (the first version) left a 128 x 128 layer with 64 blocks
+// walking 1024 dependent-latency loads each: 0.3 ms per launch for 67 MB.
 __global__ void __launch_bounds__(256) wgrad_wino_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout, int Cin,
                                                               int splitK) {
+  __shared__ double red[4][16][16];                  // [p][xi][el]
+  __shared__ float us[16][16];                       // [xi][el]
   const long n = (long)Cout * Cin;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    float u[16];
+  const int tid = threadIdx.x, el = tid & 15, q = (tid >> 4) & 3, p = tid >> 6;
+  const int kq = (splitK + 3) / 4;
+  const int k0 = p * kq, k1 = (k0 + kq < splitK) ? k0 + kq : splitK;
+  for (long e0 = (long)blockIdx.x * 16; e0 < n; e0 += (long)gridDim.x * 16) {
+    const long e = e0 + el;
+    const bool live = e < n;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (live)
+      for (int k = k0; k < k1; ++k) {
+        const float* src = part + ((size_t)k * 16 + 4 * q) * n + e;
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) {
-      double s = 0.0;
-      for (int k = 0; k < splitK; ++k) s += (double)part[((size_t)k * 16 + xi) * n + e];
-      u[xi] = (float)s;
-    }
-    // t = G^T u (3x4), dW = t G (3x3);  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
-    float t[3][4];
+        for (int j = 0; j < 4; ++j) s[j] += (double)src[(size_t)j * n];
+      }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float u0 = u[j], u1 = u[4 + j], u2 = u[8 + j], u3 = u[12 + j];
-      t[0][j] = u0 + 0.5f * (u1 + u2);
-      t[1][j] = 0.5f * (u1 - u2);
-      t[2][j] = 0.5f * (u1 + u2) + u3;
-    }
-    float* o = dw + e * 9;
+    for (int j = 0; j < 4; ++j) red[p][4 * q + j][el] = s[j];
+    __syncthreads();
+    if (p == 0) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      o[r * 3 + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
-      o[r * 3 + 1] = 0.5f * (t[r][1] - t[r][2]);
-      o[r * 3 + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+      for (int j = 0; j < 4; ++j) {
+        const int xi = 4 * q + j;
+        us[xi][el] = (float)(((red[0][xi][el] + red[1][xi][el]) + red[2][xi][el]) + red[3][xi][el]);
+      }
     }
+    __syncthreads();
+    if (p == 0 && q < 3 && live) {
+      // t = G^T u (3x4), dW = t G (3x3);  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]; this thread: row r = q of dW
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u0 = us[j][el], u1 = us[4 + j][el], u2 = us[8 + j][el], u3 = us[12 + j][el];
+        t[j] = q == 0 ? u0 + 0.5f * (u1 + u2) : (q == 1 ? 0.5f * (u1 - u2) : 0.5f * (u1 + u2) + u3);
+      }
+      float* o = dw + e * 9 + q * 3;
+      o[0] = t[0] + 0.5f * (t[1] + t[2]);
+      o[1] = 0.5f * (t[1] - t[2]);
+      o[2] = 0.5f * (t[1] + t[2]) + t[3];
+    }
+    __syncthreads();
   }
 }
 

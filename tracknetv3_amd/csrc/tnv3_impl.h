@@ -558,6 +558,7 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
 inline bool wgrad_wino_supported(int cin, int cout, int h, int w) {
   return cin > 0 && cout > 0 && cin % 64 == 0 && cout % 64 == 0 && h % 2 == 0 && w % 16 == 0;
 }
+inline int wgrad_wino_fold_blocks(long elements) { const long b = (elements + 15) / 16; return (int)(b > 65536 ? 65536 : b); }   // 16 elements per block
 inline int wgrad_wino_splitk(int n, int cin, int cout, int h, int w) {
   const int nb = (cout / 64) * (cin / 64);
   const long chunks = (long)n * (h / 2) * (w / 16);
@@ -594,7 +595,7 @@ int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float*
   if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
   WgradWinoArgs a{x, dz, (const float*)ws, slabs, n, cin, cout, h, w, sk};
   if ((rc = L.launch(wgrad_wino_mfma_kernel, (cout / 64) * (cin / 64) * sk, WgradWinoCfg::NT, a))) return rc;
-  return L.launch(wgrad_wino_fold_kernel, grid_for((long)cout * cin, 256, 4096), 256, (const float*)slabs, dw, cout, cin, sk);
+  return L.launch(wgrad_wino_fold_kernel, wgrad_wino_fold_blocks((long)cout * cin), 256, (const float*)slabs, dw, cout, cin, sk);
 }
 
 // ---- decoder-entry layer: weight gradient with the upsampled channels evaluated at the low resolution (conv_up2x_mfma.h)
@@ -603,7 +604,7 @@ using WgradA4 = WgradCfg<4, 2, 4, 32, 4>;   // 2x2 tap window: 128 co x 64 ci, 8
 using WgradB4 = WgradCfg<2, 2, 4, 32, 4>;
 struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; };
 // the skip half (a plain layer of c1 -> cout channels at full resolution) takes the Winograd-form kernel where that one wins
-inline bool wgrad_up2x_skip_wino(int c1, int cout, int h, int w) { return c1 >= 128 && cout >= 128 && wgrad_wino_supported(c1, cout, h, w); }
+inline bool wgrad_up2x_skip_wino(int c1, int cout, int h, int w) { return wgrad_wino_supported(c1, cout, h, w); }   // 64-multiples: Winograd form
 inline size_t align16f(size_t floats) { return (floats + 3) / 4 * 4; }
 inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, int wl) {
   WgradUpLayout l;
@@ -660,7 +661,7 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
     if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
     WgradWinoArgs a{skip, dz, (const float*)ws, slabs, n, c1, cout, h, w, sk};
     if ((rc = L.launch(wgrad_wino_mfma_kernel, (cout / 64) * (c1 / 64) * sk, WgradWinoCfg::NT, a))) return rc;
-    if ((rc = L.launch(wgrad_wino_fold_kernel, grid_for((long)cout * c1, 256, 4096), 256, (const float*)slabs, dwskip, cout, c1, sk))) return rc;
+    if ((rc = L.launch(wgrad_wino_fold_kernel, wgrad_wino_fold_blocks((long)cout * c1), 256, (const float*)slabs, dwskip, cout, c1, sk))) return rc;
   } else {
     WgradArgs a{skip, (const float*)nullptr, dz, slabs, n, c1, 0, cout, h, w, 0, l.skip.splitK, (const float*)ws, 0, 0};
     const int grid = l.skip.nMB * l.skip.nCB * l.skip.splitK;

@@ -49,10 +49,10 @@ def use_winograd(cin, cout, h, w):
     return ops.wino_supported(cin, cout, h, w)
 
 
-# The Winograd-form weight gradient wins where the (co, ci) block grid is at least 2 x 2 (both channel counts >= 128:
-# 1.1-1.4x, scripts/wgrad_wino_sweep.py); the 64-channel full-resolution layers stream their strips from HBM with no
-# reuse between workgroups and are faster on the direct kernel.
-WINOGRAD_WGRAD_MIN_CH = 128
+# The Winograd-form weight gradient is 1.35-1.5x faster than the direct kernel on every plain layer shape from 64
+# channels up (scripts/wgrad_wino_sweep.py).  (It used to lose on the 64-channel layers -- because of its split-K fold,
+# not the MFMA kernel: a few blocks walking hundreds of slabs serially; fixed in wgrad_wino_fold_kernel.)
+WINOGRAD_WGRAD_MIN_CH = int(os.environ.get("TNV3_WINO_WGRAD_MIN_CH", "64"))
 
 
 def use_winograd_wgrad(cin, cout, h, w):
