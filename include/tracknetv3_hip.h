@@ -190,11 +190,13 @@ int tnv3_bn_train_forward(const float* z, const float* gamma, const float* beta,
                           float* save_invstd, void* workspace, size_t workspace_bytes, int n, int c, int hw,
                           tnv3_stream_t stream);
 
-/* Backward of the same: given dA (gradient w.r.t. a), a, z and the saved statistics, writes dZ (may alias dA),
- * dgamma[C], dbeta[C]. */
-int tnv3_bn_relu_backward(const float* da, const float* a, const float* z, const float* gamma, const float* save_mean,
-                          const float* save_invstd, float* dz, float* dgamma, float* dbeta, void* workspace,
-                          size_t workspace_bytes, int n, int c, int hw, tnv3_stream_t stream);
+/* Backward of the same: given dA (gradient w.r.t. a), z and the saved statistics, writes dZ (may alias dA),
+ * dgamma[C], dbeta[C].  The ReLU mask comes from `a` when it is given; with a == NULL it is recomputed from z, gamma, beta
+ * and the saved statistics with the forward's own expression (bit-identical to a > 0, one tensor less to read per pass):
+ * gamma / beta must then still hold the values of the forward call.  One of a, beta must be non-NULL. */
+int tnv3_bn_relu_backward(const float* da, const float* a, const float* z, const float* gamma, const float* beta,
+                          const float* save_mean, const float* save_invstd, float* dz, float* dgamma, float* dbeta,
+                          void* workspace, size_t workspace_bytes, int n, int c, int hw, tnv3_stream_t stream);
 
 /* Data gradient of Conv2DBlock's convolution: dX = conv3x3(dZ, W^T with flipped taps).  wpack_t comes from
  * tnv3_pack_conv3x3_weights(..., transpose_flip = 1).  The first c0 input-channel gradients go to dx0

@@ -20,7 +20,7 @@ def rel_err(a, b):
 
 
 def test_bn_train_forward_backward_emulated(emu):
-    from tracknetv3_amd import ops
+    from tracknetv3_amd import ops, _lib
     n, c, h, w = 3, 70, 4, 8
     z = T((n, c, h, w), 1, -2, 3)
     g, b = T((c,), 2, 0.5, 1.5), T((c,), 3)
@@ -41,6 +41,11 @@ def test_bn_train_forward_backward_emulated(emu):
     ref.backward(da.double())
     dz, dgamma, dbeta = ops.bn_relu_backward(da.clone(), a, z, g, mean, invstd)
     assert rel_err(dz, zd.grad) <= 1e-5 and rel_err(dgamma, gd.grad) <= 1e-5 and rel_err(dbeta, bd.grad) <= 1e-5
+    # mask recomputed from z instead of read from a: bit-identical results
+    dz2, dgamma2, dbeta2 = ops.bn_relu_backward(da.clone(), None, z, g, mean, invstd, beta=b)
+    assert torch.equal(dz2, dz) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
+    with pytest.raises(_lib.Tnv3Error):
+        ops.bn_relu_backward(da.clone(), None, z, g, mean, invstd)
 
 
 @pytest.mark.parametrize("case", [(2, 5, 0, 64, 6, 40, False), (1, 32, 16, 128, 4, 16, True), (2, 64, 0, 192, 4, 8, False),

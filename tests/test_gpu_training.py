@@ -35,6 +35,17 @@ def test_bn_train_forward_backward(gpu_device):
     ref.backward(da.double())
     dz, dgamma, dbeta = ops.bn_relu_backward(da.to(d), a, z.to(d), g.to(d), mean, invstd)
     assert rel_err(dz.cpu(), zd.grad) <= 1e-5 and rel_err(dgamma.cpu(), gd.grad) <= 1e-5 and rel_err(dbeta.cpu(), bd.grad) <= 1e-5
+    # mask recomputed from z instead of read from a (what the training path does): bit-identical
+    dz2, dgamma2, dbeta2 = ops.bn_relu_backward(da.to(d), None, z.to(d), g.to(d), mean, invstd, beta=b.to(d))
+    assert torch.equal(dz2, dz) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
+    # ... also at a size where near-zero pre-activations are plentiful (every mask bit must agree with a > 0)
+    zz = (torch.randn(8, 64, 72, 128, device=d) * 1e-3).contiguous()
+    gg, bb = torch.rand(64, device=d) + 0.5, torch.randn(64, device=d) * 1e-4
+    aa, m2, i2 = ops.bn_train_forward(zz, gg, bb, torch.zeros(64, device=d), torch.ones(64, device=d))
+    dd = torch.randn_like(zz)
+    r1 = ops.bn_relu_backward(dd.clone(), aa, zz, gg, m2, i2)
+    r2 = ops.bn_relu_backward(dd.clone(), None, zz, gg, m2, i2, beta=bb)
+    assert all(torch.equal(x, y) for x, y in zip(r1, r2))
 
 
 @pytest.mark.parametrize("case", [(2, 27, 0, 64, 40, 96, False), (2, 64, 0, 64, 32, 64, False), (1, 128, 64, 64, 32, 64, True),

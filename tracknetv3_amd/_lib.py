@@ -64,7 +64,7 @@ def _declare(lib):
     sig("tnv3_conv3x3_wgrad_variant", i, i)
     sig("tnv3_bn_workspace_bytes", sz, i)
     sig("tnv3_bn_train_forward", i, p, p, p, p, p, f, f, p, p, p, p, sz, i, i, i, p)
-    sig("tnv3_bn_relu_backward", i, p, p, p, p, p, p, p, p, p, p, sz, i, i, i, p)
+    sig("tnv3_bn_relu_backward", i, p, p, p, p, p, p, p, p, p, p, p, sz, i, i, i, p)
     sig("tnv3_conv3x3_dgrad", i, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wgrad_workspace_bytes", sz, i, i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad", i, p, p, p, p, p, sz, i, i, i, i, i, i, i, p)

@@ -150,7 +150,9 @@ class _TrackNetTrain(torch.autograd.Function):
 
         def block_bwd(rec, da, need_dx=True):
             blk = rec["blk"]
-            dz, dgamma, dbeta = ops.bn_relu_backward(da, rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"], rec["invstd"])
+            # ReLU mask recomputed from z (bit-identical to a > 0): the passes read two activation tensors instead of three
+            dz, dgamma, dbeta = ops.bn_relu_backward(da, None, rec["z"], blk.bn.weight.detach(), rec["mean"], rec["invstd"],
+                                                     beta=blk.bn.bias.detach())
             done(blk.bn.weight, dgamma)
             done(blk.bn.bias, dbeta)
             def wgrad():

@@ -47,6 +47,9 @@ __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const float* __re
   if (threadIdx.x == 0) { partial[((size_t)c * kRedSplit + s) * 2] = a; partial[((size_t)c * kRedSplit + s) * 2 + 1] = b; }
 }
 
+// The ReLU(BN(z)) scale as both directions evaluate it: y = fmaf(z - mean, bn_scale(gamma, invstd), beta)
+__device__ __forceinline__ float bn_scale(float gamma, float invstd) { return (float)((double)gamma * (double)invstd); }
+
 // mean / biased var -> (scale, shift) for the normalise pass, saved (mean, invstd) for backward, running-stat update
 // with the UNBIASED variance.  One thread per channel.
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
@@ -63,10 +66,10 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, con
   double var = s2 / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
-  scale[c] = (float)((double)gamma[c] * invstd);
-  (void)beta;
   save_mean[c] = (float)mean;
   save_invstd[c] = (float)invstd;
+  scale[c] = bn_scale(gamma[c], save_invstd[c]);      // from the SAVED fp32 invstd: the backward pass recomputes exactly this value
+  (void)beta;
   const double unbiased = count > 1 ? var * (n / (n - 1.0)) : var;
   running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
   running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
@@ -91,8 +94,12 @@ __global__ void __launch_bounds__(256) bn_apply_relu_kernel(const float* __restr
 
 // ---- BatchNorm + ReLU backward ---------------------------------------------------------------------------------
 // g = dA * (a > 0);  partial[c][s] = (sum g, sum g*xhat), xhat = (z - mean) * invstd.      grid = (kRedSplit, C)
+// FROM_Z: the mask is recomputed from z with the forward's own expression (bit-identical to a > 0) instead of reading a:
+// two tensors per pass instead of three.
+template <bool FROM_Z>
 __global__ void __launch_bounds__(256) bn_relu_bwd_partial_kernel(const float* __restrict__ dA, const float* __restrict__ a,
-                                                                  const float* __restrict__ z, const float* __restrict__ mean,
+                                                                  const float* __restrict__ z, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, double* __restrict__ partial,
                                                                   int N, int C, int HW) {
   __shared__ double red[4];
@@ -100,14 +107,21 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_partial_kernel(const float* _
   const int hw4 = HW >> 2;
   const long total4 = (long)N * hw4;
   const float mu = mean[c], is = invstd[c];
+  const float sc = FROM_Z ? bn_scale(gamma[c], is) : 0.0f, sh = FROM_Z ? beta[c] : 0.0f;
   double s1 = 0.0, s2 = 0.0;
   for (long t = (long)s * 256 + threadIdx.x; t < total4; t += (long)kRedSplit * 256) {
     const int n = (int)(t / hw4);
     const int p = (int)(t - (long)n * hw4) << 2;
     const size_t off = ((size_t)n * C + c) * HW + p;
     const t_f32x4 g = *reinterpret_cast<const t_f32x4*>(dA + off);
-    const t_f32x4 av = *reinterpret_cast<const t_f32x4*>(a + off);
     const t_f32x4 zv = *reinterpret_cast<const t_f32x4*>(z + off);
+    t_f32x4 av;
+    if (FROM_Z) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) av[k] = fmaf(zv[k] - mu, sc, sh);
+    } else {
+      av = *reinterpret_cast<const t_f32x4*>(a + off);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gk = av[k] > 0.0f ? g[k] : 0.0f;
@@ -137,8 +151,10 @@ __global__ void bn_relu_bwd_finalize_kernel(const double* __restrict__ partial, 
 }
 
 // dZ = k0*g - k1 - k2*xhat  (written over dA's buffer is allowed: dZ may alias dA)
+template <bool FROM_Z>
 __global__ void __launch_bounds__(256) bn_relu_bwd_apply_kernel(const float* dA, const float* __restrict__ a,
-                                                                const float* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ z, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const float* __restrict__ coef,
                                                                 float* dZ, long NC, int C, int HW) {
   const int hw4 = HW >> 2;
@@ -148,8 +164,15 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_apply_kernel(const float* dA,
     const int c = (int)(nc % C);
     const float mu = mean[c], is = invstd[c], k0 = coef[c], k1 = coef[C + c], k2 = coef[2 * C + c];
     const t_f32x4 g = *reinterpret_cast<const t_f32x4*>(dA + t * 4);
-    const t_f32x4 av = *reinterpret_cast<const t_f32x4*>(a + t * 4);
     const t_f32x4 zv = *reinterpret_cast<const t_f32x4*>(z + t * 4);
+    t_f32x4 av;
+    if (FROM_Z) {
+      const float sc = bn_scale(gamma[c], is), sh = beta[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) av[k] = fmaf(zv[k] - mu, sc, sh);
+    } else {
+      av = *reinterpret_cast<const t_f32x4*>(a + t * 4);
+    }
     t_f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -329,21 +329,26 @@ int bn_train_forward_impl(Launcher& L, const float* z, const float* gamma, const
 }
 
 template <class Launcher>
-int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const float* z, const float* gamma, const float* mean,
-                          const float* invstd, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int n, int c,
-                          int hw) {
-  if (!da || !a || !z || !gamma || !mean || !invstd || !dz || !dgamma || !dbeta || !ws || n <= 0 || c <= 0 || hw <= 0)
-    TNV3_FAIL(-1, "bn_relu_backward: bad argument");
+int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const float* z, const float* gamma, const float* beta,
+                          const float* mean, const float* invstd, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                          int n, int c, int hw) {
+  if (!da || (!a && !beta) || !z || !gamma || !mean || !invstd || !dz || !dgamma || !dbeta || !ws || n <= 0 || c <= 0 || hw <= 0)
+    TNV3_FAIL(-1, "bn_relu_backward: bad argument (a or beta must be given)");
   if (hw % 4) TNV3_FAIL(-1, "bn_relu_backward: H*W must be a multiple of 4");
   if (ws_bytes < bn_workspace_bytes(c) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "bn_relu_backward: workspace too small / misaligned");
   double* partial = (double*)ws;
   float* coef = (float*)(partial + (size_t)c * kRedSplit * 2);
   int rc;
-  if ((rc = L.launch3(bn_relu_bwd_partial_kernel, kRedSplit, c, 1, 256, da, a, z, mean, invstd, partial, n, c, hw))) return rc;
+  const bool from_z = a == nullptr;                      // recompute the ReLU mask from z (two tensors per pass instead of three)
+  if ((rc = from_z ? L.launch3(bn_relu_bwd_partial_kernel<true>, kRedSplit, c, 1, 256, da, a, z, gamma, beta, mean, invstd, partial, n, c, hw)
+                   : L.launch3(bn_relu_bwd_partial_kernel<false>, kRedSplit, c, 1, 256, da, a, z, gamma, beta, mean, invstd, partial, n, c, hw)))
+    return rc;
   if ((rc = L.launch(bn_relu_bwd_finalize_kernel, (c + 63) / 64, 64, (const double*)partial, gamma, invstd, (long)n * hw, dgamma,
                      dbeta, coef, c))) return rc;
-  return L.launch(bn_relu_bwd_apply_kernel, grid_for((long)n * c * (hw / 4)), 256, da, a, z, mean, invstd, (const float*)coef, dz,
-                  (long)n * c, c, hw);
+  return from_z ? L.launch(bn_relu_bwd_apply_kernel<true>, grid_for((long)n * c * (hw / 4)), 256, da, a, z, gamma, beta, mean, invstd,
+                           (const float*)coef, dz, (long)n * c, c, hw)
+                : L.launch(bn_relu_bwd_apply_kernel<false>, grid_for((long)n * c * (hw / 4)), 256, da, a, z, gamma, beta, mean, invstd,
+                           (const float*)coef, dz, (long)n * c, c, hw);
 }
 
 // ---- Winograd F(2x2, 3x3) form of the plain eval-mode layer (kernels/conv3x3_wino_mfma.h)

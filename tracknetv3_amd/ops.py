@@ -314,17 +314,20 @@ def bn_train_forward(z, gamma, beta, running_mean, running_var, eps=BN_EPS, mome
     return a, mean, invstd
 
 
-def bn_relu_backward(da, a, z, gamma, mean, invstd, inplace=True):
-    """Returns (dz, dgamma, dbeta); dz overwrites da when inplace."""
+def bn_relu_backward(da, a, z, gamma, mean, invstd, inplace=True, beta=None):
+    """Returns (dz, dgamma, dbeta); dz overwrites da when inplace.  With a=None the ReLU mask is recomputed from z, gamma,
+    beta and the saved statistics (bit-identical to a > 0; gamma / beta must be the forward call's values)."""
     lib = _lib.load()
-    _f32(da, a, z, gamma, mean, invstd)
-    _lib.dev_check(da, a, z, gamma, mean, invstd)
+    if a is None and beta is None:
+        raise _lib.Tnv3Error("bn_relu_backward: needs the forward output a or beta")
+    _f32(da, z, gamma, mean, invstd, *(t for t in (a, beta) if t is not None))
+    _lib.dev_check(da, a, z, gamma, beta, mean, invstd)
     n, c, h, w = (int(v) for v in z.shape)
     dz = da if inplace else torch.empty_like(da)
     dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
     dbeta = torch.empty_like(dgamma)
     ws = _workspace(lib.tnv3_bn_workspace_bytes(c), z.device)
-    _lib.check(lib.tnv3_bn_relu_backward(_lib.ptr(da), _lib.ptr(a), _lib.ptr(z), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(invstd),
+    _lib.check(lib.tnv3_bn_relu_backward(_lib.ptr(da), _lib.ptr(a), _lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
                                          _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel() * 8, n, c,
                                          h * w, _lib.stream_ptr(z)))
     return dz, dgamma, dbeta
