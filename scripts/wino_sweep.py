@@ -33,7 +33,7 @@ def main():
         err = ((a - b).abs().max() / a.abs().max()).item()
         t_d = timeit(lambda: ops.conv3x3(x, wp, cout, mean=mu, scale=sc, shift=sh, relu=True, cfg=cfg))
         t_w = timeit(lambda: ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True))
-        other = 2 if ops.wino_variant() == 0 else 0                  # the other Winograd kernel (0: one wave / SIMD, 2: xi-split)
+        other = int(os.environ.get("WINO_OTHER", "0" if ops.wino_variant() != 0 else "2"))   # the Winograd kernel to compare with
         old = ops.wino_variant(other)
         c = ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True)
         t_o = timeit(lambda: ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True))
