@@ -35,8 +35,9 @@ def main():
         t_w = timeit(lambda: ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True))
         other = int(os.environ.get("WINO_OTHER", "0" if ops.wino_variant() != 0 else "2"))   # the Winograd kernel to compare with
         old = ops.wino_variant(other)
-        c = ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True)
-        t_o = timeit(lambda: ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True))
+        uo = ops.pack_wino_weights(wt)                                # the panel layout may depend on the variant
+        c = ops.conv3x3_wino(x, uo, cout, mean=mu, scale=sc, shift=sh, relu=True)
+        t_o = timeit(lambda: ops.conv3x3_wino(x, uo, cout, mean=mu, scale=sc, shift=sh, relu=True))
         ops.wino_variant(old)
         err_o = ((a - c).abs().max() / a.abs().max()).item()
         gf = 2.0 * 9 * cin * cout * h * w * n / 1e9
