@@ -80,7 +80,10 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  *   tnv3_conv3x3_wino_supported     : 1 when the shape qualifies (Cout % 64 == 0, H % 4 == 0, W % 64 == 0)
  *   tnv3_conv3x3_wino_packed_floats : size of the transformed-filter buffer
  *   tnv3_conv3x3_wino_pack          : w [cout][cin][3][3] -> u = G w G^T, [cin_pad][16][cout] */
-int tnv3_conv3x3_wino_variant(int variant);   /* tuning knob: 0 (default) transform as its own phase, 1 interleaved with the MFMAs (measured slower); returns the old value */
+/* Tuning knob (process-wide), returns the old value; an unknown code only queries.  2 (default): xi-split kernel, two waves
+ * per SIMD; 0: one wave per SIMD, transform as its own phase; 1: transform interleaved with the MFMAs (measured slower);
+ * 11-13 / 21-26: timing twins of kernels 0 / 2 with deliberately WRONG results (scripts/wino_diag.py). */
+int tnv3_conv3x3_wino_variant(int variant);
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
 int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, tnv3_stream_t stream);
