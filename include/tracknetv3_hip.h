@@ -79,7 +79,12 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  * tnv3_conv3x3_forward_add up to fp32 rounding (~6e-7 of the output scale per layer instead of ~2e-7).
  *   tnv3_conv3x3_wino_supported     : 1 when the shape qualifies (Cout % 64 == 0, H % 4 == 0, W % 64 == 0)
  *   tnv3_conv3x3_wino_packed_floats : size of the transformed-filter buffer
- *   tnv3_conv3x3_wino_pack          : w [cout][cin][3][3] -> u = G w G^T, [cin_pad][16][cout] */
+ *   tnv3_conv3x3_wino_pack          : w [cout][cin][3][3] -> u = G w G^T, [cin_pad][16][cout]
+ *   tnv3_conv3x3_wino_pack_view     : the same straight from the nn.Conv2d weight w [cout_w][cin_w][3][3] for its input channels
+ *                                     c_from .. c_from + c_count - 1 (skip half of a decoder entry), as the forward filter
+ *                                     (u for cout_w x c_count) or, transpose_flip != 0, as the data gradient's filter
+ *                                     w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] (u for c_count x cout_w): no host-side
+ *                                     slice / flip / transpose copies (model.py:8 weight layout) */
 /* Tuning knob (process-wide), returns the old value; an unknown code only queries.  2 (default): xi-split kernel, two waves
  * per SIMD; 0: one wave per SIMD, transform as its own phase; 1: transform interleaved with the MFMAs (measured slower);
  * 11-13 / 21-26: timing twins of kernels 0 / 2 with deliberately WRONG results (scripts/wino_diag.py). */
@@ -87,6 +92,8 @@ int tnv3_conv3x3_wino_variant(int variant);
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
 int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, tnv3_stream_t stream);
+int tnv3_conv3x3_wino_pack_view(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip,
+                                tnv3_stream_t stream);
 int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, tnv3_stream_t stream);
 

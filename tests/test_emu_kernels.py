@@ -179,6 +179,26 @@ def test_conv3x3_wino_emulated_vs_torch(emu, case, variant):
     assert e_plain <= 3e-6 and e_full <= 6e-6, (e_plain, e_full)
 
 
+def _pack_view_case(device):
+    """tnv3_conv3x3_wino_pack_view (channel slice / data-gradient transpose + flip inside the pack kernel) == packing the
+    tensor torch would have materialised; bit-exact."""
+    from tracknetv3_amd import ops
+    w = T((64, 40, 3, 3), 401, -0.5, 0.5).to(device)
+    assert torch.equal(ops.pack_wino_weights(w, c_from=0), ops.pack_wino_weights(w.clone()))
+    assert torch.equal(ops.pack_wino_weights(w, c_from=16), ops.pack_wino_weights(w[:, 16:].contiguous()))
+    assert torch.equal(ops.pack_wino_weights(w, c_from=8, c_count=24), ops.pack_wino_weights(w[:, 8:32].contiguous()))
+    assert torch.equal(ops.pack_wino_weights(w, transpose_flip=True), ops.pack_wino_weights(w.flip(2, 3).transpose(0, 1).contiguous()))
+    assert torch.equal(ops.pack_wino_weights(w, c_from=16, transpose_flip=True),
+                       ops.pack_wino_weights(w[:, 16:].flip(2, 3).transpose(0, 1).contiguous()))
+    from tracknetv3_amd import _lib
+    with pytest.raises(_lib.Tnv3Error):
+        ops.pack_wino_weights(w, c_from=30, c_count=20)
+
+
+def test_wino_pack_view_emulated(emu):
+    _pack_view_case("cpu")
+
+
 def test_argument_errors_are_reported(emu):
     from tracknetv3_amd import ops, _lib
     w = ops.pack_conv3x3_weights(T((64, 4, 3, 3), 1))

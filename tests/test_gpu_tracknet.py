@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import GOLDEN
-from test_emu_kernels import UP2X_CASES, WINO_CASES, _dgrad_up2x_case, _up2x_case, _wino_case
+from test_emu_kernels import UP2X_CASES, WINO_CASES, _dgrad_up2x_case, _pack_view_case, _up2x_case, _wino_case
 from oracle import nets, prng
 from test_emu_kernels import CONV_CASES, T, conv_ref
 
@@ -75,6 +75,10 @@ def test_conv3x3_wino_vs_torch(gpu_device, case, variant):
     finally:
         ops.wino_variant(old)
     assert e_plain <= 4e-6 and e_full <= 8e-6, (e_plain, e_full)
+
+
+def test_wino_pack_view(gpu_device):
+    _pack_view_case(gpu_device)
 
 
 def test_wino_default_is_the_xi_split_kernel(gpu_device):

@@ -669,7 +669,10 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_split_mfma_kernel(const 
 }
 
 // U[Cin_pad][xi = i*4+j][Cout] = (G g G^T)[i][j] from W[Cout][Cin][3][3]; rows ci >= Cin are zero
-__global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad) {
+// The filter of logical (co, ci) starts at w + co * s_co + ci * s_ci; flip reads its taps back to front (the data
+// gradient's filter w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw] is s_co = 9, s_ci = Cin_w * 9, flip = 1 on the same tensor).
+__global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad, long s_co,
+                                         long s_ci, int flip) {
   const long body = (long)CinPad * 16 * Cout, total = body + kPackZeroTail;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     if (e >= body) { u[e] = 0.0f; continue; }
@@ -678,13 +681,13 @@ __global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __r
     const int xi = (int)(t & 15), ci = (int)(t >> 4);
     float v = 0.0f;
     if (ci < Cin) {
-      const float* g = w + ((long)co * Cin + ci) * 9;
+      const float* g = w + (long)co * s_co + (long)ci * s_ci;
       const int i = xi >> 2, j = xi & 3;
       // row i of G applied to the filter rows, then row j of G to the columns
       float rowv[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+        const float g0 = flip ? g[8 - c] : g[c], g1 = flip ? g[5 - c] : g[3 + c], g2 = flip ? g[2 - c] : g[6 + c];
         rowv[c] = i == 0 ? g0 : (i == 1 ? 0.5f * (g0 + g1 + g2) : (i == 2 ? 0.5f * (g0 - g1 + g2) : g2));
       }
       v = j == 0 ? rowv[0] : (j == 1 ? 0.5f * (rowv[0] + rowv[1] + rowv[2]) : (j == 2 ? 0.5f * (rowv[0] - rowv[1] + rowv[2]) : rowv[2]));

@@ -365,12 +365,22 @@ inline bool conv3x3_wino_supported(int cin, int cout, int h, int w) {
   return cin > 0 && cout > 0 && cout % WinoA::MB == 0 && h % 4 == 0 && w % WinoA::PW == 0;
 }
 
+// Packs input channels c_from .. c_from + c_count - 1 of the nn.Conv2d weight w[cout_w][cin_w][3][3]: as the forward filter
+// (Cout = cout_w, Cin = c_count) or, transpose_flip, as the data gradient's filter (Cout = c_count, Cin = cout_w).
 template <class Launcher>
-int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin) {
-  if (!w || !u || cout <= 0 || cin <= 0) TNV3_FAIL(-1, "conv3x3_wino_pack: bad argument");
+int conv3x3_wino_pack_view_impl(Launcher& L, const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip) {
+  if (!w || !u || cout_w <= 0 || cin_w <= 0 || c_from < 0 || c_count <= 0 || c_from + c_count > cin_w)
+    TNV3_FAIL(-1, "conv3x3_wino_pack: bad argument");
+  const int cout = transpose_flip ? c_count : cout_w, cin = transpose_flip ? cout_w : c_count;
+  const long s_w_co = (long)cin_w * 9, s_w_ci = 9;
   const int cpad = round_up(cin, kWinoCinPad);
   const long total = (long)cpad * 16 * cout + kPackZeroTail;
-  return L.launch(conv3x3_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, cpad);
+  return L.launch(conv3x3_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w + (size_t)c_from * 9, u,
+                  cout, cin, cpad, transpose_flip ? s_w_ci : s_w_co, transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
+}
+template <class Launcher>
+int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin) {
+  return conv3x3_wino_pack_view_impl(L, w, u, cout, cin, 0, cin, 0);
 }
 
 template <class Launcher>

@@ -74,7 +74,7 @@ class Conv2DBlock(nn.Module):
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
             w = self.conv.weight.detach()
-            hit = (ver, ops.pack_wino_weights(w if c_from == 0 else w[:, c_from:].contiguous()))
+            hit = (ver, ops.pack_wino_weights(w, c_from=c_from))
             self._cache[key] = hit
         return hit[1]
 
@@ -85,7 +85,7 @@ class Conv2DBlock(nn.Module):
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
             w = self.conv.weight.detach()
-            hit = (ver, ops.pack_wino_weights(w[:, c_from:].flip(2, 3).transpose(0, 1).contiguous()))
+            hit = (ver, ops.pack_wino_weights(w, c_from=c_from, transpose_flip=True))
             self._cache[key] = hit
         return hit[1]
 

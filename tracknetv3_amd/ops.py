@@ -64,14 +64,20 @@ def wino_supported(cin, cout, h, w):
     return bool(_lib.load().tnv3_conv3x3_wino_supported(int(cin), int(cout), int(h), int(w)))
 
 
-def pack_wino_weights(weight):
-    """nn.Conv2d weight (Cout, Cin, 3, 3) -> Winograd-domain filters G w G^T for tnv3_conv3x3_wino_forward."""
+def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False):
+    """nn.Conv2d weight (Cout, Cin, 3, 3) -> Winograd-domain filters G w G^T for tnv3_conv3x3_wino_forward, of its input
+    channels c_from .. c_from + c_count - 1 (default: all).  transpose_flip: the data gradient's filter
+    w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] instead (the packed panel then maps Cout -> c_count channels)."""
     lib = _lib.load()
     _f32(weight)
+    weight = weight.contiguous()
     _lib.dev_check(weight)
-    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    cout_w, cin_w = int(weight.shape[0]), int(weight.shape[1])
+    c_count = cin_w - int(c_from) if c_count is None else int(c_count)
+    cout, cin = (c_count, cout_w) if transpose_flip else (cout_w, c_count)
     u = torch.empty(lib.tnv3_conv3x3_wino_packed_floats(cin, cout), dtype=torch.float32, device=weight.device)
-    _lib.check(lib.tnv3_conv3x3_wino_pack(_lib.ptr(weight.contiguous()), _lib.ptr(u), cout, cin, _lib.stream_ptr(weight)))
+    _lib.check(lib.tnv3_conv3x3_wino_pack_view(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count,
+                                               int(bool(transpose_flip)), _lib.stream_ptr(weight)))
     return u
 
 
