@@ -168,6 +168,14 @@ def test_head_pool_upsample_mixup_backward_emulated(emu):
     p = ops.head1x1_sigmoid(a, wt, b)
     da, dw, db = ops.head_backward(dp, p, a, wt)
     assert rel_err(da, ad.grad) <= 1e-5 and rel_err(dw, wd.grad) <= 1e-5 and rel_err(db, bd.grad) <= 1e-5
+    for (n2, L2, h2, w2) in ((1, 16, 5, 7), (3, 1, 4, 33)):   # H*W not a multiple of 4 (element-wise loads), L = 16 and L = 1
+        a2, wt2, b2 = T((n2, 64, h2, w2), 11), T((L2, 64, 1, 1), 12, -0.3, 0.3), T((L2,), 13)
+        ad2, wd2, bd2 = a2.double().requires_grad_(True), wt2.double().requires_grad_(True), b2.double().requires_grad_(True)
+        pref2 = torch.sigmoid(F.conv2d(ad2, wd2, bd2))
+        dp2 = T((n2, L2, h2, w2), 14)
+        pref2.backward(dp2.double())
+        da2, dw2, db2 = ops.head_backward(dp2, pref2.detach().float().contiguous(), a2, wt2)   # (the forward head needs H*W % 4 == 0)
+        assert rel_err(da2, ad2.grad) <= 1e-5 and rel_err(dw2, wd2.grad) <= 1e-5 and rel_err(db2, bd2.grad) <= 1e-5
     # max-pool backward (+ skip add), incl. ties at zero after a ReLU
     x = torch.relu(T((2, 3, 8, 12), 5))
     xd = x.double().requires_grad_(True)

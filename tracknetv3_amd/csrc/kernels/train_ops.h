@@ -240,64 +240,136 @@ __global__ void __launch_bounds__(256) wbce_backward_kernel(const float* __restr
 // ---- head backward: p = sigmoid(W a + b) ------------------------------------------------------------------------
 // dz = dP * p * (1-p);  dA[c] = sum_l W[l][c] dz[l];  dW[l][c] = sum dz[l]*a[c];  db[l] = sum dz[l]
 // One workgroup walks pixel tiles of P = 128; partial dW/db per workgroup -> finalize.   L <= 16, C == 64.
+// LDS traffic is what bounds it, so each staged value is read once per thread that needs it:
+//   dA: a thread owns one pixel, holds its dz[0..L) in registers and takes the filter column of its (wave-uniform)
+//       channel as 16-byte LDS broadcasts (scalar global loads instead were measured slower: their latency is exposed);
+//   dW: a thread owns channel c for ALL l over a quarter of the tile's pixels: one a read and L/4 16-byte broadcast reads of
+//       dz per pixel feed L FMAs; the four pixel quarters (waves) are summed in fixed order at the end.
 constexpr int kHeadP = 128, kHeadC = 64, kHeadLMax = 16;
 __global__ void __launch_bounds__(256) head_backward_kernel(const float* __restrict__ dP, const float* __restrict__ p,
                                                             const float* __restrict__ a, const float* __restrict__ w,
                                                             float* __restrict__ dA, float* __restrict__ part /* [grid][L*C + L] */,
                                                             int N, int L, int HW) {
-  __shared__ float dz_s[kHeadLMax * kHeadP];
+  __shared__ __attribute__((aligned(16))) float dz_s[kHeadP * kHeadLMax];       // [px][l], l padded to 16 (zeros)
   __shared__ float a_s[kHeadC * (kHeadP + 1)];
-  __shared__ float w_s[kHeadLMax * kHeadC];
+  __shared__ __attribute__((aligned(16))) float w_s[kHeadC * kHeadLMax];       // [c][l]: the filter column of a channel, l padded (zeros)
   const int tid = threadIdx.x;
-  for (int i = tid; i < L * kHeadC; i += 256) w_s[i] = w[i];
+  for (int i = tid; i < kHeadC * kHeadLMax; i += 256) { const int c = i / kHeadLMax, l = i - c * kHeadLMax; w_s[i] = l < L ? w[l * kHeadC + c] : 0.0f; }
   const int tilesPer = (HW + kHeadP - 1) / kHeadP;
   const long nTiles = (long)N * tilesPer;
-  const int c_own = tid & 63, lq = tid >> 6;           // dW ownership: channel c_own, outputs l = lq, lq+4, ...
-  float accW[kHeadLMax / 4];
+  const int c_own = tid & 63, pq = tid >> 6;           // dW ownership: channel c_own, pixels [32 pq, 32 pq + 32) of every tile
+  float accW[kHeadLMax];
 #pragma unroll
-  for (int k = 0; k < kHeadLMax / 4; ++k) accW[k] = 0.0f;
+  for (int l = 0; l < kHeadLMax; ++l) accW[l] = 0.0f;
   float accB = 0.0f;                                     // thread tid < L owns db[tid]
+  for (int i = tid; i < kHeadP * kHeadLMax; i += 256) dz_s[i] = 0.0f;           // the padding lanes l >= L stay zero
+  // A tile travels global -> registers -> LDS; the loads of tile t+1 are issued before the arithmetic of tile t, so their
+  // latency hides behind it.  Thread slots: 8 pieces of 4 pixels of `a` (channel = slot / 32), L/2 (l, px) pairs of dz.
+  constexpr int NA = kHeadC * kHeadP / 4 / 256, NZ = kHeadLMax * kHeadP / 256;
+  const bool vec_ok = (HW & 3) == 0;
+  t_f32x4 ra[NA];
+  float rz[NZ];
+  auto fetch = [&](long tile) {
+    const int n = (int)(tile / tilesPer);
+    const int p0 = (int)(tile - (long)n * tilesPer) * kHeadP;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int e = tid + j * 256;
+      const int c = e >> 5, px = (e & 31) * 4;
+      const float* src = a + ((size_t)n * kHeadC + c) * HW + p0 + px;
+      if (vec_ok && p0 + px + 3 < HW) ra[j] = *reinterpret_cast<const t_f32x4*>(src);
+      else
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ra[j][k] = (p0 + px + k < HW) ? src[k] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+      const int i = tid + j * 256;
+      const int l = i / kHeadP, px = i - l * kHeadP;
+      float v = 0.0f;
+      if (l < L && p0 + px < HW) { const size_t o = ((size_t)n * L + l) * HW + p0 + px; const float pv = p[o]; v = dP[o] * pv * (1.0f - pv); }
+      rz[j] = v;
+    }
+  };
+  auto publish = [&]() {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int e = tid + j * 256;
+      float* d = a_s + (e >> 5) * (kHeadP + 1) + (e & 31) * 4;
+      d[0] = ra[j][0]; d[1] = ra[j][1]; d[2] = ra[j][2]; d[3] = ra[j][3];
+    }
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+      const int i = tid + j * 256;
+      const int l = i / kHeadP, px = i - l * kHeadP;
+      if (l < L) dz_s[px * kHeadLMax + l] = rz[j];
+    }
+  };
+  if ((long)blockIdx.x < nTiles) fetch(blockIdx.x);
   for (long tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
     const int n = (int)(tile / tilesPer);
     const int p0 = (int)(tile - (long)n * tilesPer) * kHeadP;
+    __syncthreads();                                      // the previous tile's readers are done
+    publish();
     __syncthreads();
-    for (int i = tid; i < L * kHeadP; i += 256) {
-      const int l = i / kHeadP, px = i - l * kHeadP;
-      float v = 0.0f;
-      if (p0 + px < HW) { const size_t o = ((size_t)n * L + l) * HW + p0 + px; const float pv = p[o]; v = dP[o] * pv * (1.0f - pv); }
-      dz_s[i] = v;
-    }
-    for (int i = tid; i < kHeadC * kHeadP; i += 256) {
-      const int c = i / kHeadP, px = i - c * kHeadP;
-      a_s[c * (kHeadP + 1) + px] = (p0 + px < HW) ? a[((size_t)n * kHeadC + c) * HW + p0 + px] : 0.0f;
-    }
-    __syncthreads();
-    // dA: thread -> pixel px = tid % 128, channels c = (tid/128) + 2k
+    if (tile + gridDim.x < nTiles) fetch(tile + gridDim.x);
+    // dA: thread -> pixel px = tid % 128, channels c = (tid/128) + 2k (uniform per wave: scalar filter loads)
     {
       const int px = tid & (kHeadP - 1);
+      float dzr[kHeadLMax];
+#pragma unroll
+      for (int q = 0; q < kHeadLMax / 4; ++q) {
+        const t_f32x4 v = *reinterpret_cast<const t_f32x4*>(dz_s + px * kHeadLMax + 4 * q);
+        dzr[4 * q] = v[0]; dzr[4 * q + 1] = v[1]; dzr[4 * q + 2] = v[2]; dzr[4 * q + 3] = v[3];
+      }
+      const int ch = __builtin_amdgcn_readfirstlane(tid >> 7);
       if (p0 + px < HW) {
-        for (int c = tid >> 7; c < kHeadC; c += 2) {
+        float* o = dA + (size_t)n * kHeadC * HW + p0 + px;
+#pragma unroll 4
+        for (int c = ch; c < kHeadC; c += 2) {
           float s = 0.0f;
-          for (int l = 0; l < L; ++l) s = fmaf(w_s[l * kHeadC + c], dz_s[l * kHeadP + px], s);
-          dA[((size_t)n * kHeadC + c) * HW + p0 + px] = s;
+#pragma unroll
+          for (int q = 0; q < kHeadLMax / 4; ++q) {
+            if (4 * q < L) {                              // wave-uniform address: a 16-byte broadcast read per four maps
+              const t_f32x4 wv = *reinterpret_cast<const t_f32x4*>(w_s + c * kHeadLMax + 4 * q);
+              s = fmaf(wv[0], dzr[4 * q], s); s = fmaf(wv[1], dzr[4 * q + 1], s);
+              s = fmaf(wv[2], dzr[4 * q + 2], s); s = fmaf(wv[3], dzr[4 * q + 3], s);
+            }
+          }
+          o[(size_t)c * HW] = s;
         }
       }
     }
     // dW / db partials
+    {
+      const float* arow = a_s + c_own * (kHeadP + 1) + pq * 32;
+      const float* dzq = dz_s + pq * 32 * kHeadLMax;
+      for (int px = 0; px < 32; ++px) {
+        const float av = arow[px];
 #pragma unroll
-    for (int k = 0; k < kHeadLMax / 4; ++k) {
-      const int l = lq + 4 * k;
-      if (l < L) {
-        float s = accW[k];
-        for (int px = 0; px < kHeadP; ++px) s = fmaf(dz_s[l * kHeadP + px], a_s[c_own * (kHeadP + 1) + px], s);
-        accW[k] = s;
+        for (int q = 0; q < kHeadLMax / 4; ++q) {
+          if (4 * q < L) {
+            const t_f32x4 v = *reinterpret_cast<const t_f32x4*>(dzq + px * kHeadLMax + 4 * q);
+            accW[4 * q] = fmaf(v[0], av, accW[4 * q]); accW[4 * q + 1] = fmaf(v[1], av, accW[4 * q + 1]);
+            accW[4 * q + 2] = fmaf(v[2], av, accW[4 * q + 2]); accW[4 * q + 3] = fmaf(v[3], av, accW[4 * q + 3]);
+          }
+        }
       }
     }
-    if (tid < L) { float s = accB; for (int px = 0; px < kHeadP; ++px) s += dz_s[tid * kHeadP + px]; accB = s; }
+    if (tid < L) { float s = accB; for (int px = 0; px < kHeadP; ++px) s += dz_s[px * kHeadLMax + tid]; accB = s; }
   }
-  float* out = part + (size_t)blockIdx.x * (L * kHeadC + L);
+  // fold the four pixel quarters in the fixed order pq = 0..3 (a_s is free now)
+  __syncthreads();
+  float* red = a_s;                                      // [pq][l][c]
 #pragma unroll
-  for (int k = 0; k < kHeadLMax / 4; ++k) { const int l = lq + 4 * k; if (l < L) out[l * kHeadC + c_own] = accW[k]; }
+  for (int l = 0; l < kHeadLMax; ++l) red[(pq * kHeadLMax + l) * kHeadC + c_own] = accW[l];
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * (L * kHeadC + L);
+  for (int i = tid; i < L * kHeadC; i += 256) {
+    const int l = i / kHeadC, c = i - l * kHeadC;
+    out[i] = ((red[(0 * kHeadLMax + l) * kHeadC + c] + red[(1 * kHeadLMax + l) * kHeadC + c]) + red[(2 * kHeadLMax + l) * kHeadC + c]) +
+             red[(3 * kHeadLMax + l) * kHeadC + c];
+  }
   if (tid < L) out[L * kHeadC + tid] = accB;
 }
 
