@@ -217,6 +217,42 @@ def test_train_then_eval_and_optimizer_step(gpu_device):
     assert (e1.cpu() - ref).abs().max().item() <= 1e-4
 
 
+def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
+    """The training path recomputes the ReLU mask from z with the forward's gamma / beta; if a BN parameter was modified in
+    place between forward and backward (version counter moved) it must take the mask from the saved activation instead.
+    Both routes are bit-identical when the values did not change."""
+    from tracknetv3_amd import ops
+    from tracknetv3_amd.utils.general import get_model
+    from tracknetv3_amd.utils.metric import WBCELoss
+    x = nets.synth_input((2, 9, 32, 64), 5).to(gpu_device)
+    y = nets.disc_heatmaps(2, 3, 32, 64, 6).to(gpu_device)
+    sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 21, calibrated=True)
+    grads, calls = [], []
+    real = ops.bn_relu_backward
+
+    def spy(da, a, *args, **kw):
+        calls.append(a is None)
+        return real(da, a, *args, **kw)
+
+    ops.bn_relu_backward = spy
+    try:
+        for bump in (False, True):
+            m = get_model("TrackNet", 3, "")
+            m.load_state_dict(sd, strict=True)
+            m = m.to(gpu_device).train()
+            loss = WBCELoss(m(x), y)
+            if bump:
+                with torch.no_grad():
+                    m.down_block_1.conv_1.bn.bias.add_(0.0)          # same values, new version
+            calls.clear()
+            loss.backward()
+            assert calls.count(False) == (1 if bump else 0) and len(calls) == 17
+            grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        ops.bn_relu_backward = real
+    assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
+
+
 def test_mixup_with_reference_rng_protocol(gpu_device):
     """train_utils.mixup draws lambda / permutation exactly like train.py:33-36 (numpy Beta, torch.randperm on the host);
     with the same seeds the result equals the oracle's mixup on those draws."""

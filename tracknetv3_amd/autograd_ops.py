@@ -96,7 +96,8 @@ class _TrackNetTrain(torch.autograd.Function):
             a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                    bn.eps, bn.momentum)
             bn.num_batches_tracked.add_(1)
-            saved.append(dict(blk=blk, x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd))
+            saved.append(dict(blk=blk, x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,
+                              bn_ver=(bn.weight._version, bn.bias._version)))
             return a
 
         def chain(blks, src0, src1=None, up=False):
@@ -150,9 +151,11 @@ class _TrackNetTrain(torch.autograd.Function):
 
         def block_bwd(rec, da, need_dx=True):
             blk = rec["blk"]
-            # ReLU mask recomputed from z (bit-identical to a > 0): the passes read two activation tensors instead of three
-            dz, dgamma, dbeta = ops.bn_relu_backward(da, None, rec["z"], blk.bn.weight.detach(), rec["mean"], rec["invstd"],
-                                                     beta=blk.bn.bias.detach())
+            # ReLU mask recomputed from z (bit-identical to a > 0): the passes read two activation tensors instead of three.
+            # That needs the forward's gamma / beta; if either was modified in place since, the mask comes from a itself.
+            same = rec["bn_ver"] == (blk.bn.weight._version, blk.bn.bias._version)
+            dz, dgamma, dbeta = ops.bn_relu_backward(da, None if same else rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"],
+                                                     rec["invstd"], beta=blk.bn.bias.detach())
             done(blk.bn.weight, dgamma)
             done(blk.bn.bias, dbeta)
             def wgrad():
