@@ -137,6 +137,26 @@ def test_inpaintnet_forward(gpu_device):
     assert (net(c2.to(gpu_device), m2.int().to(gpu_device)).cpu() - ref).abs().max().item() <= 2e-6
 
 
+def test_inpaintnet_hip_graph_replay(gpu_device):
+    """InpaintNet.graphed(n): the eval forward captured in a HIP graph equals the eager forward bit for bit, follows new
+    inputs and in-place weight updates, and refuses a training-mode module."""
+    from tracknetv3_amd.model import InpaintNet
+    net = InpaintNet()
+    net.load_state_dict(nets.synth_state(nets.inpaintnet_state_shapes(), 77), strict=True)
+    net = net.to(gpu_device)
+    with pytest.raises(ValueError):
+        net.train().graphed(32)
+    net.eval()
+    g = net.graphed(32)
+    for seed in (1, 2):
+        x = nets.synth_input((32, 16, 2), 600 + seed).to(gpu_device)
+        m = (nets.synth_input((32, 16, 1), 700 + seed) < 0.3).float().to(gpu_device)
+        assert torch.equal(g(x, m), net(x, m))
+    with torch.no_grad():
+        net.predictor.bias.add_(0.25)
+    assert torch.equal(g.replay(), net(x, m))
+
+
 @pytest.mark.parametrize("case", CONV1D_MFMA_CASES + [(4099, 256, 128, 128, 1), (70000, 32, 0, 64, 1)])
 def test_conv1d_mfma_vs_torch(gpu_device, case):
     assert _conv1d_case(*case, gpu_device) <= 3e-6
