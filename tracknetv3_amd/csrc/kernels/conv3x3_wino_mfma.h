@@ -8,7 +8,13 @@
 // arithmetic; in fp32 the +-1, 1/2 transforms cost ~3x the rounding noise of the direct chain (6e-7 vs 2e-7 of the
 // output scale per layer, measured) -- two orders below the 1e-4 heat-map bar.
 //
-// Mapping: MFMA 32x32x2 with M = 32 output channels, N = 32 tiles (2 tile rows x 16 tile columns = 4 x 32 pixels),
+// Three kernels share the tile (64 output channels x 64 tiles = 4 x 64 pixels per workgroup, 8-channel chunks) and the
+// packed filter panel:
+//   conv3x3_wino_split_mfma_kernel  the production one (tnv3_conv3x3_wino_variant 2): eight waves, the 16 xi split over
+//                                   two wave groups (128 accumulators per wave, two waves per SIMD), one barrier per chunk;
+//   conv3x3_wino_mfma_kernel        its predecessor (variant 0): four waves, one per SIMD, described first below;
+//   conv3x3_wino_il_mfma_kernel     variant 1: the transform interleaved into the MFMA stream (measured slower).
+// Mapping (first kernel): MFMA 32x32x2 with M = 32 output channels, N = 32 tiles (2 tile rows x 16 tile columns = 4 x 32 pixels),
 // K = 2 input channels; a wave keeps ALL 16 xi of its 32 x 32 tile (256 accumulator registers, one wave per SIMD) so the
 // inverse transform happens in registers.  Per chunk of CC channels a workgroup stages the raw halo tile and the
 // pre-transformed filter panel U (conv3x3_wino_pack_kernel), transforms the patches cooperatively into the LDS operand
