@@ -151,18 +151,16 @@ TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 296.5e9
 def bench_train(args, dev, rank, world):
     """BASELINE configs[2] shard: TrackNet(27,8) train step, batch 10 per GPU, mixup alpha 0.5, Adam, DP all-reduce."""
     import torch.distributed as dist
-    from oracle import nets
     from tracknetv3_amd.parallel import TrackNetTrainer
+    from tracknetv3_amd.utils import synth
     from tracknetv3_amd.utils.general import get_model
     in_dim = (SEQ_LEN + 1) * 3
-    model = get_model("TrackNet", SEQ_LEN, BG_MODE)
-    model.load_state_dict(nets.synth_state(nets.tracknet_state_shapes(in_dim, SEQ_LEN), 31, calibrated=False), strict=True)
-    model = model.to(dev)
+    model = synth.init_state_(get_model("TrackNet", SEQ_LEN, BG_MODE), 31, calibrated=False).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     trainer = TrackNetTrainer(model, opt, alpha=0.5, seed=13)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.rand((args.batch, in_dim, H, W), device=dev, generator=gen)
-    y = nets.disc_heatmaps(args.batch, SEQ_LEN, H, W, 77 + rank).to(dev)
+    y = synth.disc_heatmaps(args.batch, SEQ_LEN, H, W, 77 + rank, device=dev)
 
     def barrier():
         if world > 1:
@@ -234,8 +232,8 @@ def main():
     n_gpus = world
 
     from tracknetv3_amd import _lib, ops
+    from tracknetv3_amd.utils import synth
     from tracknetv3_amd.utils.general import get_model
-    from oracle import nets
     _lib.load()
     assert not _lib.is_emulator()
 
@@ -248,9 +246,7 @@ def main():
         return bench_train(args, dev, rank, world)
 
     in_dim = (SEQ_LEN + 1) * 3
-    model = get_model("TrackNet", SEQ_LEN, BG_MODE)
-    model.load_state_dict(nets.synth_state(nets.tracknet_state_shapes(in_dim, SEQ_LEN), 31, calibrated=True), strict=True)
-    model = model.to(dev).eval()
+    model = synth.init_state_(get_model("TrackNet", SEQ_LEN, BG_MODE), 31, calibrated=True).to(dev).eval()
     x = torch.rand((args.batch, in_dim, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
 
     # per-launch timing of the dominant kernel family (conv3x3_mfma_kernel<*>): HIP events on the launch stream

@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tracknetv3_amd import pipeline, postprocess as pp, ops
 from tracknetv3_amd.utils.general import get_model
-from oracle import nets   # synthetic calibrated weights only (test infrastructure)
+from tracknetv3_amd.utils import synth
 
 
 def main():
     dev = torch.device("cuda", 0)
     tn = get_model("TrackNet", 8, "concat")
-    tn.load_state_dict(nets.synth_state(nets.tracknet_state_shapes(27, 8), 31, calibrated=True), strict=True)
+    synth.init_state_(tn, 31, calibrated=True)
     tn = tn.to(dev).eval()
     net = get_model("InpaintNet").to(dev).eval()
     t_frames = 264
