@@ -167,8 +167,13 @@ def _wino_case(n, cin, cout, h, w, device):
     return ((got_plain - ref_plain).abs().max() / s).item(), ((got_full - ref_full).abs().max() / s).item()
 
 
+# emulator-only extras: an interior tile column (no horizontal padding), the stem's 27 channels, and 192 output channels
+# (three channel blocks: the generic, non-XCD block map)
+WINO_EMU_EXTRA = [(1, 27, 64, 12, 192), (1, 16, 192, 4, 64)]
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2], ids=["phased", "interleaved", "xisplit"])
-@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("case", WINO_CASES + WINO_EMU_EXTRA)
 def test_conv3x3_wino_emulated_vs_torch(emu, case, variant):
     from tracknetv3_amd import ops
     old = ops.wino_variant(variant)
