@@ -200,6 +200,21 @@ def test_head_pool_upsample_mixup_backward_emulated(emu):
     assert np.abs(out.numpy() - g["mixup_x"]).max() <= 1e-6
 
 
+def test_head_backward_many_tiles_per_workgroup_emulated(emu):
+    """More pixel tiles than workgroups (1025 x 2 > 1024): every workgroup walks several tiles, so the register prefetch of the
+    next tile overlaps the arithmetic of the current one -- the path every real training step takes (11 520 tiles)."""
+    from tracknetv3_amd import ops
+    n, L, h, w = 2, 2, 1025, 128
+    a = T((n, 64, h, w), 31)
+    wt, b = T((L, 64, 1, 1), 32, -0.3, 0.3), T((L,), 33)
+    ad, wd, bd = a.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    pref = torch.sigmoid(F.conv2d(ad, wd, bd))
+    dp = T((n, L, h, w), 34)
+    pref.backward(dp.double())
+    da, dw, db = ops.head_backward(dp, pref.detach().float().contiguous(), a, wt)
+    assert rel_err(da, ad.grad) <= 1e-5 and rel_err(dw, wd.grad) <= 1e-5 and rel_err(db, bd.grad) <= 1e-5
+
+
 @pytest.mark.slow
 @pytest.mark.skipif(os.environ.get("TNV3_EMU_FULL") != "1", reason="minutes of emulation; set TNV3_EMU_FULL=1 (the GPU suite runs the same check)")
 def test_tracknet_train_step_emulated_vs_fp64_oracle(emu):
