@@ -11,6 +11,11 @@
  *   - the caller owns all buffers (outputs, packed weights, workspaces); nothing is allocated or retained
  *   - calls only ENQUEUE on `stream` (a hipStream_t passed as void*; NULL = default stream) and return;
  *     no internal synchronisation; safe to call from several host threads on distinct streams
+ *   - the DEVICE is the stream's: a call makes the stream's device current for its own duration (and restores the
+ *     caller's), so pointers must belong to the stream's device; a NULL stream means the calling thread's current
+ *     device.  The stream-less *_workspace_bytes / *_packed_floats queries plan for the calling thread's current
+ *     device (all GPUs of one node are identical; on a mixed node query with the right device current)
+ *   - NO process-wide mutable state: kernel-family choices are per-call arguments (`cfg`, `variant`; -1 = default)
  *   - return value: 0 = OK, <0 = error (TNV3_E_*); tnv3_last_error() gives the text for the calling thread
  *   - no exceptions cross the ABI
  */
@@ -27,7 +32,7 @@ extern "C" {
 #define TNV3_OK 0
 #define TNV3_E_INVALID (-1)   /* bad argument / unsupported shape */
 #define TNV3_E_LAUNCH (-2)    /* HIP launch error */
-#define TNV3_ABI_VERSION 1
+#define TNV3_ABI_VERSION 2   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so */
 
 typedef void* tnv3_stream_t;
 
@@ -85,17 +90,17 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  *                                     (u for cout_w x c_count) or, transpose_flip != 0, as the data gradient's filter
  *                                     w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] (u for c_count x cout_w): no host-side
  *                                     slice / flip / transpose copies (model.py:8 weight layout) */
-/* Tuning knob (process-wide), returns the old value; an unknown code only queries.  2 (default): xi-split kernel, two waves
- * per SIMD; 0: one wave per SIMD, transform as its own phase; 1: transform interleaved with the MFMAs (measured slower);
- * 11-13 / 21-26: timing twins of kernels 0 / 2 with deliberately WRONG results (scripts/wino_diag.py). */
-int tnv3_conv3x3_wino_variant(int variant);
+/*   `variant` of tnv3_conv3x3_wino_forward (per call): -1 / 2 = xi-split kernel, two waves per SIMD (default, fastest);
+ *                                     0 = one wave per SIMD, transform as its own phase; 1 = transform interleaved with the
+ *                                     MFMAs (measured slower).  All three compute the same function. */
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
 int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, tnv3_stream_t stream);
 int tnv3_conv3x3_wino_pack_view(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip,
                                 tnv3_stream_t stream);
 int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
-                              const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, tnv3_stream_t stream);
+                              const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,
+                              tnv3_stream_t stream);
 
 /* Decoder-entry layers (model.py:65,67,69: Conv2DBlock on torch.cat([nn.Upsample(scale_factor=2)(x), skip], dim=1)):
  * the contribution of the UPSAMPLED channels computed at the low resolution.  A 3x3 'same' convolution over a nearest-2x
@@ -178,11 +183,6 @@ size_t tnv3_peakfind_workspace_bytes(int frames, int h, int w);
 int tnv3_heatmap_peakfind(const float* heat, float threshold, int tie_last_wins, int32_t* out_bbox, void* workspace,
                           size_t workspace_bytes, int frames, int h, int w, tnv3_stream_t stream);
 
-/* Tuning / diagnostic knob: selects the weight-gradient kernel family for the whole process and returns the previous
- * value.  0 (default): register-staged 4x32-pixel tiles;  1: LDS-DMA staged, double-buffered 2x32-pixel tiles.  Any other
- * value only queries.  Call tnv3_conv3x3_wgrad_workspace_bytes again after switching (the split-K plan follows). */
-int tnv3_conv3x3_wgrad_variant(int variant);
-
 /* Per-map maximum inside a box: out[f] = max heat[f][y:y+h, x:x+w] with (x, y, w, h) = boxes[f] (int32, clipped to the
  * map; 0 for an empty box), or the maximum of the whole map when boxes == NULL.  Replaces the detection confidence
  * `np.amax(y_p[bbox...])` of evaluate() (test.py:164-167) and its `np.amax(y_t) > 0` ground-truth test (test.py:170-178),
@@ -215,10 +215,12 @@ int tnv3_bn_relu_backward(const float* da, const float* a, const float* z, const
 int tnv3_conv3x3_dgrad(const float* dz, const float* wpack_t, float* dx0, float* dx1, int n, int cout, int c0, int c1,
                        int h, int w, int cfg, tnv3_stream_t stream);
 
-/* Weight gradient dW[Cout][C0+C1][3][3] = sum_pixels dZ * X, X = cat([up2x?(src0), src1]) as in the forward. */
-size_t tnv3_conv3x3_wgrad_workspace_bytes(int n, int c0, int c1, int cout, int h, int w);
+/* Weight gradient dW[Cout][C0+C1][3][3] = sum_pixels dZ * X, X = cat([up2x?(src0), src1]) as in the forward.
+ * `variant` (per call; the workspace query must get the same value): -1 / 0 = register-staged 4x32-pixel tiles (default),
+ * 1 = LDS-DMA staged, double-buffered 2x32-pixel tiles (same gradient, measured 8 % slower). */
+size_t tnv3_conv3x3_wgrad_workspace_bytes(int n, int c0, int c1, int cout, int h, int w, int variant);
 int tnv3_conv3x3_wgrad(const float* src0, const float* src1, const float* dz, float* dw, void* workspace,
-                       size_t workspace_bytes, int n, int c0, int c1, int cout, int h, int w, int up0,
+                       size_t workspace_bytes, int n, int c0, int c1, int cout, int h, int w, int up0, int variant,
                        tnv3_stream_t stream);
 
 /* WBCELoss(y_pred, y, reduce) (utils/metric.py:3-20): out[0] (reduce != 0) or out[N] per-sample means. */
@@ -285,18 +287,8 @@ int tnv3_median_u8(const unsigned char* frames, unsigned char* median, uint16_t*
 int tnv3_absdiff_sum_u8(const unsigned char* frames, const uint16_t* median_x2, unsigned char* out, int frames_n,
                         long pixels, tnv3_stream_t stream);
 
-/* ---- diagnostics ----------------------------------------------------------------------------------------- */
-
-/* Register-only v_mfma_f32_32x32x2_f32 loop: `blocks` workgroups of 256 threads, each wave issuing iters*8 MFMAs
- * (2*32*32*2 FLOP each).  out: blocks*256 floats (keeps the work observable).  Measures the sustained fp32 matrix
- * rate of the chip as clocked under load, to set next to the conv kernels' TFLOP/s. */
-int tnv3_mfma_f32_probe(float* out, int blocks, int iters, tnv3_stream_t stream);
-
-/* The conv kernel with parts of its pipeline switched off (results are WRONG by design): diag 1 = stage only the first
- * channel chunk (no global loads / LDS stores afterwards), diag 2 = additionally no workgroup barriers.  Timing these
- * against the production launch attributes the matrix-pipe idle time to staging / synchronisation / the MFMA loop. */
-int tnv3_conv3x3_forward_diag(const float* src0, const float* wpack, float* dst, int n, int c0, int cout, int h, int w,
-                              int cfg, int diag, tnv3_stream_t stream);
+/* Diagnostics (the register-only MFMA probe, timing twins with deliberately wrong results) are NOT part of this library:
+ * they are built from the same sources into libtnv3_diag.so, declared in include/tracknetv3_hip_diag.h. */
 
 #ifdef __cplusplus
 }

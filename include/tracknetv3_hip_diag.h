@@ -1,0 +1,42 @@
+/* tracknetv3_hip_diag.h -- C ABI of libtnv3_diag.so: measurement tools built from the same kernel sources as
+ * libtnv3_hip.so (csrc/tnv3_capi.hip with -DTNV3_DIAG -DTNV3_TU_DIAG).  NOT loaded by the product package: the scripts under
+ * scripts/ bind it explicitly (scripts/diaglib.py).  The "timing twin" entry points run a production kernel with parts of
+ * its pipeline switched off and therefore write WRONG results by design -- which is why they do not live in the product
+ * library.  Same conventions as include/tracknetv3_hip.h (device pointers, caller-owned buffers, enqueue-only).
+ */
+#ifndef TRACKNETV3_HIP_DIAG_H
+#define TRACKNETV3_HIP_DIAG_H
+
+#include "tracknetv3_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error text of the calling thread's last failed tnv3_diag_* call (this library's own buffer). */
+const char* tnv3_diag_last_error(void);
+
+/* Register-only v_mfma_f32_32x32x2_f32 loop: `blocks` workgroups of 256 threads, each wave issuing iters*8 MFMAs
+ * (2*32*32*2 FLOP each).  out: blocks*256 floats (keeps the work observable).  Measures the sustained fp32 matrix
+ * rate of the chip as clocked under load, to set next to the conv kernels' TFLOP/s. */
+int tnv3_diag_mfma_f32_probe(float* out, int blocks, int iters, tnv3_stream_t stream);
+
+/* The direct conv kernel (tile configurations 10, 11, 12) with parts of its pipeline switched off (results are WRONG by
+ * design): diag 1 = stage only the first channel chunk (no global loads / LDS stores afterwards), diag 2 = additionally no
+ * workgroup barriers; diag 0 = the production kernel.  Timing these against each other attributes the matrix-pipe idle time
+ * to staging / synchronisation / the MFMA loop. */
+int tnv3_diag_conv3x3_forward(const float* src0, const float* wpack, float* dst, int n, int c0, int cout, int h, int w,
+                              int cfg, int diag, tnv3_stream_t stream);
+
+/* The Winograd forward kernels and their timing twins, raw convolution (no addend / affine / ReLU):
+ *   variant 0, 1, 2     the production kernels (as tnv3_conv3x3_wino_forward)
+ *   variant 11, 12, 13  twins of kernel 0: no DMA after the prologue / + no patch transform / + no barriers
+ *   variant 21 .. 26    twins of kernel 2: 21-23 as above; with DMA: 24 no patch transform, 25 transform without its V writes,
+ *                       26 transform without its raw reads */
+int tnv3_diag_conv3x3_wino_forward(const float* src, const float* u, float* dst, int n, int cin, int cout, int h, int w,
+                                   int variant, tnv3_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACKNETV3_HIP_DIAG_H */

@@ -3,6 +3,8 @@
 import json, os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import diaglib
 
 
 def sample(stop, out):
@@ -49,7 +51,7 @@ def main():
     res = {}
     lib = _lib.load()
     buf = torch.empty(256 * 8 * 256, dtype=torch.float32, device=dev)
-    run_phase("mfma_probe", lambda: _lib.check(lib.tnv3_mfma_f32_probe(_lib.ptr(buf), 2048, 20000, _lib.stream_ptr(buf))), 4.0, res)
+    run_phase("mfma_probe", lambda: diaglib.mfma_f32_probe(buf, 2048, 20000), 4.0, res)
     m = get_model("TrackNet", 8, "concat").to(dev).eval()
     x = torch.rand(10, 27, 288, 512, device=dev)
     with torch.no_grad():

@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from tracknetv3_amd import _lib, ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import diaglib
 
 def main():
     dev = torch.device("cuda:0")
@@ -23,7 +25,7 @@ def main():
             if cout % info["m_block"]:
                 continue
             for diag in (0, 1, 2):
-                f = lambda: _lib.check(lib.tnv3_conv3x3_forward_diag(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), n, cin, cout, h, w, cfg, diag, _lib.stream_ptr(x)))
+                f = lambda: diaglib.conv3x3_forward(x, wp, y, cfg, diag)
                 for _ in range(2): f()
                 torch.cuda.synchronize(dev)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,0 +1,47 @@
+"""ctypes binding of libtnv3_diag.so (include/tracknetv3_hip_diag.h) for the measurement scripts.  The product package never
+loads this library: its timing twins write wrong results by design."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tracknetv3_amd import _build, _lib  # noqa: E402
+
+_diag = None
+
+
+def load():
+    global _diag
+    if _diag is None:
+        path = _build.DIAG_LIB if os.path.exists(_build.DIAG_LIB) else _build.build_diag()
+        lib = ctypes.CDLL(path)
+        i, p = ctypes.c_int, ctypes.c_void_p
+        lib.tnv3_diag_last_error.restype = ctypes.c_char_p
+        for name, args in (("tnv3_diag_mfma_f32_probe", [p, i, i, p]),
+                           ("tnv3_diag_conv3x3_forward", [p, p, p, i, i, i, i, i, i, i, p]),
+                           ("tnv3_diag_conv3x3_wino_forward", [p, p, p, i, i, i, i, i, i, p])):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = i, args
+        _diag = lib
+    return _diag
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"tnv3_diag error {rc}: {load().tnv3_diag_last_error().decode()}")
+
+
+def mfma_f32_probe(buf, blocks, iters):
+    check(load().tnv3_diag_mfma_f32_probe(_lib.ptr(buf), int(blocks), int(iters), _lib.stream_ptr(buf)))
+
+
+def conv3x3_forward(x, wpack, y, cfg, diag):
+    n, cin, h, w = (int(v) for v in x.shape)
+    check(load().tnv3_diag_conv3x3_forward(_lib.ptr(x), _lib.ptr(wpack), _lib.ptr(y), n, cin, int(y.shape[1]), h, w, int(cfg), int(diag),
+                                           _lib.stream_ptr(x)))
+
+
+def conv3x3_wino_forward(x, u, y, variant):
+    n, cin, h, w = (int(v) for v in x.shape)
+    check(load().tnv3_diag_conv3x3_wino_forward(_lib.ptr(x), _lib.ptr(u), _lib.ptr(y), n, cin, int(y.shape[1]), h, w, int(variant),
+                                                _lib.stream_ptr(x)))

@@ -30,12 +30,12 @@ def main():
     dev = torch.device("cuda:0")
     out = {}
     # sustained fp32 MFMA rate of this chip under load (register-only probe): the practical ceiling of the conv kernels
-    from tracknetv3_amd import _lib
-    lib = _lib.load()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import diaglib
     for blocks, label in ((256 * 1, "1wg_per_cu"), (256 * 3, "3wg_per_cu"), (256 * 8, "8wg_per_cu")):
         buf = torch.empty(blocks * 256, device=dev)
         iters = 4000
-        ms = timeit(lambda: _lib.check(lib.tnv3_mfma_f32_probe(_lib.ptr(buf), blocks, iters, _lib.stream_ptr(buf))), 5, dev)
+        ms = timeit(lambda: diaglib.mfma_f32_probe(buf, blocks, iters), 5, dev)
         flops = blocks * 4 * iters * 8 * (2.0 * 32 * 32 * 2)
         out[f"mfma_f32_probe_{label}"] = {"ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 1)}
     net = get_model("InpaintNet").to(dev).eval()

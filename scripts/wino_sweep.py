@@ -33,12 +33,10 @@ def main():
         err = ((a - b).abs().max() / a.abs().max()).item()
         t_d = timeit(lambda: ops.conv3x3(x, wp, cout, mean=mu, scale=sc, shift=sh, relu=True, cfg=cfg))
         t_w = timeit(lambda: ops.conv3x3_wino(x, u, cout, mean=mu, scale=sc, shift=sh, relu=True))
-        other = int(os.environ.get("WINO_OTHER", "0" if ops.wino_variant() != 0 else "2"))   # the Winograd kernel to compare with
-        old = ops.wino_variant(other)
-        uo = ops.pack_wino_weights(wt)                                # the panel layout may depend on the variant
-        c = ops.conv3x3_wino(x, uo, cout, mean=mu, scale=sc, shift=sh, relu=True)
-        t_o = timeit(lambda: ops.conv3x3_wino(x, uo, cout, mean=mu, scale=sc, shift=sh, relu=True))
-        ops.wino_variant(old)
+        other = int(os.environ.get("WINO_OTHER", "0"))               # the Winograd kernel to compare with (per-call variant)
+        uo = u
+        c = ops.conv3x3_wino(x, uo, cout, mean=mu, scale=sc, shift=sh, relu=True, variant=other)
+        t_o = timeit(lambda: ops.conv3x3_wino(x, uo, cout, mean=mu, scale=sc, shift=sh, relu=True, variant=other))
         err_o = ((a - c).abs().max() / a.abs().max()).item()
         gf = 2.0 * 9 * cin * cout * h * w * n / 1e9
         out[f"{cout},{cin},{n},{h},{w}"] = {"direct_ms": round(t_d, 4), "wino_ms": round(t_w, 4), "direct_tflops": round(gf / t_d, 1),

@@ -22,6 +22,7 @@ inline Launcher make_launcher(tnv3_stream_t) { return Launcher{}; }
 inline void init_cu_count() {}   // the emulator plans for the default 256 CUs
 }  // namespace
 
+#define TNV3_TU_ALL 1
 #include "../../tracknetv3_amd/csrc/tnv3_capi_body.inc"
 
 extern "C" int tnv3_is_emulator(void) { return 1; }

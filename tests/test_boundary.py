@@ -21,9 +21,40 @@ def test_capi_library_builds_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/tracknetv3_hip.h but not exported"
     lib.tnv3_abi_version.restype = ctypes.c_int
-    assert lib.tnv3_abi_version() == 1
+    assert lib.tnv3_abi_version() == 2
     lib.tnv3_conv3x3_num_configs.restype = ctypes.c_int
     assert lib.tnv3_conv3x3_num_configs() >= 1
+    from tracknetv3_amd import _lib
+    assert set(_lib.EXPORTS) == declared, set(_lib.EXPORTS) ^ declared      # the ctypes layer binds exactly the header
+
+
+def test_abi_has_no_process_wide_state_and_no_wrong_result_kernels():
+    """'no mutable global state'.  Kernel families are per-call arguments; the timing twins (wrong results by
+    design) and the MFMA probe live in libtnv3_diag.so, which the product never loads."""
+    import subprocess
+    from tracknetv3_amd import _build
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "tracknetv3_hip.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(tnv3_[a-z0-9_]+)\s*\(", header))
+    # every entry point either takes a stream (enqueues work) or is a pure size / capability query
+    for name in declared:
+        proto = re.search(r"\b" + name + r"\s*\(([^;]*)\);", header, re.S).group(1)
+        is_query = name.endswith(("_bytes", "_floats", "_supported", "_num_configs", "_config_info", "abi_version", "last_error"))
+        assert ("tnv3_stream_t" in proto) != is_query, name
+    assert not [n for n in declared if n.endswith("_variant") or "diag" in n or "probe" in n]
+    exported = subprocess.run(["nm", "-D", "--defined-only", _build.build()], capture_output=True, text=True, check=True).stdout
+    names = set(re.findall(r" [TW] (tnv3_\w+)", exported))
+    assert names == declared, names ^ declared
+    # the diag library builds from the same sources and exports only tnv3_diag_*
+    dpath = _build.build_diag()
+    dnames = set(re.findall(r" [TW] (tnv3_\w+)", subprocess.run(["nm", "-D", "--defined-only", dpath], capture_output=True, text=True,
+                                                                    check=True).stdout))
+    dheader = open(os.path.join(ROOT, "include", "tracknetv3_hip_diag.h")).read()
+    assert dnames == set(re.findall(r"\b(tnv3_diag_[a-z0-9_]+)\s*\(", dheader)), dnames
+    # nothing under tracknetv3_amd/ mentions the diag library except the build script
+    for root, _, files in os.walk(os.path.join(ROOT, "tracknetv3_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "_build.py":
+                assert "tnv3_diag" not in open(os.path.join(root, f)).read(), f
 
 
 def test_product_path_has_no_cpu_fallback():

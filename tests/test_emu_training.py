@@ -52,13 +52,11 @@ def test_bn_train_forward_backward_emulated(emu):
                                   (1, 27, 0, 64, 5, 36, False)],
                          ids=["b_5to64", "a_dual_up_48to128", "b_64to192", "b_27to64_ragged"])
 @pytest.mark.parametrize("variant", [0, 1], ids=["regstaged", "ldsdma"])
-def test_wgrad_mfma_and_dgrad_emulated(emu, case, variant):
+def test_wgrad_mfma_and_dgrad_emulated(monkeypatch, emu, case, variant):
     from tracknetv3_amd import ops
-    old = ops.wgrad_variant(variant)
-    try:
-        _wgrad_case(case, ops)
-    finally:
-        ops.wgrad_variant(old)
+    from tracknetv3_amd import tuning
+    monkeypatch.setattr(tuning, "WGRAD_VARIANT", variant)      # per-call kernel variant (the C ABI has no process-wide knob)
+    _wgrad_case(case, ops)
 
 
 def _wgrad_case(case, ops):

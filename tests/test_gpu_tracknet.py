@@ -67,13 +67,11 @@ def test_dgrad_up2x_vs_autograd(gpu_device, case):
 
 @pytest.mark.parametrize("variant", [2, 0, 1], ids=["xisplit", "onewave", "interleaved"])
 @pytest.mark.parametrize("case", WINO_CASES + [(2, 256, 256, 72, 128), (1, 512, 512, 36, 64), (1, 64, 64, 288, 512), (3, 27, 64, 8, 192)])
-def test_conv3x3_wino_vs_torch(gpu_device, case, variant):
+def test_conv3x3_wino_vs_torch(monkeypatch, gpu_device, case, variant):
     from tracknetv3_amd import ops
-    old = ops.wino_variant(variant)
-    try:
-        e_plain, e_full = _wino_case(*case, gpu_device)
-    finally:
-        ops.wino_variant(old)
+    from tracknetv3_amd import tuning
+    monkeypatch.setattr(tuning, "WINO_VARIANT", variant)      # per-call kernel variant (the C ABI has no process-wide knob)
+    e_plain, e_full = _wino_case(*case, gpu_device)
     assert e_plain <= 4e-6 and e_full <= 8e-6, (e_plain, e_full)
 
 
@@ -81,9 +79,9 @@ def test_wino_pack_view(gpu_device):
     _pack_view_case(gpu_device)
 
 
-def test_wino_default_is_the_xi_split_kernel(gpu_device):
-    from tracknetv3_amd import ops
-    assert ops.wino_variant() == 2
+def test_wino_default_is_the_library_default(gpu_device):
+    from tracknetv3_amd import tuning
+    assert tuning.WINO_VARIANT in (-1, 2)          # -1: the library's default = the xi-split kernel
 
 
 def test_pool_head_pack(gpu_device):

@@ -52,13 +52,11 @@ def test_bn_train_forward_backward(gpu_device):
                                   (2, 512, 256, 256, 8, 32, True), (2, 256, 0, 512, 12, 32, False), (1, 128, 0, 256, 18, 52, False)],
                          ids=["27to64", "64to64", "dual192to64", "dual768to256", "256to512", "128to256_ragged"])
 @pytest.mark.parametrize("variant", [0, 1], ids=["regstaged", "ldsdma"])
-def test_wgrad_and_dgrad(gpu_device, case, variant):
+def test_wgrad_and_dgrad(monkeypatch, gpu_device, case, variant):
     from tracknetv3_amd import ops
-    old = ops.wgrad_variant(variant)
-    try:
-        _wgrad_case(case, ops, gpu_device)
-    finally:
-        ops.wgrad_variant(old)
+    from tracknetv3_amd import tuning
+    monkeypatch.setattr(tuning, "WGRAD_VARIANT", variant)      # per-call kernel variant (the C ABI has no process-wide knob)
+    _wgrad_case(case, ops, gpu_device)
 
 
 def _wgrad_case(case, ops, d):

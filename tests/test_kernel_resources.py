@@ -17,7 +17,7 @@ def resources(tmp_path_factory):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     out = tmp_path_factory.mktemp("res") / "capi.s"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value", "-Wno-cuda-compat", "-DTNV3_TU_ALL",
                         "-Rpass-analysis=kernel-resource-usage", "-o", str(out),
                         os.path.join(ROOT, "tracknetv3_amd", "csrc", "tnv3_capi.hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -1,41 +1,108 @@
 """Build libtnv3_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and on first import
-when the library is missing but hipcc is available."""
+when the library is missing but hipcc is available.
+
+csrc/tnv3_capi.hip is compiled once per kernel family (-DTNV3_TU_<FAMILY>), in parallel, into build/*.o; a family is
+recompiled only when one of the files its depfile lists changed.  `build_diag()` makes libtnv3_diag.so (measurement twins,
+include/tracknetv3_hip_diag.h) from the same source; the product never loads it."""
 import os
 import shutil  # noqa: I001
 
 import torch  # noqa: F401  (loaded first so that libtnv3_hip.so binds to torch's HIP runtime, not a second copy)
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "tnv3_capi.hip")
 LIB = os.path.join(PKG_DIR, "libtnv3_hip.so")
+DIAG_LIB = os.path.join(PKG_DIR, "libtnv3_diag.so")
+OBJ_DIR = os.path.join(PKG_DIR, "build")
+FAMILIES = ("MISC", "CONV", "WINO", "UP2X", "WGRAD", "TRAIN")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-cuda-compat"]
 
 
 def _sources():
-    out = [SRC, os.path.join(PKG_DIR, "..", "include", "tracknetv3_hip.h")]
+    out = [SRC, os.path.join(PKG_DIR, "..", "include", "tracknetv3_hip.h"), os.path.join(PKG_DIR, "..", "include", "tracknetv3_hip_diag.h")]
     for root, _, files in os.walk(os.path.join(PKG_DIR, "csrc")):
         out += [os.path.join(root, f) for f in files]
     return out
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def _newer_than(target, paths):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(s) > t for s in _sources() if os.path.exists(s))
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in paths if os.path.exists(s))
+
+
+def is_stale():
+    return _newer_than(LIB, _sources())
+
+
+def _dep_files(depfile):
+    """Prerequisites listed in a make-style depfile (hipcc -MD), or None when unreadable."""
+    try:
+        with open(depfile) as f:
+            text = f.read().replace("\\\n", " ")
+    except OSError:
+        return None
+    deps = []
+    for line in text.splitlines():
+        if ":" in line:
+            deps += line.split(":", 1)[1].split()
+    return [d for d in deps if d.startswith(os.path.dirname(PKG_DIR))] or None
+
+
+def _hipcc():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libtnv3_hip.so")
+    return hipcc
+
+
+def _compile(hipcc, tag, defines, verbose):
+    obj = os.path.join(OBJ_DIR, f"tnv3_{tag.lower()}.o")
+    dep = obj[:-2] + ".d"
+    deps = _dep_files(dep)
+    if os.path.exists(obj) and deps is not None and not _newer_than(obj, deps + [__file__]):
+        return obj, False
+    cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-MD", "-MF", dep, "-c", SRC, "-o", obj + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(obj + ".tmp", obj)
+    return obj, True
+
+
+def _link(hipcc, objs, lib, verbose):
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(lib + ".tmp", lib)
 
 
 def build(force=False, verbose=False):
     """Compile every HIP kernel + the C ABI for gfx950.  Cross-compiles without a GPU."""
     if not force and not is_stale():
         return LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found: cannot build libtnv3_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           SRC, "-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            if f.startswith("tnv3_") and not f.startswith("tnv3_diag"):
+                os.remove(os.path.join(OBJ_DIR, f))
+    with ThreadPoolExecutor(max_workers=min(len(FAMILIES), os.cpu_count() or 1)) as pool:
+        res = list(pool.map(lambda fam: _compile(hipcc, fam, [f"TNV3_TU_{fam}"], verbose), FAMILIES))
+    _link(hipcc, [o for o, _ in res], LIB, verbose)
     return LIB
+
+
+def build_diag(force=False, verbose=False):
+    """libtnv3_diag.so: the timing twins / MFMA probe (a measurement tool for scripts/, never loaded by the package)."""
+    if not force and not _newer_than(DIAG_LIB, _sources()):
+        return DIAG_LIB
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    obj, _ = _compile(hipcc, "DIAG", ["TNV3_DIAG", "TNV3_TU_DIAG"], verbose)
+    _link(hipcc, [obj], DIAG_LIB, verbose)
+    return DIAG_LIB

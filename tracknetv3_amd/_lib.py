@@ -15,6 +15,7 @@ _c = ctypes
 _f32p = _c.c_void_p
 _lib = None
 _is_emulator = False
+ABI_VERSION = 2
 
 
 class Tnv3Error(RuntimeError):
@@ -46,12 +47,11 @@ def _declare(lib):
     sig("tnv3_dgrad_up2x", i, p, p, p, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wgrad_up2x_workspace_bytes", sz, i, i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad_up2x", i, p, p, p, p, p, sz, i, i, i, i, i, i, p)
-    sig("tnv3_conv3x3_wino_variant", i, i)
     sig("tnv3_conv3x3_wino_packed_floats", sz, i, i)
     sig("tnv3_conv3x3_wino_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wino_pack", i, p, p, i, i, p)
     sig("tnv3_conv3x3_wino_pack_view", i, p, p, i, i, i, i, i, p)
-    sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wgrad_wino_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad_wino_workspace_bytes", sz, i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad_wino", i, p, p, p, p, sz, i, i, i, i, i, p)
@@ -62,13 +62,12 @@ def _declare(lib):
     sig("tnv3_peakfind_workspace_bytes", sz, i, i, i)
     sig("tnv3_heatmap_peakfind", i, p, f, i, p, p, sz, i, i, i, p)
     sig("tnv3_heatmap_box_max", i, p, p, p, i, i, i, p)
-    sig("tnv3_conv3x3_wgrad_variant", i, i)
     sig("tnv3_bn_workspace_bytes", sz, i)
     sig("tnv3_bn_train_forward", i, p, p, p, p, p, f, f, p, p, p, p, sz, i, i, i, p)
     sig("tnv3_bn_relu_backward", i, p, p, p, p, p, p, p, p, p, p, p, sz, i, i, i, p)
     sig("tnv3_conv3x3_dgrad", i, p, p, p, p, i, i, i, i, i, i, i, p)
-    sig("tnv3_conv3x3_wgrad_workspace_bytes", sz, i, i, i, i, i, i)
-    sig("tnv3_conv3x3_wgrad", i, p, p, p, p, p, sz, i, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wgrad_workspace_bytes", sz, i, i, i, i, i, i, i)
+    sig("tnv3_conv3x3_wgrad", i, p, p, p, p, p, sz, i, i, i, i, i, i, i, i, p)
     sig("tnv3_wbce_workspace_bytes", sz, i)
     sig("tnv3_wbce_forward", i, p, p, p, p, sz, i, lg, i, p)
     sig("tnv3_wbce_backward", i, p, p, p, p, i, lg, i, p)
@@ -77,8 +76,6 @@ def _declare(lib):
     sig("tnv3_maxpool2x2_backward_add", i, p, p, p, p, lg, i, i, p)
     sig("tnv3_upsample2x_backward", i, p, p, lg, i, i, p)
     sig("tnv3_mixup", i, p, p, p, p, i, lg, p)
-    sig("tnv3_mfma_f32_probe", i, p, i, i, p)
-    sig("tnv3_conv3x3_forward_diag", i, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_resample_bicubic_u8", i, p, p, p, p, p, p, p, i, p, p, p, i, p, i, i, i, i, i, i, p)
     sig("tnv3_median_u8", i, p, p, p, i, lg, p)
     sig("tnv3_absdiff_sum_u8", i, p, p, p, i, lg, p)
@@ -95,12 +92,12 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_bn_relu_backward", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",
            "tnv3_wbce_workspace_bytes", "tnv3_wbce_forward", "tnv3_wbce_backward", "tnv3_head_backward_workspace_bytes",
            "tnv3_head_backward", "tnv3_maxpool2x2_backward_add", "tnv3_upsample2x_backward", "tnv3_mixup",
-           "tnv3_mfma_f32_probe", "tnv3_conv3x3_forward_diag", "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_absdiff_sum_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad",
-           "tnv3_heatmap_box_max", "tnv3_conv3x3_wgrad_variant", "tnv3_conv3x3_forward_add", "tnv3_conv_up2x_packed_floats",
+           "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_absdiff_sum_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad",
+           "tnv3_heatmap_box_max", "tnv3_conv3x3_forward_add", "tnv3_conv_up2x_packed_floats",
            "tnv3_pack_up2x_weights", "tnv3_conv_up2x_forward", "tnv3_dgrad_up2x_packed_floats", "tnv3_pack_dgrad_up2x_weights",
            "tnv3_dgrad_up2x", "tnv3_conv3x3_wgrad_up2x_workspace_bytes", "tnv3_conv3x3_wgrad_up2x",
            "tnv3_conv3x3_wgrad_wino_supported", "tnv3_conv3x3_wgrad_wino_workspace_bytes", "tnv3_conv3x3_wgrad_wino",
-           "tnv3_conv3x3_wino_variant", "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_forward"]
+           "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_forward"]
 
 
 def library_path():
@@ -123,13 +120,9 @@ def load():
     except OSError as e:
         raise Tnv3Error(f"cannot load {path}: {e}") from e
     _declare(lib)
-    if lib.tnv3_abi_version() != 1:
+    if lib.tnv3_abi_version() != ABI_VERSION:
         raise Tnv3Error("libtnv3_hip.so ABI version mismatch")
     _lib, _is_emulator = lib, False
-    if os.environ.get("TNV3_WINO_VARIANT", "") in ("0", "1", "2"):    # pick the Winograd forward kernel (ops.wino_variant; default 2)
-        lib.tnv3_conv3x3_wino_variant(int(os.environ["TNV3_WINO_VARIANT"]))
-    if os.environ.get("TNV3_WGRAD_VARIANT", "") in ("0", "1"):       # diagnostic: pick the weight-gradient kernel family
-        lib.tnv3_conv3x3_wgrad_variant(int(os.environ["TNV3_WGRAD_VARIANT"]))
     return lib
 
 
@@ -182,3 +175,19 @@ def dev_check(*tensors):
 
 def ptr(t):
     return _c.c_void_p(t.data_ptr()) if t is not None else _c.c_void_p(0)
+
+
+def on_tensor_device(fn):
+    """Decorator: run `fn` with the device of its first tensor argument current (see the note at the end of ops.py)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                if a.is_cuda and a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapper

@@ -96,6 +96,7 @@ class _TrackNetTrain(torch.autograd.Function):
             a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                    bn.eps, bn.momentum)
             bn.num_batches_tracked.add_(1)
+            blk._cache.pop("aff", None)       # running_var was rewritten through a raw pointer: the folded eval scale is stale
             saved.append(dict(blk=blk, x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,
                               bn_ver=(bn.weight._version, bn.bias._version)))
             return a
@@ -127,6 +128,9 @@ class _TrackNetTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dp):
         net, saved = ctx.net, ctx.saved
+        if saved is None:
+            raise RuntimeError("TrackNet backward ran twice over the same forward: the training node frees its activations at the "
+                               "end of backward (retain_graph=True is not supported); run the forward again")
         hook = _grad_ready_hook
         grads = {}
         keep = []
@@ -238,7 +242,7 @@ class _TrackNetTrain(torch.autograd.Function):
 def tracknet_forward_train(net, x):
     params = [p for p in net.parameters()]
     net._train_params = params
-    if not torch.is_grad_enabled() or not any(p.requires_grad for p in params):
+    if not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for p in params)):
         # train-mode forward without autograd (e.g. under no_grad): still uses batch statistics / updates buffers
         class _Ctx:
             pass

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(S* COB) conv1d_k3_kernel(const Conv1dArgs a) {
 
 // dPre = dOut * act'(out):  LeakyReLU'(0.01) from the sign of the output, sigmoid' = o(1-o).   (autograd of model.py:81,111)
 // nlc != 0: dOut / out are [N][L][C] (the network output), dPre is always [N][C][L].
-__global__ void __launch_bounds__(256) conv1d_act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+inline __global__ void __launch_bounds__(256) conv1d_act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                              float* __restrict__ dpre, int N, int C, int L, int act, int nlc) {
   const long total = (long)N * C * L;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {

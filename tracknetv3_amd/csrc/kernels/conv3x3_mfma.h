@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) conv3x3_mfma_kernel(const 
 // Weight packing:  W[Cout][Cin][3][3]  ->  Wp[Cin_pad][3][3][Cout]              (forward)
 //                  W[Cout][Cin][3][3]  ->  Wp[Cout_pad][3][3][Cin] with taps flipped  (dgrad: dX = conv(dY, W^T flipped))
 // One thread per packed element; rows >= the real K extent are zero.
-__global__ void pack_conv3x3_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
+inline __global__ void pack_conv3x3_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                             int Cout, int Cin, int Kpad, int transpose_flip) {
   const int M = transpose_flip ? Cin : Cout;     // packed inner (GEMM M) extent
   const int Kc = transpose_flip ? Cout : Cin;    // packed outer (GEMM K channels) extent
@@ -432,7 +432,7 @@ __global__ void pack_conv3x3_weights_kernel(const float* __restrict__ w, float* 
 
 // Eval-mode BatchNorm2d (model.py:9): y = (x - running_mean) * scale + beta with
 //   scale = gamma / sqrt(running_var + eps)      (the mean is NOT folded into the shift: see the epilogue note)
-__global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ rvar, float eps,
+inline __global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ rvar, float eps,
                                      float* __restrict__ scale, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) scale[c] = gamma[c] / sqrtf(rvar[c] + eps);

@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_split_mfma_kernel(const 
 // U[Cin_pad][xi = i*4+j][Cout] = (G g G^T)[i][j] from W[Cout][Cin][3][3]; rows ci >= Cin are zero
 // The filter of logical (co, ci) starts at w + co * s_co + ci * s_ci; flip reads its taps back to front (the data
 // gradient's filter w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw] is s_co = 9, s_ci = Cin_w * 9, flip = 1 on the same tensor).
-__global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad, long s_co,
+inline __global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad, long s_co,
                                          long s_ci, int flip) {
   const long body = (long)CinPad * 16 * Cout, total = body + kPackZeroTail;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {

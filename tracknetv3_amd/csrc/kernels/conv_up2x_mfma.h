@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv_up2x_mfma_kernel(const ConvUp2xA
 }
 
 // Wq[C0_pad][cls][a*2+b][Cout] from the layer's nn.Conv2d weight W[Cout][Cin][3][3] (first C0 input channels), + zero rows.
-__global__ void pack_up2x_weights_kernel(const float* __restrict__ w, float* __restrict__ wq, int Cout, int Cin, int C0, int C0pad) {
+inline __global__ void pack_up2x_weights_kernel(const float* __restrict__ w, float* __restrict__ wq, int Cout, int Cin, int C0, int C0pad) {
   const long total = (long)C0pad * 16 * Cout;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int co = (int)(e % Cout);
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(Cfg::NT) dgrad_up2x_mfma_kernel(const DgradUp2
 }
 
 // G[Cout_pad][dri*4+dci][C0] from W[Cout][Cin][3][3] (first C0 input channels): dr = dri - 1 = 2 - 2a - ph, dc likewise.
-__global__ void pack_dgrad_up2x_weights_kernel(const float* __restrict__ w, float* __restrict__ g, int Cout, int Cin, int C0, int CoutPad) {
+inline __global__ void pack_dgrad_up2x_weights_kernel(const float* __restrict__ w, float* __restrict__ g, int Cout, int Cin, int C0, int CoutPad) {
   const long total = (long)CoutPad * 16 * C0;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(e % C0);
@@ -408,7 +408,7 @@ __global__ void pack_dgrad_up2x_weights_kernel(const float* __restrict__ w, floa
 // ordinary 3x3 weight gradient of (Xlow, Z[pr][pc]) -- wgrad3x3_mfma_kernel<WgradCfg<.., NTAP = 4>>.
 
 // zp[(pr*2+pc)][plane][i][j] = dz[plane][2i+pr][2j+pc];  planes = N*Cout, W % 4 == 0
-__global__ void __launch_bounds__(256) space_to_depth2_kernel(const float* __restrict__ dz, float* __restrict__ zp, long planes, int H, int W) {
+inline __global__ void __launch_bounds__(256) space_to_depth2_kernel(const float* __restrict__ dz, float* __restrict__ zp, long planes, int H, int W) {
   typedef float s2d_f2 __attribute__((ext_vector_type(2)));
   const int HL = H >> 1, WL = W >> 1, W4 = W >> 2;
   const long total = planes * H * W4;
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256) space_to_depth2_kernel(const float* __res
 }
 
 // dW[Cout][C0+C1][3][3]: channels < C0 folded from D4[img = pr*2+pc][Cout][C0][th*2+tw], the rest copied from dw_skip[Cout][C1][9]
-__global__ void __launch_bounds__(256) wgrad_up2x_assemble_kernel(const float* __restrict__ d4, const float* __restrict__ dw_skip,
+inline __global__ void __launch_bounds__(256) wgrad_up2x_assemble_kernel(const float* __restrict__ d4, const float* __restrict__ dw_skip,
                                                                   float* __restrict__ dw, int Cout, int C0, int C1) {
   const int Cin = C0 + C1;
   const long total = (long)Cout * Cin * 9;

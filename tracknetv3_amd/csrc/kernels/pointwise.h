@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) head1x1_sigmoid_kernel(const float* __res
 // 2x2 / stride-2 max pooling over [NC][H][W] planes; each thread produces two horizontally adjacent outputs
 // from two 16-byte row reads.  Comparison order = row-major window order with strict '>' (PyTorch's tie rule;
 // immaterial here).  NaN propagates like torch (a NaN input wins).
-__global__ void __launch_bounds__(256) maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ y,
+inline __global__ void __launch_bounds__(256) maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          long NC, int H, int W) {
   const int Ho = H >> 1, Wo = W >> 1, Wo2 = Wo >> 1;
   const long total = NC * Ho * Wo2;
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) maxpool2x2_kernel(const float* __restrict
 // Diagnostic: sustained v_mfma_f32_32x32x2_f32 rate of the chip as it is clocked under load -- every wave issues
 // `iters` x 8 independent accumulator chains from registers only (no LDS, no global traffic in the loop).  Used by
 // scripts/microbench.py to put the conv kernels' TFLOP/s next to what the matrix pipe delivers at the same time.
-__global__ void __launch_bounds__(256) mfma_f32_probe_kernel(float* __restrict__ out, int iters, float a0, float b0) {
+inline __global__ void __launch_bounds__(256) mfma_f32_probe_kernel(float* __restrict__ out, int iters, float a0, float b0) {
   typedef float pf32x16 __attribute__((ext_vector_type(16)));
   pf32x16 acc[8];
 #pragma unroll

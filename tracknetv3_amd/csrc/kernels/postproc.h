@@ -23,7 +23,7 @@ namespace tnv3 {
 
 typedef float pp_f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256) ensemble_frames_kernel(const float* __restrict__ win, int n_local, long s_base,
+inline __global__ void __launch_bounds__(256) ensemble_frames_kernel(const float* __restrict__ win, int n_local, long s_base,
                                                               int L, int E, const float* __restrict__ weight, long t0,
                                                               int n_frames, long num_sample, float* __restrict__ out) {
   // win: [n_local][L][E] (window s_base + i at row i), E = elements per position (H*W, or 2 for coordinates)
@@ -81,7 +81,7 @@ __device__ __forceinline__ void ccl_union(int* lab, int a, int b) {
 // Pass 1 -- threshold + horizontal runs, no atomics: a wave owns 64 consecutive pixels; from the ballot of the
 // foreground bits every pixel gets the index of the first pixel of its run (within the 64-pixel segment and the image
 // row) as its label, and the run's first pixel records the run's box.  Dense maps collapse to one node per run.
-__global__ void __launch_bounds__(256) ccl_init_kernel(const float* __restrict__ heat, float thr, int* __restrict__ label,
+inline __global__ void __launch_bounds__(256) ccl_init_kernel(const float* __restrict__ heat, float thr, int* __restrict__ label,
                                                        int* __restrict__ box, unsigned long long* __restrict__ best,
                                                        int H, int W) {
   const int HW = H * W;
@@ -120,7 +120,7 @@ __device__ __forceinline__ bool ccl_fg(const int* lab, int q) { return ccl_load(
 //   * against the row above, the pixel under N links with N unless its left neighbour already sits under the same
 //     upper run (W and NW set); with N clear, NW is linked only by a run's first pixel and NE only when the right
 //     neighbour (which has NE as its N) is background.
-__global__ void __launch_bounds__(256) ccl_merge_kernel(int* __restrict__ label, int H, int W) {
+inline __global__ void __launch_bounds__(256) ccl_merge_kernel(int* __restrict__ label, int H, int W) {
   const int HW = H * W;
   int* lab = label + (size_t)blockIdx.y * HW;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(int* __restrict__ label,
 
 // Pass 3 -- one node per run: resolve the root, fold the run's box into the root's box (atomics only when they would
 // change the value; min-y needs none: the root is the component's first pixel in raster order), flatten the label.
-__global__ void __launch_bounds__(256) ccl_box_kernel(int* __restrict__ label, int* __restrict__ box, int H, int W) {
+inline __global__ void __launch_bounds__(256) ccl_box_kernel(int* __restrict__ label, int* __restrict__ box, int H, int W) {
   const int HW = H * W;
   int* lab = label + (size_t)blockIdx.y * HW;
   int* bx = box + (size_t)blockIdx.y * 4 * HW;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) ccl_box_kernel(int* __restrict__ label, i
   }
 }
 
-__global__ void __launch_bounds__(256) ccl_select_kernel(const int* __restrict__ label, const int* __restrict__ box,
+inline __global__ void __launch_bounds__(256) ccl_select_kernel(const int* __restrict__ label, const int* __restrict__ box,
                                                          unsigned long long* __restrict__ best, int H, int W,
                                                          int tie_last_wins) {
   const int HW = H * W;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) ccl_select_kernel(const int* __restrict__
 // out[f] = max of heat[f] over the box (x, y, w, h) = boxes[f] (the whole map when boxes == nullptr); 0 for an empty box.
 // test.py:164-167: the detection confidence `np.amax(y_p[y:y+h, x:x+w])`; with boxes == nullptr: the `np.amax(y_t) > 0`
 // "ground truth has a ball" test of test.py:170-178.  One workgroup per map, fixed-shape tree reduction (max is exact).
-__global__ void __launch_bounds__(256) heatmap_box_max_kernel(const float* __restrict__ heat, const int* __restrict__ boxes,
+inline __global__ void __launch_bounds__(256) heatmap_box_max_kernel(const float* __restrict__ heat, const int* __restrict__ boxes,
                                                               float* __restrict__ out, int H, int W) {
   __shared__ float red[256];
   const int f = blockIdx.x;
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) heatmap_box_max_kernel(const float* __res
 }
 
 // out[f] = (x, y, w, h) of the winning box, or (0,0,0,0) when the thresholded map is empty (test.py:60-62)
-__global__ void ccl_emit_kernel(const int* __restrict__ box, const unsigned long long* __restrict__ best,
+inline __global__ void ccl_emit_kernel(const int* __restrict__ box, const unsigned long long* __restrict__ best,
                                 int* __restrict__ out, int frames, int H, int W, int tie_last_wins) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= frames) return;

@@ -20,7 +20,7 @@ __device__ __forceinline__ unsigned char resample_clip8(int acc) {
 }
 
 // One workgroup per (frame, source row).  src [F][H][W][C] u8 -> dst [F][H][OW][C] u8.
-__global__ void __launch_bounds__(256) resample_h_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+inline __global__ void __launch_bounds__(256) resample_h_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
                                                             const int* __restrict__ xmin, const int* __restrict__ xcnt,
                                                             const int* __restrict__ kk, int ksize, int H, int W, int C, int OW) {
   __shared__ unsigned char row_s[kResampleMaxRowBytes];
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) resample_h_u8_kernel(const unsigned char*
 }
 
 // One workgroup per (frame, output row).  src [F][H][OW][C] u8 -> dst_f32 [F][C][OH][OW] = lut[u8]  and/or  dst_u8 [F][OH][OW][C].
-__global__ void __launch_bounds__(256) resample_v_u8_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst_f32,
+inline __global__ void __launch_bounds__(256) resample_v_u8_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst_f32,
                                                             unsigned char* __restrict__ dst_u8, const int* __restrict__ ymin,
                                                             const int* __restrict__ ycnt, const int* __restrict__ kk, int ksize,
                                                             const float* __restrict__ lut, int H, int OW, int C, int OH) {
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) resample_h_rgb_kernel(const unsigned char
 }
 
 // Vertical pass, four consecutive output bytes per thread (32-bit loads of the intermediate rows); (OW*C) % 4 == 0.
-__global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst_f32,
+inline __global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst_f32,
                                                               unsigned char* __restrict__ dst_u8, const int* __restrict__ ymin,
                                                               const int* __restrict__ ycnt, const int* __restrict__ kk, int ksize,
                                                               const float* __restrict__ lut, int H, int OW, int C, int OH) {
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsigned cha
 // 128 threads x 256 32-bit bins = 128 KB of LDS; bin-major layout keeps the 32 lanes of a half-wave on 32 banks.
 // med2 (optional): a + b as uint16 = twice the float median (np.median of an even count ends in .5): what the
 // difference-frame modes subtract (dataset.py:439) without leaving integer arithmetic.
-__global__ void __launch_bounds__(128) median_u8_kernel(const unsigned char* __restrict__ frames, unsigned char* __restrict__ med,
+inline __global__ void __launch_bounds__(128) median_u8_kernel(const unsigned char* __restrict__ frames, unsigned char* __restrict__ med,
                                                         unsigned short* __restrict__ med2, int T, long P) {
   __shared__ unsigned int hist_s[256 * 128];          // [bin][thread]: 128 KB of the CU's 160 KB
   const int tid = threadIdx.x;
@@ -199,7 +199,7 @@ struct NibbleHist {
   }
 };
 
-__global__ void __launch_bounds__(256) median_u8_radix_kernel(const unsigned int* __restrict__ frames4, unsigned char* __restrict__ med,
+inline __global__ void __launch_bounds__(256) median_u8_radix_kernel(const unsigned int* __restrict__ frames4, unsigned char* __restrict__ med,
                                                               unsigned short* __restrict__ med2, int T, long P4) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P4) return;
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) median_u8_radix_kernel(const unsigned int
 // Difference frame of bg_mode 'subtract' / 'subtract_concat' (dataset.py:439, 443):
 //   out[f][p] = uint8( sum_c |frame[f][p][c] - median[p][c]| )   with a float64 median -> truncate, then wrap mod 256.
 // In integers: s2 = sum_c |2*v - med2|,  out = (s2 >> 1) & 255.   frames [F][P][3] u8, med2 [P][3] u16 -> out [F][P] u8.
-__global__ void __launch_bounds__(256) absdiff_sum_u8_kernel(const unsigned char* __restrict__ frames,
+inline __global__ void __launch_bounds__(256) absdiff_sum_u8_kernel(const unsigned char* __restrict__ frames,
                                                              const unsigned short* __restrict__ med2,
                                                              unsigned char* __restrict__ out, int F, long P) {
   const long total = (long)F * P;

@@ -28,7 +28,7 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* [4] LDS
 
 // ---- BatchNorm (training) forward ------------------------------------------------------------------------------
 // partial[c][s] = (sum, sumsq) of z[:, c, :] over the s-th slice of the N*HW elements.  grid = (kRedSplit, C)
-__global__ void __launch_bounds__(256) bn_stats_partial_kernel(const float* __restrict__ z, double* __restrict__ partial,
+inline __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const float* __restrict__ z, double* __restrict__ partial,
                                                                int N, int C, int HW) {
   __shared__ double red[4];
   const int c = blockIdx.y, s = blockIdx.x;
@@ -52,7 +52,7 @@ __device__ __forceinline__ float bn_scale(float gamma, float invstd) { return (f
 
 // mean / biased var -> (scale, shift) for the normalise pass, saved (mean, invstd) for backward, running-stat update
 // with the UNBIASED variance.  One thread per channel.
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+inline __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, float* __restrict__ running_mean,
                                          float* __restrict__ running_var, float eps, float momentum, long count,
                                          float* __restrict__ scale, float* __restrict__ save_mean,
@@ -76,7 +76,7 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, con
 }
 
 // a = max((z - mean[c])*scale[c] + beta[c], 0)  -- subtract first, like the reference: no cancellation when |mean| >> std
-__global__ void __launch_bounds__(256) bn_apply_relu_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+inline __global__ void __launch_bounds__(256) bn_apply_relu_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ a, long NC, int C, int HW) {
   const int hw4 = HW >> 2;
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_partial_kernel(const float* _
 }
 
 // dbeta = sum g, dgamma = sum g*xhat; coefficients of the apply pass:  dZ = k0*g - k1 - k2*xhat
-__global__ void bn_relu_bwd_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+inline __global__ void bn_relu_bwd_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
                                             const float* __restrict__ invstd, long count, float* __restrict__ dgamma,
                                             float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,7 +191,7 @@ __device__ __forceinline__ float wbce_elem(float p, float y) {
 }
 
 // partial[n][s] = sum of the element losses of sample n over slice s.     grid = (kRedSplit, N)
-__global__ void __launch_bounds__(256) wbce_partial_kernel(const float* __restrict__ p, const float* __restrict__ y,
+inline __global__ void __launch_bounds__(256) wbce_partial_kernel(const float* __restrict__ p, const float* __restrict__ y,
                                                            double* __restrict__ partial, long per_sample) {
   __shared__ double red[4];
   const int n = blockIdx.y, s = blockIdx.x;
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) wbce_partial_kernel(const float* __restri
 }
 
 // reduce != 0: out[0] = mean over everything; else out[n] = per-sample mean   (utils/metric.py:17-20)
-__global__ void wbce_finalize_kernel(const double* __restrict__ partial, float* __restrict__ out, int N, long per_sample, int reduce) {
+inline __global__ void wbce_finalize_kernel(const double* __restrict__ partial, float* __restrict__ out, int N, long per_sample, int reduce) {
   if (reduce) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       double t = 0.0;
@@ -222,7 +222,7 @@ __global__ void wbce_finalize_kernel(const double* __restrict__ partial, float* 
 }
 
 // dL/dp = upstream[n or 0] * d(elem)/dp / denom      (closed form; clamp gradient is 0 outside [1e-7, 1])
-__global__ void __launch_bounds__(256) wbce_backward_kernel(const float* __restrict__ p, const float* __restrict__ y,
+inline __global__ void __launch_bounds__(256) wbce_backward_kernel(const float* __restrict__ p, const float* __restrict__ y,
                                                             const float* __restrict__ upstream, int upstream_per_sample,
                                                             float inv_denom, float* __restrict__ dp, long per_sample, long total) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) wbce_backward_kernel(const float* __restr
 //   dW: a thread owns channel c for ALL l over a quarter of the tile's pixels: one a read and L/4 16-byte broadcast reads of
 //       dz per pixel feed L FMAs; the four pixel quarters (waves) are summed in fixed order at the end.
 constexpr int kHeadP = 128, kHeadC = 64, kHeadLMax = 16;
-__global__ void __launch_bounds__(256) head_backward_kernel(const float* __restrict__ dP, const float* __restrict__ p,
+inline __global__ void __launch_bounds__(256) head_backward_kernel(const float* __restrict__ dP, const float* __restrict__ p,
                                                             const float* __restrict__ a, const float* __restrict__ w,
                                                             float* __restrict__ dA, float* __restrict__ part /* [grid][L*C + L] */,
                                                             int N, int L, int HW) {
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256) head_backward_kernel(const float* __restr
 }
 
 // out[i] = sum_b part[b][i] in fixed order (double accumulate).  Used for head dW/db and the wgrad split-K slabs.
-__global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nparts) {
+inline __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nparts) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     double s = 0.0;
     for (int b = 0; b < nparts; ++b) s += (double)part[(size_t)b * n + i];
@@ -382,13 +382,13 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restri
   }
 }
 
-__global__ void __launch_bounds__(256) fill_zero_kernel(float* __restrict__ p, int n) {
+inline __global__ void __launch_bounds__(256) fill_zero_kernel(float* __restrict__ p, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.0f;
 }
 
 // Same sum (same order, so the same bits), 16 bytes per lane and four slabs in flight: n % 4 == 0, 16-byte aligned.
 typedef float to_f32x4 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) sum_partials_vec4_kernel(const float* __restrict__ part, float* __restrict__ out, long n4,
+inline __global__ void __launch_bounds__(256) sum_partials_vec4_kernel(const float* __restrict__ part, float* __restrict__ out, long n4,
                                                                 int nparts) {
   const to_f32x4* src = reinterpret_cast<const to_f32x4*>(part);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(256) sum_partials_vec4_kernel(const float* __r
 }
 
 // out[i] = sum_b part[b*stride + offset + i]  (fixed order, double accumulate)
-__global__ void __launch_bounds__(256) sum_partials_strided_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+inline __global__ void __launch_bounds__(256) sum_partials_strided_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
                                                                    int nparts, long stride, long offset) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     double s = 0.0;
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) sum_partials_strided_kernel(const float* 
 // The same strided sum for FEW outputs and MANY parts (head dW/db: 520 outputs x 1024 workgroup partials): one wave per
 // output, lane l adds parts l, l+64, ... in order, then the 64 lane sums are folded in lane order -- a fixed summation
 // tree, so the result is deterministic (it differs from the serial order above only in association).
-__global__ void __launch_bounds__(256) sum_partials_wave_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+inline __global__ void __launch_bounds__(256) sum_partials_wave_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
                                                                 int nparts, long stride, long offset) {
   const int lane = threadIdx.x & 63;
   const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256) sum_partials_wave_kernel(const float* __r
 
 // ---- pooling / upsampling backward ------------------------------------------------------------------------------
 // dx = dskip + route(dpool): the FIRST maximum of each 2x2 window (row-major, strict '>') receives the pooled gradient.
-__global__ void __launch_bounds__(256) maxpool2x2_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dpool,
+inline __global__ void __launch_bounds__(256) maxpool2x2_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dpool,
                                                                  const float* __restrict__ dskip, float* __restrict__ dx,
                                                                  long NC, int H, int W) {
   const int Ho = H >> 1, Wo = W >> 1;
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_add_kernel(const float* __
 }
 
 // nearest 2x upsample backward: d_lo[h][w] = sum of the 2x2 block of d_hi
-__global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __restrict__ d_hi, float* __restrict__ d_lo,
+inline __global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __restrict__ d_hi, float* __restrict__ d_lo,
                                                              long NC, int Hl, int Wl) {
   const long total = NC * Hl * Wl;
   const int Wh = 2 * Wl;
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __rest
 }
 
 // ---- mixup (train.py:32-40): out[n] = x[n]*lam[n] + x[perm[n]]*(1-lam[n]) -----------------------------------------
-__global__ void __launch_bounds__(256) mixup_kernel(const float* __restrict__ x, const float* __restrict__ lam,
+inline __global__ void __launch_bounds__(256) mixup_kernel(const float* __restrict__ x, const float* __restrict__ lam,
                                                     const int* __restrict__ perm, float* __restrict__ out, int N, long per_sample) {
   const long per4 = per_sample >> 2;
   const long total4 = (long)N * per4;

@@ -41,7 +41,7 @@ struct WgradWinoCfg {
   static_assert(DZ_RAW % (4 * NT) == 0 && X_RAW % (4 * NT) == 0, "pieces must deal evenly");
 };
 
-__global__ void __launch_bounds__(WgradWinoCfg::NT) wgrad_wino_mfma_kernel(const WgradWinoArgs a) {
+inline __global__ void __launch_bounds__(WgradWinoCfg::NT) wgrad_wino_mfma_kernel(const WgradWinoArgs a) {
   using Cfg = WgradWinoCfg;
   constexpr int NT = Cfg::NT, TS = Cfg::TS, XW = Cfg::XW;
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(WgradWinoCfg::NT) wgrad_wino_mfma_kernel(const
 // quarter in fp64; the quarters are combined in the fixed order p = 0..3 through LDS (deterministic), then 48 threads
 // apply G^T . G, three outputs each.  One thread per element (the first version) left a 128 x 128 layer with 64 blocks
 // walking 1024 dependent-latency loads each: 0.3 ms per launch for 67 MB.
-__global__ void __launch_bounds__(256) wgrad_wino_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout, int Cin,
+inline __global__ void __launch_bounds__(256) wgrad_wino_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout, int Cin,
                                                               int splitK) {
   __shared__ double red[4][16][16];                  // [p][xi][el]
   __shared__ float us[16][16];                       // [xi][el]

@@ -50,10 +50,12 @@ using ConvC16 = ConvCfg<2, 1, 1, 4, 4, 32, 4, 1, 2, 1, 2>;   // cfg 12 tile, CC 
 using ConvC17 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1, 2>;   // cfg 11 tile,       3-stage LDS-DMA + counted vmcnt
 using ConvC18 = ConvCfg<2, 1, 1, 8, 8, 32, 4, 1, 2, 1, 2>;   // cfg 10 tile, CC 4, 3-stage LDS-DMA + counted vmcnt
 constexpr int kNumConvConfigs = 19;
-// diagnostic twins (tnv3_conv3x3_forward_diag only): same geometry, runtime `diag` honoured
+#ifdef TNV3_DIAG
+// diagnostic twins (libtnv3_diag.so only: tnv3_diag_conv3x3_forward): same geometry, runtime `diag` honoured
 using ConvD10 = ConvCfg<2, 1, 1, 8, 8, 32, 8, 1, 2, 1, 0, 1>;
 using ConvD11 = ConvCfg<2, 1, 2, 4, 4, 32, 4, 1, 2, 1, 0, 1>;
 using ConvD12 = ConvCfg<2, 1, 1, 4, 4, 32, 8, 1, 2, 1, 0, 1>;
+#endif
 
 struct ConvCfgInfo { int MB, TR, TC, CC, NT, LDS; };
 template <class C> constexpr ConvCfgInfo cfg_info() { return {C::MB, C::TR, C::TC, C::CC, C::NT, C::LDS_BYTES}; }
@@ -84,9 +86,10 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// Compute units of the current device (256 on an unpartitioned MI355X: 8 XCDs x 32 CUs); the C-ABI translation unit
-// sets it once from hipDeviceGetAttribute, the emulator keeps the default.
-inline int& num_cus() { static int n = 256; return n; }
+// Compute units of the device the CURRENT CALL runs on (256 on an unpartitioned MI355X: 8 XCDs x 32 CUs).  Per thread: the
+// C-ABI translation unit sets it at the top of every entry point from the stream's device (hipDeviceGetAttribute, cached per
+// device); the emulator keeps the default.
+inline int& num_cus() { static thread_local int n = 256; return n; }
 
 // Library default when the caller passes cfg = -1 (overridden per layer by the tuned table on the Python side, which
 // holds the measured winners for batch 10).  For every other batch size the choice follows the launch-tail model that
@@ -141,12 +144,16 @@ int conv3x3_forward_impl(Launcher& L, const float* src0, const float* src1, cons
   const float* zeros = wpack + (size_t)round_up(c0 + c1, 32) * 9 * cout;       // the packed filter's zero tail
   Conv3x3Args a{src0, src1, wpack, zeros, mean, scale, shift, dst, dst1, csplit, n, c0, c1, cout, h, w, up0 ? 1 : 0, relu ? 1 : 0, addend, diag};
   if (diag) {
+#ifdef TNV3_DIAG
     switch (cfg) {
       case 10: return launch_conv_cfg<ConvD10>(L, a);
       case 11: return launch_conv_cfg<ConvD11>(L, a);
       case 12: return launch_conv_cfg<ConvD12>(L, a);
       default: TNV3_FAIL(-1, "conv3x3 diagnostics exist for configs 10, 11, 12 only (got %d)", cfg);
     }
+#else
+    TNV3_FAIL(-1, "conv3x3: the diagnostic twins live in libtnv3_diag.so");
+#endif
   }
   switch (cfg) {
     case 0: return launch_conv_cfg<ConvC0>(L, a);
@@ -356,7 +363,7 @@ using WinoA = WinoCfg<2, 2, 8>;              // 64 channels x 64 tiles (4 x 64 p
 using WinoSplit = WinoSplitCfg<8>;          // same tile, 512 threads: two wave groups split the 16 transform rows (2 waves / SIMD)
 using WinoIl = WinoIlCfg<2, 2, 6>;           // same tile, 6-channel chunks, patch transform interleaved with the MFMAs
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
-inline int& wino_variant() { static int v = 2; return v; }   // 2: WinoSplit (default, fastest), 0: WinoA (one wave / SIMD), 1: WinoIl; 11.., 21..: timing twins
+constexpr int kWinoDefaultVariant = 2;       // per-call `variant`: 2 WinoSplit (default, fastest), 0 WinoA (one wave / SIMD), 1 WinoIl; -1 = default
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
   return (size_t)round_up(cin, kWinoCinPad) * 16 * cout + kPackZeroTail;
@@ -385,8 +392,9 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
 
 template <class Launcher>
 int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, const float* addend, const float* mean, const float* scale,
-                              const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu) {
+                              const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant = -1) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino: bad argument");
+  if (variant < 0) variant = kWinoDefaultVariant;
   if (!conv3x3_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino: inconsistent affine arguments");
@@ -394,7 +402,8 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
   WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0};
   const long npt = (long)n * (h / 4) * (w / WinoA::PW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino: too many pixel tiles");
-  switch (wino_variant()) {          // 11..13 / 21..26: timing twins of WinoA / WinoSplit (wrong results by design, scripts/wino_diag.py)
+#ifdef TNV3_DIAG
+  switch (variant) {                 // 11..13 / 21..26: timing twins of WinoA / WinoSplit (wrong results by design; libtnv3_diag.so only)
     case 11: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 1>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
     case 12: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 2>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
     case 13: return L.launch(conv3x3_wino_mfma_kernel<WinoCfg<2, 2, 8, 3>>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
@@ -406,11 +415,13 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     case 26: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 6>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
     default: break;
   }
-  if (wino_variant() == 2)
-    return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplit>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
-  if (wino_variant() == 1)
-    return L.launch(conv3x3_wino_il_mfma_kernel<WinoIl>, conv_grid_blocks(cout / WinoIl::MB, (int)npt), WinoIl::NT, a);
-  return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
+#endif
+  switch (variant) {
+    case 2: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplit>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
+    case 1: return L.launch(conv3x3_wino_il_mfma_kernel<WinoIl>, conv_grid_blocks(cout / WinoIl::MB, (int)npt), WinoIl::NT, a);
+    case 0: return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
+    default: TNV3_FAIL(-1, "conv3x3_wino: unknown kernel variant %d", variant);
+  }
 }
 
 // ---- the upsampled half of a decoder-entry layer at the low resolution (kernels/conv_up2x_mfma.h)
@@ -496,20 +507,18 @@ using WgradDmaB = WgradDmaCfg<2, 2>;
 static_assert(WgradDmaA::MB == WgradA::MB && WgradDmaA::CB == WgradA::CB && WgradDmaB::MB == WgradB::MB && WgradDmaB::CB == WgradB::CB,
               "both kernel families share the (co, ci) blocking");
 
-// 0: register-staged kernels (WgradA/B, default: measured 8 % faster), 1: LDS-DMA kernels (WgradDmaA/B).
-// A tuning / diagnostic knob, process-wide.
-inline int& wgrad_variant() { static int v = 0; return v; }
+// Per-call `variant`: 0 register-staged kernels (WgradA/B, default: measured 8 % faster), 1 LDS-DMA kernels (WgradDmaA/B).
 constexpr size_t kWgradZeroBytes = 1024;     // zero prefix of the workspace: padding source of the LDS-DMA kernels
 
 struct WgradPlan { int use_b, nMB, nCB, splitK, nTiles; };
 // cb_a: ci per workgroup of the 128-channel configuration in use (WgradA: 32; the 2x2-window WgradA4: 64)
-inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w, int cb_a = 32) {
+inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w, int cb_a = 32, int variant = 0) {
   WgradPlan p;
   p.use_b = (cout % 128) != 0;
   const int MB = p.use_b ? WgradB::MB : WgradA::MB, CB = p.use_b ? WgradB::CB : cb_a;
   p.nMB = (cout + MB - 1) / MB;
   p.nCB = (cin + CB - 1) / CB;
-  const int TR = wgrad_variant() == 1 ? WgradDmaA::TR : (p.use_b ? WgradB::TR : WgradA::TR);
+  const int TR = variant == 1 ? WgradDmaA::TR : (p.use_b ? WgradB::TR : WgradA::TR);
   p.nTiles = n * ((h + TR - 1) / TR) * ((w + 31) / 32);
   // One workgroup is resident per CU (LDS), all workgroups of a launch do the same work, so the launch runs in
   // ceil(workgroups / CUs) rounds of ceil(nTiles / splitK) tiles (+ ~0.6 tile of prologue / slab write each).
@@ -530,16 +539,18 @@ inline WgradPlan wgrad_plan(int n, int cin, int cout, int h, int w, int cb_a = 3
   p.splitK = best_sk;
   return p;
 }
-inline size_t wgrad_workspace_bytes(int n, int c0, int c1, int cout, int h, int w) {
-  if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
-  const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
+inline size_t wgrad_workspace_bytes(int n, int c0, int c1, int cout, int h, int w, int variant = 0) {
+  if (n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0 || variant < 0 || variant > 1) return 0;
+  const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w, 32, variant);
   return kWgradZeroBytes + (size_t)p.splitK * cout * (c0 + c1) * 9 * sizeof(float);
 }
 
 template <class Launcher>
 int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const float* dz, float* dw, void* ws, size_t ws_bytes,
-                       int n, int c0, int c1, int cout, int h, int w, int up0) {
+                       int n, int c0, int c1, int cout, int h, int w, int up0, int variant = 0) {
   if (!src0 || !dz || !dw || !ws || n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "conv3x3_wgrad: bad argument");
+  if (variant < 0) variant = 0;
+  if (variant > 1) TNV3_FAIL(-1, "conv3x3_wgrad: unknown kernel variant %d", variant);
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3_wgrad: src1 / c1 mismatch");
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3_wgrad: upsampled source needs even H,W");
   if (w % 4) TNV3_FAIL(-1, "conv3x3_wgrad: W must be a multiple of 4 (16-byte dZ loads)");
@@ -549,14 +560,14 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   }
   if ((long)cout * h * w >= (1l << 31) || (long)(c0 > c1 ? c0 : c1) * h * w >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad: sample too large");
   if (h > 250 * 2 * 1024 || c0 + c1 > 32767) TNV3_FAIL(-1, "conv3x3_wgrad: dimension too large");
-  if (ws_bytes < wgrad_workspace_bytes(n, c0, c1, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad: workspace too small");
-  const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w);
+  if (ws_bytes < wgrad_workspace_bytes(n, c0, c1, cout, h, w, variant)) TNV3_FAIL(-1, "conv3x3_wgrad: workspace too small");
+  const WgradPlan p = wgrad_plan(n, c0 + c1, cout, h, w, 32, variant);
   if (((uintptr_t)ws) & 15) TNV3_FAIL(-1, "conv3x3_wgrad: workspace must be 16-byte aligned");
   float* slabs = (float*)((char*)ws + kWgradZeroBytes);
   WgradArgs a{src0, src1, dz, slabs, n, c0, c1, cout, h, w, up0 ? 1 : 0, p.splitK, (const float*)ws, 0, 0};
   const int grid = p.nMB * p.nCB * p.splitK;
   int rc;
-  if (wgrad_variant() == 1) {
+  if (variant == 1) {
     if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
     rc = p.use_b ? L.launch(wgrad3x3_dma_kernel<WgradDmaB>, grid, WgradDmaB::NT, a) : L.launch(wgrad3x3_dma_kernel<WgradDmaA>, grid, WgradDmaA::NT, a);
   } else {
@@ -623,11 +634,8 @@ inline bool wgrad_up2x_skip_wino(int c1, int cout, int h, int w) { return wgrad_
 inline size_t align16f(size_t floats) { return (floats + 3) / 4 * 4; }
 inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, int wl) {
   WgradUpLayout l;
-  const int saved = wgrad_variant();
-  wgrad_variant() = 0;                                   // both halves use the register-staged family (4-row tiles)
-  l.up = wgrad_plan(n, c0, cout, hl, wl, WgradA4::CB);
-  l.skip = wgrad_plan(n, c1, cout, 2 * hl, 2 * wl);
-  wgrad_variant() = saved;
+  l.up = wgrad_plan(n, c0, cout, hl, wl, WgradA4::CB, 0);   // both halves use the register-staged family (4-row tiles)
+  l.skip = wgrad_plan(n, c1, cout, 2 * hl, 2 * wl, 32, 0);
   size_t off = kWgradZeroBytes / 4;
   l.zp = off;      off += align16f((size_t)4 * n * cout * hl * wl);
   l.d4 = off;      off += align16f((size_t)4 * cout * c0 * 4);

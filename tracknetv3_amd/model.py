@@ -131,9 +131,17 @@ class Conv2DBlock(nn.Module):
             return ops.conv3x3_wino(skip, self.packed_wino(c0), self.conv.out_dim, addend=part, relu=relu)
         return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, relu=relu, cfg=cfg)
 
+    def invalidate_caches(self):
+        """Drop every cached operand (packed / Winograd-domain filters, folded BN scale).  The caches are keyed on the tensors'
+        version counters, which ordinary in-place ops (optimiser steps, load_state_dict, copy_ / mul_ on the tensor or on
+        tensor.detach()) bump -- writes through `.data` or through raw pointers do NOT, and need this call."""
+        self._cache.clear()
+
     def eval_scale(self):
-        """gamma / sqrt(running_var + eps), recomputed when gamma or running_var change."""
-        ver = self._versions(["weight", "running_var"])
+        """gamma / sqrt(running_var + eps), recomputed when gamma or running_var change (running_var is also written by the
+        training-mode BN kernel through a raw pointer, which no version counter sees: num_batches_tracked, bumped with
+        every training forward, is part of the key, and the training forward drops the entry as well)."""
+        ver = self._versions(["weight", "running_var", "num_batches_tracked"])
         hit = self._cache.get("aff")
         if hit is None or hit[0] != ver:
             bn = self.bn
@@ -232,6 +240,13 @@ class TrackNet(nn.Module):
         x = self._chain_eval(self.up_block_2.blocks(), x, skip=x2, up=True)
         x = self._chain_eval(self.up_block_3.blocks(), x, skip=x1, up=True)
         return ops.head1x1_sigmoid(x, self.predictor.weight.detach(), self.predictor.bias.detach())
+
+    def invalidate_caches(self):
+        """Drop the cached packed operands of every block (needed after writes through `.data` / raw pointers, which bump no
+        version counter; ordinary in-place updates are tracked automatically)."""
+        for m in self.modules():
+            if isinstance(m, Conv2DBlock):
+                m.invalidate_caches()
 
     def prepare_eval(self):
         """Build (on the current stream) every cached eval-mode operand -- packed filters, folded BN scales -- so that

@@ -53,13 +53,6 @@ def bn_eval_scale(gamma, running_var, eps=BN_EPS):
     return scale
 
 
-def wino_variant(variant=-1):
-    """Select or query (-1) the Winograd forward kernel; returns the old value.  2: xi-split, two waves per SIMD (default);
-    0: one wave per SIMD, separate transform phase; 1: transform interleaved with the MFMAs; 11-13 / 21-26: timing twins
-    with wrong results (scripts/wino_diag.py)."""
-    return int(_lib.load().tnv3_conv3x3_wino_variant(int(variant)))
-
-
 def wino_supported(cin, cout, h, w):
     return bool(_lib.load().tnv3_conv3x3_wino_supported(int(cin), int(cout), int(h), int(w)))
 
@@ -81,8 +74,9 @@ def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False):
     return u
 
 
-def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None):
-    """The plain eval-mode layer in Winograd F(2x2, 3x3) form (tnv3_conv3x3_wino_forward)."""
+def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None, variant=None):
+    """The plain eval-mode layer in Winograd F(2x2, 3x3) form (tnv3_conv3x3_wino_forward).  variant: kernel family for THIS
+    call (None: tuning.WINO_VARIANT, -1 = the library's default; 2 xi-split, 0 one wave per SIMD, 1 interleaved transform)."""
     lib = _lib.load()
     _f32(src, u, mean, scale, shift, addend)
     _lib.dev_check(src, u, mean, scale, shift, addend)
@@ -93,9 +87,12 @@ def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, ad
     if addend is not None and tuple(addend.shape) != tuple(out.shape):
         raise _lib.Tnv3Error("conv3x3_wino: addend must have the output's shape")
     if n:
+        if variant is None:
+            from . import tuning
+            variant = tuning.WINO_VARIANT
         _lib.check(lib.tnv3_conv3x3_wino_forward(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(mean), _lib.ptr(scale),
                                                  _lib.ptr(shift), _lib.ptr(out), n, cin, int(cout), h, w, int(bool(relu)),
-                                                 _lib.stream_ptr(src)))
+                                                 int(variant), _lib.stream_ptr(src)))
     return out
 
 
@@ -277,11 +274,6 @@ def heatmap_peakfind(heat, threshold=0.5, tie_last_wins=True):
     return out
 
 
-def wgrad_variant(variant=-1):
-    """Select (0: register-staged, 1: LDS-DMA staged) or query (-1) the weight-gradient kernel family; returns the old one."""
-    return int(_lib.load().tnv3_conv3x3_wgrad_variant(int(variant)))
-
-
 def heatmap_box_max(heat, boxes=None):
     """(frames, H, W) fp32 maps [+ (frames, 4) int32 boxes (x, y, w, h)] -> (frames,) maxima (0 for an empty box)."""
     lib = _lib.load()
@@ -354,8 +346,9 @@ def conv3x3_dgrad(dz, wpack_t, c0, c1=0, cfg=-1):
     return dx0, dx1
 
 
-def conv3x3_wgrad(src0, dz, src1=None, up0=False):
-    """dW[Cout][C0+C1][3][3] for X = cat([up2x?(src0), src1], 1)."""
+def conv3x3_wgrad(src0, dz, src1=None, up0=False, variant=None):
+    """dW[Cout][C0+C1][3][3] for X = cat([up2x?(src0), src1], 1).  variant: kernel family for THIS call (None:
+    tuning.WGRAD_VARIANT; 0 register-staged, 1 LDS-DMA staged)."""
     lib = _lib.load()
     _f32(src0, src1, dz)
     _lib.dev_check(src0, src1, dz)
@@ -363,9 +356,13 @@ def conv3x3_wgrad(src0, dz, src1=None, up0=False):
     c0 = int(src0.shape[1])
     c1 = int(src1.shape[1]) if src1 is not None else 0
     dw = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dz.device)
-    ws = _workspace(lib.tnv3_conv3x3_wgrad_workspace_bytes(n, c0, c1, cout, h, w), dz.device)
+    if variant is None:
+        from . import tuning
+        variant = tuning.WGRAD_VARIANT
+    variant = max(0, int(variant))
+    ws = _workspace(lib.tnv3_conv3x3_wgrad_workspace_bytes(n, c0, c1, cout, h, w, variant), dz.device)
     _lib.check(lib.tnv3_conv3x3_wgrad(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8,
-                                      n, c0, c1, cout, h, w, int(bool(up0)), _lib.stream_ptr(dz)))
+                                      n, c0, c1, cout, h, w, int(bool(up0)), variant, _lib.stream_ptr(dz)))
     return dw
 
 
@@ -530,3 +527,17 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
     _lib.check(lib.tnv3_conv1d_k3_wgrad(_lib.ptr(src0), _lib.ptr(src1), _lib.ptr(dpre), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
                                         ws.numel() * 8, n, c0, c1, cout, l, int(bool(src_nlc)), _lib.stream_ptr(dpre)))
     return dw, db
+
+
+# ------------------------------------------------------------------------------------------------- device guard
+# The C ABI runs a call on its stream's device, but a tensor's *default* stream is the NULL stream (= "the calling thread's
+# current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
+# device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
+_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "pack_up2x_weights", "conv_up2x",
+               "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "ensemble_frames",
+               "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
+               "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward",
+               "maxpool2x2_backward_add", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad"]
+for _name in _TENSOR_OPS:
+    globals()[_name] = _lib.on_tensor_device(globals()[_name])
+del _name

@@ -92,13 +92,26 @@ class GradAllReducer:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
         self.arrived = [0] * len(self.buckets)
 
+    def reset(self):
+        """Forget a partially reduced step (backward raised): wait for what was launched, clear the arrival counters."""
+        for w in self.pending:
+            try:
+                w.wait()
+            except Exception:  # noqa: BLE001
+                pass
+        self.pending = []
+        self.arrived = [0] * len(self.buckets)
+
 
 def broadcast_module(net, src=0, group=None):
     """Make every replica start from rank `src`'s parameters and buffers."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for t in list(net.parameters()) + list(net.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():
+        for t in list(net.parameters()) + list(net.buffers()):
+            dist.broadcast(t.detach(), src=src, group=group)     # detach() shares the version counter: the in-place receive bumps it
+    if hasattr(net, "invalidate_caches"):
+        net.invalidate_caches()          # belt and braces: operands packed from the pre-broadcast weights must not survive
 
 
 def shard_range(global_batch, rank, world):
@@ -144,6 +157,10 @@ class TrackNetTrainer:
             self.net.train()
             loss = self.loss_fn(self.net(x), y)
             loss.backward()
+        except BaseException:
+            if self.reducer is not None:
+                self.reducer.reset()      # a bucket half-filled by a failed backward must not trigger early next step
+            raise
         finally:
             autograd_ops.set_grad_ready_hook(None, None)
         self.opt.step()

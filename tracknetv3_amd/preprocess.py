@@ -64,6 +64,7 @@ def _device_tables(h, w, oh, ow, device):
     return _tables[key]
 
 
+@_lib.on_tensor_device
 def resize_frames(frames_u8, out_h=HEIGHT, out_w=WIDTH, want_f32=True, want_u8=False):
     """(F, H, W, C) uint8 -> fp32 (F, C, out_h, out_w) in [0, 1] (and/or uint8 (F, out_h, out_w, C)); bit-exact with
     `np.moveaxis(np.array(Image.fromarray(img).resize((out_w, out_h))), -1, 0) / 255.`"""
@@ -86,6 +87,7 @@ def resize_frames(frames_u8, out_h=HEIGHT, out_w=WIDTH, want_f32=True, want_u8=F
     return (out_f, out_u) if (want_f32 and want_u8) else (out_f if want_f32 else out_u)
 
 
+@_lib.on_tensor_device
 def median_background(frames_u8, doubled=False):
     """np.median(frame_arr, 0) of a (T, H, W, C) uint8 stack.  Default: `.astype('uint8')` -> (H, W, C) uint8 (bg_mode
     'concat').  doubled=True: twice the float median as int16-range uint16 (exact, halves included) for the
@@ -102,6 +104,7 @@ def median_background(frames_u8, doubled=False):
     return med
 
 
+@_lib.on_tensor_device
 def difference_frames(frames_u8, median_x2):
     """(F, H, W, 3) uint8 and the doubled median (H, W, 3) -> (F, H, W, 1) uint8 = uint8(sum_c |frame - median|)."""
     lib = _lib.load()

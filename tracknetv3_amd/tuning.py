@@ -60,3 +60,9 @@ def use_winograd_wgrad(cin, cout, h, w):
         return False
     from . import ops
     return ops.wgrad_wino_supported(cin, cout, h, w)
+
+
+# Kernel-family choices are per-call arguments of the C ABI (no process-wide state inside the library); these are the
+# defaults the Python layer passes.  -1 = the library's default (xi-split Winograd kernel; register-staged weight gradient).
+WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 0: one wave per SIMD, 1: interleaved transform, 2: xi-split
+WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA staged kernels (parity-green, 8 % slower)

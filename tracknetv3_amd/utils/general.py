@@ -45,3 +45,32 @@ def get_model(model_name, seq_len=None, bg_mode=None):
     else:
         raise ValueError('Invalid model name.')
     return model
+
+
+_CSV_COLUMNS = ('Frame', 'Visibility', 'X', 'Y')
+_CSV_COLUMNS_INPAINT = ('Frame', 'Visibility_GT', 'X_GT', 'Y_GT', 'Visibility', 'X', 'Y', 'Inpaint_Mask')
+
+
+def write_pred_csv(pred_dict, save_file, save_inpaint_mask=False):
+    """Write a prediction dict as the reference's csv wire format (utils/general.py:319-354): columns
+    ``Frame,Visibility,X,Y`` -- or, with ``save_inpaint_mask``, the InpaintNet-training layout
+    ``Frame,Visibility_GT,X_GT,Y_GT,Visibility,X,Y,Inpaint_Mask`` -- one row per frame, no index column.  The reference
+    goes through ``pandas.DataFrame.to_csv(index=False)``; this writes the same bytes for the integer lists the
+    post-process produces (tests compare with pandas) without needing pandas on the box."""
+    cols = _CSV_COLUMNS_INPAINT if save_inpaint_mask else _CSV_COLUMNS
+    series = [list(pred_dict[c]) for c in cols]
+    n = len(series[0])
+    if any(len(s) != n for s in series):
+        raise ValueError('All arrays must be of the same length')         # pandas' message for ragged columns
+
+    def fmt(v):
+        if hasattr(v, 'item'):
+            v = v.item()
+        if isinstance(v, bool):
+            return 'True' if v else 'False'
+        return repr(v) if isinstance(v, float) else str(v)
+
+    with open(save_file, 'w', newline='') as f:
+        f.write(','.join(cols) + '\n')
+        for row in zip(*series):
+            f.write(','.join(fmt(v) for v in row) + '\n')
