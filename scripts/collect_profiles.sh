@@ -2,7 +2,7 @@
 # Copies the summaries of the last scripts/gpu_session.sh run from gpurun_out/ (scratch) into profiles/ (tracked).
 set -eu
 cd "$(dirname "$0")/.."
-R=${ROUND:-r01}
+R=${ROUND:-r02}
 O=gpurun_out
 P=profiles
 cp $O/bench.json $P/${R}_bench_n1.json
@@ -14,6 +14,6 @@ cp $O/prof_infer_kernel_stats.csv $P/${R}_infer_kernel_stats.csv
 cp $O/prof_train_kernel_stats.csv $P/${R}_train_kernel_stats.csv
 cp $O/pmc_fetch_pmc.csv $P/${R}_infer_pmc_fetch_size.csv
 cp $O/pmc_write_pmc.csv $P/${R}_infer_pmc_write_size.csv
-python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json
+python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json ${COMMIT:-$(git rev-parse --short HEAD)}
 cp $O/session.log $P/${R}_session_final.log
 echo "profiles/ refreshed from $O"

@@ -24,40 +24,53 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)      # RCCL: one GPU per rank; gloo: both ranks share cuda:0
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tracknetv3_amd.parallel import TrackNetTrainer, shard_range
         from tracknetv3_amd.utils.general import get_model
-        dev = torch.device("cuda:0")
         sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 13, calibrated=True)
         net = get_model("TrackNet", 3, "")
         if rank == 0:
             net.load_state_dict(sd, strict=True)           # rank 1 starts from random init: broadcast must fix it
         net = net.to(dev)
         opt = torch.optim.SGD(net.parameters(), lr=1.0)    # lr 1, no momentum: parameter delta == -averaged gradient
-        tr = TrackNetTrainer(net, opt, alpha=0.0, bucket_bytes=4 << 20)
+        tr = TrackNetTrainer(net, opt, alpha=0.0, bucket_bytes=4 << 20, record_timing=(backend == "nccl"))
         assert tr.reducer is not None and tr.reducer.num_buckets() >= 8
         x = nets.synth_input((4, 9, 64, 128), 1013)
         y = nets.disc_heatmaps(4, 3, 64, 128, 2013)
         lo, hi = shard_range(4, rank, world)
         loss = tr.step(x[lo:hi].to(dev), y[lo:hi].to(dev))
         torch.cuda.synchronize()
-        out[rank] = dict(loss=float(loss), params={k: v.detach().cpu() for k, v in net.named_parameters()},
+        out[rank] = dict(loss=float(loss), overlap=tr.overlap_report(), params={k: v.detach().cpu() for k, v in net.named_parameters()},
                          grads={k: v.grad.detach().cpu() for k, v in net.named_parameters()},
                          bn={k: v.detach().cpu() for k, v in net.state_dict().items() if "running_" in k})
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_train_step_equals_sequential_shard_oracle(gpu_device):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_train_step_equals_sequential_shard_oracle(gpu_device, backend):
+    """gloo: both ranks on cuda:0 (runs on the 1-GPU test box).  nccl: the RCCL path itself -- one GPU per rank, bucketed
+    all-reduce on the side stream, per-bucket timing -- needs two visible GPUs and is skipped otherwise."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL leg needs two GPUs")
     world, port = 2, _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, out, backend), nprocs=world, join=True)
         r0, r1 = out[0], out[1]
+    if backend == "nccl":
+        rep = r0["overlap"]
+        assert rep and len(rep["buckets"]) >= 8 and all(b["finish_ms"] >= b["launch_ms"] for b in rep["buckets"]), rep
     sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 13, calibrated=True)
     x = nets.synth_input((4, 9, 64, 128), 1013)
     y = nets.disc_heatmaps(4, 3, 64, 128, 2013)
@@ -86,3 +99,23 @@ def test_two_rank_train_step_equals_sequential_shard_oracle(gpu_device):
     for r, got in ((0, r0["bn"]), (1, r1["bn"])):
         for k, v in got.items():
             assert torch.allclose(v.double(), stats[r][k], rtol=2e-4, atol=2e-6), (r, k)
+
+
+def test_ops_follow_the_tensor_device_not_the_current_device(gpu_device):
+    """a tensor on cuda:1 while cuda:0 is current must run on cuda:1 (its NULL stream means 'the current device').
+    Needs two GPUs; the single-GPU box skips it (the C side additionally switches to the stream's device)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from tracknetv3_amd import ops
+    torch.cuda.set_device(0)
+    x = nets.synth_input((1, 16, 8, 64), 3)
+    w = nets.synth_input((64, 16, 3, 3), 4) - 0.5
+    outs = []
+    for d in ("cuda:0", "cuda:1"):
+        xd, wd = x.to(d), w.to(d)
+        assert torch.cuda.current_device() == 0
+        y = ops.conv3x3(xd, ops.pack_conv3x3_weights(wd), 64)
+        assert y.device == xd.device
+        outs.append(y.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert torch.cuda.current_device() == 0

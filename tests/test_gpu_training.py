@@ -336,3 +336,42 @@ def test_training_steps_do_not_retain_memory(gpu_device):
         assert max(marks[2:]) - min(marks[2:]) < (8 << 20), marks        # small allocator jitter, no per-step growth
     finally:
         gc.enable()
+
+
+def test_eval_after_no_grad_train_forward_uses_fresh_bn_scale(gpu_device):
+    """eval -> train-mode forward under no_grad (BN recalibration: running stats rewritten through raw pointers) ->
+    eval must equal a fresh module loaded with the same state_dict (the folded gamma / sqrt(var + eps) used to go stale)."""
+    from tracknetv3_amd.utils.general import get_model
+    sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 21, calibrated=True)
+    m = get_model("TrackNet", 3, "")
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu_device).eval()
+    x = nets.synth_input((2, 9, 32, 64), 5).to(gpu_device)
+    e0 = m(x).clone()
+    m.train()
+    with torch.no_grad():
+        m(x)
+    m.eval()
+    e1 = m(x)
+    fresh = get_model("TrackNet", 3, "")
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()}, strict=True)
+    e2 = fresh.to(gpu_device).eval()(x)
+    assert (e1 - e0).abs().max().item() > 1e-5
+    assert torch.equal(e1, e2)
+
+
+def test_second_backward_raises_a_clear_error_and_input_gradient_flows_with_frozen_params(gpu_device):
+    from tracknetv3_amd.utils.general import get_model
+    from tracknetv3_amd.utils.metric import WBCELoss
+    m = get_model("TrackNet", 3, "").to(gpu_device).train()
+    x = nets.synth_input((2, 9, 32, 64), 5).to(gpu_device)
+    y = nets.disc_heatmaps(2, 3, 32, 64, 6).to(gpu_device)
+    loss = WBCELoss(m(x), y)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="backward ran twice"):
+        loss.backward()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    xg = x.clone().requires_grad_(True)
+    WBCELoss(m(xg), y).backward()                 # frozen parameters, train mode: dL/dx must not be dropped silently
+    assert xg.grad is not None and float(xg.grad.abs().sum()) > 0

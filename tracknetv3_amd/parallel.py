@@ -22,8 +22,10 @@ from . import autograd_ops, ops
 class GradAllReducer:
     """Packs gradients into flat buckets as they become final and all-reduces each full bucket asynchronously."""
 
-    def __init__(self, params_in_ready_order, group=None, bucket_bytes=12 << 20):
+    def __init__(self, params_in_ready_order, group=None, bucket_bytes=12 << 20, record_timing=False):
         self.group = group
+        self.record_timing = bool(record_timing)      # per-bucket launch / finish events on the side stream (bench.py: overlap evidence)
+        self.timeline = []                            # [(bucket, bytes, start_event, end_event)] of the last step
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = list(params_in_ready_order)
         dev = self.params[0].device
@@ -79,10 +81,24 @@ class GradAllReducer:
                 self.side.wait_stream(s)                             # weight-gradient stream: wait for both
             with torch.cuda.stream(self.side):
                 flat.div_(self.world)
-                self.pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.record_timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.side)
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.record_timing:
+                    # Work.wait() on a GPU collective only makes the CURRENT stream (the side stream) wait for the
+                    # communicator's stream -- no host block -- so the event after it marks the collective's end
+                    work.wait()
+                    e1.record(self.side)
+                    self.timeline.append((b, flat.numel() * 4, e0, e1))
+                else:
+                    self.pending.append(work)
         else:
             flat.div_(self.world)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def begin_step(self):
+        self.timeline = []
 
     def on_backward_end(self):
         for w in self.pending:
@@ -136,14 +152,17 @@ class TrackNetTrainer:
     optimizer.step().  Returns the loss as a DEVICE scalar: no per-step host sync (the reference's `.item()` at
     train.py:94 is what would serialise 8 GPUs)."""
 
-    def __init__(self, net, optimizer, alpha=0.0, seed=13, group=None, bucket_bytes=12 << 20):
+    def __init__(self, net, optimizer, alpha=0.0, seed=13, group=None, bucket_bytes=12 << 20, record_timing=False):
         from .utils.metric import WBCELoss
+        self.record_timing = bool(record_timing)
+        self.last_timing = None
         self.net, self.opt, self.alpha, self.loss_fn = net, optimizer, alpha, WBCELoss
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rng = np.random.RandomState(seed + 1000 * self.rank)
         broadcast_module(net, 0, group)
-        self.reducer = GradAllReducer(autograd_ops.grad_ready_order(net), group, bucket_bytes) if self.world > 1 else None
+        self.reducer = GradAllReducer(autograd_ops.grad_ready_order(net), group, bucket_bytes,
+                                      record_timing=record_timing) if self.world > 1 else None
 
     def step(self, x, y):
         self.opt.zero_grad(set_to_none=True)
@@ -151,12 +170,20 @@ class TrackNetTrainer:
             lamb, perm = draw_mixup(x.shape[0], self.alpha, self.rng)
             lam_d, perm_d = torch.from_numpy(lamb).to(x.device), torch.from_numpy(perm).to(x.device)
             x, y = ops.mixup(x, lam_d, perm_d), ops.mixup(y, lam_d, perm_d)
+        timing = self.record_timing and x.is_cuda
         if self.reducer is not None:
+            self.reducer.begin_step()
             autograd_ops.set_grad_ready_hook(self.reducer.on_grad, self.reducer.on_backward_end)
         try:
             self.net.train()
             loss = self.loss_fn(self.net(x), y)
+            if timing:
+                b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                b0.record()
             loss.backward()
+            if timing:
+                b1.record()          # after backward's own join of the weight-gradient stream, before the optimiser
+                self.last_timing = (b0, b1, list(self.reducer.timeline) if self.reducer is not None else [])
         except BaseException:
             if self.reducer is not None:
                 self.reducer.reset()      # a bucket half-filled by a failed backward must not trigger early next step
@@ -165,3 +192,19 @@ class TrackNetTrainer:
             autograd_ops.set_grad_ready_hook(None, None)
         self.opt.step()
         return loss.detach()
+
+    def overlap_report(self):
+        """After a synchronised step with record_timing: when each gradient bucket's all-reduce started / ended relative to
+        the start of backward, and how much of the collective time ran before backward's compute had finished.  NOTE: the
+        `backward_end` mark is recorded AFTER the main stream has joined the reducer's side stream (on_backward_end), so it
+        is `max(compute end, last all-reduce end)`; the compute end is estimated by the last bucket's launch time."""
+        if not self.last_timing:
+            return None
+        b0, b1, tl = self.last_timing
+        rows = [{"bucket": b, "bytes": nbytes, "launch_ms": round(b0.elapsed_time(e0), 3), "finish_ms": round(b0.elapsed_time(e1), 3)}
+                for b, nbytes, e0, e1 in tl]
+        total = sum(r["finish_ms"] - r["launch_ms"] for r in rows)
+        compute_end = max((r["launch_ms"] for r in rows), default=0.0)      # the last bucket is launched when the last gradient is final
+        hidden = sum(max(0.0, min(r["finish_ms"], compute_end) - r["launch_ms"]) for r in rows)
+        return {"backward_ms": round(b0.elapsed_time(b1), 3), "last_gradient_ready_ms": round(compute_end, 3), "buckets": rows,
+                "allreduce_ms_total": round(total, 3), "overlap_fraction": round(hidden / total, 4) if total > 0 else None}
