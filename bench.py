@@ -132,7 +132,7 @@ def cpu_baseline(mode="infer", budget_s=40.0):
     * infer: configs[1] as written -- eval forward, batch 10, 288x512 (80 frames per run).
     * train: configs[2] shard reduced to batch 2 (a bounded sample: a batch-10 CPU step takes ~1 min) -- mixup with injected
       draws, forward in train mode, WBCE, backward (autograd), no optimiser.
-    Threads: a short scan at batch 2 over {8, 16, 32, 64, physical cores} keeps the fastest -- running on every SMT thread of a
+    Threads: a short scan at the measured batch over {16, 32, 64, physical cores} keeps the fastest -- running on every SMT thread of a
     2-socket host is several times SLOWER for these shapes (oneDNN), which would flatter the GPU.  Returns frames/s."""
     from oracle import nets
     in_dim = (SEQ_LEN + 1) * 3
@@ -155,24 +155,20 @@ def cpu_baseline(mode="infer", budget_s=40.0):
         nets.tracknet_train_step_grads(sd, xm, ym, torch.float32)
         return time.time() - t
 
-    x2 = nets.synth_input((2, in_dim, H, W), 4242)
-    y2 = nets.disc_heatmaps(2, SEQ_LEN, H, W, 4243) if mode == "train" else None
-    run2 = (lambda: fwd(x2)) if mode == "infer" else (lambda: train_step(x2, y2))
+    n = 10 if mode == "infer" else 2
+    xn = nets.synth_input((n, in_dim, H, W), 4244)
+    yn = nets.disc_heatmaps(n, SEQ_LEN, H, W, 4243) if mode == "train" else None
+    run = (lambda: fwd(xn)) if mode == "infer" else (lambda: train_step(xn, yn))
     scan = {}
-    for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu), min(phys, ncpu)}):
-        if scan and (time.time() - t_all > budget_s * 0.35 or scan[max(scan)] > 1.6 * min(scan.values())):
+    torch.set_num_threads(min(16, ncpu))
+    run()                                       # warm-up (thread pool, oneDNN primitive cache)
+    for th in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu), min(phys, ncpu)}):      # scan at the MEASURED batch size
+        if scan and (time.time() - t_all > budget_s * 0.5 or scan[max(scan)] > 1.5 * min(scan.values())):
             break                               # out of budget, or clearly past the sweet spot (more threads = slower)
         torch.set_num_threads(th)
-        run2()                                  # warm-up (thread pool, oneDNN primitive cache)
-        scan[th] = run2()
+        scan[th] = run()
     best = min(scan, key=scan.get)
     torch.set_num_threads(best)
-    n = 10 if mode == "infer" else 2
-    if mode == "infer":
-        xn = nets.synth_input((n, in_dim, H, W), 4244)
-        run = lambda: fwd(xn)                   # noqa: E731
-    else:
-        run = run2
     run(); run()                                # 2 warm-up iterations
     times = [run() for _ in range(5)]
     while time.time() - t_all < budget_s and len(times) < 9:
@@ -189,7 +185,7 @@ def cpu_baseline(mode="infer", budget_s=40.0):
     what = "eval forward" if mode == "infer" else "train step (mixup + forward(train) + WBCE + backward, no optimiser)"
     out = {"value": round(n * SEQ_LEN / med, 2), "unit": "frames/s", "cores": best, "kind": "port",
            "sample": f"oracle (torch-CPU fp32 restatement, equal to the imported reference) TrackNet(27,8) {what}, batch {n} x 288x512, "
-                     f"2 warm-ups, median of {len(times)} runs ({med:.2f} s each) on {best} threads; thread scan at batch 2, s/run: "
+                     f"2 warm-ups, median of {len(times)} runs ({med:.2f} s each) on {best} threads; thread scan at that batch, s/run: "
                      f"{{{', '.join(f'{k}: {v:.2f}' for k, v in scan.items())}}}",
            "one_thread": one, "torch": torch.__version__}
     out.update(info)
@@ -215,7 +211,8 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False):
     from tracknetv3_amd.utils.general import get_model
     in_dim = (SEQ_LEN + 1) * 3
     model = synth.init_state_(get_model("TrackNet", SEQ_LEN, BG_MODE), 31, calibrated=False).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    from tracknetv3_amd.optim import FusedAdam
+    opt = FusedAdam(model.parameters(), lr=1e-3)          # torch.optim.Adam's arithmetic and state layout, one launch per step
     trainer = TrackNetTrainer(model, opt, alpha=0.5, seed=13)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.rand((batch, in_dim, H, W), device=dev, generator=gen)
@@ -253,7 +250,8 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False):
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2] shard: TrackNet seq_len=8 bg_mode=concat, batch 10 per GPU, mixup alpha=0.5, "
-                               "WBCE, backward, Adam(lr=1e-3); DP gradient all-reduce over RCCL when n_gpus > 1",
+                               "WBCE, backward, Adam(lr=1e-3) as one fused launch, mixup draws on the device; DP gradient all-reduce over RCCL when "
+                               "n_gpus > 1",
                    "batch_per_gpu": batch, "global_batch": world * batch, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "achieved": round(tf_exec, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tf_exec / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,

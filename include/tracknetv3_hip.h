@@ -246,6 +246,39 @@ int tnv3_upsample2x_backward(const float* d_hi, float* d_lo, long nc, int hl, in
 int tnv3_mixup(const float* x, const float* lam, const int32_t* perm, float* out, int n, long per_sample,
                tnv3_stream_t stream);
 
+/* ---- optimiser step and mixup draws on the device (train.py:33-36, 85, 96, 165, 242-248) ----------
+ * Tensor lists are HOST arrays of DEVICE pointers (+ element counts); they travel in the kernel-argument buffer, so a step
+ * needs no device-side pointer table, no H2D copy and no host sync.  All tensors fp32, contiguous. */
+
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) (train.py:165), device side: out_norm_coef[0] = global L2 norm of all
+ * gradients (fixed-order fp64 reduction: deterministic), out_norm_coef[1] = min(1, max_norm / (norm + 1e-6)).  The scaling
+ * itself is applied by the optimiser kernels below through their `clip_coef` argument (pass out_norm_coef + 1). */
+size_t tnv3_grad_norm_workspace_bytes(int count);
+int tnv3_grad_norm(float* const* grads, const long* numel, int count, float max_norm, float* out_norm_coef, void* workspace,
+                   size_t workspace_bytes, tnv3_stream_t stream);
+
+/* torch.optim.Adam.step() (train.py:96 with the optimiser of train.py:242; amsgrad / maximize off) for `count` tensors in one
+ * launch per 64 tensors, following torch's foreach implementation operation by operation in fp32:
+ *   g *= clip (if clip_coef);  g += weight_decay * p;  m += (1-beta1) * (g - m);  v = v * beta2 + (1-beta2) * g * g;
+ *   p += -(lr / (1 - beta1^step)) * (m / (sqrt(v) / sqrt(1 - beta2^step) + eps))
+ * step: 1-based count of this update (the bias corrections are formed on the host in double, as torch does).
+ * clip_coef: DEVICE pointer to the gradient scale (tnv3_grad_norm's out_norm_coef + 1) or NULL; with it the clipped gradient
+ * is written back to grads (what clip_grad_norm_ leaves behind).  zero_grad != 0: grads are zeroed instead (train.py:85). */
+int tnv3_adam_step(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
+                   int count, double lr, double beta1, double beta2, double eps, double weight_decay, long step, const float* clip_coef,
+                   int zero_grad, tnv3_stream_t stream);
+
+/* torch.optim.SGD.step() (train.py:244: momentum 0.9; dampening 0, no Nesterov): buf = g on the first step, else
+ * momentum * buf + g;  p -= lr * buf.  momentum_buf may be NULL when momentum == 0. */
+int tnv3_sgd_step(float* const* params, float* const* grads, float* const* momentum_buf, const long* numel, int count, double lr,
+                  double momentum, double weight_decay, int first_step, const float* clip_coef, int zero_grad, tnv3_stream_t stream);
+
+/* The random draws of mixup (train.py:33-36) on the device: lam[n] = max(B, 1 - B) with B ~ Beta(alpha, alpha) (two Gamma
+ * variates, Marsaglia-Tsang), perm[n] = a uniform random permutation (Fisher-Yates), from Philox4x32-10 keyed by `seed` with
+ * counter `step` -- deterministic per (seed, step), no host RNG, no H2D copy.  (The reference draws with numpy / torch CPU
+ * generators; the RNG stream is not part of parity -- tnv3_mixup applies whatever draws it is given.)  n <= 65536. */
+int tnv3_mixup_draw(float* lam, int32_t* perm, int n, float alpha, uint64_t seed, uint64_t step, tnv3_stream_t stream);
+
 /* ---- InpaintNet backward (train.py:156-164: autograd through Conv1DBlock / predictor) ------------------------ */
 
 /* dPre[N][C][L] = dOut * act'(out); act as in tnv3_conv1d_k3_forward; nlc != 0: dOut/out are [N][L][C]. */

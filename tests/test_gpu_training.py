@@ -375,3 +375,66 @@ def test_second_backward_raises_a_clear_error_and_input_gradient_flows_with_froz
     xg = x.clone().requires_grad_(True)
     WBCELoss(m(xg), y).backward()                 # frozen parameters, train mode: dL/dx must not be dropped silently
     assert xg.grad is not None and float(xg.grad.abs().sum()) > 0
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    xo = x.cpu().double().requires_grad_(True)
+    sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    nets.wbce_loss(nets.tracknet_forward(sd64, xo, training=True), y.cpu().double()).backward()
+    assert rel_err(xg.grad.cpu(), xo.grad) <= 1e-3, rel_err(xg.grad.cpu(), xo.grad)
+
+
+def test_fused_adam_equals_torch_foreach_adam_on_the_53_tensors(gpu_device):
+    """the one-launch Adam (+ clip_grad_norm_) against torch.optim.Adam (foreach, the GPU default) over 10
+    steps on the 53 parameter tensors of TrackNet(27, 8): parameters within 1 ulp at the scale of the parameter or of one
+    update (lr), the clipped global norm within 1e-6 relative."""
+    from test_emu_optim import _ulps
+    from tracknetv3_amd.optim import FusedAdam
+    from tracknetv3_amd.utils.general import get_model
+    torch.manual_seed(3)
+    net_m = get_model("TrackNet", 8, "concat").to(gpu_device)
+    net_r = get_model("TrackNet", 8, "concat").to(gpu_device)
+    net_r.load_state_dict(net_m.state_dict())
+    pm, pr = list(net_m.parameters()), list(net_r.parameters())
+    assert len(pm) == 53
+    for clip in (None, 1.0):
+        o_m = FusedAdam(pm, lr=1e-3, max_grad_norm=clip)
+        o_r = torch.optim.Adam(pr, lr=1e-3, foreach=True)
+        gen = torch.Generator(device=gpu_device).manual_seed(11)
+        for it in range(10):
+            for a, b in zip(pm, pr):
+                g = torch.randn(a.shape, device=gpu_device, generator=gen) * (10.0 ** ((it % 3) - 2))
+                a.grad, b.grad = g.clone(), g.clone()
+            if clip is not None:
+                total = torch.nn.utils.clip_grad_norm_(pr, clip)
+            o_r.step()
+            o_m.step()
+            if clip is not None:
+                assert abs(o_m.last_grad_norm[0].item() - total.item()) <= 1e-6 * total.item()
+        worst = max(_ulps(a.cpu(), b.cpu(), floor=1e-3) for a, b in zip(pm, pr))
+        assert worst <= (1.0 if clip is None else 4.0), (clip, worst)      # with clipping the coefficient itself differs in the last bits
+        for a, b in zip(pm, pr):
+            assert torch.allclose(o_m.state[a]["exp_avg_sq"], o_r.state[b]["exp_avg_sq"], rtol=(0 if clip is None else 1e-5), atol=0)
+
+
+def test_trainer_with_fused_adam_and_device_mixup_draws(gpu_device):
+    """TrackNetTrainer with FusedAdam + device-side mixup draws trains (loss falls), is deterministic per seed, and the
+    packed-filter caches follow the raw-pointer parameter updates (eval after training == fresh module)."""
+    from tracknetv3_amd.optim import FusedAdam
+    from tracknetv3_amd.parallel import TrackNetTrainer
+    from tracknetv3_amd.utils.general import get_model
+    x = nets.synth_input((4, 12, 32, 64), 5).to(gpu_device)
+    y = nets.disc_heatmaps(4, 3, 32, 64, 6).to(gpu_device)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(1)
+        net = get_model("TrackNet", 3, "concat").to(gpu_device)
+        tr = TrackNetTrainer(net, FusedAdam(net.parameters(), lr=1e-3), alpha=0.5, seed=13)
+        runs.append([tr.step(x, y).item() for _ in range(5)])
+    assert runs[0] == runs[1]
+    assert min(runs[0][1:]) < runs[0][0]
+    net.eval()
+    e1 = net(x)
+    fresh = get_model("TrackNet", 3, "concat")
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    assert torch.equal(e1, fresh.to(gpu_device).eval()(x))
+    lam, perm = __import__("tracknetv3_amd.ops", fromlist=["ops"]).mixup_draw(10, 0.5, 13, 1, gpu_device)
+    assert lam.is_cuda and float(lam.min()) >= 0.5 and sorted(perm.cpu().tolist()) == list(range(10))

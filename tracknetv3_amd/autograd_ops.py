@@ -201,6 +201,15 @@ class _TrackNetTrain(torch.autograd.Function):
             if c1 == 0 and not rec["up"] and tuning.use_winograd(blk.conv.out_dim, c0, int(h), int(w)):
                 # plain layer: dX = conv3x3(dZ, W^T flipped) is itself a plain 3x3 convolution -> the Winograd kernel
                 return ops.conv3x3_wino(dz, blk.packed_wino_t(), c0), None
+            if c1 == 0 and c0 % 64:
+                # gradient w.r.t. the network INPUT (9 / 27 channels; only when the caller asked for it -- train.py never does):
+                # the data-gradient kernels produce channel blocks of 64, so run it on the filter zero-padded to 64 input
+                # channels and keep the first c0 planes
+                cpad = (c0 + 63) // 64 * 64
+                wpad = torch.zeros((blk.conv.out_dim, cpad, 3, 3), dtype=torch.float32, device=dz.device)
+                wpad[:, :c0] = blk.conv.weight.detach()
+                dxp, _ = ops.conv3x3_dgrad(dz, ops.pack_conv3x3_weights(wpad, transpose_flip=True), cpad, 0)
+                return dxp[:, :c0].contiguous(), None
             cfg = tuning.conv_config(c0 + c1, blk.conv.out_dim, int(n), int(h), int(w))
             return ops.conv3x3_dgrad(dz, blk.packed_weight(transpose_flip=True), c0, c1, cfg=cfg)
 

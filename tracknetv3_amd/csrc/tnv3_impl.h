@@ -13,6 +13,7 @@
 #include "kernels/pointwise.h"
 #include "kernels/postproc.h"
 #include "kernels/preproc.h"
+#include "kernels/optim.h"
 #include "kernels/train_ops.h"
 #include "kernels/wgrad3x3_mfma.h"
 #include "kernels/wgrad_wino_mfma.h"
@@ -752,6 +753,100 @@ template <class Launcher>
 int mixup_impl(Launcher& L, const float* x, const float* lam, const int32_t* perm, float* out, int n, long per_sample) {
   if (!x || !lam || !perm || !out || n <= 0 || per_sample <= 0 || (per_sample % 4)) TNV3_FAIL(-1, "mixup: bad argument");
   return L.launch(mixup_kernel, grid_for((long)n * (per_sample / 4)), 256, x, lam, (const int*)perm, out, n, per_sample);
+}
+
+// ---- optimiser step and mixup draws on the device (kernels/optim.h)
+inline int opt_fill_table(OptTensorTable& t, float* const* params, float* const* grads, float* const* s0, float* const* s1,
+                          const long* numel, int first, int count) {
+  t.count = count;
+  int chunks = 0;
+  for (int i = 0; i < count; ++i) {
+    t.param[i] = params ? params[first + i] : nullptr;
+    t.grad[i] = grads[first + i];
+    t.s0[i] = s0 ? s0[first + i] : nullptr;
+    t.s1[i] = s1 ? s1[first + i] : nullptr;
+    t.numel[i] = numel[first + i];
+    t.first_chunk[i] = chunks;
+    const long c = (numel[first + i] + kOptChunk - 1) / kOptChunk;
+    if (c > (1l << 30) - chunks) return -1;
+    chunks += (int)c;
+  }
+  t.first_chunk[count] = chunks;
+  for (int i = count; i < kOptMaxTensors; ++i) { t.param[i] = t.grad[i] = t.s0[i] = t.s1[i] = nullptr; t.numel[i] = 0; t.first_chunk[i + 1] = chunks; }
+  return chunks;
+}
+
+inline size_t grad_norm_workspace_bytes(int count) {
+  return count <= 0 ? 0 : (size_t)((count + kOptMaxTensors - 1) / kOptMaxTensors) * kNormSplit * sizeof(double);
+}
+
+template <class Launcher>
+int grad_norm_impl(Launcher& L, float* const* grads, const long* numel, int count, float max_norm, float* out2, void* ws, size_t ws_bytes) {
+  if (!grads || !numel || count <= 0 || !out2 || !ws) TNV3_FAIL(-1, "grad_norm: bad argument");
+  if (ws_bytes < grad_norm_workspace_bytes(count) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "grad_norm: workspace too small / misaligned");
+  for (int i = 0; i < count; ++i)
+    if (!grads[i] || numel[i] <= 0) TNV3_FAIL(-1, "grad_norm: tensor %d is empty or NULL", i);
+  double* partial = (double*)ws;
+  const int groups = (count + kOptMaxTensors - 1) / kOptMaxTensors;
+  int rc;
+  for (int gidx = 0; gidx < groups; ++gidx) {
+    OptTensorTable t;
+    const int first = gidx * kOptMaxTensors, c = count - first < kOptMaxTensors ? count - first : kOptMaxTensors;
+    if (opt_fill_table(t, nullptr, grads, nullptr, nullptr, numel, first, c) < 0) TNV3_FAIL(-1, "grad_norm: too many elements");
+    if ((rc = L.launch(grad_sumsq_partial_kernel, kNormSplit, 256, t, partial + (size_t)gidx * kNormSplit))) return rc;
+  }
+  return L.launch(grad_norm_finalize_kernel, 1, 64, (const double*)partial, groups * kNormSplit, max_norm, out2);
+}
+
+template <class Launcher>
+int adam_step_impl(Launcher& L, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const long* numel, int count, double lr, double beta1, double beta2, double eps, double weight_decay, long step,
+                   const float* clip_coef, int zero_grad) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || count <= 0) TNV3_FAIL(-1, "adam_step: bad argument");
+  if (step < 1) TNV3_FAIL(-1, "adam_step: step counts from 1 (got %ld)", step);
+  if (!(lr >= 0.0) || !(eps >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(weight_decay >= 0.0))
+    TNV3_FAIL(-1, "adam_step: invalid hyper-parameter");
+  if (!(1.0 - beta1 < 0.5)) TNV3_FAIL(-1, "adam_step: beta1 <= 0.5 is not supported (lerp's other branch)");
+  for (int i = 0; i < count; ++i)
+    if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] <= 0) TNV3_FAIL(-1, "adam_step: tensor %d is empty or NULL", i);
+  // torch/optim/adam.py (_multi_tensor_adam, non-capturable): python floats, i.e. doubles, rounded to fp32 at the kernel boundary
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  int rc;
+  for (int first = 0; first < count; first += kOptMaxTensors) {
+    OptTensorTable t;
+    const int c = count - first < kOptMaxTensors ? count - first : kOptMaxTensors;
+    const int chunks = opt_fill_table(t, params, grads, exp_avg, exp_avg_sq, numel, first, c);
+    if (chunks < 0) TNV3_FAIL(-1, "adam_step: too many elements");
+    const AdamScalars a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), -step_size, bc2_sqrt, (float)eps, (float)weight_decay};
+    if ((rc = L.launch(adam_multi_kernel, chunks, 256, t, a, clip_coef, zero_grad ? 1 : 0))) return rc;
+  }
+  return 0;
+}
+
+template <class Launcher>
+int sgd_step_impl(Launcher& L, float* const* params, float* const* grads, float* const* momentum_buf, const long* numel, int count,
+                  double lr, double momentum, double weight_decay, int first_step, const float* clip_coef, int zero_grad) {
+  if (!params || !grads || !numel || count <= 0) TNV3_FAIL(-1, "sgd_step: bad argument");
+  if (momentum != 0.0 && !momentum_buf) TNV3_FAIL(-1, "sgd_step: momentum needs its buffers");
+  for (int i = 0; i < count; ++i)
+    if (!params[i] || !grads[i] || numel[i] <= 0 || (momentum != 0.0 && !momentum_buf[i])) TNV3_FAIL(-1, "sgd_step: tensor %d is empty or NULL", i);
+  int rc;
+  for (int first = 0; first < count; first += kOptMaxTensors) {
+    OptTensorTable t;
+    const int c = count - first < kOptMaxTensors ? count - first : kOptMaxTensors;
+    const int chunks = opt_fill_table(t, params, grads, momentum != 0.0 ? momentum_buf : nullptr, nullptr, numel, first, c);
+    if (chunks < 0) TNV3_FAIL(-1, "sgd_step: too many elements");
+    if ((rc = L.launch(sgd_multi_kernel, chunks, 256, t, (float)lr, (float)momentum, (float)weight_decay, first_step ? 1 : 0, clip_coef,
+                       zero_grad ? 1 : 0))) return rc;
+  }
+  return 0;
+}
+
+template <class Launcher>
+int mixup_draw_impl(Launcher& L, float* lam, int32_t* perm, int n, float alpha, unsigned long long seed, unsigned long long step) {
+  if (!lam || !perm || n <= 0 || n > 65536 || !(alpha > 0.0f)) TNV3_FAIL(-1, "mixup_draw: bad argument (0 < n <= 65536, alpha > 0)");
+  return L.launch(mixup_draw_kernel, 1, 256, lam, (int*)perm, n, alpha, seed, step);
 }
 
 // ---- frame preprocessing

@@ -479,6 +479,89 @@ def mixup(x, lam, perm):
     return out
 
 
+# ------------------------------------------------------------------------------------------------- optimiser / mixup draws
+def _ptr_array(tensors):
+    import ctypes
+    arr = (ctypes.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def _numel_array(tensors):
+    import ctypes
+    return (ctypes.c_long * len(tensors))(*[int(t.numel()) for t in tensors])
+
+
+def _check_tensor_lists(*lists):
+    flat = [t for lst in lists if lst is not None for t in lst]
+    _f32(*flat)
+    _lib.dev_check(*flat)
+    n = len(lists[0])
+    for lst in lists:
+        if lst is not None and len(lst) != n:
+            raise _lib.Tnv3Error("tensor lists must have the same length")
+    for lst in lists[1:]:
+        if lst is not None and any(a.numel() != b.numel() for a, b in zip(lists[0], lst)):
+            raise _lib.Tnv3Error("tensor lists must have matching sizes")
+    return n
+
+
+def grad_norm(grads, max_norm):
+    """clip_grad_norm_'s two scalars on the device: returns a (2,) tensor [total L2 norm, min(1, max_norm / (norm + 1e-6))]."""
+    lib = _lib.load()
+    n = _check_tensor_lists(grads)
+    out = torch.empty(2, dtype=torch.float32, device=grads[0].device)
+    ws = _workspace(lib.tnv3_grad_norm_workspace_bytes(n), grads[0].device)
+    _lib.check(lib.tnv3_grad_norm(_ptr_array(grads), _numel_array(grads), n, float(max_norm), _lib.ptr(out), _lib.ptr(ws), ws.numel() * 8,
+                                  _lib.stream_ptr(grads[0])))
+    return out
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, clip_coef=None,
+              zero_grad=False):
+    """torch.optim.Adam's update of every listed tensor in one launch (tnv3_adam_step); `step` is the 1-based update count;
+    clip_coef: (1,) device tensor scaling the gradients first (grad_norm(...)[1:]), or None."""
+    lib = _lib.load()
+    n = _check_tensor_lists(params, grads, exp_avgs, exp_avg_sqs)
+    if clip_coef is not None:
+        _f32(clip_coef)
+        _lib.dev_check(params[0], clip_coef)
+    _lib.check(lib.tnv3_adam_step(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avgs), _ptr_array(exp_avg_sqs), _numel_array(params),
+                                  n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                  _lib.ptr(clip_coef), int(bool(zero_grad)), _lib.stream_ptr(params[0])))
+
+
+def sgd_step(params, grads, momentum_bufs, lr, momentum=0.0, weight_decay=0.0, first_step=False, clip_coef=None, zero_grad=False):
+    """torch.optim.SGD's update (momentum, dampening 0, no Nesterov) of every listed tensor in one launch (tnv3_sgd_step)."""
+    lib = _lib.load()
+    n = _check_tensor_lists(params, grads, momentum_bufs if momentum else None)
+    _lib.check(lib.tnv3_sgd_step(_ptr_array(params), _ptr_array(grads), _ptr_array(momentum_bufs) if momentum else None, _numel_array(params), n,
+                                 float(lr), float(momentum), float(weight_decay), int(bool(first_step)), _lib.ptr(clip_coef),
+                                 int(bool(zero_grad)), _lib.stream_ptr(params[0])))
+
+
+def mixup_draw(n, alpha, seed, step, device):
+    """(lam float32 (n,), perm int32 (n,)) of train.py:33-36 drawn ON THE DEVICE from Philox(seed, step): no host RNG, no H2D copy."""
+    lib = _lib.load()
+    device = torch.device(device)
+    lam = torch.empty(int(n), dtype=torch.float32, device=device)
+    perm = torch.empty(int(n), dtype=torch.int32, device=device)
+    _lib.dev_check(lam, perm)
+    with torch.cuda.device(device) if device.type == "cuda" else _nullcontext():
+        _lib.check(lib.tnv3_mixup_draw(_lib.ptr(lam), _lib.ptr(perm), int(n), float(alpha), int(seed) & (2 ** 64 - 1), int(step) & (2 ** 64 - 1),
+                                       _lib.stream_ptr(lam)))
+    return lam, perm
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 # ------------------------------------------------------------------------------------------------- InpaintNet backward
 def conv1d_act_backward(dout, out, act, nlc=False):
     """dPre[N][C][L] = dOut * act'(out); nlc: dOut/out are (N, L, C)."""

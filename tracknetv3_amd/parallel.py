@@ -150,10 +150,12 @@ class TrackNetTrainer:
 
     step(x, y): zero_grad -> (mixup) -> forward(train) -> WBCELoss -> backward (+ overlapped gradient all-reduce) ->
     optimizer.step().  Returns the loss as a DEVICE scalar: no per-step host sync (the reference's `.item()` at
-    train.py:94 is what would serialise 8 GPUs)."""
+    train.py:94 is what would serialise 8 GPUs).  With `device_rng` (default) the mixup draws come from the device-side Philox
+    generator, and with `optim.FusedAdam` the update is one launch: a step then issues no H2D copy at all."""
 
-    def __init__(self, net, optimizer, alpha=0.0, seed=13, group=None, bucket_bytes=12 << 20, record_timing=False):
+    def __init__(self, net, optimizer, alpha=0.0, seed=13, group=None, bucket_bytes=12 << 20, record_timing=False, device_rng=True):
         from .utils.metric import WBCELoss
+        self.device_rng, self.seed, self.steps_done = bool(device_rng), int(seed), 0
         self.record_timing = bool(record_timing)
         self.last_timing = None
         self.net, self.opt, self.alpha, self.loss_fn = net, optimizer, alpha, WBCELoss
@@ -166,9 +168,14 @@ class TrackNetTrainer:
 
     def step(self, x, y):
         self.opt.zero_grad(set_to_none=True)
+        self.steps_done += 1
         if self.alpha > 0:
-            lamb, perm = draw_mixup(x.shape[0], self.alpha, self.rng)
-            lam_d, perm_d = torch.from_numpy(lamb).to(x.device), torch.from_numpy(perm).to(x.device)
+            if self.device_rng:
+                # draws made ON THE DEVICE (Philox keyed by seed + rank, counter = step): no host RNG, no H2D copy, no sync
+                lam_d, perm_d = ops.mixup_draw(x.shape[0], self.alpha, self.seed + 1000 * self.rank, self.steps_done, x.device)
+            else:                                                    # the reference's host protocol (train.py:33-36)
+                lamb, perm = draw_mixup(x.shape[0], self.alpha, self.rng)
+                lam_d, perm_d = torch.from_numpy(lamb).to(x.device), torch.from_numpy(perm).to(x.device)
             x, y = ops.mixup(x, lam_d, perm_d), ops.mixup(y, lam_d, perm_d)
         timing = self.record_timing and x.is_cuda
         if self.reducer is not None:
