@@ -26,7 +26,7 @@ import torch  # noqa: E402
 SEQ_LEN, BG_MODE, H, W = 8, "concat", 288, 512
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (= fp32 vector peak)
 PEAK_HBM_GBPS = 8000.0
-KERNEL_SET = "wino_split+conv_up2x+direct"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
+KERNEL_SET = "wino_v3+conv_up2x+direct"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
 ALG_BYTES_PER_SAMPLE = 693.55e6    # ideal-fusion fp32 bytes of one 27->8 forward
 
 
@@ -447,7 +447,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch",
-                         "kernel": f"conv3x3_wino_split_mfma_kernel<*> + conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} "
+                         "kernel": f"conv3x3_wino_v3_mfma_kernel<*> + conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} "
                                    "launches/step for the 17 conv layers, fp32 MFMA 32x32x2)",
                          "avg_launch_ms": round(conv_ms / launches_per_step, 4), "conv_ms_per_step": round(conv_ms, 4),
                          "algorithmic_gflop_per_step": round(float(fl.sum()) / 1e9, 3),

@@ -90,14 +90,20 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  *                                     (u for cout_w x c_count) or, transpose_flip != 0, as the data gradient's filter
  *                                     w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] (u for c_count x cout_w): no host-side
  *                                     slice / flip / transpose copies (model.py:8 weight layout) */
-/*   `variant` of tnv3_conv3x3_wino_forward (per call): -1 / 2 = xi-split kernel, two waves per SIMD (default, fastest);
- *                                     0 = one wave per SIMD, transform as its own phase; 1 = transform interleaved with the
- *                                     MFMAs (measured slower).  All three compute the same function. */
+/*   `variant` of tnv3_conv3x3_wino_forward (per call): -1 = the library's default (3);  2 = xi-split kernel, two waves per SIMD;
+ *                                     3 = the same tile with buffer-descriptor DMA and a paired patch transform (6-12 % faster);  4 = 3 with the
+ *                                     "quad" operand layouts (one LDS read per four MFMAs; needs filters packed with
+ *                                     layout 1: ask tnv3_conv3x3_wino_layout);  0 = one wave per SIMD, transform as its own
+ *                                     phase;  1 = transform interleaved with the MFMAs (measured slower).  Variants 2, 3, 4
+ *                                     are bit-identical to each other; all compute the same function.
+ *   `layout` of the pack calls: 0 = u[cin_pad][16][cout];  1 = u[cin_pad / 2][4][2][cout][4] (transform row major, the four xi of
+ *                                     a row adjacent). */
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
-int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, tnv3_stream_t stream);
+int tnv3_conv3x3_wino_layout(int variant);     /* filter pack layout (0 or 1) the kernel `variant` reads; -1 = the default kernel */
+int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, int layout, tnv3_stream_t stream);
 int tnv3_conv3x3_wino_pack_view(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip,
-                                tnv3_stream_t stream);
+                                int layout, tnv3_stream_t stream);
 int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,
                               tnv3_stream_t stream);

@@ -32,9 +32,17 @@ int tnv3_diag_conv3x3_forward(const float* src0, const float* wpack, float* dst,
  *   variant 0, 1, 2     the production kernels (as tnv3_conv3x3_wino_forward)
  *   variant 11, 12, 13  twins of kernel 0: no DMA after the prologue / + no patch transform / + no barriers
  *   variant 21 .. 26    twins of kernel 2: 21-23 as above; with DMA: 24 no patch transform, 25 transform without its V writes,
- *                       26 transform without its raw reads */
+ *                       26 transform without its raw reads
+ *   variant 27 / 37 ..  kernel 2 / kernel 3 with s_memtime phase totals of one mid-grid workgroup written to dst (uint64
+ *                       [wave][8]; scripts/wino_timeline.py); 41, 51, 61, 71 ...: experimental schedules of kernel 3 */
 int tnv3_diag_conv3x3_wino_forward(const float* src, const float* u, float* dst, int n, int cin, int cout, int h, int w,
                                    int variant, tnv3_stream_t stream);
+
+/* What an instruction costs next to a stream of v_mfma_f32_32x32x2_f32 (kernels/coissue_probe.h): `blocks` workgroups of 8
+ * waves (one per CU; waves w and w + 4 share a SIMD); waves 0-3 run role_a, waves 4-7 role_b, `iters` x 8 steps each; out
+ * [blocks][8] uint64 = each wave's s_memtime cycles.  gsrc_1mb: any device buffer of >= 1 MiB (source of the LDS-DMA role). */
+int tnv3_diag_coissue_probe(unsigned long long* out, const float* gsrc_1mb, int blocks, int role_a, int role_b, int iters,
+                            tnv3_stream_t stream);
 
 #ifdef __cplusplus
 }

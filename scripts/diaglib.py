@@ -19,7 +19,8 @@ def load():
         lib.tnv3_diag_last_error.restype = ctypes.c_char_p
         for name, args in (("tnv3_diag_mfma_f32_probe", [p, i, i, p]),
                            ("tnv3_diag_conv3x3_forward", [p, p, p, i, i, i, i, i, i, i, p]),
-                           ("tnv3_diag_conv3x3_wino_forward", [p, p, p, i, i, i, i, i, i, p])):
+                           ("tnv3_diag_conv3x3_wino_forward", [p, p, p, i, i, i, i, i, i, p]),
+                           ("tnv3_diag_coissue_probe", [p, p, i, i, i, i, p])):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = i, args
         _diag = lib
@@ -45,3 +46,8 @@ def conv3x3_wino_forward(x, u, y, variant):
     n, cin, h, w = (int(v) for v in x.shape)
     check(load().tnv3_diag_conv3x3_wino_forward(_lib.ptr(x), _lib.ptr(u), _lib.ptr(y), n, cin, int(y.shape[1]), h, w, int(variant),
                                                 _lib.stream_ptr(x)))
+
+
+def coissue_probe(out_u64, gsrc, blocks, role_a, role_b, iters):
+    check(load().tnv3_diag_coissue_probe(_lib.ptr(out_u64), _lib.ptr(gsrc), int(blocks), int(role_a), int(role_b), int(iters),
+                                         _lib.stream_ptr(gsrc)))

@@ -200,6 +200,7 @@ inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline unsigned long long __builtin_amdgcn_s_memtime() { return 0; }   // only the diag twins (never instantiated here) read the clock
 inline void __builtin_amdgcn_s_waitcnt(int) {}   // the emulated LDS DMA is synchronous
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline void __threadfence() {}
@@ -282,6 +283,17 @@ inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(
   memcpy((void*)(base + (uintptr_t)emu::lane_id() * size + offset), (const void*)((uintptr_t)g + offset), size);
 }
 
+// buffer_load ... lds through a raw buffer descriptor (kernels/conv3x3_wino3_mfma.h): LDS[base + lane*16] <- buffer[voffset..+16),
+// zeros when the access is out of the descriptor's range (the hardware bounds check the kernels use for zero padding)
+struct tnv3_rsrc_t { const char* base; unsigned num_records; };
+inline tnv3_rsrc_t tnv3_make_rsrc(const void* base, unsigned bytes) { return tnv3_rsrc_t{(const char*)base, bytes}; }
+inline void tnv3_buf_dma16(tnv3_rsrc_t r, float* lds_base, unsigned voffset) {
+  const uintptr_t base = emu::wave_read((uintptr_t)lds_base, 0);
+  void* dst = (void*)(base + (uintptr_t)emu::lane_id() * 16);
+  if ((unsigned long long)voffset + 16ull <= (unsigned long long)r.num_records) memcpy(dst, r.base + voffset, 16);
+  else memset(dst, 0, 16);
+}
+
 // atomics (the emulator is single-threaded: plain read-modify-write)
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
@@ -292,6 +304,7 @@ template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o
 
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
+inline float __cosf(float x) { return cosf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __frcp_rn(float a) { return 1.0f / a; }
 inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }

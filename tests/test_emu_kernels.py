@@ -172,7 +172,7 @@ def _wino_case(n, cin, cout, h, w, device):
 WINO_EMU_EXTRA = [(1, 27, 64, 12, 192), (1, 16, 192, 4, 64)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["phased", "interleaved", "xisplit"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4], ids=["phased", "interleaved", "xisplit", "balanced", "quad"])
 @pytest.mark.parametrize("case", WINO_CASES + WINO_EMU_EXTRA)
 def test_conv3x3_wino_emulated_vs_torch(monkeypatch, emu, case, variant):
     from tracknetv3_amd import ops
@@ -295,3 +295,17 @@ def test_empty_batches_are_accepted(emu):
         m(torch.zeros((1, 9, 12, 32)))                # H not divisible by 8
     with pytest.raises(ValueError):
         net(torch.zeros((2, 16, 3)), torch.zeros((2, 16, 1)))
+
+
+@pytest.mark.parametrize("case", WINO_CASES + WINO_EMU_EXTRA)
+def test_conv3x3_wino_balanced_kernel_is_bit_identical_to_the_xi_split_kernel(emu, case):
+    """Variant 3 re-balances the non-MFMA work (buffer-descriptor DMA, paired patch transform) but performs the same fp32
+    operations per element in the same order as variant 2: the outputs must agree to the last bit."""
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = case
+    x, wt = torch.relu(T((n, cin, h, w), 91)), T((cout, cin, 3, 3), 92, -0.3, 0.3)
+    u = ops.pack_wino_weights(wt, variant=2)
+    want = ops.conv3x3_wino(x, u, cout, variant=2)
+    assert ops.wino_layout(3) == 0 and ops.wino_layout(4) == 1
+    assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=3))
+    assert torch.equal(want, ops.conv3x3_wino(x, ops.pack_wino_weights(wt, variant=4), cout, variant=4))      # quad operand layouts

@@ -67,6 +67,10 @@ def test_conv_and_wgrad_budgets(resources):
     k = _find(resources, "conv3x3_wino_split_mfma_kernelINS_12WinoSplitCfgILi8ELi0E")  # production: 128 accumulators, TWO waves per SIMD
     assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0
     assert k["LDS Size [bytes/block]"] <= 160 * 1024                                    # two filter + two V + two raw stages
+    for args in ("Li8ELi0ELi0ELi0ELi0ELi0E", "Li8ELi0ELi0ELi0ELi1ELi0E"):            # variant 3 (the default) and 4: the same budget
+        k = _find(resources, "conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgI" + args)
+        assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+        assert k["LDS Size [bytes/block]"] <= 160 * 1024
     for name, occ in (("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi2ELi4ELi2ELi4E", 4), ("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi1ELi4ELi2ELi4E", 4),
                       ("dgrad_up2x_mfma_kernelINS_12DgradUp2xCfgILi2ELi2ELi4ELi1ELi2E", 4)):
         k = _find(resources, name)

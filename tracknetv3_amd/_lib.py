@@ -49,8 +49,9 @@ def _declare(lib):
     sig("tnv3_conv3x3_wgrad_up2x", i, p, p, p, p, p, sz, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_packed_floats", sz, i, i)
     sig("tnv3_conv3x3_wino_supported", i, i, i, i, i)
-    sig("tnv3_conv3x3_wino_pack", i, p, p, i, i, p)
-    sig("tnv3_conv3x3_wino_pack_view", i, p, p, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino_layout", i, i)
+    sig("tnv3_conv3x3_wino_pack", i, p, p, i, i, i, p)
+    sig("tnv3_conv3x3_wino_pack_view", i, p, p, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wgrad_wino_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad_wino_workspace_bytes", sz, i, i, i, i, i)
@@ -104,7 +105,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_pack_up2x_weights", "tnv3_conv_up2x_forward", "tnv3_dgrad_up2x_packed_floats", "tnv3_pack_dgrad_up2x_weights",
            "tnv3_dgrad_up2x", "tnv3_conv3x3_wgrad_up2x_workspace_bytes", "tnv3_conv3x3_wgrad_up2x",
            "tnv3_conv3x3_wgrad_wino_supported", "tnv3_conv3x3_wgrad_wino_workspace_bytes", "tnv3_conv3x3_wgrad_wino",
-           "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_forward"]
+           "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_layout", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_forward"]
 
 
 def library_path():

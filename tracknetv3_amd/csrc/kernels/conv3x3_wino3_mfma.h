@@ -1,0 +1,383 @@
+// conv3x3_wino3_mfma.h -- third generation of the fused Winograd F(2x2, 3x3) forward kernel (variant 3 of
+// tnv3_conv3x3_wino_forward).  Same tile, same LDS operands, same MFMA stream and epilogue as the xi-split kernel
+// (conv3x3_wino_split_mfma_kernel, conv3x3_wino_mfma.h) -- and therefore bit-identical results -- but the non-MFMA work of
+// a chunk is re-balanced after a cycle-level timeline of that kernel (s_memtime per phase, profiles/r02_wino_timeline*.json)
+// showed what its counters only hinted at: the matrix pipe idles because ONE wave group's serial chain
+// [issue 12 LDS-DMA pieces: 2700 cycles] -> [patch transform: 930] -> [32 MFMAs: 2150] is 5800 cycles long while the other
+// group finishes its [MFMAs: 2200] -> [transform: 1150] in 3400 and then waits 2200 cycles at the chunk barrier.
+//
+//   1. DMA by buffer_load ... lds with a per-chunk scalar descriptor: every per-lane offset is chunk-invariant (6 VGPRs), the
+//      chunk advance and the channel bound live in the descriptor (SALU), zero padding comes from the hardware range check
+//      (offset >= num_records -> 0) -- no per-piece address arithmetic on the vector ALU (was ~86 VALU per chunk).
+//   2. DMA issue split evenly over all eight waves (6 pieces each): group 0 issues its half at the start of the chunk, group 1
+//      after its MFMAs -- both groups now carry the same non-MFMA load.
+//   3. Patch transform by transform-row pairs: a thread produces, for TWO horizontally adjacent tiles, the two rows of
+//      B^T d B that its OWN wave group consumes (xi = 8g .. 8g+7): 3 raw rows x (2 x ds_read_b128 + ds_read_b32) instead
+//      of 16 stride-2 ds_read_b32 (2-way bank conflicts), 28 instead of 32 adds, 8 x ds_write_b64 instead of 16 x
+//      ds_write_b32.  Same operations per element as before => the same bits.
+//
+// What that bought (MI355X, batch 10): 0-8 %, because the premise "one wave's VALU / LDS / DMA work hides under the other
+// wave's MFMAs" is false for the fp32 MFMA.  A microbenchmark (kernels/coissue_probe.h, profiles/r02_mfma_f32_coissue.json)
+// measured it directly: beside a partner wave that streams v_mfma_f32_32x32x2_f32 a wave gets ONE short burst (4 VALU, or 2
+// ds_read_b32, or 1 ds_read_b128, or half an LDS-DMA piece) per 64-cycle MFMA, and inside the MFMA wave every extra instruction
+// costs ~5 cycles of matrix-pipe time (MFMA + 2 VALU: 76 cycles per step instead of 66; + 2 ds_read_b32: 77).  The SIMD is
+// time-multiplexed: a chunk costs its MFMAs plus ~5 cycles for EVERY other instruction either wave executes, wherever it is
+// placed (which is why priorities, orders and DMA splits -- all measured, profiles/r02_wino_timeline.json -- change nothing).
+// The lever is the instruction COUNT.  Hence the QUAD form (variant 4):
+//   4. operand layouts with the four xi of a transform row adjacent -- U[pair][row][parity][co][4], V[pair][row][parity][tile][4]
+//      -- so that ONE conflict-free ds_read_b128 per operand feeds FOUR MFMAs (0.5 instead of 2 LDS reads per MFMA), the
+//      transform stores rows as ds_write_b128 (4 instead of 8 stores), and the LDS-DMA destinations are scalar (2 instead of
+//      4 instructions per piece).  Every accumulator still sees its channel pairs in the same order => the same bits.
+#pragma once
+#include "conv3x3_wino_mfma.h"
+
+namespace tnv3 {
+
+#ifndef TNV3_EMU
+typedef __amdgpu_buffer_rsrc_t tnv3_rsrc_t;
+// Raw buffer descriptor (stride 0): base, size in bytes (< 2^31); loads at offset >= num_records return 0.
+__device__ __forceinline__ tnv3_rsrc_t tnv3_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// LDS[lds_base + lane*16 .. +16) <- buffer[voffset .. +16) (or zeros when out of range); tracked by vmcnt.
+__device__ __forceinline__ void tnv3_buf_dma16(tnv3_rsrc_t r, float* lds_base, unsigned voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)voffset, 0, 0, 0);
+}
+#endif
+
+constexpr unsigned kDmaOob = 0x80000000u;      // voffset of a padding lane: beyond any descriptor (num_records < 2^31)
+
+template <int CC_, int DIAG_ = 0, int DMA_MODE_ = 0, int PRIO_ = 0, int QUAD_ = 0, int SYM_ = 0>
+struct WinoV3Cfg {
+  // 1: both wave groups run the SAME program per chunk -- MFMAs, then their DMA pieces, then their transform rows -- instead of
+  // opposite orders.  Non-MFMA work of one wave does not hide under the other wave's fp32 MFMAs anyway (header comment), and
+  // next to an MFMA stream it crawls (one instruction per MFMA slot: a 700-cycle transform takes 2800); in lockstep both waves
+  // of a SIMD share the matrix pipe for 2 x 32 MFMAs and then do their other work at full speed.
+  static constexpr int SYM = SYM_;
+  static constexpr int QUAD = QUAD_;                 // 1: quad operand layouts (filters packed with layout 1), see the header comment
+  // 1: the wave raises its priority (s_setprio 3) for its DMA-issue and patch-transform phases and drops it for its MFMAs.
+  // The timeline (profiles/r02_wino_timeline.json) shows that with equal priorities a wave's VALU / LDS / VMEM instructions
+  // barely issue while its SIMD partner streams MFMAs (a 700-cycle transform takes 2500); an MFMA needs one issue slot per 64
+  // cycles, so the matrix pipe loses nothing when everything else goes first.
+  static constexpr int PRIO = PRIO_;
+  static constexpr int WM = 2, WN = 2, CC = CC_;
+  static constexpr int DIAG = DIAG_;                 // 7: s_memtime phase totals of one workgroup written to dst (libtnv3_diag.so)
+  // who issues the chunk's LDS-DMA pieces, and when: 0 = every thread its own pieces, group 0 at the start of the chunk and
+  // group 1 after its MFMAs; 1 = group 1 issues ALL pieces after its MFMAs; 2 = every thread its own pieces, both groups
+  // after their MFMAs
+  static constexpr int DMA_MODE = DMA_MODE_;
+  static constexpr int NTD = DMA_MODE_ == 1 ? WM * WN * 64 : 2 * WM * WN * 64;     // threads that issue DMA
+  static constexpr int NT = 2 * WM * WN * 64;        // 512 threads: waves 0-3 = xi group 0, waves 4-7 = xi group 1
+  static constexpr int MB = 32 * WM, TB = 32 * WN, PW = 32 * WN;
+  static constexpr int RW = PW + 8, RAWP = 6 * RW;
+  static constexpr int RAW_FLOATS = CC * RAWP;
+  static constexpr int U_FLOATS = CC * 16 * MB, V_FLOATS = CC * 16 * TB;
+  static constexpr int NU4 = U_FLOATS / 4 / NTD;                         // filter pieces per issuing thread and chunk (4 or 8)
+  static constexpr int NRAW = (RAW_FLOATS / 4 + NTD - 1) / NTD;          // raw pieces per issuing thread and chunk (2 or 4)
+  static constexpr int RAW_STAGE = NRAW * NTD * 4;
+  static constexpr int LDS_FLOATS = 2 * U_FLOATS + 2 * V_FLOATS + 2 * RAW_STAGE;
+  static constexpr int XCH_FLOATS = (NT / 64) * 32 * 64;
+  static_assert((U_FLOATS / 4) % NTD == 0, "filter panel must deal evenly");
+  static_assert(CC * (TB / 2) == NT / 2, "one tile pair per thread, group and chunk");
+  static_assert(XCH_FLOATS <= 2 * U_FLOATS, "the exchange reuses the filter stages");
+  static_assert((RW % 4) == 0 && (RAWP % 4) == 0, "16-byte rows");
+  static_assert(!QUAD_ || (DMA_MODE_ == 0 && CC_ == 8), "the quad form is built for 8-channel chunks, every thread moving its own pieces");
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const WinoArgs a) {
+  constexpr int WN = Cfg::WN, CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, PW = Cfg::PW, RW = Cfg::RW, RAWP = Cfg::RAWP;
+  constexpr int NU4 = Cfg::NU4, NRAW = Cfg::NRAW, NTD = Cfg::NTD, DMA_MODE = Cfg::DMA_MODE;
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  float* u_s = lds;                                   // two stages
+  float* v_s = lds + 2 * Cfg::U_FLOATS;               // two stages
+  float* raw_s = v_s + 2 * Cfg::V_FLOATS;             // two stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int wn = wq % WN, wm = wq / WN;
+  const int half = lane >> 5, bl = lane & 31;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+  const int tilesH = H / 4, tilesW = W / PW;
+  const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
+  int mb, pt;
+  if (!conv_block_map(blockIdx.x, nMB, nPT, mb, pt)) return;
+  const int n = pt / (tilesH * tilesW);
+  const int trem = pt - n * (tilesH * tilesW);
+  const int h0 = (trem / tilesW) * 4, w0 = (trem % tilesW) * PW;
+  const int m0 = mb * MB;
+  const int nChunks = (Cin + CC - 1) / CC;
+
+  // ---- chunk-invariant per-lane byte offsets of this thread's DMA pieces
+  unsigned vo_u[NU4], vo_r[NRAW];
+#pragma unroll
+  for (int i = 0; i < NU4; ++i) {                     // filter piece e4 of [CC*16 rows][MB/4]: row = (ci, xi), 16 bytes of 64 channels
+    const int e4 = (tid & (NTD - 1)) + i * NTD;
+    if (Cfg::QUAD) {                                    // packed [pair][row][parity][Cout][4]: piece e4 = (prow = (pair, row, parity), co)
+      const int prow = e4 / MB, co = e4 - prow * MB;
+      vo_u[i] = (unsigned)(prow * Cout + co) * 16u;
+    } else {
+      const int row = e4 / (MB / 4), m4 = e4 - row * (MB / 4);
+      vo_u[i] = (unsigned)(row * Cout + m4 * 4) * 4u;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NRAW; ++i) {                    // raw piece e of [CC][6][RW/4]; padding / unused slots read out of range (= 0)
+    const int e = (tid & (NTD - 1)) + i * NTD;
+    const int c = e / (RAWP / 4), r = e - c * (RAWP / 4);
+    const int tr = r / (RW / 4), q = r - tr * (RW / 4);
+    const int gh = h0 - 1 + tr, gw = w0 - 4 + 4 * q;
+    const bool ok = e < Cfg::RAW_FLOATS / 4 && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    vo_r[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
+  }
+  const float* u_base = a.u + (Cfg::QUAD ? (size_t)m0 * 4 : (size_t)m0);
+  const float* x_base = a.src + (size_t)n * Cin * HW;
+  const int wbase = __builtin_amdgcn_readfirstlane((wave & (NTD / 64 - 1)) * 64);      // scalar: the LDS-DMA destinations (M0) stay on the SALU
+  // half h (0: issued by group 0 at the start of the chunk, 1: by group 1 after its MFMAs) of the DMAs of one chunk:
+  // filters of chunk ku -> stage ku & 1, raw tile of chunk kr -> stage kr & 1.  A thread moves its own NU4 + NRAW pieces.
+  auto dma_chunk = [&](int ku, int kr) {
+    if (ku < nChunks) {
+      const tnv3_rsrc_t ru = tnv3_make_rsrc(u_base + (size_t)ku * CC * 16 * Cout, (unsigned)(CC * 16 * Cout) * 4u);
+      float* us = u_s + (ku & 1) * Cfg::U_FLOATS;
+#pragma unroll
+      for (int i = 0; i < NU4; ++i) tnv3_buf_dma16(ru, us + (i * NTD + wbase) * 4, vo_u[i]);
+    }
+    if (kr < nChunks) {
+      const int cleft = Cin - kr * CC;                // channels past Cin lie beyond num_records: zero
+      const tnv3_rsrc_t rr = tnv3_make_rsrc(x_base + (size_t)kr * CC * HW, (unsigned)(cleft < CC ? cleft : CC) * (unsigned)HW * 4u);
+      float* rs = raw_s + (kr & 1) * Cfg::RAW_STAGE;
+#pragma unroll
+      for (int i = 0; i < NRAW; ++i) tnv3_buf_dma16(rr, rs + (i * NTD + wbase) * 4, vo_r[i]);
+    }
+  };
+
+  // ---- patch transform: thread -> (channel c, tile row tr, tile pair pj), its group's two transform rows
+  const int tg = tid & (NT / 2 - 1);
+  const int pc = tg / (TB / 2), prem = tg - pc * (TB / 2);
+  const int ptr_ = prem / (TB / 4), pj = prem - ptr_ * (TB / 4);
+  const int t_src = pc * RAWP + (2 * ptr_ + grp) * RW + 4 * pj;                 // first of three raw rows, 16-byte aligned
+  const int t_dst = Cfg::QUAD ? ((((pc >> 1) * 4 + 2 * grp) * 2 + (pc & 1)) * TB + ptr_ * (TB / 2) + 2 * pj) * 4     // [pair][row][parity][tile][4]
+                              : (pc * 16 + grp * 8) * TB + ptr_ * (TB / 2) + 2 * pj;   // xi = 8*grp .. 8*grp+7, tiles (2pj, 2pj+1)
+  typedef float wf2 __attribute__((ext_vector_type(2)));
+  auto transform = [&](int stage) {                     // raw stage -> V stage of the same parity
+    const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src;
+    float x[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                       // patch columns 4pj+3 .. 4pj+8 of raw row r
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(d + r * RW);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(d + r * RW + 4);
+      const float q2 = d[r * RW + 8];
+      x[r][0] = q0[3]; x[r][1] = q1[0]; x[r][2] = q1[1]; x[r][3] = q1[2]; x[r][4] = q1[3]; x[r][5] = q2;
+    }
+    float e[2][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      // group 0 holds patch rows d0,d1,d2 -> (B^T d) rows 0,1;  group 1 holds d1,d2,d3 -> rows 2,3
+      e[0][j] = grp ? x[1][j] - x[0][j] : x[0][j] - x[2][j];      // d2 - d1      | d0 - d2
+      e[1][j] = grp ? x[0][j] - x[2][j] : x[1][j] + x[2][j];      // d1 - d3      | d1 + d2
+    }
+    float* v = v_s + stage * Cfg::V_FLOATS + t_dst;
+    if constexpr (Cfg::QUAD) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {                       // transform row 2*grp + r of both tiles: four xi each, one 16-byte store
+        f32x4 o;
+        o[0] = e[r][0] - e[r][2]; o[1] = e[r][1] + e[r][2]; o[2] = e[r][2] - e[r][1]; o[3] = e[r][1] - e[r][3];
+        *reinterpret_cast<f32x4*>(v + r * (2 * TB * 4)) = o;
+        o[0] = e[r][2] - e[r][4]; o[1] = e[r][3] + e[r][4]; o[2] = e[r][4] - e[r][3]; o[3] = e[r][3] - e[r][5];
+        *reinterpret_cast<f32x4*>(v + r * (2 * TB * 4) + 4) = o;
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      wf2 o;
+      o[0] = e[r][0] - e[r][2]; o[1] = e[r][2] - e[r][4]; *reinterpret_cast<wf2*>(v + (r * 4 + 0) * TB) = o;
+      o[0] = e[r][1] + e[r][2]; o[1] = e[r][3] + e[r][4]; *reinterpret_cast<wf2*>(v + (r * 4 + 1) * TB) = o;
+      o[0] = e[r][2] - e[r][1]; o[1] = e[r][4] - e[r][3]; *reinterpret_cast<wf2*>(v + (r * 4 + 2) * TB) = o;
+      o[0] = e[r][1] - e[r][3]; o[1] = e[r][3] - e[r][5]; *reinterpret_cast<wf2*>(v + (r * 4 + 3) * TB) = o;
+    }
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+
+  const int a_off = (half * 16 + grp * 8) * MB + wm * 32 + bl;
+  const int b_off = (half * 16 + grp * 8) * TB + wn * 32 + bl;
+  // quad form: float offsets of this lane's 16-byte operand groups inside a stage: [pair][row][parity][64][4], row = 2*grp + j
+  const int aq_off = ((2 * grp * 2 + half) * MB + wm * 32 + bl) * 4;
+  const int bq_off = ((2 * grp * 2 + half) * TB + wn * 32 + bl) * 4;
+  auto mfma_chunk = [&](int k) {
+    if constexpr (Cfg::QUAD) {
+      const float* A = u_s + (k & 1) * Cfg::U_FLOATS + aq_off;
+      const float* B = v_s + (k & 1) * Cfg::V_FLOATS + bq_off;
+      constexpr int PSTR = 4 * 2 * MB * 4, RSTR = 2 * MB * 4;     // floats per channel pair / per transform row (MB == TB)
+      f32x4 av[2][2], bv[2][2];                            // [ring][row j]: one 16-byte read feeds the four xi of a row
+      auto read_pair = [&](int cp) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          av[cp & 1][j] = *reinterpret_cast<const f32x4*>(A + cp * PSTR + j * RSTR);
+          bv[cp & 1][j] = *reinterpret_cast<const f32x4*>(B + cp * PSTR + j * RSTR);
+        }
+      };
+      read_pair(0);
+#pragma unroll
+      for (int cp = 0; cp < CC / 2; ++cp) {
+        if (cp + 1 < CC / 2) read_pair(cp + 1);            // the next pair's four reads go out BEFORE this pair's eight MFMAs
+        __builtin_amdgcn_sched_barrier(0);                 // (the scheduler would otherwise sink them next to their use)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+            acc[j * 4 + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cp & 1][j][x], bv[cp & 1][j][x], acc[j * 4 + x], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
+    const float* A = u_s + (k & 1) * Cfg::U_FLOATS + a_off;
+    const float* B = v_s + (k & 1) * Cfg::V_FLOATS + b_off;
+    constexpr int NSTEP = (CC / 2) * 8;                  // (channel pair, xi of this group): one MFMA each
+    constexpr int PF = 4, RING = PF + 1;
+    float av[RING], bv[RING];
+    auto read_step = [&](int s) {
+      const int cp = s >> 3, x = s & 7;
+      av[s % RING] = A[(2 * cp * 16 + x) * MB];
+      bv[s % RING] = B[(2 * cp * 16 + x) * TB];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) read_step(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + PF < NSTEP) read_step(s + PF);
+      acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s & 7], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+  auto chunk_barrier = [&]() {                          // own DMAs landed, own V writes done, everybody finished with the old stages
+    __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+  };
+
+  unsigned long long t_acc0 = 0, t_acc1 = 0, t_acc2 = 0, t_acc3 = 0, t_acc4 = 0, t_acc5 = 0, t_last = 0;
+  auto stamp = [&](int slot) {
+    if constexpr (Cfg::DIAG == 7) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      const unsigned long long dcy = now - t_last;
+      t_last = now;
+      if (slot == 0) t_acc0 += dcy; else if (slot == 1) t_acc1 += dcy; else if (slot == 2) t_acc2 += dcy;
+      else if (slot == 3) t_acc3 += dcy; else if (slot == 4) t_acc4 += dcy; else if (slot == 5) t_acc5 += dcy;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // prologue: filters of chunk 0, raw tiles of chunks 0 and 1 (every thread its own pieces), then V_0
+  if (DMA_MODE != 1 || grp == 1) {
+    dma_chunk(0, 0);
+    dma_chunk(nChunks, 1);
+  }
+  chunk_barrier();
+  transform(0);
+  chunk_barrier();
+  for (int k = 0; k < nChunks; ++k) {
+    // free since the barrier that ended chunk k-1: filter stage (k+1)&1 (held chunk k-1), raw stage k&1 (held chunk k,
+    // transformed during chunk k-1) and V stage (k+1)&1 (read by the MFMAs of chunk k-1)
+    const bool more = k + 1 < nChunks;
+    stamp(0);
+    if (grp == 0 && !Cfg::SYM) {
+      if (Cfg::PRIO) __builtin_amdgcn_s_setprio(3);
+      // group 0 issues its pieces of BOTH halves' worth?  No: each thread owns NU4 + NRAW pieces of the chunk; group 0's
+      // threads issue theirs now, group 1's threads theirs after the MFMAs -- half of the chunk's bytes each.
+      if (DMA_MODE == 0) dma_chunk(k + 1, k + 2);
+      stamp(1);
+      if (more) transform((k + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (Cfg::PRIO) __builtin_amdgcn_s_setprio(0);
+      stamp(2);
+      mfma_chunk(k);
+      stamp(3);
+      if (DMA_MODE == 2) { __builtin_amdgcn_sched_barrier(0); dma_chunk(k + 1, k + 2); }
+    } else {
+      mfma_chunk(k);
+      __builtin_amdgcn_sched_barrier(0);
+      if (Cfg::PRIO) __builtin_amdgcn_s_setprio(3);
+      stamp(1);
+      dma_chunk(k + 1, k + 2);
+      stamp(2);
+      if (more) transform((k + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (Cfg::PRIO) __builtin_amdgcn_s_setprio(0);
+      stamp(3);
+    }
+    if constexpr (Cfg::DIAG == 7) {
+      __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+      __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+      stamp(4);
+      __builtin_amdgcn_s_barrier();
+      stamp(5);
+    } else {
+      chunk_barrier();
+    }
+  }
+  if constexpr (Cfg::DIAG == 7) {
+    float keep = 0.0f;                                     // the accumulators must stay live or the MFMAs are dead code
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep += acc[x][r];
+    if (blockIdx.x == gridDim.x / 2) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dst) + wave * 8;
+      if (lane == 0) { o[0] = t_acc0; o[1] = t_acc1; o[2] = t_acc2; o[3] = t_acc3; o[4] = t_acc4; o[5] = t_acc5; o[6] = (unsigned long long)nChunks; }
+      if (keep == 1234.5678f) o[7] = 1;
+    }
+    return;
+  }
+
+  // ---- inverse transform: rows of A^T M (this group's two xi rows), columns, then the halves meet through LDS
+  float pv[16][2][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float tt[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = acc[j][r], hi = acc[4 + j][r];    // M rows 2*grp and 2*grp + 1
+      tt[0][j] = grp ? lo : lo + hi;                     // A^T row 0 = [1 1 1 0]
+      tt[1][j] = grp ? -lo - hi : hi;                    // A^T row 1 = [0 1 -1 -1]
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      pv[r][y][0] = tt[y][0] + tt[y][1] + tt[y][2];
+      pv[r][y][1] = tt[y][1] - tt[y][2] - tt[y][3];
+    }
+  }
+  float* xch = lds;                                      // all stages are free after the last chunk barrier
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) xch[(wave * 32 + r * 2 + x) * 64 + lane] = grp ? pv[r][0][x] : pv[r][1][x];
+  __syncthreads();
+  const bool has_affine = a.scale != nullptr;
+  const int t = wn * 32 + bl;
+  const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
+  const int oh = h0 + 2 * tr + grp, ow = w0 + 2 * tc;    // group g finishes output row g of the tile
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    wf2 v;
+    v[0] = (grp ? pv[r][1][0] : pv[r][0][0]) + xch[((wave ^ 4) * 32 + r * 2 + 0) * 64 + lane];
+    v[1] = (grp ? pv[r][1][1] : pv[r][0][1]) + xch[((wave ^ 4) * 32 + r * 2 + 1) * 64 + lane];
+    float mu = 0.0f, sc = 1.0f, sh = 0.0f;
+    if (has_affine) { mu = a.mean ? a.mean[co] : 0.0f; sc = a.scale[co]; sh = a.shift[co]; }
+    const size_t o = ((size_t)n * Cout + co) * HW + (size_t)oh * W + ow;
+    if (a.addend) { const wf2 ad = *reinterpret_cast<const wf2*>(a.addend + o); v[0] += ad[0]; v[1] += ad[1]; }
+    if (has_affine) { v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh; }
+    if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
+    *reinterpret_cast<wf2*>(a.dst + o) = v;
+  }
+}
+
+}  // namespace tnv3

@@ -603,6 +603,21 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_split_mfma_kernel(const 
   };
 
   const int nChunks = (Cin + CC - 1) / CC;
+  // DIAG 7 (libtnv3_diag.so): every wave accumulates, in SGPRs only (no register pressure on the vector side), the s_memtime
+  // cycles it spends in each phase of the chunk loop; at the end the wave of the mid-grid workgroup writes its six totals to
+  // dst (uint64 [wave][8]: 6 phase totals, chunk count, 0).  The output is garbage by design.
+  unsigned long long t_acc0 = 0, t_acc1 = 0, t_acc2 = 0, t_acc3 = 0, t_acc4 = 0, t_acc5 = 0, t_last = 0;
+  auto stamp = [&](int slot) {
+    if constexpr (Cfg::DIAG == 7) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      const unsigned long long d = now - t_last;
+      t_last = now;
+      if (slot == 0) t_acc0 += d; else if (slot == 1) t_acc1 += d; else if (slot == 2) t_acc2 += d;
+      else if (slot == 3) t_acc3 += d; else if (slot == 4) t_acc4 += d; else if (slot == 5) t_acc5 += d;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   if (grp == 0) {
     dma_u(0);
     dma_raw(0);
@@ -616,18 +631,43 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_split_mfma_kernel(const 
     // transformed during chunk k-1)
     constexpr bool kDma = Cfg::DIAG < 1 || Cfg::DIAG > 3, kTransform = Cfg::DIAG < 2 || Cfg::DIAG > 4;
     const bool more = k + 1 < nChunks && kTransform;
+    stamp(0);                                              // slot 0: loop overhead since the barrier release
     if (grp == 0) {
       if (k + 1 < nChunks && kDma) dma_u(k + 1);
       if (k + 2 < nChunks && kDma) dma_raw(k + 2);
+      stamp(1);                                            // grp 0: DMA issue
       if (more) transform((k + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(2);                                            // grp 0: patch transform
       mfma_chunk(k);
+      stamp(3);                                            // grp 0: MFMAs
     } else {
       mfma_chunk(k);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(1);                                            // grp 1: MFMAs
       if (more) transform((k + 1) & 1);
+      stamp(2);                                            // grp 1: patch transform
     }
-    if (Cfg::DIAG != 3) chunk_barrier();
+    if (Cfg::DIAG == 7) {
+      __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+      __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+      stamp(4);                                            // own DMAs landed, own LDS writes done
+      __builtin_amdgcn_s_barrier();
+      stamp(5);                                            // waiting for the other waves
+    } else if (Cfg::DIAG != 3) chunk_barrier();
+  }
+  if constexpr (Cfg::DIAG == 7) {
+    float keep = 0.0f;                                     // the accumulators must stay live or the MFMAs are dead code
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep += acc[x][r];
+    if (blockIdx.x == gridDim.x / 2) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dst) + wave * 8;
+      if (lane == 0) { o[0] = t_acc0; o[1] = t_acc1; o[2] = t_acc2; o[3] = t_acc3; o[4] = t_acc4; o[5] = t_acc5; o[6] = (unsigned long long)nChunks; }
+      if (keep == 1234.5678f) o[7] = 1;
+    }
+    return;
   }
 
   // ---- inverse transform: rows of A^T M (this group's two xi rows), columns, then the halves meet through LDS
@@ -677,14 +717,25 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_split_mfma_kernel(const 
 // U[Cin_pad][xi = i*4+j][Cout] = (G g G^T)[i][j] from W[Cout][Cin][3][3]; rows ci >= Cin are zero
 // The filter of logical (co, ci) starts at w + co * s_co + ci * s_ci; flip reads its taps back to front (the data
 // gradient's filter w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw] is s_co = 9, s_ci = Cin_w * 9, flip = 1 on the same tensor).
+// layout 0: U[ci][xi][Cout];  layout 1 ("quad", conv3x3_wino3_mfma.h): U[ci / 2][xi / 4][ci % 2][Cout][xi % 4] (CinPad even)
 inline __global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad, long s_co,
-                                         long s_ci, int flip) {
+                                         long s_ci, int flip, int layout) {
   const long body = (long)CinPad * 16 * Cout, total = body + kPackZeroTail;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     if (e >= body) { u[e] = 0.0f; continue; }
-    const int co = (int)(e % Cout);
-    const long t = e / Cout;
-    const int xi = (int)(t & 15), ci = (int)(t >> 4);
+    int co, xi, ci;
+    if (layout == 1) {
+      const int x = (int)(e & 3);
+      co = (int)((e >> 2) % Cout);
+      const long t = (e >> 2) / Cout;                     // ((pair * 4 + row) * 2 + parity)
+      xi = (int)((t >> 1) & 3) * 4 + x;
+      ci = (int)(t >> 3) * 2 + (int)(t & 1);
+    } else {
+      co = (int)(e % Cout);
+      const long t = e / Cout;
+      xi = (int)(t & 15);
+      ci = (int)(t >> 4);
+    }
     float v = 0.0f;
     if (ci < Cin) {
       const float* g = w + (long)co * s_co + (long)ci * s_ci;

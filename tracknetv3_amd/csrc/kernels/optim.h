@@ -83,7 +83,7 @@ __device__ __forceinline__ void adam_element(float& par, float& grad, float& mm,
   if (a.weight_decay != 0.0f) grad = fmaf(a.weight_decay, par, grad);  // grad.add(param, alpha=weight_decay)
   mm = fmaf(a.one_minus_beta1, grad - mm, mm);                         // exp_avg.lerp_(grad, 1 - beta1): self + w * (end - self)
   vv = vv * a.beta2;                                                   // exp_avg_sq.mul_(beta2)
-  vv = fmaf(a.one_minus_beta2 * grad, grad, vv);                       // .addcmul_(grad, grad, value): self + value * t1 * t2
+  vv = fmaf(a.one_minus_beta2, grad * grad, vv);                       // .addcmul_(grad, grad, value): self + value * (t1 * t2)
   float denom = sqrtf(vv);                                             // exp_avg_sq.sqrt()
   denom = denom / a.bc2_sqrt;                                          // .div_(bias_correction2_sqrt)
   denom = denom + a.eps;                                               // .add_(eps)
@@ -180,18 +180,20 @@ struct PhiloxStream {                      // a private sequence of uniforms for
   Philox px;
   __device__ __forceinline__ uint32_t next_u32() {
     if (have == 0) { px.run(seed, step, ((uint64_t)lane << 32) | block); ++block; have = 4; }
-    return px.c[4 - have--];
+    const uint32_t r = have == 4 ? px.c[0] : (have == 3 ? px.c[1] : (have == 2 ? px.c[2] : px.c[3]));   // no dynamic indexing: stays in registers
+    --have;
+    return r;
   }
   __device__ __forceinline__ float uniform() { return ((float)(next_u32() >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
   __device__ __forceinline__ float normal() {                                                                     // Box-Muller
     const float u1 = uniform(), u2 = uniform();
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);     // hardware log2 / cos: plenty for a sampler, no scratch
   }
 };
 
 // Gamma(shape a, scale 1): Marsaglia & Tsang (2000) for a >= 1; for a < 1, Gamma(a) = Gamma(a + 1) * U^(1/a)
 __device__ __forceinline__ float philox_gamma(PhiloxStream& s, float a) {
-  const float boost = a < 1.0f ? powf(s.uniform(), 1.0f / a) : 1.0f;
+  const float boost = a < 1.0f ? __expf(__logf(s.uniform()) / a) : 1.0f;
   if (a < 1.0f) a += 1.0f;
   const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
   for (int it = 0; it < 64; ++it) {
@@ -200,7 +202,7 @@ __device__ __forceinline__ float philox_gamma(PhiloxStream& s, float a) {
     if (v <= 0.0f) continue;
     v = v * v * v;
     const float u = s.uniform();
-    if (u < 1.0f - 0.0331f * x * x * x * x || logf(u) < 0.5f * x * x + d * (1.0f - v + logf(v))) return boost * d * v;
+    if (u < 1.0f - 0.0331f * x * x * x * x || __logf(u) < 0.5f * x * x + d * (1.0f - v + __logf(v))) return boost * d * v;
   }
   return boost * d;                                             // (never reached in practice: acceptance > 95 % per trial)
 }

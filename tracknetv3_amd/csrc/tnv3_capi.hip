@@ -11,6 +11,9 @@
 #include "../../include/tracknetv3_hip_diag.h"
 #endif
 #include "tnv3_impl.h"
+#ifdef TNV3_DIAG
+#include "kernels/coissue_probe.h"
+#endif
 
 namespace {
 // CU count of a device (a partitioned GPU exposes fewer CUs), queried once per device.

@@ -8,6 +8,7 @@
 #include "kernels/conv3x3_mfma.h"
 #include "kernels/conv_up2x_mfma.h"
 #include "kernels/conv3x3_wino_mfma.h"
+#include "kernels/conv3x3_wino3_mfma.h"
 #include "kernels/conv1d_k3.h"
 #include "kernels/conv1d_mfma.h"
 #include "kernels/pointwise.h"
@@ -363,8 +364,13 @@ int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const fl
 using WinoA = WinoCfg<2, 2, 8>;              // 64 channels x 64 tiles (4 x 64 pixels), 256 threads, 8-channel chunks
 using WinoSplit = WinoSplitCfg<8>;          // same tile, 512 threads: two wave groups split the 16 transform rows (2 waves / SIMD)
 using WinoIl = WinoIlCfg<2, 2, 6>;           // same tile, 6-channel chunks, patch transform interleaved with the MFMAs
+using WinoV3 = WinoV3Cfg<8>;                // same tile and operands as WinoSplit; balanced DMA issue, buffer-descriptor DMA, paired transform
+using WinoV4 = WinoV3Cfg<8, 0, 0, 0, 1>;    // + quad operand layouts (filter pack layout 1): 0.5 instead of 2 LDS reads per MFMA
+// filter pack layout a kernel variant expects (tnv3_conv3x3_wino_layout)
+inline int conv3x3_wino_layout(int variant) { return (variant == 4 || variant == 47 || variant == 44) ? 1 : 0; }
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
-constexpr int kWinoDefaultVariant = 2;       // per-call `variant`: 2 WinoSplit (default, fastest), 0 WinoA (one wave / SIMD), 1 WinoIl; -1 = default
+constexpr int kWinoDefaultVariant = 3;       // per-call `variant`: 3 WinoV3 (default: measured 6-12 % faster than 2), 2 WinoSplit, 4 WinoV4 (quad
+                                             // layouts), 0 WinoA (one wave / SIMD), 1 WinoIl; -1 = default
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
   return (size_t)round_up(cin, kWinoCinPad) * 16 * cout + kPackZeroTail;
@@ -376,19 +382,20 @@ inline bool conv3x3_wino_supported(int cin, int cout, int h, int w) {
 // Packs input channels c_from .. c_from + c_count - 1 of the nn.Conv2d weight w[cout_w][cin_w][3][3]: as the forward filter
 // (Cout = cout_w, Cin = c_count) or, transpose_flip, as the data gradient's filter (Cout = c_count, Cin = cout_w).
 template <class Launcher>
-int conv3x3_wino_pack_view_impl(Launcher& L, const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip) {
-  if (!w || !u || cout_w <= 0 || cin_w <= 0 || c_from < 0 || c_count <= 0 || c_from + c_count > cin_w)
+int conv3x3_wino_pack_view_impl(Launcher& L, const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip,
+                                int layout = 0) {
+  if (!w || !u || cout_w <= 0 || cin_w <= 0 || c_from < 0 || c_count <= 0 || c_from + c_count > cin_w || layout < 0 || layout > 1)
     TNV3_FAIL(-1, "conv3x3_wino_pack: bad argument");
   const int cout = transpose_flip ? c_count : cout_w, cin = transpose_flip ? cout_w : c_count;
   const long s_w_co = (long)cin_w * 9, s_w_ci = 9;
   const int cpad = round_up(cin, kWinoCinPad);
   const long total = (long)cpad * 16 * cout + kPackZeroTail;
   return L.launch(conv3x3_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w + (size_t)c_from * 9, u,
-                  cout, cin, cpad, transpose_flip ? s_w_ci : s_w_co, transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
+                  cout, cin, cpad, transpose_flip ? s_w_ci : s_w_co, transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0, layout);
 }
 template <class Launcher>
-int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin) {
-  return conv3x3_wino_pack_view_impl(L, w, u, cout, cin, 0, cin, 0);
+int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin, int layout = 0) {
+  return conv3x3_wino_pack_view_impl(L, w, u, cout, cin, 0, cin, 0, layout);
 }
 
 template <class Launcher>
@@ -414,10 +421,35 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     case 24: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 4>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
     case 25: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 5>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
     case 26: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 6>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
+    case 27: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplitCfg<8, 7>>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
+    default: break;
+  }
+#endif
+  if (variant == 3 || variant == 4 || variant >= 30) {
+    if ((long)cin * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variants 3, 4): one sample of the input must stay below 2 GiB");
+    if ((long)cout * 16 * 8 * 16 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variants 3, 4): Cout too large");
+  }
+#ifdef TNV3_DIAG
+  // timeline twins (phase totals instead of results) and the measured-and-rejected schedules of kernel 3 (results correct):
+  // 37 / 47: timelines of variants 3 / 4;  41: group 1 issues all DMAs after its MFMAs;  51: both groups after their MFMAs;
+  // 61 / 71: variant 3 / 41 with raised priority in the DMA / transform phases
+  const int grid3 = conv_grid_blocks(cout / WinoV3::MB, (int)npt);
+  switch (variant) {
+    case 37: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 7>>, grid3, WinoV3::NT, a);
+    case 47: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 7, 0, 0, 1>>, grid3, WinoV3::NT, a);
+    case 41: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 1>>, grid3, WinoV3::NT, a);
+    case 33: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 0, 0, 0, 1>>, grid3, WinoV3::NT, a);     // variant 3, lockstep groups
+    case 44: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 0, 0, 1, 1>>, grid3, WinoV3::NT, a);     // variant 4, lockstep groups
+    case 38: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 7, 0, 0, 0, 1>>, grid3, WinoV3::NT, a);     // timeline of 33
+    case 51: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 2>>, grid3, WinoV3::NT, a);
+    case 61: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 0, 1>>, grid3, WinoV3::NT, a);
+    case 71: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 1, 1>>, grid3, WinoV3::NT, a);
     default: break;
   }
 #endif
   switch (variant) {
+    case 4: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV4>, conv_grid_blocks(cout / WinoV4::MB, (int)npt), WinoV4::NT, a);
+    case 3: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3>, conv_grid_blocks(cout / WinoV3::MB, (int)npt), WinoV3::NT, a);
     case 2: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplit>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
     case 1: return L.launch(conv3x3_wino_il_mfma_kernel<WinoIl>, conv_grid_blocks(cout / WinoIl::MB, (int)npt), WinoIl::NT, a);
     case 0: return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);

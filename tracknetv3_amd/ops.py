@@ -57,11 +57,21 @@ def wino_supported(cin, cout, h, w):
     return bool(_lib.load().tnv3_conv3x3_wino_supported(int(cin), int(cout), int(h), int(w)))
 
 
-def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False):
+def wino_layout(variant=None):
+    """Filter pack layout the Winograd kernel `variant` reads (None: tuning.WINO_VARIANT)."""
+    if variant is None:
+        from . import tuning
+        variant = tuning.WINO_VARIANT
+    return int(_lib.load().tnv3_conv3x3_wino_layout(int(variant)))
+
+
+def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False, variant=None):
     """nn.Conv2d weight (Cout, Cin, 3, 3) -> Winograd-domain filters G w G^T for tnv3_conv3x3_wino_forward, of its input
     channels c_from .. c_from + c_count - 1 (default: all).  transpose_flip: the data gradient's filter
-    w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] instead (the packed panel then maps Cout -> c_count channels)."""
+    w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] instead (the packed panel then maps Cout -> c_count channels).
+    variant: the kernel the panel is for (its layout follows; None: tuning.WINO_VARIANT)."""
     lib = _lib.load()
+    layout = wino_layout(variant)
     _f32(weight)
     weight = weight.contiguous()
     _lib.dev_check(weight)
@@ -70,7 +80,7 @@ def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False):
     cout, cin = (c_count, cout_w) if transpose_flip else (cout_w, c_count)
     u = torch.empty(lib.tnv3_conv3x3_wino_packed_floats(cin, cout), dtype=torch.float32, device=weight.device)
     _lib.check(lib.tnv3_conv3x3_wino_pack_view(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count,
-                                               int(bool(transpose_flip)), _lib.stream_ptr(weight)))
+                                               int(bool(transpose_flip)), layout, _lib.stream_ptr(weight)))
     return u
 
 
