@@ -168,6 +168,17 @@ int tnv3_maxpool2x2(const float* x, float* y, long nc, int h, int w, tnv3_stream
 int tnv3_conv1d_k3_forward(const float* src0, const float* src1, const float* w, const float* b, float* dst, int n,
                            int c0, int c1, int cout, int l, int src_nlc, int dst_nlc, int act, tnv3_stream_t stream);
 
+/* InpaintNet.forward (model.py:113-129) as ONE persistent kernel: a workgroup carries a sequence through all nine layers with
+ * every activation in LDS; the dense layers run on v_mfma_f32_16x16x4_f32 with filters streamed from L2 into registers.
+ *   tnv3_inpaintnet_packed_floats : size of the packed parameter buffer (filters in lane order + biases)
+ *   tnv3_inpaintnet_pack          : weights9 / biases9 = HOST arrays of the nine nn.Conv1d weight / bias DEVICE pointers in network
+ *                                   order (down_1, down_2, down_3, buttleneck.conv_1, buttleneck.conv_2, up_1, up_2, up_3, predictor)
+ *   tnv3_inpaintnet_fused_forward : x [n][16][2], m [n][16][1] -> out [n][16][2]; l must be 16; packed 16-byte aligned.
+ * Same function as the nine tnv3_conv1d_k3_forward launches (fp32 rounding order differs: K is walked tap-major). */
+size_t tnv3_inpaintnet_packed_floats(void);
+int tnv3_inpaintnet_pack(const float* const* weights9, const float* const* biases9, float* packed, tnv3_stream_t stream);
+int tnv3_inpaintnet_fused_forward(const float* x, const float* m, const float* packed, float* out, int n, int l, tnv3_stream_t stream);
+
 /* ---- heat-map post-process (predict.py:14-69,163-209; test.py:25-79) ------------------------------------- */
 
 /* Temporal ensemble in closed form (predict.py:163-209 heat maps, 243-301 coordinates).

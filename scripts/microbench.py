@@ -39,10 +39,14 @@ def main():
         flops = blocks * 4 * iters * 8 * (2.0 * 32 * 32 * 2)
         out[f"mfma_f32_probe_{label}"] = {"ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 1)}
     net = get_model("InpaintNet").to(dev).eval()
-    for n in (32, 4096, 65536):
+    from tracknetv3_amd import inpaint_ops
+    for n in (1, 32, 256, 512, 2048, 8192, 65536):
         x, m = torch.rand(n, 16, 2, device=dev), (torch.rand(n, 16, 1, device=dev) < 0.3).float()
-        ms = timeit(lambda: net(x, m), 5 if n > 4096 else 20, dev)
-        out[f"inpaintnet_fwd_n{n}"] = {"ms": round(ms, 4), "seq_per_s": round(n / ms * 1e3, 1), "tflops": round(16.63e6 * n / ms / 1e9, 2)}
+        for tag, flag in (("fused", "1"), ("layers", "0")):
+            inpaint_ops.FUSED = flag
+            ms = timeit(lambda: net(x, m), 5 if n > 4096 else 20, dev)
+            out[f"inpaintnet_fwd_n{n}_{tag}"] = {"ms": round(ms, 4), "seq_per_s": round(n / ms * 1e3, 1), "tflops": round(16.63e6 * n / ms / 1e9, 2)}
+    inpaint_ops.FUSED = "auto"
     x, m = torch.rand(32, 16, 2, device=dev), (torch.rand(32, 16, 1, device=dev) < 0.3).float()
     g = net.graphed(32)
     g.x.copy_(x); g.m.copy_(m)

@@ -309,3 +309,31 @@ def test_conv3x3_wino_balanced_kernel_is_bit_identical_to_the_xi_split_kernel(em
     assert ops.wino_layout(3) == 0 and ops.wino_layout(4) == 1
     assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=3))
     assert torch.equal(want, ops.conv3x3_wino(x, ops.pack_wino_weights(wt, variant=4), cout, variant=4))      # quad operand layouts
+
+
+def test_inpaintnet_fused_kernel_emulated_vs_layer_kernels_and_oracle(emu, monkeypatch):
+    """The single persistent kernel (inpaint_fused.h) against the nine-launch path and the oracle: same function, K walked in a
+    different order (tap-major), so equal to fp32 rounding."""
+    from tracknetv3_amd import inpaint_ops
+    from tracknetv3_amd.model import InpaintNet
+    sd = nets.synth_state(nets.inpaintnet_state_shapes(), 78)
+    net = InpaintNet()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x, m = nets.synth_input((3, 16, 2), 21), (nets.synth_input((3, 16, 1), 22) < 0.4).float()
+    monkeypatch.setattr(inpaint_ops, "FUSED", "1")
+    fused = net(x, m)
+    monkeypatch.setattr(inpaint_ops, "FUSED", "0")
+    layered = net(x, m)
+    with torch.no_grad():
+        ref = nets.inpaintnet_forward(sd, x, m)
+    assert (fused - ref).abs().max().item() <= 2e-6 and (fused - layered).abs().max().item() <= 2e-6
+    # the packed parameters follow in-place updates (version counters)
+    monkeypatch.setattr(inpaint_ops, "FUSED", "1")
+    with torch.no_grad():
+        net.up_1.conv.weight.mul_(1.5)
+        net.predictor.bias.add_(0.1)
+    sd2 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref2 = nets.inpaintnet_forward(sd2, x, m)
+    assert (net(x, m) - ref2).abs().max().item() <= 2e-6

@@ -269,3 +269,23 @@ def test_evaluate_vs_reference_golden(gpu_device):
     from tracknetv3_amd import postprocess as pp
     g = np.load(os.path.join(GOLDEN, "evaluate.npz"))
     check_evaluate_against_golden(pp.evaluate, g, to_dev=lambda a: a.to(gpu_device))
+
+
+@pytest.mark.parametrize("n", [1, 32, 257, 1100])
+def test_inpaintnet_fused_kernel_vs_layer_kernels_and_oracle(gpu_device, n, monkeypatch):
+    """InpaintNet.forward as ONE persistent kernel (activations in LDS, filters streamed into registers) against the nine-launch
+    path and the oracle; n = 1100 exceeds two workgroups per CU, i.e. the grid-stride loop runs."""
+    from tracknetv3_amd import inpaint_ops
+    from tracknetv3_amd.model import InpaintNet
+    sd = nets.synth_state(nets.inpaintnet_state_shapes(), 78)
+    net = InpaintNet()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(gpu_device).eval()
+    x, m = nets.synth_input((n, 16, 2), 21), (nets.synth_input((n, 16, 1), 22) < 0.4).float()
+    monkeypatch.setattr(inpaint_ops, "FUSED", "1")
+    fused = net(x.to(gpu_device), m.to(gpu_device)).cpu()
+    monkeypatch.setattr(inpaint_ops, "FUSED", "0")
+    layered = net(x.to(gpu_device), m.to(gpu_device)).cpu()
+    with torch.no_grad():
+        ref = nets.inpaintnet_forward(sd, x, m)
+    assert (fused - ref).abs().max().item() <= 2e-6 and (fused - layered).abs().max().item() <= 2e-6

@@ -59,6 +59,9 @@ def _declare(lib):
     sig("tnv3_head1x1_sigmoid", i, p, p, p, p, i, i, i, i, i, p)
     sig("tnv3_maxpool2x2", i, p, p, lg, i, i, p)
     sig("tnv3_conv1d_k3_forward", i, p, p, p, p, p, i, i, i, i, i, i, i, i, p)
+    sig("tnv3_inpaintnet_packed_floats", sz)
+    sig("tnv3_inpaintnet_pack", i, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), p, p)
+    sig("tnv3_inpaintnet_fused_forward", i, p, p, p, p, i, i, p)
     sig("tnv3_ensemble_frames", i, p, i, lg, i, i, p, lg, i, lg, p, p)
     sig("tnv3_peakfind_workspace_bytes", sz, i, i, i)
     sig("tnv3_heatmap_peakfind", i, p, f, i, p, p, sz, i, i, i, p)
@@ -94,7 +97,8 @@ def _declare(lib):
 
 EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "tnv3_conv3x3_config_info",
            "tnv3_conv3x3_packed_floats", "tnv3_pack_conv3x3_weights", "tnv3_bn_eval_scale", "tnv3_conv3x3_forward",
-           "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2", "tnv3_conv1d_k3_forward", "tnv3_ensemble_frames",
+           "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2", "tnv3_conv1d_k3_forward", "tnv3_inpaintnet_packed_floats", "tnv3_inpaintnet_pack", "tnv3_inpaintnet_fused_forward",
+           "tnv3_ensemble_frames",
            "tnv3_peakfind_workspace_bytes", "tnv3_heatmap_peakfind", "tnv3_bn_workspace_bytes", "tnv3_bn_train_forward",
            "tnv3_bn_relu_backward", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",
            "tnv3_wbce_workspace_bytes", "tnv3_wbce_forward", "tnv3_wbce_backward", "tnv3_head_backward_workspace_bytes",

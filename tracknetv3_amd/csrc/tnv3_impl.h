@@ -11,6 +11,7 @@
 #include "kernels/conv3x3_wino3_mfma.h"
 #include "kernels/conv1d_k3.h"
 #include "kernels/conv1d_mfma.h"
+#include "kernels/inpaint_fused.h"
 #include "kernels/pointwise.h"
 #include "kernels/postproc.h"
 #include "kernels/preproc.h"
@@ -253,6 +254,31 @@ int conv1d_k3_impl(Launcher& L, const float* src0, const float* src1, const floa
   const long gx = (n + S - 1) / S;
   if (gx > 0x7fffffffl) TNV3_FAIL(-1, "conv1d_k3: batch too large");
   return L.launch3(conv1d_k3_kernel<S, COB, CK, LT>, (int)gx, (cout + COB - 1) / COB, (l + LT - 1) / LT, S * COB, a);
+}
+
+// ---- InpaintNet as one persistent kernel (kernels/inpaint_fused.h)
+inline size_t inpaintnet_packed_floats() { return (size_t)kIfPackedFloats; }
+
+template <class Launcher>
+int inpaintnet_pack_impl(Launcher& L, const float* const* w9, const float* const* b9, float* packed) {
+  if (!w9 || !b9 || !packed) TNV3_FAIL(-1, "inpaintnet_pack: bad argument");
+  InpaintPackArgs a;
+  for (int i = 0; i < 9; ++i) {
+    if (!w9[i] || !b9[i]) TNV3_FAIL(-1, "inpaintnet_pack: layer %d has a NULL tensor", i);
+    a.w[i] = w9[i];
+    a.b[i] = b9[i];
+  }
+  a.packed = packed;
+  return L.launch(inpaint_pack_kernel, (kIfPackedFloats + 255) / 256, 256, a);
+}
+
+template <class Launcher>
+int inpaintnet_fused_forward_impl(Launcher& L, const float* x, const float* m, const float* packed, float* out, int n, int l) {
+  if (!x || !m || !packed || !out || n <= 0) TNV3_FAIL(-1, "inpaintnet_fused_forward: bad argument");
+  if (l != kIfL) TNV3_FAIL(-1, "inpaintnet_fused_forward: built for sequences of %d positions (got %d)", kIfL, l);
+  if (((uintptr_t)packed) & 15) TNV3_FAIL(-1, "inpaintnet_fused_forward: the packed parameters must be 16-byte aligned");
+  const int cap = 2 * num_cus();                         // two resident workgroups per CU (59 KB of LDS each); grid-stride beyond
+  return L.launch(inpaintnet_fused_kernel, n < cap ? n : cap, 256, x, m, packed, out, n);
 }
 
 template <class Launcher>

@@ -243,6 +243,36 @@ def conv1d_k3(src0, weight, bias, src1=None, src_nlc=False, dst_nlc=False, act=A
     return out
 
 
+def inpaintnet_pack(weights, biases):
+    """The nine (weight, bias) pairs of an InpaintNet in network order -> the packed parameter buffer of the fused kernel."""
+    lib = _lib.load()
+    if len(weights) != 9 or len(biases) != 9:
+        raise _lib.Tnv3Error("inpaintnet_pack: expected nine layers")
+    ws = [w.contiguous() for w in weights]
+    bs = [b.contiguous() for b in biases]
+    _f32(*ws, *bs)
+    _lib.dev_check(*ws, *bs)
+    shapes = [(32, 3, 3), (64, 32, 3), (128, 64, 3), (256, 128, 3), (256, 256, 3), (128, 384, 3), (64, 192, 3), (32, 96, 3), (2, 32, 3)]
+    for w, b, sh in zip(ws, bs, shapes):
+        if tuple(w.shape) != sh or b.numel() != sh[0]:
+            raise _lib.Tnv3Error(f"inpaintnet_pack: expected a weight of shape {sh}, got {tuple(w.shape)}")
+    packed = torch.empty(lib.tnv3_inpaintnet_packed_floats(), dtype=torch.float32, device=ws[0].device)
+    _lib.check(lib.tnv3_inpaintnet_pack(_ptr_array(ws), _ptr_array(bs), _lib.ptr(packed), _lib.stream_ptr(packed)))
+    return packed
+
+
+def inpaintnet_fused(x, m, packed):
+    """InpaintNet.forward as one kernel (tnv3_inpaintnet_fused_forward): x (N, 16, 2), m (N, 16, 1) -> (N, 16, 2)."""
+    lib = _lib.load()
+    _f32(x, m, packed)
+    _lib.dev_check(x, m, packed)
+    n, l = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty((n, l, 2), dtype=torch.float32, device=x.device)
+    if n:
+        _lib.check(lib.tnv3_inpaintnet_fused_forward(_lib.ptr(x), _lib.ptr(m), _lib.ptr(packed), _lib.ptr(out), n, l, _lib.stream_ptr(x)))
+    return out
+
+
 def ensemble_frames(win, s_base, weight, t0, n_frames, num_sample):
     """Temporal ensemble of global frames t0..t0+n_frames-1 from resident windows win[i] = window s_base+i.
     win: (n_local, L, *tail) -> out: (n_frames, *tail).  See tnv3_ensemble_frames."""
@@ -627,7 +657,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
 _TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "pack_up2x_weights", "conv_up2x",
-               "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "ensemble_frames",
+               "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward",
                "maxpool2x2_backward_add", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad"]
