@@ -254,6 +254,17 @@ int tnv3_head_backward(const float* dp, const float* p, const float* a, const fl
                        float* db, void* workspace, size_t workspace_bytes, int n, int l, int hw,
                        tnv3_stream_t stream);
 
+/* sigmoid + WBCELoss FUSED INTO THE HEAD (model.py:71-72 followed by utils/metric.py:15-20, train.py:92-93), both directions:
+ *   forward : p = sigmoid(conv1x1(x) + b) is written once and the loss partial sums are taken from the registers that hold it
+ *             (loss[0] with reduce != 0, else loss[n] per-sample means); y [n][l][hw] are the targets;  l <= 8, hw % 4 == 0.
+ *   backward: dL/dp is formed on the fly from (p, y) and the loss node's upstream gradient (1 value, or n values when reduce == 0)
+ *             inside the head's backward -- no dP tensor is written or read; outputs as tnv3_head_backward (same workspace). */
+size_t tnv3_head_wbce_workspace_bytes(int n);
+int tnv3_head1x1_sigmoid_wbce(const float* x, const float* w, const float* b, const float* y, float* p, float* loss, void* workspace,
+                              size_t workspace_bytes, int n, int c, int l, int hw, int reduce, tnv3_stream_t stream);
+int tnv3_head_wbce_backward(const float* y, const float* p, const float* a, const float* w, const float* upstream, float* da, float* dw,
+                            float* db, void* workspace, size_t workspace_bytes, int n, int l, int hw, int reduce, tnv3_stream_t stream);
+
 /* MaxPool2d(2,2) backward fused with the skip-connection gradient add: dx = dskip + route(dpool). dskip may be NULL. */
 int tnv3_maxpool2x2_backward_add(const float* x, const float* dpool, const float* dskip, float* dx, long nc, int h,
                                  int w, tnv3_stream_t stream);

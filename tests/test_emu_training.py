@@ -294,3 +294,24 @@ def test_inpaintnet_train_step_emulated_vs_reference_golden(emu):
     assert rel_err(params["predictor.weight"].grad, torch.from_numpy(g["grad_pred_w"])) <= 2e-5
     assert rel_err(params["down_1.conv.weight"].grad, torch.from_numpy(g["grad_down1_w"])) <= 2e-4
     torch.nn.utils.clip_grad_norm_(net.parameters(), 1)          # train.py:165 works on the leaf parameters
+
+
+def test_head_sigmoid_wbce_fused_both_directions_emulated(emu):
+    """sigmoid + WBCELoss fused into the head: the one-pass forward equals head -> WBCELoss, and the backward without a dP tensor
+    equals wbce_backward -> head_backward (same element arithmetic)."""
+    from tracknetv3_amd import ops
+    n, L, h, w = 2, 3, 8, 40
+    a = T((n, 64, h, w), 41)
+    wt, b = T((L, 64, 1, 1), 42, -0.4, 0.4), T((L,), 43)
+    y = (T((n, L, h, w), 44) > 0.6).float() * T((n, L, h, w), 45, 0.2, 1.0)          # fractional targets, as after mixup
+    for reduce in (True, False):
+        p_ref = ops.head1x1_sigmoid(a, wt, b)
+        loss_ref = ops.wbce_forward(p_ref, y, reduce)
+        p, loss = ops.head1x1_sigmoid_wbce(a, wt, b, y, reduce)
+        assert torch.equal(p, p_ref)
+        assert torch.allclose(loss, loss_ref, rtol=1e-6, atol=1e-9)
+        up = T((1 if reduce else n,), 46, 0.5, 1.5)
+        dp = ops.wbce_backward(p_ref, y, up, reduce)
+        da_ref, dw_ref, db_ref = ops.head_backward(dp, p_ref, a, wt)
+        da, dw, db = ops.head_wbce_backward(y, p, a, wt, up, reduce)
+        assert rel_err(da, da_ref) <= 1e-6 and rel_err(dw, dw_ref) <= 1e-6 and rel_err(db, db_ref) <= 1e-6

@@ -441,3 +441,35 @@ def test_trainer_with_fused_adam_and_device_mixup_draws(gpu_device):
     assert torch.equal(e1, fresh.to(gpu_device).eval()(x))
     lam, perm = __import__("tracknetv3_amd.ops", fromlist=["ops"]).mixup_draw(10, 0.5, 13, 1, gpu_device)
     assert lam.is_cuda and float(lam.min()) >= 0.5 and sorted(perm.cpu().tolist()) == list(range(10))
+
+
+def test_fused_loss_node_equals_the_two_call_protocol(gpu_device):
+    """autograd_ops.tracknet_forward_loss (sigmoid + WBCE fused into the head, both directions) against the reference protocol
+    `y_pred = model(x); loss = WBCELoss(y_pred, y); loss.backward()` (train.py:92-95): same heat maps, loss, BN buffers, gradients."""
+    from tracknetv3_amd import autograd_ops
+    from tracknetv3_amd.utils.general import get_model
+    from tracknetv3_amd.utils.metric import WBCELoss
+    sd = nets.synth_state(nets.tracknet_state_shapes(27, 8), 21, calibrated=True)
+    x = nets.synth_input((2, 27, 64, 128), 5).to(gpu_device)
+    y = (nets.disc_heatmaps(2, 8, 64, 128, 6) * 0.8).to(gpu_device)                 # fractional targets, as after mixup
+    outs = []
+    for fused in (False, True):
+        m = get_model("TrackNet", 8, "concat")
+        m.load_state_dict(sd, strict=True)
+        m = m.to(gpu_device).train()
+        if fused:
+            loss, p = autograd_ops.tracknet_forward_loss(m, x, y)
+            assert not p.requires_grad
+        else:
+            p = m(x)
+            loss = WBCELoss(p, y)
+        loss.backward()
+        outs.append((loss.item(), p.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters()},
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+    (l0, p0, g0, b0), (l1, p1, g1, b1) = outs
+    assert abs(l0 - l1) <= 1e-7 and torch.equal(p0, p1)
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)
+    # dL/dz of the head may differ in its last bit between the two routes (the compiler contracts the fused expression
+    # differently); sixteen BatchNorm backward passes amplify that to a few 1e-6 of max|g|
+    worst = max(rel_err(g1[k].cpu(), g0[k].cpu()) for k in g0)
+    assert worst <= 2e-5, worst

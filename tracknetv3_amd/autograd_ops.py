@@ -76,176 +76,227 @@ def _cfg(blk, n, h, w):
     return tuning.conv_config(blk.conv.out_dim, blk.conv.in_dim, n, h, w)
 
 
+def _train_forward_body(net, x):
+    """conv -> BN(batch statistics) -> ReLU per Conv2DBlock up to the head's input; returns (saved records, head input, skips)."""
+    saved = []          # per block: dict(x0, x1, up, z, a, mean, invstd)
+    n = x.shape[0]
+
+    def block_fwd(blk, src0, src1=None, up=False):
+        h = src0.shape[2] * (2 if up else 1)
+        w = src0.shape[3] * (2 if up else 1)
+        if up and src1 is not None:
+            z = blk.conv_up_skip(src0, src1, int(n), relu=False, affine=False)
+        elif src1 is None and not up and tuning.use_winograd(blk.conv.in_dim, blk.conv.out_dim, int(h), int(w)):
+            z = ops.conv3x3_wino(src0, blk.packed_wino(), blk.conv.out_dim)      # raw conv output in Winograd form
+        else:
+            z = ops.conv3x3(src0, blk.packed_weight(), blk.conv.out_dim, src1=src1, up0=up, relu=False, cfg=_cfg(blk, n, h, w))
+        bn = blk.bn
+        a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                               bn.eps, bn.momentum)
+        bn.num_batches_tracked.add_(1)
+        blk._cache.pop("aff", None)       # running_var was rewritten through a raw pointer: the folded eval scale is stale
+        saved.append(dict(blk=blk, x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,
+                          bn_ver=(bn.weight._version, bn.bias._version)))
+        return a
+
+    def chain(blks, src0, src1=None, up=False):
+        y = block_fwd(blks[0], src0, src1, up)
+        for b in blks[1:]:
+            y = block_fwd(b, y)
+        return y
+
+    d1, d2, d3, bt, u1, u2, u3 = _blocks(net)
+    x1 = chain(d1, x)
+    x2 = chain(d2, ops.maxpool2x2(x1))
+    x3 = chain(d3, ops.maxpool2x2(x2))
+    y = chain(bt, ops.maxpool2x2(x3))
+    y = chain(u1, y, x3, True)
+    y = chain(u2, y, x2, True)
+    y = chain(u3, y, x1, True)
+    return saved, y, (x1, x2, x3)
+
+
+def _train_backward_body(ctx, dev, head_backward):
+    """Everything behind the loss: `head_backward()` -> (da, dW_head, db_head), then per block in reverse BN+ReLU backward,
+    data gradient, weight gradient (side stream).  Returns the tuple autograd expects after the non-tensor arguments."""
+    net, saved = ctx.net, ctx.saved
+    if saved is None:
+        raise RuntimeError("TrackNet backward ran twice over the same forward: the training node frees its activations at the "
+                           "end of backward (retain_graph=True is not supported); run the forward again")
+    hook = _grad_ready_hook
+    grads = {}
+    keep = []
+
+    def done(param, g):
+        if hook is not None:
+            r = hook(param, g)
+            if r is not None:
+                g = r
+        grads[id(param)] = g
+
+    side = wgrad_stream(dev)
+    main = torch.cuda.current_stream(dev) if side is not None else None
+    if dev.type == "cuda":
+        _BACKWARD_STREAMS[dev.index if dev.index is not None else 0] = \
+            [torch.cuda.current_stream(dev)] + ([side] if side is not None else [])
+    da, dw_head, db_head = head_backward()
+    done(net.predictor.weight, dw_head)
+    done(net.predictor.bias, db_head)
+
+    def block_bwd(rec, da, need_dx=True):
+        blk = rec["blk"]
+        # ReLU mask recomputed from z (bit-identical to a > 0): the passes read two activation tensors instead of three.
+        # That needs the forward's gamma / beta; if either was modified in place since, the mask comes from a itself.
+        same = rec["bn_ver"] == (blk.bn.weight._version, blk.bn.bias._version)
+        dz, dgamma, dbeta = ops.bn_relu_backward(da, None if same else rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"],
+                                                 rec["invstd"], beta=blk.bn.bias.detach())
+        done(blk.bn.weight, dgamma)
+        done(blk.bn.bias, dbeta)
+
+        def wgrad():
+            if rec["up"] and rec["x1"] is not None:       # decoder entry: upsampled channels at the low resolution
+                return ops.conv3x3_wgrad_up2x(rec["x0"], rec["x1"], dz)
+            if rec["x1"] is None and not rec["up"] and tuning.use_winograd_wgrad(
+                    int(rec["x0"].shape[1]), blk.conv.out_dim, int(dz.shape[2]), int(dz.shape[3])):
+                return ops.conv3x3_wgrad_wino(rec["x0"], dz)      # plain deep layer: Winograd-form weight gradient
+            return ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
+
+        if side is None:
+            dw = wgrad()
+            done(blk.conv.weight, dw)
+        else:
+            ready = torch.cuda.Event()
+            ready.record(main)                                   # dZ (and, first time round, the activations) are final
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                dw = wgrad()
+                done(blk.conv.weight, dw)                        # the hook's bucket copy is ordered on the side stream
+            keep.append(dz)      # read by the side stream: stays alive until the main stream has joined it (below), so the
+                                 # allocator can never hand its memory to later main-stream work too early
+        if not need_dx:
+            return None, None
+        c0 = int(rec["x0"].shape[1])
+        c1 = int(rec["x1"].shape[1]) if rec["x1"] is not None else 0
+        n, _, h, w = dz.shape
+        if rec["up"] and c1:
+            # decoder entry: the gradient of the upsampled operand straight at the low resolution (4x4 stride-2
+            # correlation of dZ, 4/9 of the MACs, no full-resolution intermediate), the skip half as a plain 3x3 dgrad
+            g_low, w_skip_t = blk.packed_dgrad_up2x(c0)
+            d_low = ops.dgrad_up2x(dz, g_low, c0)
+            if tuning.use_winograd(blk.conv.out_dim, c1, int(h), int(w)):
+                d_skip = ops.conv3x3_wino(dz, blk.packed_wino_t(c0), c1)
+            else:
+                cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))
+                d_skip, _ = ops.conv3x3_dgrad(dz, w_skip_t, c1, 0, cfg=cfg)
+            return d_low, d_skip
+        if c1 == 0 and not rec["up"] and tuning.use_winograd(blk.conv.out_dim, c0, int(h), int(w)):
+            # plain layer: dX = conv3x3(dZ, W^T flipped) is itself a plain 3x3 convolution -> the Winograd kernel
+            return ops.conv3x3_wino(dz, blk.packed_wino_t(), c0), None
+        if c1 == 0 and c0 % 64:
+            # gradient w.r.t. the network INPUT (9 / 27 channels; only when the caller asked for it -- train.py never does):
+            # the data-gradient kernels produce channel blocks of 64, so run it on the filter zero-padded to 64 input
+            # channels and keep the first c0 planes
+            cpad = (c0 + 63) // 64 * 64
+            wpad = torch.zeros((blk.conv.out_dim, cpad, 3, 3), dtype=torch.float32, device=dz.device)
+            wpad[:, :c0] = blk.conv.weight.detach()
+            dxp, _ = ops.conv3x3_dgrad(dz, ops.pack_conv3x3_weights(wpad, transpose_flip=True), cpad, 0)
+            return dxp[:, :c0].contiguous(), None
+        cfg = tuning.conv_config(c0 + c1, blk.conv.out_dim, int(n), int(h), int(w))
+        return ops.conv3x3_dgrad(dz, blk.packed_weight(transpose_flip=True), c0, c1, cfg=cfg)
+
+    x1, x2, x3 = ctx.skips
+    idx = len(saved) - 1
+
+    def chain_bwd(count, da, first_needs_dx=True):
+        nonlocal idx
+        d_skip = None
+        for k in range(count):
+            rec = saved[idx]
+            idx -= 1
+            last = (k == count - 1)
+            da, d_skip = block_bwd(rec, da, need_dx=(first_needs_dx or not last))
+        return da, d_skip
+
+    # up_block_3 (2) -> dUp(128ch, full res), dSkip(x1)
+    da, d_x1 = chain_bwd(2, da)                        # (the first block of each chain returns the gradient of the
+    da, d_x2 = chain_bwd(2, da)                        # up_block_2      low-resolution operand of nn.Upsample directly)
+    da, d_x3 = chain_bwd(3, da)                        # up_block_1
+    d_pool3, _ = chain_bwd(3, da)                      # bottleneck -> gradient of pool(x3)
+    da = ops.maxpool2x2_backward_add(x3, d_pool3, d_x3)
+    d_pool2, _ = chain_bwd(3, da)                      # down_block_3
+    da = ops.maxpool2x2_backward_add(x2, d_pool2, d_x2)
+    d_pool1, _ = chain_bwd(2, da)                      # down_block_2
+    da = ops.maxpool2x2_backward_add(x1, d_pool1, d_x1)
+    dx, _ = chain_bwd(2, da, first_needs_dx=ctx.need_dx)   # down_block_1
+    if side is not None:
+        main.wait_stream(side)                                   # every weight gradient is final for whoever comes next
+    keep.clear()
+    ctx.saved = ctx.skips = ctx.head_in = None
+    if _backward_end_hook is not None:
+        _backward_end_hook()
+    return (dx if ctx.need_dx else None), tuple(grads.get(id(p)) for p in net._train_params)
+
+
 class _TrackNetTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
         # params are listed only so that autograd routes their gradients; values are read from the module.
-        saved = []          # per block: dict(x0, x1, up, z, a, mean, invstd)
-        n = x.shape[0]
-
-        def block_fwd(blk, src0, src1=None, up=False):
-            h = src0.shape[2] * (2 if up else 1)
-            w = src0.shape[3] * (2 if up else 1)
-            if up and src1 is not None:
-                z = blk.conv_up_skip(src0, src1, int(n), relu=False, affine=False)
-            elif src1 is None and not up and tuning.use_winograd(blk.conv.in_dim, blk.conv.out_dim, int(h), int(w)):
-                z = ops.conv3x3_wino(src0, blk.packed_wino(), blk.conv.out_dim)      # raw conv output in Winograd form
-            else:
-                z = ops.conv3x3(src0, blk.packed_weight(), blk.conv.out_dim, src1=src1, up0=up, relu=False, cfg=_cfg(blk, n, h, w))
-            bn = blk.bn
-            a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                                   bn.eps, bn.momentum)
-            bn.num_batches_tracked.add_(1)
-            blk._cache.pop("aff", None)       # running_var was rewritten through a raw pointer: the folded eval scale is stale
-            saved.append(dict(blk=blk, x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,
-                              bn_ver=(bn.weight._version, bn.bias._version)))
-            return a
-
-        def chain(blks, src0, src1=None, up=False):
-            y = block_fwd(blks[0], src0, src1, up)
-            for b in blks[1:]:
-                y = block_fwd(b, y)
-            return y
-
-        d1, d2, d3, bt, u1, u2, u3 = _blocks(net)
-        x1 = chain(d1, x)
-        x2 = chain(d2, ops.maxpool2x2(x1))
-        x3 = chain(d3, ops.maxpool2x2(x2))
-        y = chain(bt, ops.maxpool2x2(x3))
-        y = chain(u1, y, x3, True)
-        y = chain(u2, y, x2, True)
-        y = chain(u3, y, x1, True)
+        saved, y, skips = _train_forward_body(net, x)
         p = ops.head1x1_sigmoid(y, net.predictor.weight.detach(), net.predictor.bias.detach())
         # The OUTPUT goes through save_for_backward: an output kept as a plain ctx attribute is a reference cycle
         # (p.grad_fn -> ctx -> p) that pins every activation of the step until the cyclic GC runs (measured: +0.85 GB/step).
         if hasattr(ctx, "save_for_backward"):
             ctx.save_for_backward(p)
         ctx.net, ctx.saved, ctx.head_in = net, saved, y
-        ctx.skips = (x1, x2, x3)
+        ctx.skips = skips
         ctx.need_dx = x.requires_grad
         return p
 
     @staticmethod
     def backward(ctx, dp):
-        net, saved = ctx.net, ctx.saved
-        if saved is None:
-            raise RuntimeError("TrackNet backward ran twice over the same forward: the training node frees its activations at the "
-                               "end of backward (retain_graph=True is not supported); run the forward again")
-        hook = _grad_ready_hook
-        grads = {}
-        keep = []
-
-        def done(param, g):
-            if hook is not None:
-                r = hook(param, g)
-                if r is not None:
-                    g = r
-            grads[id(param)] = g
-
         dp = dp.contiguous()
-        side = wgrad_stream(dp.device)
-        main = torch.cuda.current_stream(dp.device) if side is not None else None
-        if dp.device.type == "cuda":
-            _BACKWARD_STREAMS[dp.device.index if dp.device.index is not None else 0] = \
-                [torch.cuda.current_stream(dp.device)] + ([side] if side is not None else [])
         (p_out,) = ctx.saved_tensors
-        da, dw_head, db_head = ops.head_backward(dp, p_out, ctx.head_in, net.predictor.weight.detach())
-        done(net.predictor.weight, dw_head)
-        done(net.predictor.bias, db_head)
+        net, head_in = ctx.net, ctx.head_in
+        dx, pgrads = _train_backward_body(ctx, dp.device, lambda: ops.head_backward(dp, p_out, head_in, net.predictor.weight.detach()))
+        return (None, dx) + pgrads
 
-        def block_bwd(rec, da, need_dx=True):
-            blk = rec["blk"]
-            # ReLU mask recomputed from z (bit-identical to a > 0): the passes read two activation tensors instead of three.
-            # That needs the forward's gamma / beta; if either was modified in place since, the mask comes from a itself.
-            same = rec["bn_ver"] == (blk.bn.weight._version, blk.bn.bias._version)
-            dz, dgamma, dbeta = ops.bn_relu_backward(da, None if same else rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"],
-                                                     rec["invstd"], beta=blk.bn.bias.detach())
-            done(blk.bn.weight, dgamma)
-            done(blk.bn.bias, dbeta)
-            def wgrad():
-                if rec["up"] and rec["x1"] is not None:       # decoder entry: upsampled channels at the low resolution
-                    return ops.conv3x3_wgrad_up2x(rec["x0"], rec["x1"], dz)
-                if rec["x1"] is None and not rec["up"] and tuning.use_winograd_wgrad(
-                        int(rec["x0"].shape[1]), blk.conv.out_dim, int(dz.shape[2]), int(dz.shape[3])):
-                    return ops.conv3x3_wgrad_wino(rec["x0"], dz)      # plain deep layer: Winograd-form weight gradient
-                return ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
 
-            if side is None:
-                dw = wgrad()
-                done(blk.conv.weight, dw)
-            else:
-                ready = torch.cuda.Event()
-                ready.record(main)                                   # dZ (and, first time round, the activations) are final
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    dw = wgrad()
-                    done(blk.conv.weight, dw)                        # the hook's bucket copy is ordered on the side stream
-                keep.append(dz)      # read by the side stream: stays alive until the main stream has joined it (below), so the
-                                     # allocator can never hand its memory to later main-stream work too early
-            if not need_dx:
-                return None, None
-            c0 = int(rec["x0"].shape[1])
-            c1 = int(rec["x1"].shape[1]) if rec["x1"] is not None else 0
-            n, _, h, w = dz.shape
-            if rec["up"] and c1:
-                # decoder entry: the gradient of the upsampled operand straight at the low resolution (4x4 stride-2
-                # correlation of dZ, 4/9 of the MACs, no full-resolution intermediate), the skip half as a plain 3x3 dgrad
-                g_low, w_skip_t = blk.packed_dgrad_up2x(c0)
-                d_low = ops.dgrad_up2x(dz, g_low, c0)
-                if tuning.use_winograd(blk.conv.out_dim, c1, int(h), int(w)):
-                    d_skip = ops.conv3x3_wino(dz, blk.packed_wino_t(c0), c1)
-                else:
-                    cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))
-                    d_skip, _ = ops.conv3x3_dgrad(dz, w_skip_t, c1, 0, cfg=cfg)
-                return d_low, d_skip
-            if c1 == 0 and not rec["up"] and tuning.use_winograd(blk.conv.out_dim, c0, int(h), int(w)):
-                # plain layer: dX = conv3x3(dZ, W^T flipped) is itself a plain 3x3 convolution -> the Winograd kernel
-                return ops.conv3x3_wino(dz, blk.packed_wino_t(), c0), None
-            if c1 == 0 and c0 % 64:
-                # gradient w.r.t. the network INPUT (9 / 27 channels; only when the caller asked for it -- train.py never does):
-                # the data-gradient kernels produce channel blocks of 64, so run it on the filter zero-padded to 64 input
-                # channels and keep the first c0 planes
-                cpad = (c0 + 63) // 64 * 64
-                wpad = torch.zeros((blk.conv.out_dim, cpad, 3, 3), dtype=torch.float32, device=dz.device)
-                wpad[:, :c0] = blk.conv.weight.detach()
-                dxp, _ = ops.conv3x3_dgrad(dz, ops.pack_conv3x3_weights(wpad, transpose_flip=True), cpad, 0)
-                return dxp[:, :c0].contiguous(), None
-            cfg = tuning.conv_config(c0 + c1, blk.conv.out_dim, int(n), int(h), int(w))
-            return ops.conv3x3_dgrad(dz, blk.packed_weight(transpose_flip=True), c0, c1, cfg=cfg)
+class _TrackNetTrainLoss(torch.autograd.Function):
+    """forward(train) + WBCELoss as ONE node with sigmoid + WBCE fused into the head in both directions (the north-star's
+    "sigmoid+WBCE-loss fused into the heatmap head"): the forward writes p once and takes the loss from the registers that hold
+    it; the backward forms dL/dp inside the head's backward from (p, y) -- no dP tensor exists.  Returns (loss, p); p is
+    marked non-differentiable (it is an observation, the loss is what is differentiated)."""
 
-        x1, x2, x3 = ctx.skips
-        idx = len(saved) - 1
+    @staticmethod
+    def forward(ctx, net, x, y, reduce, *params):
+        saved, head_in, skips = _train_forward_body(net, x)
+        p, loss = ops.head1x1_sigmoid_wbce(head_in, net.predictor.weight.detach(), net.predictor.bias.detach(), y, reduce)
+        ctx.save_for_backward(p, y)
+        ctx.mark_non_differentiable(p)
+        ctx.net, ctx.saved, ctx.head_in, ctx.skips = net, saved, head_in, skips
+        ctx.need_dx, ctx.reduce = x.requires_grad, bool(reduce)
+        return (loss.reshape(()) if reduce else loss), p
 
-        def chain_bwd(count, da, first_needs_dx=True):
-            nonlocal idx
-            d_skip = None
-            for k in range(count):
-                rec = saved[idx]
-                idx -= 1
-                last = (k == count - 1)
-                da, d_skip = block_bwd(rec, da, need_dx=(first_needs_dx or not last))
-            return da, d_skip
+    @staticmethod
+    def backward(ctx, dloss, _dp_unused):
+        p_out, y = ctx.saved_tensors
+        net, head_in = ctx.net, ctx.head_in
+        up = dloss.reshape(-1).contiguous().float()
+        dx, pgrads = _train_backward_body(
+            ctx, up.device, lambda: ops.head_wbce_backward(y, p_out, head_in, net.predictor.weight.detach(), up, ctx.reduce))
+        return (None, dx, None, None) + pgrads
 
-        # up_block_3 (2) -> dUp(128ch, full res), dSkip(x1)
-        da, d_x1 = chain_bwd(2, da)                        # (the first block of each chain returns the gradient of the
-        da, d_x2 = chain_bwd(2, da)                        # up_block_2      low-resolution operand of nn.Upsample directly)
-        da, d_x3 = chain_bwd(3, da)                        # up_block_1
-        d_pool3, _ = chain_bwd(3, da)                      # bottleneck -> gradient of pool(x3)
-        da = ops.maxpool2x2_backward_add(x3, d_pool3, d_x3)
-        d_pool2, _ = chain_bwd(3, da)                      # down_block_3
-        da = ops.maxpool2x2_backward_add(x2, d_pool2, d_x2)
-        d_pool1, _ = chain_bwd(2, da)                      # down_block_2
-        da = ops.maxpool2x2_backward_add(x1, d_pool1, d_x1)
-        dx, _ = chain_bwd(2, da, first_needs_dx=ctx.need_dx)   # down_block_1
-        if side is not None:
-            main.wait_stream(side)                                   # every weight gradient is final for whoever comes next
-        keep.clear()
-        ctx.saved = ctx.skips = ctx.head_in = None
-        if _backward_end_hook is not None:
-            _backward_end_hook()
-        out = [None, dx if ctx.need_dx else None]
-        out.extend(grads.get(id(p)) for p in net._train_params)
-        return tuple(out)
+
+def tracknet_forward_loss(net, x, y, reduce=True):
+    """(loss, y_pred) of one training forward: `y_pred = net(x); loss = WBCELoss(y_pred, y, reduce)` (train.py:92-93) with the
+    loss fused into the head.  Differentiable through `loss` (parameters and, if requested, x)."""
+    if not net.training:
+        raise RuntimeError("tracknet_forward_loss is the training-mode path: call net.train() first")
+    x = x.contiguous()
+    y = y.to(torch.float32).contiguous()
+    params = [p for p in net.parameters()]
+    net._train_params = params
+    return _TrackNetTrainLoss.apply(net, x, y, bool(reduce), *params)
 
 
 def tracknet_forward_train(net, x):

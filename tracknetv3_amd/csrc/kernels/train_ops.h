@@ -221,19 +221,85 @@ inline __global__ void wbce_finalize_kernel(const double* __restrict__ partial, 
   }
 }
 
-// dL/dp = upstream[n or 0] * d(elem)/dp / denom      (closed form; clamp gradient is 0 outside [1e-7, 1])
+// d(elem)/dp in closed form (the clamp's gradient is 0 outside [1e-7, 1])
+__device__ __forceinline__ float wbce_elem_grad(float pv, float yv) {
+  const float q = 1.0f - pv;
+  const float pc = fminf(fmaxf(pv, 1e-7f), 1.0f), qc = fminf(fmaxf(q, 1e-7f), 1.0f);
+  const float in_p = (pv >= 1e-7f && pv <= 1.0f) ? 1.0f : 0.0f;
+  const float in_q = (q >= 1e-7f && q <= 1.0f) ? 1.0f : 0.0f;
+  return -(-2.0f * q * yv * logf(pc) + q * q * yv * in_p / pc + 2.0f * pv * (1.0f - yv) * logf(qc) - pv * pv * (1.0f - yv) * in_q / qc);
+}
+
+// dL/dp = upstream[n or 0] * d(elem)/dp / denom
 inline __global__ void __launch_bounds__(256) wbce_backward_kernel(const float* __restrict__ p, const float* __restrict__ y,
                                                             const float* __restrict__ upstream, int upstream_per_sample,
                                                             float inv_denom, float* __restrict__ dp, long per_sample, long total) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const float pv = p[t], yv = y[t];
-    const float q = 1.0f - pv;
-    const float pc = fminf(fmaxf(pv, 1e-7f), 1.0f), qc = fminf(fmaxf(q, 1e-7f), 1.0f);
-    const float in_p = (pv >= 1e-7f && pv <= 1.0f) ? 1.0f : 0.0f;
-    const float in_q = (q >= 1e-7f && q <= 1.0f) ? 1.0f : 0.0f;
-    const float g = -(-2.0f * q * yv * logf(pc) + q * q * yv * in_p / pc + 2.0f * pv * (1.0f - yv) * logf(qc) - pv * pv * (1.0f - yv) * in_q / qc);
+    const float g = wbce_elem_grad(p[t], y[t]);
     const float up = upstream[upstream_per_sample ? (int)(t / per_sample) : 0];
     dp[t] = g * up * inv_denom;
+  }
+}
+
+// ---- head forward with the loss: p = sigmoid(W a + b) written once, WBCE partial sums taken from the registers that hold it ---
+// grid = (kHeadLossSplit, N): block (s, n) walks 4-pixel groups s, s + kHeadLossSplit, ... of sample n; partial[n][s] in fp64
+// (fixed assignment: deterministic).  C input planes, L <= LT maps.
+constexpr int kHeadLossSplit = 256;
+template <int LT>
+__global__ void __launch_bounds__(256) head1x1_sigmoid_wbce_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ b, const float* __restrict__ y,
+                                                                   float* __restrict__ pout, double* __restrict__ partial, int C, int L, int HW) {
+  __shared__ double red[4];
+  const int n = blockIdx.y, hw4 = HW >> 2;
+  double acc_loss = 0.0;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < hw4; t += kHeadLossSplit * 256) {
+    const int px = t << 2;
+    const float* xb = x + (size_t)n * C * HW + px;
+    t_f32x4 acc[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) acc[l] = (t_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+      const t_f32x4 v = *reinterpret_cast<const t_f32x4*>(xb + (size_t)c * HW);
+#pragma unroll
+      for (int l = 0; l < LT; ++l) {
+        const float wl = l < L ? w[l * C + c] : 0.0f;
+        acc[l] += wl * v;
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      if (l < L) {
+        const size_t o = ((size_t)n * L + l) * HW + px;
+        t_f32x4 z = acc[l] + b[l];
+        const t_f32x4 yy = *reinterpret_cast<const t_f32x4*>(y + o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          z[k] = 1.0f / (1.0f + expf(-z[k]));
+          acc_loss += (double)wbce_elem(z[k], yy[k]);
+        }
+        *reinterpret_cast<t_f32x4*>(pout + o) = z;
+      }
+    }
+  }
+  const double r = block_sum_256(acc_loss, red);
+  if (threadIdx.x == 0) partial[(size_t)n * kHeadLossSplit + blockIdx.x] = r;
+}
+
+// the matching finalize: out[0] = mean over everything (reduce) or out[n] = per-sample means
+inline __global__ void head_wbce_finalize_kernel(const double* __restrict__ partial, float* __restrict__ out, int N, long per_sample, int reduce) {
+  if (reduce) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      double t = 0.0;
+      for (int n = 0; n < N; ++n) for (int s = 0; s < kHeadLossSplit; ++s) t += partial[(size_t)n * kHeadLossSplit + s];
+      out[0] = (float)(t / ((double)N * (double)per_sample));
+    }
+  } else {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) {
+      double t = 0.0;
+      for (int s = 0; s < kHeadLossSplit; ++s) t += partial[(size_t)n * kHeadLossSplit + s];
+      out[n] = (float)(t / (double)per_sample);
+    }
   }
 }
 
@@ -245,11 +311,15 @@ inline __global__ void __launch_bounds__(256) wbce_backward_kernel(const float* 
 //       channel as 16-byte LDS broadcasts (scalar global loads instead were measured slower: their latency is exposed);
 //   dW: a thread owns channel c for ALL l over a quarter of the tile's pixels: one a read and L/4 16-byte broadcast reads of
 //       dz per pixel feed L FMAs; the four pixel quarters (waves) are summed in fixed order at the end.
+// FUSED_WBCE: sigmoid + WBCELoss fused into the head (the north-star's wording): `dP` then holds the TARGETS y and dL/dp is formed on
+// the fly from (p, y) and the loss node's upstream gradient -- the dP tensor (N*L*H*W floats) is neither written nor read.
 constexpr int kHeadP = 128, kHeadC = 64, kHeadLMax = 16;
-inline __global__ void __launch_bounds__(256) head_backward_kernel(const float* __restrict__ dP, const float* __restrict__ p,
+template <bool FUSED_WBCE>
+__global__ void __launch_bounds__(256) head_backward_kernel(const float* __restrict__ dP, const float* __restrict__ p,
                                                             const float* __restrict__ a, const float* __restrict__ w,
                                                             float* __restrict__ dA, float* __restrict__ part /* [grid][L*C + L] */,
-                                                            int N, int L, int HW) {
+                                                            int N, int L, int HW, const float* __restrict__ upstream, int upstream_per_sample,
+                                                            float inv_denom) {
   __shared__ __attribute__((aligned(16))) float dz_s[kHeadP * kHeadLMax];       // [px][l], l padded to 16 (zeros)
   __shared__ float a_s[kHeadC * (kHeadP + 1)];
   __shared__ __attribute__((aligned(16))) float w_s[kHeadC * kHeadLMax];       // [c][l]: the filter column of a channel, l padded (zeros)
@@ -287,7 +357,14 @@ inline __global__ void __launch_bounds__(256) head_backward_kernel(const float* 
       const int i = tid + j * 256;
       const int l = i / kHeadP, px = i - l * kHeadP;
       float v = 0.0f;
-      if (l < L && p0 + px < HW) { const size_t o = ((size_t)n * L + l) * HW + p0 + px; const float pv = p[o]; v = dP[o] * pv * (1.0f - pv); }
+      if (l < L && p0 + px < HW) {
+        const size_t o = ((size_t)n * L + l) * HW + p0 + px;
+        const float pv = p[o];
+        float dpv;
+        if (FUSED_WBCE) dpv = wbce_elem_grad(pv, dP[o]) * upstream[upstream_per_sample ? n : 0] * inv_denom;      // = wbce_backward_kernel's dp
+        else dpv = dP[o];
+        v = dpv * pv * (1.0f - pv);
+      }
       rz[j] = v;
     }
   };

@@ -778,16 +778,39 @@ int wbce_backward_impl(Launcher& L, const float* p, const float* y, const float*
 constexpr int kHeadGrid = 1024;
 inline size_t head_backward_workspace_bytes(int l) { return l <= 0 ? 0 : (size_t)kHeadGrid * (l * kHeadC + l) * sizeof(float); }
 
+inline size_t head_wbce_workspace_bytes(int n) { return n <= 0 ? 0 : (size_t)n * kHeadLossSplit * sizeof(double); }
+
+// head + sigmoid + WBCELoss in one pass (model.py:71-72 + utils/metric.py:15-20): p and the loss
+template <class Launcher>
+int head_wbce_forward_impl(Launcher& L, const float* x, const float* w, const float* b, const float* y, float* p, float* loss, void* ws,
+                           size_t ws_bytes, int n, int c, int l, int hw, int reduce) {
+  if (!x || !w || !b || !y || !p || !loss || !ws || n <= 0 || c <= 0 || l <= 0 || hw <= 0) TNV3_FAIL(-1, "head_wbce_forward: bad argument");
+  if (hw % 4) TNV3_FAIL(-1, "head_wbce_forward: H*W=%d must be a multiple of 4", hw);
+  if (l > 8) TNV3_FAIL(-1, "head_wbce_forward: at most 8 output maps (got %d)", l);
+  if (n > 65535) TNV3_FAIL(-1, "head_wbce_forward: at most 65535 samples per call");
+  if (ws_bytes < head_wbce_workspace_bytes(n) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "head_wbce_forward: workspace too small / misaligned");
+  int rc;
+  if ((rc = L.launch3(head1x1_sigmoid_wbce_kernel<8>, kHeadLossSplit, n, 1, 256, x, w, b, y, p, (double*)ws, c, l, hw))) return rc;
+  return L.launch(head_wbce_finalize_kernel, reduce ? 1 : (n + 63) / 64, 64, (const double*)ws, loss, n, (long)l * hw, reduce ? 1 : 0);
+}
+
+// `dp_or_y`: dL/dp (upstream == NULL), or the TARGETS y with the loss node's upstream gradient (fused WBCE backward)
 template <class Launcher>
 int head_backward_impl(Launcher& L, const float* dp, const float* p, const float* a, const float* w, float* da, float* dw, float* db,
-                       void* ws, size_t ws_bytes, int n, int l, int hw) {
+                       void* ws, size_t ws_bytes, int n, int l, int hw, const float* upstream = nullptr, int reduce = 1) {
   if (!dp || !p || !a || !w || !da || !dw || !db || !ws || n <= 0 || l <= 0 || hw <= 0) TNV3_FAIL(-1, "head_backward: bad argument");
   if (l > kHeadLMax) TNV3_FAIL(-1, "head_backward: at most %d output maps", kHeadLMax);
   if (ws_bytes < head_backward_workspace_bytes(l)) TNV3_FAIL(-1, "head_backward: workspace too small");
   const long nTiles = (long)n * ((hw + kHeadP - 1) / kHeadP);
   const int grid = (int)(nTiles < kHeadGrid ? nTiles : kHeadGrid);
   int rc;
-  if ((rc = L.launch(head_backward_kernel, grid, 256, dp, p, a, w, da, (float*)ws, n, l, hw))) return rc;
+  if (upstream) {
+    const float inv = reduce ? (float)(1.0 / ((double)n * (double)l * (double)hw)) : (float)(1.0 / ((double)l * (double)hw));
+    rc = L.launch(head_backward_kernel<true>, grid, 256, dp, p, a, w, da, (float*)ws, n, l, hw, upstream, reduce ? 0 : 1, inv);
+  } else {
+    rc = L.launch(head_backward_kernel<false>, grid, 256, dp, p, a, w, da, (float*)ws, n, l, hw, (const float*)nullptr, 0, 1.0f);
+  }
+  if (rc) return rc;
   // partial layout per workgroup: [L*64 dW | L db]; dW and db are contiguous slices of one reduction
   const long nel = (long)l * kHeadC + l;
   // reduce into a temporary tail of the workspace is avoided: sum directly into dw / db with two launches

@@ -485,6 +485,41 @@ def head_backward(dp, p, a, weight):
     return da, dw, db
 
 
+def head1x1_sigmoid_wbce(x, weight, bias, y, reduce=True):
+    """(p, loss): the head (1x1 conv + bias + sigmoid) and WBCELoss(p, y, reduce) in ONE pass (tnv3_head1x1_sigmoid_wbce)."""
+    lib = _lib.load()
+    _f32(x, weight, bias, y)
+    _lib.dev_check(x, weight, bias, y)
+    n, c, h, w = (int(v) for v in x.shape)
+    l = int(weight.shape[0])
+    if tuple(y.shape) != (n, l, h, w):
+        raise _lib.Tnv3Error("head1x1_sigmoid_wbce: y must have the heat maps' shape")
+    p = torch.empty((n, l, h, w), dtype=torch.float32, device=x.device)
+    loss = torch.empty(1 if reduce else n, dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.tnv3_head_wbce_workspace_bytes(n), x.device)
+    _lib.check(lib.tnv3_head1x1_sigmoid_wbce(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(p), _lib.ptr(loss),
+                                             _lib.ptr(ws), ws.numel() * 8, n, c, l, h * w, int(bool(reduce)), _lib.stream_ptr(x)))
+    return p, loss
+
+
+def head_wbce_backward(y, p, a, weight, upstream, reduce=True):
+    """Backward of head + sigmoid + WBCELoss without a dP tensor: returns (da, dW (L,64,1,1), db (L,))."""
+    lib = _lib.load()
+    _f32(y, p, a, weight, upstream)
+    _lib.dev_check(y, p, a, weight, upstream)
+    n, l, h, w = (int(v) for v in p.shape)
+    if int(a.shape[1]) != 64:
+        raise _lib.Tnv3Error("head_wbce_backward: expects 64 input channels")
+    da = torch.empty_like(a)
+    dw = torch.empty((l, 64, 1, 1), dtype=torch.float32, device=p.device)
+    db = torch.empty(l, dtype=torch.float32, device=p.device)
+    ws = _workspace(lib.tnv3_head_backward_workspace_bytes(l), p.device)
+    _lib.check(lib.tnv3_head_wbce_backward(_lib.ptr(y), _lib.ptr(p), _lib.ptr(a), _lib.ptr(weight), _lib.ptr(upstream), _lib.ptr(da),
+                                           _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), ws.numel() * 8, n, l, h * w, int(bool(reduce)),
+                                           _lib.stream_ptr(p)))
+    return da, dw, db
+
+
 def maxpool2x2_backward_add(x, dpool, dskip=None):
     lib = _lib.load()
     _f32(x, dpool, dskip)
@@ -659,7 +694,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 _TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "pack_up2x_weights", "conv_up2x",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
-               "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward",
+               "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
                "maxpool2x2_backward_add", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad"]
 for _name in _TENSOR_OPS:
     globals()[_name] = _lib.on_tensor_device(globals()[_name])

@@ -156,6 +156,7 @@ class TrackNetTrainer:
     def __init__(self, net, optimizer, alpha=0.0, seed=13, group=None, bucket_bytes=12 << 20, record_timing=False, device_rng=True):
         from .utils.metric import WBCELoss
         self.device_rng, self.seed, self.steps_done = bool(device_rng), int(seed), 0
+        self.fused_loss = hasattr(net, "predictor") and hasattr(net, "down_block_1")      # TrackNet: loss fused into the head
         self.record_timing = bool(record_timing)
         self.last_timing = None
         self.net, self.opt, self.alpha, self.loss_fn = net, optimizer, alpha, WBCELoss
@@ -183,7 +184,10 @@ class TrackNetTrainer:
             autograd_ops.set_grad_ready_hook(self.reducer.on_grad, self.reducer.on_backward_end)
         try:
             self.net.train()
-            loss = self.loss_fn(self.net(x), y)
+            if self.fused_loss:
+                loss, _ = autograd_ops.tracknet_forward_loss(self.net, x, y)      # sigmoid + WBCE fused into the head, both directions
+            else:
+                loss = self.loss_fn(self.net(x), y)                               # the reference's two calls (train.py:92-93)
             if timing:
                 b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 b0.record()
