@@ -108,6 +108,15 @@ int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* add
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,
                               tnv3_stream_t stream);
 
+/* Training-mode forward of a Conv2DBlock with the BatchNorm batch statistics taken in the convolution's epilogue (model.py:8-9):
+ * dst = conv3x3(src, W) + addend (raw sums, kernel variants 3 / 4), and tile_stats[cout][tiles][2] (doubles) = per output channel and
+ * pixel tile (4 x 64 pixels; tiles = tnv3_conv3x3_wino_stats_tiles(n, h, w)) the sum and the sum of squares of the values written --
+ * reduced inside the kernel by a wave butterfly and a fixed-order fold, so the statistics cost no pass over dst.  Feed them to
+ * tnv3_bn_train_forward_tiles. */
+long tnv3_conv3x3_wino_stats_tiles(int n, int h, int w);
+int tnv3_conv3x3_wino_forward_stats(const float* src, const float* u, const float* addend, float* dst, double* tile_stats, int n, int cin,
+                                    int cout, int h, int w, int variant, tnv3_stream_t stream);
+
 /* Decoder-entry layers (model.py:65,67,69: Conv2DBlock on torch.cat([nn.Upsample(scale_factor=2)(x), skip], dim=1)):
  * the contribution of the UPSAMPLED channels computed at the low resolution.  A 3x3 'same' convolution over a nearest-2x
  * upsampled tensor reads only 2x2 distinct source pixels per output pixel, so with the taps that coincide pre-summed
@@ -216,6 +225,13 @@ int tnv3_bn_train_forward(const float* z, const float* gamma, const float* beta,
                           float* running_var, float eps, float momentum, float* a, float* save_mean,
                           float* save_invstd, void* workspace, size_t workspace_bytes, int n, int c, int hw,
                           tnv3_stream_t stream);
+
+/* The same with the batch statistics already reduced per pixel tile by the producing convolution (tile_stats [c][n_tiles][2] doubles
+ * from tnv3_conv3x3_wino_forward_stats): fixed-order sums, then the identical finalize and normalise + ReLU pass -- one read of z
+ * less per layer.  Same workspace as tnv3_bn_train_forward. */
+int tnv3_bn_train_forward_tiles(const float* z, const double* tile_stats, long n_tiles, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float eps, float momentum, float* a, float* save_mean,
+                                float* save_invstd, void* workspace, size_t workspace_bytes, int n, int c, int hw, tnv3_stream_t stream);
 
 /* Backward of the same: given dA (gradient w.r.t. a), z and the saved statistics, writes dZ (may alias dA),
  * dgamma[C], dbeta[C].  The ReLU mask comes from `a` when it is given; with a == NULL it is recomputed from z, gamma, beta

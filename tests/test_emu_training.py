@@ -315,3 +315,29 @@ def test_head_sigmoid_wbce_fused_both_directions_emulated(emu):
         da_ref, dw_ref, db_ref = ops.head_backward(dp, p_ref, a, wt)
         da, dw, db = ops.head_wbce_backward(y, p, a, wt, up, reduce)
         assert rel_err(da, da_ref) <= 1e-6 and rel_err(dw, dw_ref) <= 1e-6 and rel_err(db, db_ref) <= 1e-6
+
+
+@pytest.mark.parametrize("case", [(2, 16, 64, 8, 64, False), (1, 24, 128, 4, 128, True)], ids=["plain", "with_addend"])
+def test_bn_statistics_from_the_conv_epilogue_emulated(emu, case):
+    """conv3x3_wino_stats: the raw output is bit-identical to conv3x3_wino and the per-tile (sum, sum of squares) fold to the
+    batch statistics; bn_train_forward(tile_stats=...) equals the pass over z (same finalize arithmetic)."""
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w, with_add = case
+    x, wt = torch.relu(T((n, cin, h, w), 61)), T((cout, cin, 3, 3), 62, -0.3, 0.3)
+    add = T((n, cout, h, w), 63) if with_add else None
+    u = ops.pack_wino_weights(wt)
+    z_ref = ops.conv3x3_wino(x, u, cout, addend=add)
+    z, stats = ops.conv3x3_wino_stats(x, u, cout, addend=add)
+    assert torch.equal(z, z_ref)
+    assert stats.shape == (cout, n * (h // 4) * (w // 64), 2) and stats.dtype == torch.float64
+    s1, s2 = stats[:, :, 0].sum(1), stats[:, :, 1].sum(1)
+    zd = z.double()
+    assert torch.allclose(s1, zd.sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9) and torch.allclose(s2, (zd * zd).sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9)
+    g, b = T((cout,), 64, 0.5, 1.5), T((cout,), 65)
+    outs = []
+    for ts in (None, stats):
+        rm, rv = T((cout,), 66), T((cout,), 67, 0.5, 2.0)
+        a, mean, invstd = ops.bn_train_forward(z, g, b, rm, rv, tile_stats=ts)
+        outs.append((a, mean, invstd, rm, rv))
+    for p_, q_ in zip(outs[0], outs[1]):
+        assert torch.allclose(p_, q_, rtol=1e-6, atol=1e-7)

@@ -84,15 +84,19 @@ def _train_forward_body(net, x):
     def block_fwd(blk, src0, src1=None, up=False):
         h = src0.shape[2] * (2 if up else 1)
         w = src0.shape[3] * (2 if up else 1)
+        stats = None           # BatchNorm's batch statistics taken in the conv epilogue (Winograd kernels 3 / 4), else a pass over z
         if up and src1 is not None:
-            z = blk.conv_up_skip(src0, src1, int(n), relu=False, affine=False)
+            z, stats = blk.conv_up_skip(src0, src1, int(n), relu=False, affine=False, want_stats=True)
         elif src1 is None and not up and tuning.use_winograd(blk.conv.in_dim, blk.conv.out_dim, int(h), int(w)):
-            z = ops.conv3x3_wino(src0, blk.packed_wino(), blk.conv.out_dim)      # raw conv output in Winograd form
+            if tuning.wino_has_stats():
+                z, stats = ops.conv3x3_wino_stats(src0, blk.packed_wino(), blk.conv.out_dim)
+            else:
+                z = ops.conv3x3_wino(src0, blk.packed_wino(), blk.conv.out_dim)      # raw conv output in Winograd form
         else:
             z = ops.conv3x3(src0, blk.packed_weight(), blk.conv.out_dim, src1=src1, up0=up, relu=False, cfg=_cfg(blk, n, h, w))
         bn = blk.bn
         a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                               bn.eps, bn.momentum)
+                                               bn.eps, bn.momentum, tile_stats=stats)
         bn.num_batches_tracked.add_(1)
         blk._cache.pop("aff", None)       # running_var was rewritten through a raw pointer: the folded eval scale is stale
         saved.append(dict(blk=blk, x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,

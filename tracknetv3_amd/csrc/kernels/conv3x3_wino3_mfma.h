@@ -364,6 +364,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
   const int t = wn * 32 + bl;
   const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
   const int oh = h0 + 2 * tr + grp, ow = w0 + 2 * tc;    // group g finishes output row g of the tile
+  const bool want_stats = a.stats != nullptr;            // wave-uniform (kernel argument)
+  double q1[16], q2[16];                                 // this lane's two pixels per channel r: sum, sum of squares
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -377,6 +379,56 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
     if (has_affine) { v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh; }
     if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
     *reinterpret_cast<wf2*>(a.dst + o) = v;
+    if (want_stats) {
+      q1[r] = (double)v[0] + (double)v[1];
+      q2[r] = (double)v[0] * (double)v[0] + (double)v[1] * (double)v[1];
+    }
+  }
+  if (want_stats) {
+    // BatchNorm batch statistics from the epilogue's registers (model.py:9 in training mode): a half-wave holds 32 tiles x 2 pixels
+    // of 16 channels.  Reduce-scatter butterfly over the 32 lanes: at offset o the lane keeps the half of its channel list its
+    // bit selects and adds the partner's copy of that half -- 8 + 4 + 2 + 1 exchanges, then one plain exchange at offset 1;
+    // lane bl ends up with channel index r = bl >> 1 summed over the half-wave.  fp64, fixed order: deterministic.
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+      const int o = 16 >> step, cnt = 8 >> step;         // cnt values survive this step
+      const bool up = (bl & o) != 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < cnt) {
+          const double s1 = up ? q1[i] : q1[i + cnt], k1 = up ? q1[i + cnt] : q1[i];
+          const double s2 = up ? q2[i] : q2[i + cnt], k2 = up ? q2[i + cnt] : q2[i];
+          q1[i] = k1 + __shfl_xor(s1, o, 64);
+          q2[i] = k2 + __shfl_xor(s2, o, 64);
+        }
+      }
+    }
+    q1[0] += __shfl_xor(q1[0], 1, 64);
+    q2[0] += __shfl_xor(q2[0], 1, 64);
+    __syncthreads();                                       // everybody has read the exchange buffer: LDS is free again
+    double* red = reinterpret_cast<double*>(lds);          // [wave][half][16 r][2]
+    if ((bl & 1) == 0) {
+      double* d = red + ((wave * 2 + half) * 16 + (bl >> 1)) * 2;
+      d[0] = q1[0];
+      d[1] = q2[0];
+    }
+    __syncthreads();
+    if (tid < MB) {                                        // channel tid of this block: fold the four waves that own its pixels
+      const int cwm = tid >> 5, q = tid & 31;
+      const int chalf = (q >> 2) & 1, cr = (q & 3) + 4 * (q >> 3);
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int x = 0; x < WN; ++x) {
+          const double* d = red + (((g * 4 + cwm * WN + x) * 2 + chalf) * 16 + cr) * 2;
+          s1 += d[0];
+          s2 += d[1];
+        }
+      double* o = a.stats + ((size_t)(m0 + tid) * nPT + pt) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
   }
 }
 

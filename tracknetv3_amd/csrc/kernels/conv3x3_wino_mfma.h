@@ -38,6 +38,9 @@ struct WinoArgs {
   const float* shift;
   float* dst;           // [N][Cout][H][W]
   int N, Cin, Cout, H, W, relu;
+  double* stats;        // optional (kernel variant 3 / 4 only) [Cout][nTiles][2]: per output channel and pixel tile (4 x 64 pixels) the sum
+                        // and the sum of squares of the values written to dst -- the batch statistics of training-mode BatchNorm taken
+                        // from the epilogue's registers (wave butterfly + fixed-order LDS fold: deterministic)
 };
 
 template <int WM_, int WN_, int CC_, int DIAG_ = 0>

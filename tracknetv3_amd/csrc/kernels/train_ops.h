@@ -47,6 +47,20 @@ inline __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const floa
   if (threadIdx.x == 0) { partial[((size_t)c * kRedSplit + s) * 2] = a; partial[((size_t)c * kRedSplit + s) * 2 + 1] = b; }
 }
 
+// partial[c][s] = sum over tiles s, s + kRedSplit, ... of the (sum, sum of squares) pairs a convolution epilogue left per channel
+// and pixel tile (tile_stats [C][n_tiles][2], conv3x3_wino3_mfma.h): the input of bn_stats_finalize_kernel without a pass over z.
+// grid = (kRedSplit, C), 64 threads: a wave strides over its slice, then a fixed-order butterfly.
+inline __global__ void __launch_bounds__(64) bn_tile_stats_reduce_kernel(const double* __restrict__ tile_stats, double* __restrict__ partial,
+                                                                  long n_tiles) {
+  const int c = blockIdx.y, s = blockIdx.x;
+  const double* src = tile_stats + (size_t)c * n_tiles * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (long t = (long)s * 64 + threadIdx.x; t < n_tiles; t += (long)kRedSplit * 64) { s1 += src[2 * t]; s2 += src[2 * t + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+  if (threadIdx.x == 0) { partial[((size_t)c * kRedSplit + s) * 2] = s1; partial[((size_t)c * kRedSplit + s) * 2 + 1] = s2; }
+}
+
 // The ReLU(BN(z)) scale as both directions evaluate it: y = fmaf(z - mean, bn_scale(gamma, invstd), beta)
 __device__ __forceinline__ float bn_scale(float gamma, float invstd) { return (float)((double)gamma * (double)invstd); }
 

@@ -363,6 +363,28 @@ int bn_train_forward_impl(Launcher& L, const float* z, const float* gamma, const
                   (long)n * c, c, hw);
 }
 
+// Training-mode BatchNorm whose batch statistics were taken in the producing convolution's epilogue (tnv3_conv3x3_wino_forward_stats):
+// tile_stats [C][n_tiles][2] doubles -> fixed-order sums per channel, then exactly bn_train_forward's finalize + apply.
+inline long conv3x3_wino_stats_tiles(int n, int h, int w) { return (n <= 0 || h % 4 || w % 64) ? 0 : (long)n * (h / 4) * (w / 64); }
+
+template <class Launcher>
+int bn_train_forward_tiles_impl(Launcher& L, const float* z, const double* tile_stats, long n_tiles, const float* gamma, const float* beta,
+                                float* rm, float* rv, float eps, float momentum, float* a, float* save_mean, float* save_invstd, void* ws,
+                                size_t ws_bytes, int n, int c, int hw) {
+  if (!z || !tile_stats || !gamma || !beta || !rm || !rv || !a || !save_mean || !save_invstd || !ws || n <= 0 || c <= 0 || hw <= 0 || n_tiles <= 0)
+    TNV3_FAIL(-1, "bn_train_forward_tiles: bad argument");
+  if (hw % 4) TNV3_FAIL(-1, "bn_train_forward_tiles: H*W must be a multiple of 4");
+  if (ws_bytes < bn_workspace_bytes(c) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "bn_train_forward_tiles: workspace too small / misaligned");
+  double* partial = (double*)ws;
+  float* scale = (float*)(partial + (size_t)c * kRedSplit * 2);
+  int rc;
+  if ((rc = L.launch3(bn_tile_stats_reduce_kernel, kRedSplit, c, 1, 64, tile_stats, partial, n_tiles))) return rc;
+  if ((rc = L.launch(bn_stats_finalize_kernel, (c + 63) / 64, 64, (const double*)partial, gamma, beta, rm, rv, eps, momentum,
+                     (long)n * hw, scale, save_mean, save_invstd, c))) return rc;
+  return L.launch(bn_apply_relu_kernel, grid_for((long)n * c * (hw / 4)), 256, z, (const float*)save_mean, (const float*)scale, beta, a,
+                  (long)n * c, c, hw);
+}
+
 template <class Launcher>
 int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const float* z, const float* gamma, const float* beta,
                           const float* mean, const float* invstd, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
@@ -426,14 +448,17 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
 
 template <class Launcher>
 int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, const float* addend, const float* mean, const float* scale,
-                              const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant = -1) {
+                              const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant = -1,
+                              double* stats = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino: bad argument");
   if (variant < 0) variant = kWinoDefaultVariant;
+  if (stats && variant != 3 && variant != 4) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3 and 4");
+  if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino: statistics buffer must be 8-byte aligned");
   if (!conv3x3_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino: inconsistent affine arguments");
   const float* zeros = u + (size_t)round_up(cin, kWinoCinPad) * 16 * cout;
-  WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0};
+  WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats};
   const long npt = (long)n * (h / 4) * (w / WinoA::PW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino: too many pixel tiles");
 #ifdef TNV3_DIAG

@@ -113,8 +113,9 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
-    def conv_up_skip(self, x_low, skip, n, relu, affine):
-        """conv3x3(cat([upsample2x(x_low), skip], 1)) with the upsampled half computed at the low resolution."""
+    def conv_up_skip(self, x_low, skip, n, relu, affine, want_stats=False):
+        """conv3x3(cat([upsample2x(x_low), skip], 1)) with the upsampled half computed at the low resolution.  want_stats (training
+        forward, Winograd skip half): returns (z, tile_stats) -- BatchNorm's batch statistics from the kernel's epilogue."""
         c0, c1 = int(x_low.shape[1]), int(skip.shape[1])
         wq, wskip = self.packed_up2x(c0)
         part = ops.conv_up2x(x_low, wq, self.conv.out_dim)
@@ -128,8 +129,12 @@ class Conv2DBlock(nn.Module):
             return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, mean=bn.running_mean, scale=self.eval_scale(),
                                shift=bn.bias.detach(), relu=relu, cfg=cfg)
         if c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # training forward: raw sums
-            return ops.conv3x3_wino(skip, self.packed_wino(c0), self.conv.out_dim, addend=part, relu=relu)
-        return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, relu=relu, cfg=cfg)
+            if want_stats and tuning.wino_has_stats():
+                return ops.conv3x3_wino_stats(skip, self.packed_wino(c0), self.conv.out_dim, addend=part)
+            z = ops.conv3x3_wino(skip, self.packed_wino(c0), self.conv.out_dim, addend=part, relu=relu)
+            return (z, None) if want_stats else z
+        z = ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, relu=relu, cfg=cfg)
+        return (z, None) if want_stats else z
 
     def invalidate_caches(self):
         """Drop every cached operand (packed / Winograd-domain filters, folded BN scale).  The caches are keyed on the tensors'

@@ -106,6 +106,28 @@ def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, ad
     return out
 
 
+def conv3x3_wino_stats(src, u, cout, addend=None, variant=None):
+    """Training-mode forward of a plain layer: (z, tile_stats) -- the raw convolution (+ addend) and, from the same kernel's
+    epilogue, the per-channel / per-tile sums and sums of squares BatchNorm needs (tnv3_conv3x3_wino_forward_stats)."""
+    lib = _lib.load()
+    _f32(src, u, addend)
+    _lib.dev_check(src, u, addend)
+    n, cin, h, w = (int(v) for v in src.shape)
+    if variant is None:
+        from . import tuning
+        variant = tuning.WINO_VARIANT
+    tiles = int(lib.tnv3_conv3x3_wino_stats_tiles(n, h, w))
+    if tiles <= 0 or u.numel() != lib.tnv3_conv3x3_wino_packed_floats(cin, int(cout)):
+        raise _lib.Tnv3Error("conv3x3_wino_stats: unsupported shape or filter buffer mismatch")
+    out = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=src.device)
+    stats = torch.empty((int(cout), tiles, 2), dtype=torch.float64, device=src.device)
+    if addend is not None and tuple(addend.shape) != tuple(out.shape):
+        raise _lib.Tnv3Error("conv3x3_wino_stats: addend must have the output's shape")
+    _lib.check(lib.tnv3_conv3x3_wino_forward_stats(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(out), _lib.ptr(stats), n, cin,
+                                                   int(cout), h, w, int(variant), _lib.stream_ptr(src)))
+    return out, stats
+
+
 def pack_up2x_weights(weight, c0):
     """nn.Conv2d weight (Cout, Cin, 3, 3) -> pre-summed class filters of its first c0 (upsampled) input channels."""
     lib = _lib.load()
@@ -335,17 +357,26 @@ def _workspace(nbytes, device):
     return torch.empty((int(nbytes) + 7) // 8, dtype=torch.int64, device=device)
 
 
-def bn_train_forward(z, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=0.1):
+def bn_train_forward(z, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=0.1, tile_stats=None):
     """Training-mode BatchNorm2d + ReLU on the raw conv output; updates running stats in place.
-    Returns (a, save_mean, save_invstd)."""
+    Returns (a, save_mean, save_invstd).  tile_stats: the (C, tiles, 2) float64 sums the producing convolution's epilogue left
+    (conv3x3_wino_stats) -- the statistics pass over z is then skipped."""
     lib = _lib.load()
     _f32(z, gamma, beta, running_mean, running_var)
-    _lib.dev_check(z, gamma, beta, running_mean, running_var)
+    _lib.dev_check(z, gamma, beta, running_mean, running_var, tile_stats)
     n, c, h, w = (int(v) for v in z.shape)
     a = torch.empty_like(z)
     mean = torch.empty(c, dtype=torch.float32, device=z.device)
     invstd = torch.empty_like(mean)
     ws = _workspace(lib.tnv3_bn_workspace_bytes(c), z.device)
+    if tile_stats is not None:
+        if tile_stats.dtype != torch.float64 or tile_stats.dim() != 3 or int(tile_stats.shape[0]) != c or int(tile_stats.shape[2]) != 2:
+            raise _lib.Tnv3Error("bn_train_forward: tile_stats must be float64 (C, tiles, 2)")
+        _lib.check(lib.tnv3_bn_train_forward_tiles(_lib.ptr(z), _lib.ptr(tile_stats), int(tile_stats.shape[1]), _lib.ptr(gamma), _lib.ptr(beta),
+                                                   _lib.ptr(running_mean), _lib.ptr(running_var), float(eps), float(momentum), _lib.ptr(a),
+                                                   _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(ws), ws.numel() * 8, n, c, h * w,
+                                                   _lib.stream_ptr(z)))
+        return a, mean, invstd
     _lib.check(lib.tnv3_bn_train_forward(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
                                          _lib.ptr(running_var), float(eps), float(momentum), _lib.ptr(a), _lib.ptr(mean),
                                          _lib.ptr(invstd), _lib.ptr(ws), ws.numel() * 8, n, c, h * w, _lib.stream_ptr(z)))
@@ -691,7 +722,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # The C ABI runs a call on its stream's device, but a tensor's *default* stream is the NULL stream (= "the calling thread's
 # current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
-_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "pack_up2x_weights", "conv_up2x",
+_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
