@@ -93,9 +93,11 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
 /*   `variant` of tnv3_conv3x3_wino_forward (per call): -1 = the library's default (3);  2 = xi-split kernel, two waves per SIMD;
  *                                     3 = the same tile with buffer-descriptor DMA and a paired patch transform (6-12 % faster);  4 = 3 with the
  *                                     "quad" operand layouts (one LDS read per four MFMAs; needs filters packed with
- *                                     layout 1: ask tnv3_conv3x3_wino_layout);  0 = one wave per SIMD, transform as its own
- *                                     phase;  1 = transform interleaved with the MFMAs (measured slower).  Variants 2, 3, 4
- *                                     are bit-identical to each other; all compute the same function.
+ *                                     layout 1: ask tnv3_conv3x3_wino_layout);  5 = 3 as persistent workgroups (one per CU walking the tile
+ *                                     list: no per-tile launch / set-up, the next tile's first DMAs issued before the output
+ *                                     transform);  0 = one wave per SIMD, transform as its own phase.  (1, the round-1 kernel with
+ *                                     the transform interleaved into the MFMA stream, was removed: TNV3_E_INVALID.)  Variants 2, 3,
+ *                                     4, 5 are bit-identical to each other; all compute the same function.
  *   `layout` of the pack calls: 0 = u[cin_pad][16][cout];  1 = u[cin_pad / 2][4][2][cout][4] (transform row major, the four xi of
  *                                     a row adjacent). */
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);

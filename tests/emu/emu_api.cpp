@@ -5,6 +5,8 @@
 #include "../../include/tracknetv3_hip.h"
 #include "../../tracknetv3_amd/csrc/tnv3_impl.h"
 
+#include <stdlib.h>
+
 namespace {
 struct Launcher {
   template <class... KArgs, class... Args>
@@ -18,8 +20,13 @@ struct Launcher {
     return TNV3_OK;
   }
 };
-inline Launcher make_launcher(tnv3_stream_t) { return Launcher{}; }
-inline void init_cu_count() {}   // the emulator plans for the default 256 CUs
+// the emulator plans for the default 256 CUs; TNV3_EMU_CUS overrides (small values make the persistent kernels walk several tiles
+// per workgroup on small test shapes)
+inline void init_cu_count() {
+  const char* e = getenv("TNV3_EMU_CUS");
+  tnv3::num_cus() = e && atoi(e) > 0 ? atoi(e) : 256;
+}
+inline Launcher make_launcher(tnv3_stream_t) { init_cu_count(); return Launcher{}; }
 }  // namespace
 
 #define TNV3_TU_ALL 1

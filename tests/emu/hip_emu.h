@@ -294,6 +294,20 @@ inline void tnv3_buf_dma16(tnv3_rsrc_t r, float* lds_base, unsigned voffset) {
   else memset(dst, 0, 16);
 }
 
+// 8-byte buffer load / store through a descriptor: address = base + voffset (per lane) + soffset (scalar); out-of-range loads give 0,
+// out-of-range stores are dropped
+typedef float tnv3_f2 __attribute__((ext_vector_type(2)));
+inline tnv3_f2 tnv3_buf_load_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
+  tnv3_f2 v = {0.0f, 0.0f};
+  const unsigned long long o = (unsigned long long)voffset + soffset;
+  if (o + 8ull <= (unsigned long long)r.num_records) memcpy(&v, r.base + o, 8);
+  return v;
+}
+inline void tnv3_buf_store_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f2 v) {
+  const unsigned long long o = (unsigned long long)voffset + soffset;
+  if (o + 8ull <= (unsigned long long)r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 8);
+}
+
 // atomics (the emulator is single-threaded: plain read-modify-write)
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }

@@ -172,7 +172,7 @@ def _wino_case(n, cin, cout, h, w, device):
 WINO_EMU_EXTRA = [(1, 27, 64, 12, 192), (1, 16, 192, 4, 64)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4], ids=["phased", "interleaved", "xisplit", "balanced", "quad"])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5], ids=["phased", "xisplit", "balanced", "quad", "persistent"])
 @pytest.mark.parametrize("case", WINO_CASES + WINO_EMU_EXTRA)
 def test_conv3x3_wino_emulated_vs_torch(monkeypatch, emu, case, variant):
     from tracknetv3_amd import ops
@@ -309,6 +309,29 @@ def test_conv3x3_wino_balanced_kernel_is_bit_identical_to_the_xi_split_kernel(em
     assert ops.wino_layout(3) == 0 and ops.wino_layout(4) == 1
     assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=3))
     assert torch.equal(want, ops.conv3x3_wino(x, ops.pack_wino_weights(wt, variant=4), cout, variant=4))      # quad operand layouts
+    assert ops.wino_layout(5) == 0
+    assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=5))                                         # persistent workgroups
+
+
+# more tiles than the 8 workgroups the emulated "8-CU device" launches: every persistent workgroup walks 2-4 tiles (XCD-aware
+# and generic block maps, entries of the padded grid that hold no tile, a last workgroup with fewer tiles than the others)
+WINO_PERSIST_CASES = [(3, 12, 64, 8, 128), (1, 27, 64, 12, 192), (2, 20, 128, 12, 64), (5, 8, 192, 4, 64)]
+
+
+@pytest.mark.parametrize("case", WINO_PERSIST_CASES)
+def test_conv3x3_wino_persistent_kernel_walks_several_tiles_per_workgroup(emu, monkeypatch, case):
+    """Variant 5 = variant 3 as persistent workgroups (one per CU, next tile's first DMAs issued before the output transform,
+    accumulators started from the MFMA's inline zero): bit-identical to variant 3, with the affine / addend / ReLU epilogue too."""
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = case
+    x, wt = torch.relu(T((n, cin, h, w), 91)), T((cout, cin, 3, 3), 92, -0.3, 0.3)
+    mean, scale, shift, add = T((cout,), 93), T((cout,), 94, 0.5, 1.5), T((cout,), 95), T((n, cout, h, w), 96)
+    u = ops.pack_wino_weights(wt, variant=3)
+    want = ops.conv3x3_wino(x, u, cout, variant=3)
+    want_full = ops.conv3x3_wino(x, u, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=3)
+    monkeypatch.setenv("TNV3_EMU_CUS", "8")
+    assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=5))
+    assert torch.equal(want_full, ops.conv3x3_wino(x, u, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=5))
 
 
 def test_inpaintnet_fused_kernel_emulated_vs_layer_kernels_and_oracle(emu, monkeypatch):

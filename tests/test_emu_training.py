@@ -317,8 +317,9 @@ def test_head_sigmoid_wbce_fused_both_directions_emulated(emu):
         assert rel_err(da, da_ref) <= 1e-6 and rel_err(dw, dw_ref) <= 1e-6 and rel_err(db, db_ref) <= 1e-6
 
 
-@pytest.mark.parametrize("case", [(2, 16, 64, 8, 64, False), (1, 24, 128, 4, 128, True)], ids=["plain", "with_addend"])
-def test_bn_statistics_from_the_conv_epilogue_emulated(emu, case):
+@pytest.mark.parametrize("variant", [3, 5], ids=["balanced", "persistent"])
+@pytest.mark.parametrize("case", [(2, 16, 64, 8, 64, False), (1, 24, 128, 4, 128, True), (3, 16, 64, 12, 128, True)], ids=["plain", "with_addend", "18_tiles"])
+def test_bn_statistics_from_the_conv_epilogue_emulated(emu, monkeypatch, case, variant):
     """conv3x3_wino_stats: the raw output is bit-identical to conv3x3_wino and the per-tile (sum, sum of squares) fold to the
     batch statistics; bn_train_forward(tile_stats=...) equals the pass over z (same finalize arithmetic)."""
     from tracknetv3_amd import ops
@@ -326,8 +327,9 @@ def test_bn_statistics_from_the_conv_epilogue_emulated(emu, case):
     x, wt = torch.relu(T((n, cin, h, w), 61)), T((cout, cin, 3, 3), 62, -0.3, 0.3)
     add = T((n, cout, h, w), 63) if with_add else None
     u = ops.pack_wino_weights(wt)
-    z_ref = ops.conv3x3_wino(x, u, cout, addend=add)
-    z, stats = ops.conv3x3_wino_stats(x, u, cout, addend=add)
+    z_ref = ops.conv3x3_wino(x, u, cout, addend=add, variant=3)
+    monkeypatch.setenv("TNV3_EMU_CUS", "8")           # the persistent kernel walks several tiles per workgroup in the third case
+    z, stats = ops.conv3x3_wino_stats(x, u, cout, addend=add, variant=variant)
     assert torch.equal(z, z_ref)
     assert stats.shape == (cout, n * (h // 4) * (w // 64), 2) and stats.dtype == torch.float64
     s1, s2 = stats[:, :, 0].sum(1), stats[:, :, 1].sum(1)

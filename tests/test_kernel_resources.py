@@ -16,21 +16,29 @@ def resources(tmp_path_factory):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("res") / "capi.s"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value", "-Wno-cuda-compat", "-DTNV3_TU_ALL",
-                        "-Rpass-analysis=kernel-resource-usage", "-o", str(out),
-                        os.path.join(ROOT, "tracknetv3_amd", "csrc", "tnv3_capi.hip")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
+    from concurrent.futures import ThreadPoolExecutor
+    from tracknetv3_amd import _build
+    tmp = tmp_path_factory.mktemp("res")
+
+    def one(fam):                                     # same per-family flags as the product build (tracknetv3_amd/_build.py)
+        return subprocess.run([hipcc] + [f for f in _build.FLAGS if f != "-fPIC"] + _build.FAMILY_FLAGS.get(fam, []) +
+                              ["-S", "--cuda-device-only", f"-DTNV3_TU_{fam}", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp / f"{fam}.s"),
+                               os.path.join(ROOT, "tracknetv3_amd", "csrc", "tnv3_capi.hip")], capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(_build.FAMILIES), os.cpu_count() or 1)) as pool:
+        runs = list(pool.map(one, _build.FAMILIES))
     kernels, cur = {}, None
-    for line in r.stderr.splitlines():
-        m = re.search(r"Function Name: (\S+)", line)
-        if m:
-            cur = m.group(1)
-            kernels[cur] = {}
-            continue
-        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
-        if m and cur:
-            kernels[cur][m.group(1).strip()] = int(m.group(2))
+    for r in runs:
+        assert r.returncode == 0, r.stderr[-2000:]
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = m.group(1)
+                kernels[cur] = {}
+                continue
+            m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+            if m and cur:
+                kernels[cur][m.group(1).strip()] = int(m.group(2))
     assert len(kernels) > 30
     return kernels
 
@@ -67,7 +75,7 @@ def test_conv_and_wgrad_budgets(resources):
     k = _find(resources, "conv3x3_wino_split_mfma_kernelINS_12WinoSplitCfgILi8ELi0E")  # production: 128 accumulators, TWO waves per SIMD
     assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0
     assert k["LDS Size [bytes/block]"] <= 160 * 1024                                    # two filter + two V + two raw stages
-    for args in ("Li8ELi0ELi0ELi0ELi0ELi0E", "Li8ELi0ELi0ELi0ELi1ELi0E"):            # variant 3 (the default) and 4: the same budget
+    for args in ("Li8ELi0ELi0ELi0ELi0ELi0ELi0E", "Li8ELi0ELi0ELi0ELi1ELi0ELi0E", "Li8ELi0ELi0ELi0ELi0ELi0ELi1E"):   # variants 3, 4 and 5 (persistent): the same budget
         k = _find(resources, "conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgI" + args)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024

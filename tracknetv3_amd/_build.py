@@ -18,6 +18,10 @@ DIAG_LIB = os.path.join(PKG_DIR, "libtnv3_diag.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 FAMILIES = ("MISC", "CONV", "WINO", "UP2X", "WGRAD", "TRAIN")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-cuda-compat"]
+# Per-family extras.  The Winograd kernels are compiled without the SLP vectoriser: it pairs the fp32 adds of the patch / output
+# transforms into v_pk_add_f32 at the price of a v_mov per operand pair (61 instead of 56 vector instructions per chunk) and of
+# ~40 temporaries in the output transform, which pushed the persistent kernel past its 256-register budget (26 spills).
+FAMILY_FLAGS = {"WINO": ["-fno-slp-vectorize"], "DIAG": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -65,7 +69,7 @@ def _compile(hipcc, tag, defines, verbose):
     deps = _dep_files(dep)
     if os.path.exists(obj) and deps is not None and not _newer_than(obj, deps + [__file__]):
         return obj, False
-    cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-MD", "-MF", dep, "-c", SRC, "-o", obj + ".tmp"]
+    cmd = [hipcc] + FLAGS + FAMILY_FLAGS.get(tag, []) + [f"-D{d}" for d in defines] + ["-MD", "-MF", dep, "-c", SRC, "-o", obj + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

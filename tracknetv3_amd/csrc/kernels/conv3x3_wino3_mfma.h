@@ -29,6 +29,7 @@
 //      transform stores rows as ds_write_b128 (4 instead of 8 stores), and the LDS-DMA destinations are scalar (2 instead of
 //      4 instructions per piece).  Every accumulator still sees its channel pairs in the same order => the same bits.
 #pragma once
+#include <type_traits>
 #include "conv3x3_wino_mfma.h"
 
 namespace tnv3 {
@@ -43,12 +44,37 @@ __device__ __forceinline__ tnv3_rsrc_t tnv3_make_rsrc(const void* base, unsigned
 __device__ __forceinline__ void tnv3_buf_dma16(tnv3_rsrc_t r, float* lds_base, unsigned voffset) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)voffset, 0, 0, 0);
 }
+// 8-byte load / store at base + voffset (per lane, bytes) + soffset (scalar, bytes): no vector address arithmetic per access
+typedef float tnv3_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned tnv3_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tnv3_f2 tnv3_buf_load_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
+  return __builtin_bit_cast(tnv3_f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voffset, (int)soffset, 0));
+}
+__device__ __forceinline__ void tnv3_buf_store_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(tnv3_u2, v), r, (int)voffset, (int)soffset, 0);
+}
+#endif
+
+// Makes a per-lane value opaque to the optimiser at this point: what is derived from it afterwards cannot be hoisted out of the
+// enclosing loop (the persistent kernel's per-tile code would otherwise park ~80 loop-invariant VGPRs across the MFMA loop).
+#ifdef TNV3_EMU
+#define TNV3_OPAQUE_V(x) ((void)0)
+#else
+#define TNV3_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #endif
 
 constexpr unsigned kDmaOob = 0x80000000u;      // voffset of a padding lane: beyond any descriptor (num_records < 2^31)
 
-template <int CC_, int DIAG_ = 0, int DMA_MODE_ = 0, int PRIO_ = 0, int QUAD_ = 0, int SYM_ = 0>
+template <int CC_, int DIAG_ = 0, int DMA_MODE_ = 0, int PRIO_ = 0, int QUAD_ = 0, int SYM_ = 0, int PERSIST_ = 0>
 struct WinoV3Cfg {
+  // 1: persistent workgroups (variant 5).  The launch has one workgroup per CU and each walks the tile list with the grid as its
+  // stride (same XCD as the one-tile-per-workgroup launch gives that tile).  One workgroup fills a CU (512 threads x 256
+  // registers, 150 KB of LDS), so nothing of a tile's fixed cost -- workgroup launch, index set-up, 128 accumulator writes,
+  // the first DMA's round trip to HBM, the output transform and its stores: ~18 000 cycles, i.e. three chunk periods, 29 % of
+  // a 64-channel layer -- overlaps anything.  The loop removes the launch and set-up, issues the NEXT tile's first DMAs before
+  // the output transform of the current one (the exchange buffer moves from the filter stages to the V stages for that) and
+  // starts each accumulator from the MFMA's inline zero.  Same arithmetic in the same order => the same bits.
+  static constexpr int PERSIST = PERSIST_;
   // 1: both wave groups run the SAME program per chunk -- MFMAs, then their DMA pieces, then their transform rows -- instead of
   // opposite orders.  Non-MFMA work of one wave does not hide under the other wave's fp32 MFMAs anyway (header comment), and
   // next to an MFMA stream it crawls (one instruction per MFMA slot: a 700-cycle transform takes 2800); in lockstep both waves
@@ -100,13 +126,21 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
   const int tilesH = H / 4, tilesW = W / PW;
   const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
-  int mb, pt;
-  if (!conv_block_map(blockIdx.x, nMB, nPT, mb, pt)) return;
-  const int n = pt / (tilesH * tilesW);
-  const int trem = pt - n * (tilesH * tilesW);
-  const int h0 = (trem / tilesW) * 4, w0 = (trem % tilesW) * PW;
-  const int m0 = mb * MB;
   const int nChunks = (Cin + CC - 1) / CC;
+  // tile list: entry b of the XCD-aware order (conv_block_map); a persistent workgroup takes b = blockIdx.x, + gridDim.x, ...
+  const int nItems = Cfg::PERSIST ? conv_grid_blocks(nMB, nPT) : 0;
+  int item = blockIdx.x;
+  int mb, pt;
+  if constexpr (Cfg::PERSIST) {
+    while (item < nItems && !conv_block_map(item, nMB, nPT, mb, pt)) item += gridDim.x;
+    if (item >= nItems) return;
+  } else {
+    if (!conv_block_map(item, nMB, nPT, mb, pt)) return;
+  }
+  int n = pt / (tilesH * tilesW);
+  int trem = pt - n * (tilesH * tilesW);
+  int h0 = (trem / tilesW) * 4, w0 = (trem % tilesW) * PW;
+  int m0 = mb * MB;
 
   // ---- chunk-invariant per-lane byte offsets of this thread's DMA pieces
   unsigned vo_u[NU4], vo_r[NRAW];
@@ -121,17 +155,24 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
       vo_u[i] = (unsigned)(row * Cout + m4 * 4) * 4u;
     }
   }
+  const float* u_base;
+  const float* x_base;
+  auto set_item = [&]() {                               // what changes from tile to tile: the raw pieces' offsets and the two bases
+    int t_op = tid;
+    if constexpr (Cfg::PERSIST) TNV3_OPAQUE_V(t_op);
 #pragma unroll
-  for (int i = 0; i < NRAW; ++i) {                    // raw piece e of [CC][6][RW/4]; padding / unused slots read out of range (= 0)
-    const int e = (tid & (NTD - 1)) + i * NTD;
-    const int c = e / (RAWP / 4), r = e - c * (RAWP / 4);
-    const int tr = r / (RW / 4), q = r - tr * (RW / 4);
-    const int gh = h0 - 1 + tr, gw = w0 - 4 + 4 * q;
-    const bool ok = e < Cfg::RAW_FLOATS / 4 && gh >= 0 && gh < H && gw >= 0 && gw < W;
-    vo_r[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
-  }
-  const float* u_base = a.u + (Cfg::QUAD ? (size_t)m0 * 4 : (size_t)m0);
-  const float* x_base = a.src + (size_t)n * Cin * HW;
+    for (int i = 0; i < NRAW; ++i) {                  // raw piece e of [CC][6][RW/4]; padding / unused slots read out of range (= 0)
+      const int e = (t_op & (NTD - 1)) + i * NTD;
+      const int c = e / (RAWP / 4), r = e - c * (RAWP / 4);
+      const int tr = r / (RW / 4), q = r - tr * (RW / 4);
+      const int gh = h0 - 1 + tr, gw = w0 - 4 + 4 * q;
+      const bool ok = e < Cfg::RAW_FLOATS / 4 && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      vo_r[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
+    }
+    u_base = a.u + (Cfg::QUAD ? (size_t)m0 * 4 : (size_t)m0);
+    x_base = a.src + (size_t)n * Cin * HW;
+  };
+  set_item();
   const int wbase = __builtin_amdgcn_readfirstlane((wave & (NTD / 64 - 1)) * 64);      // scalar: the LDS-DMA destinations (M0) stay on the SALU
   // half h (0: issued by group 0 at the start of the chunk, 1: by group 1 after its MFMAs) of the DMAs of one chunk:
   // filters of chunk ku -> stage ku & 1, raw tile of chunk kr -> stage kr & 1.  A thread moves its own NU4 + NRAW pieces.
@@ -199,17 +240,23 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
   };
 
   f32x16 acc[8];
+  if constexpr (!Cfg::PERSIST) {
 #pragma unroll
-  for (int x = 0; x < 8; ++x)
+    for (int x = 0; x < 8; ++x)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+  }
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
 
   const int a_off = (half * 16 + grp * 8) * MB + wm * 32 + bl;
   const int b_off = (half * 16 + grp * 8) * TB + wn * 32 + bl;
   // quad form: float offsets of this lane's 16-byte operand groups inside a stage: [pair][row][parity][64][4], row = 2*grp + j
   const int aq_off = ((2 * grp * 2 + half) * MB + wm * 32 + bl) * 4;
   const int bq_off = ((2 * grp * 2 + half) * TB + wn * 32 + bl) * 4;
-  auto mfma_chunk = [&](int k) {
+  auto mfma_chunk = [&](int k, auto first_c) {          // first_c: the tile's first chunk starts every accumulator from the inline zero
+    constexpr bool FIRST = decltype(first_c)::value;
     if constexpr (Cfg::QUAD) {
       const float* A = u_s + (k & 1) * Cfg::U_FLOATS + aq_off;
       const float* B = v_s + (k & 1) * Cfg::V_FLOATS + bq_off;
@@ -231,7 +278,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int x = 0; x < 4; ++x)
-            acc[j * 4 + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cp & 1][j][x], bv[cp & 1][j][x], acc[j * 4 + x], 0, 0, 0);
+            acc[j * 4 + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cp & 1][j][x], bv[cp & 1][j][x], FIRST && cp == 0 ? zero16 : acc[j * 4 + x], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       return;
@@ -251,7 +298,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       if (s + PF < NSTEP) read_step(s + PF);
-      acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s & 7], 0, 0, 0);
+      acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], FIRST && s < 8 ? zero16 : acc[s & 7], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
@@ -263,8 +310,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
   };
 
   unsigned long long t_acc0 = 0, t_acc1 = 0, t_acc2 = 0, t_acc3 = 0, t_acc4 = 0, t_acc5 = 0, t_last = 0;
-  auto stamp = [&](int slot) {
-    if constexpr (Cfg::DIAG == 7) {
+  auto stamp_to = [&](int slot) {
+    {
       __builtin_amdgcn_sched_barrier(0);
       const unsigned long long now = __builtin_amdgcn_s_memtime();
       const unsigned long long dcy = now - t_last;
@@ -274,35 +321,40 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  auto stamp = [&](int slot) {
+    if constexpr (Cfg::DIAG == 7) stamp_to(slot);
+  };
 
-  // prologue: filters of chunk 0, raw tiles of chunks 0 and 1 (every thread its own pieces), then V_0
-  if (DMA_MODE != 1 || grp == 1) {
-    dma_chunk(0, 0);
-    dma_chunk(nChunks, 1);
-  }
-  chunk_barrier();
-  transform(0);
-  chunk_barrier();
-  for (int k = 0; k < nChunks; ++k) {
+  auto stamp8 = [&](int slot) {                         // DIAG 8: per-tile fixed-cost phases of a persistent workgroup
+    if constexpr (Cfg::DIAG == 8) stamp_to(slot);
+  };
+  // first DMAs of a tile: filters of chunk 0, raw tiles of chunks 0 and 1 (every thread its own pieces)
+  auto issue_first = [&]() {
+    if (DMA_MODE != 1 || grp == 1) {
+      dma_chunk(0, 0);
+      dma_chunk(nChunks, 1);
+    }
+  };
+  auto chunk_body = [&](int k, auto first_c) {
     // free since the barrier that ended chunk k-1: filter stage (k+1)&1 (held chunk k-1), raw stage k&1 (held chunk k,
     // transformed during chunk k-1) and V stage (k+1)&1 (read by the MFMAs of chunk k-1)
     const bool more = k + 1 < nChunks;
     stamp(0);
     if (grp == 0 && !Cfg::SYM) {
       if (Cfg::PRIO) __builtin_amdgcn_s_setprio(3);
-      // group 0 issues its pieces of BOTH halves' worth?  No: each thread owns NU4 + NRAW pieces of the chunk; group 0's
-      // threads issue theirs now, group 1's threads theirs after the MFMAs -- half of the chunk's bytes each.
+      // each thread owns NU4 + NRAW pieces of the chunk; group 0's threads issue theirs now, group 1's threads theirs after
+      // the MFMAs -- half of the chunk's bytes each.
       if (DMA_MODE == 0) dma_chunk(k + 1, k + 2);
       stamp(1);
       if (more) transform((k + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
       if (Cfg::PRIO) __builtin_amdgcn_s_setprio(0);
       stamp(2);
-      mfma_chunk(k);
+      mfma_chunk(k, first_c);
       stamp(3);
       if (DMA_MODE == 2) { __builtin_amdgcn_sched_barrier(0); dma_chunk(k + 1, k + 2); }
     } else {
-      mfma_chunk(k);
+      mfma_chunk(k, first_c);
       __builtin_amdgcn_sched_barrier(0);
       if (Cfg::PRIO) __builtin_amdgcn_s_setprio(3);
       stamp(1);
@@ -322,7 +374,25 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
     } else {
       chunk_barrier();
     }
+  };
+
+  unsigned long long t_begin = 0;
+  int n_items_done = 0;
+  if constexpr (Cfg::DIAG == 8) { t_begin = __builtin_amdgcn_s_memtime(); t_last = t_begin; }
+  issue_first();
+  for (;;) {                                            // one pass per tile; a non-persistent workgroup leaves after the first
+  chunk_barrier();                                      // first DMAs landed; (persistent) everybody is done with the exchange buffer
+  stamp8(0);
+  transform(0);
+  chunk_barrier();
+  stamp8(1);
+  if constexpr (Cfg::PERSIST) {
+    chunk_body(0, std::true_type{});
+    for (int k = 1; k < nChunks; ++k) chunk_body(k, std::false_type{});
+  } else {
+    for (int k = 0; k < nChunks; ++k) chunk_body(k, std::false_type{});
   }
+  stamp8(2);
   if constexpr (Cfg::DIAG == 7) {
     float keep = 0.0f;                                     // the accumulators must stay live or the MFMAs are dead code
 #pragma unroll
@@ -337,54 +407,101 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
     return;
   }
 
-  // ---- inverse transform: rows of A^T M (this group's two xi rows), columns, then the halves meet through LDS
-  float pv[16][2][2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float tt[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float lo = acc[j][r], hi = acc[4 + j][r];    // M rows 2*grp and 2*grp + 1
-      tt[0][j] = grp ? lo : lo + hi;                     // A^T row 0 = [1 1 1 0]
-      tt[1][j] = grp ? -lo - hi : hi;                    // A^T row 1 = [0 1 -1 -1]
-    }
-#pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      pv[r][y][0] = tt[y][0] + tt[y][1] + tt[y][2];
-      pv[r][y][1] = tt[y][1] - tt[y][2] - tt[y][3];
+  // ---- the tile whose accumulators are complete; a persistent workgroup moves on to its next tile and gets that one's first
+  //      DMAs going (filter stage 0, both raw stages: all free since the last chunk barrier) before it writes this one out
+  const int e_n = n, e_h0 = h0, e_w0 = w0, e_m0 = m0, e_pt = pt;
+  bool have_next = false;
+  if constexpr (Cfg::PERSIST) {
+    item += gridDim.x;
+    while (item < nItems && !conv_block_map(item, nMB, nPT, mb, pt)) item += gridDim.x;
+    have_next = item < nItems;
+    if (have_next) {
+      n = pt / (tilesH * tilesW);
+      trem = pt - n * (tilesH * tilesW);
+      h0 = (trem / tilesW) * 4; w0 = (trem % tilesW) * PW;
+      m0 = mb * MB;
+      set_item();
+      issue_first();
     }
   }
-  float* xch = lds;                                      // all stages are free after the last chunk barrier
+  stamp8(3);
+
+  // ---- inverse transform: rows of A^T M (this group's two xi rows), columns, then the halves meet through LDS
+  int tid_e = threadIdx.x;
+  if constexpr (Cfg::PERSIST) TNV3_OPAQUE_V(tid_e);     // the write-out's lane arithmetic is redone per tile, not kept live across the MFMA loop
+  const int tid = tid_e, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wq = wave & 3;
+  const int wn = wq % WN, wm = wq / WN, half = lane >> 5, bl = lane & 31;
+  // group g finishes output row g of every tile: `own` is its partial sum of that row; its partial sum of the other row goes
+  // to the partner wave through LDS.  The group is wave-uniform: one scalar branch, no per-element selects.
+  float* xch = Cfg::PERSIST ? v_s : lds;                 // all stages are free after the last chunk barrier; the persistent form has
+                                                         // the next tile's filters on their way into the filter stages
+  float own[16][2];
+  auto out_rows = [&](auto gc) {
+    constexpr int G = decltype(gc)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float tt[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = acc[j][r], hi = acc[4 + j][r];  // M rows 2*grp and 2*grp + 1
+        tt[0][j] = G ? lo : lo + hi;                     // A^T row 0 = [1 1 1 0]
+        tt[1][j] = G ? -lo - hi : hi;                    // A^T row 1 = [0 1 -1 -1]
+      }
+      float pv[2][2];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        pv[y][0] = tt[y][0] + tt[y][1] + tt[y][2];
+        pv[y][1] = tt[y][1] - tt[y][2] - tt[y][3];
+      }
+      own[r][0] = pv[G][0]; own[r][1] = pv[G][1];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) xch[(wave * 32 + r * 2 + x) * 64 + lane] = pv[1 - G][x];
+    }
+  };
+  if (__builtin_amdgcn_readfirstlane(grp)) out_rows(std::true_type{}); else out_rows(std::false_type{});
+  __syncthreads();
+  stamp8(4);
+  // write-out: every load this lane needs -- the partner's 32 partial sums, the 16 channels' BatchNorm constants (four 16-byte
+  // loads each: the lane's channels are 4 runs of 4), the addend -- is issued BEFORE the first use, and the 16 stores go out
+  // back to back through one scalar base per channel + one 32-bit lane offset (no per-store 64-bit address arithmetic, no
+  // s_waitcnt between a store and the next channel's loads: that chain used to cost 6000 cycles per tile).
+  const bool has_affine = a.scale != nullptr, has_mean = a.mean != nullptr, has_addend = a.addend != nullptr;
+  const int t = wn * 32 + bl;
+  const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
+  const int oh = e_h0 + 2 * tr + grp, ow = e_w0 + 2 * tc;
+  // bytes from channel plane (n, m0) to this lane's pixel pair (< 2^31: host check): the one per-lane part of every address below.
+  // The 64 planes of the tile's channel block sit behind one buffer descriptor; channel r of the lane's run is a scalar offset.
+  const unsigned lane_off_b = (unsigned)((wm * 32 + 4 * half) * HW + oh * W + ow) * 4u;
+  const size_t plane0 = ((size_t)e_n * Cout + e_m0) * HW;
+  const unsigned planes_b = (unsigned)MB * (unsigned)HW * 4u;
+  const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
+  auto chan_off = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)HW * 4u; };
+  float got[16][2];
 #pragma unroll
   for (int r = 0; r < 16; ++r)
 #pragma unroll
-    for (int x = 0; x < 2; ++x) xch[(wave * 32 + r * 2 + x) * 64 + lane] = grp ? pv[r][0][x] : pv[r][1][x];
-  __syncthreads();
-  const bool has_affine = a.scale != nullptr;
-  const int t = wn * 32 + bl;
-  const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
-  const int oh = h0 + 2 * tr + grp, ow = w0 + 2 * tc;    // group g finishes output row g of the tile
-  const bool want_stats = a.stats != nullptr;            // wave-uniform (kernel argument)
-  double q1[16], q2[16];                                 // this lane's two pixels per channel r: sum, sum of squares
+    for (int x = 0; x < 2; ++x) got[r][x] = xch[((wave ^ 4) * 32 + r * 2 + x) * 64 + lane];
+  typedef float wf2 __attribute__((ext_vector_type(2)));
+  wf2 ad[16];
+  if (has_addend) {
+    const tnv3_rsrc_t r_add = tnv3_make_rsrc(a.addend + plane0, planes_b);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    wf2 v;
-    v[0] = (grp ? pv[r][1][0] : pv[r][0][0]) + xch[((wave ^ 4) * 32 + r * 2 + 0) * 64 + lane];
-    v[1] = (grp ? pv[r][1][1] : pv[r][0][1]) + xch[((wave ^ 4) * 32 + r * 2 + 1) * 64 + lane];
-    float mu = 0.0f, sc = 1.0f, sh = 0.0f;
-    if (has_affine) { mu = a.mean ? a.mean[co] : 0.0f; sc = a.scale[co]; sh = a.shift[co]; }
-    const size_t o = ((size_t)n * Cout + co) * HW + (size_t)oh * W + ow;
-    if (a.addend) { const wf2 ad = *reinterpret_cast<const wf2*>(a.addend + o); v[0] += ad[0]; v[1] += ad[1]; }
-    if (has_affine) { v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh; }
-    if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
-    *reinterpret_cast<wf2*>(a.dst + o) = v;
-    if (want_stats) {
+    for (int r = 0; r < 16; ++r) ad[r] = tnv3_buf_load_f2(r_add, lane_off_b, chan_off(r));
+  }
+  const bool want_stats = a.stats != nullptr;            // wave-uniform (kernel argument); never together with the affine (host check)
+  if (want_stats) {                                      // training forward: raw convolution (+ addend) out, statistics from the same registers
+    double q1[16], q2[16];                               // this lane's two pixels per channel r: sum, sum of squares
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      wf2 v;
+      v[0] = own[r][0] + got[r][0];
+      v[1] = own[r][1] + got[r][1];
+      if (has_addend) { v[0] += ad[r][0]; v[1] += ad[r][1]; }
+      if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
+      tnv3_buf_store_f2(r_dst, lane_off_b, chan_off(r), v);
       q1[r] = (double)v[0] + (double)v[1];
       q2[r] = (double)v[0] * (double)v[0] + (double)v[1] * (double)v[1];
     }
-  }
-  if (want_stats) {
     // BatchNorm batch statistics from the epilogue's registers (model.py:9 in training mode): a half-wave holds 32 tiles x 2 pixels
     // of 16 channels.  Reduce-scatter butterfly over the 32 lanes: at offset o the lane keeps the half of its channel list its
     // bit selects and adds the partner's copy of that half -- 8 + 4 + 2 + 1 exchanges, then one plain exchange at offset 1;
@@ -406,7 +523,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
     q1[0] += __shfl_xor(q1[0], 1, 64);
     q2[0] += __shfl_xor(q2[0], 1, 64);
     __syncthreads();                                       // everybody has read the exchange buffer: LDS is free again
-    double* red = reinterpret_cast<double*>(lds);          // [wave][half][16 r][2]
+    double* red = reinterpret_cast<double*>(xch);          // [wave][half][16 r][2]
     if ((bl & 1) == 0) {
       double* d = red + ((wave * 2 + half) * 16 + (bl >> 1)) * 2;
       d[0] = q1[0];
@@ -425,9 +542,51 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
           s1 += d[0];
           s2 += d[1];
         }
-      double* o = a.stats + ((size_t)(m0 + tid) * nPT + pt) * 2;
+      double* o = a.stats + ((size_t)(e_m0 + tid) * nPT + e_pt) * 2;
       o[0] = s1;
       o[1] = s2;
+    }
+  } else {
+    f32x4 mu4[4], sc4[4], sh4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mu4[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; sc4[q] = f32x4{1.0f, 1.0f, 1.0f, 1.0f}; sh4[q] = mu4[q];
+    }
+    if (has_affine) {
+      const int c4 = e_m0 + wm * 32 + 4 * half;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sc4[q] = *reinterpret_cast<const f32x4*>(a.scale + c4 + 8 * q);
+        sh4[q] = *reinterpret_cast<const f32x4*>(a.shift + c4 + 8 * q);
+      }
+      if (has_mean) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mu4[q] = *reinterpret_cast<const f32x4*>(a.mean + c4 + 8 * q);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      wf2 v;
+      v[0] = own[r][0] + got[r][0];
+      v[1] = own[r][1] + got[r][1];
+      if (has_addend) { v[0] += ad[r][0]; v[1] += ad[r][1]; }
+      if (has_affine) {
+        const float mu = mu4[r >> 2][r & 3], sc = sc4[r >> 2][r & 3], sh = sh4[r >> 2][r & 3];
+        v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh;
+      }
+      if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
+      tnv3_buf_store_f2(r_dst, lane_off_b, chan_off(r), v);
+    }
+  }
+  stamp8(5);
+  ++n_items_done;
+  if (!have_next) break;
+  }                                                     // tile loop
+  if constexpr (Cfg::DIAG == 8) {                       // phase totals of one workgroup, behind the N-th image of dst (the caller allocates N + 1)
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dst + (size_t)a.N * Cout * HW) + wave * 8;
+      o[0] = t_acc0; o[1] = t_acc1; o[2] = t_acc2; o[3] = t_acc3; o[4] = t_acc4; o[5] = t_acc5;
+      o[6] = (unsigned long long)n_items_done; o[7] = __builtin_amdgcn_s_memtime() - t_begin;
     }
   }
 }

@@ -8,12 +8,12 @@
 // arithmetic; in fp32 the +-1, 1/2 transforms cost ~3x the rounding noise of the direct chain (6e-7 vs 2e-7 of the
 // output scale per layer, measured) -- two orders below the 1e-4 heat-map bar.
 //
-// Three kernels share the tile (64 output channels x 64 tiles = 4 x 64 pixels per workgroup, 8-channel chunks) and the
+// Two kernels here (and the third-generation kernel of conv3x3_wino3_mfma.h, variants 3-5) share the tile (64 output channels x 64 tiles = 4 x 64 pixels per workgroup, 8-channel chunks) and the
 // packed filter panel:
 //   conv3x3_wino_split_mfma_kernel  the production one (tnv3_conv3x3_wino_variant 2): eight waves, the 16 xi split over
 //                                   two wave groups (128 accumulators per wave, two waves per SIMD), one barrier per chunk;
-//   conv3x3_wino_mfma_kernel        its predecessor (variant 0): four waves, one per SIMD, described first below;
-//   conv3x3_wino_il_mfma_kernel     variant 1: the transform interleaved into the MFMA stream (measured slower).
+//   conv3x3_wino_mfma_kernel        its predecessor (variant 0): four waves, one per SIMD, described first below.
+// (Variant 1 -- the patch transform interleaved into the MFMA stream, 20 % slower in round 1 -- was removed in round 2.)
 // Mapping (first kernel): MFMA 32x32x2 with M = 32 output channels, N = 32 tiles (2 tile rows x 16 tile columns = 4 x 32 pixels),
 // K = 2 input channels; a wave keeps ALL 16 xi of its 32 x 32 tile (256 accumulator registers, one wave per SIMD) so the
 // inverse transform happens in registers.  Per chunk of CC channels a workgroup stages the raw halo tile and the
@@ -205,211 +205,6 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_mfma_kernel(const WinoAr
       if (Cfg::DIAG < 3) publish_lds();
     }
   }
-
-  // ---- inverse transform A^T M A in registers, affine + ReLU, two 8-byte stores per (channel, tile)
-  const bool has_affine = a.scale != nullptr;
-  const int t = wn * 32 + bl;
-  const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
-  const int oh = h0 + 2 * tr, ow = w0 + 2 * tc;
-  typedef float wf2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    float tt[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float m0j = acc[j][r], m1j = acc[4 + j][r], m2j = acc[8 + j][r], m3j = acc[12 + j][r];
-      tt[0][j] = m0j + m1j + m2j;
-      tt[1][j] = m1j - m2j - m3j;
-    }
-    float mu = 0.0f, sc = 1.0f, sh = 0.0f;
-    if (has_affine) { mu = a.mean ? a.mean[co] : 0.0f; sc = a.scale[co]; sh = a.shift[co]; }
-    const size_t plane = ((size_t)n * Cout + co) * HW;
-#pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      wf2 v;
-      v[0] = tt[y][0] + tt[y][1] + tt[y][2];
-      v[1] = tt[y][1] - tt[y][2] - tt[y][3];
-      const size_t o = plane + (size_t)(oh + y) * W + ow;
-      if (a.addend) { const wf2 ad = *reinterpret_cast<const wf2*>(a.addend + o); v[0] += ad[0]; v[1] += ad[1]; }
-      if (has_affine) { v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh; }
-      if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
-      *reinterpret_cast<wf2*>(a.dst + o) = v;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Interleaved variant: the patch transform of chunk k+1 is spread over the MFMA stream of chunk k (one small slice of it
-// after every third MFMA, in the shadow of the 64-cycle matrix instructions) and writes a SECOND V stage, so a chunk
-// costs its MFMAs plus one barrier.  The raw tile is therefore needed one chunk earlier than the filters: filters are
-// fetched two chunks ahead, raw tiles three (three stages each); 6-channel chunks make everything fit in 154 KB.
-template <int WM_, int WN_, int CC_>
-struct WinoIlCfg {
-  static constexpr int WM = WM_, WN = WN_, CC = CC_;
-  static constexpr int NT = WM * WN * 64;
-  static constexpr int MB = 32 * WM, TB = 32 * WN, PW = 32 * WN;
-  static constexpr int RW = PW + 2, RAWP = 6 * RW;
-  static constexpr int RAW_FLOATS = CC * RAWP;
-  static constexpr int U_FLOATS = CC * 16 * MB, V_FLOATS = CC * 16 * TB;
-  static constexpr int NU4 = U_FLOATS / 4 / NT;
-  static constexpr int NRAW = (RAW_FLOATS + NT - 1) / NT;
-  static constexpr int RAW_STAGE = NRAW * NT;
-  static constexpr int NPAIR = (CC * TB + NT - 1) / NT;
-  static constexpr int NSTEP = (CC / 2) * 16;
-  static constexpr int DMA_PER_CHUNK = NU4 + NRAW;
-  static constexpr int V_DUMMY = 16 * TB;               // sink of the transform slots beyond CC*TB (keeps the stream branch-free)
-  static constexpr int LDS_FLOATS = 3 * U_FLOATS + 2 * V_FLOATS + V_DUMMY + 3 * RAW_STAGE;
-  static_assert((U_FLOATS / 4) % NT == 0, "filter panel must deal evenly");
-  static_assert(CC % 2 == 0, "one MFMA = 2 channels");
-  static_assert(NPAIR * 8 <= (NSTEP + 2) / 3, "eight transform slices per patch, one after every third MFMA of a chunk");
-};
-
-template <class Cfg>
-__global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_il_mfma_kernel(const WinoArgs a) {
-  constexpr int WN = Cfg::WN, CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, PW = Cfg::PW, RW = Cfg::RW, RAWP = Cfg::RAWP;
-  constexpr int NU4 = Cfg::NU4, NRAW = Cfg::NRAW, NPAIR = Cfg::NPAIR, NSTEP = Cfg::NSTEP;
-  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  float* u_s = lds;                                   // three stages
-  float* v_s = lds + 3 * Cfg::U_FLOATS;               // two stages + the dummy sink
-  float* raw_s = v_s + 2 * Cfg::V_FLOATS + Cfg::V_DUMMY;   // three stages
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave % WN, wm = wave / WN;
-  const int half = lane >> 5, bl = lane & 31;
-  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
-  const int tilesH = H / 4, tilesW = W / PW;
-  const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
-  int mb, pt;
-  if (!conv_block_map(blockIdx.x, nMB, nPT, mb, pt)) return;
-  const int n = pt / (tilesH * tilesW);
-  const int trem = pt - n * (tilesH * tilesW);
-  const int h0 = (trem / tilesW) * 4, w0 = (trem % tilesW) * PW;
-  const int m0 = mb * MB;
-  const int nChunks = (Cin + CC - 1) / CC;
-
-  int so[NRAW];
-#pragma unroll
-  for (int i = 0; i < NRAW; ++i) {
-    const int e = tid + i * NT;
-    const int r = e % RAWP;
-    const int tr = r / RW, tc = r - tr * RW;
-    const int gh = h0 - 1 + tr, gw = w0 - 1 + tc;
-    so[i] = (e < Cfg::RAW_FLOATS && gh >= 0 && gh < H && gw >= 0 && gw < W) ? gh * W + gw : -1;
-  }
-  const float* zsrc = a.zeros + lane;
-  const float* zsrc16 = a.zeros + (lane & 15) * 4;
-  const int wbase = wave * 64;
-  // Every call issues exactly NU4 / NRAW DMA instructions per wave (chunks past the end read zeros), so the counted vmcnt
-  // below never depends on where in the K range the workgroup is.
-  auto dma_u = [&](int k) {
-    float* us = u_s + (k % 3) * Cfg::U_FLOATS;
-    const bool live = k < nChunks;
-    const float* usrc = a.u + (size_t)(live ? k : 0) * CC * 16 * Cout + m0;
-#pragma unroll
-    for (int i = 0; i < NU4; ++i) {
-      const int e4 = tid + i * NT;
-      const int row = e4 / (MB / 4), m4 = e4 - row * (MB / 4);
-      lds_dma16(live ? usrc + (size_t)row * Cout + m4 * 4 : zsrc16, us + (i * NT + wbase) * 4);
-    }
-  };
-  auto dma_raw = [&](int k) {
-    float* rs = raw_s + (k % 3) * Cfg::RAW_STAGE;
-    const float* base = a.src + ((size_t)n * Cin + (size_t)(k < nChunks ? k : 0) * CC) * HW;
-#pragma unroll
-    for (int i = 0; i < NRAW; ++i) {
-      const int c = (tid + i * NT) / RAWP;
-      const bool ok = so[i] >= 0 && k * CC + c < Cin;          // false for every lane of a chunk past the end
-      lds_dma4(ok ? base + (size_t)c * HW + so[i] : zsrc, rs + i * NT + wbase);
-    }
-  };
-  // transform slots of this thread: patch p = tid + q*NT; slots beyond CC*TB read a valid patch and write to the dummy sink
-  int t_src[NPAIR], t_dst[NPAIR];
-#pragma unroll
-  for (int q = 0; q < NPAIR; ++q) {
-    const int p = tid + q * NT;
-    const bool live = p < CC * TB;
-    const int pc = live ? p : tid;
-    const int c = pc / TB, t = pc - c * TB;
-    const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
-    t_src[q] = c * RAWP + (2 * tr) * RW + 2 * tc;
-    t_dst[q] = live ? (c * 16) * TB + t : 2 * Cfg::V_FLOATS + (tid & (TB - 1));       // relative to v_s (stage offset added for live slots)
-  }
-  float te[NPAIR][4][4];
-  // slice `sl` (0..7) of patch q: 0..3 = column j of B^T d, 4..7 = row r of (B^T d) B written to V
-  auto transform_slice = [&](int q, int sl, const float* rs, float* vdst, bool live_stage) {
-    if (sl < 4) {
-      const float* d = rs + t_src[q] + sl;
-      const float d0 = d[0], d1 = d[RW], d2 = d[2 * RW], d3 = d[3 * RW];
-      te[q][0][sl] = d0 - d2; te[q][1][sl] = d1 + d2; te[q][2][sl] = d2 - d1; te[q][3][sl] = d1 - d3;
-    } else {
-      const int r = sl - 4;
-      float* v = vdst + t_dst[q];
-      (void)live_stage;
-      v[(r * 4 + 0) * TB] = te[q][r][0] - te[q][r][2];
-      v[(r * 4 + 1) * TB] = te[q][r][1] + te[q][r][2];
-      v[(r * 4 + 2) * TB] = te[q][r][2] - te[q][r][1];
-      v[(r * 4 + 3) * TB] = te[q][r][1] - te[q][r][3];
-    }
-  };
-  // destination base of the V stage for live slots; dummy slots carry an absolute offset (2*V_FLOATS + ...) and must not move
-  auto vbase = [&](int q, int stage) -> float* {
-    return (tid + q * NT < CC * TB) ? v_s + stage * Cfg::V_FLOATS : v_s;
-  };
-
-  f32x16 acc[16];
-#pragma unroll
-  for (int x = 0; x < 16; ++x)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
-
-  const int a_off = half * 16 * MB + wm * 32 + bl;
-  const int b_off = half * 16 * TB + wn * 32 + bl;
-  auto publish_lds = [&]() {
-    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
-    __builtin_amdgcn_s_barrier();
-  };
-
-  // prologue: filters 0, 1 and raw tiles 0, 1, 2 (one exposed round trip per workgroup), then V_0
-  dma_u(0); dma_raw(0); dma_u(1); dma_raw(1); dma_raw(2);
-  __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int q = 0; q < NPAIR; ++q)
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl) transform_slice(q, sl, raw_s, vbase(q, 0), true);
-  publish_lds();
-
-  for (int k = 0; k < nChunks; ++k) {
-    // landed and visible here: U_k, U_{k+1}, raw_{k+1}, raw_{k+2}; V_k is complete
-    dma_u(k + 2);                                          // stage (k+2)%3 held U_{k-1}
-    dma_raw(k + 3);                                        // stage k%3 held raw_k (transformed during iteration k-1)
-    const float* A = u_s + (k % 3) * Cfg::U_FLOATS + a_off;
-    const float* B = v_s + (k & 1) * Cfg::V_FLOATS + b_off;
-    const float* rs = raw_s + ((k + 1) % 3) * Cfg::RAW_STAGE;
-    constexpr int PF = 4, RING = PF + 1;
-    float av[RING], bv[RING];
-    auto read_step = [&](int s) {
-      const int cp = s >> 4, xi = s & 15;
-      av[s % RING] = A[(2 * cp * 16 + xi) * MB];
-      bv[s % RING] = B[(2 * cp * 16 + xi) * TB];
-    };
-#pragma unroll
-    for (int s = 0; s < PF; ++s) read_step(s);
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      if (s + PF < NSTEP) read_step(s + PF);
-      if (s % 3 == 0 && s / 3 < NPAIR * 8) {               // one transform slice of chunk k+1 in the shadow of this MFMA
-        const int q = (s / 3) / 8, sl = (s / 3) % 8;
-        transform_slice(q, sl, rs, vbase(q, (k + 1) & 1), true);
-      }
-      acc[s & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s & 15], 0, 0, 0);
-    }
-    // U_{k+1}... are landed except what this iteration issued; V_{k+1} written; nobody reads V_k / U_k / raw_{k+1} any more
-    __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(Cfg::DMA_PER_CHUNK));
-    publish_lds();
-  }
-  __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));          // the (zero) DMAs of the chunks past the end must not outlive the workgroup's LDS
 
   // ---- inverse transform A^T M A in registers, affine + ReLU, two 8-byte stores per (channel, tile)
   const bool has_affine = a.scale != nullptr;

@@ -411,14 +411,16 @@ int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const fl
 // ---- Winograd F(2x2, 3x3) form of the plain eval-mode layer (kernels/conv3x3_wino_mfma.h)
 using WinoA = WinoCfg<2, 2, 8>;              // 64 channels x 64 tiles (4 x 64 pixels), 256 threads, 8-channel chunks
 using WinoSplit = WinoSplitCfg<8>;          // same tile, 512 threads: two wave groups split the 16 transform rows (2 waves / SIMD)
-using WinoIl = WinoIlCfg<2, 2, 6>;           // same tile, 6-channel chunks, patch transform interleaved with the MFMAs
 using WinoV3 = WinoV3Cfg<8>;                // same tile and operands as WinoSplit; balanced DMA issue, buffer-descriptor DMA, paired transform
 using WinoV4 = WinoV3Cfg<8, 0, 0, 0, 1>;    // + quad operand layouts (filter pack layout 1): 0.5 instead of 2 LDS reads per MFMA
+using WinoV5 = WinoV3Cfg<8, 0, 0, 0, 0, 0, 1>;   // WinoV3 as persistent workgroups (one per CU walking the tile list, next tile's DMAs before the output transform)
+// persistent launch: one workgroup per CU, a whole number of XCD rounds so that a workgroup's tiles all map to its XCD
+inline int wino_persistent_grid(int items) { const int g = std::max(8, num_cus() / 8 * 8); return items < g ? items : g; }
 // filter pack layout a kernel variant expects (tnv3_conv3x3_wino_layout)
 inline int conv3x3_wino_layout(int variant) { return (variant == 4 || variant == 47 || variant == 44) ? 1 : 0; }
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
 constexpr int kWinoDefaultVariant = 3;       // per-call `variant`: 3 WinoV3 (default: measured 6-12 % faster than 2), 2 WinoSplit, 4 WinoV4 (quad
-                                             // layouts), 0 WinoA (one wave / SIMD), 1 WinoIl; -1 = default
+                                             // layouts), 5 WinoV5 (persistent), 0 WinoA (one wave / SIMD); -1 = default
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
   return (size_t)round_up(cin, kWinoCinPad) * 16 * cout + kPackZeroTail;
@@ -452,7 +454,8 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
                               double* stats = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino: bad argument");
   if (variant < 0) variant = kWinoDefaultVariant;
-  if (stats && variant != 3 && variant != 4) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3 and 4");
+  if (stats && variant != 3 && variant != 4 && variant != 5) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3, 4 and 5");
+  if (stats && (scale || shift || mean)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue writes the raw convolution (no affine)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino: statistics buffer must be 8-byte aligned");
   if (!conv3x3_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
@@ -476,9 +479,12 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     default: break;
   }
 #endif
-  if (variant == 3 || variant == 4 || variant >= 30) {
+  if (variant == 3 || variant == 4 || variant == 5 || variant >= 30) {
     if ((long)cin * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variants 3, 4): one sample of the input must stay below 2 GiB");
     if ((long)cout * 16 * 8 * 16 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variants 3, 4): Cout too large");
+    if ((long)WinoV3::MB * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variants 3-5): 64 output planes must stay below 2 GiB");
+    if ((((uintptr_t)a.scale | (uintptr_t)a.shift | (uintptr_t)a.mean) & 15) != 0)
+      TNV3_FAIL(-1, "conv3x3_wino (variants 3-5): mean / scale / shift must be 16-byte aligned");
   }
 #ifdef TNV3_DIAG
   // timeline twins (phase totals instead of results) and the measured-and-rejected schedules of kernel 3 (results correct):
@@ -495,14 +501,17 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     case 51: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 2>>, grid3, WinoV3::NT, a);
     case 61: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 0, 1>>, grid3, WinoV3::NT, a);
     case 71: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 1, 1>>, grid3, WinoV3::NT, a);
+    // 83 / 85: variants 3 / 5 with the per-tile fixed-cost phases timed (results correct; totals behind the N-th image of dst)
+    case 83: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 8>>, grid3, WinoV3::NT, a);
+    case 85: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 8, 0, 0, 0, 0, 1>>, wino_persistent_grid(grid3), WinoV3::NT, a);
     default: break;
   }
 #endif
   switch (variant) {
+    case 5: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV5>, wino_persistent_grid(conv_grid_blocks(cout / WinoV5::MB, (int)npt)), WinoV5::NT, a);
     case 4: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV4>, conv_grid_blocks(cout / WinoV4::MB, (int)npt), WinoV4::NT, a);
     case 3: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3>, conv_grid_blocks(cout / WinoV3::MB, (int)npt), WinoV3::NT, a);
     case 2: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplit>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
-    case 1: return L.launch(conv3x3_wino_il_mfma_kernel<WinoIl>, conv_grid_blocks(cout / WinoIl::MB, (int)npt), WinoIl::NT, a);
     case 0: return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
     default: TNV3_FAIL(-1, "conv3x3_wino: unknown kernel variant %d", variant);
   }

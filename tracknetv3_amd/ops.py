@@ -86,7 +86,7 @@ def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False, vari
 
 def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None, variant=None):
     """The plain eval-mode layer in Winograd F(2x2, 3x3) form (tnv3_conv3x3_wino_forward).  variant: kernel family for THIS
-    call (None: tuning.WINO_VARIANT, -1 = the library's default; 2 xi-split, 0 one wave per SIMD, 1 interleaved transform)."""
+    call (None: tuning.WINO_VARIANT, -1 = the library's default; 3 balanced (default), 5 persistent workgroups, 4 quad layouts, 2 xi-split, 0 one wave per SIMD)."""
     lib = _lib.load()
     _f32(src, u, mean, scale, shift, addend)
     _lib.dev_check(src, u, mean, scale, shift, addend)

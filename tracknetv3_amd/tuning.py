@@ -64,13 +64,13 @@ def use_winograd_wgrad(cin, cout, h, w):
 
 # Kernel-family choices are per-call arguments of the C ABI (no process-wide state inside the library); these are the
 # defaults the Python layer passes.  -1 = the library's default (xi-split Winograd kernel; register-staged weight gradient).
-WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 0: one wave per SIMD, 1: interleaved transform, 2: xi-split
+WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 0: one wave per SIMD, 2: xi-split
 WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA staged kernels (parity-green, 8 % slower)
 
 
-# BatchNorm batch statistics from the convolution's epilogue (training forward): available in Winograd kernel variants 3 and 4.
+# BatchNorm batch statistics from the convolution's epilogue (training forward): available in Winograd kernel variants 3, 4 and 5.
 BN_STATS_IN_EPILOGUE = os.environ.get("TNV3_BN_STATS_EPILOGUE", "1") != "0"
 
 
 def wino_has_stats():
-    return BN_STATS_IN_EPILOGUE and WINO_VARIANT in (-1, 3, 4)
+    return BN_STATS_IN_EPILOGUE and WINO_VARIANT in (-1, 3, 4, 5)
