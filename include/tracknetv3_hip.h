@@ -90,12 +90,12 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  *                                     (u for cout_w x c_count) or, transpose_flip != 0, as the data gradient's filter
  *                                     w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] (u for c_count x cout_w): no host-side
  *                                     slice / flip / transpose copies (model.py:8 weight layout) */
-/*   `variant` of tnv3_conv3x3_wino_forward (per call): -1 = the library's default (3);  2 = xi-split kernel, two waves per SIMD;
+/*   `variant` of tnv3_conv3x3_wino_forward (per call): -1 = the library's default (5);  2 = xi-split kernel, two waves per SIMD;
  *                                     3 = the same tile with buffer-descriptor DMA and a paired patch transform (6-12 % faster);  4 = 3 with the
  *                                     "quad" operand layouts (one LDS read per four MFMAs; needs filters packed with
  *                                     layout 1: ask tnv3_conv3x3_wino_layout);  5 = 3 as persistent workgroups (one per CU walking the tile
- *                                     list: no per-tile launch / set-up, the next tile's first DMAs issued before the output
- *                                     transform);  0 = one wave per SIMD, transform as its own phase.  (1, the round-1 kernel with
+ *                                     list, the chunk pipeline running through the tile boundaries: no per-tile launch, set-up, first-DMA
+ *                                     wait or first transform; Cin <= 8 runs as 3);  0 = one wave per SIMD, transform as its own phase.  (1, the round-1 kernel with
  *                                     the transform interleaved into the MFMA stream, was removed: TNV3_E_INVALID.)  Variants 2, 3,
  *                                     4, 5 are bit-identical to each other; all compute the same function.
  *   `layout` of the pack calls: 0 = u[cin_pad][16][cout];  1 = u[cin_pad / 2][4][2][cout][4] (transform row major, the four xi of

@@ -115,6 +115,58 @@ __host__ __device__ inline int conv_grid_blocks(int nMB, int nPT) {
   return nMB * nPT;
 }
 
+// A persistent workgroup's walk through the block list: entries b0, b0 + G, b0 + 2G, ... of conv_block_map's order, decoded into
+// (channel block, image, tile row, tile column) WITHOUT a division per step (six scalar divisions cost ~1000 cycles per tile on
+// the SALU; the walk is a handful of adds and compares).  G must be a multiple of 8 when the XCD-aware order applies.
+struct ConvTileWalk {
+  int nMB, nPT, tilesH, tilesW;
+  int mb, pt, n, trow, tcol;          // current entry
+  int q, per;                         // XCD-aware order: position inside the XCD's run and the run length
+  int d_mb, d_pt, d_n, d_row, d_col;  // per-step advance (d_pt decomposed into image / row / column steps)
+  bool xcd, valid;
+  __host__ __device__ void init(int b0, int G, int nMB_, int nPT_, int tilesH_, int tilesW_) {
+    nMB = nMB_; nPT = nPT_; tilesH = tilesH_; tilesW = tilesW_;
+    xcd = nMB <= 8 && (8 % nMB) == 0;
+    if (xcd) {
+      const int g = 8 / nMB;
+      per = (nPT + g - 1) / g;
+      const int x = b0 & 7;
+      q = b0 >> 3;
+      mb = x % nMB;
+      pt = (x / nMB) * per + q;
+      d_mb = 0; d_pt = G >> 3;
+      valid = q < per && pt < nPT;
+    } else {
+      per = 0; q = 0;
+      mb = b0 % nMB; pt = b0 / nMB;
+      d_mb = G % nMB; d_pt = G / nMB;
+      valid = pt < nPT;
+    }
+    const int tpi = tilesH * tilesW;
+    n = pt / tpi;
+    const int rem = pt - n * tpi;
+    trow = rem / tilesW; tcol = rem - trow * tilesW;
+    d_n = d_pt / tpi;
+    const int drem = d_pt - d_n * tpi;
+    d_row = drem / tilesW; d_col = drem - d_row * tilesW;
+  }
+  __host__ __device__ void bump_col() { if (++tcol >= tilesW) { tcol = 0; if (++trow >= tilesH) { trow = 0; ++n; } } }
+  __host__ __device__ void next() {
+    pt += d_pt;
+    tcol += d_col; if (tcol >= tilesW) { tcol -= tilesW; ++trow; }
+    trow += d_row; if (trow >= tilesH) { trow -= tilesH; ++n; }
+    n += d_n;
+    if (xcd) {
+      q += d_pt;
+      valid = q < per && pt < nPT;
+    } else {
+      mb += d_mb;
+      if (mb >= nMB) { mb -= nMB; ++pt; bump_col(); }
+      valid = pt < nPT;
+    }
+  }
+};
+
 constexpr int kPackZeroTail = 64;      // floats of zeros appended to every packed filter
 
 // s_waitcnt immediate that waits for vmcnt <= n only (gfx9+ encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14])

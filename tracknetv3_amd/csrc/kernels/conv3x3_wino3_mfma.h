@@ -110,6 +110,173 @@ struct WinoV3Cfg {
   static_assert(!QUAD_ || (DMA_MODE_ == 0 && CC_ == 8), "the quad form is built for 8-channel chunks, every thread moving its own pieces");
 };
 
+// ---- write-out of a finished 64-channel x 64-tile accumulator block (shared by the kernels of this file)
+// acc: this wave's 8 accumulators (xi rows 2*grp, 2*grp+1 of its 32 x 32 block);  xch_g0 / xch_g1: 32 KB of free LDS each -- the
+// partial sums group 0 / group 1 hand to the partner group;  e_*: the tile (image, first row / column, first channel, tile index).
+// STREAM: the caller goes straight on to its next chunk, so the function ends with everybody done reading the regions.
+template <class Cfg, bool OPAQUE, bool STREAM, class StampMid>
+__device__ __forceinline__ void wino3_writeout(const WinoArgs& a, const f32x16 (&acc)[8], float* xch_g0, float* xch_g1, int e_n, int e_h0, int e_w0,
+                                               int e_m0, int e_pt, int nPT, StampMid&& stamp_mid) {
+  constexpr int WN = Cfg::WN, MB = Cfg::MB, TB = Cfg::TB;
+  const int H = a.H, W = a.W, Cout = a.Cout, HW = H * W;
+  (void)H;
+  // ---- inverse transform: rows of A^T M (this group's two xi rows), columns, then the halves meet through LDS
+  int tid_e = threadIdx.x;
+  if constexpr (OPAQUE) TNV3_OPAQUE_V(tid_e);           // the write-out's lane arithmetic is redone per tile, not kept live across the MFMA loop
+  const int tid = tid_e, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wq = wave & 3;
+  const int wn = wq % WN, wm = wq / WN, half = lane >> 5, bl = lane & 31;
+  // group g finishes output row g of every tile: `own` is its partial sum of that row; its partial sum of the other row goes
+  // to the partner wave through LDS.  The group is wave-uniform: one scalar branch, no per-element selects.
+  float* xch_wr = (grp ? xch_g1 : xch_g0) + wq * (32 * 64) + lane;       // this wave's 8 KB slot of its group's region
+  const float* xch_rd = (grp ? xch_g0 : xch_g1) + wq * (32 * 64) + lane;  // the partner wave's slot
+  float own[16][2];
+  auto out_rows = [&](auto gc) {
+    constexpr int G = decltype(gc)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float tt[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = acc[j][r], hi = acc[4 + j][r];  // M rows 2*grp and 2*grp + 1
+        tt[0][j] = G ? lo : lo + hi;                     // A^T row 0 = [1 1 1 0]
+        tt[1][j] = G ? -lo - hi : hi;                    // A^T row 1 = [0 1 -1 -1]
+      }
+      float pv[2][2];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        pv[y][0] = tt[y][0] + tt[y][1] + tt[y][2];
+        pv[y][1] = tt[y][1] - tt[y][2] - tt[y][3];
+      }
+      own[r][0] = pv[G][0]; own[r][1] = pv[G][1];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) xch_wr[(r * 2 + x) * 64] = pv[1 - G][x];
+    }
+  };
+  if (__builtin_amdgcn_readfirstlane(grp)) out_rows(std::true_type{}); else out_rows(std::false_type{});
+  __syncthreads();
+  stamp_mid();
+  // write-out: every load this lane needs -- the partner's 32 partial sums, the 16 channels' BatchNorm constants (four 16-byte
+  // loads each: the lane's channels are 4 runs of 4), the addend -- is issued BEFORE the first use, and the 16 stores go out
+  // back to back through one scalar base per channel + one 32-bit lane offset (no per-store 64-bit address arithmetic, no
+  // s_waitcnt between a store and the next channel's loads: that chain used to cost 6000 cycles per tile).
+  const bool has_affine = a.scale != nullptr, has_mean = a.mean != nullptr, has_addend = a.addend != nullptr;
+  const int t = wn * 32 + bl;
+  const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
+  const int oh = e_h0 + 2 * tr + grp, ow = e_w0 + 2 * tc;
+  // bytes from channel plane (n, m0) to this lane's pixel pair (< 2^31: host check): the one per-lane part of every address below.
+  // The 64 planes of the tile's channel block sit behind one buffer descriptor; channel r of the lane's run is a scalar offset.
+  const unsigned lane_off_b = (unsigned)((wm * 32 + 4 * half) * HW + oh * W + ow) * 4u;
+  const size_t plane0 = ((size_t)e_n * Cout + e_m0) * HW;
+  const unsigned planes_b = (unsigned)MB * (unsigned)HW * 4u;
+  const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
+  auto chan_off = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)HW * 4u; };
+  float got[16][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) got[r][x] = xch_rd[(r * 2 + x) * 64];
+  typedef float wf2 __attribute__((ext_vector_type(2)));
+  wf2 ad[16];
+  if (has_addend) {
+    const tnv3_rsrc_t r_add = tnv3_make_rsrc(a.addend + plane0, planes_b);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ad[r] = tnv3_buf_load_f2(r_add, lane_off_b, chan_off(r));
+  }
+  const bool want_stats = a.stats != nullptr;            // wave-uniform (kernel argument); never together with the affine (host check)
+  if (want_stats) {                                      // training forward: raw convolution (+ addend) out, statistics from the same registers
+    double q1[16], q2[16];                               // this lane's two pixels per channel r: sum, sum of squares
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      wf2 v;
+      v[0] = own[r][0] + got[r][0];
+      v[1] = own[r][1] + got[r][1];
+      if (has_addend) { v[0] += ad[r][0]; v[1] += ad[r][1]; }
+      if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
+      tnv3_buf_store_f2(r_dst, lane_off_b, chan_off(r), v);
+      q1[r] = (double)v[0] + (double)v[1];
+      q2[r] = (double)v[0] * (double)v[0] + (double)v[1] * (double)v[1];
+    }
+    // BatchNorm batch statistics from the epilogue's registers (model.py:9 in training mode): a half-wave holds 32 tiles x 2 pixels
+    // of 16 channels.  Reduce-scatter butterfly over the 32 lanes: at offset o the lane keeps the half of its channel list its
+    // bit selects and adds the partner's copy of that half -- 8 + 4 + 2 + 1 exchanges, then one plain exchange at offset 1;
+    // lane bl ends up with channel index r = bl >> 1 summed over the half-wave.  fp64, fixed order: deterministic.
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+      const int o = 16 >> step, cnt = 8 >> step;         // cnt values survive this step
+      const bool up = (bl & o) != 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < cnt) {
+          const double s1 = up ? q1[i] : q1[i + cnt], k1 = up ? q1[i + cnt] : q1[i];
+          const double s2 = up ? q2[i] : q2[i + cnt], k2 = up ? q2[i + cnt] : q2[i];
+          q1[i] = k1 + __shfl_xor(s1, o, 64);
+          q2[i] = k2 + __shfl_xor(s2, o, 64);
+        }
+      }
+    }
+    q1[0] += __shfl_xor(q1[0], 1, 64);
+    q2[0] += __shfl_xor(q2[0], 1, 64);
+    __syncthreads();                                       // everybody has read the exchange buffer: LDS is free again
+    double* red = reinterpret_cast<double*>(xch_g0);       // [wave][half][16 r][2]
+    if ((bl & 1) == 0) {
+      double* d = red + ((wave * 2 + half) * 16 + (bl >> 1)) * 2;
+      d[0] = q1[0];
+      d[1] = q2[0];
+    }
+    __syncthreads();
+    if (tid < MB) {                                        // channel tid of this block: fold the four waves that own its pixels
+      const int cwm = tid >> 5, q = tid & 31;
+      const int chalf = (q >> 2) & 1, cr = (q & 3) + 4 * (q >> 3);
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int x = 0; x < WN; ++x) {
+          const double* d = red + (((g * 4 + cwm * WN + x) * 2 + chalf) * 16 + cr) * 2;
+          s1 += d[0];
+          s2 += d[1];
+        }
+      double* o = a.stats + ((size_t)(e_m0 + tid) * nPT + e_pt) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+    if constexpr (STREAM) __syncthreads();                 // the fold has read `red`: the next chunk may overwrite the regions
+  } else {
+    if constexpr (STREAM) __syncthreads();                 // (after the waits the compiler puts before a barrier) the partial sums are in registers:
+                                                           // the next chunk's DMAs and transform may overwrite the regions
+    f32x4 mu4[4], sc4[4], sh4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mu4[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; sc4[q] = f32x4{1.0f, 1.0f, 1.0f, 1.0f}; sh4[q] = mu4[q];
+    }
+    if (has_affine) {
+      const int c4 = e_m0 + wm * 32 + 4 * half;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sc4[q] = *reinterpret_cast<const f32x4*>(a.scale + c4 + 8 * q);
+        sh4[q] = *reinterpret_cast<const f32x4*>(a.shift + c4 + 8 * q);
+      }
+      if (has_mean) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mu4[q] = *reinterpret_cast<const f32x4*>(a.mean + c4 + 8 * q);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      wf2 v;
+      v[0] = own[r][0] + got[r][0];
+      v[1] = own[r][1] + got[r][1];
+      if (has_addend) { v[0] += ad[r][0]; v[1] += ad[r][1]; }
+      if (has_affine) {
+        const float mu = mu4[r >> 2][r & 3], sc = sc4[r >> 2][r & 3], sh = sh4[r >> 2][r & 3];
+        v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh;
+      }
+      if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
+      tnv3_buf_store_f2(r_dst, lane_off_b, chan_off(r), v);
+    }
+  }
+}
+
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const WinoArgs a) {
   constexpr int WN = Cfg::WN, CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, PW = Cfg::PW, RW = Cfg::RW, RAWP = Cfg::RAWP;
@@ -426,162 +593,278 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_v3_mfma_kernel(const Win
   }
   stamp8(3);
 
-  // ---- inverse transform: rows of A^T M (this group's two xi rows), columns, then the halves meet through LDS
-  int tid_e = threadIdx.x;
-  if constexpr (Cfg::PERSIST) TNV3_OPAQUE_V(tid_e);     // the write-out's lane arithmetic is redone per tile, not kept live across the MFMA loop
-  const int tid = tid_e, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wq = wave & 3;
-  const int wn = wq % WN, wm = wq / WN, half = lane >> 5, bl = lane & 31;
-  // group g finishes output row g of every tile: `own` is its partial sum of that row; its partial sum of the other row goes
-  // to the partner wave through LDS.  The group is wave-uniform: one scalar branch, no per-element selects.
-  float* xch = Cfg::PERSIST ? v_s : lds;                 // all stages are free after the last chunk barrier; the persistent form has
-                                                         // the next tile's filters on their way into the filter stages
-  float own[16][2];
-  auto out_rows = [&](auto gc) {
-    constexpr int G = decltype(gc)::value;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float tt[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float lo = acc[j][r], hi = acc[4 + j][r];  // M rows 2*grp and 2*grp + 1
-        tt[0][j] = G ? lo : lo + hi;                     // A^T row 0 = [1 1 1 0]
-        tt[1][j] = G ? -lo - hi : hi;                    // A^T row 1 = [0 1 -1 -1]
-      }
-      float pv[2][2];
-#pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        pv[y][0] = tt[y][0] + tt[y][1] + tt[y][2];
-        pv[y][1] = tt[y][1] - tt[y][2] - tt[y][3];
-      }
-      own[r][0] = pv[G][0]; own[r][1] = pv[G][1];
-#pragma unroll
-      for (int x = 0; x < 2; ++x) xch[(wave * 32 + r * 2 + x) * 64 + lane] = pv[1 - G][x];
-    }
-  };
-  if (__builtin_amdgcn_readfirstlane(grp)) out_rows(std::true_type{}); else out_rows(std::false_type{});
-  __syncthreads();
-  stamp8(4);
-  // write-out: every load this lane needs -- the partner's 32 partial sums, the 16 channels' BatchNorm constants (four 16-byte
-  // loads each: the lane's channels are 4 runs of 4), the addend -- is issued BEFORE the first use, and the 16 stores go out
-  // back to back through one scalar base per channel + one 32-bit lane offset (no per-store 64-bit address arithmetic, no
-  // s_waitcnt between a store and the next channel's loads: that chain used to cost 6000 cycles per tile).
-  const bool has_affine = a.scale != nullptr, has_mean = a.mean != nullptr, has_addend = a.addend != nullptr;
-  const int t = wn * 32 + bl;
-  const int tr = t / (TB / 2), tc = t - tr * (TB / 2);
-  const int oh = e_h0 + 2 * tr + grp, ow = e_w0 + 2 * tc;
-  // bytes from channel plane (n, m0) to this lane's pixel pair (< 2^31: host check): the one per-lane part of every address below.
-  // The 64 planes of the tile's channel block sit behind one buffer descriptor; channel r of the lane's run is a scalar offset.
-  const unsigned lane_off_b = (unsigned)((wm * 32 + 4 * half) * HW + oh * W + ow) * 4u;
-  const size_t plane0 = ((size_t)e_n * Cout + e_m0) * HW;
-  const unsigned planes_b = (unsigned)MB * (unsigned)HW * 4u;
-  const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
-  auto chan_off = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)HW * 4u; };
-  float got[16][2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-#pragma unroll
-    for (int x = 0; x < 2; ++x) got[r][x] = xch[((wave ^ 4) * 32 + r * 2 + x) * 64 + lane];
-  typedef float wf2 __attribute__((ext_vector_type(2)));
-  wf2 ad[16];
-  if (has_addend) {
-    const tnv3_rsrc_t r_add = tnv3_make_rsrc(a.addend + plane0, planes_b);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ad[r] = tnv3_buf_load_f2(r_add, lane_off_b, chan_off(r));
-  }
-  const bool want_stats = a.stats != nullptr;            // wave-uniform (kernel argument); never together with the affine (host check)
-  if (want_stats) {                                      // training forward: raw convolution (+ addend) out, statistics from the same registers
-    double q1[16], q2[16];                               // this lane's two pixels per channel r: sum, sum of squares
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      wf2 v;
-      v[0] = own[r][0] + got[r][0];
-      v[1] = own[r][1] + got[r][1];
-      if (has_addend) { v[0] += ad[r][0]; v[1] += ad[r][1]; }
-      if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
-      tnv3_buf_store_f2(r_dst, lane_off_b, chan_off(r), v);
-      q1[r] = (double)v[0] + (double)v[1];
-      q2[r] = (double)v[0] * (double)v[0] + (double)v[1] * (double)v[1];
-    }
-    // BatchNorm batch statistics from the epilogue's registers (model.py:9 in training mode): a half-wave holds 32 tiles x 2 pixels
-    // of 16 channels.  Reduce-scatter butterfly over the 32 lanes: at offset o the lane keeps the half of its channel list its
-    // bit selects and adds the partner's copy of that half -- 8 + 4 + 2 + 1 exchanges, then one plain exchange at offset 1;
-    // lane bl ends up with channel index r = bl >> 1 summed over the half-wave.  fp64, fixed order: deterministic.
-#pragma unroll
-    for (int step = 0; step < 4; ++step) {
-      const int o = 16 >> step, cnt = 8 >> step;         // cnt values survive this step
-      const bool up = (bl & o) != 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (i < cnt) {
-          const double s1 = up ? q1[i] : q1[i + cnt], k1 = up ? q1[i + cnt] : q1[i];
-          const double s2 = up ? q2[i] : q2[i + cnt], k2 = up ? q2[i + cnt] : q2[i];
-          q1[i] = k1 + __shfl_xor(s1, o, 64);
-          q2[i] = k2 + __shfl_xor(s2, o, 64);
-        }
-      }
-    }
-    q1[0] += __shfl_xor(q1[0], 1, 64);
-    q2[0] += __shfl_xor(q2[0], 1, 64);
-    __syncthreads();                                       // everybody has read the exchange buffer: LDS is free again
-    double* red = reinterpret_cast<double*>(xch);          // [wave][half][16 r][2]
-    if ((bl & 1) == 0) {
-      double* d = red + ((wave * 2 + half) * 16 + (bl >> 1)) * 2;
-      d[0] = q1[0];
-      d[1] = q2[0];
-    }
-    __syncthreads();
-    if (tid < MB) {                                        // channel tid of this block: fold the four waves that own its pixels
-      const int cwm = tid >> 5, q = tid & 31;
-      const int chalf = (q >> 2) & 1, cr = (q & 3) + 4 * (q >> 3);
-      double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int x = 0; x < WN; ++x) {
-          const double* d = red + (((g * 4 + cwm * WN + x) * 2 + chalf) * 16 + cr) * 2;
-          s1 += d[0];
-          s2 += d[1];
-        }
-      double* o = a.stats + ((size_t)(e_m0 + tid) * nPT + e_pt) * 2;
-      o[0] = s1;
-      o[1] = s2;
-    }
-  } else {
-    f32x4 mu4[4], sc4[4], sh4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      mu4[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; sc4[q] = f32x4{1.0f, 1.0f, 1.0f, 1.0f}; sh4[q] = mu4[q];
-    }
-    if (has_affine) {
-      const int c4 = e_m0 + wm * 32 + 4 * half;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        sc4[q] = *reinterpret_cast<const f32x4*>(a.scale + c4 + 8 * q);
-        sh4[q] = *reinterpret_cast<const f32x4*>(a.shift + c4 + 8 * q);
-      }
-      if (has_mean) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mu4[q] = *reinterpret_cast<const f32x4*>(a.mean + c4 + 8 * q);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      wf2 v;
-      v[0] = own[r][0] + got[r][0];
-      v[1] = own[r][1] + got[r][1];
-      if (has_addend) { v[0] += ad[r][0]; v[1] += ad[r][1]; }
-      if (has_affine) {
-        const float mu = mu4[r >> 2][r & 3], sc = sc4[r >> 2][r & 3], sh = sh4[r >> 2][r & 3];
-        v[0] = (v[0] - mu) * sc + sh; v[1] = (v[1] - mu) * sc + sh;
-      }
-      if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
-      tnv3_buf_store_f2(r_dst, lane_off_b, chan_off(r), v);
-    }
+  // ---- inverse transform + write-out (wino3_writeout); the exchange regions: all stages are free after the last chunk barrier,
+  //      except that the persistent form has the next tile's filters on their way into the filter stages
+  {
+    float* xch = Cfg::PERSIST ? v_s : lds;
+    wino3_writeout<Cfg, Cfg::PERSIST != 0, false>(a, acc, xch, xch + 4 * 32 * 64, e_n, e_h0, e_w0, e_m0, e_pt, nPT, [&]() { stamp8(4); });
   }
   stamp8(5);
   ++n_items_done;
   if (!have_next) break;
   }                                                     // tile loop
+  if constexpr (Cfg::DIAG == 8) {                       // phase totals of one workgroup, behind the N-th image of dst (the caller allocates N + 1)
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dst + (size_t)a.N * Cout * HW) + wave * 8;
+      o[0] = t_acc0; o[1] = t_acc1; o[2] = t_acc2; o[3] = t_acc3; o[4] = t_acc4; o[5] = t_acc5;
+      o[6] = (unsigned long long)n_items_done; o[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming kernel (variant 5): persistent workgroups whose chunk pipeline runs THROUGH the tile boundaries.
+//
+// A workgroup of the kernel above fills its CU (512 threads x 256 registers, 160 KB of LDS), so nothing of a tile's fixed cost
+// overlaps anything: workgroup launch (~7000 cycles seen from outside), index set-up, 128 accumulator writes, the first DMAs'
+// round trip to HBM (1300-4600), the first patch transform (1200), the output transform and its stores (profiles/
+// r02_wino_fixed_cost.json: ~14 000 cycles per tile inside the kernel, i.e. 2.5 chunk periods -- a quarter of a 64-channel
+// layer).  Here one workgroup per CU walks the tile list (ConvTileWalk: no divisions per tile) and treats the chunks of
+// consecutive tiles as ONE stream: stage parity follows a running chunk counter, and at the last chunks of a tile the
+// "next chunk" DMAs (filters one chunk ahead, raw tile two ahead) and the patch transform simply belong to the next tile.
+// At a tile boundary everything the next tile's first chunk needs is already in LDS; the only per-tile cost left is the output
+// transform + write-out (wino3_writeout), which uses the two stages the last chunk just released.  Accumulators start from
+// the MFMA's inline zero (no 128 register writes).  Same arithmetic in the same order as variants 2 / 3 => the same bits.
+// Needs Cin > 8 (two chunks per tile; the host falls back to variant 3 otherwise).
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const WinoArgs a) {
+  static_assert(!Cfg::QUAD && !Cfg::SYM && Cfg::DMA_MODE == 0, "the streaming kernel is built on the variant-3 schedule");
+  constexpr int CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, PW = Cfg::PW, RW = Cfg::RW, RAWP = Cfg::RAWP;
+  constexpr int NU4 = Cfg::NU4, NRAW = Cfg::NRAW, NTD = Cfg::NTD, WN = Cfg::WN;
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  float* u_s = lds;                                   // two stages each
+  float* v_s = lds + 2 * Cfg::U_FLOATS;
+  float* raw_s = v_s + 2 * Cfg::V_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int wn = wq % WN, wm = wq / WN;
+  const int half = lane >> 5, bl = lane & 31;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+  const int tilesH = H / 4, tilesW = W / PW;
+  const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
+  const int nChunks = (Cin + CC - 1) / CC;             // >= 2 (host)
+
+  ConvTileWalk walk;                                  // always one tile ahead of the one being computed
+  walk.init(blockIdx.x, gridDim.x, nMB, nPT, tilesH, tilesW);
+  if (!walk.valid) return;
+
+  // ---- per-lane DMA offsets: the filter pieces' are the same for every tile and chunk, the raw pieces' follow the tile
+  unsigned vo_u[NU4], vo_r[NRAW], vo_rn[NRAW];
+#pragma unroll
+  for (int i = 0; i < NU4; ++i) {                     // filter piece e4 of [CC*16 rows][MB/4]: row = (ci, xi), 16 bytes of 64 channels
+    const int e4 = tid + i * NTD;
+    const int row = e4 / (MB / 4), m4 = e4 - row * (MB / 4);
+    vo_u[i] = (unsigned)(row * Cout + m4 * 4) * 4u;
+  }
+  auto raw_offsets = [&](unsigned (&vo)[NRAW], int h0, int w0) {
+    int t_op = tid;
+    TNV3_OPAQUE_V(t_op);                              // recomputed per tile; nothing of it stays live across the chunk loop
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) {                  // raw piece e of [CC][6][RW/4]; padding / unused slots read out of range (= 0)
+      const int e = t_op + i * NTD;
+      const int c = e / (RAWP / 4), r = e - c * (RAWP / 4);
+      const int tr = r / (RW / 4), q = r - tr * (RW / 4);
+      const int gh = h0 - 1 + tr, gw = w0 - 4 + 4 * q;
+      const bool ok = e < Cfg::RAW_FLOATS / 4 && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      vo[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
+    }
+  };
+  // the tile being computed and the one after it
+  int c_n = walk.n, c_h0 = walk.trow * 4, c_w0 = walk.tcol * PW, c_m0 = walk.mb * MB, c_pt = walk.pt;
+  raw_offsets(vo_r, c_h0, c_w0);
+  walk.next();
+  bool have_next = walk.valid;
+  int n_n = walk.n, n_h0 = walk.trow * 4, n_w0 = walk.tcol * PW, n_m0 = walk.mb * MB, n_pt = walk.pt;
+  if (have_next) raw_offsets(vo_rn, n_h0, n_w0);
+
+  const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);      // scalar: the LDS-DMA destinations (M0) stay on the SALU
+  // filter chunk at `up` (CC*16 rows of Cout floats, this tile's 64 channels first) -> filter stage su
+  const size_t u_step = (size_t)CC * 16 * Cout, x_step = (size_t)CC * HW;       // floats per chunk
+  auto dma_u = [&](const float* up, int su) {
+    const tnv3_rsrc_t ru = tnv3_make_rsrc(up, (unsigned)(CC * 16 * Cout) * 4u);
+    float* us = u_s + su * Cfg::U_FLOATS;
+#pragma unroll
+    for (int i = 0; i < NU4; ++i) tnv3_buf_dma16(ru, us + (i * NTD + wbase) * 4, vo_u[i]);
+  };
+  // raw tile of the chunk whose first channel plane is `xp` (cvalid of its CC channels exist; per-lane offsets vo) -> raw stage sr
+  auto dma_r = [&](const float* xp, int cvalid, const unsigned (&vo)[NRAW], int sr) {
+    const tnv3_rsrc_t rr = tnv3_make_rsrc(xp, (unsigned)(cvalid < CC ? cvalid : CC) * (unsigned)HW * 4u);   // channels past Cin: beyond num_records, zero
+    float* rs = raw_s + sr * Cfg::RAW_STAGE;
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) tnv3_buf_dma16(rr, rs + (i * NTD + wbase) * 4, vo[i]);
+  };
+  // scalar bases of the two tiles' filters and images
+  const float* c_u = a.u + c_m0;
+  const float* c_x = a.src + (size_t)c_n * Cin * HW;
+  const float* n_u = a.u + n_m0;
+  const float* n_x = a.src + (size_t)n_n * Cin * HW;
+
+  // ---- patch transform: thread -> (channel c, tile row tr, tile pair pj), its group's two transform rows (as in the kernel above)
+  const int tg = tid & (NT / 2 - 1);
+  const int pc = tg / (TB / 2), prem = tg - pc * (TB / 2);
+  const int ptr_ = prem / (TB / 4), pj = prem - ptr_ * (TB / 4);
+  const int t_src = pc * RAWP + (2 * ptr_ + grp) * RW + 4 * pj;
+  const int t_dst = (pc * 16 + grp * 8) * TB + ptr_ * (TB / 2) + 2 * pj;
+  typedef float wf2 __attribute__((ext_vector_type(2)));
+  auto transform = [&](int stage) {                     // raw stage -> V stage of the same parity
+    const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src;
+    float x[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(d + r * RW);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(d + r * RW + 4);
+      const float q2 = d[r * RW + 8];
+      x[r][0] = q0[3]; x[r][1] = q1[0]; x[r][2] = q1[1]; x[r][3] = q1[2]; x[r][4] = q1[3]; x[r][5] = q2;
+    }
+    float e[2][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      e[0][j] = grp ? x[1][j] - x[0][j] : x[0][j] - x[2][j];
+      e[1][j] = grp ? x[0][j] - x[2][j] : x[1][j] + x[2][j];
+    }
+    float* v = v_s + stage * Cfg::V_FLOATS + t_dst;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      wf2 o;
+      o[0] = e[r][0] - e[r][2]; o[1] = e[r][2] - e[r][4]; *reinterpret_cast<wf2*>(v + (r * 4 + 0) * TB) = o;
+      o[0] = e[r][1] + e[r][2]; o[1] = e[r][3] + e[r][4]; *reinterpret_cast<wf2*>(v + (r * 4 + 1) * TB) = o;
+      o[0] = e[r][2] - e[r][1]; o[1] = e[r][4] - e[r][3]; *reinterpret_cast<wf2*>(v + (r * 4 + 2) * TB) = o;
+      o[0] = e[r][1] - e[r][3]; o[1] = e[r][3] - e[r][5]; *reinterpret_cast<wf2*>(v + (r * 4 + 3) * TB) = o;
+    }
+  };
+
+  f32x16 acc[8];
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+  const int a_off = (half * 16 + grp * 8) * MB + wm * 32 + bl;
+  const int b_off = (half * 16 + grp * 8) * TB + wn * 32 + bl;
+  auto mfma_chunk = [&](int stage, auto first_c) {      // first_c: the tile's first chunk starts every accumulator from the inline zero
+    constexpr bool FIRST = decltype(first_c)::value;
+    const float* A = u_s + stage * Cfg::U_FLOATS + a_off;
+    const float* B = v_s + stage * Cfg::V_FLOATS + b_off;
+    constexpr int NSTEP = (CC / 2) * 8;                  // (channel pair, xi of this group): one MFMA each
+    constexpr int PF = 4, RING = PF + 1;
+    float av[RING], bv[RING];
+    auto read_step = [&](int s) {
+      const int cp = s >> 3, x = s & 7;
+      av[s % RING] = A[(2 * cp * 16 + x) * MB];
+      bv[s % RING] = B[(2 * cp * 16 + x) * TB];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) read_step(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + PF < NSTEP) read_step(s + PF);
+      acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], FIRST && s < 8 ? zero16 : acc[s & 7], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+  auto chunk_barrier = [&]() {                          // own DMAs landed, own V writes done, everybody finished with the old stages
+    __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+  };
+
+  unsigned long long t_acc0 = 0, t_acc1 = 0, t_acc2 = 0, t_acc3 = 0, t_acc4 = 0, t_acc5 = 0, t_last = 0, t_begin = 0;
+  int n_items_done = 0;
+  auto stamp8 = [&](int slot) {                         // DIAG 8: phase totals of one workgroup
+    if constexpr (Cfg::DIAG == 8) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      const unsigned long long dcy = now - t_last;
+      t_last = now;
+      if (slot == 0) t_acc0 += dcy; else if (slot == 1) t_acc1 += dcy; else if (slot == 2) t_acc2 += dcy;
+      else if (slot == 3) t_acc3 += dcy; else if (slot == 4) t_acc4 += dcy; else if (slot == 5) t_acc5 += dcy;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  int gs = 0;                                          // chunks done so far: the current chunk uses stage gs & 1
+  const float* pu;                                     // filters one chunk ahead / raw tile two chunks ahead, inside the current tile
+  const float* px;
+  int px_left;                                         // channels from px's chunk to Cin
+  // One chunk.  Free since the barrier that ended the previous chunk: filter stage sn (held the previous chunk), raw stage sc
+  // (holds this chunk's raw tile, transformed during the previous chunk) and V stage sn.  "One chunk ahead" (filters, patch
+  // transform) and "two chunks ahead" (raw tile) run on into the next tile when this one ends -- WHERE: 0 = both inside this tile
+  // (no conditions in the steady loop), 1 = the tile's second-to-last chunk (raw tile of the next tile's chunk 0), 2 = its last
+  // chunk (filters, transform: next tile's chunk 0; raw tile: its chunk 1).
+  auto chunk_body = [&](auto first_c, auto where_c) {
+    constexpr int WHERE = decltype(where_c)::value;
+    const int sc = gs & 1, sn = sc ^ 1;
+    const bool ahead = WHERE != 2 || have_next;         // is there a chunk after this one at all
+    auto dmas = [&]() {                                 // this thread's NU4 + NRAW pieces
+      if constexpr (WHERE == 0) {
+        dma_u(pu, sn);
+        dma_r(px, px_left, vo_r, sc);
+      } else if constexpr (WHERE == 1) {
+        dma_u(pu, sn);
+        if (have_next) dma_r(n_x, Cin, vo_rn, sc);
+      } else if (have_next) {
+        dma_u(n_u, sn);
+        dma_r(n_x + x_step, Cin - CC, vo_rn, sc);
+      }
+    };
+    if (grp == 0) {                                     // group 0: DMAs, transform, MFMAs;  group 1: MFMAs, DMAs, transform
+      dmas();
+      if (ahead) transform(sn);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_chunk(sc, first_c);
+    } else {
+      mfma_chunk(sc, first_c);
+      __builtin_amdgcn_sched_barrier(0);
+      dmas();
+      if (ahead) transform(sn);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pu += u_step; px += x_step; px_left -= CC;
+    chunk_barrier();
+    ++gs;
+  };
+  typedef std::integral_constant<int, 0> in_tile_t;
+  typedef std::integral_constant<int, 1> second_to_last_t;
+  typedef std::integral_constant<int, 2> last_t;
+
+  if constexpr (Cfg::DIAG == 8) { t_begin = __builtin_amdgcn_s_memtime(); t_last = t_begin; }
+  // pipeline fill (once per workgroup): filters of chunk 0, raw tiles of chunks 0 and 1, V of chunk 0
+  dma_u(c_u, 0);
+  dma_r(c_x, Cin, vo_r, 0);
+  dma_r(c_x + x_step, Cin - CC, vo_r, 1);
+  chunk_barrier();
+  transform(0);
+  chunk_barrier();
+  stamp8(0);
+  for (;;) {                                            // one pass per tile
+    stamp8(3);
+    pu = c_u + u_step; px = c_x + 2 * x_step; px_left = Cin - 2 * CC;
+    if (nChunks == 2) {
+      chunk_body(std::true_type{}, second_to_last_t{});
+    } else {
+      chunk_body(std::true_type{}, in_tile_t{});
+      for (int k = 1; k < nChunks - 2; ++k) chunk_body(std::false_type{}, in_tile_t{});
+      chunk_body(std::false_type{}, second_to_last_t{});
+    }
+    chunk_body(std::false_type{}, last_t{});
+    stamp8(2);
+    // the stages the last chunk used (parity of gs - 1) are free; the other filter / V stages already hold the next tile's chunk 0
+    const int sf = (gs & 1) ^ 1;
+    wino3_writeout<Cfg, true, true>(a, acc, u_s + sf * Cfg::U_FLOATS, v_s + sf * Cfg::V_FLOATS, c_n, c_h0, c_w0, c_m0, c_pt, nPT, [&]() { stamp8(4); });
+    stamp8(5);
+    ++n_items_done;
+    if (!have_next) break;
+    c_n = n_n; c_h0 = n_h0; c_w0 = n_w0; c_m0 = n_m0; c_pt = n_pt; c_u = n_u; c_x = n_x;
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) vo_r[i] = vo_rn[i];
+    walk.next();
+    have_next = walk.valid;
+    n_n = walk.n; n_h0 = walk.trow * 4; n_w0 = walk.tcol * PW; n_m0 = walk.mb * MB; n_pt = walk.pt;
+    n_u = a.u + n_m0;
+    n_x = a.src + (size_t)n_n * Cin * HW;
+    if (have_next) raw_offsets(vo_rn, n_h0, n_w0);
+  }
   if constexpr (Cfg::DIAG == 8) {                       // phase totals of one workgroup, behind the N-th image of dst (the caller allocates N + 1)
     if (blockIdx.x == gridDim.x / 2 && lane == 0) {
       unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dst + (size_t)a.N * Cout * HW) + wave * 8;

@@ -413,13 +413,13 @@ using WinoA = WinoCfg<2, 2, 8>;              // 64 channels x 64 tiles (4 x 64 p
 using WinoSplit = WinoSplitCfg<8>;          // same tile, 512 threads: two wave groups split the 16 transform rows (2 waves / SIMD)
 using WinoV3 = WinoV3Cfg<8>;                // same tile and operands as WinoSplit; balanced DMA issue, buffer-descriptor DMA, paired transform
 using WinoV4 = WinoV3Cfg<8, 0, 0, 0, 1>;    // + quad operand layouts (filter pack layout 1): 0.5 instead of 2 LDS reads per MFMA
-using WinoV5 = WinoV3Cfg<8, 0, 0, 0, 0, 0, 1>;   // WinoV3 as persistent workgroups (one per CU walking the tile list, next tile's DMAs before the output transform)
+using WinoV5 = WinoV3Cfg<8>;                // persistent workgroups, the chunk pipeline running through the tile boundaries (conv3x3_wino_stream_mfma_kernel)
 // persistent launch: one workgroup per CU, a whole number of XCD rounds so that a workgroup's tiles all map to its XCD
 inline int wino_persistent_grid(int items) { const int g = std::max(8, num_cus() / 8 * 8); return items < g ? items : g; }
 // filter pack layout a kernel variant expects (tnv3_conv3x3_wino_layout)
 inline int conv3x3_wino_layout(int variant) { return (variant == 4 || variant == 47 || variant == 44) ? 1 : 0; }
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
-constexpr int kWinoDefaultVariant = 3;       // per-call `variant`: 3 WinoV3 (default: measured 6-12 % faster than 2), 2 WinoSplit, 4 WinoV4 (quad
+constexpr int kWinoDefaultVariant = 5;       // per-call `variant`: 5 streaming persistent kernel (default), 3 WinoV3, 2 WinoSplit, 4 WinoV4 (quad
                                              // layouts), 5 WinoV5 (persistent), 0 WinoA (one wave / SIMD); -1 = default
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
@@ -503,12 +503,18 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     case 71: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 1, 1>>, grid3, WinoV3::NT, a);
     // 83 / 85: variants 3 / 5 with the per-tile fixed-cost phases timed (results correct; totals behind the N-th image of dst)
     case 83: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 8>>, grid3, WinoV3::NT, a);
-    case 85: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 8, 0, 0, 0, 0, 1>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+    case 85: if (cin <= WinoV3::CC) break;
+             return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV3Cfg<8, 8>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+    // 86: the first persistent form (per-tile prologue kept, next tile's first DMAs issued before the output transform), timed like 85
+    case 86: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 8, 0, 0, 0, 0, 1>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+    case 56: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 0, 0, 0, 0, 1>>, wino_persistent_grid(grid3), WinoV3::NT, a);
     default: break;
   }
 #endif
   switch (variant) {
-    case 5: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV5>, wino_persistent_grid(conv_grid_blocks(cout / WinoV5::MB, (int)npt)), WinoV5::NT, a);
+    case 5:                                      // one chunk per tile cannot stream: the variant-3 kernel takes Cin <= 8
+      if (cin <= WinoV5::CC) return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3>, conv_grid_blocks(cout / WinoV3::MB, (int)npt), WinoV3::NT, a);
+      return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV5>, wino_persistent_grid(conv_grid_blocks(cout / WinoV5::MB, (int)npt)), WinoV5::NT, a);
     case 4: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV4>, conv_grid_blocks(cout / WinoV4::MB, (int)npt), WinoV4::NT, a);
     case 3: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3>, conv_grid_blocks(cout / WinoV3::MB, (int)npt), WinoV3::NT, a);
     case 2: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplit>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
