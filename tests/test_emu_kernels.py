@@ -318,6 +318,15 @@ def test_conv3x3_wino_balanced_kernel_is_bit_identical_to_the_xi_split_kernel(em
 WINO_PERSIST_CASES = [(3, 12, 64, 8, 128), (1, 27, 64, 12, 192), (2, 20, 128, 12, 64), (5, 8, 192, 4, 64)]
 
 
+def test_persistent_tile_walk_matches_the_block_map(emu_lib_path):
+    """ConvTileWalk (adds and compares per tile) == conv_block_map (divisions) for every grid / shape combination tried, and
+    once a workgroup meets an entry without a tile no later entry of its walk has one (the kernels stop there)."""
+    import ctypes
+    lib = ctypes.CDLL(emu_lib_path)
+    lib.tnv3_emu_tile_walk_check.restype = ctypes.c_long
+    assert lib.tnv3_emu_tile_walk_check() > 100000
+
+
 @pytest.mark.parametrize("case", WINO_PERSIST_CASES)
 def test_conv3x3_wino_persistent_kernel_walks_several_tiles_per_workgroup(emu, monkeypatch, case):
     """Variant 5 = variant 3 as persistent workgroups (one per CU, next tile's first DMAs issued before the output transform,
