@@ -26,7 +26,7 @@ import torch  # noqa: E402
 SEQ_LEN, BG_MODE, H, W = 8, "concat", 288, 512
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (= fp32 vector peak)
 PEAK_HBM_GBPS = 8000.0
-KERNEL_SET = "wino_v3+conv_up2x+direct"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
+KERNEL_SET = "wino_stream+conv_up2x+direct"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
 ALG_BYTES_PER_SAMPLE = 693.55e6    # ideal-fusion fp32 bytes of one 27->8 forward
 
 
@@ -288,6 +288,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="infer mode: also time this many configs[2]-shard training steps (2 warm-ups) and report them as `train` (0 = skip)")
+    ap.add_argument("--infer-split", type=int, default=None, choices=(0, 1),
+                    help="force the intra-batch two-stream split of the eval forward off / on (default: the product's setting)")
     ap.add_argument("--overlap-streams", type=int, default=2,
                     help="also time the K steps round-robin on this many HIP streams (reported as `overlap`; 0/1 = skip)")
     ap.add_argument("--layers-out", default=os.path.join(ROOT, "gpurun_out", "bench_layers.json"))
@@ -346,16 +348,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    from tracknetv3_amd import tuning as _tuning
+    from tracknetv3_amd.model import no_infer_split
+    if args.infer_split is not None:
+        _tuning.INFER_SPLIT = bool(args.infer_split)
+    split_on = bool(_tuning.INFER_SPLIT and args.batch >= _tuning.INFER_SPLIT_MIN_BATCH)
+
+    # the headline: K steps of the product's default path (the batch split 6 : 4 over two HIP streams unless switched off)
     for _ in range(args.warmup):
         model(x)
     barrier()
-    ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino = timed_conv, timed_up2x, timed_wino
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = model(x)
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino = ops_conv, ops_up2x, ops_wino
+    if split_on:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(x)
+        barrier()
+        dt = time.perf_counter() - t0
+
+    # the roofline pass: the same K steps with the whole batch on ONE stream and HIP events around every conv launch, so that a
+    # launch's duration is its own (co-running launches of the other half would stretch each other's event brackets).  With the
+    # split off (--infer-split 0: the profiling scripts) this IS the headline pass.
+    with no_infer_split():
+        if split_on:
+            for _ in range(min(args.warmup, 2)):
+                model(x)
+            barrier()
+        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino = timed_conv, timed_up2x, timed_wino
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(x)
+        barrier()
+        dt_single = time.perf_counter() - t0
+        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino = ops_conv, ops_up2x, ops_wino
+    if not split_on:
+        dt = dt_single
 
     # Extra (reported beside, never instead of, `value`): the same K steps on independent batches issued round-robin on two
     # HIP streams.  Windows are independent, so the second stream's launches fill the CUs that the 45/48 tail of every
@@ -366,22 +392,24 @@ def main():
         xs = [x] + [torch.rand_like(x) for _ in range(args.overlap_streams - 1)]
         model.prepare_eval()
         barrier()
-        for k in range(2 * len(side)):
-            with torch.cuda.stream(side[k % len(side)]):
-                model(xs[k % len(side)])
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            with torch.cuda.stream(side[k % len(side)]):
-                model(xs[k % len(side)])
-        barrier()
-        dt2 = time.perf_counter() - t0
+        with no_infer_split():                              # whole batches in flight, as pipeline.predict_video keeps them
+            for k in range(2 * len(side)):
+                with torch.cuda.stream(side[k % len(side)]):
+                    model(xs[k % len(side)])
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                with torch.cuda.stream(side[k % len(side)]):
+                    model(xs[k % len(side)])
+            barrier()
+            dt2 = time.perf_counter() - t0
 
     if world > 1:
-        tmax = torch.tensor([dt, dt2 if dt2 is not None else 0.0], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt, dt2 if dt2 is not None else 0.0, dt_single], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0].item())
         dt2 = float(tmax[1].item()) if dt2 is not None else None
+        dt_single = float(tmax[2].item())
 
     if rank == 0:
         # A decoder-entry layer is two launches: conv_up2x (its upsampled channels, at the low resolution) followed by
@@ -401,8 +429,6 @@ def main():
         fl = np.array([conv_flops(c0, c1, co, h, w) * args.batch for (_, c0, c1, co, h, w, _) in layers])
         # multiply-adds the device executes: the upsampled channels (c0 of an `up` layer) cost 4 taps instead of 9, and the
         # plain halves that run in Winograd F(2x2,3x3) form cost 16 instead of 36 per 2x2 tile
-        from tracknetv3_amd import tuning as _tuning
-
         def executed(c0, c1, co, h, w, up):
             if up:
                 skip = conv_flops(c1, 0, co, h, w) * (16 / 36 if _tuning.use_winograd(c1, co, h, w) else 1.0)
@@ -443,12 +469,20 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: TrackNet seq_len=8 bg_mode=concat eval forward, batch 10 per GPU, "
                                    "288x512 synthetic frames, synthetic (PRNG) weights", "batch_per_gpu": args.batch,
-                       "frames_per_step": n_gpus * args.batch * SEQ_LEN, "parallelism": f"replicated windows x{n_gpus} (no collective)"},
+                       "frames_per_step": n_gpus * args.batch * SEQ_LEN, "parallelism": f"replicated windows x{n_gpus} (no collective)",
+                       "schedule": ("the batch's images split 6 : 4 over two HIP streams (product default, tuning.INFER_SPLIT): the halves' "
+                                    "per-layer launches overlap at their tails; outputs bit-identical to the one-stream forward")
+                       if split_on else "whole batch on one HIP stream"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch",
-                         "kernel": f"conv3x3_wino_v3_mfma_kernel<*> + conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} "
+                         "kernel": f"conv3x3_wino_stream_mfma_kernel<*> + conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} "
                                    "launches/step for the 17 conv layers, fp32 MFMA 32x32x2)",
+                         "measured": "second pass of the same K steps with the whole batch on ONE stream (model.no_infer_split) and HIP "
+                                     "events around every conv launch: a launch's duration is its own, not stretched by the other half's "
+                                     "co-running launches; `single_stream_ms_per_step` is that pass's wall time per step",
+                         "single_stream_ms_per_step": round(dt_single / args.steps * 1e3, 4),
+                         "step_view_tflops": round(float(fl_exec.sum()) / (dt / args.steps) / 1e12, 2),
                          "avg_launch_ms": round(conv_ms / launches_per_step, 4), "conv_ms_per_step": round(conv_ms, 4),
                          "algorithmic_gflop_per_step": round(float(fl.sum()) / 1e9, 3),
                          "executed_gflop_per_step": round(float(fl_exec.sum()) / 1e9, 3),

@@ -109,3 +109,20 @@ def test_state_dict_layout_and_checkpoint_roundtrip():
     assert m2.load_state_dict(back["model"], strict=True).missing_keys == []
     # synthetic reference-layout state loads too
     m2.load_state_dict(nets.synth_state(shapes, 5), strict=True)
+
+
+def test_infer_split_gate_is_thread_local_and_restored():
+    """model.no_infer_split(): nests, restores the previous state, and does not leak into other threads."""
+    import threading
+    from tracknetv3_amd import model as M
+    assert not M._NO_SPLIT.active
+    seen = []
+    with M.no_infer_split():
+        assert M._NO_SPLIT.active
+        with M.no_infer_split():
+            assert M._NO_SPLIT.active
+        assert M._NO_SPLIT.active
+        t = threading.Thread(target=lambda: seen.append(M._NO_SPLIT.active))
+        t.start()
+        t.join()
+    assert not M._NO_SPLIT.active and seen == [False]

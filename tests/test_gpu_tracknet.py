@@ -175,3 +175,33 @@ def test_tracknet_batch10_properties(gpu_device):
     assert torch.equal(m(x[perm].contiguous()), y_a[perm])
     err = np.abs(y_a[0].cpu().numpy().reshape(-1)[g["eval_probe_idx"]] - g["eval_probe_val"]).max()
     assert err <= HEATMAP_TOL / 4
+
+
+def test_tracknet_batch_split_over_two_streams_is_bit_identical(gpu_device):
+    """The default eval forward splits a batch 6 : 4 over two HIP streams (tuning.INFER_SPLIT): same bits as the one-stream
+    forward, also when the caller runs on a side stream of its own, and switched off inside model.no_infer_split()."""
+    from tracknetv3_amd import model as M
+    from tracknetv3_amd import tuning
+    g = np.load(os.path.join(GOLDEN, "tracknet_27_8_288x512.npz"))
+    m, x1, _ = _load_model(g, gpu_device)
+    x = torch.cat([x1] + [nets.synth_input(tuple(x1.shape), 700 + k) for k in range(6)], 0).to(gpu_device)     # batch 7 -> 4 + 3
+    assert tuning.INFER_SPLIT and x.shape[0] >= tuning.INFER_SPLIT_MIN_BATCH
+    calls = []
+    orig = m._forward_eval
+    m._forward_eval = lambda t: (calls.append(int(t.shape[0])), orig(t))[1]
+    y_split = m(x)
+    assert calls == [3, 4] or calls == [4, 3], calls              # side-stream half is issued first
+    calls.clear()
+    with M.no_infer_split():
+        y_one = m(x)
+    assert calls == [7]
+    assert torch.equal(y_split, y_one)
+    s = torch.cuda.Stream(gpu_device)
+    s.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(s):
+        y_side = m(x)
+    torch.cuda.current_stream(gpu_device).wait_stream(s)
+    assert torch.equal(y_side, y_one)
+    calls.clear()
+    m(x[:2].contiguous())                                          # below the minimum batch: one stream
+    assert calls == [2]

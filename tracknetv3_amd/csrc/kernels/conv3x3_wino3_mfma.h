@@ -709,6 +709,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const
   const int t_dst = (pc * 16 + grp * 8) * TB + ptr_ * (TB / 2) + 2 * pj;
   typedef float wf2 __attribute__((ext_vector_type(2)));
   auto transform = [&](int stage) {                     // raw stage -> V stage of the same parity
+    if constexpr (Cfg::DIAG == 10 || Cfg::DIAG == 13) return;       // timing experiments (wrong results): no patch transform at all
     const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src;
     float x[3][6];
 #pragma unroll
@@ -725,6 +726,17 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const
       e[1][j] = grp ? x[0][j] - x[2][j] : x[1][j] + x[2][j];
     }
     float* v = v_s + stage * Cfg::V_FLOATS + t_dst;
+    if constexpr (Cfg::DIAG == 9) {                       // timing experiment (wrong results): the same loads and stores, no arithmetic
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        wf2 o;
+        o[0] = x[r][0]; o[1] = x[r][1]; *reinterpret_cast<wf2*>(v + (r * 4 + 0) * TB) = o;
+        o[0] = x[r][2]; o[1] = x[r][3]; *reinterpret_cast<wf2*>(v + (r * 4 + 1) * TB) = o;
+        o[0] = x[r][4]; o[1] = x[r][5]; *reinterpret_cast<wf2*>(v + (r * 4 + 2) * TB) = o;
+        o[0] = x[2][r]; o[1] = x[2][r + 2]; *reinterpret_cast<wf2*>(v + (r * 4 + 3) * TB) = o;
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       wf2 o;
@@ -757,7 +769,9 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const
     for (int s = 0; s < PF; ++s) read_step(s);
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-      if (s + PF < NSTEP) read_step(s + PF);
+      if constexpr (Cfg::DIAG != 12 && Cfg::DIAG != 13) {            // (12 / 13: timing experiments, the MFMAs reuse the first operands)
+        if (s + PF < NSTEP) read_step(s + PF);
+      }
       acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], FIRST && s < 8 ? zero16 : acc[s & 7], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -797,6 +811,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const
     const int sc = gs & 1, sn = sc ^ 1;
     const bool ahead = WHERE != 2 || have_next;         // is there a chunk after this one at all
     auto dmas = [&]() {                                 // this thread's NU4 + NRAW pieces
+      if constexpr (Cfg::DIAG == 11 || Cfg::DIAG == 13) return;     // timing experiments (wrong results): no LDS-DMA in the chunk loop
       if constexpr (WHERE == 0) {
         dma_u(pu, sn);
         dma_r(px, px_left, vo_r, sc);

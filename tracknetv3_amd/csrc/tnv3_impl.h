@@ -505,6 +505,15 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     case 83: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 8>>, grid3, WinoV3::NT, a);
     case 85: if (cin <= WinoV3::CC) break;
              return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV3Cfg<8, 8>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+    // 95 ... 99: timing twins of 5 (wrong results): patch transform without its arithmetic / no patch transform / no LDS-DMA in the
+    // chunk loop / no operand reads in the MFMA stream / none of the three
+    case 95: case 96: case 97: case 98: case 99:
+      if (cin <= WinoV3::CC) break;
+      if (variant == 95) return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV3Cfg<8, 9>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+      if (variant == 96) return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV3Cfg<8, 10>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+      if (variant == 97) return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV3Cfg<8, 11>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+      if (variant == 98) return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV3Cfg<8, 12>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+      return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV3Cfg<8, 13>>, wino_persistent_grid(grid3), WinoV3::NT, a);
     // 86: the first persistent form (per-tile prologue kept, next tile's first DMAs issued before the output transform), timed like 85
     case 86: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 8, 0, 0, 0, 0, 1>>, wino_persistent_grid(grid3), WinoV3::NT, a);
     case 56: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 0, 0, 0, 0, 1>>, wino_persistent_grid(grid3), WinoV3::NT, a);

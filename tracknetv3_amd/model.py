@@ -9,7 +9,9 @@ The sub-modules below are parameter containers only: they never run a torch conv
 hand-written gfx950 kernels through the C ABI (``ops``).  There is no CPU or ATen fallback: on a non-GPU tensor, or
 without the HIP library, the call raises.
 """
+import contextlib
 import math
+import threading
 
 import torch
 import torch.nn as nn
@@ -270,6 +272,26 @@ class TrackNet(nn.Module):
                             b.packed_wino()
                     b.eval_scale()
 
+    def _forward_eval_split(self, x):
+        """The eval forward with the batch split 6 : 4 over the current stream and a side stream (tuning.INFER_SPLIT).  Images are
+        independent in eval mode, so the outputs are those of _forward_eval to the last bit; the two halves' per-layer launches
+        overlap at their tails, where a single launch leaves CUs idle."""
+        dev = x.device
+        n = int(x.shape[0])
+        n0 = (3 * n + 2) // 5
+        main = torch.cuda.current_stream(dev)
+        side = _split_stream(dev)
+        self.prepare_eval()                                  # cached operands are built on this stream, before the side stream reads them
+        ready = torch.cuda.Event()
+        ready.record(main)                                   # x (and the caches) were produced on this stream
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            y1 = self._forward_eval(x[n0:])
+        y0 = self._forward_eval(x[:n0])
+        main.wait_stream(side)
+        y1.record_stream(main)                               # allocated on the side stream, consumed (and freed) on this one
+        return torch.cat((y0, y1), 0)
+
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_dim:
             raise ValueError(f"TrackNet expects (N, {self.in_dim}, H, W), got {tuple(x.shape)}")
@@ -280,7 +302,41 @@ class TrackNet(nn.Module):
             from . import autograd_ops
             return autograd_ops.tracknet_forward_train(self, x)
         with torch.no_grad():
+            n = int(x.shape[0])
+            if (x.is_cuda and tuning.INFER_SPLIT and not _NO_SPLIT.active and n >= tuning.INFER_SPLIT_MIN_BATCH
+                    and n * int(x.shape[2]) * int(x.shape[3]) >= tuning.INFER_SPLIT_MIN_PIXELS and not torch.cuda.is_current_stream_capturing()):
+                return self._forward_eval_split(x)
             return self._forward_eval(x)
+
+
+_SPLIT_STREAMS = {}
+
+
+def _split_stream(dev):
+    """The side stream of the intra-batch split, one per device (the caching allocator pools memory per stream: a fresh stream per
+    call would pay a hipMalloc for every activation)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SPLIT_STREAMS:
+        _SPLIT_STREAMS[key] = torch.cuda.Stream(dev)
+    return _SPLIT_STREAMS[key]
+
+
+class _NoSplit(threading.local):
+    active = False
+
+
+_NO_SPLIT = _NoSplit()
+
+
+@contextlib.contextmanager
+def no_infer_split():
+    """Callers that already keep several batches in flight on their own streams (pipeline.predict_video) switch the intra-batch
+    split off for their forwards."""
+    prev, _NO_SPLIT.active = _NO_SPLIT.active, True
+    try:
+        yield
+    finally:
+        _NO_SPLIT.active = prev
 
 
 # --------------------------------------------------------------------------- InpaintNet

@@ -9,6 +9,7 @@ already-resized float frames (T, 3, 288, 512) in [0, 1].  Video decoding stays o
 import torch
 
 from . import postprocess as pp
+from .model import no_infer_split as _no_infer_split
 from .utils.general import HEIGHT, WIDTH
 
 
@@ -82,7 +83,7 @@ def _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, n_str
     def launch(k):
         wi = widx[starts[k]:starts[k] + batch_size]
         st = side[k % n_streams]
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(st), _no_infer_split():     # batches already overlap here: no second split inside each
             st.wait_event(ready)
             y = tracknet(_assemble(frames, median, wi, bg_mode))
             done = torch.cuda.Event()

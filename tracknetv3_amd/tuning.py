@@ -72,5 +72,13 @@ WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA 
 BN_STATS_IN_EPILOGUE = os.environ.get("TNV3_BN_STATS_EPILOGUE", "1") != "0"
 
 
+# Inference: one batch is split over two HIP streams (6 : 4) -- its images are independent, and the second stream's launches fill
+# the CUs that the tail of every per-layer launch leaves idle (720 tiles on 256 CUs = 2.8 rounds: the last one is 81 % full).
+# Measured on the batch-10 288x512 forward: 9.91 -> 9.33 ms (profiles/r02_split_stream_probe.json); outputs are bit-identical.
+INFER_SPLIT = os.environ.get("TNV3_INFER_SPLIT", "1") != "0"
+INFER_SPLIT_MIN_BATCH = 4
+INFER_SPLIT_MIN_PIXELS = 1 << 19          # batch x H x W below which the launches are too short to be worth a second stream
+
+
 def wino_has_stats():
     return BN_STATS_IN_EPILOGUE and WINO_VARIANT in (-1, 3, 4, 5)
