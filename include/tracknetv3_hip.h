@@ -32,7 +32,8 @@ extern "C" {
 #define TNV3_OK 0
 #define TNV3_E_INVALID (-1)   /* bad argument / unsupported shape */
 #define TNV3_E_LAUNCH (-2)    /* HIP launch error */
-#define TNV3_ABI_VERSION 2   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so */
+#define TNV3_ABI_VERSION 3   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
+                                 3: `variant` argument on the Winograd-form weight gradients */
 
 typedef void* tnv3_stream_t;
 
@@ -145,20 +146,24 @@ int tnv3_dgrad_up2x(const float* dz, const float* g, float* dx_low, int n, int c
 /* Weight gradient of a plain layer (single source, no upsampling) in Winograd F(2x2, 3x3) form: dw[cout][cin][3][3] =
  * G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- 16 instead of 36 multiply-adds per (co, ci, 2x2 tile); same gradient as
  * tnv3_conv3x3_wgrad up to fp32 rounding; deterministic (fixed-order split-K sum).
- *   supported: cin % 64 == 0, cout % 64 == 0, h % 2 == 0, w % 16 == 0;  workspace 16-byte aligned, size from the query. */
+ *   supported: cin % 64 == 0, cout % 64 == 0, h % 2 == 0, w % 16 == 0;  workspace 16-byte aligned, size from the query.
+ *   `variant` (per call): -1 = the library's default (1);  1 = two waves per SIMD, the wave groups half a period apart (one
+ *   transforms while the other streams MFMAs), paired transforms, buffer-descriptor LDS-DMA;  0 = the first kernel (one wave per
+ *   SIMD, transform and MFMA phases alternate).  Both accumulate in the same order: bit-identical results. */
 int tnv3_conv3x3_wgrad_wino_supported(int cin, int cout, int h, int w);
 size_t tnv3_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w);
 int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes, int n, int cin, int cout,
-                            int h, int w, tnv3_stream_t stream);
+                            int h, int w, int variant, tnv3_stream_t stream);
 
 /* Weight gradient of a whole decoder-entry layer, dw[cout][c0+c1][3][3] for the nn.Conv2d applied to
  * cat([Upsample(2)(x_low), skip], dim=1): the c0 upsampled channels through the four parity images of dz and 2x2 tap
  * windows against x_low (16 instead of 36 taps per low-res pixel), the c1 skip channels as an ordinary 3x3 weight gradient.
  *   x_low [n][c0][h_low][w_low], skip [n][c1][2*h_low][2*w_low], dz [n][cout][2*h_low][2*w_low];  w_low % 4 == 0.
- * Deterministic (split-K slabs reduced in a fixed order); workspace from the _workspace_bytes query, 16-byte aligned. */
+ * Deterministic (split-K slabs reduced in a fixed order); workspace from the _workspace_bytes query, 16-byte aligned.
+ * `wino_variant`: kernel of the skip half when it runs in Winograd form (as `variant` of tnv3_conv3x3_wgrad_wino). */
 size_t tnv3_conv3x3_wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int h_low, int w_low);
 int tnv3_conv3x3_wgrad_up2x(const float* x_low, const float* skip, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
-                            int n, int c0, int c1, int cout, int h_low, int w_low, tnv3_stream_t stream);
+                            int n, int c0, int c1, int cout, int h_low, int w_low, int wino_variant, tnv3_stream_t stream);
 
 /* ---- head + pooling (model.py:54-55,59,61,63,71-72) ----------------------------------------------------- */
 

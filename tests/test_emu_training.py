@@ -114,16 +114,29 @@ def _wgrad_wino_case(case, device):
     F.conv2d(x.double(), wd, padding=1).backward(dz.double())
     dw = ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))
     assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))), "split-K reduction must be deterministic"
+    # the two kernel generations accumulate every element in the same order: bit-identical gradients
+    assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=0))
+    assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=1))
     return rel_err(dw.cpu(), wd.grad)
 
 
 # emulator-only: 5 and 7 strips of work -> split-K counts whose quarters are uneven / partly empty in the fold kernel
-WGRAD_WINO_EMU_EXTRA = [(1, 64, 64, 10, 16), (1, 64, 64, 14, 16)]
+# (3, 64, 64, 4, 48): 18 strips over images, tile rows and segments -- the chunk walk's carries; borders on every side
+WGRAD_WINO_EMU_EXTRA = [(1, 64, 64, 10, 16), (1, 64, 64, 14, 16), (3, 64, 64, 4, 48)]
 
 
 @pytest.mark.parametrize("case", WGRAD_WINO_CASES + WGRAD_WINO_EMU_EXTRA)
 def test_wgrad_wino_emulated_vs_autograd(emu, case):
     assert _wgrad_wino_case(case, "cpu") <= 4e-6
+
+
+@pytest.mark.parametrize("cus", [1, 2, 3, 5])
+def test_wgrad_wino_long_chunk_walks_emulated(emu, monkeypatch, cus):
+    """Few CUs -> small split-K -> every workgroup walks many strips (steps of 1, 2, 3, 5 strips: segment, tile-row and image
+    carries of the division-free cursor, DMA two chunks ahead, both wave groups' phase loops)."""
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+    assert _wgrad_wino_case((3, 64, 64, 4, 48), "cpu") <= 4e-6
+    assert _wgrad_wino_case((2, 64, 128, 6, 32), "cpu") <= 4e-6
 
 
 def test_dgrad_split_destinations_emulated(emu):

@@ -75,10 +75,14 @@ def test_conv_and_wgrad_budgets(resources):
     k = _find(resources, "conv3x3_wino_split_mfma_kernelINS_12WinoSplitCfgILi8ELi0E")  # production: 128 accumulators, TWO waves per SIMD
     assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0
     assert k["LDS Size [bytes/block]"] <= 160 * 1024                                    # two filter + two V + two raw stages
-    for args in ("Li8ELi0ELi0ELi0ELi0ELi0ELi0E", "Li8ELi0ELi0ELi0ELi1ELi0ELi0E", "Li8ELi0ELi0ELi0ELi0ELi0ELi1E"):   # variants 3, 4 and 5 (persistent): the same budget
-        k = _find(resources, "conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgI" + args)
+    # variants 3 and 4 (one tile per workgroup) and 5 (the streaming persistent kernel, the default): the same budget
+    for name in ("conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0E", "conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi1ELi0ELi0E",
+                 "conv3x3_wino_stream_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0E"):
+        k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
+    k = _find(resources, "wgrad_wino2_mfma_kernel")                                     # Winograd weight gradient, two waves per SIMD
+    assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
     for name, occ in (("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi2ELi4ELi2ELi4E", 4), ("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi1ELi4ELi2ELi4E", 4),
                       ("dgrad_up2x_mfma_kernelINS_12DgradUp2xCfgILi2ELi2ELi4ELi1ELi2E", 4)):
         k = _find(resources, name)

@@ -115,6 +115,39 @@ __host__ __device__ inline int conv_grid_blocks(int nMB, int nPT) {
   return nMB * nPT;
 }
 
+// ---- raw buffer descriptors: LDS-DMA / loads / stores whose per-lane address part is one 32-bit offset (used by the Winograd
+//      forward kernels of conv3x3_wino3_mfma.h and the Winograd weight-gradient kernel of wgrad_wino_mfma.h)
+#ifndef TNV3_EMU
+typedef __amdgpu_buffer_rsrc_t tnv3_rsrc_t;
+// Raw buffer descriptor (stride 0): base, size in bytes (< 2^31); loads at offset >= num_records return 0.
+__device__ __forceinline__ tnv3_rsrc_t tnv3_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// LDS[lds_base + lane*16 .. +16) <- buffer[voffset .. +16) (or zeros when out of range); tracked by vmcnt.
+__device__ __forceinline__ void tnv3_buf_dma16(tnv3_rsrc_t r, float* lds_base, unsigned voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)voffset, 0, 0, 0);
+}
+// 8-byte load / store at base + voffset (per lane, bytes) + soffset (scalar, bytes): no vector address arithmetic per access
+typedef float tnv3_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned tnv3_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tnv3_f2 tnv3_buf_load_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
+  return __builtin_bit_cast(tnv3_f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voffset, (int)soffset, 0));
+}
+__device__ __forceinline__ void tnv3_buf_store_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(tnv3_u2, v), r, (int)voffset, (int)soffset, 0);
+}
+#endif
+
+// Makes a per-lane value opaque to the optimiser at this point: what is derived from it afterwards cannot be hoisted out of the
+// enclosing loop (the persistent kernel's per-tile code would otherwise park ~80 loop-invariant VGPRs across the MFMA loop).
+#ifdef TNV3_EMU
+#define TNV3_OPAQUE_V(x) ((void)0)
+#else
+#define TNV3_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+
+constexpr unsigned kDmaOob = 0x80000000u;      // voffset of a padding lane: beyond any descriptor (num_records < 2^31)
+
 // A persistent workgroup's walk through the block list: entries b0, b0 + G, b0 + 2G, ... of conv_block_map's order, decoded into
 // (channel block, image, tile row, tile column) WITHOUT a division per step (six scalar divisions cost ~1000 cycles per tile on
 // the SALU; the walk is a handful of adds and compares).  G must be a multiple of 8 when the XCD-aware order applies.

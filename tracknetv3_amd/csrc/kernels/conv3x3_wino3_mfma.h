@@ -34,37 +34,6 @@
 
 namespace tnv3 {
 
-#ifndef TNV3_EMU
-typedef __amdgpu_buffer_rsrc_t tnv3_rsrc_t;
-// Raw buffer descriptor (stride 0): base, size in bytes (< 2^31); loads at offset >= num_records return 0.
-__device__ __forceinline__ tnv3_rsrc_t tnv3_make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-// LDS[lds_base + lane*16 .. +16) <- buffer[voffset .. +16) (or zeros when out of range); tracked by vmcnt.
-__device__ __forceinline__ void tnv3_buf_dma16(tnv3_rsrc_t r, float* lds_base, unsigned voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)voffset, 0, 0, 0);
-}
-// 8-byte load / store at base + voffset (per lane, bytes) + soffset (scalar, bytes): no vector address arithmetic per access
-typedef float tnv3_f2 __attribute__((ext_vector_type(2)));
-typedef unsigned tnv3_u2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ tnv3_f2 tnv3_buf_load_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
-  return __builtin_bit_cast(tnv3_f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voffset, (int)soffset, 0));
-}
-__device__ __forceinline__ void tnv3_buf_store_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f2 v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(tnv3_u2, v), r, (int)voffset, (int)soffset, 0);
-}
-#endif
-
-// Makes a per-lane value opaque to the optimiser at this point: what is derived from it afterwards cannot be hoisted out of the
-// enclosing loop (the persistent kernel's per-tile code would otherwise park ~80 loop-invariant VGPRs across the MFMA loop).
-#ifdef TNV3_EMU
-#define TNV3_OPAQUE_V(x) ((void)0)
-#else
-#define TNV3_OPAQUE_V(x) asm volatile("" : "+v"(x))
-#endif
-
-constexpr unsigned kDmaOob = 0x80000000u;      // voffset of a padding lane: beyond any descriptor (num_records < 2^31)
-
 template <int CC_, int DIAG_ = 0, int DMA_MODE_ = 0, int PRIO_ = 0, int QUAD_ = 0, int SYM_ = 0, int PERSIST_ = 0>
 struct WinoV3Cfg {
   // 1: persistent workgroups (variant 5).  The launch has one workgroup per CU and each walks the tile list with the grid as its

@@ -16,6 +16,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "conv3x3_mfma.h"
 
 namespace tnv3 {
@@ -193,6 +195,219 @@ inline __global__ void __launch_bounds__(WgradWinoCfg::NT) wgrad_wino_mfma_kerne
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       slab[((size_t)xi * Cout + co) * Cin + ci] = acc[xi][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second generation (variant 1 of tnv3_conv3x3_wgrad_wino): the same GEMMs, the same K order per accumulator -- hence the
+// same bits -- restructured the way the forward kernel was (conv3x3_wino_mfma.h -> conv3x3_wino3_mfma.h):
+//   * 512 threads, two waves per SIMD: wave group g keeps transform rows 2g, 2g+1 (8 of the 16 xi, 128 accumulator registers)
+//     of the 64 x 64 block and PRODUCES those rows of both operands itself, so the groups share nothing but the raw strips.
+//     They run half a period apart -- while one group's waves stream their 32 MFMAs of a chunk, the other group transforms
+//     its next chunk -- instead of the whole workgroup alternating between a transform phase (matrix pipe idle) and an MFMA
+//     phase: the first kernel spent 3.6 LDS instructions per MFMA serially with the MFMAs and reached ~35 % of the fp32 peak.
+//   * a thread transforms a horizontal tile PAIR: dZ rows as two 16-byte reads, X rows as 2 x 16 bytes + 4 (the forward
+//     kernel's paired patch transform) instead of 20 scalar reads per patch; results leave as 8-byte pairs.
+//   * LDS-DMA through buffer descriptors: per-lane offsets are chunk-invariant, the strip position is one scalar add, image
+//     borders are the hardware's out-of-range zeros (no per-piece address arithmetic, no zero page), and the chunk walk
+//     (image, tile row, 16-pixel segment) advances by adds and carries instead of two divisions per chunk.
+struct WgradWino2Cfg {
+  static constexpr int NT = 512, TCH = 8, TS = TCH + 1;
+  static constexpr int OP_FLOATS = 16 * 64 * TS;                        // one transformed operand: [xi][channel][tile]
+  static constexpr int DZ_RAW = 64 * 2 * 16;                            // [co][2 rows][16 px]
+  static constexpr int XW = 24, X_RAW = 64 * 4 * XW;                    // [ci][4 rows][24 px: columns 16j-4 .. 16j+19]
+  static constexpr int RAW_STAGE = DZ_RAW + X_RAW;
+  static constexpr int NX = X_RAW / 4 / NT;                             // x pieces per thread and chunk (3); one dZ piece
+  static constexpr int LDS_FLOATS = 2 * OP_FLOATS + 2 * RAW_STAGE;
+  static_assert(DZ_RAW / 4 == NT && X_RAW % (4 * NT) == 0, "pieces must deal evenly");
+};
+
+inline __global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_kernel(const WgradWinoArgs a) {
+  using Cfg = WgradWino2Cfg;
+  constexpr int NT = Cfg::NT, TS = Cfg::TS, XW = Cfg::XW, NX = Cfg::NX;
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  float* yh_s = lds;
+  float* v_s = lds + Cfg::OP_FLOATS;
+  float* raw_s = lds + 2 * Cfg::OP_FLOATS;                 // two stages of [dz strip | x strip]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int wn = wq & 1, wm = wq >> 1;                      // wm: co half, wn: ci half
+  const int half = lane >> 5, bl = lane & 31;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+  const int nCB = Cin / 64;
+  int b = blockIdx.x;
+  const int ks = b % a.splitK; b /= a.splitK;
+  const int cb = b % nCB, mb = b / nCB;
+  const int co0 = mb * 64, ci0 = cb * 64;
+  const int segW = W / 16, rowsT = H / 2;
+  const int nChunksAll = a.N * rowsT * segW;
+  const int nMine = nChunksAll > ks ? (nChunksAll - ks + a.splitK - 1) / a.splitK : 0;      // chunks ks, ks + splitK, ...
+
+  // ---- the DMA cursor: (image, tile row, segment) of the next chunk to fetch; one step = splitK chunks
+  const int per_img = rowsT * segW;
+  int c_n = ks / per_img, c_i = (ks - c_n * per_img) / segW, c_j = ks - c_n * per_img - c_i * segW;
+  const int d_n = a.splitK / per_img, d_i = (a.splitK - d_n * per_img) / segW, d_j = a.splitK - d_n * per_img - d_i * segW;
+
+  // ---- chunk-invariant per-lane byte offsets, relative to the strip origin (dZ: row 2i, column 16j; X: row 2i-1, column 16j-4)
+  unsigned vo_dz, vo_x[NX], edge[NX];                      // edge bits: piece lies in strip row 0 / row 3 / column piece 0 / column piece 5
+  {
+    const int q4 = tid & 3, r = (tid >> 2) & 1, co = tid >> 3;            // dZ piece of [co][2 rows][4 pieces]
+    vo_dz = (unsigned)(co * HW + r * W + 4 * q4) * 4u;
+#pragma unroll
+    for (int p = 0; p < NX; ++p) {
+      const int e = tid + p * NT;                                          // X piece of [ci][4 rows][6 pieces]
+      const int q6 = e % 6, t2 = e / 6;
+      const int r4 = t2 & 3, ci = t2 >> 2;
+      vo_x[p] = (unsigned)(ci * HW + r4 * W + 4 * q6) * 4u;
+      edge[p] = (r4 == 0 ? 1u : 0u) | (r4 == 3 ? 2u : 0u) | (q6 == 0 ? 4u : 0u) | (q6 == 5 ? 8u : 0u);
+    }
+  }
+  const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);             // scalar: the LDS-DMA destinations (M0) stay on the SALU
+  const unsigned planes_dz = 64u * (unsigned)HW * 4u;                      // 64 channel planes of one image (< 2^31: host check)
+  auto dma_chunk = [&](int stage) {                                        // the cursor's chunk -> raw stage; then the cursor advances
+    const tnv3_rsrc_t r_dz = tnv3_make_rsrc(a.dz + ((size_t)c_n * Cout + co0) * HW, planes_dz);
+    const tnv3_rsrc_t r_x = tnv3_make_rsrc(a.x + ((size_t)c_n * Cin + ci0) * HW, planes_dz);
+    const int off_dz = (2 * c_i * W + 16 * c_j) * 4;
+    const int off_x = ((2 * c_i - 1) * W + 16 * c_j - 4) * 4;            // negative at the top-left corner: only out-of-image pieces
+    const unsigned border = (c_i == 0 ? 1u : 0u) | (c_i == rowsT - 1 ? 2u : 0u) | (c_j == 0 ? 4u : 0u) | (c_j == segW - 1 ? 8u : 0u);
+    float* rs = raw_s + stage * Cfg::RAW_STAGE;
+    tnv3_buf_dma16(r_dz, rs + wbase * 4, vo_dz + (unsigned)off_dz);
+#pragma unroll
+    for (int p = 0; p < NX; ++p)
+      tnv3_buf_dma16(r_x, rs + Cfg::DZ_RAW + (p * NT + wbase) * 4, (edge[p] & border) ? kDmaOob : vo_x[p] + (unsigned)off_x);
+    c_j += d_j; if (c_j >= segW) { c_j -= segW; ++c_i; }
+    c_i += d_i; if (c_i >= rowsT) { c_i -= rowsT; ++c_n; }
+    c_n += d_n;
+  };
+
+  // ---- transform of a tile pair: thread (channel ch, pair tp) of its group -> rows 2*grp, 2*grp+1 of Yh and V, tiles 2tp, 2tp+1
+  const int tg = tid & 255, ch = tg >> 2, tp = tg & 3;
+  auto transform = [&](int stage, auto gc) {
+    constexpr int G = decltype(gc)::value;
+    const float* rs = raw_s + stage * Cfg::RAW_STAGE;
+    {   // Yh = A dY A^T,  A = [1 0; 1 1; 1 -1; 0 -1]: rows (y0, y0 + y1 | y0 - y1, -y1), the same along the columns
+      const f32x4 ya = *reinterpret_cast<const f32x4*>(rs + ch * 32 + 4 * tp);          // dZ row 2i,   columns 4tp .. 4tp+3
+      const f32x4 yb = *reinterpret_cast<const f32x4*>(rs + ch * 32 + 16 + 4 * tp);     // dZ row 2i+1
+      float* o = yh_s + (G * 8) * 64 * TS + ch * TS + 2 * tp;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                                                      // transform row 2G + i
+        float rr[2][2];                                                                  // [tile][column of the 2x2 block]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float y00 = ya[2 * t], y01 = ya[2 * t + 1], y10 = yb[2 * t], y11 = yb[2 * t + 1];
+          if (G == 0) { rr[t][0] = i == 0 ? y00 : y00 + y10; rr[t][1] = i == 0 ? y01 : y01 + y11; }
+          else { rr[t][0] = i == 0 ? y00 - y10 : -y10; rr[t][1] = i == 0 ? y01 - y11 : -y11; }
+        }
+        float* oi = o + (i * 4) * 64 * TS;
+        oi[0 * 64 * TS] = rr[0][0];            oi[0 * 64 * TS + 1] = rr[1][0];
+        oi[1 * 64 * TS] = rr[0][0] + rr[0][1]; oi[1 * 64 * TS + 1] = rr[1][0] + rr[1][1];
+        oi[2 * 64 * TS] = rr[0][0] - rr[0][1]; oi[2 * 64 * TS + 1] = rr[1][0] - rr[1][1];
+        oi[3 * 64 * TS] = -rr[0][1];           oi[3 * 64 * TS + 1] = -rr[1][1];
+      }
+    }
+    {   // V = B^T d B: strip rows G .. G+2 (patch rows d0,d1,d2 | d1,d2,d3), patch columns 4tp+3 .. 4tp+8 of the 24-float strip row
+      const float* d = rs + Cfg::DZ_RAW + ch * (4 * XW) + G * XW + 4 * tp;
+      float x[3][6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(d + r * XW);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(d + r * XW + 4);
+        const float q2 = d[r * XW + 8];
+        x[r][0] = q0[3]; x[r][1] = q1[0]; x[r][2] = q1[1]; x[r][3] = q1[2]; x[r][4] = q1[3]; x[r][5] = q2;
+      }
+      float e[2][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        e[0][j] = G ? x[1][j] - x[0][j] : x[0][j] - x[2][j];      // d2 - d1      | d0 - d2
+        e[1][j] = G ? x[0][j] - x[2][j] : x[1][j] + x[2][j];      // d1 - d3      | d1 + d2
+      }
+      float* o = v_s + (G * 8) * 64 * TS + ch * TS + 2 * tp;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        float* orow = o + (r * 4) * 64 * TS;
+        orow[0 * 64 * TS] = e[r][0] - e[r][2]; orow[0 * 64 * TS + 1] = e[r][2] - e[r][4];
+        orow[1 * 64 * TS] = e[r][1] + e[r][2]; orow[1 * 64 * TS + 1] = e[r][3] + e[r][4];
+        orow[2 * 64 * TS] = e[r][2] - e[r][1]; orow[2 * 64 * TS + 1] = e[r][4] - e[r][3];
+        orow[3 * 64 * TS] = e[r][1] - e[r][3]; orow[3 * 64 * TS + 1] = e[r][3] - e[r][5];
+      }
+    }
+  };
+  const int sgrp = __builtin_amdgcn_readfirstlane(grp);                    // wave-uniform: scalar branches, no per-element selects
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+  const float* A = yh_s + (grp * 8) * 64 * TS + (wm * 32 + bl) * TS + half;
+  const float* B = v_s + (grp * 8) * 64 * TS + (wn * 32 + bl) * TS + half;
+  auto mfma_chunk = [&]() {                                 // 4 tile pairs x this group's 8 xi; per accumulator the K order of kernel 1
+    constexpr int NSTEP = 4 * 8;
+    constexpr int PF = 4, RING = PF + 1;
+    float av[RING], bv[RING];
+    auto read_step = [&](int s) {
+      const int t2 = s >> 3, xi = s & 7;
+      av[s % RING] = A[xi * 64 * TS + 2 * t2];
+      bv[s % RING] = B[xi * 64 * TS + 2 * t2];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) read_step(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + PF < NSTEP) read_step(s + PF);
+      acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s & 7], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+  auto phase_end = [&](bool dma_too) {                      // own LDS traffic (and, at the end of an odd phase, own DMAs) done; everybody
+    if (dma_too) __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // Phases (one workgroup barrier each); group 0 runs half a period ahead of group 1:
+  //   fill      DMA(0), DMA(1);  group 0: T(0)
+  //   odd  q    group 0: MFMA(q)        group 1: T(q)          -- ends with the DMAs issued one phase earlier landed
+  //   even q    all: issue DMA(q+2) into stage q & 1 (both groups are done with the strips of chunk q)
+  //             group 0: T(q+1)         group 1: MFMA(q)
+  if (nMine > 0) {
+    dma_chunk(0);
+    if (nMine > 1) dma_chunk(1);
+  }
+  phase_end(true);
+  // (one loop per group, each with a single MFMA site: the accumulators stay in place; both execute the same barriers)
+  if (sgrp == 0) {
+    if (nMine > 0) transform(0, std::integral_constant<int, 0>{});
+    phase_end(false);
+    for (int q = 0; q < nMine; ++q) {
+      mfma_chunk();
+      phase_end(true);
+      if (q + 2 < nMine) dma_chunk(q & 1);
+      if (q + 1 < nMine) transform((q + 1) & 1, std::integral_constant<int, 0>{});
+      phase_end(false);
+    }
+  } else {
+    phase_end(false);
+    for (int q = 0; q < nMine; ++q) {
+      transform(q & 1, std::integral_constant<int, 1>{});
+      phase_end(true);
+      if (q + 2 < nMine) dma_chunk(q & 1);
+      mfma_chunk();
+      phase_end(false);
+    }
+  }
+
+  // partial slab: part[ks][xi][co][ci]
+  float* slab = a.part + (size_t)ks * 16 * Cout * Cin;
+  const int ci = ci0 + wn * 32 + bl;
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      slab[((size_t)(grp * 8 + x) * Cout + co) * Cin + ci] = acc[x][r];
     }
 }
 

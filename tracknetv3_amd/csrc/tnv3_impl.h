@@ -714,9 +714,19 @@ inline size_t wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w)
   return kWgradZeroBytes + (size_t)wgrad_wino_splitk(n, cin, cout, h, w) * 16 * cout * cin * sizeof(float);
 }
 
+constexpr int kWgradWinoDefaultVariant = 1;     // 1: two waves per SIMD, wave groups half a period apart; 0: the first kernel
+template <class Launcher>
+int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
+  const int grid = (a.Cout / 64) * (a.Cin / 64) * a.splitK;
+  if (variant < 0) variant = kWgradWinoDefaultVariant;
+  if (variant == 0) return L.launch(wgrad_wino_mfma_kernel, grid, WgradWinoCfg::NT, a);
+  if ((long)64 * a.H * a.W * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (variant 1): 64 channel planes must stay below 2 GiB");
+  return L.launch(wgrad_wino2_mfma_kernel, grid, WgradWino2Cfg::NT, a);
+}
+
 template <class Launcher>
 int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int n, int cin, int cout,
-                            int h, int w) {
+                            int h, int w, int variant = -1) {
   if (!x || !dz || !dw || !ws || n <= 0) TNV3_FAIL(-1, "conv3x3_wgrad_wino: bad argument");
   if (!wgrad_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wgrad_wino: needs Cin %% 64 == 0, Cout %% 64 == 0, H %% 2 == 0, W %% 16 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
@@ -728,7 +738,7 @@ int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float*
   int rc;
   if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
   WgradWinoArgs a{x, dz, (const float*)ws, slabs, n, cin, cout, h, w, sk};
-  if ((rc = L.launch(wgrad_wino_mfma_kernel, (cout / 64) * (cin / 64) * sk, WgradWinoCfg::NT, a))) return rc;
+  if ((rc = launch_wgrad_wino(L, a, variant))) return rc;
   return L.launch(wgrad_wino_fold_kernel, wgrad_wino_fold_blocks((long)cout * cin), 256, (const float*)slabs, dw, cout, cin, sk);
 }
 
@@ -761,7 +771,7 @@ inline size_t wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int hl
 
 template <class Launcher>
 int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, const float* dz, float* dw, void* ws, size_t ws_bytes,
-                            int n, int c0, int c1, int cout, int hl, int wl) {
+                            int n, int c0, int c1, int cout, int hl, int wl, int wino_variant = -1) {
   if (!x_low || !skip || !dz || !dw || !ws || n <= 0 || c0 <= 0 || c1 <= 0 || cout <= 0 || hl <= 0 || wl <= 0)
     TNV3_FAIL(-1, "conv3x3_wgrad_up2x: bad argument");
   if (wl % 4) TNV3_FAIL(-1, "conv3x3_wgrad_up2x: the low-resolution width must be a multiple of 4");
@@ -791,7 +801,7 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
     const int sk = wgrad_wino_splitk(n, c1, cout, h, w);
     if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
     WgradWinoArgs a{skip, dz, (const float*)ws, slabs, n, c1, cout, h, w, sk};
-    if ((rc = L.launch(wgrad_wino_mfma_kernel, (cout / 64) * (c1 / 64) * sk, WgradWinoCfg::NT, a))) return rc;
+    if ((rc = launch_wgrad_wino(L, a, wino_variant))) return rc;
     if ((rc = L.launch(wgrad_wino_fold_kernel, wgrad_wino_fold_blocks((long)cout * c1), 256, (const float*)slabs, dwskip, cout, c1, sk))) return rc;
   } else {
     WgradArgs a{skip, (const float*)nullptr, dz, slabs, n, c1, 0, cout, h, w, 0, l.skip.splitK, (const float*)ws, 0, 0};

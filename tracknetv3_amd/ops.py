@@ -441,8 +441,16 @@ def wgrad_wino_supported(cin, cout, h, w):
     return bool(_lib.load().tnv3_conv3x3_wgrad_wino_supported(int(cin), int(cout), int(h), int(w)))
 
 
-def conv3x3_wgrad_wino(x, dz):
-    """dW[Cout][Cin][3][3] of a plain layer in Winograd F(2x2,3x3) form -- see tnv3_conv3x3_wgrad_wino."""
+def _wgrad_wino_variant(variant):
+    if variant is None:
+        from . import tuning
+        variant = tuning.WGRAD_WINO_VARIANT
+    return int(variant)
+
+
+def conv3x3_wgrad_wino(x, dz, variant=None):
+    """dW[Cout][Cin][3][3] of a plain layer in Winograd F(2x2,3x3) form -- see tnv3_conv3x3_wgrad_wino.  variant: kernel for THIS
+    call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's default, 1 two waves per SIMD, 0 the first kernel)."""
     lib = _lib.load()
     _f32(x, dz)
     _lib.dev_check(x, dz)
@@ -453,11 +461,11 @@ def conv3x3_wgrad_wino(x, dz):
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dz.device)
     ws = _workspace(lib.tnv3_conv3x3_wgrad_wino_workspace_bytes(n, cin, cout, h, w), dz.device)
     _lib.check(lib.tnv3_conv3x3_wgrad_wino(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8, n, cin, cout, h, w,
-                                           _lib.stream_ptr(dz)))
+                                           _wgrad_wino_variant(variant), _lib.stream_ptr(dz)))
     return dw
 
 
-def conv3x3_wgrad_up2x(x_low, skip, dz):
+def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None):
     """dW[Cout][C0+C1][3][3] of a decoder-entry layer (X = cat([upsample2x(x_low), skip], 1)), its upsampled channels at the
     low resolution -- see tnv3_conv3x3_wgrad_up2x."""
     lib = _lib.load()
@@ -470,7 +478,7 @@ def conv3x3_wgrad_up2x(x_low, skip, dz):
     dw = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dz.device)
     ws = _workspace(lib.tnv3_conv3x3_wgrad_up2x_workspace_bytes(n, c0, c1, cout, h // 2, w // 2), dz.device)
     _lib.check(lib.tnv3_conv3x3_wgrad_up2x(_lib.ptr(x_low), _lib.ptr(skip), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8,
-                                           n, c0, c1, cout, h // 2, w // 2, _lib.stream_ptr(dz)))
+                                           n, c0, c1, cout, h // 2, w // 2, _wgrad_wino_variant(wino_variant), _lib.stream_ptr(dz)))
     return dw
 
 

@@ -66,6 +66,7 @@ def use_winograd_wgrad(cin, cout, h, w):
 # defaults the Python layer passes.  -1 = the library's default (xi-split Winograd kernel; register-staged weight gradient).
 WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 0: one wave per SIMD, 2: xi-split
 WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA staged kernels (parity-green, 8 % slower)
+WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))   # Winograd-form weight gradient: 0 the first kernel, 1 two waves / SIMD
 
 
 # BatchNorm batch statistics from the convolution's epilogue (training forward): available in Winograd kernel variants 3, 4 and 5.
