@@ -26,7 +26,7 @@ import torch  # noqa: E402
 SEQ_LEN, BG_MODE, H, W = 8, "concat", 288, 512
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (= fp32 vector peak)
 PEAK_HBM_GBPS = 8000.0
-KERNEL_SET = "wino_stream+conv_up2x+direct"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
+KERNEL_SET = "wino_stream+up2x_wino+direct"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
 ALG_BYTES_PER_SAMPLE = 693.55e6    # ideal-fusion fp32 bytes of one 27->8 forward
 
 
@@ -198,7 +198,10 @@ TRAIN_FLOPS_PER_SAMPLE = 678.2e9    # fwd + dgrad + wgrad (no dgrad f
 # form (16/36) in forward and data gradient, and those with >= 64 channels on both sides also in the weight gradient
 # (everything but the first layer).
 #   forward 98.7 (of 227.6), data gradient 96.6 (of 223.0), weight gradient 101.2 (of 227.6)
-TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 296.5e9
+# Round 2: the FORWARD of the upsampled halves runs in a Winograd form that keeps 9 of 16 GEMMs (9/36 instead of 4/9 of their
+# 65.2 GFLOP): forward 86.0.
+TRAIN_FLOPS_EXECUTED_PER_SAMPLE_CLASS_FILTERS = 296.5e9
+TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 296.5e9 - 65.2e9 * (4 / 9 - 9 / 36)
 
 
 def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False):
@@ -260,7 +263,8 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False):
                      "note": "`achieved` / `frac`: multiply-adds the matrix pipe EXECUTES per second (whole step time, so the HBM-bound "
                              "passes count against it) over the fp32 MFMA peak; `effective_tflops` prices the same time at the "
                              "reference's algorithmic FLOP count (SURVEY 8d: 678.2 GFLOP/sample) -- the upsampled channels of the "
-                             "three decoder-entry layers run at the low resolution in all three passes (4/9 of those MACs), the plain "
+                             "three decoder-entry layers run at the low resolution in all three passes (9/36 of those MACs in forward, 4/9 in the "
+                             "gradients), the plain "
                              "layers in fused Winograd F(2x2,3x3) form (16/36) in forward, data gradient and, from 64 channels, "
                              "weight gradient"},
         "dp_overlap": overlap, "final_loss": round(float(loss.item()), 6)}
@@ -329,7 +333,7 @@ def main():
     # per-launch timing of the dominant kernel family (conv3x3_mfma_kernel<*>): HIP events on the launch stream
     layers = conv_layer_table(in_dim, H, W)
     events = []
-    ops_conv, ops_up2x, ops_wino = ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino
+    ops_conv, ops_up2x, ops_wino, ops_up2xw = ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino
 
     def timed(kind, fn):
         def wrap(*a, **kw):
@@ -342,6 +346,7 @@ def main():
         return wrap
 
     timed_conv, timed_up2x, timed_wino = timed("conv", ops_conv), timed("up2x", ops_up2x), timed("conv", ops_wino)
+    timed_up2xw = timed("up2x", ops_up2xw)
 
     def barrier():
         if world > 1:
@@ -373,13 +378,13 @@ def main():
             for _ in range(min(args.warmup, 2)):
                 model(x)
             barrier()
-        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino = timed_conv, timed_up2x, timed_wino
+        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino = timed_conv, timed_up2x, timed_wino, timed_up2xw
         t0 = time.perf_counter()
         for _ in range(args.steps):
             y = model(x)
         barrier()
         dt_single = time.perf_counter() - t0
-        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino = ops_conv, ops_up2x, ops_wino
+        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino = ops_conv, ops_up2x, ops_wino, ops_up2xw
     if not split_on:
         dt = dt_single
 
@@ -432,7 +437,8 @@ def main():
         def executed(c0, c1, co, h, w, up):
             if up:
                 skip = conv_flops(c1, 0, co, h, w) * (16 / 36 if _tuning.use_winograd(c1, co, h, w) else 1.0)
-                return conv_flops(c0, 0, co, h, w) * 4 / 9 + skip
+                up_frac = 9 / 36 if (_tuning.UP2X_WINO and ops.up2x_wino_supported(c0, co, h // 2, w // 2)) else 4 / 9
+                return conv_flops(c0, 0, co, h, w) * up_frac + skip
             return conv_flops(c0, c1, co, h, w) * (16 / 36 if _tuning.use_winograd(c0, co, h, w) else 1.0)
         fl_exec = np.array([executed(c0, c1, co, h, w, up) * args.batch for (_, c0, c1, co, h, w, up) in layers])
         conv_ms = float(per_layer_ms.sum())
@@ -476,7 +482,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch",
-                         "kernel": f"conv3x3_wino_stream_mfma_kernel<*> + conv3x3_mfma_kernel<*> + conv_up2x_mfma_kernel<*> ({launches_per_step} "
+                         "kernel": f"conv3x3_wino_stream_mfma_kernel<*> + conv_up2x_wino_stream_kernel + conv3x3_mfma_kernel<*> ({launches_per_step} "
                                    "launches/step for the 17 conv layers, fp32 MFMA 32x32x2)",
                          "measured": "second pass of the same K steps with the whole batch on ONE stream (model.no_infer_split) and HIP "
                                      "events around every conv launch: a launch's duration is its own, not stretched by the other half's "
@@ -490,7 +496,7 @@ def main():
                          "speedup_vs_direct_flops": round(float(fl.sum() / fl_exec.sum()), 3),
                          "note": "`achieved` / `frac` = FLOPs the matrix pipe EXECUTES per second over the fp32 MFMA peak (an honest "
                                  "roofline position, <= 1).  The three decoder-entry layers evaluate their upsampled channels at the "
-                                 "low resolution with pre-summed taps (4/9 of those multiply-adds) and the plain layers run in fused "
+                                 "low resolution in a Winograd form that keeps 9 of the 16 GEMMs (9/36 of those multiply-adds) and the plain layers run in fused "
                                  "Winograd F(2x2,3x3) form (16/36), so the executed count is `executed_gflop_per_step`; "
                                  "`effective_tflops` prices the same kernel time at the reference's algorithmic count "
                                  "(2*9*Cin*Cout*H*W per layer, SURVEY 8d) and may exceed the peak -- it is a speed-up over the direct "

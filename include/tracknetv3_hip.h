@@ -135,6 +135,18 @@ int tnv3_pack_up2x_weights(const float* w, float* wq, int cout, int cin, int c0,
 int tnv3_conv_up2x_forward(const float* src_low, const float* wq, float* dst, int n, int c0, int cout, int h_low, int w_low,
                            int cfg /* tile configuration 0..3, -1 = library default */, tnv3_stream_t stream);
 
+/* The same partial sums in Winograd F(2x2, 3x3) form.  The 4x4 input patch of a nearest-2x upsampled tensor has rows
+ * (L[i-1], L[i], L[i], L[i+1]) of the low-resolution tensor, so the transform row d2 - d1 (and column) vanishes identically:
+ * 9 of the 16 Winograd GEMMs remain -- 9 multiply-adds per low-resolution pixel and channel pair instead of the 16 of the class
+ * filters above (36 in the reference's direct form).  Persistent streaming kernel, output transform in registers.
+ *   supported: c0 > 8, cout % 64 == 0, h_low % 2 == 0, w_low % 64 == 0.  u from tnv3_conv_up2x_wino_pack (the layer's
+ *   nn.Conv2d weight, its first c0 input channels), 16-byte aligned.  Same function up to fp32 rounding. */
+int tnv3_conv_up2x_wino_supported(int c0, int cout, int h_low, int w_low);
+size_t tnv3_conv_up2x_wino_packed_floats(int c0, int cout);
+int tnv3_conv_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, tnv3_stream_t stream);
+int tnv3_conv_up2x_wino_forward(const float* src_low, const float* u, float* dst, int n, int c0, int cout, int h_low, int w_low,
+                                tnv3_stream_t stream);
+
 /* Data gradient of that half-layer (autograd of nn.Upsample(scale_factor=2) -> Conv2d w.r.t. the low-res tensor), also at
  * the low resolution: dx_low[n][c0][h_low][w_low] = 4x4 stride-2 correlation of dz[n][cout][2*h_low][2*w_low] with the
  * pre-summed filters g (tnv3_pack_dgrad_up2x_weights from the same nn.Conv2d weight).  Replaces "3x3 data gradient at full

@@ -1,0 +1,45 @@
+"""Upsampled half of the three decoder-entry layers (batch 10): class-filter kernel (conv_up2x, 16 multiply-adds per low-res
+pixel and channel pair) vs the Winograd form that keeps 9 of the 16 GEMMs (conv_up2x_wino).  ms per launch, executed TFLOP/s of
+each formulation, max difference relative to the output scale."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tracknetv3_amd import ops
+
+
+def timeit(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    out = {}
+    for c0, c1, cout, hl, wl in ((512, 256, 256, 36, 64), (256, 128, 128, 72, 128), (128, 64, 64, 144, 256)):
+        xl = torch.relu(torch.randn(n, c0, hl, wl, device=dev))
+        w = (torch.rand(cout, c0 + c1, 3, 3, device=dev) - 0.5) * 0.1
+        wq, u = ops.pack_up2x_weights(w, c0), ops.pack_up2x_wino_weights(w, c0)
+        a, b = ops.conv_up2x(xl, wq, cout), ops.conv_up2x_wino(xl, u, cout)
+        row = {"rel_diff": float(f"{((a - b).abs().max() / a.abs().max()).item():.2e}")}
+        for rep in range(2):
+            t_a = timeit(lambda: ops.conv_up2x(xl, wq, cout))
+            t_b = timeit(lambda: ops.conv_up2x_wino(xl, u, cout))
+        lowpix = n * hl * wl
+        row["class_filters"] = {"ms": round(t_a, 4), "executed_tflops": round(2.0 * 16 * c0 * cout * lowpix / t_a / 1e9, 1)}
+        row["winograd_9_of_16"] = {"ms": round(t_b, 4), "executed_tflops": round(2.0 * 9 * c0 * cout * lowpix / t_b / 1e9, 1)}
+        out[f"{c0}->{cout}@{hl}x{wl}"] = row
+        print(f"{c0}->{cout}@{hl}x{wl}", json.dumps(row), flush=True)
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "up2x_wino_ab.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

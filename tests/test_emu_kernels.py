@@ -142,6 +142,42 @@ def test_conv_up2x_emulated_vs_torch(emu, case):
     assert e_up <= 2e-6 and e_full <= 2e-6, (e_up, e_full)
 
 
+# (n, c0, cout, h_low, w_low): two / three / nine chunks, one / two channel blocks, several tiles per workgroup, borders on all sides
+UP2X_WINO_CASES = [(1, 12, 64, 2, 64), (2, 20, 128, 4, 64), (1, 70, 64, 2, 128), (3, 16, 192, 6, 64)]
+
+
+def _up2x_wino_case(n, c0, cout, hl, wl, device):
+    """The upsampled half in Winograd form (9 of 16 GEMMs) against fp64 torch on the materialised upsampled tensor and against
+    the class-filter kernel (conv_up2x)."""
+    from tracknetv3_amd import ops
+    assert ops.up2x_wino_supported(c0, cout, hl, wl)
+    xl = torch.relu(T((n, c0, hl, wl), 71))
+    w = T((cout, c0 + 8, 3, 3), 73, -0.3, 0.3)
+    up = xl.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    ref = F.conv2d(up.double(), w[:, :c0].double(), padding=1)
+    got = ops.conv_up2x_wino(xl.to(device), ops.pack_up2x_wino_weights(w.to(device), c0), cout)
+    old = ops.conv_up2x(xl.to(device), ops.pack_up2x_weights(w.to(device), c0), cout)
+    s = ref.abs().max()
+    return ((got.cpu().double() - ref).abs().max() / s).item(), ((got - old).abs().max().cpu().double() / s).item()
+
+
+@pytest.mark.parametrize("cus", [256, 8])
+@pytest.mark.parametrize("case", UP2X_WINO_CASES)
+def test_conv_up2x_wino_emulated_vs_torch(emu, monkeypatch, case, cus):
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))        # 8 CUs: the persistent workgroups walk several tiles each
+    e_ref, e_old = _up2x_wino_case(*case, "cpu")
+    assert e_ref <= 3e-6 and e_old <= 4e-6, (e_ref, e_old)
+
+
+def test_conv_up2x_wino_unsupported_shapes_are_refused(emu):
+    from tracknetv3_amd import _lib, ops
+    assert not ops.up2x_wino_supported(8, 64, 4, 64) and not ops.up2x_wino_supported(16, 64, 3, 64) and not ops.up2x_wino_supported(16, 64, 4, 32)
+    assert not ops.up2x_wino_supported(16, 96, 4, 64)
+    w = T((64, 24, 3, 3), 73, -0.3, 0.3)
+    with pytest.raises(_lib.Tnv3Error):
+        ops.conv_up2x_wino(T((1, 16, 4, 32), 1), ops.pack_up2x_wino_weights(w, 16), 64)
+
+
 @pytest.mark.parametrize("cfg", [2, 3])
 def test_conv_up2x_big_tile_configs_emulated(emu, cfg):
     e_up, e_full = _up2x_case(1, 8, 128, 5, 36, "cpu", cfg=cfg)       # 8-row tiles: ragged in both directions

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import GOLDEN
-from test_emu_kernels import UP2X_CASES, WINO_CASES, _dgrad_up2x_case, _pack_view_case, _up2x_case, _wino_case
+from test_emu_kernels import UP2X_CASES, UP2X_WINO_CASES, WINO_CASES, _dgrad_up2x_case, _pack_view_case, _up2x_case, _up2x_wino_case, _wino_case
 from oracle import nets, prng
 from test_emu_kernels import CONV_CASES, T, conv_ref
 
@@ -58,6 +58,14 @@ def test_conv_up2x_vs_torch(gpu_device, case):
     n, c0, cout, hl, wl = case
     e_up, e_full = _up2x_case(n, c0, cout, hl, wl, gpu_device, c1=c0 // 2 if c0 >= 64 else 16)
     assert e_up <= 3e-6 and e_full <= 3e-6, (e_up, e_full)
+
+
+@pytest.mark.parametrize("case", UP2X_WINO_CASES + [(2, 512, 256, 36, 64), (1, 128, 64, 144, 256), (3, 256, 128, 72, 128), (10, 128, 64, 144, 256)])
+def test_conv_up2x_wino_vs_torch(gpu_device, case):
+    """The upsampled half in Winograd form (9 of the 16 GEMMs) against fp64 torch on the materialised upsampled tensor and against
+    the class-filter kernel; the last case is the batch-10 network shape (several tiles per persistent workgroup)."""
+    e_ref, e_old = _up2x_wino_case(*case, gpu_device)
+    assert e_ref <= 3e-6 and e_old <= 4e-6, (e_ref, e_old)
 
 
 @pytest.mark.parametrize("case", UP2X_CASES + [(2, 512, 256, 36, 64), (1, 128, 64, 144, 256), (2, 256, 128, 9, 40)])

@@ -7,6 +7,7 @@
 
 #include "kernels/conv3x3_mfma.h"
 #include "kernels/conv_up2x_mfma.h"
+#include "kernels/conv_up2x_wino_mfma.h"
 #include "kernels/conv3x3_wino_mfma.h"
 #include "kernels/conv3x3_wino3_mfma.h"
 #include "kernels/conv1d_k3.h"
@@ -686,6 +687,36 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   if ((nel & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dw) & 15) == 0)
     return L.launch(sum_partials_vec4_kernel, grid_for(nel / 4, 256, 8192), 256, (const float*)slabs, dw, nel / 4, p.splitK);
   return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)slabs, dw, nel, p.splitK);
+}
+
+// ---- the upsampled half of a decoder-entry layer in Winograd form: 9 of the 16 GEMMs (kernels/conv_up2x_wino_mfma.h)
+inline bool conv_up2x_wino_supported(int c0, int cout, int hl, int wl) {
+  return c0 > ConvUp2xWinoCfg::CC && cout > 0 && cout % 64 == 0 && hl > 0 && wl > 0 && hl % 2 == 0 && wl % ConvUp2xWinoCfg::TW == 0 &&
+         (long)64 * 4 * hl * wl * 4 < (1l << 31) && (long)c0 * hl * wl * 4 < (1l << 31) && (long)cout * 9 * 8 * 4 < (1l << 31);
+}
+inline size_t conv_up2x_wino_packed_floats(int c0, int cout) {
+  if (c0 <= 0 || cout <= 0) return 0;
+  return (size_t)round_up(c0, ConvUp2xWinoCfg::CC) * 9 * cout + kPackZeroTail;
+}
+template <class Launcher>
+int conv_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin, int c0) {
+  if (!w || !u || cout <= 0 || cin <= 0 || c0 <= 0 || c0 > cin) TNV3_FAIL(-1, "conv_up2x_wino_pack: bad argument");
+  const int c0pad = round_up(c0, ConvUp2xWinoCfg::CC);
+  const long total = (long)c0pad * cout;
+  int rc;
+  if ((rc = L.launch(fill_zero_kernel, 1, 256, u + (size_t)c0pad * 9 * cout, kPackZeroTail))) return rc;
+  return L.launch(conv_up2x_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, c0, c0pad);
+}
+template <class Launcher>
+int conv_up2x_wino_forward_impl(Launcher& L, const float* src, const float* u, float* dst, int n, int c0, int cout, int hl, int wl) {
+  if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv_up2x_wino: bad argument");
+  if (!conv_up2x_wino_supported(c0, cout, hl, wl))
+    TNV3_FAIL(-1, "conv_up2x_wino: needs C0 > 8, Cout %% 64 == 0, H_low %% 2 == 0, W_low %% 64 == 0 (got %d -> %d, %dx%d)", c0, cout, hl, wl);
+  if ((((uintptr_t)dst) & 7) || (((uintptr_t)u | (uintptr_t)src) & 15)) TNV3_FAIL(-1, "conv_up2x_wino: misaligned pointer");
+  ConvUp2xWinoArgs a{src, u, dst, n, c0, cout, hl, wl};
+  const long npt = (long)n * (hl / 2) * (wl / ConvUp2xWinoCfg::TW);
+  if (npt > (1l << 28)) TNV3_FAIL(-1, "conv_up2x_wino: too many tiles");
+  return L.launch(conv_up2x_wino_stream_kernel, wino_persistent_grid(conv_grid_blocks(cout / ConvUp2xWinoCfg::MB, (int)npt)), ConvUp2xWinoCfg::NT, a);
 }
 
 // ---- weight gradient of a plain layer in Winograd F(2x2, 3x3) form (kernels/wgrad_wino_mfma.h)

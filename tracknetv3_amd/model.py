@@ -103,6 +103,16 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
+    def packed_up2x_wino(self, c0):
+        """U' of the first c0 (upsampled) input channels for the Winograd form of the low-resolution half (ops.conv_up2x_wino)."""
+        key = ("up2xw", int(c0))
+        ver = self._versions(["conv"])
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_up2x_wino_weights(self.conv.weight.detach(), c0))
+            self._cache[key] = hit
+        return hit[1]
+
     def packed_dgrad_up2x(self, c0):
         """(4x4 stride-2 filters of the low-resolution data gradient w.r.t. the first c0 inputs, transposed / flipped 3x3
         filter of the remaining skip channels): the backward twins of packed_up2x."""
@@ -119,9 +129,15 @@ class Conv2DBlock(nn.Module):
         """conv3x3(cat([upsample2x(x_low), skip], 1)) with the upsampled half computed at the low resolution.  want_stats (training
         forward, Winograd skip half): returns (z, tile_stats) -- BatchNorm's batch statistics from the kernel's epilogue."""
         c0, c1 = int(x_low.shape[1]), int(skip.shape[1])
-        wq, wskip = self.packed_up2x(c0)
-        part = ops.conv_up2x(x_low, wq, self.conv.out_dim)
         h, w = int(skip.shape[2]), int(skip.shape[3])
+        if tuning.UP2X_WINO and ops.up2x_wino_supported(c0, self.conv.out_dim, h // 2, w // 2):
+            part = ops.conv_up2x_wino(x_low, self.packed_up2x_wino(c0), self.conv.out_dim)     # 9 of the 16 Winograd GEMMs
+            wskip = None
+        else:
+            wq, wskip = self.packed_up2x(c0)
+            part = ops.conv_up2x(x_low, wq, self.conv.out_dim)
+        if wskip is None and not (c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_winograd(c1, self.conv.out_dim, h, w)):
+            wskip = self.packed_up2x(c0)[1]
         cfg = tuning.conv_config(self.conv.out_dim, c1, n, h, w)
         bn = self.bn
         if affine and c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # eval mode: the skip half in Winograd form
@@ -265,6 +281,7 @@ class TrackNet(nn.Module):
                     if i == 0 and blk in (self.up_block_1, self.up_block_2, self.up_block_3):
                         c0 = b.conv.in_dim * 2 // 3               # decoder entry: 2/3 of the inputs are the upsampled tensor
                         b.packed_up2x(c0)
+                        b.packed_up2x_wino(c0)
                         b.packed_wino(c0)
                     else:
                         b.packed_weight()

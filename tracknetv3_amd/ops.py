@@ -154,6 +154,36 @@ def conv_up2x(src_low, wq, cout, cfg=-1):
     return out
 
 
+def up2x_wino_supported(c0, cout, hl, wl):
+    return bool(_lib.load().tnv3_conv_up2x_wino_supported(int(c0), int(cout), int(hl), int(wl)))
+
+
+def pack_up2x_wino_weights(weight, c0):
+    """U' of the first c0 (upsampled) input channels of a decoder-entry layer's weight (tnv3_conv_up2x_wino_pack)."""
+    lib = _lib.load()
+    _f32(weight)
+    _lib.dev_check(weight)
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    u = torch.empty(lib.tnv3_conv_up2x_wino_packed_floats(int(c0), cout), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.tnv3_conv_up2x_wino_pack(_lib.ptr(weight), _lib.ptr(u), cout, cin, int(c0), _lib.stream_ptr(weight)))
+    return u
+
+
+def conv_up2x_wino(src_low, u, cout):
+    """Partial sums of conv3x3 over the nearest-2x upsampling of src_low in Winograd form, 9 of 16 GEMMs (tnv3_conv_up2x_wino_forward)."""
+    lib = _lib.load()
+    _f32(src_low, u)
+    _lib.dev_check(src_low, u)
+    n, c0, hl, wl = (int(v) for v in src_low.shape)
+    if u.numel() != lib.tnv3_conv_up2x_wino_packed_floats(c0, int(cout)):
+        raise _lib.Tnv3Error("conv_up2x_wino: filter buffer does not match the channel counts")
+    out = torch.empty((n, int(cout), 2 * hl, 2 * wl), dtype=torch.float32, device=src_low.device)
+    if n:
+        _lib.check(lib.tnv3_conv_up2x_wino_forward(_lib.ptr(src_low), _lib.ptr(u), _lib.ptr(out), n, c0, int(cout), hl, wl,
+                                                   _lib.stream_ptr(src_low)))
+    return out
+
+
 def pack_dgrad_up2x_weights(weight, c0):
     """nn.Conv2d weight (Cout, Cin, 3, 3) -> the 4x4 stride-2 filters of the low-resolution data gradient (first c0 inputs)."""
     lib = _lib.load()
@@ -730,7 +760,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # The C ABI runs a call on its stream's device, but a tensor's *default* stream is the NULL stream (= "the calling thread's
 # current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
-_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x",
+_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",

@@ -81,5 +81,10 @@ INFER_SPLIT_MIN_BATCH = 4
 INFER_SPLIT_MIN_PIXELS = 1 << 19          # batch x H x W below which the launches are too short to be worth a second stream
 
 
+# Upsampled half of the decoder-entry layers: Winograd form with 9 of the 16 GEMMs (kernels/conv_up2x_wino_mfma.h) instead of the
+# four pre-summed 2x2 class filters (conv_up2x_mfma.h): 0.79 -> 0.50 ms per layer at batch 10 (profiles/r02_up2x_wino_ab.json).
+UP2X_WINO = os.environ.get("TNV3_UP2X_WINO", "1") != "0"
+
+
 def wino_has_stats():
     return BN_STATS_IN_EPILOGUE and WINO_VARIANT in (-1, 3, 4, 5)
