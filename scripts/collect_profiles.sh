@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies the summaries of the last scripts/gpu_session.sh run from gpurun_out/ (scratch) into profiles/ (tracked).
+# Copies the summaries of the last scripts/gpu_s8.sh evidence session from gpurun_out/ (scratch) into profiles/ (tracked).
 set -eu
 cd "$(dirname "$0")/.."
 R=${ROUND:-r02}
@@ -8,12 +8,16 @@ P=profiles
 cp $O/bench.json $P/${R}_bench_n1.json
 cp $O/bench_layers.json $P/${R}_bench_layers.json
 cp $O/bench_train.json $P/${R}_bench_train_n1.json
-cp $O/microbench.json $P/${R}_microbench.json
 cp $O/prof_infer.json $P/${R}_bench_n1_under_rocprof.json
+cp $O/prof_train.json $P/${R}_bench_train_under_rocprof.json
 cp $O/prof_infer_kernel_stats.csv $P/${R}_infer_kernel_stats.csv
 cp $O/prof_train_kernel_stats.csv $P/${R}_train_kernel_stats.csv
 cp $O/pmc_fetch_pmc.csv $P/${R}_infer_pmc_fetch_size.csv
 cp $O/pmc_write_pmc.csv $P/${R}_infer_pmc_write_size.csv
+for f in sq1 sq2 sq3 tcc; do cp $O/pmc_$f.csv $P/${R}_infer_pmc_$f.csv; done
+for f in r02_wino_variants_ab2.json r02_wino_stream_twins.json r02_wino_fixed_cost.json; do [ -f $O/$f ] && cp $O/$f $P/$f; done
+[ -f $O/fullsize_train_parity.json ] && cp $O/fullsize_train_parity.json $P/${R}_fullsize_train_parity.json
+[ -f $O/e2e_real_network_report.json ] && cp $O/e2e_real_network_report.json $P/${R}_e2e_real_network_report.json
 python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json ${COMMIT:-$(git rev-parse --short HEAD)}
 cp $O/session.log $P/${R}_session_final.log
 echo "profiles/ refreshed from $O"
