@@ -172,7 +172,10 @@ int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* wo
  * windows against x_low (16 instead of 36 taps per low-res pixel), the c1 skip channels as an ordinary 3x3 weight gradient.
  *   x_low [n][c0][h_low][w_low], skip [n][c1][2*h_low][2*w_low], dz [n][cout][2*h_low][2*w_low];  w_low % 4 == 0.
  * Deterministic (split-K slabs reduced in a fixed order); workspace from the _workspace_bytes query, 16-byte aligned.
- * `wino_variant`: kernel of the skip half when it runs in Winograd form (as `variant` of tnv3_conv3x3_wgrad_wino). */
+ * `wino_variant` (per call): -1 / 2 = the defaults -- upsampled half in the 9-GEMM Winograd form of tnv3_conv_up2x_wino_forward
+ * (9 instead of 16 multiply-adds per low-res pixel; needs c0 % 128 == 0, cout % 64 == 0, w_low % 8 == 0, else the next), skip half
+ * by the second Winograd weight-gradient kernel;  1 = upsampled half by four 2x2-window launches over the parity images of dz;
+ * 0 = 1 with the first Winograd kernel for the skip half.  All compute the same gradient up to fp32 rounding. */
 size_t tnv3_conv3x3_wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int h_low, int w_low);
 int tnv3_conv3x3_wgrad_up2x(const float* x_low, const float* skip, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
                             int n, int c0, int c1, int cout, int h_low, int w_low, int wino_variant, tnv3_stream_t stream);

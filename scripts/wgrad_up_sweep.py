@@ -36,9 +36,10 @@ def main():
         b = via_wino()
         err = ((a - b).abs().max() / a.abs().max()).item()
         t_a = timeit(lambda: ops.conv3x3_wgrad_up2x(x_low, skip, dz))
+        t_old = timeit(lambda: ops.conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=1))
         t_b = timeit(via_wino)
         t_up = timeit(lambda: F.interpolate(x_low, scale_factor=2, mode="nearest"))
-        out[f"{c0}+{c1}->{cout}@{2*hl}x{2*wl}"] = {"up2x_ms": round(t_a, 4), "wino_on_upsampled_ms": round(t_b, 4), "upsample_ms": round(t_up, 4),
+        out[f"{c0}+{c1}->{cout}@{2*hl}x{2*wl}"] = {"up2x_ms": round(t_a, 4), "up2x_2x2_windows_ms": round(t_old, 4), "wino_on_upsampled_ms": round(t_b, 4), "upsample_ms": round(t_up, 4),
                                                   "rel_diff": float(f"{err:.2e}")}
     print(json.dumps(out, indent=1))
 

@@ -80,7 +80,8 @@ def _wgrad_case(case, ops):
 
 
 WGRAD_UP2X_CASES = [(1, 8, 16, 64, 4, 20), (2, 32, 32, 128, 3, 36), (1, 64, 32, 64, 6, 32),    # (n, c0, c1, cout, h_low, w_low)
-                    (1, 64, 128, 128, 2, 16)]                                              # skip half on the Winograd-form kernel
+                    (1, 64, 128, 128, 2, 16),                                              # skip half on the Winograd-form kernel
+                    (1, 128, 64, 64, 4, 16), (2, 128, 16, 128, 3, 24), (1, 256, 64, 64, 2, 8)]   # c0 % 128 == 0: upsampled half in the 9-GEMM form
 
 
 def _wgrad_up2x_case(case, device):
@@ -94,6 +95,9 @@ def _wgrad_up2x_case(case, device):
     dw = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device))
     dw2 = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device))
     assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
+    for v in (0, 1):                             # the older kernel choices compute the same gradient
+        dwv = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=v)
+        assert rel_err(dwv.cpu(), dw.cpu().double()) <= 4e-6, v
     return rel_err(dw.cpu(), wd.grad), rel_err(dw.cpu()[:, :c0], wd.grad[:, :c0])
 
 
@@ -128,6 +132,15 @@ WGRAD_WINO_EMU_EXTRA = [(1, 64, 64, 10, 16), (1, 64, 64, 14, 16), (3, 64, 64, 4,
 @pytest.mark.parametrize("case", WGRAD_WINO_CASES + WGRAD_WINO_EMU_EXTRA)
 def test_wgrad_wino_emulated_vs_autograd(emu, case):
     assert _wgrad_wino_case(case, "cpu") <= 4e-6
+
+
+@pytest.mark.parametrize("cus", [1, 2, 3, 5])
+def test_wgrad_up2x_wino_long_chunk_walks_emulated(emu, monkeypatch, cus):
+    """The 9-GEMM weight gradient of the upsampled half with few CUs: every workgroup walks many 8-pixel strips (cursor carries
+    over segments, rows and images; borders on every side)."""
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+    e_all, e_up = _wgrad_up2x_case((3, 128, 16, 64, 4, 24), "cpu")
+    assert e_all <= 3e-6 and e_up <= 3e-6, (e_all, e_up)
 
 
 @pytest.mark.parametrize("cus", [1, 2, 3, 5])

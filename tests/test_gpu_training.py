@@ -81,7 +81,7 @@ def _wgrad_case(case, ops, d):
             assert rel_err(dx1.cpu(), xd.grad[:, c0:]) <= 3e-6
 
 
-@pytest.mark.parametrize("case", WGRAD_UP2X_CASES + [(2, 512, 256, 256, 8, 32), (1, 128, 64, 64, 32, 64)])
+@pytest.mark.parametrize("case", WGRAD_UP2X_CASES + [(2, 512, 256, 256, 8, 32), (1, 128, 64, 64, 32, 64), (3, 256, 128, 128, 72, 128)])
 def test_wgrad_up2x_vs_autograd(gpu_device, case):
     e_all, e_up = _wgrad_up2x_case(case, gpu_device)
     assert e_all <= 3e-6 and e_up <= 3e-6, (e_all, e_up)

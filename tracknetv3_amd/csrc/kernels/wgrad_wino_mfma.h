@@ -411,6 +411,253 @@ inline __global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_ker
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the UPSAMPLED half of a decoder-entry layer (model.py:65,67,69) in the 9-GEMM Winograd form of
+// conv_up2x_wino_mfma.h.  Forward: M_xi = sum_ci U'_xi V'_xi for the nine xi at transform rows / columns {0, 1, 3}, U' = G' g G'^T
+// (G' = [1 0 0; 1 1 1; 0 0 1]), V' from the 3x3 low-resolution neighbourhood (rows L[i-1] - L[i], L[i], L[i] - L[i+1], then the
+// same along the columns), Y = A^T M A.  Hence
+//     dU'_xi[co][ci] = sum_{n, low-res pixels}  Yh_xi[co][p] * V'_xi[ci][p],     Yh = rows / columns {0, 1, 3} of A dY A^T
+//     dg = G'^T dU' G'                                                           (wgrad_up2x_wino_fold_kernel)
+// -- nine GEMMs with K = the low-resolution pixels of the batch: 9 multiply-adds per (co, ci, low-res pixel) instead of the 16 of
+// the four 2x2-window launches (and no parity split of dZ, no per-parity reductions).
+// Kernel: the structure of wgrad_wino2_mfma_kernel -- 512 threads, two wave groups half a period apart, buffer-descriptor LDS-DMA,
+// strip cursor without divisions -- with a 64 co x 128 ci block: nine accumulators per 32 x 32 block fit one wave (144 registers),
+// so a wave owns all xi of its block; group g takes ci 64g .. 64g+63 and keeps its own copy of both transformed operands (Yh of
+// all 64 co: 12 adds per tile pair, cheaper than sharing it across the groups' phases).  A chunk = 8 low-resolution pixels of one
+// row (2 x 16 pixels of dZ): 36 MFMAs per wave.
+struct WgradUp2xWinoArgs {
+  const float* x_low;   // [N][C0][Hl][Wl]
+  const float* dz;      // [N][Cout][2 Hl][2 Wl]
+  float* part;          // [splitK][9][Cout][C0]
+  int N, C0, Cout, Hl, Wl, splitK;
+};
+
+struct WgradUp2xWinoCfg {
+  static constexpr int NT = 512, TCH = 8, TS = TCH + 1, NXI = 9, CB = 128;
+  static constexpr int OP_FLOATS = NXI * 64 * TS;                       // one transformed operand of one group: [xi][channel][tile]
+  static constexpr int DZ_RAW = 64 * 2 * 16;                            // [co][2 rows][16 px]
+  static constexpr int XW = 16, X_RAW = CB * 3 * XW;                    // [ci][3 low rows][16 low px: columns 8j-4 .. 8j+11]
+  static constexpr int RAW_STAGE = DZ_RAW + X_RAW;
+  static constexpr int NX = X_RAW / 4 / NT;                             // x pieces per thread and chunk (3); one dZ piece
+  static constexpr int LDS_FLOATS = 4 * OP_FLOATS + 2 * RAW_STAGE;
+  static_assert(DZ_RAW / 4 == NT && X_RAW % (4 * NT) == 0, "pieces must deal evenly");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
+
+inline __global__ void __launch_bounds__(WgradUp2xWinoCfg::NT) wgrad_up2x_wino_mfma_kernel(const WgradUp2xWinoArgs a) {
+  using Cfg = WgradUp2xWinoCfg;
+  constexpr int NT = Cfg::NT, TS = Cfg::TS, XW = Cfg::XW, NX = Cfg::NX, NXI = Cfg::NXI, CB = Cfg::CB;
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int wm = wq & 1, wn = wq >> 1;                      // wm: co half; wn: 32-channel half of the group's 64 ci
+  const int half = lane >> 5, bl = lane & 31;
+  float* yh_s = lds + grp * 2 * Cfg::OP_FLOATS;             // this group's operands
+  float* v_s = yh_s + Cfg::OP_FLOATS;
+  float* raw_s = lds + 4 * Cfg::OP_FLOATS;                  // two stages of [dz strip | x strip], shared by the groups
+  const int Hl = a.Hl, Wl = a.Wl, C0 = a.C0, Cout = a.Cout, HWl = Hl * Wl, W = 2 * Wl, HW = 4 * HWl;
+  const int nCB = C0 / CB;
+  int b = blockIdx.x;
+  const int ks = b % a.splitK; b /= a.splitK;
+  const int cb = b % nCB, mb = b / nCB;
+  const int co0 = mb * 64, ci0 = cb * CB;
+  const int segW = Wl / 8;
+  const int nChunksAll = a.N * Hl * segW;
+  const int nMine = nChunksAll > ks ? (nChunksAll - ks + a.splitK - 1) / a.splitK : 0;      // chunks ks, ks + splitK, ...
+
+  // ---- the DMA cursor: (image, low-res row, 8-pixel segment) of the next chunk to fetch; one step = splitK chunks
+  const int per_img = Hl * segW;
+  int c_n = ks / per_img, c_i = (ks - c_n * per_img) / segW, c_j = ks - c_n * per_img - c_i * segW;
+  const int d_n = a.splitK / per_img, d_i = (a.splitK - d_n * per_img) / segW, d_j = a.splitK - d_n * per_img - d_i * segW;
+
+  unsigned vo_dz, vo_x[NX], edge[NX];                      // edge bits: piece lies in strip row 0 / row 2 / column piece 0 / column piece 3
+  {
+    const int q4 = tid & 3, r = (tid >> 2) & 1, co = tid >> 3;            // dZ piece of [co][2 rows][4 pieces]
+    vo_dz = (unsigned)(co * HW + r * W + 4 * q4) * 4u;
+#pragma unroll
+    for (int p = 0; p < NX; ++p) {
+      const int e = tid + p * NT;                                          // X piece of [ci][3 rows][4 pieces]
+      const int q = e & 3, t2 = e >> 2;
+      const int r3 = t2 % 3, ci = t2 / 3;
+      vo_x[p] = (unsigned)(ci * HWl + r3 * Wl + 4 * q) * 4u;
+      edge[p] = (r3 == 0 ? 1u : 0u) | (r3 == 2 ? 2u : 0u) | (q == 0 ? 4u : 0u) | (q == 3 ? 8u : 0u);
+    }
+  }
+  const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);             // scalar: the LDS-DMA destinations (M0) stay on the SALU
+  auto dma_chunk = [&](int stage) {                                        // the cursor's chunk -> raw stage; then the cursor advances
+    const tnv3_rsrc_t r_dz = tnv3_make_rsrc(a.dz + ((size_t)c_n * Cout + co0) * HW, 64u * (unsigned)HW * 4u);
+    const tnv3_rsrc_t r_x = tnv3_make_rsrc(a.x_low + ((size_t)c_n * C0 + ci0) * HWl, (unsigned)CB * (unsigned)HWl * 4u);
+    const int off_dz = (2 * c_i * W + 16 * c_j) * 4;
+    const int off_x = ((c_i - 1) * Wl + 8 * c_j - 4) * 4;                // negative at the top-left corner: only out-of-image pieces
+    const unsigned border = (c_i == 0 ? 1u : 0u) | (c_i == Hl - 1 ? 2u : 0u) | (c_j == 0 ? 4u : 0u) | (c_j == segW - 1 ? 8u : 0u);
+    float* rs = raw_s + stage * Cfg::RAW_STAGE;
+    tnv3_buf_dma16(r_dz, rs + wbase * 4, vo_dz + (unsigned)off_dz);
+#pragma unroll
+    for (int p = 0; p < NX; ++p)
+      tnv3_buf_dma16(r_x, rs + Cfg::DZ_RAW + (p * NT + wbase) * 4, (edge[p] & border) ? kDmaOob : vo_x[p] + (unsigned)off_x);
+    c_j += d_j; if (c_j >= segW) { c_j -= segW; ++c_i; }
+    c_i += d_i; if (c_i >= Hl) { c_i -= Hl; ++c_n; }
+    c_n += d_n;
+  };
+
+  // ---- transforms of a low-res pixel pair (2tp, 2tp+1): thread (channel ch, pair tp) of its group -> Yh (co = ch) and V' (ci = 64 grp + ch)
+  const int tg = tid & 255, ch = tg >> 2, tp = tg & 3;
+  const bool odd = (tp & 1) != 0;
+  auto transform = [&](int stage) {
+    const float* rs = raw_s + stage * Cfg::RAW_STAGE;
+    {   // Yh = rows / columns {0, 1, 3} of A dY A^T,  A = [1 0; 1 1; 1 -1; 0 -1]: (y0, y0 + y1, -y1), the same along the columns
+      const f32x4 ya = *reinterpret_cast<const f32x4*>(rs + ch * 32 + 4 * tp);          // dZ row 2i,   columns 4tp .. 4tp+3
+      const f32x4 yb = *reinterpret_cast<const f32x4*>(rs + ch * 32 + 16 + 4 * tp);     // dZ row 2i+1
+      float* o = yh_s + ch * TS + 2 * tp;
+#pragma unroll
+      for (int ra = 0; ra < 3; ++ra) {
+        float rr[2][2];                                                                  // [pixel of the pair][column of its 2x2 block]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float y00 = ya[2 * t], y01 = ya[2 * t + 1], y10 = yb[2 * t], y11 = yb[2 * t + 1];
+          rr[t][0] = ra == 0 ? y00 : (ra == 1 ? y00 + y10 : -y10);
+          rr[t][1] = ra == 0 ? y01 : (ra == 1 ? y01 + y11 : -y11);
+        }
+        float* oi = o + (ra * 3) * 64 * TS;
+        oi[0 * 64 * TS] = rr[0][0];            oi[0 * 64 * TS + 1] = rr[1][0];
+        oi[1 * 64 * TS] = rr[0][0] + rr[0][1]; oi[1 * 64 * TS + 1] = rr[1][0] + rr[1][1];
+        oi[2 * 64 * TS] = -rr[0][1];           oi[2 * 64 * TS + 1] = -rr[1][1];
+      }
+    }
+    {   // V': low rows i-1, i, i+1 (strip rows 0..2), low columns 8j + 2tp - 1 .. 8j + 2tp + 2 = strip columns 2tp+3 .. 2tp+6
+      const float* d = rs + Cfg::DZ_RAW + (grp * 64 + ch) * (3 * XW) + 4 * (tp >> 1);
+      float x[3][4];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(d + r * XW);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(d + r * XW + 4);
+        const float q2 = d[r * XW + 8];
+        x[r][0] = odd ? q1[1] : q0[3]; x[r][1] = odd ? q1[2] : q1[0]; x[r][2] = odd ? q1[3] : q1[1]; x[r][3] = odd ? q2 : q1[2];
+      }
+      float* o = v_s + ch * TS + 2 * tp;
+#pragma unroll
+      for (int ra = 0; ra < 3; ++ra) {
+        float rr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = ra == 0 ? x[0][j] - x[1][j] : (ra == 1 ? x[1][j] : x[1][j] - x[2][j]);
+        float* oi = o + (ra * 3) * 64 * TS;
+        oi[0 * 64 * TS] = rr[0] - rr[1]; oi[0 * 64 * TS + 1] = rr[1] - rr[2];
+        oi[1 * 64 * TS] = rr[1];         oi[1 * 64 * TS + 1] = rr[2];
+        oi[2 * 64 * TS] = rr[1] - rr[2]; oi[2 * 64 * TS + 1] = rr[2] - rr[3];
+      }
+    }
+  };
+
+  f32x16 acc[NXI];
+#pragma unroll
+  for (int x = 0; x < NXI; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+  const float* A = yh_s + (wm * 32 + bl) * TS + half;
+  const float* B = v_s + (wn * 32 + bl) * TS + half;
+  auto mfma_chunk = [&]() {                                 // 4 pixel pairs x 9 xi
+    constexpr int NSTEP = 4 * NXI;
+    constexpr int PF = 4, RING = PF + 1;
+    float av[RING], bv[RING];
+    auto read_step = [&](int s) {
+      const int t2 = s / NXI, xi = s - t2 * NXI;
+      av[s % RING] = A[xi * 64 * TS + 2 * t2];
+      bv[s % RING] = B[xi * 64 * TS + 2 * t2];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) read_step(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + PF < NSTEP) read_step(s + PF);
+      acc[s % NXI] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s % NXI], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+  auto phase_end = [&](bool dma_too) {
+    if (dma_too) __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // Phases as in wgrad_wino2_mfma_kernel: group 0 runs half a period ahead of group 1; one loop per group (one MFMA site each).
+  const int sgrp = __builtin_amdgcn_readfirstlane(grp);
+  if (nMine > 0) {
+    dma_chunk(0);
+    if (nMine > 1) dma_chunk(1);
+  }
+  phase_end(true);
+  if (sgrp == 0) {
+    if (nMine > 0) transform(0);
+    phase_end(false);
+    for (int q = 0; q < nMine; ++q) {
+      mfma_chunk();
+      phase_end(true);
+      if (q + 2 < nMine) dma_chunk(q & 1);
+      if (q + 1 < nMine) transform((q + 1) & 1);
+      phase_end(false);
+    }
+  } else {
+    phase_end(false);
+    for (int q = 0; q < nMine; ++q) {
+      transform(q & 1);
+      phase_end(true);
+      if (q + 2 < nMine) dma_chunk(q & 1);
+      mfma_chunk();
+      phase_end(false);
+    }
+  }
+
+  // partial slab: part[ks][xi][co][ci]
+  float* slab = a.part + (size_t)ks * NXI * Cout * C0;
+  const int ci = ci0 + grp * 64 + wn * 32 + bl;
+#pragma unroll
+  for (int x = 0; x < NXI; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      slab[((size_t)x * Cout + co) * C0 + ci] = acc[x][r];
+    }
+}
+
+// d9[co][ci][3][3] = G'^T (sum_ks part[ks][.][co][ci]) G',  G' = [1 0 0; 1 1 1; 0 0 1]: the slabs are added in the fixed order
+// ks = 0, 1, ... in fp64 (deterministic), one thread per (co, ci).
+inline __global__ void __launch_bounds__(256) wgrad_up2x_wino_fold_kernel(const float* __restrict__ part, float* __restrict__ d9, int Cout, int C0,
+                                                                       int splitK) {
+  const long n = (long)Cout * C0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    double u[9];
+#pragma unroll
+    for (int x = 0; x < 9; ++x) u[x] = 0.0;
+    for (int k = 0; k < splitK; ++k) {
+      const float* src = part + (size_t)k * 9 * n + e;
+#pragma unroll
+      for (int x = 0; x < 9; ++x) u[x] += (double)src[(size_t)x * n];
+    }
+    float uf[3][3], t[3][3];
+#pragma unroll
+    for (int x = 0; x < 9; ++x) uf[x / 3][x % 3] = (float)u[x];
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2) { t[0][b2] = uf[0][b2] + uf[1][b2]; t[1][b2] = uf[1][b2]; t[2][b2] = uf[1][b2] + uf[2][b2]; }
+    float* o = d9 + e * 9;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) { o[kh * 3 + 0] = t[kh][0] + t[kh][1]; o[kh * 3 + 1] = t[kh][1]; o[kh * 3 + 2] = t[kh][1] + t[kh][2]; }
+  }
+}
+
+// dW[Cout][C0+C1][9]: input channels < C0 from d9[Cout][C0][9], the rest from dw_skip[Cout][C1][9]
+inline __global__ void __launch_bounds__(256) wgrad_up2x_join_kernel(const float* __restrict__ d9, const float* __restrict__ dw_skip,
+                                                                  float* __restrict__ dw, int Cout, int C0, int C1) {
+  const int Cin = C0 + C1;
+  const long total = (long)Cout * Cin * 9;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int tap = (int)(e % 9);
+    const long t = e / 9;
+    const int ci = (int)(t % Cin), co = (int)(t / Cin);
+    dw[e] = ci < C0 ? d9[((size_t)co * C0 + ci) * 9 + tap] : dw_skip[((size_t)co * C1 + (ci - C0)) * 9 + tap];
+  }
+}
+
 // dW[co][ci][3][3] = G^T (sum_ks part[ks][.][co][ci]) G.
 // A block folds 16 (co, ci) elements: thread = (element el, xi row q, quarter p of the ks range) sums four xi over its
 // quarter in fp64; the quarters are combined in the fixed order p = 0..3 through LDS (deterministic), then 48 threads

@@ -777,7 +777,27 @@ int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float*
 using WgradA4 = WgradCfg<4, 2, 4, 32, 4>;   // 2x2 tap window: 128 co x 64 ci, 8 waves (4 taps reuse a staged tile less than 9 do,
                                             // so the ci block is doubled to keep the flops per staged byte)
 using WgradB4 = WgradCfg<2, 2, 4, 32, 4>;
-struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; };
+struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; int up_wino_sk; };
+// the upsampled half in the 9-GEMM Winograd form (kernels/wgrad_wino_mfma.h: wgrad_up2x_wino_mfma_kernel)
+inline bool wgrad_up2x_wino_supported(int c0, int cout, int hl, int wl) {
+  return c0 > 0 && c0 % WgradUp2xWinoCfg::CB == 0 && cout > 0 && cout % 64 == 0 && hl > 0 && wl > 0 && wl % 8 == 0 &&
+         (long)64 * 4 * hl * wl * 4 < (1l << 31) && (long)WgradUp2xWinoCfg::CB * hl * wl * 4 < (1l << 31);
+}
+inline int wgrad_up2x_wino_splitk(int n, int c0, int cout, int hl, int wl) {
+  const int nb = (cout / 64) * (c0 / WgradUp2xWinoCfg::CB);
+  const long chunks = (long)n * hl * (wl / 8);
+  const int cus = num_cus();
+  int best_sk = 1;
+  double best = 1e300;
+  const long cap = chunks < 4096 ? chunks : 4096;
+  for (int sk = 1; sk <= cap; ++sk) {
+    const long blocks = (long)nb * sk;
+    if (sk > 1 && blocks > 16l * cus) break;
+    const double cost = (double)((blocks + cus - 1) / cus) * ((double)((chunks + sk - 1) / sk) + 6.0);   // as wgrad_wino_splitk
+    if (cost < best - 1e-9) { best = cost; best_sk = sk; }
+  }
+  return best_sk;
+}
 // the skip half (a plain layer of c1 -> cout channels at full resolution) takes the Winograd-form kernel where that one wins
 inline bool wgrad_up2x_skip_wino(int c1, int cout, int h, int w) { return wgrad_wino_supported(c1, cout, h, w); }   // 64-multiples: Winograd form
 inline size_t align16f(size_t floats) { return (floats + 3) / 4 * 4; }
@@ -791,6 +811,9 @@ inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, 
   l.dwskip = off;  off += align16f((size_t)cout * c1 * 9);
   size_t s_up = (size_t)l.up.splitK * cout * c0 * 4, s_skip = (size_t)l.skip.splitK * cout * c1 * 9;
   if (wgrad_up2x_skip_wino(c1, cout, 2 * hl, 2 * wl)) s_skip = (size_t)wgrad_wino_splitk(n, c1, cout, 2 * hl, 2 * wl) * 16 * cout * c1;
+  l.up_wino_sk = wgrad_up2x_wino_supported(c0, cout, hl, wl) ? wgrad_up2x_wino_splitk(n, c0, cout, hl, wl) : 0;
+  const size_t s_up9 = (size_t)l.up_wino_sk * 9 * cout * c0;
+  if (s_up9 > s_up) s_up = s_up9;
   l.slabs = off;   off += align16f(s_up > s_skip ? s_up : s_skip);
   l.total = off * sizeof(float);
   return l;
@@ -802,7 +825,7 @@ inline size_t wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int hl
 
 template <class Launcher>
 int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, const float* dz, float* dw, void* ws, size_t ws_bytes,
-                            int n, int c0, int c1, int cout, int hl, int wl, int wino_variant = -1) {
+                            int n, int c0, int c1, int cout, int hl, int wl, int wino_variant = -1, int up_variant = -1) {
   if (!x_low || !skip || !dz || !dw || !ws || n <= 0 || c0 <= 0 || c1 <= 0 || cout <= 0 || hl <= 0 || wl <= 0)
     TNV3_FAIL(-1, "conv3x3_wgrad_up2x: bad argument");
   if (wl % 4) TNV3_FAIL(-1, "conv3x3_wgrad_up2x: the low-resolution width must be a multiple of 4");
@@ -815,13 +838,20 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
   const int h = 2 * hl, w = 2 * wl;
   int rc;
   const long s2d_items = (long)n * cout * h * (w / 4);
-  if ((rc = L.launch(space_to_depth2_kernel, grid_for(s2d_items, 256, 32768), 256, dz, zp, (long)n * cout, h, w))) return rc;
+  if (!(up_variant != 0 && l.up_wino_sk > 0))
+    if ((rc = L.launch(space_to_depth2_kernel, grid_for(s2d_items, 256, 32768), 256, dz, zp, (long)n * cout, h, w))) return rc;
   auto reduce = [&](float* out, long nel, int parts) -> int {
     if ((nel & 3) == 0) return L.launch(sum_partials_vec4_kernel, grid_for(nel / 4, 256, 8192), 256, (const float*)slabs, out, nel / 4, parts);
     return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)slabs, out, nel, parts);
   };
+  const bool up9 = up_variant != 0 && l.up_wino_sk > 0;    // upsampled half: 9-GEMM Winograd form (default) or the four 2x2-window launches
+  if (up9) {
+    WgradUp2xWinoArgs ua{x_low, dz, slabs, n, c0, cout, hl, wl, l.up_wino_sk};
+    if ((rc = L.launch(wgrad_up2x_wino_mfma_kernel, (cout / 64) * (c0 / WgradUp2xWinoCfg::CB) * l.up_wino_sk, WgradUp2xWinoCfg::NT, ua))) return rc;
+    if ((rc = L.launch(wgrad_up2x_wino_fold_kernel, grid_for((long)cout * c0, 256, 4096), 256, (const float*)slabs, d4, cout, c0, l.up_wino_sk))) return rc;
+  }
   const size_t img = (size_t)n * cout * hl * wl;
-  for (int im = 0; im < 4; ++im) {                              // parity image (pr, pc) = (im >> 1, im & 1): 2x2 window at (pr, pc)
+  for (int im = 0; !up9 && im < 4; ++im) {                              // parity image (pr, pc) = (im >> 1, im & 1): 2x2 window at (pr, pc)
     WgradArgs a{x_low, (const float*)nullptr, zp + im * img, slabs, n, c0, 0, cout, hl, wl, 0, l.up.splitK, (const float*)ws, im >> 1, im & 1};
     const int grid = l.up.nMB * l.up.nCB * l.up.splitK;
     rc = l.up.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB4>, grid, WgradB4::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA4>, grid, WgradA4::NT, a);
@@ -841,6 +871,7 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
     if (rc) return rc;
     if ((rc = reduce(dwskip, (long)cout * c1 * 9, l.skip.splitK))) return rc;
   }
+  if (up9) return L.launch(wgrad_up2x_join_kernel, grid_for((long)cout * (c0 + c1) * 9, 256, 8192), 256, (const float*)d4, (const float*)dwskip, dw, cout, c0, c1);
   return L.launch(wgrad_up2x_assemble_kernel, grid_for((long)cout * (c0 + c1) * 9, 256, 8192), 256, (const float*)d4, (const float*)dwskip, dw, cout, c0, c1);
 }
 
