@@ -198,10 +198,10 @@ TRAIN_FLOPS_PER_SAMPLE = 678.2e9    # fwd + dgrad + wgrad (no dgrad f
 # form (16/36) in forward and data gradient, and those with >= 64 channels on both sides also in the weight gradient
 # (everything but the first layer).
 #   forward 98.7 (of 227.6), data gradient 96.6 (of 223.0), weight gradient 101.2 (of 227.6)
-# Round 2: the FORWARD and the WEIGHT GRADIENT of the upsampled halves run in a Winograd form that keeps 9 of 16 GEMMs (9/36
-# instead of 4/9 of their 65.2 GFLOP each): forward 86.0, weight gradient 88.5; their data gradient still costs 4/9.
+# Round 2: all three passes of the upsampled halves run in Winograd forms that keep 9 of the 16 GEMMs (9/36 instead of 4/9 of
+# their 65.2 GFLOP each): forward 86.0, data gradient 83.9, weight gradient 88.5.
 TRAIN_FLOPS_EXECUTED_PER_SAMPLE_CLASS_FILTERS = 296.5e9
-TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 296.5e9 - 2 * 65.2e9 * (4 / 9 - 9 / 36)
+TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 296.5e9 - 3 * 65.2e9 * (4 / 9 - 9 / 36)
 
 
 def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False):
@@ -263,8 +263,8 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False):
                      "note": "`achieved` / `frac`: multiply-adds the matrix pipe EXECUTES per second (whole step time, so the HBM-bound "
                              "passes count against it) over the fp32 MFMA peak; `effective_tflops` prices the same time at the "
                              "reference's algorithmic FLOP count (SURVEY 8d: 678.2 GFLOP/sample) -- the upsampled channels of the "
-                             "three decoder-entry layers run at the low resolution in all three passes (9/36 of those MACs in forward and weight "
-                             "gradient, 4/9 in the data gradient), the plain "
+                             "three decoder-entry layers run at the low resolution in all three passes, in Winograd forms that keep 9 of the 16 "
+                             "GEMMs (9/36 of those MACs), the plain "
                              "layers in fused Winograd F(2x2,3x3) form (16/36) in forward, data gradient and, from 64 channels, "
                              "weight gradient"},
         "dp_overlap": overlap, "final_loss": round(float(loss.item()), 6)}

@@ -155,6 +155,16 @@ size_t tnv3_dgrad_up2x_packed_floats(int c0, int cout);
 int tnv3_pack_dgrad_up2x_weights(const float* w, float* g, int cout, int cin, int c0, tnv3_stream_t stream);
 int tnv3_dgrad_up2x(const float* dz, const float* g, float* dx_low, int n, int c0, int cout, int h_low, int w_low, tnv3_stream_t stream);
 
+/* The same gradient as ONE GEMM with K = 9 * cout: in Winograd F(2x2, 3x3) form the 2x2 block sum of nn.Upsample's backward is
+ * c^T M c with c = A 1 = (1, 2, 0, -1), so transform row / column 2 drops out and the nine remaining products share one accumulator:
+ * dx_low[ci][p] = sum_{co, xi} U''_xi[co][ci] * (B^T d B)_xi[co][p] -- 9 instead of 16 multiply-adds per (ci, co, low-res pixel).
+ *   supported: c0 % 128 == 0, cout > 8, h_low % 2 == 0, w_low % 32 == 0;  u from tnv3_dgrad_up2x_wino_pack (the layer's nn.Conv2d
+ *   weight, its first c0 input channels), 16-byte aligned.  Same gradient up to fp32 rounding. */
+int tnv3_dgrad_up2x_wino_supported(int c0, int cout, int h_low, int w_low);
+size_t tnv3_dgrad_up2x_wino_packed_floats(int c0, int cout);
+int tnv3_dgrad_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, tnv3_stream_t stream);
+int tnv3_dgrad_up2x_wino(const float* dz, const float* u, float* dx_low, int n, int c0, int cout, int h_low, int w_low, tnv3_stream_t stream);
+
 /* Weight gradient of a plain layer (single source, no upsampling) in Winograd F(2x2, 3x3) form: dw[cout][cin][3][3] =
  * G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- 16 instead of 36 multiply-adds per (co, ci, 2x2 tile); same gradient as
  * tnv3_conv3x3_wgrad up to fp32 rounding; deterministic (fixed-order split-K sum).

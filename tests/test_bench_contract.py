@@ -33,10 +33,10 @@ def test_training_flop_constants():
     up = 3 * 21.743                                               # upsampled halves, each pass
     plain = 9 * 10.872 + 4 * 5.436                                # the 13 plain layers with >= 64 channels
     fwd = 4.586 * 16 / 36 + plain * 16 / 36 + up * 9 / 36 + 3 * 10.872 * 16 / 36   # upsampled halves: 9 of the 16 Winograd GEMMs
-    dgrad = plain * 16 / 36 + up * 4 / 9 + 3 * 10.872 * 16 / 36
+    dgrad = plain * 16 / 36 + up * 9 / 36 + 3 * 10.872 * 16 / 36
     wgrad = 4.586 + plain * 16 / 36 + up * 9 / 36 + 3 * 10.872 * 16 / 36     # only the first layer keeps the direct kernel
     assert abs((fwd + dgrad + wgrad) - b.TRAIN_FLOPS_EXECUTED_PER_SAMPLE / 1e9) < 1.5
-    assert abs((fwd + dgrad + wgrad) + 2 * up * (4 / 9 - 9 / 36) - b.TRAIN_FLOPS_EXECUTED_PER_SAMPLE_CLASS_FILTERS / 1e9) < 1.5
+    assert abs((fwd + dgrad + wgrad) + 3 * up * (4 / 9 - 9 / 36) - b.TRAIN_FLOPS_EXECUTED_PER_SAMPLE_CLASS_FILTERS / 1e9) < 1.5
 
 
 def test_cli_contract_flags():

@@ -178,6 +178,34 @@ def test_conv_up2x_wino_unsupported_shapes_are_refused(emu):
         ops.conv_up2x_wino(T((1, 16, 4, 32), 1), ops.pack_up2x_wino_weights(w, 16), 64)
 
 
+# (n, c0, cout, h_low, w_low): two / three / nine chunks of output channels, one / two ci blocks, borders on all sides
+DGRAD_UP2X_WINO_CASES = [(1, 128, 16, 2, 32), (2, 128, 24, 4, 32), (1, 256, 70, 2, 64), (3, 128, 16, 6, 32)]
+
+
+def _dgrad_up2x_wino_case(n, c0, cout, hl, wl, device):
+    """The one-GEMM data gradient (K = 9 * Cout) against fp64 autograd of conv2d(upsample2x(x_low), W[:, :c0]) and against the
+    4x4 stride-2 kernel (dgrad_up2x)."""
+    from tracknetv3_amd import ops
+    assert ops.dgrad_up2x_wino_supported(c0, cout, hl, wl)
+    xl = T((n, c0, hl, wl), 81).double().requires_grad_(True)
+    w = T((cout, c0 + 8, 3, 3), 82, -0.3, 0.3)
+    dz = T((n, cout, 2 * hl, 2 * wl), 83)
+    up = xl.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    F.conv2d(up, w[:, :c0].double(), padding=1).backward(dz.double())
+    got = ops.dgrad_up2x_wino(dz.to(device), ops.pack_dgrad_up2x_wino_weights(w.to(device), c0), c0)
+    old = ops.dgrad_up2x(dz.to(device), ops.pack_dgrad_up2x_weights(w.to(device), c0), c0)
+    s = xl.grad.abs().max()
+    return ((got.cpu().double() - xl.grad).abs().max() / s).item(), ((got - old).abs().max().cpu().double() / s).item()
+
+
+@pytest.mark.parametrize("cus", [256, 8])
+@pytest.mark.parametrize("case", DGRAD_UP2X_WINO_CASES)
+def test_dgrad_up2x_wino_emulated_vs_autograd(emu, monkeypatch, case, cus):
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))        # 8 CUs: the persistent workgroups walk several tiles each
+    e_ref, e_old = _dgrad_up2x_wino_case(*case, "cpu")
+    assert e_ref <= 3e-6 and e_old <= 4e-6, (e_ref, e_old)
+
+
 @pytest.mark.parametrize("cfg", [2, 3])
 def test_conv_up2x_big_tile_configs_emulated(emu, cfg):
     e_up, e_full = _up2x_case(1, 8, 128, 5, 36, "cpu", cfg=cfg)       # 8-row tiles: ragged in both directions

@@ -213,3 +213,11 @@ def test_tracknet_batch_split_over_two_streams_is_bit_identical(gpu_device):
     calls.clear()
     m(x[:2].contiguous())                                          # below the minimum batch: one stream
     assert calls == [2]
+
+
+@pytest.mark.parametrize("case", [(1, 128, 16, 2, 32), (2, 512, 256, 36, 64), (1, 128, 64, 144, 256), (3, 256, 128, 72, 128)])
+def test_dgrad_up2x_wino_vs_autograd(gpu_device, case):
+    """The one-GEMM low-resolution data gradient (K = 9 * Cout) against fp64 autograd and the 4x4 stride-2 kernel."""
+    from test_emu_kernels import _dgrad_up2x_wino_case
+    e_ref, e_old = _dgrad_up2x_wino_case(*case, gpu_device)
+    assert e_ref <= 3e-6 and e_old <= 4e-6, (e_ref, e_old)

@@ -46,6 +46,10 @@ def _declare(lib):
     sig("tnv3_conv_up2x_wino_packed_floats", sz, i, i)
     sig("tnv3_conv_up2x_wino_pack", i, p, p, i, i, i, p)
     sig("tnv3_conv_up2x_wino_forward", i, p, p, p, i, i, i, i, i, p)
+    sig("tnv3_dgrad_up2x_wino_supported", i, i, i, i, i)
+    sig("tnv3_dgrad_up2x_wino_packed_floats", sz, i, i)
+    sig("tnv3_dgrad_up2x_wino_pack", i, p, p, i, i, i, p)
+    sig("tnv3_dgrad_up2x_wino", i, p, p, p, i, i, i, i, i, p)
     sig("tnv3_dgrad_up2x_packed_floats", sz, i, i)
     sig("tnv3_pack_dgrad_up2x_weights", i, p, p, i, i, i, p)
     sig("tnv3_dgrad_up2x", i, p, p, p, i, i, i, i, i, p)
@@ -118,7 +122,8 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_absdiff_sum_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad",
            "tnv3_heatmap_box_max", "tnv3_conv3x3_forward_add", "tnv3_conv_up2x_packed_floats",
            "tnv3_pack_up2x_weights", "tnv3_conv_up2x_forward", "tnv3_conv_up2x_wino_supported", "tnv3_conv_up2x_wino_packed_floats",
-           "tnv3_conv_up2x_wino_pack", "tnv3_conv_up2x_wino_forward", "tnv3_dgrad_up2x_packed_floats", "tnv3_pack_dgrad_up2x_weights",
+           "tnv3_conv_up2x_wino_pack", "tnv3_conv_up2x_wino_forward", "tnv3_dgrad_up2x_wino_supported", "tnv3_dgrad_up2x_wino_packed_floats",
+           "tnv3_dgrad_up2x_wino_pack", "tnv3_dgrad_up2x_wino", "tnv3_dgrad_up2x_packed_floats", "tnv3_pack_dgrad_up2x_weights",
            "tnv3_dgrad_up2x", "tnv3_conv3x3_wgrad_up2x_workspace_bytes", "tnv3_conv3x3_wgrad_up2x",
            "tnv3_conv3x3_wgrad_wino_supported", "tnv3_conv3x3_wgrad_wino_workspace_bytes", "tnv3_conv3x3_wgrad_wino",
            "tnv3_conv3x3_wino_stats_tiles", "tnv3_conv3x3_wino_forward_stats", "tnv3_bn_train_forward_tiles",

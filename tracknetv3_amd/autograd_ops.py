@@ -185,9 +185,16 @@ def _train_backward_body(ctx, dev, head_backward):
         if rec["up"] and c1:
             # decoder entry: the gradient of the upsampled operand straight at the low resolution (4x4 stride-2
             # correlation of dZ, 4/9 of the MACs, no full-resolution intermediate), the skip half as a plain 3x3 dgrad
-            g_low, w_skip_t = blk.packed_dgrad_up2x(c0)
-            d_low = ops.dgrad_up2x(dz, g_low, c0)
-            if tuning.use_winograd(blk.conv.out_dim, c1, int(h), int(w)):
+            skip_wino = tuning.use_winograd(blk.conv.out_dim, c1, int(h), int(w))
+            w_skip_t = None
+            if tuning.UP2X_WINO and ops.dgrad_up2x_wino_supported(c0, blk.conv.out_dim, int(h) // 2, int(w) // 2):
+                d_low = ops.dgrad_up2x_wino(dz, blk.packed_dgrad_up2x_wino(c0), c0)      # one GEMM with K = 9 * Cout
+                if not skip_wino:
+                    w_skip_t = blk.packed_dgrad_up2x(c0)[1]
+            else:
+                g_low, w_skip_t = blk.packed_dgrad_up2x(c0)
+                d_low = ops.dgrad_up2x(dz, g_low, c0)
+            if skip_wino:
                 d_skip = ops.conv3x3_wino(dz, blk.packed_wino_t(c0), c1)
             else:
                 cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))

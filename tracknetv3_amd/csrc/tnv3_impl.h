@@ -8,6 +8,7 @@
 #include "kernels/conv3x3_mfma.h"
 #include "kernels/conv_up2x_mfma.h"
 #include "kernels/conv_up2x_wino_mfma.h"
+#include "kernels/dgrad_up2x_wino_mfma.h"
 #include "kernels/conv3x3_wino_mfma.h"
 #include "kernels/conv3x3_wino3_mfma.h"
 #include "kernels/conv1d_k3.h"
@@ -717,6 +718,36 @@ int conv_up2x_wino_forward_impl(Launcher& L, const float* src, const float* u, f
   const long npt = (long)n * (hl / 2) * (wl / ConvUp2xWinoCfg::TW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv_up2x_wino: too many tiles");
   return L.launch(conv_up2x_wino_stream_kernel, wino_persistent_grid(conv_grid_blocks(cout / ConvUp2xWinoCfg::MB, (int)npt)), ConvUp2xWinoCfg::NT, a);
+}
+
+// ---- data gradient of the upsampled half at the low resolution as one GEMM with K = 9 * Cout (kernels/dgrad_up2x_wino_mfma.h)
+inline bool dgrad_up2x_wino_supported(int c0, int cout, int hl, int wl) {
+  return c0 > 0 && c0 % DgradUp2xWinoCfg::MB == 0 && cout > DgradUp2xWinoCfg::CC && hl > 0 && wl > 0 && hl % 2 == 0 && wl % DgradUp2xWinoCfg::TWL == 0 &&
+         (long)DgradUp2xWinoCfg::CC * 4 * hl * wl * 4 < (1l << 31) && (long)72 * c0 * 4 < (1l << 31);
+}
+inline size_t dgrad_up2x_wino_packed_floats(int c0, int cout) {
+  if (c0 <= 0 || cout <= 0) return 0;
+  return (size_t)round_up(cout, DgradUp2xWinoCfg::CC) * 9 * c0 + kPackZeroTail;
+}
+template <class Launcher>
+int dgrad_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin, int c0) {
+  if (!w || !u || cout <= 0 || cin <= 0 || c0 <= 0 || c0 > cin) TNV3_FAIL(-1, "dgrad_up2x_wino_pack: bad argument");
+  const int copad = round_up(cout, DgradUp2xWinoCfg::CC);
+  const long total = (long)copad * c0;
+  int rc;
+  if ((rc = L.launch(fill_zero_kernel, 1, 256, u + (size_t)copad * 9 * c0, kPackZeroTail))) return rc;
+  return L.launch(dgrad_up2x_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, c0, copad);
+}
+template <class Launcher>
+int dgrad_up2x_wino_impl(Launcher& L, const float* dz, const float* u, float* dst, int n, int c0, int cout, int hl, int wl) {
+  if (!dz || !u || !dst || n <= 0) TNV3_FAIL(-1, "dgrad_up2x_wino: bad argument");
+  if (!dgrad_up2x_wino_supported(c0, cout, hl, wl))
+    TNV3_FAIL(-1, "dgrad_up2x_wino: needs C0 %% 128 == 0, Cout > 8, H_low %% 2 == 0, W_low %% 32 == 0 (got %d <- %d, %dx%d)", c0, cout, hl, wl);
+  if ((((uintptr_t)u | (uintptr_t)dz) & 15) || (((uintptr_t)dst) & 3)) TNV3_FAIL(-1, "dgrad_up2x_wino: misaligned pointer");
+  DgradUp2xWinoArgs a{dz, u, dst, n, c0, cout, hl, wl};
+  const long npt = (long)n * (hl / 2) * (wl / DgradUp2xWinoCfg::TWL);
+  if (npt > (1l << 28)) TNV3_FAIL(-1, "dgrad_up2x_wino: too many tiles");
+  return L.launch(dgrad_up2x_wino_stream_kernel, wino_persistent_grid(conv_grid_blocks(c0 / DgradUp2xWinoCfg::MB, (int)npt)), DgradUp2xWinoCfg::NT, a);
 }
 
 // ---- weight gradient of a plain layer in Winograd F(2x2, 3x3) form (kernels/wgrad_wino_mfma.h)

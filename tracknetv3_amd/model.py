@@ -113,6 +113,16 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
+    def packed_dgrad_up2x_wino(self, c0):
+        """U'' of the first c0 (upsampled) input channels for the one-GEMM low-resolution data gradient (ops.dgrad_up2x_wino)."""
+        key = ("dup2xw", int(c0))
+        ver = self._versions(["conv"])
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_dgrad_up2x_wino_weights(self.conv.weight.detach(), c0))
+            self._cache[key] = hit
+        return hit[1]
+
     def packed_dgrad_up2x(self, c0):
         """(4x4 stride-2 filters of the low-resolution data gradient w.r.t. the first c0 inputs, transposed / flipped 3x3
         filter of the remaining skip channels): the backward twins of packed_up2x."""

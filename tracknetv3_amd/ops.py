@@ -184,6 +184,35 @@ def conv_up2x_wino(src_low, u, cout):
     return out
 
 
+def dgrad_up2x_wino_supported(c0, cout, hl, wl):
+    return bool(_lib.load().tnv3_dgrad_up2x_wino_supported(int(c0), int(cout), int(hl), int(wl)))
+
+
+def pack_dgrad_up2x_wino_weights(weight, c0):
+    """U'' of the first c0 (upsampled) input channels for the one-GEMM data gradient (tnv3_dgrad_up2x_wino_pack)."""
+    lib = _lib.load()
+    _f32(weight)
+    _lib.dev_check(weight)
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    u = torch.empty(lib.tnv3_dgrad_up2x_wino_packed_floats(int(c0), cout), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.tnv3_dgrad_up2x_wino_pack(_lib.ptr(weight), _lib.ptr(u), cout, cin, int(c0), _lib.stream_ptr(weight)))
+    return u
+
+
+def dgrad_up2x_wino(dz, u, c0):
+    """Gradient w.r.t. the low-res operand of nn.Upsample(2) -> conv3x3 as one GEMM with K = 9 * Cout (tnv3_dgrad_up2x_wino)."""
+    lib = _lib.load()
+    _f32(dz, u)
+    _lib.dev_check(dz, u)
+    n, cout, h, w = (int(v) for v in dz.shape)
+    if (h | w) & 1 or u.numel() != lib.tnv3_dgrad_up2x_wino_packed_floats(int(c0), cout):
+        raise _lib.Tnv3Error("dgrad_up2x_wino: odd output size or filter buffer / channel mismatch")
+    out = torch.empty((n, int(c0), h // 2, w // 2), dtype=torch.float32, device=dz.device)
+    if n:
+        _lib.check(lib.tnv3_dgrad_up2x_wino(_lib.ptr(dz), _lib.ptr(u), _lib.ptr(out), n, int(c0), cout, h // 2, w // 2, _lib.stream_ptr(dz)))
+    return out
+
+
 def pack_dgrad_up2x_weights(weight, c0):
     """nn.Conv2d weight (Cout, Cin, 3, 3) -> the 4x4 stride-2 filters of the low-resolution data gradient (first c0 inputs)."""
     lib = _lib.load()
@@ -760,7 +789,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # The C ABI runs a call on its stream's device, but a tensor's *default* stream is the NULL stream (= "the calling thread's
 # current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
-_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino",
+_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
