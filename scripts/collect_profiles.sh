@@ -16,6 +16,7 @@ cp $O/pmc_fetch_pmc.csv $P/${R}_infer_pmc_fetch_size.csv
 cp $O/pmc_write_pmc.csv $P/${R}_infer_pmc_write_size.csv
 for f in sq1 sq2 sq3 tcc; do cp $O/pmc_$f.csv $P/${R}_infer_pmc_$f.csv; done
 for f in r02_wino_variants_ab2.json r02_wino_stream_twins.json r02_wino_fixed_cost.json; do [ -f $O/$f ] && cp $O/$f $P/$f; done
+for f in up2x_wino_ab dgrad_up2x_ab wgrad_up_sweep wgrad_wino_ab; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
 [ -f $O/fullsize_train_parity.json ] && cp $O/fullsize_train_parity.json $P/${R}_fullsize_train_parity.json
 [ -f $O/e2e_real_network_report.json ] && cp $O/e2e_real_network_report.json $P/${R}_e2e_real_network_report.json
 python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json ${COMMIT:-$(git rev-parse --short HEAD)}

@@ -21,6 +21,11 @@ echo "== winograd A/B, fixed cost, twins" | tee -a $LOG
 timeout 300 python scripts/wino_ab.py 2 3 56 5 > $OUT/ab1.log 2>&1; cp $OUT/wino_ab.json $OUT/r02_wino_variants_ab2.json; python scripts/ab_fmt.py < $OUT/ab1.log | tee -a $LOG
 timeout 300 python scripts/wino_ab.py 5 95 96 97 98 99 > $OUT/ab2.log 2>&1; cp $OUT/wino_ab.json $OUT/r02_wino_stream_twins.json; python scripts/ab_fmt.py < $OUT/ab2.log | tee -a $LOG
 timeout 300 python scripts/wino_fixed_cost.py 83 86 85 > $OUT/wino_fixed_cost.log 2>&1; cp $OUT/wino_fixed_cost.json $OUT/r02_wino_fixed_cost.json; echo "fixed rc=$?" | tee -a $LOG
+echo "== decoder-entry kernels: forward / data gradient / weight gradient A/Bs" | tee -a $LOG
+timeout 200 python scripts/up2x_wino_ab.py > $OUT/up2x_wino_ab.log 2>&1; grep -v amdgpu $OUT/up2x_wino_ab.log | cut -c1-260 | tee -a $LOG
+timeout 200 python scripts/dgrad_up2x_ab.py > $OUT/dgrad_up2x_ab.log 2>&1; grep -v amdgpu $OUT/dgrad_up2x_ab.log | cut -c1-260 | tee -a $LOG
+timeout 200 python scripts/wgrad_up_sweep.py > $OUT/wgrad_up_sweep.log 2>&1; echo "wgrad up sweep rc=$?" | tee -a $LOG
+timeout 200 python scripts/wgrad_wino_ab.py 0 1 > $OUT/wgrad_wino_ab.log 2>&1; echo "wgrad wino ab rc=$?" | tee -a $LOG
 cd /tmp
 echo "== rocprofv3 kernel traces" | tee -a $LOG
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_infer -o trace -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --overlap-streams 0 --infer-split 0 --train-steps 0 --layers-out $OUT/prof_infer_layers.json > $OUT/prof_infer.json 2> $OUT/prof_infer.err; echo "rocprof infer rc=$?" | tee -a $LOG

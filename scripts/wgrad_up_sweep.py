@@ -42,6 +42,7 @@ def main():
         out[f"{c0}+{c1}->{cout}@{2*hl}x{2*wl}"] = {"up2x_ms": round(t_a, 4), "up2x_2x2_windows_ms": round(t_old, 4), "wino_on_upsampled_ms": round(t_b, 4), "upsample_ms": round(t_up, 4),
                                                   "rel_diff": float(f"{err:.2e}")}
     print(json.dumps(out, indent=1))
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "wgrad_up_sweep.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
