@@ -677,32 +677,37 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const
   const int t_src = pc * RAWP + (2 * ptr_ + grp) * RW + 4 * pj;
   const int t_dst = (pc * 16 + grp * 8) * TB + ptr_ * (TB / 2) + 2 * pj;
   typedef float wf2 __attribute__((ext_vector_type(2)));
-  auto transform = [&](int stage) {                     // raw stage -> V stage of the same parity
+  // The transform in two parts, so that the LDS-DMA issue of the chunk can sit between the patch reads and their first use
+  // (the reads' latency then hides behind the DMA instructions instead of stalling the wave right after them).
+  float tx[3][6];
+  auto transform_read = [&](int stage) {                // patch columns 4pj+3 .. 4pj+8 of the three raw rows this group needs
     if constexpr (Cfg::DIAG == 10 || Cfg::DIAG == 13) return;       // timing experiments (wrong results): no patch transform at all
     const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src;
-    float x[3][6];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const f32x4 q0 = *reinterpret_cast<const f32x4*>(d + r * RW);
       const f32x4 q1 = *reinterpret_cast<const f32x4*>(d + r * RW + 4);
       const float q2 = d[r * RW + 8];
-      x[r][0] = q0[3]; x[r][1] = q1[0]; x[r][2] = q1[1]; x[r][3] = q1[2]; x[r][4] = q1[3]; x[r][5] = q2;
+      tx[r][0] = q0[3]; tx[r][1] = q1[0]; tx[r][2] = q1[1]; tx[r][3] = q1[2]; tx[r][4] = q1[3]; tx[r][5] = q2;
     }
+  };
+  auto transform_finish = [&](int stage) {              // raw stage -> V stage of the same parity
+    if constexpr (Cfg::DIAG == 10 || Cfg::DIAG == 13) return;
     float e[2][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      e[0][j] = grp ? x[1][j] - x[0][j] : x[0][j] - x[2][j];
-      e[1][j] = grp ? x[0][j] - x[2][j] : x[1][j] + x[2][j];
+      e[0][j] = grp ? tx[1][j] - tx[0][j] : tx[0][j] - tx[2][j];
+      e[1][j] = grp ? tx[0][j] - tx[2][j] : tx[1][j] + tx[2][j];
     }
     float* v = v_s + stage * Cfg::V_FLOATS + t_dst;
     if constexpr (Cfg::DIAG == 9) {                       // timing experiment (wrong results): the same loads and stores, no arithmetic
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         wf2 o;
-        o[0] = x[r][0]; o[1] = x[r][1]; *reinterpret_cast<wf2*>(v + (r * 4 + 0) * TB) = o;
-        o[0] = x[r][2]; o[1] = x[r][3]; *reinterpret_cast<wf2*>(v + (r * 4 + 1) * TB) = o;
-        o[0] = x[r][4]; o[1] = x[r][5]; *reinterpret_cast<wf2*>(v + (r * 4 + 2) * TB) = o;
-        o[0] = x[2][r]; o[1] = x[2][r + 2]; *reinterpret_cast<wf2*>(v + (r * 4 + 3) * TB) = o;
+        o[0] = tx[r][0]; o[1] = tx[r][1]; *reinterpret_cast<wf2*>(v + (r * 4 + 0) * TB) = o;
+        o[0] = tx[r][2]; o[1] = tx[r][3]; *reinterpret_cast<wf2*>(v + (r * 4 + 1) * TB) = o;
+        o[0] = tx[r][4]; o[1] = tx[r][5]; *reinterpret_cast<wf2*>(v + (r * 4 + 2) * TB) = o;
+        o[0] = tx[2][r]; o[1] = tx[2][r + 2]; *reinterpret_cast<wf2*>(v + (r * 4 + 3) * TB) = o;
       }
       return;
     }
@@ -715,6 +720,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const
       o[0] = e[r][1] - e[r][3]; o[1] = e[r][3] - e[r][5]; *reinterpret_cast<wf2*>(v + (r * 4 + 3) * TB) = o;
     }
   };
+  auto transform = [&](int stage) { transform_read(stage); transform_finish(stage); };
 
   f32x16 acc[8];
   f32x16 zero16;
@@ -792,16 +798,22 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const
         dma_r(n_x + x_step, Cin - CC, vo_rn, sc);
       }
     };
-    if (grp == 0) {                                     // group 0: DMAs, transform, MFMAs;  group 1: MFMAs, DMAs, transform
+    if (grp == 0) {                                     // group 0: patch reads, DMAs, transform, MFMAs;  group 1: MFMAs, then the same
+      if (ahead) transform_read(sn);
+      __builtin_amdgcn_sched_barrier(0);
       dmas();
-      if (ahead) transform(sn);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ahead) transform_finish(sn);
       __builtin_amdgcn_sched_barrier(0);
       mfma_chunk(sc, first_c);
     } else {
       mfma_chunk(sc, first_c);
       __builtin_amdgcn_sched_barrier(0);
+      if (ahead) transform_read(sn);
+      __builtin_amdgcn_sched_barrier(0);
       dmas();
-      if (ahead) transform(sn);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ahead) transform_finish(sn);
       __builtin_amdgcn_sched_barrier(0);
     }
     pu += u_step; px += x_step; px_left -= CC;
