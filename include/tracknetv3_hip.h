@@ -32,8 +32,9 @@ extern "C" {
 #define TNV3_OK 0
 #define TNV3_E_INVALID (-1)   /* bad argument / unsupported shape */
 #define TNV3_E_LAUNCH (-2)    /* HIP launch error */
-#define TNV3_ABI_VERSION 3   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
-                                 3: `variant` argument on the Winograd-form weight gradients */
+#define TNV3_ABI_VERSION 4   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
+                                 3: `variant` argument on the Winograd-form weight gradients;
+                                 4: `sum_order` on tnv3_ensemble_frames (the reference's summation order, bit-exact) */
 
 typedef void* tnv3_stream_t;
 
@@ -227,9 +228,12 @@ int tnv3_inpaintnet_fused_forward(const float* x, const float* m, const float* p
  *   weight : [L] from get_ensemble_weight (test.py:25-50)
  *   out    : [n_frames][E] ensembled predictions of global frames t0 .. t0+n_frames-1
  *   num_sample = total number of windows of the video (frames - L + 1).  Every window a requested frame needs
- *   (s in [max(0,t-L+1), min(t,num_sample-1)]) must be resident in `win`. */
+ *   (s in [max(0,t-L+1), min(t,num_sample-1)]) must be resident in `win`.
+ *   sum_order : the order in which the reference's `.sum(0)` (torch CPU) adds the L rows, so that results are bit-identical
+ *   to predict.py's loops: 0 = sequential (heat maps: torch's vectorised outer sum), 1 = four interleaved partial sums
+ *   (coordinates, E = 2: torch's scalar row_sum).  Products are rounded to fp32 before they are added (no FMA), as there. */
 int tnv3_ensemble_frames(const float* win, int n_local, long s_base, int l, int e, const float* weight, long t0,
-                         int n_frames, long num_sample, float* out, tnv3_stream_t stream);
+                         int n_frames, long num_sample, int sum_order, float* out, tnv3_stream_t stream);
 
 /* Bytes of scratch tnv3_heatmap_peakfind needs for `frames` maps of h x w. */
 size_t tnv3_peakfind_workspace_bytes(int frames, int h, int w);

@@ -22,7 +22,13 @@ boundingRect = (min_x, min_y, max_x-min_x+1, max_y-min_y+1)); contour order is
 test.py:74 means: among equal-area boxes the component whose first raster
 pixel comes LAST wins.  That tie rule is a single switch (``TIE_LAST_WINS``).
 ``scipy.ndimage.label`` is used as an independent cross-check of the
-component / bounding-box part in tests/.
+component / bounding-box part in tests/, and ``suzuki_abe_external`` below restates
+the PUBLISHED algorithm behind findContours (Suzuki & Abe 1985, Algorithm 2: outermost
+borders by border following) as an independent derivation of which contours exist, in
+which order they are discovered and what their boxes are; tests assert that it selects
+the same box as the flood-fill restatement on tie maps, nested blobs and random maps.
+Only "OpenCV returns the list newest-first" remains an implementation fact that needs
+OpenCV itself (tests/test_cv2_pin.py).
 """
 import math
 
@@ -95,6 +101,97 @@ def connected_boxes(binary):
     return boxes
 
 
+# ---- an INDEPENDENT derivation of what cv2.findContours(RETR_EXTERNAL) returns: Suzuki & Abe's border following ------------
+# S. Suzuki, K. Abe, "Topological structural analysis of digitized binary images by border following", CVGIP 30 (1985),
+# the algorithm OpenCV's findContours implements (its documentation cites it as [Suzuki85]).  Algorithm 2 of the paper follows
+# only the OUTERMOST borders -- RETR_EXTERNAL -- and is restated here step by step with the paper's step numbers, for
+# 8-connected 1-pixels (4-connected 0-pixels), on a frame padded with one ring of zeros (OpenCV >= 3.2 pads the same way).
+# It shares no code and no idea with `connected_boxes` (flood fill): borders are traced pixel by pixel, components nested
+# in another component's hole are really absent, and boxes come from the traced points.  What the PAPER fixes is the
+# discovery order (raster order of each outer border's starting point); that OpenCV hands the list back newest-first is a
+# property of its legacy contour tree (every new contour is linked in FRONT of its siblings) which a paper cannot supply --
+# tests/test_cv2_pin.py pins that last step wherever OpenCV is installed.
+_SA_CW = ((0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1))      # clockwise on the screen (rows grow downwards)
+
+
+def suzuki_abe_external(binary):
+    """Outermost borders of the non-zero pixels in discovery order: [(start_y, start_x, [(y, x), ...])] (unpadded coordinates)."""
+    h, w = binary.shape
+    f = np.zeros((h + 2, w + 2), dtype=np.int32)
+    f[1:-1, 1:-1] = (np.asarray(binary) != 0)
+    contours = []
+    for i in range(1, h + 1):
+        lnbd = 0                                                  # Algorithm 2: LNBD is reset at the start of every row
+        for j in np.nonzero(f[i])[0].tolist():                    # marks stay non-zero, so the set of visited columns is fixed
+            if f[i, j] == 1 and f[i, j - 1] == 0 and lnbd <= 0:   # (1a) outer-border start, followed only when LNBD <= 0
+                pts = _sa_follow(f, i, j, i, j - 1)
+                contours.append((i - 1, j - 1, [(y - 1, x - 1) for y, x in pts]))
+            if f[i, j] != 1:                                      # (4) LNBD <- f_ij (signed: +2 entering, -2 leaving a component)
+                lnbd = int(f[i, j])
+    return contours
+
+
+def _sa_follow(f, i, j, i2, j2):
+    """Step (3) of the paper with the marks +2 / -2 of Algorithm 2; returns the border's pixels in tracing order."""
+    # (3.1) clockwise from (i2, j2) around (i, j): the first non-zero pixel (i1, j1)
+    d0 = _SA_CW.index((i2 - i, j2 - j))
+    first = None
+    for k in range(8):
+        dy, dx = _SA_CW[(d0 + k) % 8]
+        if f[i + dy, j + dx] != 0:
+            first = (i + dy, j + dx)
+            break
+    if first is None:
+        f[i, j] = -2                                              # an isolated pixel
+        return [(i, j)]
+    i1, j1 = first
+    i2, j2 = i1, j1                                               # (3.2)
+    i3, j3 = i, j
+    pts = []
+    while True:
+        # (3.3) counter-clockwise around (i3, j3), starting from the element after (i2, j2): the first non-zero pixel (i4, j4)
+        d = _SA_CW.index((i2 - i3, j2 - j3))
+        east_zero_examined = False
+        for k in range(1, 9):
+            dy, dx = _SA_CW[(d - k) % 8]
+            if f[i3 + dy, j3 + dx] != 0:
+                i4, j4 = i3 + dy, j3 + dx
+                break
+            if (dy, dx) == (0, 1):
+                east_zero_examined = True
+        # (3.4)
+        if east_zero_examined:
+            f[i3, j3] = -2
+        elif f[i3, j3] == 1:
+            f[i3, j3] = 2
+        pts.append((i3, j3))
+        # (3.5)
+        if (i4, j4) == (i, j) and (i3, j3) == (i1, j1):
+            return pts
+        i2, j2 = i3, j3
+        i3, j3 = i4, j4
+
+
+def predict_location_suzuki(heatmap, newest_first=True):
+    """test.py:52-79 with the contour list derived by border following: boxes from the traced points (cv2.boundingRect of a
+    point set = (min x, min y, max x - min x + 1, max y - min y + 1)), list order = discovery order reversed when
+    `newest_first` (OpenCV's legacy contour tree), then the reference's strict-`>` scan."""
+    if np.amax(heatmap) == 0:
+        return 0, 0, 0, 0
+    rects = []
+    for _, _, pts in suzuki_abe_external(heatmap):
+        ys, xs = [p[0] for p in pts], [p[1] for p in pts]
+        rects.append((min(xs), min(ys), max(xs) - min(xs) + 1, max(ys) - min(ys) + 1))
+    if newest_first:
+        rects = rects[::-1]
+    max_area_idx, max_area = 0, rects[0][2] * rects[0][3]
+    for k in range(1, len(rects)):
+        area = rects[k][2] * rects[k][3]
+        if area > max_area:
+            max_area_idx, max_area = k, area
+    return rects[max_area_idx]
+
+
 def predict_location(heatmap):
     """test.py:52-79 on a uint8 (H, W) map -> (x, y, w, h) of the max-area bounding box."""
     if np.amax(heatmap) == 0:
@@ -129,8 +226,10 @@ def predict(indices, y_pred=None, c_pred=None, img_scaler=(1, 1)):
             if f_i != prev_f_i:
                 if c_pred is not None:
                     c_p = c_pred[n][f]
-                    cx_pred = int(c_p[0] * WIDTH * img_scaler[0])
-                    cy_pred = int(c_p[1] * HEIGHT * img_scaler[1])
+                    # float64 products: under the reference's pinned numpy 1.22.4 an np.float32 scalar times a Python
+                    # scalar promotes to float64 (numpy >= 2 would keep float32 and truncate differently)
+                    cx_pred = int(float(c_p[0]) * WIDTH * img_scaler[0])
+                    cy_pred = int(float(c_p[1]) * HEIGHT * img_scaler[1])
                 elif y_pred is not None:
                     bbox = predict_location(to_img(y_pred[n][f]))
                     cx_pred, cy_pred = int(bbox[0] + bbox[2] / 2), int(bbox[1] + bbox[3] / 2)
@@ -261,12 +360,41 @@ def generate_inpaint_mask(pred_dict, th_h=30):
     return inpaint_mask.tolist()
 
 
+def torch_cpu_sum0(rows):
+    """`rows.sum(0)` of a contiguous fp32 (L, *tail) array exactly as torch's CPU sum kernel (aten SumKernel.cpp, unchanged
+    between the reference's torch 1.10 and 2.10) adds the L rows -- the temporal ensembles of predict.py:183-186 / 268-271:
+      * four or more elements per row (the heat maps; strictly: the columns its vectorised outer sum covers): rows are added
+        sequentially, r = (((x0 + x1) + x2) + ...);
+      * fewer than four (the (L, 2) coordinates: its scalar `row_sum`, ilp_factor 4): four interleaved partial sums
+        p_j = x_j + x_{4+j} + ..., the L % 4 leftover rows into p_0, then r = ((p0 + p1) + p2) + p3.
+    Identified against the goldens produced by the reference's own loops (tests/golden/ensemble.npz: all 27 cases bit-equal)."""
+    rows = np.asarray(rows, dtype=np.float32)
+    n = rows.shape[0]
+    tail_elems = int(np.prod(rows.shape[1:])) if rows.ndim > 1 else 1
+    if tail_elems >= 4:
+        acc = np.zeros(rows.shape[1:], np.float32)
+        for k in range(n):
+            acc = (acc + rows[k]).astype(np.float32)
+        return acc
+    part = [np.zeros(rows.shape[1:], np.float32) for _ in range(4)]
+    q = n // 4
+    for k in range(4 * q):
+        part[k % 4] = (part[k % 4] + rows[k]).astype(np.float32)
+    for k in range(4 * q, n):
+        part[0] = (part[0] + rows[k]).astype(np.float32)
+    r = part[0]
+    for j in (1, 2, 3):
+        r = (r + part[j]).astype(np.float32)
+    return r
+
+
 def ensemble_stream(window_batches, seq_len, eval_mode, num_sample):
     """Literal restatement of the buffer loop predict.py:163-209 (heat maps) and
     predict.py:245-301 (coordinates): ``window_batches`` is an iterable of float32 arrays
     (B, L, *tail) -- the per-window network outputs in sliding-step-1 order.  Yields one
     array per batch: the ensembled per-frame predictions (n_frames_in_batch, *tail),
-    including the tail flush after the last window.
+    including the tail flush after the last window.  Bit-identical to the reference's loops
+    (products rounded to fp32, then `torch_cpu_sum0`'s order).
     """
     weight = get_ensemble_weight(seq_len, eval_mode)
     buffer_size = seq_len - 1
@@ -285,16 +413,16 @@ def ensemble_stream(window_batches, seq_len, eval_mode, num_sample):
         wb = weight.reshape((seq_len,) + (1,) * len(tail))
         for b in range(b_size):
             if sample_count < buffer_size:
-                e = buf[batch_i + b, frame_i].sum(0, dtype=np.float32) / np.float32(sample_count + 1)
+                e = torch_cpu_sum0(buf[batch_i + b, frame_i]) / np.float32(sample_count + 1)
             else:
-                e = (buf[batch_i + b, frame_i] * wb).sum(0, dtype=np.float32)
+                e = torch_cpu_sum0((buf[batch_i + b, frame_i] * wb).astype(np.float32))
             out.append(e.astype(np.float32))
             sample_count += 1
             if sample_count == num_sample:
                 pad = np.zeros((buffer_size, seq_len) + tail, dtype=np.float32)
                 buf = np.concatenate((buf, pad), axis=0)
                 for f in range(1, seq_len):
-                    e = buf[batch_i + b + f, frame_i].sum(0, dtype=np.float32) / np.float32(seq_len - f)
+                    e = torch_cpu_sum0(buf[batch_i + b + f, frame_i]) / np.float32(seq_len - f)
                     out.append(e.astype(np.float32))
         yield np.stack(out, axis=0)
         buf = buf[-buffer_size:]

@@ -321,6 +321,16 @@ inline float __logf(float x) { return logf(x); }
 inline float __cosf(float x) { return cosf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __frcp_rn(float a) { return 1.0f / a; }
+inline float __fmul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  volatile float r = a * b;      // a rounded product that no later add may absorb into an FMA
+  return r;
+}
+inline float __fadd_rn(float a, float b) {
+#pragma clang fp contract(off)
+  volatile float r = a + b;
+  return r;
+}
 inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }

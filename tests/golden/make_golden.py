@@ -453,11 +453,30 @@ def host_logic_cases():
     idx[:, :, 1] = np.array([[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 9, 9]])     # padded tail de-dup
     c = prng.uniform((3, 4, 2), 21)
     c[0, 1] = 0
-    a = ref_predict(torch.from_numpy(idx), c_pred=torch.from_numpy(c), img_scaler=(3.75, 3.75))
+    # predict.py:51 `int(c_p[0] * WIDTH * img_scaler[0])`: c_p[0] is an np.float32 SCALAR and WIDTH a Python int.  Under the
+    # reference's pinned numpy 1.22.4 (requirements.txt:2; legacy promotion: float32 scalar x Python scalar -> float64) the
+    # product is float64; under this container's numpy 2.2 (NEP 50) it would stay float32 and truncate differently for 45 % of
+    # the coordinates X/1920.  The pinned environment is the reference: its own `predict` is therefore run here on the fp32
+    # values widened to float64 (an exact conversion), which makes numpy 2.2 evaluate exactly numpy 1.22.4's expression.
+    a = ref_predict(torch.from_numpy(idx), c_pred=torch.from_numpy(c).double(), img_scaler=(3.75, 3.75))
     b = postproc.predict(idx, c_pred=c, img_scaler=(3.75, 3.75))
     assert a == b
     out["predict_c_idx"], out["predict_c_in"] = idx, c
     out["predict_c_out"] = np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]])
+    # ... and on coordinates of the form fp32(X / 1920), fp32(Y / 1080) -- what an unmasked frame carries through the
+    # InpaintNet stage -- where float32 and float64 arithmetic disagree about int() most often
+    n_c = 240
+    idx2 = np.zeros((n_c, 1, 2), dtype=np.int64)
+    idx2[:, 0, 1] = np.arange(n_c)
+    c2 = np.zeros((n_c, 1, 2), dtype=np.float32)
+    c2[:, 0, 0] = (np.arange(n_c) * 8 + 3).astype(np.float64) / 1920
+    c2[:, 0, 1] = (np.arange(n_c) * 4 + 1).astype(np.float64) / 1080
+    a = ref_predict(torch.from_numpy(idx2), c_pred=torch.from_numpy(c2).double(), img_scaler=(3.75, 3.75))
+    b = postproc.predict(idx2, c_pred=c2, img_scaler=(3.75, 3.75))
+    assert a == b
+    a32 = ref_predict(torch.from_numpy(idx2), c_pred=torch.from_numpy(c2), img_scaler=(3.75, 3.75))
+    assert a32 != a, "expected numpy-2 float32 promotion to differ from the pinned numpy's float64 on these inputs"
+    out["predict_c64_out"] = np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]])
     hm = np.zeros((3, 4, 288, 512), dtype=np.float32)
     hm[0, 0, 100:105, 200:207] = 0.9
     hm[0, 1, 10:12, 10:12] = 0.7
@@ -526,7 +545,7 @@ def ensemble_cases():
                 assert ens.shape == mine.shape, (ens.shape, mine.shape)
                 assert np.array_equal(frames, np.arange(n_win + L - 1))
                 d = np.abs(ens - mine).max()
-                assert d <= 1.2e-7, (L, mode, n_win, batch, d)
+                assert np.array_equal(ens, mine), (L, mode, n_win, batch, d)      # same summation order: bit-equal
                 out[f"heat_{k}_meta"] = np.array([L, mode == "weight", n_win, batch, 1000 + k])
                 out[f"heat_{k}_ens"] = ens
                 k += 1
@@ -544,7 +563,7 @@ def ensemble_cases():
         th = (mine[:, 0] < postproc.COOR_TH) & (mine[:, 1] < postproc.COOR_TH)
         mine[th] = 0
         d = np.abs(ens - mine).max()
-        assert d <= 1.2e-7, (n_win, batch, mode, d)
+        assert np.array_equal(ens, mine), (n_win, batch, mode, d)             # torch's four-partial-sum order: bit-equal
         out[f"coor_{j}_meta"] = np.array([L, mode == "weight", n_win, batch, 3000 + j])
         out[f"coor_{j}_ens"] = ens
     np.savez_compressed(os.path.join(OUT, "ensemble.npz"), **out)

@@ -52,7 +52,7 @@ def oracle_flow(frames, stub, sd_inpaint, seq_len, inp_len, eval_mode, batch, im
     t, _, h, w = frames.shape
     w_src, h_src = img_shape
     scaler = (w_src / opp.WIDTH, h_src / opp.HEIGHT)
-    median = frames.median(dim=0).values
+    median = torch.from_numpy(np.median(frames.numpy(), 0))
     starts = list(range(0, t - seq_len + 1))
     pred = {"Frame": [], "X": [], "Y": [], "Visibility": []}
     outs = []
@@ -75,7 +75,10 @@ def oracle_flow(frames, stub, sd_inpaint, seq_len, inp_len, eval_mode, batch, im
     oracle_flow.near_threshold_frames = near
     mask = opp.generate_inpaint_mask(pred, th_h=h_src * 0.05)
     n_pts = len(pred["Frame"])
-    coor = np.stack([np.array(pred["X"], np.float32) / w_src, np.array(pred["Y"], np.float32) / h_src], 1)
+    # dataset.py:360-394,470-471: int lists concatenated onto an empty float32 array give FLOAT64; the division by the image size
+    # is float64 and `coor_pred.float()` (predict.py:249) rounds once
+    coor = np.stack([(np.array(pred["X"], np.float64) / w_src).astype(np.float32),
+                     (np.array(pred["Y"], np.float64) / h_src).astype(np.float32)], 1)
     m = np.array(mask, np.float32).reshape(-1, 1)
     starts = list(range(0, n_pts - inp_len + 1))
     outs = []
@@ -173,11 +176,33 @@ def disc_video(t, h=288, w=512, seed=5, sigma=3.0):
     return torch.stack(frames, 0), track
 
 
+def compare_final_stage(got, got_pre, want_final, want_pre, img_shape, n_masked_frames):
+    """The InpaintNet stage of predict.py (213-301) against the oracle flow, given identical TrackNet-stage integers:
+      * the float64 values that predict.py:51 truncates agree to 1e-6 x (source size) on EVERY coordinate -- and are EQUAL on every
+        frame that no InpaintNet output reaches (blend with mask 0 returns the input exactly, and the ensemble runs in the reference's
+        summation order), so those frames' integers are equal by construction;
+      * the integers are compared on all 2 x T coordinates; mismatches are counted (a mismatch needs an InpaintNet-dependent float
+        within 1e-6 x size of an integer).  Returns the statistics; the caller asserts the mismatch count."""
+    t = len(want_final["Frame"])
+    assert got["Frame"] == want_final["Frame"] and len(got_pre) == len(want_pre) == t
+    worst, exact_floats, mism = 0.0, 0, []
+    for f in range(t):
+        for k, j in (("X", 0), ("Y", 1)):
+            d = abs(got_pre[f][j] - want_pre[f][j])
+            worst = max(worst, d / img_shape[j])
+            exact_floats += d == 0.0
+            assert d <= 1e-6 * img_shape[j], (f, k, got_pre[f][j], want_pre[f][j])
+            if got[k][f] != want_final[k][f]:
+                mism.append((f, k, got[k][f], want_final[k][f], want_pre[f][j]))
+    return {"coordinates": 2 * t, "integer_mismatches": len(mism), "mismatch_list": mism, "pre_int_bit_equal": int(exact_floats),
+            "pre_int_worst_rel": worst, "masked_frames": int(n_masked_frames)}
+
+
 def check_real_network_pipeline(device, t=24, h=288, w=512, batch=6, eval_mode="weight", report=None):
     """predict_video(HIP TrackNet(27,8) + HIP InpaintNet) against oracle_flow with the ORACLE TrackNet / InpaintNet on the
     same frames.  TrackNet stage: integer dict bit-exact except frames whose ensembled oracle heat map has a pixel within
-    1e-4 of the threshold (counted and reported); final stage: integers equal wherever the float that predict.py:51
-    truncates is farther than 1e-5 * (source size) from an integer, and never off by more than one."""
+    1e-4 of the threshold (counted and reported); final stage: `compare_final_stage` -- pre-int() floats within 1e-6 x size on
+    every coordinate, integer mismatches counted over all 2 x T coordinates and asserted to be ZERO."""
     from tracknetv3_amd.model import InpaintNet, TrackNet
     from tracknetv3_amd.pipeline import predict_video
     seq_len, inp_len, img_shape = 8, 16, (1920, 1080)
@@ -207,26 +232,17 @@ def check_real_network_pipeline(device, t=24, h=288, w=512, batch=6, eval_mode="
     bad = [f for f in range(t) if f not in near and any(got_track[k][f] != want_track[k][f] for k in ("X", "Y", "Visibility"))]
     assert not bad, (bad, [(got_track["X"][f], want_track["X"][f]) for f in bad])
     assert len(near) <= t // 4, near
-    got = predict_video(frames.to(device), tn, net, seq_len, inp_len, "concat", eval_mode, batch, img_shape)
-    strict = loose = 0
+    dbg = {}
+    got = predict_video(frames.to(device), tn, net, seq_len, inp_len, "concat", eval_mode, batch, img_shape, debug=dbg)
+    stats = None
     if not near:                                   # the InpaintNet stage consumes the TrackNet-stage integers: identical inputs
         assert got["Inpaint_Mask"] == want_mask and sum(want_mask) > 0
-        assert got["Frame"] == want_final["Frame"]
-        band = 1e-5 * max(img_shape)
-        for f in range(t):
-            for k, j in (("X", 0), ("Y", 1)):
-                v = pre_int[f][j]
-                if abs(v - round(v)) > band:
-                    assert got[k][f] == want_final[k][f], (f, k, got[k][f], want_final[k][f], v)
-                    strict += 1
-                else:
-                    assert abs(got[k][f] - want_final[k][f]) <= 1, (f, k, got[k][f], want_final[k][f], v)
-                    loose += 1
+        stats = compare_final_stage(got, dbg["pre_int"], want_final, pre_int, img_shape, sum(want_mask))
+        assert stats["integer_mismatches"] == 0, stats["mismatch_list"]
         assert got["Visibility"] == want_final["Visibility"]
-        assert strict > 0
+        assert stats["pre_int_bit_equal"] >= stats["coordinates"] // 2        # most frames never see an InpaintNet output
     if report is not None:
-        report.update(near_threshold_frames=near, strict_coordinates=strict, band_coordinates=loose, visible=n_vis,
-                      masked=sum(want_mask))
+        report.update(near_threshold_frames=near, visible=n_vis, masked=sum(want_mask), final_stage=stats)
     return got_track, got
 
 
@@ -245,12 +261,14 @@ def check_pipeline(device, h, w, t, batch, eval_mode):
     got_track = predict_video(frames.to(device), stub, None, seq_len, inp_len, "concat", eval_mode, batch, img_shape)
     assert got_track == want_track                                   # integer peak-find + scaling: bit-exact
     assert len(got_track["Frame"]) == t and got_track["Frame"] == list(range(t))
-    got = predict_video(frames.to(device), stub, net, seq_len, inp_len, "concat", eval_mode, batch, img_shape)
+    want_pre = list(oracle_flow.pre_int)
+    dbg = {}
+    got = predict_video(frames.to(device), stub, net, seq_len, inp_len, "concat", eval_mode, batch, img_shape, debug=dbg)
     assert got["Inpaint_Mask"] == want_mask and sum(want_mask) > 0
-    assert got["Frame"] == want_final["Frame"] and got["Visibility"] == want_final["Visibility"]
-    # coordinates pass through fp32 InpaintNet arithmetic and int() truncation: allow one source pixel
-    assert max(abs(a - b) for a, b in zip(got["X"], want_final["X"])) <= 1
-    assert max(abs(a - b) for a, b in zip(got["Y"], want_final["Y"])) <= 1
+    # pre-int() floats within 1e-6 x size everywhere, bit-equal where no InpaintNet output reaches; ALL integers equal
+    stats = compare_final_stage(got, dbg["pre_int"], want_final, want_pre, img_shape, sum(want_mask))
+    assert stats["integer_mismatches"] == 0, stats["mismatch_list"]
+    assert got["Visibility"] == want_final["Visibility"]
     # the non-overlap mode covers every frame exactly once as well
     no = predict_video(frames.to(device), stub, net, seq_len, inp_len, "concat", "nonoverlap", batch, img_shape)
     assert no["Frame"] == list(range(t))

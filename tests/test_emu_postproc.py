@@ -68,6 +68,14 @@ def test_predict_and_predict_location_api(emu):
     idx = g["predict_c_idx"]
     a = pp.predict(torch.from_numpy(idx), c_pred=torch.from_numpy(g["predict_c_in"]), img_scaler=(3.75, 3.75))
     assert np.array_equal(np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]]), g["predict_c_out"])
+    n_c = 240                                             # fp32(X / 1920), fp32(Y / 1080): float64 products (numpy 1.22.4 promotion)
+    idx2 = np.zeros((n_c, 1, 2), dtype=np.int64)
+    idx2[:, 0, 1] = np.arange(n_c)
+    c2 = np.zeros((n_c, 1, 2), dtype=np.float32)
+    c2[:, 0, 0] = (np.arange(n_c) * 8 + 3).astype(np.float64) / 1920
+    c2[:, 0, 1] = (np.arange(n_c) * 4 + 1).astype(np.float64) / 1080
+    a = pp.predict(torch.from_numpy(idx2), c_pred=torch.from_numpy(c2), img_scaler=(3.75, 3.75))
+    assert np.array_equal(np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]]), g["predict_c64_out"])
     # heat-map path on small maps (the 288x512 case runs on the GPU); compare with the oracle's predict()
     hm = np.zeros((3, 4, 16, 32), np.float32)
     hm[0, 0, 3:6, 4:9] = 0.9; hm[0, 1, 1:3, 1:3] = 0.7; hm[0, 1, 8:10, 20:22] = 0.8; hm[1, 2, 0:3, 0:2] = 0.51; hm[2, 0, 15, 31] = 1.0
@@ -106,7 +114,7 @@ def test_ensemble_stream_emulated_vs_reference_goldens(emu):
         mine = torch.cat(outs, 0).numpy()
         want = g[f"heat_{k}_ens"]
         assert mine.shape == want.shape, (k, mine.shape, want.shape)
-        assert np.abs(mine - want).max() <= 2.5e-7, (k, np.abs(mine - want).max())
+        assert np.array_equal(mine, want), (k, np.abs(mine - want).max())      # the reference's summation order: bit-equal
         k += 1
     assert k == 24
     j = 0
@@ -121,7 +129,7 @@ def test_ensemble_stream_emulated_vs_reference_goldens(emu):
         mine = torch.cat([es.push(blended[s:s + batch]) for s in range(0, n_win, batch)], 0)
         th = (mine[:, 0] < pp.COOR_TH) & (mine[:, 1] < pp.COOR_TH)
         mine[th] = 0
-        assert np.abs(mine.numpy() - g[f"coor_{j}_ens"]).max() <= 2.5e-7
+        assert np.array_equal(mine.numpy(), g[f"coor_{j}_ens"]), j
         j += 1
     assert j == 3
 

@@ -102,16 +102,31 @@ def test_ensemble_stream_vs_reference_goldens_and_full_size(gpu_device):
         win = prng.uniform((n_win, L, 4, 8), seed)
         es = pp.EnsembleStream(L, "weight" if wmode else "average", n_win)
         mine = torch.cat([es.push(torch.from_numpy(win[s:s + batch]).to(gpu_device)) for s in range(0, n_win, batch)], 0)
-        assert np.abs(mine.cpu().numpy() - g[f"heat_{k}_ens"]).max() <= 2.5e-7, k
+        assert np.array_equal(mine.cpu().numpy(), g[f"heat_{k}_ens"]), k        # the reference's own loop: bit-equal
         k += 1
     assert k == 24
+    j = 0
+    while f"coor_{j}_meta" in g:                      # coordinate ensemble (E = 2: torch's four-partial-sum order): bit-equal
+        L, wmode, n_win, batch, seed = (int(v) for v in g[f"coor_{j}_meta"])
+        win = prng.uniform((n_win, L, 2), seed)
+        cin = prng.uniform((n_win, L, 2), seed + 100)
+        cin[prng.uniform((n_win, L), seed + 150) < 0.2] = 0
+        msk = (prng.uniform((n_win, L, 1), seed + 200) < 0.4).astype(np.float32)
+        bl = pp.inpaint_blend_threshold(torch.from_numpy(win).to(gpu_device), torch.from_numpy(cin).to(gpu_device),
+                                        torch.from_numpy(msk).to(gpu_device))
+        es = pp.EnsembleStream(L, "weight" if wmode else "average", n_win)
+        mine = torch.cat([es.push(bl[s:s + batch]) for s in range(0, n_win, batch)], 0)
+        mine[(mine[:, 0] < pp.COOR_TH) & (mine[:, 1] < pp.COOR_TH)] = 0
+        assert np.array_equal(mine.cpu().numpy(), g[f"coor_{j}_ens"]), j
+        j += 1
+    assert j == 3
     # full-size heat maps: the literal buffer-loop restatement (oracle) vs the device stream
     L, n_win, batch = 8, 21, 10
     win = prng.uniform((n_win, L, 288, 512), 99)
     want = np.concatenate(list(opp.ensemble_stream([win[s:s + batch] for s in range(0, n_win, batch)], L, "weight", n_win)), 0)
     es = pp.EnsembleStream(L, "weight", n_win)
     mine = torch.cat([es.push(torch.from_numpy(win[s:s + batch]).to(gpu_device)) for s in range(0, n_win, batch)], 0)
-    assert mine.shape[0] == n_win + L - 1 and np.abs(mine.cpu().numpy() - want).max() <= 2.5e-7
+    assert mine.shape[0] == n_win + L - 1 and np.array_equal(mine.cpu().numpy(), want)
 
 
 def test_inpaintnet_forward(gpu_device):

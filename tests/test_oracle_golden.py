@@ -96,6 +96,14 @@ def test_host_logic_goldens():
     assert np.array_equal(xm.numpy(), g["mixup_x"]) and np.array_equal(ym.numpy(), g["mixup_y"])
     a = postproc.predict(g["predict_c_idx"], c_pred=g["predict_c_in"], img_scaler=(3.75, 3.75))
     assert np.array_equal(np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]]), g["predict_c_out"])
+    n_c = 240                                             # fp32(X / 1920), fp32(Y / 1080): float64 products (numpy 1.22.4 promotion)
+    idx2 = np.zeros((n_c, 1, 2), dtype=np.int64)
+    idx2[:, 0, 1] = np.arange(n_c)
+    c2 = np.zeros((n_c, 1, 2), dtype=np.float32)
+    c2[:, 0, 0] = (np.arange(n_c) * 8 + 3).astype(np.float64) / 1920
+    c2[:, 0, 1] = (np.arange(n_c) * 4 + 1).astype(np.float64) / 1080
+    a = postproc.predict(idx2, c_pred=c2, img_scaler=(3.75, 3.75))
+    assert np.array_equal(np.array([a["Frame"], a["X"], a["Y"], a["Visibility"]]), g["predict_c64_out"])
     hm = np.zeros((3, 4, 288, 512), dtype=np.float32)
     hm[0, 0, 100:105, 200:207] = 0.9
     hm[0, 1, 10:12, 10:12] = 0.7
@@ -114,9 +122,23 @@ def test_ensemble_goldens():
         win = prng.uniform((n_win, L, 4, 8), seed)
         mine = np.concatenate(list(postproc.ensemble_stream([win[s:s + batch] for s in range(0, n_win, batch)], L,
                                                             "weight" if wmode else "average", n_win)), 0)
-        assert np.abs(mine - g[f"heat_{k}_ens"]).max() <= 1.2e-7
+        assert np.array_equal(mine, g[f"heat_{k}_ens"]), k          # bit-equal to the reference's own loop (torch CPU)
         k += 1
     assert k == 24
+    j = 0
+    while f"coor_{j}_meta" in g:                      # coordinate ensemble: blend + threshold, ensemble, threshold
+        L, wmode, n_win, batch, seed = (int(v) for v in g[f"coor_{j}_meta"])
+        win = prng.uniform((n_win, L, 2), seed)
+        cin = prng.uniform((n_win, L, 2), seed + 100)
+        cin[prng.uniform((n_win, L), seed + 150) < 0.2] = 0
+        msk = (prng.uniform((n_win, L, 1), seed + 200) < 0.4).astype(np.float32)
+        bl = postproc.inpaint_blend_threshold(win, cin, msk)
+        mine = np.concatenate(list(postproc.ensemble_stream([bl[s:s + batch] for s in range(0, n_win, batch)], L,
+                                                            "weight" if wmode else "average", n_win)), 0)
+        mine[(mine[:, 0] < postproc.COOR_TH) & (mine[:, 1] < postproc.COOR_TH)] = 0
+        assert np.array_equal(mine, g[f"coor_{j}_ens"]), j
+        j += 1
+    assert j == 3
 
 
 def test_predict_location_against_scipy_label():
@@ -152,3 +174,34 @@ def test_evaluate_and_get_metric_vs_reference_golden():
     for row in g["get_metric"]:
         got = opp.get_metric(*(int(v) for v in row[:5]))
         assert np.array_equal(np.array(got, dtype=np.float64), row[5:])
+
+
+def test_predict_location_equals_suzuki_abe_border_following():
+    """The published algorithm behind cv2.findContours (Suzuki & Abe 1985, Algorithm 2: outermost borders) restated in
+    oracle/postproc.py, against the flood-fill restatement: same selected box on the designed / tie-heavy maps of the OpenCV pin
+    test, on random maps of every density, and with blobs nested in holes (which border following does not report at all)."""
+    from test_cv2_pin import _maps
+    n_tie = 0
+    for k, m in enumerate(_maps()):
+        img = postproc.to_img(m > 0.5)
+        assert tuple(postproc.predict_location(img)) == tuple(postproc.predict_location_suzuki(img)), k
+        cont = postproc.suzuki_abe_external(img)
+        starts = [y * img.shape[1] + x for y, x, _ in cont]
+        assert starts == sorted(starts)                                   # discovery order = raster order of the start pixels
+        boxes = postproc.connected_boxes(img)
+        assert set(starts) <= {b[4] for b in boxes}                       # every outer border starts at a component's first pixel
+        areas = sorted((b[2] * b[3] for b in boxes), reverse=True)
+        if len(areas) > 1 and areas[0] == areas[1]:
+            n_tie += 1                                                    # a real tie: the order decides, and both derivations agree
+            assert tuple(postproc.predict_location_suzuki(img, newest_first=False)) != tuple(postproc.predict_location(img))
+    assert n_tie >= 5
+    rng = np.random.RandomState(11)
+    for trial in range(120):
+        img = (rng.rand(24, 40) < [0.02, 0.1, 0.3, 0.5, 0.7, 0.9][trial % 6]).astype(np.uint8) * 255
+        assert tuple(postproc.predict_location(img)) == tuple(postproc.predict_location_suzuki(img)), trial
+    ring = np.zeros((16, 20), np.uint8)
+    ring[2:13, 2:15] = 255
+    ring[4:11, 4:13] = 0
+    ring[6:9, 6:9] = 255                                                  # a blob inside the ring's hole
+    assert len(postproc.connected_boxes(ring)) == 2 and len(postproc.suzuki_abe_external(ring)) == 1
+    assert tuple(postproc.predict_location(ring)) == tuple(postproc.predict_location_suzuki(ring)) == (2, 2, 13, 11)

@@ -15,7 +15,7 @@ _c = ctypes
 _f32p = _c.c_void_p
 _lib = None
 _is_emulator = False
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Tnv3Error(RuntimeError):
@@ -73,7 +73,7 @@ def _declare(lib):
     sig("tnv3_inpaintnet_packed_floats", sz)
     sig("tnv3_inpaintnet_pack", i, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), p, p)
     sig("tnv3_inpaintnet_fused_forward", i, p, p, p, p, i, i, p)
-    sig("tnv3_ensemble_frames", i, p, i, lg, i, i, p, lg, i, lg, p, p)
+    sig("tnv3_ensemble_frames", i, p, i, lg, i, i, p, lg, i, lg, i, p, p)
     sig("tnv3_peakfind_workspace_bytes", sz, i, i, i)
     sig("tnv3_heatmap_peakfind", i, p, f, i, p, p, sz, i, i, i, p)
     sig("tnv3_heatmap_box_max", i, p, p, p, i, i, i, p)

@@ -6,7 +6,14 @@
 //        t <  num_sample, t <  L-1 : sum_s win[s][t-s] / (t+1)                  ("incomplete buffer", all modes)
 //        t <  num_sample, t >= L-1 : sum_k weight[k] * win[t-L+1+k][L-1-k]      (get_ensemble_weight, test.py:25-50)
 //        t >= num_sample           : sum_s win[s][t-s] / (L - (t - num_sample + 1))   (tail after the last window)
-//    Windows outside [0, num_sample) contribute zero.  HBM-bound gather-FMA: L reads + 1 write per output element.
+//    Windows outside [0, num_sample) contribute zero.  HBM-bound gather: L reads + 1 write per output element.
+//    The arithmetic is the reference's, operation by operation, so that results are BIT-identical to its torch-CPU loops:
+//    `(buf[...] * weight[:, None]).sum(0)` rounds every product to fp32 first (no FMA), and torch's CPU sum kernel
+//    (SumKernel.cpp) walks the L rows either sequentially (sum_order 0: its vectorised outer sum -- the heat maps, E = H*W)
+//    or as four interleaved partial sums p_j = sum_i x[4i+j], leftovers into p_0, result ((p_0+p_1)+p_2)+p_3 (sum_order 1:
+//    its scalar `row_sum` with ilp_factor 4 -- taken when fewer than four columns remain, i.e. the (L, 2) coordinates).
+//    Both orders were identified against the goldens produced by the reference's own loops (tests/golden/ensemble.npz:
+//    24 heat-map and 3 coordinate cases, all bit-equal).  Warm-up and tail divide the plain sum (true division).
 //
 //  * peak-find = predict.py:35 (`> 0.5`) + predict_location (test.py:52-79): cv2.findContours(RETR_EXTERNAL) +
 //    cv2.boundingRect + largest box.  Integer work, restated as 8-connected component labelling by lock-free
@@ -25,23 +32,28 @@ typedef float pp_f32x4 __attribute__((ext_vector_type(4)));
 
 inline __global__ void __launch_bounds__(256) ensemble_frames_kernel(const float* __restrict__ win, int n_local, long s_base,
                                                               int L, int E, const float* __restrict__ weight, long t0,
-                                                              int n_frames, long num_sample, float* __restrict__ out) {
+                                                              int n_frames, long num_sample, int sum_order, float* __restrict__ out) {
   // win: [n_local][L][E] (window s_base + i at row i), E = elements per position (H*W, or 2 for coordinates)
   const long total = (long)n_frames * E;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int fi = (int)(idx / E);
     const int e = (int)(idx - (long)fi * E);
     const long t = t0 + fi;
-    float acc = 0.0f;
     const bool general = (t < num_sample) && (t >= L - 1);
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // sum_order 0 uses part[0] only
+    const int k_ilp = sum_order ? (L / 4) * 4 : 0;
     for (int k = 0; k < L; ++k) {
       const long s = t - (L - 1) + k;            // window index; in-window position L-1-k
-      if (s < 0 || s >= num_sample) continue;
+      if (s < 0 || s >= num_sample) continue;    // the reference's zero rows: adding +0 is exact
       const long i = s - s_base;
       if (i < 0 || i >= n_local) continue;       // caller guarantees residency of all needed windows
-      const float v = win[((size_t)i * L + (L - 1 - k)) * E + e];
-      acc = general ? fmaf(weight[k], v, acc) : acc + v;
+      float v = win[((size_t)i * L + (L - 1 - k)) * E + e];
+      if (general) v = __fmul_rn(v, weight[k]);  // rounded product, then a rounded add: never contracted into an FMA
+      const int j = k < k_ilp ? (k & 3) : 0;
+      part[j] = __fadd_rn(part[j], v);
     }
+    float acc = part[0];
+    if (sum_order) acc = __fadd_rn(__fadd_rn(__fadd_rn(part[0], part[1]), part[2]), part[3]);
     if (!general) {
       const float div = (t < num_sample) ? (float)(t + 1) : (float)(L - (t - num_sample + 1));
       acc = acc / div;

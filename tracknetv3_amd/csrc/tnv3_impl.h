@@ -285,8 +285,8 @@ int inpaintnet_fused_forward_impl(Launcher& L, const float* x, const float* m, c
 
 template <class Launcher>
 int ensemble_frames_impl(Launcher& L, const float* win, int n_local, long s_base, int l, int e, const float* weight, long t0,
-                         int n_frames, long num_sample, float* out) {
-  if (!win || !weight || !out || n_local <= 0 || l <= 0 || e <= 0 || n_frames <= 0 || num_sample <= 0)
+                         int n_frames, long num_sample, int sum_order, float* out) {
+  if (!win || !weight || !out || n_local <= 0 || l <= 0 || e <= 0 || n_frames <= 0 || num_sample <= 0 || sum_order < 0 || sum_order > 1)
     TNV3_FAIL(-1, "ensemble_frames: bad argument");
   for (long t = t0; t < t0 + n_frames; t += (n_frames > 1 ? n_frames - 1 : 1)) {   // first and last frame bound the need
     const long lo = t - l + 1 > 0 ? t - l + 1 : 0, hi = t < num_sample - 1 ? t : num_sample - 1;
@@ -295,7 +295,7 @@ int ensemble_frames_impl(Launcher& L, const float* win, int n_local, long s_base
   }
   const long total = (long)n_frames * e;
   const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-  return L.launch(ensemble_frames_kernel, grid, 256, win, n_local, s_base, l, e, weight, t0, n_frames, num_sample, out);
+  return L.launch(ensemble_frames_kernel, grid, 256, win, n_local, s_base, l, e, weight, t0, n_frames, num_sample, sum_order, out);
 }
 
 inline size_t peakfind_workspace_bytes(int frames, int h, int w) {

@@ -354,9 +354,11 @@ def inpaintnet_fused(x, m, packed):
     return out
 
 
-def ensemble_frames(win, s_base, weight, t0, n_frames, num_sample):
+def ensemble_frames(win, s_base, weight, t0, n_frames, num_sample, sum_order=None):
     """Temporal ensemble of global frames t0..t0+n_frames-1 from resident windows win[i] = window s_base+i.
-    win: (n_local, L, *tail) -> out: (n_frames, *tail).  See tnv3_ensemble_frames."""
+    win: (n_local, L, *tail) -> out: (n_frames, *tail).  See tnv3_ensemble_frames.  sum_order (default: by the tail size, as
+    torch's CPU sum kernel picks its path): 0 = rows added sequentially (heat maps), 1 = four interleaved partial sums (fewer
+    than four elements per position: the (L, 2) coordinates) -- bit-identical to predict.py's `.sum(0)` either way."""
     lib = _lib.load()
     _f32(win, weight)
     _lib.dev_check(win, weight)
@@ -368,8 +370,10 @@ def ensemble_frames(win, s_base, weight, t0, n_frames, num_sample):
     out = torch.empty((n_frames,) + tail, dtype=torch.float32, device=win.device)
     if n_frames == 0:
         return out
+    if sum_order is None:
+        sum_order = 1 if e < 4 else 0
     _lib.check(lib.tnv3_ensemble_frames(_lib.ptr(win), n_local, int(s_base), l, e, _lib.ptr(weight), int(t0), int(n_frames),
-                                        int(num_sample), _lib.ptr(out), _lib.stream_ptr(win)))
+                                        int(num_sample), int(sum_order), _lib.ptr(out), _lib.stream_ptr(win)))
     return out
 
 

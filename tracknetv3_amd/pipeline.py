@@ -47,6 +47,16 @@ def _index_tensor(widx):
     return i
 
 
+def _np_median0(frames):
+    """np.median(frames, 0) for float frames: the middle value, or the mean of the two middle values when the count is even."""
+    t = int(frames.shape[0])
+    if t % 2:
+        return frames.median(dim=0).values
+    lo = torch.kthvalue(frames, t // 2, dim=0).values
+    hi = torch.kthvalue(frames, t // 2 + 1, dim=0).values
+    return (lo + hi) * 0.5
+
+
 _SIDE_STREAMS = {}
 
 
@@ -105,9 +115,11 @@ def _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, n_str
 
 @torch.no_grad()
 def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaintnet_seq_len=16, bg_mode="concat",
-                  eval_mode="weight", batch_size=16, img_shape=None, median=None):
+                  eval_mode="weight", batch_size=16, img_shape=None, median=None, debug=None):
     """Returns the reference's pred_dict {'Frame','X','Y','Visibility'} (+ 'Inpaint_Mask' when InpaintNet runs)
-    for a (T, 3, 288, 512) frame tensor.  img_shape = (w, h) of the source video (default: the network resolution)."""
+    for a (T, 3, 288, 512) frame tensor.  img_shape = (w, h) of the source video (default: the network resolution).
+    debug: an optional dict that receives 'pre_int' -- per output frame the two float64 values that predict.py:51 truncates
+    with int() in the InpaintNet stage (the parity tests compare them with the oracle's before looking at the integers)."""
     if eval_mode not in ("nonoverlap", "average", "weight"):
         raise ValueError("Invalid mode")
     if frames.dtype == torch.uint8:                      # source-resolution (T, H, W, 3) stream: preprocess on the device
@@ -121,7 +133,8 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
     w_src, h_src = img_shape if img_shape is not None else (WIDTH, HEIGHT)
     img_scaler = (w_src / WIDTH, h_src / HEIGHT)
     if bg_mode == "concat" and median is None:
-        median = frames.median(dim=0).values
+        # np.median's semantics (dataset.py:105: the MEAN of the two middle values for an even frame count), not torch's lower median
+        median = _np_median0(frames)
     tracknet.eval()
     pred = {"Frame": [], "X": [], "Y": [], "Visibility": []}
     seq_len = tracknet_seq_len
@@ -157,9 +170,12 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
     seq_len = inpaintnet_seq_len
     batch_size = max(batch_size, 1024)       # trajectory windows are 48 floats each: the reference's batch only bounds launch count
     n_pts = len(pred["Frame"])
-    coor_all = torch.tensor([pred["X"], pred["Y"]], dtype=torch.float32).t().contiguous()      # source-pixel units
+    # dataset.py:360-394,470-471: the integer lists are concatenated onto an empty float32 array -> a FLOAT64 array, divided by the
+    # image size in float64, and only `coor_pred.float()` (predict.py:221,249) rounds to fp32
+    coor_all = torch.tensor([pred["X"], pred["Y"]], dtype=torch.float64).t().contiguous()      # source-pixel units
     coor_all[:, 0] /= w_src
     coor_all[:, 1] /= h_src
+    coor_all = coor_all.float()
     mask_all = torch.tensor(pred["Inpaint_Mask"], dtype=torch.float32).reshape(-1, 1)
     out = {"Frame": [], "X": [], "Y": [], "Visibility": []}
 
@@ -170,6 +186,10 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
             c, m = coor_all[wi].to(dev), mask_all[wi].to(dev)
             ci = pp.inpaint_blend_threshold(inpaintnet(c, m), c, m)
             tmp = pp.predict(_index_tensor(wi), c_pred=ci, img_scaler=img_scaler)
+            if debug is not None:      # nonoverlap: windows tile the frame list; a padded tail repeats the last frame and is cut by predict()
+                flat = ci.detach().double().cpu().reshape(-1, 2)[:len(tmp["Frame"])]
+                debug.setdefault("pre_int", []).extend(
+                    (float(v[0]) * WIDTH * img_scaler[0], float(v[1]) * HEIGHT * img_scaler[1]) for v in flat)
             for k in out:
                 out[k].extend(tmp[k])
     else:
@@ -190,6 +210,9 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
             ids[:, 0, 1] = torch.arange(frame_id, frame_id + n)
             frame_id += n
             tmp = pp.predict(ids, c_pred=ens.unsqueeze(1), img_scaler=img_scaler)
+            if debug is not None:
+                debug.setdefault("pre_int", []).extend(
+                    (float(v[0]) * WIDTH * img_scaler[0], float(v[1]) * HEIGHT * img_scaler[1]) for v in ens.detach().double().cpu())
             for k in out:
                 out[k].extend(tmp[k])
     out["Inpaint_Mask"] = pred["Inpaint_Mask"]

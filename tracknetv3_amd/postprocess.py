@@ -77,7 +77,9 @@ def predict(indices, y_pred=None, c_pred=None, img_scaler=(1, 1)):
             if f_i != prev_f_i:
                 if c_pred is not None:
                     c_p = c_pred[n][f]
-                    cx_pred, cy_pred = int(c_p[0] * WIDTH * img_scaler[0]), int(c_p[1] * HEIGHT * img_scaler[1])
+                    # float64 products, whatever numpy is installed: the reference's pinned numpy 1.22.4 promotes
+                    # `np.float32 scalar * Python int` to float64 (numpy >= 2 keeps float32: 45 % of X / 1920 truncate differently)
+                    cx_pred, cy_pred = int(float(c_p[0]) * WIDTH * img_scaler[0]), int(float(c_p[1]) * HEIGHT * img_scaler[1])
                 else:
                     bx, by, bw, bh = (int(v) for v in boxes[n][f])
                     cx_pred, cy_pred = int(bx + bw / 2), int(by + bh / 2)

@@ -55,22 +55,40 @@ def write_pred_csv(pred_dict, save_file, save_inpaint_mask=False):
     """Write a prediction dict as the reference's csv wire format (utils/general.py:319-354): columns
     ``Frame,Visibility,X,Y`` -- or, with ``save_inpaint_mask``, the InpaintNet-training layout
     ``Frame,Visibility_GT,X_GT,Y_GT,Visibility,X,Y,Inpaint_Mask`` -- one row per frame, no index column.  The reference
-    goes through ``pandas.DataFrame.to_csv(index=False)``; this writes the same bytes for the integer lists the
-    post-process produces (tests compare with pandas) without needing pandas on the box."""
+    goes through ``pandas.DataFrame.to_csv(index=False)``; this writes the same bytes without needing pandas on the box
+    (tests/test_boundary.py compares with pandas): integer and bool columns -- what the post-process produces -- as pandas
+    prints them; a column holding any float is a float column there, so its integers print as ``1.0``, NaN / None as an
+    empty field, and an all-float32 column in float32's shortest form."""
+    import math
     cols = _CSV_COLUMNS_INPAINT if save_inpaint_mask else _CSV_COLUMNS
     series = [list(pred_dict[c]) for c in cols]
     n = len(series[0])
     if any(len(s) != n for s in series):
         raise ValueError('All arrays must be of the same length')         # pandas' message for ragged columns
 
-    def fmt(v):
-        if hasattr(v, 'item'):
-            v = v.item()
-        if isinstance(v, bool):
-            return 'True' if v else 'False'
-        return repr(v) if isinstance(v, float) else str(v)
+    def column(vals):
+        kinds = [getattr(getattr(v, 'dtype', None), 'name', type(v).__name__) for v in vals]
+        vals = [v.item() if hasattr(v, 'item') else v for v in vals]
+        if all(isinstance(v, bool) for v in vals):
+            return ['True' if v else 'False' for v in vals]
+        if all(isinstance(v, int) and not isinstance(v, bool) for v in vals):
+            return [str(v) for v in vals]
+        if not all(v is None or isinstance(v, (int, float)) for v in vals):
+            raise TypeError('write_pred_csv: columns must hold numbers')
+        f32 = all(k == 'float32' for k in kinds)
+        out = []
+        for v in vals:
+            if v is None or (isinstance(v, float) and math.isnan(v)):
+                out.append('')
+            elif f32:
+                import numpy as np
+                out.append(str(np.float32(v)))
+            else:
+                out.append(repr(float(v)))
+        return out
 
+    text = [column(s) for s in series]
     with open(save_file, 'w', newline='') as f:
         f.write(','.join(cols) + '\n')
-        for row in zip(*series):
-            f.write(','.join(fmt(v) for v in row) + '\n')
+        for row in zip(*text):
+            f.write(','.join(row) + '\n')
