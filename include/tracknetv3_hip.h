@@ -105,6 +105,8 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
 int tnv3_conv3x3_wino_layout(int variant);     /* filter pack layout (0 or 1) the kernel `variant` reads; -1 = the default kernel */
+int tnv3_conv3x3_wino_has_stats(int variant);  /* 1 when `variant` (-1 = the default kernel) can emit BatchNorm batch statistics from its
+                                                  epilogue (tnv3_conv3x3_wino_forward_stats), else 0 */
 int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, int layout, tnv3_stream_t stream);
 int tnv3_conv3x3_wino_pack_view(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip,
                                 int layout, tnv3_stream_t stream);

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Copies the summaries of the last scripts/gpu_s8.sh evidence session from gpurun_out/ (scratch) into profiles/ (tracked).
+# Copies the summaries of the last scripts/gpu_session.sh evidence session (PARTS="host smoke pytest infer train ab fixed decoder profinfer proftrain pmc sq") from gpurun_out/ (scratch) into profiles/ (tracked).
 set -eu
 cd "$(dirname "$0")/.."
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 O=gpurun_out
 P=profiles
 cp $O/bench.json $P/${R}_bench_n1.json

@@ -8,7 +8,7 @@ rocprofv3 -L > $OUT/counters_list.txt 2>&1
 grep -oE "\b(SQ_[A-Z0-9_]+|GRBM_[A-Z0-9_]+|TCC_[A-Z0-9_]+|TCP_[A-Z0-9_]+)\b" $OUT/counters_list.txt | sort -u > $OUT/counter_names.txt
 wc -l $OUT/counter_names.txt
 cd /tmp
-run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap-streams 0 --infer-split 0 --train-steps 0 > /dev/null 2> $OUT/pmc_$name.err; echo "pmc $name rc=$?"; }
+run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline --overlap-streams 0 --infer-split 0 --train-steps 0 --extras 0 --layers-out /tmp/sq_layers.json > /dev/null 2> $OUT/pmc_$name.err; echo "pmc $name rc=$?"; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES
 run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
 run sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES GRBM_GUI_ACTIVE

@@ -138,3 +138,56 @@ def test_mixup_draws_on_the_device(emu):
         _, pm = ops.mixup_draw(10, 0.5, 99, s, "cpu")
         pos[pm.tolist().index(0)] += 1
     assert pos.min() >= 15 and pos.max() <= 70, pos
+
+
+def test_fused_sgd_writes_the_clipped_gradient_back(emu):
+    """clip_grad_norm_ (train.py:165) modifies the gradients in place: after a clipped FusedSGD step `.grad` holds grad * coef."""
+    from tracknetv3_amd.optim import FusedSGD
+    mine, ref = _params(300), _params(300)
+    o_m = FusedSGD(mine, lr=1e-2, momentum=0.9, max_grad_norm=0.5)
+    o_r = torch.optim.SGD(ref, lr=1e-2, momentum=0.9, foreach=False)
+    for it in range(3):
+        for k, (a, b) in enumerate(zip(mine, ref)):
+            g = T(a.shape, 7000 + 50 * it + k, -2.0, 2.0)
+            a.grad, b.grad = g.clone(), g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 0.5, foreach=False)
+        o_r.step()
+        o_m.step()
+        for a, b in zip(mine, ref):
+            assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
+            assert _ulps(a, b, floor=1e-2) <= 16
+
+
+def test_fused_adam_validates_up_front_and_keeps_counters_on_failure(emu):
+    from tracknetv3_amd.optim import FusedAdam
+    ps = _params(400)
+    with pytest.raises(ValueError, match="beta1"):
+        FusedAdam(ps, betas=(0.4, 0.999))                      # refused in __init__, not at the first step
+    opt = FusedAdam(ps, lr=1e-3)
+    for k, p in enumerate(ps):
+        p.grad = T(p.shape, 8000 + k)
+    opt.step()
+    assert all(float(opt.state[p]["step"]) == 1.0 for p in ps)
+    opt.param_groups[0]["decoupled_weight_decay"] = True       # a later edit is caught at step time ...
+    before = [p.detach().clone() for p in ps]
+    with pytest.raises(RuntimeError, match="decoupled_weight_decay"):
+        opt.step()
+    assert all(float(opt.state[p]["step"]) == 1.0 for p in ps)          # ... before any counter or tensor moved
+    assert all(torch.equal(a, b) for a, b in zip(before, ps))
+    opt.param_groups[0]["decoupled_weight_decay"] = False
+    opt.param_groups[0]["betas"] = (0.3, 0.999)
+    with pytest.raises(ValueError, match="beta1"):
+        opt.step()
+    assert all(float(opt.state[p]["step"]) == 1.0 for p in ps)
+
+
+def test_device_guard_sees_tensors_inside_list_arguments():
+    """ops.grad_norm / adam_step / sgd_step / inpaintnet_pack take LISTS of tensors: the device guard must find them."""
+    from tracknetv3_amd import _lib, ops
+    a, b = torch.zeros(3), torch.ones(2)
+    assert _lib.first_tensor((a, [b])) is a
+    assert _lib.first_tensor(([b, a], 1.0)) is b
+    assert _lib.first_tensor(((), [], (b,))) is b
+    assert _lib.first_tensor((1, "x", None)) is None
+    for name in ("grad_norm", "adam_step", "sgd_step", "inpaintnet_pack"):
+        assert hasattr(getattr(ops, name), "__wrapped__"), name          # wrapped by _lib.on_tensor_device

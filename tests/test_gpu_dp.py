@@ -119,3 +119,29 @@ def test_ops_follow_the_tensor_device_not_the_current_device(gpu_device):
         outs.append(y.cpu())
     assert torch.equal(outs[0], outs[1])
     assert torch.cuda.current_device() == 0
+
+
+@pytest.mark.gpu
+def test_fused_optimizers_and_inpaint_pack_follow_the_tensor_device(gpu_device):
+    """the list-of-tensor ops (grad_norm, adam_step, sgd_step, inpaintnet_pack) on cuda:1 while cuda:0 is current."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from tracknetv3_amd.model import InpaintNet
+    from tracknetv3_amd.optim import FusedAdam, FusedSGD
+    torch.cuda.set_device(0)
+    res = []
+    for d in ("cuda:0", "cuda:1"):
+        ps = [torch.nn.Parameter((nets.synth_input(s, 40 + k) - 0.5).to(d)) for k, s in enumerate([(64, 27, 3, 3), (64,), (4097,)])]
+        for cls in (FusedAdam, FusedSGD):
+            opt = cls(ps, lr=1e-2, max_grad_norm=0.5)
+            for k, p in enumerate(ps):
+                p.grad = (nets.synth_input(tuple(p.shape), 90 + k) - 0.5).to(d)
+            opt.step()
+        net = InpaintNet()
+        net.load_state_dict(nets.synth_state(nets.inpaintnet_state_shapes(), 77), strict=True)
+        net = net.to(d).eval()
+        y = net(nets.synth_input((3, 16, 2), 5).to(d), (nets.synth_input((3, 16, 1), 6) < 0.3).float().to(d))
+        assert torch.cuda.current_device() == 0
+        res.append([p.detach().cpu() for p in ps] + [y.cpu()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

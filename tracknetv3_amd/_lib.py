@@ -58,6 +58,7 @@ def _declare(lib):
     sig("tnv3_conv3x3_wino_packed_floats", sz, i, i)
     sig("tnv3_conv3x3_wino_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wino_layout", i, i)
+    sig("tnv3_conv3x3_wino_has_stats", i, i)
     sig("tnv3_conv3x3_wino_pack", i, p, p, i, i, i, p)
     sig("tnv3_conv3x3_wino_pack_view", i, p, p, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
@@ -127,7 +128,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_dgrad_up2x", "tnv3_conv3x3_wgrad_up2x_workspace_bytes", "tnv3_conv3x3_wgrad_up2x",
            "tnv3_conv3x3_wgrad_wino_supported", "tnv3_conv3x3_wgrad_wino_workspace_bytes", "tnv3_conv3x3_wgrad_wino",
            "tnv3_conv3x3_wino_stats_tiles", "tnv3_conv3x3_wino_forward_stats", "tnv3_bn_train_forward_tiles",
-           "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_layout", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_forward"]
+           "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_layout", "tnv3_conv3x3_wino_has_stats", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_forward"]
 
 
 def library_path():
@@ -213,11 +214,22 @@ def on_tensor_device(fn):
 
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
-        for a in args:
-            if isinstance(a, torch.Tensor):
-                if a.is_cuda and a.device.index != torch.cuda.current_device():
-                    with torch.cuda.device(a.device):
-                        return fn(*args, **kwargs)
-                break
+        a = first_tensor(args)
+        if a is not None and a.is_cuda and a.device.index != torch.cuda.current_device():
+            with torch.cuda.device(a.device):
+                return fn(*args, **kwargs)
         return fn(*args, **kwargs)
     return wrapper
+
+
+def first_tensor(args):
+    """The first tensor among the positional arguments, looking inside list / tuple arguments too (the multi-tensor ops --
+    grad_norm, adam_step, sgd_step, inpaintnet_pack -- take lists of tensors)."""
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            return a
+        if isinstance(a, (list, tuple)):
+            for b in a:
+                if isinstance(b, torch.Tensor):
+                    return b
+    return None

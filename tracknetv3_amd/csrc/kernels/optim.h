@@ -152,6 +152,7 @@ inline __global__ void __launch_bounds__(256) sgd_multi_kernel(const OptTensorTa
     p[e] = sgd_element(par, grad, bv, lr, momentum, weight_decay, first_step, coef, clip != nullptr);
     if (momentum != 0.0f) buf[e] = bv;
     if (zero_grad) g[e] = 0.0f;
+    else if (clip != nullptr) g[e] = grad * coef;                     // as clip_grad_norm_ does: the caller sees the clipped gradient
   }
 }
 

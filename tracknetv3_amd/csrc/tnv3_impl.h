@@ -420,6 +420,8 @@ using WinoV5 = WinoV3Cfg<8>;                // persistent workgroups, the chunk 
 inline int wino_persistent_grid(int items) { const int g = std::max(8, num_cus() / 8 * 8); return items < g ? items : g; }
 // filter pack layout a kernel variant expects (tnv3_conv3x3_wino_layout)
 inline int conv3x3_wino_layout(int variant) { return (variant == 4 || variant == 47 || variant == 44) ? 1 : 0; }
+// kernel variants whose epilogue can emit the BatchNorm batch statistics (tnv3_conv3x3_wino_has_stats)
+inline bool conv3x3_wino_has_stats(int variant) { return variant == 3 || variant == 4 || variant == 5; }
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
 constexpr int kWinoDefaultVariant = 5;       // per-call `variant`: 5 streaming persistent kernel (default), 3 WinoV3, 2 WinoSplit, 4 WinoV4 (quad
                                              // layouts), 5 WinoV5 (persistent), 0 WinoA (one wave / SIMD); -1 = default
@@ -456,7 +458,7 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
                               double* stats = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino: bad argument");
   if (variant < 0) variant = kWinoDefaultVariant;
-  if (stats && variant != 3 && variant != 4 && variant != 5) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3, 4 and 5");
+  if (stats && !conv3x3_wino_has_stats(variant)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3, 4 and 5");
   if (stats && (scale || shift || mean)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue writes the raw convolution (no affine)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino: statistics buffer must be 8-byte aligned");
   if (!conv3x3_wino_supported(cin, cout, h, w))

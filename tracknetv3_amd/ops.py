@@ -65,6 +65,15 @@ def wino_layout(variant=None):
     return int(_lib.load().tnv3_conv3x3_wino_layout(int(variant)))
 
 
+def wino_variant_has_stats(variant=None):
+    """Whether the Winograd kernel `variant` (None: tuning.WINO_VARIANT; -1 = the library's default, resolved there) can emit
+    the BatchNorm batch statistics from its epilogue."""
+    if variant is None:
+        from . import tuning
+        variant = tuning.WINO_VARIANT
+    return bool(_lib.load().tnv3_conv3x3_wino_has_stats(int(variant)))
+
+
 def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False, variant=None):
     """nn.Conv2d weight (Cout, Cin, 3, 3) -> Winograd-domain filters G w G^T for tnv3_conv3x3_wino_forward, of its input
     channels c_from .. c_from + c_count - 1 (default: all).  transpose_flip: the data gradient's filter
@@ -86,7 +95,8 @@ def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False, vari
 
 def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None, variant=None):
     """The plain eval-mode layer in Winograd F(2x2, 3x3) form (tnv3_conv3x3_wino_forward).  variant: kernel family for THIS
-    call (None: tuning.WINO_VARIANT, -1 = the library's default; 3 balanced (default), 5 persistent workgroups, 4 quad layouts, 2 xi-split, 0 one wave per SIMD)."""
+    call (None: tuning.WINO_VARIANT, -1 = the library's default = 5, the streaming persistent kernel; 3 balanced, 4 quad layouts,
+    2 xi-split, 0 one wave per SIMD)."""
     lib = _lib.load()
     _f32(src, u, mean, scale, shift, addend)
     _lib.dev_check(src, u, mean, scale, shift, addend)
@@ -797,7 +807,8 @@ _TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "co
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
-               "maxpool2x2_backward_add", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad"]
+               "maxpool2x2_backward_add", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad",
+               "grad_norm", "adam_step", "sgd_step", "inpaintnet_pack"]          # list-of-tensor ops: the guard looks inside the lists
 for _name in _TENSOR_OPS:
     globals()[_name] = _lib.on_tensor_device(globals()[_name])
 del _name

@@ -33,6 +33,23 @@ class FusedAdam(torch.optim.Adam):
                          fused=False)
         self.max_grad_norm, self.zero_grad_in_step = max_grad_norm, bool(zero_grad_in_step)
         self.last_grad_norm = None            # (2,) device tensor [norm, clip coefficient] of the last clipped step
+        for group in self.param_groups:
+            self._check_group(group)
+
+    @staticmethod
+    def _check_group(group):
+        """Everything the kernel cannot do is refused up front (and again at step time for groups added or edited later), BEFORE
+        any state is touched."""
+        if group.get("amsgrad") or group.get("maximize"):
+            raise RuntimeError("FusedAdam: amsgrad / maximize are not implemented")
+        if group.get("decoupled_weight_decay"):
+            raise RuntimeError("FusedAdam: decoupled_weight_decay (AdamW) is not implemented")
+        if isinstance(group["lr"], torch.Tensor):
+            raise RuntimeError("FusedAdam: a tensor learning rate would need a device read-back; use a float")
+        b1, b2 = group["betas"]
+        if not (0.5 < b1 < 1.0) or not (0.0 <= b2 < 1.0):
+            raise ValueError(f"FusedAdam: needs 0.5 < beta1 < 1 and 0 <= beta2 < 1 (got {b1}, {b2}): the kernel reproduces torch's foreach "
+                             "arithmetic only on that range")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -42,48 +59,47 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         work = []
         for group in self.param_groups:
-            if group.get("amsgrad") or group.get("maximize"):
-                raise RuntimeError("FusedAdam: amsgrad / maximize are not implemented")
-            lr = group["lr"]
-            if isinstance(lr, torch.Tensor):
-                raise RuntimeError("FusedAdam: a tensor learning rate would need a device read-back; use a float")
+            self._check_group(group)
+        for group in self.param_groups:      # the whole work list is built and validated before any counter moves
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             for p in ps:
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be contiguous")
+                if not p.grad.is_contiguous():      # once: the norm and the update read (and the clip writes) the same tensor
+                    p.grad = p.grad.contiguous()
                 st = self.state[p]
                 if len(st) == 0:          # torch.optim.Adam._init_group's layout
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1           # a CPU tensor: host arithmetic only
-            steps = {int(self.state[p]["step"]) for p in ps}
-            by_step = {s: [p for p in ps if int(self.state[p]["step"]) == s] for s in steps}      # normally one entry
+            steps = {int(self.state[p]["step"]) + 1 for p in ps}
+            by_step = {s: [p for p in ps if int(self.state[p]["step"]) + 1 == s] for s in steps}      # normally one entry
             for s, plist in by_step.items():
                 work.append((group, s, plist))
         if not work:
             return loss
         clip = None
         if self.max_grad_norm is not None:
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for _, _, plist in work for p in plist]
-            self.last_grad_norm = ops.grad_norm(grads, self.max_grad_norm)
+            self.last_grad_norm = ops.grad_norm([p.grad for _, _, plist in work for p in plist], self.max_grad_norm)
             clip = self.last_grad_norm[1:]
         for group, s, plist in work:
-            grads = []
-            for p in plist:
-                if not p.grad.is_contiguous():
-                    p.grad = p.grad.contiguous()
-                grads.append(p.grad)
+            grads = [p.grad for p in plist]
             b1, b2 = group["betas"]
             ops.adam_step([p.detach() for p in plist], grads, [self.state[p]["exp_avg"] for p in plist],
                           [self.state[p]["exp_avg_sq"] for p in plist], s, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
                           weight_decay=group["weight_decay"], clip_coef=clip, zero_grad=self.zero_grad_in_step)
+            for p in plist:
+                self.state[p]["step"] += 1    # a CPU tensor: host arithmetic only; advanced only once the launch was accepted
             _bump_versions(plist)
         return loss
 
 
 class FusedSGD(torch.optim.SGD):
-    """torch.optim.SGD (momentum, dampening 0, no Nesterov) with the update of all parameters in one HIP launch."""
+    """torch.optim.SGD (momentum, dampening 0, no Nesterov) with the update of all parameters in one HIP launch.  With
+    `max_grad_norm` the clipped gradients are written back to `.grad` (as `clip_grad_norm_` at train.py:165 leaves them),
+    unless `zero_grad_in_step` clears them."""
 
     def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0, max_grad_norm=None, zero_grad_in_step=False):
         super().__init__(params, lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False, foreach=False)
@@ -100,16 +116,21 @@ class FusedSGD(torch.optim.SGD):
         groups = [(g, ps) for g, ps in groups if ps]
         if not groups:
             return loss
-        clip = None
-        if self.max_grad_norm is not None:
-            self.last_grad_norm = ops.grad_norm([p.grad.contiguous() for _, ps in groups for p in ps], self.max_grad_norm)
-            clip = self.last_grad_norm[1:]
         for g, ps in groups:
             if g.get("nesterov") or g.get("dampening") or g.get("maximize"):
                 raise RuntimeError("FusedSGD: nesterov / dampening / maximize are not implemented")
+            for p in ps:                      # made contiguous ONCE: the norm and the update read (and the clip writes) the same tensor
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+        clip = None
+        if self.max_grad_norm is not None:
+            self.last_grad_norm = ops.grad_norm([p.grad for _, ps in groups for p in ps], self.max_grad_norm)
+            clip = self.last_grad_norm[1:]
+        for g, ps in groups:
             mom = g["momentum"]
             fresh = [p for p in ps if mom and "momentum_buffer" not in self.state[p]]
-            for first, plist in ((True, fresh), (False, [p for p in ps if p not in set(fresh)])):
+            fresh_ids = {id(p) for p in fresh}
+            for first, plist in ((True, fresh), (False, [p for p in ps if id(p) not in fresh_ids])):
                 if not plist:
                     continue
                 bufs = None
@@ -118,9 +139,6 @@ class FusedSGD(torch.optim.SGD):
                         if first:
                             self.state[p]["momentum_buffer"] = torch.empty_like(p)
                     bufs = [self.state[p]["momentum_buffer"] for p in plist]
-                for p in plist:
-                    if not p.grad.is_contiguous():
-                        p.grad = p.grad.contiguous()
                 ops.sgd_step([p.detach() for p in plist], [p.grad for p in plist], bufs, g["lr"], momentum=mom, weight_decay=g["weight_decay"],
                              first_step=first, clip_coef=clip, zero_grad=self.zero_grad_in_step)
                 _bump_versions(plist)

@@ -63,8 +63,10 @@ def use_winograd_wgrad(cin, cout, h, w):
 
 
 # Kernel-family choices are per-call arguments of the C ABI (no process-wide state inside the library); these are the
-# defaults the Python layer passes.  -1 = the library's default (xi-split Winograd kernel; register-staged weight gradient).
-WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 0: one wave per SIMD, 2: xi-split
+# defaults the Python layer passes.  -1 = the library's default, resolved INSIDE the library (kWinoDefaultVariant: today 5, the
+# streaming persistent Winograd kernel; register-staged weight gradient) -- layout and capabilities of "-1" are queried from it
+# (tnv3_conv3x3_wino_layout / tnv3_conv3x3_wino_has_stats), never assumed here.
+WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 5 streaming persistent (default), 3 balanced, 4 quad layouts, 2 xi-split, 0 one wave per SIMD
 WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA staged kernels (parity-green, 8 % slower)
 WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))   # Winograd-form weight gradient: 0 the first kernel, 1 two waves / SIMD
 
@@ -87,4 +89,5 @@ UP2X_WINO = os.environ.get("TNV3_UP2X_WINO", "1") != "0"
 
 
 def wino_has_stats():
-    return BN_STATS_IN_EPILOGUE and WINO_VARIANT in (-1, 3, 4, 5)
+    from . import ops
+    return BN_STATS_IN_EPILOGUE and ops.wino_variant_has_stats(WINO_VARIANT)
