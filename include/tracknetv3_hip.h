@@ -100,11 +100,17 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  *                                     wait or first transform; Cin <= 8 runs as 3);  0 = one wave per SIMD, transform as its own phase.  (1, the round-1 kernel with
  *                                     the transform interleaved into the MFMA stream, was removed: TNV3_E_INVALID.)  Variants 2, 3,
  *                                     4, 5 are bit-identical to each other; all compute the same function.
+ *                                     6 = 5 re-tiled to 128 output channels x (4 x 32 pixels) per workgroup, the filter operand read
+ *                                     straight from L2 into registers (kernels/conv3x3_wino6_mfma.h; Cout % 128 == 0, Cin > 8,
+ *                                     W % 32 == 0; filters packed with layout 2); bit-identical to 2-5.
+ *                                     -1 = tnv3_conv3x3_wino_pick(cin, cout): 6 where it applies, else 5 -- by channel counts only,
+ *                                     so a panel packed ahead of time is the one every call of that layer reads.
  *   `layout` of the pack calls: 0 = u[cin_pad][16][cout];  1 = u[cin_pad / 2][4][2][cout][4] (transform row major, the four xi of
- *                                     a row adjacent). */
+ *                                     a row adjacent);  2 = u[cout / 32][cin_pad / 8][2][8][64][4] (the A operand in lane order). */
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
-int tnv3_conv3x3_wino_layout(int variant);     /* filter pack layout (0 or 1) the kernel `variant` reads; -1 = the default kernel */
+int tnv3_conv3x3_wino_pick(int cin, int cout); /* the kernel variant that `variant` = -1 means for these channel counts */
+int tnv3_conv3x3_wino_layout(int variant);     /* filter pack layout (0, 1 or 2) the kernel `variant` (>= 0) reads */
 int tnv3_conv3x3_wino_has_stats(int variant);  /* 1 when `variant` (-1 = the default kernel) can emit BatchNorm batch statistics from its
                                                   epilogue (tnv3_conv3x3_wino_forward_stats), else 0 */
 int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, int layout, tnv3_stream_t stream);
@@ -116,10 +122,10 @@ int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* add
 
 /* Training-mode forward of a Conv2DBlock with the BatchNorm batch statistics taken in the convolution's epilogue (model.py:8-9):
  * dst = conv3x3(src, W) + addend (raw sums, kernel variants 3 / 4), and tile_stats[cout][tiles][2] (doubles) = per output channel and
- * pixel tile (4 x 64 pixels; tiles = tnv3_conv3x3_wino_stats_tiles(n, h, w)) the sum and the sum of squares of the values written --
+ * pixel tile (4 x 64 pixels, variant 6: 4 x 32; tiles = tnv3_conv3x3_wino_stats_tiles(n, h, w, variant)) the sum and the sum of squares of the values written --
  * reduced inside the kernel by a wave butterfly and a fixed-order fold, so the statistics cost no pass over dst.  Feed them to
  * tnv3_bn_train_forward_tiles. */
-long tnv3_conv3x3_wino_stats_tiles(int n, int h, int w);
+long tnv3_conv3x3_wino_stats_tiles(int n, int h, int w, int variant);
 int tnv3_conv3x3_wino_forward_stats(const float* src, const float* u, const float* addend, float* dst, double* tile_stats, int n, int cin,
                                     int cout, int h, int w, int variant, tnv3_stream_t stream);
 

@@ -35,6 +35,9 @@ def main():
         gf = 2.0 * 16 * cin * cout * (h // 2) * (w // 2) * 10 / 1e9
         row, ref = {}, None
         for v in variants:
+            if v in (6,) or 100 <= v < 110:
+                if cout % 128 or cin <= 8:
+                    continue
             u = ops.pack_wino_weights(wt, variant=v)      # the panel layout follows the kernel
             if v >= 10:                   # experimental arms live in libtnv3_diag.so (raw convolution, no affine)
                 y = torch.empty(10, cout, h, w, device=dev)

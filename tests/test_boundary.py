@@ -38,7 +38,7 @@ def test_abi_has_no_process_wide_state_and_no_wrong_result_kernels():
     # every entry point either takes a stream (enqueues work) or is a pure size / capability query
     for name in declared:
         proto = re.search(r"\b" + name + r"\s*\(([^;]*)\);", header, re.S).group(1)
-        is_query = name.endswith(("_bytes", "_floats", "_supported", "_num_configs", "_config_info", "_layout", "_has_stats", "_stats_tiles", "abi_version", "last_error"))
+        is_query = name.endswith(("_bytes", "_floats", "_supported", "_num_configs", "_config_info", "_layout", "_has_stats", "_pick", "_stats_tiles", "abi_version", "last_error"))
         assert ("tnv3_stream_t" in proto) != is_query, name
     assert not [n for n in declared if n.endswith("_variant") or "diag" in n or "probe" in n]
     exported = subprocess.run(["nm", "-D", "--defined-only", _build.build()], capture_output=True, text=True, check=True).stdout

@@ -370,10 +370,10 @@ def test_conv3x3_wino_balanced_kernel_is_bit_identical_to_the_xi_split_kernel(em
     x, wt = torch.relu(T((n, cin, h, w), 91)), T((cout, cin, 3, 3), 92, -0.3, 0.3)
     u = ops.pack_wino_weights(wt, variant=2)
     want = ops.conv3x3_wino(x, u, cout, variant=2)
-    assert ops.wino_layout(3) == 0 and ops.wino_layout(4) == 1
+    assert ops.wino_layout(3, cin, cout) == 0 and ops.wino_layout(4, cin, cout) == 1
     assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=3))
     assert torch.equal(want, ops.conv3x3_wino(x, ops.pack_wino_weights(wt, variant=4), cout, variant=4))      # quad operand layouts
-    assert ops.wino_layout(5) == 0
+    assert ops.wino_layout(5, cin, cout) == 0
     assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=5))                                         # persistent workgroups
 
 
@@ -405,6 +405,66 @@ def test_conv3x3_wino_persistent_kernel_walks_several_tiles_per_workgroup(emu, m
     monkeypatch.setenv("TNV3_EMU_CUS", "8")
     assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=5))
     assert torch.equal(want_full, ops.conv3x3_wino(x, u, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=5))
+
+
+# variant 6 (kernels/conv3x3_wino6_mfma.h): 128 output channels x (4 x 32 pixels) per workgroup, A operand from the layout-2 panel.
+# Cases: several tiles per persistent workgroup (8 emulated CUs), 2 / 3 / many chunks, a ragged last chunk (Cin % 8 != 0), two
+# channel blocks, W = 32 (one tile column) and the XCD-aware / generic block maps.
+WINO6_CASES = [(2, 16, 128, 8, 64), (1, 24, 128, 12, 96), (3, 20, 256, 4, 32), (1, 64, 128, 8, 128), (2, 12, 384, 8, 32)]
+
+
+@pytest.mark.parametrize("case", WINO6_CASES)
+def test_conv3x3_wino_128_channel_kernel_is_bit_identical_to_the_streaming_kernel(emu, monkeypatch, case):
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = case
+    x, wt = torch.relu(T((n, cin, h, w), 191)), T((cout, cin, 3, 3), 192, -0.3, 0.3)
+    mean, scale, shift, add = T((cout,), 193), T((cout,), 194, 0.5, 1.5), T((cout,), 195), T((n, cout, h, w), 196)
+    assert ops.wino_variant(-1, cin, cout) == 6 and ops.wino_layout(-1, cin, cout) == 2 and ops.wino_layout(6, cin, cout) == 2
+    assert ops.wino_variant(-1, cin, 64) == 5 and ops.wino_variant(-1, 8, cout) == 5 and ops.wino_variant(3, cin, cout) == 3
+    u3, u6 = ops.pack_wino_weights(wt, variant=3), ops.pack_wino_weights(wt, variant=6)
+    assert u3.numel() == u6.numel() and not torch.equal(u3, u6)
+    assert torch.equal(u3.sort().values, u6.sort().values)                      # the same numbers in another order
+    want = ops.conv3x3_wino(x, u3, cout, variant=3) if w % 64 == 0 else None
+    want_full = ops.conv3x3_wino(x, u3, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=3) if w % 64 == 0 else None
+    if want is None:                                                             # W % 64 != 0: variants 2-5 do not take the shape; fp64 torch then
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
+    for cus in ("8", "256"):
+        monkeypatch.setenv("TNV3_EMU_CUS", cus)
+        got = ops.conv3x3_wino(x, u6, cout, variant=6)
+        got_full = ops.conv3x3_wino(x, u6, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=6)
+        if want is not None:
+            assert torch.equal(want, got) and torch.equal(want_full, got_full)
+            assert torch.equal(got, ops.conv3x3_wino(x, ops.pack_wino_weights(wt), cout))     # and -1 picks it
+        else:
+            assert (got.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+            full = torch.relu((ref + add.double() - mean.double()[None, :, None, None]) * scale.double()[None, :, None, None]
+                              + shift.double()[None, :, None, None])
+            assert (got_full.double() - full).abs().max().item() <= 3e-6 * max(full.abs().max().item(), ref.abs().max().item())
+
+
+def test_conv3x3_wino_128_channel_kernel_statistics_and_data_gradient_pack(emu, monkeypatch):
+    """Variant 6's epilogue statistics (tiles of 4 x 32 pixels) sum to the same per-channel totals as variant 5's (4 x 64), and the
+    transposed / flipped layout-2 panel (the data gradient's filter) gives the data gradient of the convolution."""
+    from tracknetv3_amd import ops
+    monkeypatch.setenv("TNV3_EMU_CUS", "8")
+    n, cin, cout, h, w = 2, 16, 128, 8, 64
+    x, wt = torch.relu(T((n, cin, h, w), 291)), T((cout, cin, 3, 3), 292, -0.3, 0.3)
+    add = T((n, cout, h, w), 293)
+    z5, s5 = ops.conv3x3_wino_stats(x, ops.pack_wino_weights(wt, variant=5), cout, addend=add, variant=5)
+    z6, s6 = ops.conv3x3_wino_stats(x, ops.pack_wino_weights(wt, variant=6), cout, addend=add, variant=6)
+    assert torch.equal(z5, z6) and s6.shape[1] == 2 * s5.shape[1]
+    assert torch.allclose(s5.sum(1), s6.sum(1), rtol=1e-13, atol=1e-12)
+    ref = torch.stack((z6.double().sum((0, 2, 3)), (z6.double() ** 2).sum((0, 2, 3))), 1)
+    assert torch.allclose(s6.sum(1), ref, rtol=1e-12, atol=1e-10)
+    # data gradient of a 128 -> 16 ... no: of a layer with 128 INPUT channels (dX has 128 channels = the kernel's "Cout")
+    cin2, cout2 = 128, 24
+    w2, dz = T((cout2, cin2, 3, 3), 294, -0.3, 0.3), T((n, cout2, h, w), 295)
+    assert ops.wino_variant(-1, cout2, cin2) == 6
+    dx = ops.conv3x3_wino(dz, ops.pack_wino_weights(w2, transpose_flip=True), cin2)
+    xd = torch.zeros((n, cin2, h, w), dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xd, w2.double(), padding=1).backward(dz.double())
+    assert (dx.double() - xd.grad).abs().max().item() <= 3e-6 * xd.grad.abs().max().item()
+    assert torch.equal(dx, ops.conv3x3_wino(dz, ops.pack_wino_weights(w2, transpose_flip=True, variant=3), cin2, variant=3))
 
 
 def test_inpaintnet_fused_kernel_emulated_vs_layer_kernels_and_oracle(emu, monkeypatch):

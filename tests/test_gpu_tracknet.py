@@ -83,13 +83,46 @@ def test_conv3x3_wino_vs_torch(monkeypatch, gpu_device, case, variant):
     assert e_plain <= 4e-6 and e_full <= 8e-6, (e_plain, e_full)
 
 
+WINO6_GPU_CASES = [(2, 16, 128, 8, 64), (1, 24, 128, 12, 96), (3, 20, 256, 4, 32), (2, 64, 128, 144, 256), (2, 256, 256, 72, 128),
+                   (10, 512, 512, 36, 64), (1, 128, 256, 72, 128)]
+
+
+@pytest.mark.parametrize("case", WINO6_GPU_CASES)
+def test_conv3x3_wino_128_channel_kernel_vs_torch_and_streaming_kernel(gpu_device, case):
+    """Variant 6 (kernels/conv3x3_wino6_mfma.h): against fp64 torch, bit-identical to variant 5 wherever 5 takes the shape (plain,
+    affine + addend + ReLU, and the statistics epilogue), and what `variant` -1 picks for Cout % 128 == 0."""
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = case
+    d = gpu_device
+    x, wt = torch.relu(T((n, cin, h, w), 191)).to(d), T((cout, cin, 3, 3), 192, -0.3, 0.3).to(d)
+    mean, scale, shift, add = T((cout,), 193).to(d), T((cout,), 194, 0.5, 1.5).to(d), T((cout,), 195).to(d), T((n, cout, h, w), 196).to(d)
+    assert ops.wino_variant(-1, cin, cout) == 6
+    u6 = ops.pack_wino_weights(wt, variant=6)
+    got = ops.conv3x3_wino(x, u6, cout, variant=6)
+    got_full = ops.conv3x3_wino(x, u6, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=6)
+    if n * cin * cout * h * w <= 2 * 256 * 256 * 72 * 128:
+        ref = F.conv2d(x.double().cpu(), wt.double().cpu(), padding=1)
+        s = ref.abs().max().item()
+        assert (got.cpu().double() - ref).abs().max().item() <= 4e-6 * s
+    if w % 64 == 0:
+        u5 = ops.pack_wino_weights(wt, variant=5)
+        assert torch.equal(got, ops.conv3x3_wino(x, u5, cout, variant=5))
+        assert torch.equal(got_full, ops.conv3x3_wino(x, u5, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=5))
+        z5, s5 = ops.conv3x3_wino_stats(x, u5, cout, addend=add, variant=5)
+        z6, s6 = ops.conv3x3_wino_stats(x, u6, cout, addend=add, variant=6)
+        assert torch.equal(z5, z6) and torch.allclose(s5.sum(1), s6.sum(1), rtol=1e-12, atol=1e-9)
+        assert torch.equal(got, ops.conv3x3_wino(x, ops.pack_wino_weights(wt), cout))            # -1 picks variant 6 and its layout
+    for _ in range(2):                                                                            # run-to-run identical
+        assert torch.equal(got_full, ops.conv3x3_wino(x, u6, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=6))
+
+
 def test_wino_pack_view(gpu_device):
     _pack_view_case(gpu_device)
 
 
 def test_wino_default_is_the_library_default(gpu_device):
     from tracknetv3_amd import tuning
-    assert tuning.WINO_VARIANT == -1               # -1: the library's default (variant 3)
+    assert tuning.WINO_VARIANT == -1               # -1: the library's default (variant 6 for Cout % 128 == 0 and Cin > 8, else 5)
 
 
 def test_pool_head_pack(gpu_device):

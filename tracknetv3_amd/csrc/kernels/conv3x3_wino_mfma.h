@@ -515,14 +515,24 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_split_mfma_kernel(const 
 // U[Cin_pad][xi = i*4+j][Cout] = (G g G^T)[i][j] from W[Cout][Cin][3][3]; rows ci >= Cin are zero
 // The filter of logical (co, ci) starts at w + co * s_co + ci * s_ci; flip reads its taps back to front (the data
 // gradient's filter w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw] is s_co = 9, s_ci = Cin_w * 9, flip = 1 on the same tensor).
-// layout 0: U[ci][xi][Cout];  layout 1 ("quad", conv3x3_wino3_mfma.h): U[ci / 2][xi / 4][ci % 2][Cout][xi % 4] (CinPad even)
+// layout 0: U[ci][xi][Cout];  layout 1 ("quad", conv3x3_wino3_mfma.h): U[ci / 2][xi / 4][ci % 2][Cout][xi % 4] (CinPad even);
+// layout 2 (conv3x3_wino6_mfma.h: the A operand in the order its lanes load it, Cout % 32 == 0, CinPad % 8 == 0):
+//   U[co / 32][ci / 8][xi / 8][q = (ci % 8 / 2) * 2 + (xi % 8) / 4][lane = (ci % 2) * 32 + co % 32][xi % 4]
 inline __global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad, long s_co,
                                          long s_ci, int flip, int layout) {
   const long body = (long)CinPad * 16 * Cout, total = body + kPackZeroTail;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     if (e >= body) { u[e] = 0.0f; continue; }
     int co, xi, ci;
-    if (layout == 1) {
+    if (layout == 2) {
+      const int j = (int)(e & 3), ln = (int)((e >> 2) & 63), q = (int)((e >> 8) & 7), g = (int)((e >> 11) & 1);
+      const long rest = e >> 12;                          // mb32 * (CinPad / 8) + chunk
+      const int nch = CinPad / 8;
+      const int k = (int)(rest % nch), mb32 = (int)(rest / nch);
+      ci = 8 * k + 2 * (q >> 1) + (ln >> 5);
+      xi = 8 * g + 4 * (q & 1) + j;
+      co = 32 * mb32 + (ln & 31);
+    } else if (layout == 1) {
       const int x = (int)(e & 3);
       co = (int)((e >> 2) % Cout);
       const long t = (e >> 2) / Cout;                     // ((pair * 4 + row) * 2 + parity)

@@ -11,6 +11,7 @@
 #include "kernels/dgrad_up2x_wino_mfma.h"
 #include "kernels/conv3x3_wino_mfma.h"
 #include "kernels/conv3x3_wino3_mfma.h"
+#include "kernels/conv3x3_wino6_mfma.h"
 #include "kernels/conv1d_k3.h"
 #include "kernels/conv1d_mfma.h"
 #include "kernels/inpaint_fused.h"
@@ -367,7 +368,11 @@ int bn_train_forward_impl(Launcher& L, const float* z, const float* gamma, const
 
 // Training-mode BatchNorm whose batch statistics were taken in the producing convolution's epilogue (tnv3_conv3x3_wino_forward_stats):
 // tile_stats [C][n_tiles][2] doubles -> fixed-order sums per channel, then exactly bn_train_forward's finalize + apply.
-inline long conv3x3_wino_stats_tiles(int n, int h, int w) { return (n <= 0 || h % 4 || w % 64) ? 0 : (long)n * (h / 4) * (w / 64); }
+// pixel tiles per channel in the statistics buffer: 4 x 64 pixels (variants 3-5) or 4 x 32 (variant 6)
+inline long conv3x3_wino_stats_tiles(int n, int h, int w, int variant = 5) {
+  const int pw = variant == 6 ? 32 : 64;
+  return (n <= 0 || h % 4 || w % pw) ? 0 : (long)n * (h / 4) * (w / pw);
+}
 
 template <class Launcher>
 int bn_train_forward_tiles_impl(Launcher& L, const float* z, const double* tile_stats, long n_tiles, const float* gamma, const float* beta,
@@ -419,12 +424,17 @@ using WinoV5 = WinoV3Cfg<8>;                // persistent workgroups, the chunk 
 // persistent launch: one workgroup per CU, a whole number of XCD rounds so that a workgroup's tiles all map to its XCD
 inline int wino_persistent_grid(int items) { const int g = std::max(8, num_cus() / 8 * 8); return items < g ? items : g; }
 // filter pack layout a kernel variant expects (tnv3_conv3x3_wino_layout)
-inline int conv3x3_wino_layout(int variant) { return (variant == 4 || variant == 47 || variant == 44) ? 1 : 0; }
+inline int conv3x3_wino_layout(int variant) { return (variant == 6 || (variant >= 100 && variant < 110)) ? 2 : ((variant == 4 || variant == 47 || variant == 44) ? 1 : 0); }
 // kernel variants whose epilogue can emit the BatchNorm batch statistics (tnv3_conv3x3_wino_has_stats)
-inline bool conv3x3_wino_has_stats(int variant) { return variant == 3 || variant == 4 || variant == 5; }
+inline bool conv3x3_wino_has_stats(int variant) { return variant == 3 || variant == 4 || variant == 5 || variant == 6; }
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
-constexpr int kWinoDefaultVariant = 5;       // per-call `variant`: 5 streaming persistent kernel (default), 3 WinoV3, 2 WinoSplit, 4 WinoV4 (quad
-                                             // layouts), 5 WinoV5 (persistent), 0 WinoA (one wave / SIMD); -1 = default
+constexpr int kWinoDefaultVariant = 5;       // per-call `variant`: 5 streaming persistent kernel, 6 its 128-channel form with the filter operand
+                                             // straight from L2 (conv3x3_wino6_mfma.h), 3 WinoV3, 2 WinoSplit, 4 WinoV4 (quad layouts),
+                                             // 0 WinoA (one wave / SIMD); -1 = conv3x3_wino_pick(cin, cout)
+static_assert(kWinoCinPad == kWinoCinPadK, "conv3x3_wino6_mfma.h carries its own copy of the filter row padding");
+// What `variant` -1 means for a layer: by CHANNEL counts only, so that a filter panel packed ahead of the first forward (its
+// layout follows the variant) is the one every later call of that layer reads, whatever the image size.
+inline int conv3x3_wino_pick(int cin, int cout) { return (cout % WinoV6Cfg<>::MB == 0 && cin > WinoV6Cfg<>::CC) ? 6 : kWinoDefaultVariant; }
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
   return (size_t)round_up(cin, kWinoCinPad) * 16 * cout + kPackZeroTail;
@@ -438,9 +448,10 @@ inline bool conv3x3_wino_supported(int cin, int cout, int h, int w) {
 template <class Launcher>
 int conv3x3_wino_pack_view_impl(Launcher& L, const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip,
                                 int layout = 0) {
-  if (!w || !u || cout_w <= 0 || cin_w <= 0 || c_from < 0 || c_count <= 0 || c_from + c_count > cin_w || layout < 0 || layout > 1)
+  if (!w || !u || cout_w <= 0 || cin_w <= 0 || c_from < 0 || c_count <= 0 || c_from + c_count > cin_w || layout < 0 || layout > 2)
     TNV3_FAIL(-1, "conv3x3_wino_pack: bad argument");
   const int cout = transpose_flip ? c_count : cout_w, cin = transpose_flip ? cout_w : c_count;
+  if (layout == 2 && cout % 32) TNV3_FAIL(-1, "conv3x3_wino_pack: layout 2 needs Cout %% 32 == 0 (got %d)", cout);
   const long s_w_co = (long)cin_w * 9, s_w_ci = 9;
   const int cpad = round_up(cin, kWinoCinPad);
   const long total = (long)cpad * 16 * cout + kPackZeroTail;
@@ -457,15 +468,39 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant = -1,
                               double* stats = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino: bad argument");
-  if (variant < 0) variant = kWinoDefaultVariant;
+  if (variant < 0) variant = conv3x3_wino_pick(cin, cout);
   if (stats && !conv3x3_wino_has_stats(variant)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3, 4 and 5");
   if (stats && (scale || shift || mean)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue writes the raw convolution (no affine)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino: statistics buffer must be 8-byte aligned");
-  if (!conv3x3_wino_supported(cin, cout, h, w))
+  const bool is_v6 = variant == 6 || (variant >= 100 && variant < 110);
+  if (is_v6 ? (h % 4 != 0) : !conv3x3_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino: inconsistent affine arguments");
   const float* zeros = u + (size_t)round_up(cin, kWinoCinPad) * 16 * cout;
   WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats};
+  if (is_v6) {     // 128 channels x (4 x 32 pixels) per workgroup, filters packed with layout 2
+    using V6 = WinoV6Cfg<>;
+    if (cout % V6::MB || w % V6::PW || cin <= V6::CC)
+      TNV3_FAIL(-1, "conv3x3_wino (variant 6): needs Cout %% %d == 0, W %% %d == 0, Cin > %d (got %d -> %d, %dx%d)", V6::MB, V6::PW, V6::CC, cin, cout, h, w);
+    if ((long)cin * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variant 6): one sample of the input must stay below 2 GiB");
+    if ((long)V6::MB * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variant 6): 128 output planes must stay below 2 GiB");
+    if ((((uintptr_t)a.scale | (uintptr_t)a.shift | (uintptr_t)a.mean | (uintptr_t)a.u) & 15) != 0)
+      TNV3_FAIL(-1, "conv3x3_wino (variant 6): filters / mean / scale / shift must be 16-byte aligned");
+    const long npt6 = (long)n * (h / 4) * (w / V6::PW);
+    if (npt6 > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino: too many pixel tiles");
+    const int grid6 = wino_persistent_grid(conv_grid_blocks(cout / V6::MB, (int)npt6));
+#ifdef TNV3_DIAG
+    switch (variant) {                // timing twins (wrong results by design): no patch transform / no raw DMA / none of the three / no A loads
+      case 100: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<10>>, grid6, V6::NT, a);
+      case 101: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<11>>, grid6, V6::NT, a);
+      case 103: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<13>>, grid6, V6::NT, a);
+      case 104: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<14>>, grid6, V6::NT, a);
+      default: break;
+    }
+#endif
+    if (variant != 6) TNV3_FAIL(-1, "conv3x3_wino: unknown kernel variant %d", variant);
+    return L.launch(conv3x3_wino_a128_stream_kernel<V6>, grid6, V6::NT, a);
+  }
   const long npt = (long)n * (h / 4) * (w / WinoA::PW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino: too many pixel tiles");
 #ifdef TNV3_DIAG

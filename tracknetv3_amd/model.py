@@ -71,7 +71,8 @@ class Conv2DBlock(nn.Module):
 
     def packed_wino(self, c_from=0):
         """Winograd-domain filters G w G^T of input channels c_from.. (the whole layer, or the skip half of a decoder entry)."""
-        key = ("wino", int(c_from), ops.wino_layout())          # the panel layout follows the kernel variant in use
+        # the panel layout follows the kernel variant in use, which follows the channel counts of the (sub-)layer
+        key = ("wino", int(c_from), ops.wino_layout(None, self.conv.in_dim - int(c_from), self.conv.out_dim))
         ver = self._versions(["conv"])
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
@@ -82,7 +83,7 @@ class Conv2DBlock(nn.Module):
 
     def packed_wino_t(self, c_from=0):
         """Winograd-domain filters of the data gradient: G w' G^T with w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw]."""
-        key = ("wino_t", int(c_from), ops.wino_layout())
+        key = ("wino_t", int(c_from), ops.wino_layout(None, self.conv.out_dim, self.conv.in_dim - int(c_from)))      # dgrad: Cout -> c_count channels
         ver = self._versions(["conv"])
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:

@@ -57,21 +57,31 @@ def wino_supported(cin, cout, h, w):
     return bool(_lib.load().tnv3_conv3x3_wino_supported(int(cin), int(cout), int(h), int(w)))
 
 
-def wino_layout(variant=None):
-    """Filter pack layout the Winograd kernel `variant` reads (None: tuning.WINO_VARIANT)."""
+def wino_variant(variant, cin, cout):
+    """The kernel variant a call with `variant` (None: tuning.WINO_VARIANT) runs for a cin -> cout layer: -1 is resolved by the
+    library from the CHANNEL counts only (tnv3_conv3x3_wino_pick), so the panel packed for a layer fits every image size."""
     if variant is None:
         from . import tuning
         variant = tuning.WINO_VARIANT
-    return int(_lib.load().tnv3_conv3x3_wino_layout(int(variant)))
+    variant = int(variant)
+    return int(_lib.load().tnv3_conv3x3_wino_pick(int(cin), int(cout))) if variant < 0 else variant
+
+
+def wino_layout(variant, cin, cout):
+    """Filter pack layout the Winograd kernel `variant` (None / -1: the default for cin -> cout) reads."""
+    return int(_lib.load().tnv3_conv3x3_wino_layout(wino_variant(variant, cin, cout)))
 
 
 def wino_variant_has_stats(variant=None):
-    """Whether the Winograd kernel `variant` (None: tuning.WINO_VARIANT; -1 = the library's default, resolved there) can emit
-    the BatchNorm batch statistics from its epilogue."""
+    """Whether the Winograd kernel `variant` (None: tuning.WINO_VARIANT; -1 = the library's defaults -- both of them, 5 and 6) can
+    emit the BatchNorm batch statistics from its epilogue."""
     if variant is None:
         from . import tuning
         variant = tuning.WINO_VARIANT
-    return bool(_lib.load().tnv3_conv3x3_wino_has_stats(int(variant)))
+    lib = _lib.load()
+    if int(variant) < 0:
+        return all(bool(lib.tnv3_conv3x3_wino_has_stats(int(lib.tnv3_conv3x3_wino_pick(ci, co)))) for ci, co in ((64, 64), (128, 128)))
+    return bool(lib.tnv3_conv3x3_wino_has_stats(int(variant)))
 
 
 def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False, variant=None):
@@ -80,13 +90,13 @@ def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False, vari
     w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] instead (the packed panel then maps Cout -> c_count channels).
     variant: the kernel the panel is for (its layout follows; None: tuning.WINO_VARIANT)."""
     lib = _lib.load()
-    layout = wino_layout(variant)
     _f32(weight)
     weight = weight.contiguous()
     _lib.dev_check(weight)
     cout_w, cin_w = int(weight.shape[0]), int(weight.shape[1])
     c_count = cin_w - int(c_from) if c_count is None else int(c_count)
     cout, cin = (c_count, cout_w) if transpose_flip else (cout_w, c_count)
+    layout = wino_layout(variant, cin, cout)
     u = torch.empty(lib.tnv3_conv3x3_wino_packed_floats(cin, cout), dtype=torch.float32, device=weight.device)
     _lib.check(lib.tnv3_conv3x3_wino_pack_view(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count,
                                                int(bool(transpose_flip)), layout, _lib.stream_ptr(weight)))
@@ -107,9 +117,7 @@ def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, ad
     if addend is not None and tuple(addend.shape) != tuple(out.shape):
         raise _lib.Tnv3Error("conv3x3_wino: addend must have the output's shape")
     if n:
-        if variant is None:
-            from . import tuning
-            variant = tuning.WINO_VARIANT
+        variant = wino_variant(variant, cin, cout)
         _lib.check(lib.tnv3_conv3x3_wino_forward(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(mean), _lib.ptr(scale),
                                                  _lib.ptr(shift), _lib.ptr(out), n, cin, int(cout), h, w, int(bool(relu)),
                                                  int(variant), _lib.stream_ptr(src)))
@@ -123,10 +131,8 @@ def conv3x3_wino_stats(src, u, cout, addend=None, variant=None):
     _f32(src, u, addend)
     _lib.dev_check(src, u, addend)
     n, cin, h, w = (int(v) for v in src.shape)
-    if variant is None:
-        from . import tuning
-        variant = tuning.WINO_VARIANT
-    tiles = int(lib.tnv3_conv3x3_wino_stats_tiles(n, h, w))
+    variant = wino_variant(variant, cin, cout)
+    tiles = int(lib.tnv3_conv3x3_wino_stats_tiles(n, h, w, variant))
     if tiles <= 0 or u.numel() != lib.tnv3_conv3x3_wino_packed_floats(cin, int(cout)):
         raise _lib.Tnv3Error("conv3x3_wino_stats: unsupported shape or filter buffer mismatch")
     out = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=src.device)
