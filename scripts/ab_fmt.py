@@ -10,4 +10,4 @@ for line in sys.stdin:
         if "amdgpu.ids" not in line:
             print(line.strip())
         continue
-    print(key, " ".join(f"{v}:{d[v]['ms']}" for v in d))
+    print(key, " ".join(f"{v}:{d[v]['ms']}{'' if d[v].get('bit_equal_to_first', True) else '(DIFF)'}" for v in d))

@@ -35,7 +35,7 @@ def main():
         gf = 2.0 * 16 * cin * cout * (h // 2) * (w // 2) * 10 / 1e9
         row, ref = {}, None
         for v in variants:
-            if v in (6,) or 100 <= v < 110:
+            if v in (6,) or 100 <= v < 120:
                 if cout % 128 or cin <= 8:
                     continue
             u = ops.pack_wino_weights(wt, variant=v)      # the panel layout follows the kernel

@@ -34,8 +34,14 @@
 
 namespace tnv3 {
 
-template <int CC_, int DIAG_ = 0, int DMA_MODE_ = 0, int PRIO_ = 0, int QUAD_ = 0, int SYM_ = 0, int PERSIST_ = 0>
+template <int CC_, int DIAG_ = 0, int DMA_MODE_ = 0, int PRIO_ = 0, int QUAD_ = 0, int SYM_ = 0, int PERSIST_ = 0, int SWAP_ = 0>
 struct WinoV3Cfg {
+  // Streaming kernel only.  Which wave group runs its MFMAs FIRST in a chunk: 0 = group 1 (waves 4-7), 1 = group 0 (waves 0-3) -- the
+  // OLDER waves of each SIMD, which the matrix pipe's arbitration favours (69 : 31, kernels/coissue_probe.h) when two MFMA streams
+  // compete.  Round 3's timeline of the 128-channel kernel (profiles/r03_wino6_timeline*.json) showed that with the younger waves
+  // first, their MFMA phase is stretched by the late-starting older waves' MFMAs until BOTH end together -- and the first group's
+  // patch transform then runs with the pipe idle; with the older waves first they finish early and transform under the others' MFMAs.
+  static constexpr int SWAP = SWAP_;
   // 1: persistent workgroups (variant 5).  The launch has one workgroup per CU and each walks the tile list with the grid as its
   // stride (same XCD as the one-tile-per-workgroup launch gives that tile).  One workgroup fills a CU (512 threads x 256
   // registers, 150 KB of LDS), so nothing of a tile's fixed cost -- workgroup launch, index set-up, 128 accumulator writes,
@@ -798,7 +804,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_stream_mfma_kernel(const
         dma_r(n_x + x_step, Cin - CC, vo_rn, sc);
       }
     };
-    if (grp == 0) {                                     // group 0: patch reads, DMAs, transform, MFMAs;  group 1: MFMAs, then the same
+    if (grp == Cfg::SWAP) {                             // transform-first group: patch reads, DMAs, transform, MFMAs;  the other: MFMAs, then the same
       if (ahead) transform_read(sn);
       __builtin_amdgcn_sched_barrier(0);
       dmas();

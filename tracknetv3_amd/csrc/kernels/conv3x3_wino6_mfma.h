@@ -31,8 +31,18 @@ namespace tnv3 {
 
 constexpr int kWinoCinPadK = 24;     // = kWinoCinPad (tnv3_impl.h): packed filter rows are padded to a multiple of 24 input channels
 
-template <int DIAG_ = 0>
+template <int DIAG_ = 0, int SWAP_ = 0, int PRIO_ = 0, int QB_ = 0, int ALATE_ = 0>
 struct WinoV6Cfg {
+  // 1: "quad" V layout V[c][transform row R][tile][4] (the four xi of a row adjacent): ONE conflict-free ds_read_b128 feeds the B
+  // operand of four MFMAs (8 instead of 32 LDS reads inside a wave's MFMA phase) and the transform stores a tile's row as one
+  // ds_write_b128.  Every accumulator still sees its channel pairs in the same order => the same bits.
+  static constexpr int QB = QB_;
+  // 1: the eight A loads of the next chunk are issued in one burst right BEHIND the wave's MFMA phase instead of inside it.
+  static constexpr int ALATE = ALATE_;
+  // Which wave group runs its MFMAs FIRST in a chunk (the other one starts with the patch transform): 0 = group 1 (waves 4-7),
+  // 1 = group 0 (waves 0-3, the OLDER waves of a SIMD, which the matrix pipe's arbitration favours when two MFMA streams compete).
+  static constexpr int SWAP = SWAP_;
+  static constexpr int PRIO = PRIO_;                 // > 0: the MFMA-first group raises its priority (s_setprio) for its MFMA phase
   static constexpr int DIAG = DIAG_;                 // timing twins (WRONG results; libtnv3_diag.so): 10 no patch transform, 11 no raw DMA,
                                                      // 14 no A loads in the chunk loop, 13 none of the three
   static constexpr int WM = 4, WN = 1, CC = 8;
@@ -123,7 +133,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
   const int rowA = tR == 0 ? 0 : (tR == 2 ? 2 : 1), rowB = tR == 0 ? 2 : (tR == 1 ? 2 : (tR == 2 ? 1 : 3));     // e = d[rowA] -/+ d[rowB]
   const int t_srcA = t_c * RAWP + (2 * t_tr + rowA) * RW + 4 * t_pj;     // 16-byte aligned
   const int t_srcB = t_c * RAWP + (2 * t_tr + rowB) * RW + 4 * t_pj;
-  const int t_dst = t_c * VC + (tR * 4) * TB + t_tr * (TB / 2) + 2 * t_pj;
+  const int t_dst = Cfg::QB ? t_c * VC + tR * (TB * 4) + (t_tr * (TB / 2) + 2 * t_pj) * 4       // [c][R][tile][4]
+                            : t_c * VC + (tR * 4) * TB + t_tr * (TB / 2) + 2 * t_pj;
   typedef float wf2 __attribute__((ext_vector_type(2)));
   float txa[6], txb[6];
   auto transform_read = [&](int stage) {                // patch columns 4pj+3 .. 4pj+8 of the two raw rows this transform row needs
@@ -147,6 +158,14 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
       for (int j = 0; j < 6; ++j) e[j] = txa[j] - txb[j];
     }
     float* v = v_s + stage * Cfg::V_FLOATS + t_dst;
+    if constexpr (Cfg::QB) {                              // the four xi of this row, tile 2pj then tile 2pj + 1: two 16-byte stores
+      f32x4 o4;
+      o4[0] = e[0] - e[2]; o4[1] = e[1] + e[2]; o4[2] = e[2] - e[1]; o4[3] = e[1] - e[3];
+      *reinterpret_cast<f32x4*>(v) = o4;
+      o4[0] = e[2] - e[4]; o4[1] = e[3] + e[4]; o4[2] = e[4] - e[3]; o4[3] = e[3] - e[5];
+      *reinterpret_cast<f32x4*>(v + 4) = o4;
+      return;
+    }
     wf2 o;
     o[0] = e[0] - e[2]; o[1] = e[2] - e[4]; *reinterpret_cast<wf2*>(v + 0 * TB) = o;
     o[0] = e[1] + e[2]; o[1] = e[3] + e[4]; *reinterpret_cast<wf2*>(v + 1 * TB) = o;
@@ -158,7 +177,7 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
   f32x16 zero16;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
-  const int b_off = half * VC + (grp * 8) * TB + bl;
+  const int b_off = Cfg::QB ? half * VC + (2 * grp) * (TB * 4) + bl * 4 : half * VC + (grp * 8) * TB + bl;
   // One chunk of MFMAs: step s = (channel pair cp, xi x of this group); A from registers, B from the V stage four steps ahead.
   // Right behind the four MFMAs that consumed a quad, its registers are re-loaded with the NEXT chunk's quad from `anext` (always a
   // valid address: the last chunk of the last tile re-reads its own -- unconditional loads keep the MFMA stream one basic block).
@@ -166,6 +185,35 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
     constexpr bool FIRST = decltype(first_c)::value;
     const float* B = v_s + stage * Cfg::V_FLOATS + b_off;
     constexpr int NSTEP = (CC / 2) * 8;
+    if constexpr (Cfg::QB) {                              // step s = (cp, x): B quad (cp, x >> 2) = one 16-byte read, two quads ahead
+      f32x4 bq[3];
+      auto read_quad = [&](int qd) { bq[qd % 3] = *reinterpret_cast<const f32x4*>(B + (2 * (qd >> 1)) * VC + (qd & 1) * (TB * 4)); };
+      read_quad(0);
+      read_quad(1);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const int q = (s >> 3) * 2 + ((s & 7) >> 2);
+        if ((s & 3) == 0 && q + 2 < 8) {
+          read_quad(q + 2);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][s & 3], bq[q % 3][s & 3], FIRST && s < 8 ? zero16 : acc[s & 7], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if ((s & 3) == 3) {
+          if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13 && !Cfg::ALATE) {
+            load_a(anext, q);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        }
+      }
+      if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13 && Cfg::ALATE) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) load_a(anext, q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     constexpr int PF = 4, RING = PF + 1;
     float bv[RING];
     auto read_step = [&](int s) {
@@ -184,18 +232,24 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if ((s & 3) == 3) {
-        if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13) {
+        if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13 && !Cfg::ALATE) {
           load_a(anext, q);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
       }
+    }
+    if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13 && Cfg::ALATE) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) load_a(anext, q);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // End of a chunk: this wave's raw piece has landed (it is OLDER than the A loads the wave issued inside its MFMA stream when the
   // wave is of group 0 -- patch reads, DMA, transform, MFMAs -- so eight loads may stay in flight; group 1 issues its DMA last),
   // its V writes are done, and everybody has finished with the old stages.
   auto chunk_barrier = [&]() {
-    if (grp == 0) __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(8));
+    if (grp == Cfg::SWAP) __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(8));
     else __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
     __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
     __builtin_amdgcn_s_barrier();
@@ -206,6 +260,17 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
     __builtin_amdgcn_s_barrier();
   };
 
+  // DIAG 7: s_memtime phase totals of one mid-grid workgroup (results stay correct; totals behind the N-th image of dst)
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+  auto stamp = [&](int slot) {
+    if constexpr (Cfg::DIAG == 7) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      t_acc[slot] += now - t_last;
+      t_last = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   int gs = 0;                                          // chunks done so far: the current chunk uses stage gs & 1
   const float* pa;                                     // A one chunk ahead / raw tile two chunks ahead, inside the current tile
   const float* px;
@@ -223,26 +288,44 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
       else if constexpr (WHERE == 1) { if (have_next) dma_r(n_x, Cin, vo_rn, sc); }
       else if (have_next) dma_r(n_x + x_step, Cin - CC, vo_rn, sc);
     };
-    if (grp_v == 0) {                                   // group 0: patch reads, DMA, transform, MFMAs;  group 1: MFMAs, then the same
+    stamp(0);
+    if (grp_v == Cfg::SWAP) {                           // transform-first group: patch reads, DMA, transform, MFMAs;  the other: MFMAs, then the same
       if (ahead) transform_read(sn);
       __builtin_amdgcn_sched_barrier(0);
       dma();
       __builtin_amdgcn_sched_barrier(0);
+      stamp(1);
       if (ahead) transform_finish(sn);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(2);
       mfma_chunk(sc, first_c, anext);
+      stamp(3);
     } else {
+      if constexpr (Cfg::PRIO > 0) __builtin_amdgcn_s_setprio(Cfg::PRIO);
       mfma_chunk(sc, first_c, anext);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (Cfg::PRIO > 0) __builtin_amdgcn_s_setprio(0);
+      stamp(1);
       if (ahead) transform_read(sn);
       __builtin_amdgcn_sched_barrier(0);
       dma();
       __builtin_amdgcn_sched_barrier(0);
+      stamp(2);
       if (ahead) transform_finish(sn);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(3);
     }
     pa += a_step; px += x_step; px_left -= CC;
-    chunk_barrier();
+    if constexpr (Cfg::DIAG == 7) {
+      if (grp == Cfg::SWAP) __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(8));
+      else __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+      __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+      stamp(4);
+      __builtin_amdgcn_s_barrier();
+      stamp(5);
+    } else {
+      chunk_barrier();
+    }
     ++gs;
   };
   typedef std::integral_constant<int, 0> in_tile_t;
@@ -258,6 +341,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
   transform_read(0);
   transform_finish(0);
   full_barrier();
+  if constexpr (Cfg::DIAG == 7) t_last = __builtin_amdgcn_s_memtime();
+  int n_tiles_done = 0;
   for (;;) {                                            // one pass per tile
     pa = c_a + a_step; px = c_x + 2 * x_step; px_left = Cin - 2 * CC;
     if (nChunks == 2) {
@@ -269,6 +354,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
     }
     chunk_body(std::false_type{}, last_t{});
     wino3_writeout<Cfg, true, true>(a, acc, xch_s, xch_s + 4 * 32 * 64, c_n, c_h0, c_w0, c_m0, c_pt, nPT, []() {});
+    stamp(6);
+    ++n_tiles_done;
     if (!have_next) break;
     c_n = n_n; c_h0 = n_h0; c_w0 = n_w0; c_m0 = n_m0; c_pt = n_pt; c_a = n_a; c_x = n_x;
     vo_r = vo_rn;
@@ -278,6 +365,15 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
     n_a = a_base(n_m0);
     n_x = a.src + (size_t)n_n * Cin * HW;
     if (have_next) vo_rn = raw_offset(n_h0, n_w0);
+    stamp(7);
+  }
+  if constexpr (Cfg::DIAG == 7) {                       // [wave][10]: six chunk phases, write-out, tile advance, chunks, tiles
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dst + (size_t)a.N * Cout * HW) + wave * 10;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = t_acc[i];
+      o[8] = (unsigned long long)gs; o[9] = (unsigned long long)n_tiles_done;
+    }
   }
 }
 

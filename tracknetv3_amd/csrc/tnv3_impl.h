@@ -420,11 +420,12 @@ using WinoA = WinoCfg<2, 2, 8>;              // 64 channels x 64 tiles (4 x 64 p
 using WinoSplit = WinoSplitCfg<8>;          // same tile, 512 threads: two wave groups split the 16 transform rows (2 waves / SIMD)
 using WinoV3 = WinoV3Cfg<8>;                // same tile and operands as WinoSplit; balanced DMA issue, buffer-descriptor DMA, paired transform
 using WinoV4 = WinoV3Cfg<8, 0, 0, 0, 1>;    // + quad operand layouts (filter pack layout 1): 0.5 instead of 2 LDS reads per MFMA
-using WinoV5 = WinoV3Cfg<8>;                // persistent workgroups, the chunk pipeline running through the tile boundaries (conv3x3_wino_stream_mfma_kernel)
+using WinoV5 = WinoV3Cfg<8, 0, 0, 0, 0, 0, 0, 1>;   // persistent workgroups, the chunk pipeline running through the tile boundaries
+                                                     // (conv3x3_wino_stream_mfma_kernel); the older waves (group 0) run their MFMAs first
 // persistent launch: one workgroup per CU, a whole number of XCD rounds so that a workgroup's tiles all map to its XCD
 inline int wino_persistent_grid(int items) { const int g = std::max(8, num_cus() / 8 * 8); return items < g ? items : g; }
 // filter pack layout a kernel variant expects (tnv3_conv3x3_wino_layout)
-inline int conv3x3_wino_layout(int variant) { return (variant == 6 || (variant >= 100 && variant < 110)) ? 2 : ((variant == 4 || variant == 47 || variant == 44) ? 1 : 0); }
+inline int conv3x3_wino_layout(int variant) { return (variant == 6 || (variant >= 100 && variant < 120)) ? 2 : ((variant == 4 || variant == 47 || variant == 44) ? 1 : 0); }
 // kernel variants whose epilogue can emit the BatchNorm batch statistics (tnv3_conv3x3_wino_has_stats)
 inline bool conv3x3_wino_has_stats(int variant) { return variant == 3 || variant == 4 || variant == 5 || variant == 6; }
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
@@ -472,14 +473,14 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
   if (stats && !conv3x3_wino_has_stats(variant)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3, 4 and 5");
   if (stats && (scale || shift || mean)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue writes the raw convolution (no affine)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino: statistics buffer must be 8-byte aligned");
-  const bool is_v6 = variant == 6 || (variant >= 100 && variant < 110);
+  const bool is_v6 = variant == 6 || (variant >= 100 && variant < 120);
   if (is_v6 ? (h % 4 != 0) : !conv3x3_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino: inconsistent affine arguments");
   const float* zeros = u + (size_t)round_up(cin, kWinoCinPad) * 16 * cout;
   WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats};
   if (is_v6) {     // 128 channels x (4 x 32 pixels) per workgroup, filters packed with layout 2
-    using V6 = WinoV6Cfg<>;
+    using V6 = WinoV6Cfg<0, 1>;          // production: the older waves (group 0) run their MFMAs first (profiles/r03_wino6_*)
     if (cout % V6::MB || w % V6::PW || cin <= V6::CC)
       TNV3_FAIL(-1, "conv3x3_wino (variant 6): needs Cout %% %d == 0, W %% %d == 0, Cin > %d (got %d -> %d, %dx%d)", V6::MB, V6::PW, V6::CC, cin, cout, h, w);
     if ((long)cin * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variant 6): one sample of the input must stay below 2 GiB");
@@ -495,6 +496,20 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
       case 101: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<11>>, grid6, V6::NT, a);
       case 103: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<13>>, grid6, V6::NT, a);
       case 104: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<14>>, grid6, V6::NT, a);
+      case 107: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<7>>, grid6, V6::NT, a);     // timeline (dst needs N + 1 images)
+      // schedule experiments (results correct): 106 the YOUNGER waves (group 1) run their MFMAs first (6 has the older ones first);
+      // 108 = 6 + raised priority in that MFMA phase; 109 = 106 + raised priority in group 1's MFMA phase; 105 = timeline of 6, 107 of 106
+      case 106: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 0>>, grid6, V6::NT, a);     // the YOUNGER waves first (round 3's first form)
+      case 108: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 2>>, grid6, V6::NT, a);
+      case 109: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 0, 2>>, grid6, V6::NT, a);
+      case 105: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<7, 1>>, grid6, V6::NT, a);
+      // 102: 6 + quad B reads;  110 = 6 + A loads behind the MFMA phase;  111 = 6 + both;  112 = 111 + priority;  113 = timeline of 111
+      // (all measured slower than 6: profiles/r03_wino6_variants_ab.json)
+      case 102: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 0, 1, 0>>, grid6, V6::NT, a);
+      case 110: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 0, 0, 1>>, grid6, V6::NT, a);
+      case 111: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 0, 1, 1>>, grid6, V6::NT, a);
+      case 112: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 2, 1, 1>>, grid6, V6::NT, a);
+      case 113: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<7, 1, 0, 1, 1>>, grid6, V6::NT, a);
       default: break;
     }
 #endif
@@ -556,6 +571,8 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     // 86: the first persistent form (per-tile prologue kept, next tile's first DMAs issued before the output transform), timed like 85
     case 86: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 8, 0, 0, 0, 0, 1>>, wino_persistent_grid(grid3), WinoV3::NT, a);
     case 56: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3Cfg<8, 0, 0, 0, 0, 0, 1>>, wino_persistent_grid(grid3), WinoV3::NT, a);
+    case 57: if (cin <= WinoV3::CC) break;             // the streaming kernel with the YOUNGER waves (group 1) running their MFMAs first (round 2's order)
+             return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV3Cfg<8, 0, 0, 0, 0, 0, 0, 0>>, wino_persistent_grid(grid3), WinoV3::NT, a);
     default: break;
   }
 #endif
