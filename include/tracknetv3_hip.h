@@ -229,6 +229,29 @@ size_t tnv3_inpaintnet_packed_floats(void);
 int tnv3_inpaintnet_pack(const float* const* weights9, const float* const* biases9, float* packed, tnv3_stream_t stream);
 int tnv3_inpaintnet_fused_forward(const float* x, const float* m, const float* packed, float* out, int n, int l, tnv3_stream_t stream);
 
+/* An InpaintNet training step's forward + backward (train.py:147-166 through model.py:113-129) in THREE launches
+ * (kernels/inpaint_fused_train.h) instead of ~35 per-layer ones:
+ *   tnv3_inpaintnet_fused_forward_train : the fused forward that also saves the eight hidden activations, acts [n][960][16]
+ *                                         (tnv3_inpaintnet_act_floats(n) floats; order x1, x2, x3, b1, b2, u1, u2, u3)
+ *   tnv3_inpaintnet_pack_t              : transposed, tap-flipped filters of the seven dense layers in lane order
+ *                                         (tnv3_inpaintnet_packed_t_floats() floats; weights9 as for tnv3_inpaintnet_pack)
+ *   tnv3_inpaintnet_fused_backward      : dout = dLoss/dOut [n][16][2], out = the forward's output -> grads
+ *                                         [tnv3_inpaintnet_param_floats() = 520 610] = the 18 parameter gradients in state_dict
+ *                                         order (weight, bias per layer; views into it are the .grad tensors).  dpre: caller-owned
+ *                                         scratch of tnv3_inpaintnet_dpre_floats(n) floats ([n][962][16], 16-byte aligned).  One
+ *                                         workgroup carries a sequence's gradient through all nine layers in LDS (MFMA 16x16x4);
+ *                                         one more launch forms every dW / db over the whole batch in a fixed order (deterministic).
+ * Same function as tnv3_conv1d_* backward kernels up to fp32 summation order. */
+size_t tnv3_inpaintnet_packed_t_floats(void);
+size_t tnv3_inpaintnet_act_floats(int n);
+size_t tnv3_inpaintnet_dpre_floats(int n);
+size_t tnv3_inpaintnet_param_floats(void);
+int tnv3_inpaintnet_pack_t(const float* const* weights9, float* packed_t, tnv3_stream_t stream);
+int tnv3_inpaintnet_fused_forward_train(const float* x, const float* m, const float* packed, float* out, float* acts, int n, int l,
+                                        tnv3_stream_t stream);
+int tnv3_inpaintnet_fused_backward(const float* x, const float* m, const float* dout, const float* out, const float* acts,
+                                   const float* packed, const float* packed_t, float* dpre, float* grads, int n, int l, tnv3_stream_t stream);
+
 /* ---- heat-map post-process (predict.py:14-69,163-209; test.py:25-79) ------------------------------------- */
 
 /* Temporal ensemble in closed form (predict.py:163-209 heat maps, 243-301 coordinates).

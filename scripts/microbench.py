@@ -48,13 +48,6 @@ def main():
             out[f"inpaintnet_fwd_n{n}_{tag}"] = {"ms": round(ms, 4), "seq_per_s": round(n / ms * 1e3, 1), "tflops": round(16.63e6 * n / ms / 1e9, 2)}
     inpaint_ops.FUSED = "auto"
     x, m = torch.rand(32, 16, 2, device=dev), (torch.rand(32, 16, 1, device=dev) < 0.3).float()
-    g = net.graphed(32)
-    g.x.copy_(x); g.m.copy_(m)
-    same = bool(torch.equal(g.replay(), net(x, m)))
-    ms = timeit(g.replay, 50, dev)
-    out["inpaintnet_fwd_n32_hip_graph"] = {"ms": round(ms, 4), "seq_per_s": round(32 / ms * 1e3, 1), "equal_to_eager": same}
-    ms = timeit(lambda: g(x, m), 50, dev)
-    out["inpaintnet_fwd_n32_hip_graph_with_input_copies"] = {"ms": round(ms, 4)}
     hm = torch.zeros(80, 288, 512, device=dev)
     hm[:, 100:106, 200:207] = 0.9
     hm[::3, 20:23, 400:404] = 0.8

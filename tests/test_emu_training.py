@@ -322,6 +322,55 @@ def test_inpaintnet_train_step_emulated_vs_reference_golden(emu):
     torch.nn.utils.clip_grad_norm_(net.parameters(), 1)          # train.py:165 works on the leaf parameters
 
 
+def _inpaint_train_grads(net, coor, mask, gt):
+    for p in net.parameters():
+        p.grad = None
+    out = net(coor * (1 - mask), mask)
+    torch.nn.MSELoss()(out * mask, gt * mask).backward()
+    return out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+
+def test_inpaintnet_fused_training_kernels_vs_layer_kernels_and_fp64_autograd(emu, monkeypatch):
+    """The three-launch training step (kernels/inpaint_fused_train.h: forward that saves activations, one fused data-gradient
+    kernel, one launch for every dW / db) against the per-layer kernels and against fp64 autograd of the oracle, on a ragged batch
+    with more sequences than workgroups (8 emulated CUs -> 16 workgroups, 19 sequences: some carry two)."""
+    from tracknetv3_amd import inpaint_ops
+    from tracknetv3_amd.model import InpaintNet
+    monkeypatch.setenv("TNV3_EMU_CUS", "8")
+    sd = nets.synth_state(nets.inpaintnet_state_shapes(), 79)
+    net = InpaintNet()
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    n, L = 19, 16
+    coor, gt = nets.synth_input((n, L, 2), 601), nets.synth_input((n, L, 2), 602)
+    mask = (nets.synth_input((n, L, 1), 603) < 0.4).float()
+    monkeypatch.setattr(inpaint_ops, "FUSED_TRAIN", "1")
+    out_f, g_f = _inpaint_train_grads(net, coor, mask, gt)
+    monkeypatch.setattr(inpaint_ops, "FUSED_TRAIN", "0")
+    out_l, g_l = _inpaint_train_grads(net, coor, mask, gt)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    o64 = nets.inpaintnet_forward(sd64, (coor * (1 - mask)).double(), mask.double())
+    (((o64 - gt.double()) * mask.double()) ** 2).mean().backward()
+    assert (out_f - out_l).abs().max().item() <= 2e-6 and (out_f.double() - o64.detach()).abs().max().item() <= 2e-6
+    for name in g_f:
+        ref = sd64[name].grad
+        s = ref.abs().max().item()
+        assert (g_f[name].double() - ref).abs().max().item() <= 2e-5 * s + 1e-10, name
+        assert (g_l[name].double() - ref).abs().max().item() <= 2e-5 * s + 1e-10, name
+    # deterministic: a second fused step gives the same bits; and the transposed pack follows in-place weight updates
+    monkeypatch.setattr(inpaint_ops, "FUSED_TRAIN", "1")
+    _, g_f2 = _inpaint_train_grads(net, coor, mask, gt)
+    assert all(torch.equal(g_f[k], g_f2[k]) for k in g_f)
+    with torch.no_grad():
+        net.up_2.conv.weight.mul_(1.25)
+        net.down_3.conv.bias.add_(0.05)
+    _, g_new = _inpaint_train_grads(net, coor, mask, gt)
+    monkeypatch.setattr(inpaint_ops, "FUSED_TRAIN", "0")
+    _, g_new_l = _inpaint_train_grads(net, coor, mask, gt)
+    for name in g_new:
+        assert rel_err(g_new[name], g_new_l[name]) <= 2e-5, name
+
+
 def test_head_sigmoid_wbce_fused_both_directions_emulated(emu):
     """sigmoid + WBCELoss fused into the head: the one-pass forward equals head -> WBCELoss, and the backward without a dP tensor
     equals wbce_backward -> head_backward (same element arithmetic)."""

@@ -152,26 +152,6 @@ def test_inpaintnet_forward(gpu_device):
     assert (net(c2.to(gpu_device), m2.int().to(gpu_device)).cpu() - ref).abs().max().item() <= 2e-6
 
 
-def test_inpaintnet_hip_graph_replay(gpu_device):
-    """InpaintNet.graphed(n): the eval forward captured in a HIP graph equals the eager forward bit for bit, follows new
-    inputs and in-place weight updates, and refuses a training-mode module."""
-    from tracknetv3_amd.model import InpaintNet
-    net = InpaintNet()
-    net.load_state_dict(nets.synth_state(nets.inpaintnet_state_shapes(), 77), strict=True)
-    net = net.to(gpu_device)
-    with pytest.raises(ValueError):
-        net.train().graphed(32)
-    net.eval()
-    g = net.graphed(32)
-    for seed in (1, 2):
-        x = nets.synth_input((32, 16, 2), 600 + seed).to(gpu_device)
-        m = (nets.synth_input((32, 16, 1), 700 + seed) < 0.3).float().to(gpu_device)
-        assert torch.equal(g(x, m), net(x, m))
-    with torch.no_grad():
-        net.predictor.bias.add_(0.25)
-    assert torch.equal(g.replay(), net(x, m))
-
-
 @pytest.mark.parametrize("case", CONV1D_MFMA_CASES + [(4099, 256, 128, 128, 1), (70000, 32, 0, 64, 1)])
 def test_conv1d_mfma_vs_torch(gpu_device, case):
     assert _conv1d_case(*case, gpu_device) <= 3e-6
@@ -220,6 +200,38 @@ def test_inpaintnet_train_step_vs_reference_golden(gpu_device):
     for name, prm in net2.named_parameters():
         ref = sd64[name].grad
         assert (prm.grad.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-10, name
+
+
+@pytest.mark.parametrize("n", [32, 300])
+def test_inpaintnet_fused_training_kernels_vs_layer_kernels_and_fp64_autograd(gpu_device, monkeypatch, n):
+    """The three-launch training step (kernels/inpaint_fused_train.h) at the README batch and at a batch with more sequences than
+    workgroup slots x 0.5: equal to the per-layer kernels and to fp64 autograd of the oracle to fp32 summation order; run-to-run identical."""
+    from test_emu_training import _inpaint_train_grads
+    from tracknetv3_amd import inpaint_ops
+    from tracknetv3_amd.model import InpaintNet
+    sd = nets.synth_state(nets.inpaintnet_state_shapes(), 79)
+    net = InpaintNet()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(gpu_device).train()
+    L = 16
+    coor, gt = nets.synth_input((n, L, 2), 601), nets.synth_input((n, L, 2), 602)
+    mask = (nets.synth_input((n, L, 1), 603) < 0.4).float()
+    cd, md, gd = coor.to(gpu_device), mask.to(gpu_device), gt.to(gpu_device)
+    monkeypatch.setattr(inpaint_ops, "FUSED_TRAIN", "1")
+    out_f, g_f = _inpaint_train_grads(net, cd, md, gd)
+    _, g_f2 = _inpaint_train_grads(net, cd, md, gd)
+    assert all(torch.equal(g_f[k], g_f2[k]) for k in g_f)
+    monkeypatch.setattr(inpaint_ops, "FUSED_TRAIN", "0")
+    out_l, g_l = _inpaint_train_grads(net, cd, md, gd)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    o64 = nets.inpaintnet_forward(sd64, (coor * (1 - mask)).double(), mask.double())
+    (((o64 - gt.double()) * mask.double()) ** 2).mean().backward()
+    assert (out_f - out_l).abs().max().item() <= 2e-6 and (out_f.cpu().double() - o64.detach()).abs().max().item() <= 2e-6
+    for name in g_f:
+        ref = sd64[name].grad
+        s = ref.abs().max().item()
+        assert (g_f[name].cpu().double() - ref).abs().max().item() <= 2e-5 * s + 1e-10, name
+        assert (g_l[name].cpu().double() - ref).abs().max().item() <= 2e-5 * s + 1e-10, name
 
 
 @pytest.mark.parametrize("eval_mode", ["weight", "average"])

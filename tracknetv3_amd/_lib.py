@@ -75,6 +75,13 @@ def _declare(lib):
     sig("tnv3_inpaintnet_packed_floats", sz)
     sig("tnv3_inpaintnet_pack", i, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), p, p)
     sig("tnv3_inpaintnet_fused_forward", i, p, p, p, p, i, i, p)
+    sig("tnv3_inpaintnet_packed_t_floats", sz)
+    sig("tnv3_inpaintnet_act_floats", sz, i)
+    sig("tnv3_inpaintnet_dpre_floats", sz, i)
+    sig("tnv3_inpaintnet_param_floats", sz)
+    sig("tnv3_inpaintnet_pack_t", i, _c.POINTER(_c.c_void_p), p, p)
+    sig("tnv3_inpaintnet_fused_forward_train", i, p, p, p, p, p, i, i, p)
+    sig("tnv3_inpaintnet_fused_backward", i, p, p, p, p, p, p, p, p, p, i, i, p)
     sig("tnv3_ensemble_frames", i, p, i, lg, i, i, p, lg, i, lg, i, p, p)
     sig("tnv3_peakfind_workspace_bytes", sz, i, i, i)
     sig("tnv3_heatmap_peakfind", i, p, f, i, p, p, sz, i, i, i, p)
@@ -114,6 +121,8 @@ def _declare(lib):
 EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "tnv3_conv3x3_config_info",
            "tnv3_conv3x3_packed_floats", "tnv3_pack_conv3x3_weights", "tnv3_bn_eval_scale", "tnv3_conv3x3_forward",
            "tnv3_head1x1_sigmoid", "tnv3_maxpool2x2", "tnv3_conv1d_k3_forward", "tnv3_inpaintnet_packed_floats", "tnv3_inpaintnet_pack", "tnv3_inpaintnet_fused_forward",
+           "tnv3_inpaintnet_packed_t_floats", "tnv3_inpaintnet_act_floats", "tnv3_inpaintnet_dpre_floats", "tnv3_inpaintnet_param_floats",
+           "tnv3_inpaintnet_pack_t", "tnv3_inpaintnet_fused_forward_train", "tnv3_inpaintnet_fused_backward",
            "tnv3_ensemble_frames",
            "tnv3_peakfind_workspace_bytes", "tnv3_heatmap_peakfind", "tnv3_bn_workspace_bytes", "tnv3_bn_train_forward",
            "tnv3_bn_relu_backward", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",

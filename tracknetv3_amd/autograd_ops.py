@@ -406,10 +406,45 @@ class _InpaintNetTrain(torch.autograd.Function):
         return tuple(out_g)
 
 
+class _InpaintNetFusedTrain(torch.autograd.Function):
+    """The same node as three launches: fused forward that saves the hidden activations, one fused data-gradient kernel (a sequence's
+    gradient stays in LDS through all nine layers) and one launch for every dW / db (csrc/kernels/inpaint_fused_train.h)."""
+
+    @staticmethod
+    def forward(ctx, net, x, m, *params):
+        from . import inpaint_ops
+        packed = inpaint_ops.packed_params(net)
+        out, acts = ops.inpaintnet_fused_train_forward(x, m, packed)
+        if hasattr(ctx, "save_for_backward"):
+            ctx.save_for_backward(out)
+        ctx.net, ctx.acts, ctx.inp, ctx.packed = net, acts, (x, m), packed
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import inpaint_ops
+        (out,) = ctx.saved_tensors
+        x, m = ctx.inp
+        flat = ops.inpaintnet_fused_backward(x, m, dout.contiguous().float(), out, ctx.acts, ctx.packed, inpaint_ops.packed_params_t(ctx.net))
+        grads, off = [None, None, None], 0
+        for shp in ctx.shapes:                                  # views into the flat buffer, in state_dict order (weight, bias per layer)
+            n = 1
+            for v in shp:
+                n *= v
+            grads.append(flat[off:off + n].view(shp))
+            off += n
+        ctx.acts = ctx.inp = ctx.packed = None
+        return tuple(grads)
+
+
 def inpaintnet_forward_train(net, x, m):
+    from . import inpaint_ops
     x = x.contiguous().float()
     m = m.contiguous().to(torch.float32)
     flat = []
     for wt, b in net.conv_params():
         flat += [wt, b]
+    if inpaint_ops.use_fused_train(int(x.shape[0]), int(x.shape[1])):
+        return _InpaintNetFusedTrain.apply(net, x, m, *flat)
     return _InpaintNetTrain.apply(net, x, m, *flat)

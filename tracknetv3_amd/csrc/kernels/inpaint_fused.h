@@ -79,13 +79,16 @@ inline __global__ void __launch_bounds__(256) inpaint_pack_kernel(const InpaintP
   }
 }
 
-// One dense layer for the workgroup's sequence.  src0 / src1: LDS activation rows of the two concatenated sources, dst: LDS
-// rows of the output.  BPW = channel blocks a wave works on at once (Cout / 64, at least 1).
-template <int C0, int C1, int COUT>
-__device__ __forceinline__ void if_dense_layer(const float* __restrict__ wp, const float* __restrict__ bias, const float* src0,
-                                               const float* src1, float* dst, int wave, int lane) {
+// One dense layer for the workgroup's sequence.  src0 / src1: LDS activation rows of the two concatenated sources; every output
+// element (channel co, position n) is handed to epi(co, n, value).  BPW = channel blocks a wave works on at once (ceil(Cout / 64)).
+template <int C0, int C1, int COUT, class Epi>
+__device__ __forceinline__ void if_dense_core(const float* __restrict__ wp, const float* src0, const float* src1, int wave, int lane_in, Epi&& epi) {
+  int lane = lane_in;
+  TNV3_OPAQUE_V(lane);        // every per-lane address of this layer is formed HERE, not hoisted to the top of the kernel and kept live
+                              // through all nine layers (the nine layers' filter / operand / epilogue addresses cost 60+ registers)
   constexpr int CIN = C0 + C1, NCH = 3 * CIN / 16, NB = COUT / 16, CPT = CIN / 16;     // chunks of 16 K; chunks per tap
-  constexpr int BPW = NB >= 4 ? NB / 4 : 1;                                           // blocks per wave
+  constexpr int BPW = (NB + 3) / 4;                                                   // blocks per wave (NB = 6: three waves x 2; NB = 2: two waves x 1)
+  static_assert(NB % BPW == 0, "the waves' block groups must tile the layer");
   constexpr int NACC = BPW == 1 ? 2 : BPW;                                            // BPW == 1: split K over two accumulators
   constexpr int RING = BPW >= 4 ? 2 : 3;                                              // filter chunks in flight per block
   static_assert(NCH % RING == 0 && C0 % 16 == 0 && C1 % 16 == 0, "layer shape");
@@ -139,21 +142,34 @@ __device__ __forceinline__ void if_dense_layer(const float* __restrict__ wp, con
   for (int b = 0; b < BPW; ++b) {
     const if_f32x4 r4 = BPW == 1 ? if_f32x4{acc[0][0] + acc[1][0], acc[0][1] + acc[1][1], acc[0][2] + acc[1][2], acc[0][3] + acc[1][3]} : acc[b];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = (wave * BPW + b) * 16 + 4 * kq + r;                              // D layout: row = 4 * (lane >> 4) + r, column = lane & 15
-      float v = r4[r] + bias[co];
-      v = v > 0.0f ? v : 0.01f * v;                                                   // LeakyReLU(0.01), model.py:81
-      dst[co * kIfRow + 1 + n] = v;
-    }
+    for (int r = 0; r < 4; ++r) epi((wave * BPW + b) * 16 + 4 * kq + r, n, r4[r]);     // D layout: row = 4 * (lane >> 4) + r, column = lane & 15
   }
+}
+
+// Forward layer: + bias, LeakyReLU(0.01) (model.py:81), rows of the output in LDS; gsave != nullptr: the activation also goes to
+// HBM as [COUT][16] (saved for the backward pass of a training step).
+template <int C0, int C1, int COUT>
+__device__ __forceinline__ void if_dense_layer(const float* __restrict__ wp, const float* __restrict__ bias, const float* src0,
+                                               const float* src1, float* dst, int wave, int lane, float* gsave = nullptr) {
+  if_dense_core<C0, C1, COUT>(wp, src0, src1, wave, lane, [&](int co, int n, float acc) {
+    float v = acc + bias[co];
+    v = v > 0.0f ? v : 0.01f * v;
+    dst[co * kIfRow + 1 + n] = v;
+    if (gsave) gsave[co * kIfL + n] = v;
+  });
 }
 
 constexpr int kIfRows = 4 + 32 + 64 + 128 + 256 + 256;                               // input(3, padded to 4), x1, x2, x3, ping, pong
 constexpr int kIfLdsFloats = kIfRows * kIfRow;
 
 // x [N][16][2], m [N][16][1] -> out [N][16][2]; grid-stride over sequences (one sequence per workgroup at a time)
+// acts != nullptr (training forward): the eight hidden activations of every sequence are also written to HBM,
+// acts[seq][kItActCh][16] in the order x1, x2, x3, b1, b2, u1, u2, u3 (inpaint_fused_train.h reads them in the backward pass).
+constexpr int kItActCh = 32 + 64 + 128 + 256 + 256 + 128 + 64 + 32;                 // 960
+constexpr int kItActOff[8] = {0, 32, 96, 224, 480, 736, 864, 928};
 inline __global__ void __launch_bounds__(256, 2) inpaintnet_fused_kernel(const float* __restrict__ x, const float* __restrict__ m,
-                                                                      const float* __restrict__ packed, float* __restrict__ out, int N) {
+                                                                      const float* __restrict__ packed, float* __restrict__ out, int N,
+                                                                      float* __restrict__ acts) {
   __shared__ __attribute__((aligned(16))) float lds[kIfLdsFloats];
   float* in0 = lds;
   float* x1 = in0 + 4 * kIfRow;
@@ -181,23 +197,27 @@ inline __global__ void __launch_bounds__(256, 2) inpaintnet_fused_kernel(const f
         for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
           for (int k = 0; k < 3; ++k) s = fmaf(w[(co * 3 + ci) * 3 + k], in0[ci * kIfRow + p + k], s);
-        x1[co * kIfRow + 1 + p] = s > 0.0f ? s : 0.01f * s;
+        s = s > 0.0f ? s : 0.01f * s;
+        x1[co * kIfRow + 1 + p] = s;
+        if (acts) acts[((size_t)seq * kItActCh + kItActOff[0] + co) * kIfL + p] = s;
       }
     }
+    float* ga = acts ? acts + (size_t)seq * kItActCh * kIfL : nullptr;
+    auto gs = [&](int i) -> float* { return ga ? ga + kItActOff[i] * kIfL : nullptr; };
     __syncthreads();
-    if_dense_layer<32, 0, 64>(packed + if_layer_offset(0), bias + kIfBiasAt[1], x1, x1, x2, wave, lane);
+    if_dense_layer<32, 0, 64>(packed + if_layer_offset(0), bias + kIfBiasAt[1], x1, x1, x2, wave, lane, gs(1));
     __syncthreads();
-    if_dense_layer<64, 0, 128>(packed + if_layer_offset(1), bias + kIfBiasAt[2], x2, x2, x3, wave, lane);
+    if_dense_layer<64, 0, 128>(packed + if_layer_offset(1), bias + kIfBiasAt[2], x2, x2, x3, wave, lane, gs(2));
     __syncthreads();
-    if_dense_layer<128, 0, 256>(packed + if_layer_offset(2), bias + kIfBiasAt[3], x3, x3, pa, wave, lane);
+    if_dense_layer<128, 0, 256>(packed + if_layer_offset(2), bias + kIfBiasAt[3], x3, x3, pa, wave, lane, gs(3));
     __syncthreads();
-    if_dense_layer<256, 0, 256>(packed + if_layer_offset(3), bias + kIfBiasAt[4], pa, pa, pb, wave, lane);
+    if_dense_layer<256, 0, 256>(packed + if_layer_offset(3), bias + kIfBiasAt[4], pa, pa, pb, wave, lane, gs(4));
     __syncthreads();
-    if_dense_layer<256, 128, 128>(packed + if_layer_offset(4), bias + kIfBiasAt[5], pb, x3, pa, wave, lane);      // cat([x, x3], 1)
+    if_dense_layer<256, 128, 128>(packed + if_layer_offset(4), bias + kIfBiasAt[5], pb, x3, pa, wave, lane, gs(5));      // cat([x, x3], 1)
     __syncthreads();
-    if_dense_layer<128, 64, 64>(packed + if_layer_offset(5), bias + kIfBiasAt[6], pa, x2, pb, wave, lane);        // cat([x, x2], 1)
+    if_dense_layer<128, 64, 64>(packed + if_layer_offset(5), bias + kIfBiasAt[6], pa, x2, pb, wave, lane, gs(6));        // cat([x, x2], 1)
     __syncthreads();
-    if_dense_layer<64, 32, 32>(packed + if_layer_offset(6), bias + kIfBiasAt[7], pb, x1, pa, wave, lane);         // cat([x, x1], 1)
+    if_dense_layer<64, 32, 32>(packed + if_layer_offset(6), bias + kIfBiasAt[7], pb, x1, pa, wave, lane, gs(7));         // cat([x, x1], 1)
     __syncthreads();
     if (tid < 32) {                                                                   // predictor 32 -> 2, sigmoid, permute back to [L][2]
       const float* w = packed + kIfHeadOff;

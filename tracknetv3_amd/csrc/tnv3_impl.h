@@ -15,6 +15,7 @@
 #include "kernels/conv1d_k3.h"
 #include "kernels/conv1d_mfma.h"
 #include "kernels/inpaint_fused.h"
+#include "kernels/inpaint_fused_train.h"
 #include "kernels/pointwise.h"
 #include "kernels/postproc.h"
 #include "kernels/preproc.h"
@@ -281,7 +282,47 @@ int inpaintnet_fused_forward_impl(Launcher& L, const float* x, const float* m, c
   if (l != kIfL) TNV3_FAIL(-1, "inpaintnet_fused_forward: built for sequences of %d positions (got %d)", kIfL, l);
   if (((uintptr_t)packed) & 15) TNV3_FAIL(-1, "inpaintnet_fused_forward: the packed parameters must be 16-byte aligned");
   const int cap = 2 * num_cus();                         // two resident workgroups per CU (59 KB of LDS each); grid-stride beyond
-  return L.launch(inpaintnet_fused_kernel, n < cap ? n : cap, 256, x, m, packed, out, n);
+  return L.launch(inpaintnet_fused_kernel, n < cap ? n : cap, 256, x, m, packed, out, n, (float*)nullptr);
+}
+
+// ---- InpaintNet training step in three launches (kernels/inpaint_fused_train.h)
+inline size_t inpaintnet_packed_t_floats() { return (size_t)kIfStemOff; }
+inline size_t inpaintnet_act_floats(int n) { return n <= 0 ? 0 : (size_t)n * kItActCh * kIfL; }
+inline size_t inpaintnet_dpre_floats(int n) { return n <= 0 ? 0 : (size_t)n * kItPreCh * kIfL; }
+inline size_t inpaintnet_param_floats() { return (size_t)kItParamFloats; }
+
+template <class Launcher>
+int inpaintnet_pack_t_impl(Launcher& L, const float* const* w9, float* packed_t) {
+  if (!w9 || !packed_t) TNV3_FAIL(-1, "inpaintnet_pack_t: bad argument");
+  InpaintPackTArgs a;
+  for (int i = 0; i < 7; ++i) {
+    if (!w9[i + 1]) TNV3_FAIL(-1, "inpaintnet_pack_t: layer %d has a NULL tensor", i + 1);
+    a.w[i] = w9[i + 1];
+  }
+  a.packed_t = packed_t;
+  return L.launch(inpaint_pack_t_kernel, (kIfStemOff + 255) / 256, 256, a);
+}
+
+template <class Launcher>
+int inpaintnet_fused_forward_train_impl(Launcher& L, const float* x, const float* m, const float* packed, float* out, float* acts, int n, int l) {
+  if (!x || !m || !packed || !out || !acts || n <= 0) TNV3_FAIL(-1, "inpaintnet_fused_forward_train: bad argument");
+  if (l != kIfL) TNV3_FAIL(-1, "inpaintnet_fused_forward_train: built for sequences of %d positions (got %d)", kIfL, l);
+  if (((uintptr_t)packed) & 15) TNV3_FAIL(-1, "inpaintnet_fused_forward_train: the packed parameters must be 16-byte aligned");
+  const int cap = 2 * num_cus();
+  return L.launch(inpaintnet_fused_kernel, n < cap ? n : cap, 256, x, m, packed, out, n, acts);
+}
+
+template <class Launcher>
+int inpaintnet_fused_backward_impl(Launcher& L, const float* x, const float* m, const float* dout, const float* out, const float* acts,
+                                   const float* packed, const float* packed_t, float* dpre, float* grads, int n, int l) {
+  if (!x || !m || !dout || !out || !acts || !packed || !packed_t || !dpre || !grads || n <= 0) TNV3_FAIL(-1, "inpaintnet_fused_backward: bad argument");
+  if (l != kIfL) TNV3_FAIL(-1, "inpaintnet_fused_backward: built for sequences of %d positions (got %d)", kIfL, l);
+  if ((((uintptr_t)packed | (uintptr_t)packed_t | (uintptr_t)acts | (uintptr_t)dpre) & 15) != 0)
+    TNV3_FAIL(-1, "inpaintnet_fused_backward: packed filters, activations and dPre must be 16-byte aligned");
+  const int cap = 2 * num_cus();
+  int rc = L.launch(inpaintnet_fused_dgrad_kernel, n < cap ? n : cap, 256, dout, out, acts, packed_t, packed, dpre, n);
+  if (rc) return rc;
+  return L.launch(inpaintnet_wgrad_all_kernel, kItWgBlocks, 256, x, m, acts, (const float*)dpre, grads, n);
 }
 
 template <class Launcher>

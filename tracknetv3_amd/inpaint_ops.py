@@ -25,6 +25,26 @@ def packed_params(net):
     return hit[1]
 
 
+def packed_params_t(net):
+    """The fused backward's transposed filter buffer, rebuilt when a weight changes (version counters)."""
+    params = net.conv_params()
+    key = tuple((w.data_ptr(), w._version) for w, _ in params)
+    hit = getattr(net, "_fused_pack_t", None)
+    if hit is None or hit[0] != key:
+        hit = (key, ops.inpaintnet_pack_t([w.detach() for w, _ in params]))
+        net._fused_pack_t = hit
+    return hit[1]
+
+
+# The training step's forward + backward as three launches (csrc/kernels/inpaint_fused_train.h) instead of ~35; TNV3_INPAINT_FUSED_TRAIN=0
+# (or another sequence length than 16) keeps the per-layer kernels.
+FUSED_TRAIN = os.environ.get("TNV3_INPAINT_FUSED_TRAIN", "1")
+
+
+def use_fused_train(n, seq_len):
+    return seq_len == 16 and FUSED_TRAIN != "0" and FUSED != "0"
+
+
 def use_fused(n, seq_len):
     return seq_len == 16 and FUSED != "0"
 
@@ -48,46 +68,3 @@ def inpaintnet_forward(net, x, m):
         y = ops.conv1d_k3(y, *p[6], src1=x2)
         y = ops.conv1d_k3(y, *p[7], src1=x1)
         return ops.conv1d_k3(y, *p[8], dst_nlc=True, act=ops.ACT_SIGMOID)   # predictor -> sigmoid -> permute
-
-
-class GraphedInpaintNet:
-    """The eval forward of an InpaintNet for ONE batch size, captured in a HIP graph: at the reference's batch of 32
-    sequences (README.md:162) the nine launches are launch-latency bound, and a replay costs one submission.  Inputs are
-    copied into the static buffers `x` / `m` (or written there directly by the caller), `replay()` returns the static
-    output.  The graph reads the parameters in place, so in-place weight updates (load_state_dict, an optimiser step) are
-    picked up; moving the module to another device or dtype needs a new capture."""
-
-    def __init__(self, net, n, device=None, seq_len=16):
-        if net.training:
-            raise ValueError("GraphedInpaintNet captures the eval forward: call net.eval() first")
-        dev = torch.device(device) if device is not None else next(net.parameters()).device
-        if dev.type != "cuda":
-            raise ValueError("HIP graphs need a GPU")
-        self.net = net
-        self.x = torch.zeros((int(n), int(seq_len), 2), dtype=torch.float32, device=dev)
-        self.m = torch.zeros((int(n), int(seq_len), 1), dtype=torch.float32, device=dev)
-        side = torch.cuda.Stream(dev)                      # warm-up off the default stream: first launches load code objects
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                inpaintnet_forward(net, self.x, self.m)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            if use_fused(int(n), int(seq_len)):
-                # the fused kernel reads a PACKED copy of the parameters: the pack launch is part of the graph, so that a replay
-                # follows in-place weight updates exactly like the eager forward (two kernels per replay)
-                params = net.conv_params()
-                packed = ops.inpaintnet_pack([w.detach() for w, _ in params], [b.detach() for _, b in params])
-                self.out = ops.inpaintnet_fused(self.x, self.m, packed)
-            else:
-                self.out = inpaintnet_forward(net, self.x, self.m)
-
-    def replay(self):
-        self.graph.replay()
-        return self.out
-
-    def __call__(self, x, m):
-        self.x.copy_(x)
-        self.m.copy_(m)
-        return self.replay()

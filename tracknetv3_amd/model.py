@@ -418,11 +418,6 @@ class InpaintNet(nn.Module):
                 self.buttleneck.conv_2.conv, self.up_1.conv, self.up_2.conv, self.up_3.conv, self.predictor]
         return [(m.weight, m.bias) for m in mods]
 
-    def graphed(self, n, seq_len=16):
-        """HIP-graph replay of the eval forward for batch size n (launch-bound sizes): inpaint_ops.GraphedInpaintNet."""
-        from . import inpaint_ops
-        return inpaint_ops.GraphedInpaintNet(self, n, seq_len=seq_len)
-
     def forward(self, x, m):
         if x.dim() != 3 or x.shape[2] != 2 or m.shape[:2] != x.shape[:2] or m.shape[2] != 1:
             raise ValueError(f"InpaintNet expects x (N,L,2) and m (N,L,1), got {tuple(x.shape)} / {tuple(m.shape)}")

@@ -370,6 +370,48 @@ def inpaintnet_fused(x, m, packed):
     return out
 
 
+def inpaintnet_pack_t(weights):
+    """Transposed, tap-flipped filters of the seven dense InpaintNet layers in lane order (tnv3_inpaintnet_pack_t), for the fused backward."""
+    lib = _lib.load()
+    if len(weights) != 9:
+        raise _lib.Tnv3Error("inpaintnet_pack_t: expected nine layers")
+    ws = [w.contiguous() for w in weights]
+    _f32(*ws)
+    _lib.dev_check(*ws)
+    packed_t = torch.empty(lib.tnv3_inpaintnet_packed_t_floats(), dtype=torch.float32, device=ws[0].device)
+    _lib.check(lib.tnv3_inpaintnet_pack_t(_ptr_array(ws), _lib.ptr(packed_t), _lib.stream_ptr(packed_t)))
+    return packed_t
+
+
+def inpaintnet_fused_train_forward(x, m, packed):
+    """The fused forward that also saves the hidden activations: (out (N, 16, 2), acts (N, 960, 16))."""
+    lib = _lib.load()
+    _f32(x, m, packed)
+    _lib.dev_check(x, m, packed)
+    n, l = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty((n, l, 2), dtype=torch.float32, device=x.device)
+    acts = torch.empty(lib.tnv3_inpaintnet_act_floats(max(n, 1)), dtype=torch.float32, device=x.device)
+    if n:
+        _lib.check(lib.tnv3_inpaintnet_fused_forward_train(_lib.ptr(x), _lib.ptr(m), _lib.ptr(packed), _lib.ptr(out), _lib.ptr(acts), n, l,
+                                                           _lib.stream_ptr(x)))
+    return out, acts
+
+
+def inpaintnet_fused_backward(x, m, dout, out, acts, packed, packed_t):
+    """All 18 parameter gradients of an InpaintNet step as ONE flat tensor in state_dict order (tnv3_inpaintnet_fused_backward)."""
+    lib = _lib.load()
+    _f32(x, m, dout, out, acts, packed, packed_t)
+    _lib.dev_check(x, m, dout, out, acts, packed, packed_t)
+    n, l = int(x.shape[0]), int(x.shape[1])
+    grads = torch.empty(lib.tnv3_inpaintnet_param_floats(), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return grads.zero_()
+    dpre = torch.empty(lib.tnv3_inpaintnet_dpre_floats(n), dtype=torch.float32, device=x.device)
+    _lib.check(lib.tnv3_inpaintnet_fused_backward(_lib.ptr(x), _lib.ptr(m), _lib.ptr(dout), _lib.ptr(out), _lib.ptr(acts), _lib.ptr(packed),
+                                                  _lib.ptr(packed_t), _lib.ptr(dpre), _lib.ptr(grads), n, l, _lib.stream_ptr(x)))
+    return grads
+
+
 def ensemble_frames(win, s_base, weight, t0, n_frames, num_sample, sum_order=None):
     """Temporal ensemble of global frames t0..t0+n_frames-1 from resident windows win[i] = window s_base+i.
     win: (n_local, L, *tail) -> out: (n_frames, *tail).  See tnv3_ensemble_frames.  sum_order (default: by the tail size, as
@@ -814,7 +856,7 @@ _TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "co
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
                "maxpool2x2_backward_add", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad",
-               "grad_norm", "adam_step", "sgd_step", "inpaintnet_pack"]          # list-of-tensor ops: the guard looks inside the lists
+               "grad_norm", "adam_step", "sgd_step", "inpaintnet_pack", "inpaintnet_pack_t", "inpaintnet_fused_train_forward", "inpaintnet_fused_backward"]          # list-of-tensor ops: the guard looks inside the lists
 for _name in _TENSOR_OPS:
     globals()[_name] = _lib.on_tensor_device(globals()[_name])
 del _name
