@@ -37,12 +37,16 @@ def packed_params_t(net):
 
 
 # The training step's forward + backward as three launches (csrc/kernels/inpaint_fused_train.h) instead of ~35; TNV3_INPAINT_FUSED_TRAIN=0
-# (or another sequence length than 16) keeps the per-layer kernels.
+# (or another sequence length than 16) keeps the per-layer kernels.  Measured at the README batch of 32 (bench.py `inpaintnet.train_n32`):
+# 1.06 -> 0.47 ms per step incl. the masked MSE, clip_grad_norm_ and Adam.  The all-layer weight-gradient launch walks the batch
+# sequentially per (16 x 16)-channel item -- right for training batches, wrong for huge ones (one fp32 chain over 600 000 sequences
+# loses 1e-3 and takes seconds), so batches beyond FUSED_TRAIN_MAX_BATCH use the per-layer kernels with their split reductions.
 FUSED_TRAIN = os.environ.get("TNV3_INPAINT_FUSED_TRAIN", "1")
+FUSED_TRAIN_MAX_BATCH = 4096
 
 
 def use_fused_train(n, seq_len):
-    return seq_len == 16 and FUSED_TRAIN != "0" and FUSED != "0"
+    return seq_len == 16 and FUSED_TRAIN != "0" and FUSED != "0" and 0 < n <= FUSED_TRAIN_MAX_BATCH
 
 
 def use_fused(n, seq_len):
