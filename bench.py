@@ -31,7 +31,7 @@ import torch  # noqa: E402
 SEQ_LEN, BG_MODE, H, W = 8, "concat", 288, 512
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (= fp32 vector peak)
 PEAK_HBM_GBPS = 8000.0
-KERNEL_SET = "wino_stream+up2x_wino+direct"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
+KERNEL_SET = "wino_a128+wino_stream+up2x_wino"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
 ALG_BYTES_PER_SAMPLE = 693.55e6    # ideal-fusion fp32 bytes of one 27->8 forward
 
 

@@ -149,12 +149,14 @@ int tnv3_conv_up2x_forward(const float* src_low, const float* wq, float* dst, in
  * 9 of the 16 Winograd GEMMs remain -- 9 multiply-adds per low-resolution pixel and channel pair instead of the 16 of the class
  * filters above (36 in the reference's direct form).  Persistent streaming kernel, output transform in registers.
  *   supported: c0 > 8, cout % 64 == 0, h_low % 2 == 0, w_low % 64 == 0.  u from tnv3_conv_up2x_wino_pack (the layer's
- *   nn.Conv2d weight, its first c0 input channels), 16-byte aligned.  Same function up to fp32 rounding. */
+ *   nn.Conv2d weight, its first c0 input channels), 16-byte aligned.  Same function up to fp32 rounding.
+ *   variant (also of tnv3_dgrad_up2x_wino): -1 / 0 = the older waves of each SIMD run their MFMA phase first (production), 1 = the
+ *   younger ones (round 2's order); bit-identical results, a scheduling choice only. */
 int tnv3_conv_up2x_wino_supported(int c0, int cout, int h_low, int w_low);
 size_t tnv3_conv_up2x_wino_packed_floats(int c0, int cout);
 int tnv3_conv_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, tnv3_stream_t stream);
 int tnv3_conv_up2x_wino_forward(const float* src_low, const float* u, float* dst, int n, int c0, int cout, int h_low, int w_low,
-                                tnv3_stream_t stream);
+                                int variant, tnv3_stream_t stream);
 
 /* Data gradient of that half-layer (autograd of nn.Upsample(scale_factor=2) -> Conv2d w.r.t. the low-res tensor), also at
  * the low resolution: dx_low[n][c0][h_low][w_low] = 4x4 stride-2 correlation of dz[n][cout][2*h_low][2*w_low] with the
@@ -172,7 +174,8 @@ int tnv3_dgrad_up2x(const float* dz, const float* g, float* dx_low, int n, int c
 int tnv3_dgrad_up2x_wino_supported(int c0, int cout, int h_low, int w_low);
 size_t tnv3_dgrad_up2x_wino_packed_floats(int c0, int cout);
 int tnv3_dgrad_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, tnv3_stream_t stream);
-int tnv3_dgrad_up2x_wino(const float* dz, const float* u, float* dx_low, int n, int c0, int cout, int h_low, int w_low, tnv3_stream_t stream);
+int tnv3_dgrad_up2x_wino(const float* dz, const float* u, float* dx_low, int n, int c0, int cout, int h_low, int w_low, int variant,
+                         tnv3_stream_t stream);
 
 /* Weight gradient of a plain layer (single source, no upsampling) in Winograd F(2x2, 3x3) form: dw[cout][cin][3][3] =
  * G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- 16 instead of 36 multiply-adds per (co, ci, 2x2 tile); same gradient as

@@ -8,7 +8,7 @@ import csv, json, sys, time
 def conv_sum(path, counter):
     tot, disp = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if any(k in r["kernel"] for k in ("conv3x3_mfma_kernel", "conv_up2x_mfma_kernel", "conv3x3_wino_mfma_kernel", "conv3x3_wino_split_mfma_kernel", "conv3x3_wino_v3_mfma_kernel", "conv3x3_wino_stream_mfma_kernel", "conv_up2x_wino_stream_kernel")) and r["counter"] == counter:
+        if any(k in r["kernel"] for k in ("conv3x3_mfma_kernel", "conv_up2x_mfma_kernel", "conv3x3_wino_mfma_kernel", "conv3x3_wino_split_mfma_kernel", "conv3x3_wino_v3_mfma_kernel", "conv3x3_wino_stream_mfma_kernel", "conv3x3_wino_a128_stream_kernel", "conv_up2x_wino_stream_kernel")) and r["counter"] == counter:
             tot += float(r["sum"]); disp += int(r["dispatches"])
     return tot, disp
 
@@ -24,9 +24,9 @@ def main():
     fetch = 2.0 * fetch_raw                       # MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes
     json.dump({
         "commit": sys.argv[5] if len(sys.argv) > 5 else None, "taken_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
-        "kernel_set": "wino_stream+up2x_wino+direct",
+        "kernel_set": "wino_a128+wino_stream+up2x_wino",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
-                  f"bench.py --steps {steps - 1} --warmup 1 --overlap-streams 0 --infer-split 0, MI355X (raw per-kernel sums: "
+                  f"bench.py --steps {steps - 1} --warmup 1 --blocks 1 --overlap-streams 0 --infer-split 0, MI355X (raw per-kernel sums: "
                   "the two CSVs given on the command line; made by scripts/conv_traffic.py)",
         "counters_unit": "KiB (x1024 bytes)", "conv_launches_per_step": launches,
         "fetch_size_raw_bytes_per_step": round(fetch_raw, -6), "fetch_size_corrected_bytes_per_step": round(fetch, -6),
@@ -34,7 +34,7 @@ def main():
         "correction": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled; WRITE_SIZE "
                       "agrees with the known 3.020e9 output bytes per step to -1.6 %",
         "traffic_bytes_per_launch": round((fetch + write) / launches, -5),
-        "algorithmic_bytes_per_step": 6510000000.0,
+        "algorithmic_bytes_per_step": 6935500000.0,          # 693.55 MB per sample x 10
         "note": "includes the partial-sum tensors the decoder-entry layers write and re-read; the kernels are MFMA-bound "
                 "(under 0.6 TB/s of the 8 TB/s HBM roof), so traffic is not the limiter",
     }, open(out, "w"), indent=1)

@@ -35,6 +35,10 @@ def main():
         lowpix = n * hl * wl
         row["stride2_4x4"] = {"ms": round(t_a, 4), "executed_tflops": round(2.0 * 16 * c0 * cout * lowpix / t_a / 1e9, 1)}
         row["one_gemm_k9"] = {"ms": round(t_b, 4), "executed_tflops": round(2.0 * 9 * c0 * cout * lowpix / t_b / 1e9, 1)}
+        b1 = ops.dgrad_up2x_wino(dz, u, c0, variant=1)                        # round 2's group order (younger waves' MFMAs first)
+        t_c = min(timeit(lambda: ops.dgrad_up2x_wino(dz, u, c0, variant=1)) for _ in range(2))
+        t_b2 = min(timeit(lambda: ops.dgrad_up2x_wino(dz, u, c0)) for _ in range(2))
+        row["one_gemm_k9_younger_first"] = {"ms": round(t_c, 4), "bit_equal": bool(torch.equal(b, b1)), "older_first_ms_again": round(t_b2, 4)}
         out[f"{c0}<-{cout}@{hl}x{wl}"] = row
         print(f"{c0}<-{cout}@{hl}x{wl}", json.dumps(row), flush=True)
     json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "dgrad_up2x_ab.json"), "w"), indent=1)

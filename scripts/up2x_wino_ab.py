@@ -36,6 +36,10 @@ def main():
         lowpix = n * hl * wl
         row["class_filters"] = {"ms": round(t_a, 4), "executed_tflops": round(2.0 * 16 * c0 * cout * lowpix / t_a / 1e9, 1)}
         row["winograd_9_of_16"] = {"ms": round(t_b, 4), "executed_tflops": round(2.0 * 9 * c0 * cout * lowpix / t_b / 1e9, 1)}
+        b1 = ops.conv_up2x_wino(xl, u, cout, variant=1)                       # round 2's group order (younger waves' MFMAs first)
+        t_c = min(timeit(lambda: ops.conv_up2x_wino(xl, u, cout, variant=1)) for _ in range(2))
+        t_b2 = min(timeit(lambda: ops.conv_up2x_wino(xl, u, cout)) for _ in range(2))
+        row["winograd_9_of_16_younger_first"] = {"ms": round(t_c, 4), "bit_equal": bool(torch.equal(b, b1)), "older_first_ms_again": round(t_b2, 4)}
         out[f"{c0}->{cout}@{hl}x{wl}"] = row
         print(f"{c0}->{cout}@{hl}x{wl}", json.dumps(row), flush=True)
     json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "up2x_wino_ab.json"), "w"), indent=1)

@@ -39,6 +39,8 @@ struct ConvUp2xWinoArgs {
   const float* u;      // [round_up(C0, 8)][9][Cout]   U' (conv_up2x_wino_pack_kernel)
   float* dst;          // [N][Cout][2 Hl][2 Wl]   partial sums
   int N, C0, Cout, Hl, Wl;
+  int first;           // the wave group that runs its MFMAs FIRST in a chunk (the other one starts with DMAs + transform): 0 = the older
+                       // waves of each SIMD (production, see WinoV3Cfg::SWAP), 1 = round 2's order
 };
 
 // w[Cout][Cin][3][3] (the first c0 input channels) -> u[c0pad][9][Cout], xi = 3 * a + b over transform rows / columns (0, 1, 3).
@@ -231,7 +233,7 @@ inline __global__ void __launch_bounds__(ConvUp2xWinoCfg::NT) conv_up2x_wino_str
         dma_r(n_x + x_step, C0 - CC, vo_rn, sc);
       }
     };
-    if (grp == 0) {                                     // group 0: DMAs, transform, MFMAs;  group 1: MFMAs, DMAs, transform
+    if (grp != a.first) {                               // transform-first group: DMAs, transform, MFMAs;  the other: MFMAs, DMAs, transform
       dmas();
       if (ahead) transform(sn);
       __builtin_amdgcn_sched_barrier(0);

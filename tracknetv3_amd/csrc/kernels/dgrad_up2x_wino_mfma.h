@@ -32,6 +32,7 @@ struct DgradUp2xWinoArgs {
   const float* u;      // [round_up(Cout, 8)][9][C0]   U'' (dgrad_up2x_wino_pack_kernel)
   float* dst;          // [N][C0][Hl][Wl]   gradient w.r.t. the low-resolution operand of nn.Upsample(2)
   int N, C0, Cout, Hl, Wl;
+  int first;           // the wave group that runs its MFMAs first in a chunk: 0 = the older waves (production), 1 = round 2's order
 };
 
 // w[Cout][Cin][3][3] (its first c0 input channels) -> u[copad][9][c0], xi = 3 * a + b over transform rows / columns (0, 1, 3)
@@ -223,7 +224,7 @@ inline __global__ void __launch_bounds__(DgradUp2xWinoCfg::NT) dgrad_up2x_wino_s
         dma_r(n_z + z_step, Cout - CC, vo_rn, sc);
       }
     };
-    if (grp == 0) {                                     // group 0: DMAs, transform, MFMAs;  group 1: MFMAs, DMAs, transform
+    if (grp != a.first) {                               // transform-first group: DMAs, transform, MFMAs;  the other: MFMAs, DMAs, transform
       dmas();
       if (ahead) transform(sn);
       __builtin_amdgcn_sched_barrier(0);

@@ -804,12 +804,12 @@ int conv_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, in
   return L.launch(conv_up2x_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, c0, c0pad);
 }
 template <class Launcher>
-int conv_up2x_wino_forward_impl(Launcher& L, const float* src, const float* u, float* dst, int n, int c0, int cout, int hl, int wl) {
-  if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv_up2x_wino: bad argument");
+int conv_up2x_wino_forward_impl(Launcher& L, const float* src, const float* u, float* dst, int n, int c0, int cout, int hl, int wl, int variant = -1) {
+  if (!src || !u || !dst || n <= 0 || variant > 1) TNV3_FAIL(-1, "conv_up2x_wino: bad argument");
   if (!conv_up2x_wino_supported(c0, cout, hl, wl))
     TNV3_FAIL(-1, "conv_up2x_wino: needs C0 > 8, Cout %% 64 == 0, H_low %% 2 == 0, W_low %% 64 == 0 (got %d -> %d, %dx%d)", c0, cout, hl, wl);
   if ((((uintptr_t)dst) & 7) || (((uintptr_t)u | (uintptr_t)src) & 15)) TNV3_FAIL(-1, "conv_up2x_wino: misaligned pointer");
-  ConvUp2xWinoArgs a{src, u, dst, n, c0, cout, hl, wl};
+  ConvUp2xWinoArgs a{src, u, dst, n, c0, cout, hl, wl, variant == 1 ? 1 : 0};
   const long npt = (long)n * (hl / 2) * (wl / ConvUp2xWinoCfg::TW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv_up2x_wino: too many tiles");
   return L.launch(conv_up2x_wino_stream_kernel, wino_persistent_grid(conv_grid_blocks(cout / ConvUp2xWinoCfg::MB, (int)npt)), ConvUp2xWinoCfg::NT, a);
@@ -834,12 +834,12 @@ int dgrad_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, i
   return L.launch(dgrad_up2x_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, c0, copad);
 }
 template <class Launcher>
-int dgrad_up2x_wino_impl(Launcher& L, const float* dz, const float* u, float* dst, int n, int c0, int cout, int hl, int wl) {
-  if (!dz || !u || !dst || n <= 0) TNV3_FAIL(-1, "dgrad_up2x_wino: bad argument");
+int dgrad_up2x_wino_impl(Launcher& L, const float* dz, const float* u, float* dst, int n, int c0, int cout, int hl, int wl, int variant = -1) {
+  if (!dz || !u || !dst || n <= 0 || variant > 1) TNV3_FAIL(-1, "dgrad_up2x_wino: bad argument");
   if (!dgrad_up2x_wino_supported(c0, cout, hl, wl))
     TNV3_FAIL(-1, "dgrad_up2x_wino: needs C0 %% 128 == 0, Cout > 8, H_low %% 2 == 0, W_low %% 32 == 0 (got %d <- %d, %dx%d)", c0, cout, hl, wl);
   if ((((uintptr_t)u | (uintptr_t)dz) & 15) || (((uintptr_t)dst) & 3)) TNV3_FAIL(-1, "dgrad_up2x_wino: misaligned pointer");
-  DgradUp2xWinoArgs a{dz, u, dst, n, c0, cout, hl, wl};
+  DgradUp2xWinoArgs a{dz, u, dst, n, c0, cout, hl, wl, variant == 1 ? 1 : 0};
   const long npt = (long)n * (hl / 2) * (wl / DgradUp2xWinoCfg::TWL);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "dgrad_up2x_wino: too many tiles");
   return L.launch(dgrad_up2x_wino_stream_kernel, wino_persistent_grid(conv_grid_blocks(c0 / DgradUp2xWinoCfg::MB, (int)npt)), DgradUp2xWinoCfg::NT, a);

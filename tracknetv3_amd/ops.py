@@ -185,8 +185,9 @@ def pack_up2x_wino_weights(weight, c0):
     return u
 
 
-def conv_up2x_wino(src_low, u, cout):
-    """Partial sums of conv3x3 over the nearest-2x upsampling of src_low in Winograd form, 9 of 16 GEMMs (tnv3_conv_up2x_wino_forward)."""
+def conv_up2x_wino(src_low, u, cout, variant=-1):
+    """Partial sums of conv3x3 over the nearest-2x upsampling of src_low in Winograd form, 9 of 16 GEMMs (tnv3_conv_up2x_wino_forward).
+    variant: which wave group runs its MFMAs first (-1 / 0 the older waves: production; 1 round 2's order); same bits."""
     lib = _lib.load()
     _f32(src_low, u)
     _lib.dev_check(src_low, u)
@@ -196,7 +197,7 @@ def conv_up2x_wino(src_low, u, cout):
     out = torch.empty((n, int(cout), 2 * hl, 2 * wl), dtype=torch.float32, device=src_low.device)
     if n:
         _lib.check(lib.tnv3_conv_up2x_wino_forward(_lib.ptr(src_low), _lib.ptr(u), _lib.ptr(out), n, c0, int(cout), hl, wl,
-                                                   _lib.stream_ptr(src_low)))
+                                                   int(variant), _lib.stream_ptr(src_low)))
     return out
 
 
@@ -215,8 +216,9 @@ def pack_dgrad_up2x_wino_weights(weight, c0):
     return u
 
 
-def dgrad_up2x_wino(dz, u, c0):
-    """Gradient w.r.t. the low-res operand of nn.Upsample(2) -> conv3x3 as one GEMM with K = 9 * Cout (tnv3_dgrad_up2x_wino)."""
+def dgrad_up2x_wino(dz, u, c0, variant=-1):
+    """Gradient w.r.t. the low-res operand of nn.Upsample(2) -> conv3x3 as one GEMM with K = 9 * Cout (tnv3_dgrad_up2x_wino).
+    variant: as conv_up2x_wino's."""
     lib = _lib.load()
     _f32(dz, u)
     _lib.dev_check(dz, u)
@@ -225,7 +227,7 @@ def dgrad_up2x_wino(dz, u, c0):
         raise _lib.Tnv3Error("dgrad_up2x_wino: odd output size or filter buffer / channel mismatch")
     out = torch.empty((n, int(c0), h // 2, w // 2), dtype=torch.float32, device=dz.device)
     if n:
-        _lib.check(lib.tnv3_dgrad_up2x_wino(_lib.ptr(dz), _lib.ptr(u), _lib.ptr(out), n, int(c0), cout, h // 2, w // 2, _lib.stream_ptr(dz)))
+        _lib.check(lib.tnv3_dgrad_up2x_wino(_lib.ptr(dz), _lib.ptr(u), _lib.ptr(out), n, int(c0), cout, h // 2, w // 2, int(variant), _lib.stream_ptr(dz)))
     return out
 
 
