@@ -311,6 +311,24 @@ int tnv3_bn_relu_backward(const float* da, const float* a, const float* z, const
                           const float* save_mean, const float* save_invstd, float* dz, float* dgamma, float* dbeta,
                           void* workspace, size_t workspace_bytes, int n, int c, int hw, tnv3_stream_t stream);
 
+/* BatchNorm + ReLU backward in ONE pass over (dA, z): the two per-channel sums (sum g, sum g * xhat) come from the epilogue of the
+ * data-gradient launch that produced dA (model.py:8-10 backwards: the next Conv2DBlock's dX IS this block's dA):
+ *   tnv3_bn_bwd_consts              : c4 [c][4] = (mean, invstd, gamma * invstd as the passes round it, beta) of the block
+ *   tnv3_conv3x3_wino_dgrad_bnstats : the Winograd data gradient (as tnv3_conv3x3_wino_forward on the transposed / flipped filter,
+ *                                     kernel variants 3-6) that also writes tile_stats [cout][tiles][2] (doubles; tiles =
+ *                                     tnv3_conv3x3_wino_stats_tiles(n, h, w, variant)) = per channel and pixel tile the sums over
+ *                                     g = dA * [BN(z) > 0] and g * (z - mean) * invstd, taken from the epilogue's registers
+ *                                     (bn_z = the block's raw convolution output z, bn_c4 from tnv3_bn_bwd_consts)
+ *   tnv3_bn_relu_backward_tiles     : fixed-order reduction of the tiles, then tnv3_bn_relu_backward's finalize + apply.
+ * Same dgamma / dbeta / dZ as tnv3_bn_relu_backward up to the fp64 summation order of the two sums. */
+int tnv3_bn_bwd_consts(const float* save_mean, const float* save_invstd, const float* gamma, const float* beta, float* c4, int c,
+                       tnv3_stream_t stream);
+int tnv3_conv3x3_wino_dgrad_bnstats(const float* dz, const float* u, float* da, double* tile_stats, const float* bn_z, const float* bn_c4,
+                                    int n, int cin, int cout, int h, int w, int variant, tnv3_stream_t stream);
+int tnv3_bn_relu_backward_tiles(const float* da, const float* z, const float* gamma, const float* beta, const float* save_mean,
+                                const float* save_invstd, const double* tile_stats, long n_tiles, float* dz, float* dgamma, float* dbeta,
+                                void* workspace, size_t workspace_bytes, int n, int c, int hw, tnv3_stream_t stream);
+
 /* Data gradient of Conv2DBlock's convolution: dX = conv3x3(dZ, W^T with flipped taps).  wpack_t comes from
  * tnv3_pack_conv3x3_weights(..., transpose_flip = 1).  The first c0 input-channel gradients go to dx0
  * [N][c0][H][W], the remaining c1 to dx1 [N][c1][H][W] (the two operands of torch.cat at model.py:65,67,69);

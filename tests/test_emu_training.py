@@ -322,6 +322,34 @@ def test_inpaintnet_train_step_emulated_vs_reference_golden(emu):
     torch.nn.utils.clip_grad_norm_(net.parameters(), 1)          # train.py:165 works on the leaf parameters
 
 
+@pytest.mark.parametrize("case", [(2, 16, 128, 8, 64), (1, 24, 64, 8, 128), (2, 64, 64, 4, 64)])
+def test_bn_backward_sums_from_the_data_gradient_epilogue_emulated(emu, monkeypatch, case):
+    """conv3x3_wino_dgrad_bnstats + bn_relu_backward_tiles == conv3x3_wino + bn_relu_backward: the same dA bits, the same dZ /
+    dgamma / dbeta up to the fp64 summation order of the two sums (variant 6 for 128 output channels, variant 5 for 64)."""
+    from tracknetv3_amd import ops
+    monkeypatch.setenv("TNV3_EMU_CUS", "8")
+    n, cin, cout, h, w = case            # the data gradient maps cin = the next block's Cout -> cout = this block's channels
+    dz_next, wt = T((n, cin, h, w), 701), T((cin, cout, 3, 3), 702, -0.3, 0.3)       # nn.Conv2d weight of the NEXT block: [Cout_next = cin][cout]
+    z = T((n, cout, h, w), 703, -1.0, 1.0)
+    gamma, beta = T((cout,), 704, 0.5, 1.5), T((cout,), 705, -0.3, 0.3)
+    mean = z.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(z.var((0, 2, 3), unbiased=False) + 1e-5)
+    u_t = ops.pack_wino_weights(wt, transpose_flip=True)
+    da_ref = ops.conv3x3_wino(dz_next, u_t, cout)
+    dz_ref, dg_ref, db_ref = ops.bn_relu_backward(da_ref.clone(), None, z, gamma, mean, invstd, beta=beta)
+    c4 = ops.bn_bwd_consts(mean, invstd, gamma, beta)
+    da, st = ops.conv3x3_wino_dgrad_bnstats(dz_next, u_t, cout, z, c4)
+    assert torch.equal(da, da_ref)
+    # the sums themselves against fp64 torch
+    a64 = (z.double() - mean.double()[None, :, None, None]) * (gamma.double() * invstd.double())[None, :, None, None] + beta.double()[None, :, None, None]
+    g64 = da.double() * (a64 > 0)
+    xh64 = (z.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    assert torch.allclose(st.sum(1)[:, 0], g64.sum((0, 2, 3)), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(st.sum(1)[:, 1], (g64 * xh64).sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
+    dz2, dg2, db2 = ops.bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, st)
+    assert rel_err(dg2, dg_ref) <= 1e-6 and rel_err(db2, db_ref) <= 1e-6 and rel_err(dz2, dz_ref) <= 1e-6
+
+
 def _inpaint_train_grads(net, coor, mask, gt):
     for p in net.parameters():
         p.grad = None

@@ -89,6 +89,9 @@ def _declare(lib):
     sig("tnv3_bn_workspace_bytes", sz, i)
     sig("tnv3_bn_train_forward", i, p, p, p, p, p, f, f, p, p, p, p, sz, i, i, i, p)
     sig("tnv3_bn_relu_backward", i, p, p, p, p, p, p, p, p, p, p, p, sz, i, i, i, p)
+    sig("tnv3_bn_bwd_consts", i, p, p, p, p, p, i, p)
+    sig("tnv3_conv3x3_wino_dgrad_bnstats", i, p, p, p, p, p, p, i, i, i, i, i, i, p)
+    sig("tnv3_bn_relu_backward_tiles", i, p, p, p, p, p, p, p, lg, p, p, p, p, sz, i, i, i, p)
     sig("tnv3_conv3x3_dgrad", i, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wgrad_workspace_bytes", sz, i, i, i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad", i, p, p, p, p, p, sz, i, i, i, i, i, i, i, i, p)
@@ -125,7 +128,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_inpaintnet_pack_t", "tnv3_inpaintnet_fused_forward_train", "tnv3_inpaintnet_fused_backward",
            "tnv3_ensemble_frames",
            "tnv3_peakfind_workspace_bytes", "tnv3_heatmap_peakfind", "tnv3_bn_workspace_bytes", "tnv3_bn_train_forward",
-           "tnv3_bn_relu_backward", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",
+           "tnv3_bn_relu_backward", "tnv3_bn_bwd_consts", "tnv3_conv3x3_wino_dgrad_bnstats", "tnv3_bn_relu_backward_tiles", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",
            "tnv3_wbce_workspace_bytes", "tnv3_wbce_forward", "tnv3_wbce_backward", "tnv3_head_backward_workspace_bytes",
            "tnv3_head_backward", "tnv3_head_wbce_workspace_bytes", "tnv3_head1x1_sigmoid_wbce", "tnv3_head_wbce_backward",
            "tnv3_maxpool2x2_backward_add", "tnv3_upsample2x_backward", "tnv3_mixup",

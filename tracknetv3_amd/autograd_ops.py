@@ -147,13 +147,23 @@ def _train_backward_body(ctx, dev, head_backward):
     done(net.predictor.weight, dw_head)
     done(net.predictor.bias, db_head)
 
-    def block_bwd(rec, da, need_dx=True):
+    def bn_unchanged(rec):
+        return rec["bn_ver"] == (rec["blk"].bn.weight._version, rec["blk"].bn.bias._version)
+
+    def block_bwd(rec, da, need_dx=True, da_stats=None, producer=None):
+        """da_stats: the two BatchNorm-backward sums of THIS block per pixel tile, taken in the epilogue of the data-gradient launch
+        that produced `da` (then one pass over (dA, z) is left).  producer: the record of the block whose activation is this block's
+        input -- when given (and the plain Winograd data gradient runs), this block's dX launch takes ITS sums the same way."""
         blk = rec["blk"]
         # ReLU mask recomputed from z (bit-identical to a > 0): the passes read two activation tensors instead of three.
         # That needs the forward's gamma / beta; if either was modified in place since, the mask comes from a itself.
-        same = rec["bn_ver"] == (blk.bn.weight._version, blk.bn.bias._version)
-        dz, dgamma, dbeta = ops.bn_relu_backward(da, None if same else rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"],
-                                                 rec["invstd"], beta=blk.bn.bias.detach())
+        same = bn_unchanged(rec)
+        if da_stats is not None:
+            dz, dgamma, dbeta = ops.bn_relu_backward_tiles(da, rec["z"], blk.bn.weight.detach(), blk.bn.bias.detach(), rec["mean"],
+                                                           rec["invstd"], da_stats)
+        else:
+            dz, dgamma, dbeta = ops.bn_relu_backward(da, None if same else rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"],
+                                                     rec["invstd"], beta=blk.bn.bias.detach())
         done(blk.bn.weight, dgamma)
         done(blk.bn.bias, dbeta)
 
@@ -178,7 +188,7 @@ def _train_backward_body(ctx, dev, head_backward):
             keep.append(dz)      # read by the side stream: stays alive until the main stream has joined it (below), so the
                                  # allocator can never hand its memory to later main-stream work too early
         if not need_dx:
-            return None, None
+            return None, None, None
         c0 = int(rec["x0"].shape[1])
         c1 = int(rec["x1"].shape[1]) if rec["x1"] is not None else 0
         n, _, h, w = dz.shape
@@ -199,10 +209,16 @@ def _train_backward_body(ctx, dev, head_backward):
             else:
                 cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))
                 d_skip, _ = ops.conv3x3_dgrad(dz, w_skip_t, c1, 0, cfg=cfg)
-            return d_low, d_skip
+            return d_low, d_skip, None
         if c1 == 0 and not rec["up"] and tuning.use_winograd(blk.conv.out_dim, c0, int(h), int(w)):
             # plain layer: dX = conv3x3(dZ, W^T flipped) is itself a plain 3x3 convolution -> the Winograd kernel
-            return ops.conv3x3_wino(dz, blk.packed_wino_t(), c0), None
+            if (producer is not None and tuning.BN_BWD_STATS_IN_DGRAD and tuning.wino_has_stats() and bn_unchanged(producer)
+                    and producer["z"].shape[1] == c0):
+                pb = producer["blk"].bn
+                c4 = ops.bn_bwd_consts(producer["mean"], producer["invstd"], pb.weight.detach(), pb.bias.detach())
+                dx, st = ops.conv3x3_wino_dgrad_bnstats(dz, blk.packed_wino_t(), c0, producer["z"], c4)
+                return dx, None, st
+            return ops.conv3x3_wino(dz, blk.packed_wino_t(), c0), None, None
         if c1 == 0 and c0 % 64:
             # gradient w.r.t. the network INPUT (9 / 27 channels; only when the caller asked for it -- train.py never does):
             # the data-gradient kernels produce channel blocks of 64, so run it on the filter zero-padded to 64 input
@@ -211,21 +227,24 @@ def _train_backward_body(ctx, dev, head_backward):
             wpad = torch.zeros((blk.conv.out_dim, cpad, 3, 3), dtype=torch.float32, device=dz.device)
             wpad[:, :c0] = blk.conv.weight.detach()
             dxp, _ = ops.conv3x3_dgrad(dz, ops.pack_conv3x3_weights(wpad, transpose_flip=True), cpad, 0)
-            return dxp[:, :c0].contiguous(), None
+            return dxp[:, :c0].contiguous(), None, None
         cfg = tuning.conv_config(c0 + c1, blk.conv.out_dim, int(n), int(h), int(w))
-        return ops.conv3x3_dgrad(dz, blk.packed_weight(transpose_flip=True), c0, c1, cfg=cfg)
+        return ops.conv3x3_dgrad(dz, blk.packed_weight(transpose_flip=True), c0, c1, cfg=cfg) + (None,)
 
     x1, x2, x3 = ctx.skips
     idx = len(saved) - 1
 
     def chain_bwd(count, da, first_needs_dx=True):
         nonlocal idx
-        d_skip = None
+        d_skip, stats = None, None
         for k in range(count):
             rec = saved[idx]
             idx -= 1
             last = (k == count - 1)
-            da, d_skip = block_bwd(rec, da, need_dx=(first_needs_dx or not last))
+            # inside a Double / Triple block the next record is the producer of this block's input: its BatchNorm-backward sums
+            # come out of this block's data-gradient epilogue
+            da, d_skip, stats = block_bwd(rec, da, need_dx=(first_needs_dx or not last), da_stats=stats,
+                                          producer=(None if last else saved[idx]))
         return da, d_skip
 
     # up_block_3 (2) -> dUp(128ch, full res), dSkip(x1)

@@ -160,6 +160,12 @@ __device__ __forceinline__ void wino3_writeout(const WinoArgs& a, const f32x16 (
   const bool want_stats = a.stats != nullptr;            // wave-uniform (kernel argument); never together with the affine (host check)
   if (want_stats) {                                      // training forward: raw convolution (+ addend) out, statistics from the same registers
     double q1[16], q2[16];                               // this lane's two pixels per channel r: sum, sum of squares
+    const bool bn_bwd = a.bn_z != nullptr;               // wave-uniform: data-gradient launch that also takes BatchNorm backward's two sums
+    if (bn_bwd) {                                        // (no addend in that mode, host check: its registers hold the z pairs)
+      const tnv3_rsrc_t r_z = tnv3_make_rsrc(a.bn_z + plane0, planes_b);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ad[r] = tnv3_buf_load_f2(r_z, lane_off_b, chan_off(r));
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       wf2 v;
@@ -168,8 +174,17 @@ __device__ __forceinline__ void wino3_writeout(const WinoArgs& a, const f32x16 (
       if (has_addend) { v[0] += ad[r][0]; v[1] += ad[r][1]; }
       if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
       tnv3_buf_store_f2(r_dst, lane_off_b, chan_off(r), v);
-      q1[r] = (double)v[0] + (double)v[1];
-      q2[r] = (double)v[0] * (double)v[0] + (double)v[1] * (double)v[1];
+      if (!bn_bwd) {
+        q1[r] = (double)v[0] + (double)v[1];
+        q2[r] = (double)v[0] * (double)v[0] + (double)v[1] * (double)v[1];
+      } else {                                           // g = dA * [BN(z) > 0] (the forward's own expression: bit-identical mask), xhat = (z - mean) * invstd
+        const int ch = e_m0 + wm * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.bn_c4 + 4 * (size_t)ch);
+        const float g0 = fmaf(ad[r][0] - c4[0], c4[2], c4[3]) > 0.0f ? v[0] : 0.0f;
+        const float g1 = fmaf(ad[r][1] - c4[0], c4[2], c4[3]) > 0.0f ? v[1] : 0.0f;
+        q1[r] = (double)g0 + (double)g1;
+        q2[r] = (double)g0 * (double)((ad[r][0] - c4[0]) * c4[1]) + (double)g1 * (double)((ad[r][1] - c4[0]) * c4[1]);
+      }
     }
     // BatchNorm batch statistics from the epilogue's registers (model.py:9 in training mode): a half-wave holds 32 tiles x 2 pixels
     // of 16 channels.  Reduce-scatter butterfly over the 32 lanes: at offset o the lane keeps the half of its channel list its

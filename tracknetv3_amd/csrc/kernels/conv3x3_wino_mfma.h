@@ -41,6 +41,13 @@ struct WinoArgs {
   double* stats;        // optional (kernel variant 3 / 4 only) [Cout][nTiles][2]: per output channel and pixel tile (4 x 64 pixels) the sum
                         // and the sum of squares of the values written to dst -- the batch statistics of training-mode BatchNorm taken
                         // from the epilogue's registers (wave butterfly + fixed-order LDS fold: deterministic)
+  // Data-gradient launches only (with `stats`): the values written to dst are dA, the gradient at the ACTIVATION of the previous
+  // Conv2DBlock; bn_z = that block's raw convolution output [N][Cout][H][W], bn_c4 = its per-channel constants [Cout][4] =
+  // (mean, invstd, gamma * invstd as the forward rounds it, beta).  The statistics then are the two sums of BatchNorm + ReLU's
+  // backward (model.py:9-10): sum g and sum g * xhat with g = dA * [BN(z) > 0], xhat = (z - mean) * invstd -- the pass
+  // bn_relu_bwd_partial_kernel would make over dA and z, taken from the epilogue's registers instead.
+  const float* bn_z;
+  const float* bn_c4;
 };
 
 template <int WM_, int WN_, int CC_, int DIAG_ = 0>

@@ -148,6 +148,18 @@ __global__ void __launch_bounds__(256) bn_relu_bwd_partial_kernel(const float* _
   if (threadIdx.x == 0) { partial[((size_t)c * kRedSplit + s) * 2] = r1; partial[((size_t)c * kRedSplit + s) * 2 + 1] = r2; }
 }
 
+// c4[c] = (mean, invstd, gamma * invstd exactly as the forward / backward passes round it, beta): what the data-gradient epilogue
+// that takes BatchNorm backward's sums (WinoArgs::bn_c4) reads per channel.
+inline __global__ void bn_bwd_consts_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ c4, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  c4[4 * c] = mean[c];
+  c4[4 * c + 1] = invstd[c];
+  c4[4 * c + 2] = bn_scale(gamma[c], invstd[c]);
+  c4[4 * c + 3] = beta[c];
+}
+
 // dbeta = sum g, dgamma = sum g*xhat; coefficients of the apply pass:  dZ = k0*g - k1 - k2*xhat
 inline __global__ void bn_relu_bwd_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
                                             const float* __restrict__ invstd, long count, float* __restrict__ dgamma,

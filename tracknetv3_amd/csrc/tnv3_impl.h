@@ -456,6 +456,33 @@ int bn_relu_backward_impl(Launcher& L, const float* da, const float* a, const fl
                            (const float*)coef, dz, (long)n * c, c, hw);
 }
 
+// BatchNorm + ReLU backward whose two per-channel sums were taken in the epilogue of the data-gradient launch that produced dA
+// (tnv3_conv3x3_wino_dgrad_bnstats): tile_stats [C][n_tiles][2] doubles -> fixed-order sums, then bn_relu_backward's finalize +
+// apply -- one pass over (dA, z) instead of two.
+template <class Launcher>
+int bn_relu_backward_tiles_impl(Launcher& L, const float* da, const float* z, const float* gamma, const float* beta, const float* mean,
+                                const float* invstd, const double* tile_stats, long n_tiles, float* dz, float* dgamma, float* dbeta, void* ws,
+                                size_t ws_bytes, int n, int c, int hw) {
+  if (!da || !beta || !z || !gamma || !mean || !invstd || !tile_stats || !dz || !dgamma || !dbeta || !ws || n <= 0 || c <= 0 || hw <= 0 || n_tiles <= 0)
+    TNV3_FAIL(-1, "bn_relu_backward_tiles: bad argument");
+  if (hw % 4) TNV3_FAIL(-1, "bn_relu_backward_tiles: H*W must be a multiple of 4");
+  if (ws_bytes < bn_workspace_bytes(c) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "bn_relu_backward_tiles: workspace too small / misaligned");
+  double* partial = (double*)ws;
+  float* coef = (float*)(partial + (size_t)c * kRedSplit * 2);
+  int rc;
+  if ((rc = L.launch3(bn_tile_stats_reduce_kernel, kRedSplit, c, 1, 64, tile_stats, partial, n_tiles))) return rc;
+  if ((rc = L.launch(bn_relu_bwd_finalize_kernel, (c + 63) / 64, 64, (const double*)partial, gamma, invstd, (long)n * hw, dgamma,
+                     dbeta, coef, c))) return rc;
+  return L.launch(bn_relu_bwd_apply_kernel<true>, grid_for((long)n * c * (hw / 4)), 256, da, (const float*)nullptr, z, gamma, beta, mean, invstd,
+                  (const float*)coef, dz, (long)n * c, c, hw);
+}
+
+template <class Launcher>
+int bn_bwd_consts_impl(Launcher& L, const float* mean, const float* invstd, const float* gamma, const float* beta, float* c4, int c) {
+  if (!mean || !invstd || !gamma || !beta || !c4 || c <= 0) TNV3_FAIL(-1, "bn_bwd_consts: bad argument");
+  return L.launch(bn_bwd_consts_kernel, (c + 63) / 64, 64, mean, invstd, gamma, beta, c4, c);
+}
+
 // ---- Winograd F(2x2, 3x3) form of the plain eval-mode layer (kernels/conv3x3_wino_mfma.h)
 using WinoA = WinoCfg<2, 2, 8>;              // 64 channels x 64 tiles (4 x 64 pixels), 256 threads, 8-channel chunks
 using WinoSplit = WinoSplitCfg<8>;          // same tile, 512 threads: two wave groups split the 16 transform rows (2 waves / SIMD)
@@ -508,7 +535,7 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
 template <class Launcher>
 int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant = -1,
-                              double* stats = nullptr) {
+                              double* stats = nullptr, const float* bn_z = nullptr, const float* bn_c4 = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino: bad argument");
   if (variant < 0) variant = conv3x3_wino_pick(cin, cout);
   if (stats && !conv3x3_wino_has_stats(variant)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3, 4 and 5");
@@ -519,7 +546,10 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino: inconsistent affine arguments");
   const float* zeros = u + (size_t)round_up(cin, kWinoCinPad) * 16 * cout;
-  WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats};
+  if ((bn_z != nullptr) != (bn_c4 != nullptr) || (bn_z && (!stats || addend || relu)))
+    TNV3_FAIL(-1, "conv3x3_wino: the BatchNorm-backward statistics need z AND its constants, the statistics buffer, and no addend / ReLU");
+  if (bn_c4 && (((uintptr_t)bn_c4) & 15)) TNV3_FAIL(-1, "conv3x3_wino: the BatchNorm constants must be 16-byte aligned");
+  WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, bn_z, bn_c4};
   if (is_v6) {     // 128 channels x (4 x 32 pixels) per workgroup, filters packed with layout 2
     using V6 = WinoV6Cfg<0, 1>;          // production: the older waves (group 0) run their MFMAs first (profiles/r03_wino6_*)
     if (cout % V6::MB || w % V6::PW || cin <= V6::CC)

@@ -525,6 +525,54 @@ def bn_relu_backward(da, a, z, gamma, mean, invstd, inplace=True, beta=None):
     return dz, dgamma, dbeta
 
 
+def bn_bwd_consts(mean, invstd, gamma, beta):
+    """(C, 4) per-channel constants (mean, invstd, gamma * invstd as the passes round it, beta) for conv3x3_wino_dgrad_bnstats."""
+    lib = _lib.load()
+    _f32(mean, invstd, gamma, beta)
+    _lib.dev_check(mean, invstd, gamma, beta)
+    c = int(mean.numel())
+    c4 = torch.empty((c, 4), dtype=torch.float32, device=mean.device)
+    _lib.check(lib.tnv3_bn_bwd_consts(_lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(c4), c, _lib.stream_ptr(mean)))
+    return c4
+
+
+def conv3x3_wino_dgrad_bnstats(dz, u, cout, bn_z, bn_c4, variant=None):
+    """The Winograd data gradient dA = conv3x3(dZ, W^T flipped) that ALSO takes, from its epilogue's registers, the two sums of the
+    previous block's BatchNorm + ReLU backward: returns (dA, tile_stats (cout, tiles, 2) float64) -- feed them to
+    bn_relu_backward_tiles.  bn_z: that block's raw convolution output (the shape of dA), bn_c4: bn_bwd_consts(...) of it."""
+    lib = _lib.load()
+    _f32(dz, u, bn_z, bn_c4)
+    _lib.dev_check(dz, u, bn_z, bn_c4)
+    n, cin, h, w = (int(v) for v in dz.shape)
+    variant = wino_variant(variant, cin, cout)
+    tiles = int(lib.tnv3_conv3x3_wino_stats_tiles(n, h, w, variant))
+    if tiles <= 0 or u.numel() != lib.tnv3_conv3x3_wino_packed_floats(cin, int(cout)) or tuple(bn_z.shape) != (n, int(cout), h, w):
+        raise _lib.Tnv3Error("conv3x3_wino_dgrad_bnstats: unsupported shape, filter buffer or z mismatch")
+    da = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=dz.device)
+    stats = torch.empty((int(cout), tiles, 2), dtype=torch.float64, device=dz.device)
+    _lib.check(lib.tnv3_conv3x3_wino_dgrad_bnstats(_lib.ptr(dz), _lib.ptr(u), _lib.ptr(da), _lib.ptr(stats), _lib.ptr(bn_z), _lib.ptr(bn_c4), n, cin,
+                                                   int(cout), h, w, int(variant), _lib.stream_ptr(dz)))
+    return da, stats
+
+
+def bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, tile_stats, inplace=True):
+    """bn_relu_backward with the two per-channel sums already taken per pixel tile by conv3x3_wino_dgrad_bnstats: one pass over (dA, z)."""
+    lib = _lib.load()
+    _f32(da, z, gamma, beta, mean, invstd)
+    _lib.dev_check(da, z, gamma, beta, mean, invstd, tile_stats)
+    if tile_stats.dtype != torch.float64 or not tile_stats.is_contiguous():
+        raise _lib.Tnv3Error("bn_relu_backward_tiles: tile_stats must be a contiguous float64 tensor")
+    n, c, h, w = (int(v) for v in z.shape)
+    dz = da if inplace else torch.empty_like(da)
+    dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _workspace(lib.tnv3_bn_workspace_bytes(c), z.device)
+    _lib.check(lib.tnv3_bn_relu_backward_tiles(_lib.ptr(da), _lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
+                                               _lib.ptr(tile_stats), int(tile_stats.shape[1]), _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                               _lib.ptr(ws), ws.numel() * 8, n, c, h * w, _lib.stream_ptr(z)))
+    return dz, dgamma, dbeta
+
+
 def conv3x3_dgrad(dz, wpack_t, c0, c1=0, cfg=-1):
     """dX = conv3x3(dZ, W^T flipped); returns (dx0 [N,c0,H,W], dx1 [N,c1,H,W] or None)."""
     lib = _lib.load()
@@ -855,7 +903,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
 _TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
-               "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "conv3x3_dgrad", "conv3x3_wgrad",
+               "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "bn_bwd_consts", "conv3x3_wino_dgrad_bnstats", "bn_relu_backward_tiles", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
                "maxpool2x2_backward_add", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad",
                "grad_norm", "adam_step", "sgd_step", "inpaintnet_pack", "inpaintnet_pack_t", "inpaintnet_fused_train_forward", "inpaintnet_fused_backward"]          # list-of-tensor ops: the guard looks inside the lists

@@ -88,6 +88,12 @@ INFER_SPLIT_MIN_PIXELS = 1 << 19          # batch x H x W below which the launch
 UP2X_WINO = os.environ.get("TNV3_UP2X_WINO", "1") != "0"
 
 
+# BatchNorm + ReLU backward: the two per-channel sums of block L (sum g, sum g * xhat) taken in the epilogue of the Winograd data-gradient
+# launch of block L + 1 -- which produces exactly dA_L -- instead of a pass over (dA, z): ten of the seventeen blocks (those followed by a
+# plain conv inside their Double / Triple block).  TNV3_BN_BWD_STATS_IN_DGRAD=0 restores the two-pass backward.
+BN_BWD_STATS_IN_DGRAD = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD", "1") != "0"
+
+
 def wino_has_stats():
     from . import ops
     return BN_STATS_IN_EPILOGUE and ops.wino_variant_has_stats(WINO_VARIANT)
