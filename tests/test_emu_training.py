@@ -322,16 +322,17 @@ def test_inpaintnet_train_step_emulated_vs_reference_golden(emu):
     torch.nn.utils.clip_grad_norm_(net.parameters(), 1)          # train.py:165 works on the leaf parameters
 
 
-@pytest.mark.parametrize("case", [(2, 16, 128, 8, 64), (1, 24, 64, 8, 128), (2, 64, 64, 4, 64)])
-def test_bn_backward_sums_from_the_data_gradient_epilogue_emulated(emu, monkeypatch, case):
+BN_BWD_EPILOGUE_CASES = [(2, 16, 128, 8, 64), (1, 24, 64, 8, 128), (2, 64, 64, 4, 64)]
+
+
+def _bn_bwd_epilogue_case(case, device):
     """conv3x3_wino_dgrad_bnstats + bn_relu_backward_tiles == conv3x3_wino + bn_relu_backward: the same dA bits, the same dZ /
     dgamma / dbeta up to the fp64 summation order of the two sums (variant 6 for 128 output channels, variant 5 for 64)."""
     from tracknetv3_amd import ops
-    monkeypatch.setenv("TNV3_EMU_CUS", "8")
     n, cin, cout, h, w = case            # the data gradient maps cin = the next block's Cout -> cout = this block's channels
-    dz_next, wt = T((n, cin, h, w), 701), T((cin, cout, 3, 3), 702, -0.3, 0.3)       # nn.Conv2d weight of the NEXT block: [Cout_next = cin][cout]
-    z = T((n, cout, h, w), 703, -1.0, 1.0)
-    gamma, beta = T((cout,), 704, 0.5, 1.5), T((cout,), 705, -0.3, 0.3)
+    dz_next, wt = T((n, cin, h, w), 701).to(device), T((cin, cout, 3, 3), 702, -0.3, 0.3).to(device)   # weight of the NEXT block: [Cout_next = cin][cout]
+    z = T((n, cout, h, w), 703, -1.0, 1.0).to(device)
+    gamma, beta = T((cout,), 704, 0.5, 1.5).to(device), T((cout,), 705, -0.3, 0.3).to(device)
     mean = z.mean((0, 2, 3))
     invstd = 1.0 / torch.sqrt(z.var((0, 2, 3), unbiased=False) + 1e-5)
     u_t = ops.pack_wino_weights(wt, transpose_flip=True)
@@ -348,6 +349,12 @@ def test_bn_backward_sums_from_the_data_gradient_epilogue_emulated(emu, monkeypa
     assert torch.allclose(st.sum(1)[:, 1], (g64 * xh64).sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
     dz2, dg2, db2 = ops.bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, st)
     assert rel_err(dg2, dg_ref) <= 1e-6 and rel_err(db2, db_ref) <= 1e-6 and rel_err(dz2, dz_ref) <= 1e-6
+
+
+@pytest.mark.parametrize("case", BN_BWD_EPILOGUE_CASES)
+def test_bn_backward_sums_from_the_data_gradient_epilogue_emulated(emu, monkeypatch, case):
+    monkeypatch.setenv("TNV3_EMU_CUS", "8")
+    _bn_bwd_epilogue_case(case, "cpu")
 
 
 def _inpaint_train_grads(net, coor, mask, gt):

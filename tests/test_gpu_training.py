@@ -473,3 +473,10 @@ def test_fused_loss_node_equals_the_two_call_protocol(gpu_device):
     # differently); sixteen BatchNorm backward passes amplify that to a few 1e-6 of max|g|
     worst = max(rel_err(g1[k].cpu(), g0[k].cpu()) for k in g0)
     assert worst <= 2e-5, worst
+
+
+@pytest.mark.parametrize("case", [(2, 16, 128, 8, 64), (1, 24, 64, 8, 128), (2, 64, 64, 288, 512), (2, 128, 128, 144, 256), (10, 512, 512, 36, 64)])
+def test_bn_backward_sums_from_the_data_gradient_epilogue(gpu_device, case):
+    """The data-gradient launch that also takes BatchNorm + ReLU backward's two sums (kernels 5 and 6) at small and network shapes."""
+    from test_emu_training import _bn_bwd_epilogue_case
+    _bn_bwd_epilogue_case(case, gpu_device)

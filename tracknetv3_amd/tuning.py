@@ -90,8 +90,12 @@ UP2X_WINO = os.environ.get("TNV3_UP2X_WINO", "1") != "0"
 
 # BatchNorm + ReLU backward: the two per-channel sums of block L (sum g, sum g * xhat) taken in the epilogue of the Winograd data-gradient
 # launch of block L + 1 -- which produces exactly dA_L -- instead of a pass over (dA, z): ten of the seventeen blocks (those followed by a
-# plain conv inside their Double / Triple block).  TNV3_BN_BWD_STATS_IN_DGRAD=0 restores the two-pass backward.
-BN_BWD_STATS_IN_DGRAD = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD", "1") != "0"
+# plain conv inside their Double / Triple block).  Built, parity-green (tests/test_gpu_training.py::test_bn_backward_sums_from_the_data_
+# gradient_epilogue) and MEASURED SLOWER: A/B in one session 32.30 / 32.53 ms per step without, 32.88 / 33.06 with
+# (profiles/r03_bn_bwd_epilogue_ab.json) -- the 16 extra 8-byte z loads, the per-channel constants and the fp64 products per tile cost the
+# MFMA kernel's epilogue (which nothing overlaps: one workgroup fills the CU) more than the HBM-bound pass they replace, which runs
+# beside the other stream's kernels.  Default OFF; TNV3_BN_BWD_STATS_IN_DGRAD=1 switches it on.
+BN_BWD_STATS_IN_DGRAD = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD", "0") == "1"
 
 
 def wino_has_stats():
