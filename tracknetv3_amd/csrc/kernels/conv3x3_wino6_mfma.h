@@ -191,20 +191,18 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
       read_quad(0);
       read_quad(1);
 #pragma unroll
-      for (int s = 0; s < NSTEP; ++s) {
-        const int q = (s >> 3) * 2 + ((s & 7) >> 2);
-        if ((s & 3) == 0 && q + 2 < 8) {
-          read_quad(q + 2);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      for (int q = 0; q < 8; ++q) {
+        // full fences: the read of quad q + 2 goes out BEFORE the four MFMAs of quad q (with class-only group barriers the scheduler
+        // satisfied "one LDS read per group" with the read needed NEXT and the ring collapsed to read -> wait -> use)
+        if (q + 2 < 8) read_quad(q + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int s = 4 * q + j;
+          acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bq[q % 3][j], FIRST && s < 8 ? zero16 : acc[s & 7], 0, 0, 0);
         }
-        acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][s & 3], bq[q % 3][s & 3], FIRST && s < 8 ? zero16 : acc[s & 7], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if ((s & 3) == 3) {
-          if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13 && !Cfg::ALATE) {
-            load_a(anext, q);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          }
-        }
+        if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13 && !Cfg::ALATE) load_a(anext, q);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13 && Cfg::ALATE) {
         __builtin_amdgcn_sched_barrier(0);

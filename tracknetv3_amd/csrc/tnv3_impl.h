@@ -551,7 +551,7 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
   if (bn_c4 && (((uintptr_t)bn_c4) & 15)) TNV3_FAIL(-1, "conv3x3_wino: the BatchNorm constants must be 16-byte aligned");
   WinoArgs a{src, u, zeros, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, bn_z, bn_c4};
   if (is_v6) {     // 128 channels x (4 x 32 pixels) per workgroup, filters packed with layout 2
-    using V6 = WinoV6Cfg<0, 1>;          // production: the older waves (group 0) run their MFMAs first (profiles/r03_wino6_*)
+    using V6 = WinoV6Cfg<0, 1, 0, 1>;    // production: the older waves (group 0) run their MFMAs first, B operand as 16-byte quads (profiles/r03_wino6_*)
     if (cout % V6::MB || w % V6::PW || cin <= V6::CC)
       TNV3_FAIL(-1, "conv3x3_wino (variant 6): needs Cout %% %d == 0, W %% %d == 0, Cin > %d (got %d -> %d, %dx%d)", V6::MB, V6::PW, V6::CC, cin, cout, h, w);
     if ((long)cin * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variant 6): one sample of the input must stay below 2 GiB");
@@ -574,9 +574,9 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
       case 108: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 2>>, grid6, V6::NT, a);
       case 109: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 0, 2>>, grid6, V6::NT, a);
       case 105: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<7, 1>>, grid6, V6::NT, a);
-      // 102: 6 + quad B reads;  110 = 6 + A loads behind the MFMA phase;  111 = 6 + both;  112 = 111 + priority;  113 = timeline of 111
-      // (all measured slower than 6: profiles/r03_wino6_variants_ab.json)
-      case 102: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 0, 1, 0>>, grid6, V6::NT, a);
+      // 102: 6 with 4-byte B reads (6 reads 16-byte quads: 0.2-2 % faster once its prefetch was fenced);  110 = 102 + A loads behind the
+      // MFMA phase;  111 = 6 + A loads behind the MFMA phase;  112 = 111 + priority;  113 = timeline of 111 (110-112 measured slower)
+      case 102: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 0, 0, 0>>, grid6, V6::NT, a);     // 6 with 4-byte B reads (round 3's second form)
       case 110: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 0, 0, 1>>, grid6, V6::NT, a);
       case 111: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 0, 1, 1>>, grid6, V6::NT, a);
       case 112: return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 1, 2, 1, 1>>, grid6, V6::NT, a);
