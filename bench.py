@@ -325,13 +325,14 @@ def bench_train(args, dev, rank, world):
         dist.destroy_process_group()
 
 
-def self_spawn(n):
+def self_spawn(n, share_gpus=False):
     """`python bench.py --gpus N` with no launcher around it: re-execute under torch.distributed.run, one rank per GPU (RCCL).
-    Refuses (non-zero exit) when the node has fewer than N GPUs -- never a silent 1-rank run."""
+    Refuses (non-zero exit) when the node has fewer than N GPUs -- never a silent 1-rank run.  (share_gpus: the launcher TEST mode,
+    see --share-gpus.)"""
     import socket
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n:
+    if have < (1 if share_gpus else n):
         raise SystemExit(f"bench.py --gpus {n} needs {n} GPUs on this node, found {have}: refusing to run with fewer ranks")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -450,7 +451,17 @@ def main():
     ap.add_argument("--overlap-streams", type=int, default=2,
                     help="also time the K steps round-robin on this many HIP streams (reported as `overlap`; 0/1 = skip)")
     ap.add_argument("--layers-out", default=os.path.join(ROOT, "gpurun_out", "bench_layers.json"))
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend of the N > 1 run: nccl = RCCL over xGMI (the product path); gloo only for --share-gpus")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="TEST mode for boxes with fewer GPUs than ranks: rank r uses GPU r %% device_count and the ranks talk over gloo "
+                         "(RCCL refuses two ranks on one device).  Exercises the launcher, the rendezvous, the max-over-ranks timing and "
+                         "the data-parallel step end to end; its numbers are NOT a scaling measurement and the line says so")
     args = ap.parse_args()
+    if args.share_gpus:
+        args.backend = "gloo"
+    elif args.backend == "gloo":
+        raise SystemExit("--backend gloo is only meaningful with --share-gpus (the product's collective path is RCCL)")
 
     launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -459,21 +470,24 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and not launched:
-        sys.exit(self_spawn(args.gpus))
+        sys.exit(self_spawn(args.gpus, args.share_gpus))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the rank count must equal --gpus")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit(f"bench.py needs {args.gpus} GPU(s), found 0 (there is no CPU fallback for the product path)")
-    if torch.cuda.device_count() < world:
+    if torch.cuda.device_count() < world and not args.share_gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {torch.cuda.device_count()}")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if args.share_gpus else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     n_gpus = world
@@ -659,6 +673,9 @@ def main():
                                    "288x512 synthetic frames, synthetic (PRNG) weights", "batch_per_gpu": args.batch,
                        "frames_per_step": n_gpus * args.batch * SEQ_LEN, "parallelism": f"replicated windows x{n_gpus} (no collective)",
                        "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+                       "backend": (args.backend if world > 1 else None),
+                       "shared_gpus": (f"TEST MODE: {world} ranks on {torch.cuda.device_count()} GPU(s) over gloo -- not a scaling measurement"
+                                       if args.share_gpus else None),
                        "launcher": ("torch.distributed.run" if launched else "single process"),
                        "schedule": ("the batch's images split 6 : 4 over two HIP streams (product default, tuning.INFER_SPLIT): the halves' "
                                     "per-layer launches overlap at their tails; outputs bit-identical to the one-stream forward")

@@ -145,3 +145,33 @@ def test_fused_optimizers_and_inpaint_pack_follow_the_tensor_device(gpu_device):
         res.append([p.detach().cpu() for p in ps] + [y.cpu()])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_bench_spawns_and_verifies_its_own_ranks(gpu_device):
+    """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself under torch.distributed.run,
+    both ranks rendezvous, the timed blocks take the max over ranks, the data-parallel training leg runs its bucketed all-reduce, and
+    rank 0 prints ONE line with n_gpus = 2.  On a one-GPU box the ranks share the device over gloo (--share-gpus: RCCL refuses two ranks
+    on one device); with two GPUs the same command runs over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    two = torch.cuda.device_count() >= 2
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "1", "--no-cpu-baseline",
+           "--train-steps", "2", "--strong-steps", "0", "--extras", "0", "--overlap-streams", "0", "--layers-out", os.devnull]
+    if not two:
+        cmd.append("--share-gpus")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world_size"] == 2 and d["config"]["launcher"] == "torch.distributed.run"
+    assert d["config"]["backend"] == ("nccl" if two else "gloo") and (d["config"]["shared_gpus"] is None) == two
+    assert d["config"]["frames_per_step"] == 160 and d["value"] > 0
+    t = d["train"]
+    assert "error" not in t, t
+    assert t["n_gpus"] == 2 and t["config"]["global_batch"] == 20 and t["config"]["parallelism"] == "dp2"
+    assert t["dp_overlap"] is not None and len(t["dp_overlap"]["buckets"]) >= 3 and t["dp_overlap"]["allreduce_ms_total"] > 0
+
