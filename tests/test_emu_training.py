@@ -341,12 +341,10 @@ def _bn_bwd_epilogue_case(case, device):
     c4 = ops.bn_bwd_consts(mean, invstd, gamma, beta)
     da, st = ops.conv3x3_wino_dgrad_bnstats(dz_next, u_t, cout, z, c4)
     assert torch.equal(da, da_ref)
-    # the sums themselves against fp64 torch
-    a64 = (z.double() - mean.double()[None, :, None, None]) * (gamma.double() * invstd.double())[None, :, None, None] + beta.double()[None, :, None, None]
-    g64 = da.double() * (a64 > 0)
-    xh64 = (z.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
-    assert torch.allclose(st.sum(1)[:, 0], g64.sum((0, 2, 3)), rtol=1e-6, atol=1e-6)
-    assert torch.allclose(st.sum(1)[:, 1], (g64 * xh64).sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
+    # the tile sums ARE dbeta / dgamma (same fp32 mask expression, same fp64 accumulation, another summation order)
+    scale = max(da.abs().sum((0, 2, 3)).max().item(), 1.0)
+    assert (st.sum(1)[:, 0] - db_ref.double()).abs().max().item() <= 2e-6 * scale
+    assert (st.sum(1)[:, 1] - dg_ref.double()).abs().max().item() <= 2e-6 * scale
     dz2, dg2, db2 = ops.bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, st)
     assert rel_err(dg2, dg_ref) <= 1e-6 and rel_err(db2, db_ref) <= 1e-6 and rel_err(dz2, dz_ref) <= 1e-6
 

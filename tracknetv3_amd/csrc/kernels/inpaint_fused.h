@@ -81,13 +81,13 @@ inline __global__ void __launch_bounds__(256) inpaint_pack_kernel(const InpaintP
 
 // One dense layer for the workgroup's sequence.  src0 / src1: LDS activation rows of the two concatenated sources; every output
 // element (channel co, position n) is handed to epi(co, n, value).  BPW = channel blocks a wave works on at once (ceil(Cout / 64)).
-template <int C0, int C1, int COUT, class Epi>
+template <int C0, int C1, int COUT, int NW = 4, class Epi>
 __device__ __forceinline__ void if_dense_core(const float* __restrict__ wp, const float* src0, const float* src1, int wave, int lane_in, Epi&& epi) {
   int lane = lane_in;
   TNV3_OPAQUE_V(lane);        // every per-lane address of this layer is formed HERE, not hoisted to the top of the kernel and kept live
                               // through all nine layers (the nine layers' filter / operand / epilogue addresses cost 60+ registers)
   constexpr int CIN = C0 + C1, NCH = 3 * CIN / 16, NB = COUT / 16, CPT = CIN / 16;     // chunks of 16 K; chunks per tap
-  constexpr int BPW = (NB + 3) / 4;                                                   // blocks per wave (NB = 6: three waves x 2; NB = 2: two waves x 1)
+  constexpr int BPW = (NB + NW - 1) / NW;                                             // blocks per wave (NW = 4, NB = 6: three waves x 2; NB = 2: two waves x 1)
   static_assert(NB % BPW == 0, "the waves' block groups must tile the layer");
   constexpr int NACC = BPW == 1 ? 2 : BPW;                                            // BPW == 1: split K over two accumulators
   constexpr int RING = BPW >= 4 ? 2 : 3;                                              // filter chunks in flight per block
@@ -148,10 +148,10 @@ __device__ __forceinline__ void if_dense_core(const float* __restrict__ wp, cons
 
 // Forward layer: + bias, LeakyReLU(0.01) (model.py:81), rows of the output in LDS; gsave != nullptr: the activation also goes to
 // HBM as [COUT][16] (saved for the backward pass of a training step).
-template <int C0, int C1, int COUT>
+template <int C0, int C1, int COUT, int NW = 4>
 __device__ __forceinline__ void if_dense_layer(const float* __restrict__ wp, const float* __restrict__ bias, const float* src0,
                                                const float* src1, float* dst, int wave, int lane, float* gsave = nullptr) {
-  if_dense_core<C0, C1, COUT>(wp, src0, src1, wave, lane, [&](int co, int n, float acc) {
+  if_dense_core<C0, C1, COUT, NW>(wp, src0, src1, wave, lane, [&](int co, int n, float acc) {
     float v = acc + bias[co];
     v = v > 0.0f ? v : 0.01f * v;
     dst[co * kIfRow + 1 + n] = v;
@@ -167,9 +167,14 @@ constexpr int kIfLdsFloats = kIfRows * kIfRow;
 // acts[seq][kItActCh][16] in the order x1, x2, x3, b1, b2, u1, u2, u3 (inpaint_fused_train.h reads them in the backward pass).
 constexpr int kItActCh = 32 + 64 + 128 + 256 + 256 + 128 + 64 + 32;                 // 960
 constexpr int kItActOff[8] = {0, 32, 96, 224, 480, 736, 864, 928};
-inline __global__ void __launch_bounds__(256, 2) inpaintnet_fused_kernel(const float* __restrict__ x, const float* __restrict__ m,
-                                                                      const float* __restrict__ packed, float* __restrict__ out, int N,
-                                                                      float* __restrict__ acts) {
+// NW = waves per workgroup: 4 (two workgroups per CU: the throughput form) or 8 (one sequence on two waves per SIMD: the nine
+// dependent layers' MFMA / LDS latencies overlap between the two waves -- the small-batch latency form, chosen by the host when the
+// batch leaves CUs free anyway).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) inpaintnet_fused_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                                                 const float* __restrict__ packed, float* __restrict__ out, int N,
+                                                                                 float* __restrict__ acts) {
+  constexpr int NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) float lds[kIfLdsFloats];
   float* in0 = lds;
   float* x1 = in0 + 4 * kIfRow;
@@ -179,7 +184,7 @@ inline __global__ void __launch_bounds__(256, 2) inpaintnet_fused_kernel(const f
   float* pb = pa + 256 * kIfRow;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* bias = packed + kIfBiasOff;
-  for (int i = tid; i < kIfLdsFloats; i += 256) lds[i] = 0.0f;                      // the halo columns stay zero for good
+  for (int i = tid; i < kIfLdsFloats; i += NT) lds[i] = 0.0f;                      // the halo columns stay zero for good
   for (int seq = blockIdx.x; seq < N; seq += gridDim.x) {
     __syncthreads();
     if (tid < 48) {                                                                   // cat([coor, mask], 2).permute(0, 2, 1): rows x, y, mask
@@ -187,11 +192,11 @@ inline __global__ void __launch_bounds__(256, 2) inpaintnet_fused_kernel(const f
       in0[c * kIfRow + 1 + p] = c < 2 ? x[((size_t)seq * kIfL + p) * 2 + c] : m[(size_t)seq * kIfL + p];
     }
     __syncthreads();
-    {                                                                                 // down_1: 3 -> 32, two outputs per thread
+    {                                                                                 // down_1: 3 -> 32, 512 outputs over the workgroup
       const float* w = packed + kIfStemOff;
 #pragma unroll
-      for (int o = 0; o < 2; ++o) {
-        const int e = tid * 2 + o, co = e >> 4, p = e & 15;
+      for (int o = 0; o < 512 / NT; ++o) {
+        const int e = tid * (512 / NT) + o, co = e >> 4, p = e & 15;
         float s = bias[kIfBiasAt[0] + co];
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci)
@@ -205,19 +210,19 @@ inline __global__ void __launch_bounds__(256, 2) inpaintnet_fused_kernel(const f
     float* ga = acts ? acts + (size_t)seq * kItActCh * kIfL : nullptr;
     auto gs = [&](int i) -> float* { return ga ? ga + kItActOff[i] * kIfL : nullptr; };
     __syncthreads();
-    if_dense_layer<32, 0, 64>(packed + if_layer_offset(0), bias + kIfBiasAt[1], x1, x1, x2, wave, lane, gs(1));
+    if_dense_layer<32, 0, 64, NW>(packed + if_layer_offset(0), bias + kIfBiasAt[1], x1, x1, x2, wave, lane, gs(1));
     __syncthreads();
-    if_dense_layer<64, 0, 128>(packed + if_layer_offset(1), bias + kIfBiasAt[2], x2, x2, x3, wave, lane, gs(2));
+    if_dense_layer<64, 0, 128, NW>(packed + if_layer_offset(1), bias + kIfBiasAt[2], x2, x2, x3, wave, lane, gs(2));
     __syncthreads();
-    if_dense_layer<128, 0, 256>(packed + if_layer_offset(2), bias + kIfBiasAt[3], x3, x3, pa, wave, lane, gs(3));
+    if_dense_layer<128, 0, 256, NW>(packed + if_layer_offset(2), bias + kIfBiasAt[3], x3, x3, pa, wave, lane, gs(3));
     __syncthreads();
-    if_dense_layer<256, 0, 256>(packed + if_layer_offset(3), bias + kIfBiasAt[4], pa, pa, pb, wave, lane, gs(4));
+    if_dense_layer<256, 0, 256, NW>(packed + if_layer_offset(3), bias + kIfBiasAt[4], pa, pa, pb, wave, lane, gs(4));
     __syncthreads();
-    if_dense_layer<256, 128, 128>(packed + if_layer_offset(4), bias + kIfBiasAt[5], pb, x3, pa, wave, lane, gs(5));      // cat([x, x3], 1)
+    if_dense_layer<256, 128, 128, NW>(packed + if_layer_offset(4), bias + kIfBiasAt[5], pb, x3, pa, wave, lane, gs(5));      // cat([x, x3], 1)
     __syncthreads();
-    if_dense_layer<128, 64, 64>(packed + if_layer_offset(5), bias + kIfBiasAt[6], pa, x2, pb, wave, lane, gs(6));        // cat([x, x2], 1)
+    if_dense_layer<128, 64, 64, NW>(packed + if_layer_offset(5), bias + kIfBiasAt[6], pa, x2, pb, wave, lane, gs(6));        // cat([x, x2], 1)
     __syncthreads();
-    if_dense_layer<64, 32, 32>(packed + if_layer_offset(6), bias + kIfBiasAt[7], pb, x1, pa, wave, lane, gs(7));         // cat([x, x1], 1)
+    if_dense_layer<64, 32, 32, NW>(packed + if_layer_offset(6), bias + kIfBiasAt[7], pb, x1, pa, wave, lane, gs(7));         // cat([x, x1], 1)
     __syncthreads();
     if (tid < 32) {                                                                   // predictor 32 -> 2, sigmoid, permute back to [L][2]
       const float* w = packed + kIfHeadOff;

@@ -281,8 +281,10 @@ int inpaintnet_fused_forward_impl(Launcher& L, const float* x, const float* m, c
   if (!x || !m || !packed || !out || n <= 0) TNV3_FAIL(-1, "inpaintnet_fused_forward: bad argument");
   if (l != kIfL) TNV3_FAIL(-1, "inpaintnet_fused_forward: built for sequences of %d positions (got %d)", kIfL, l);
   if (((uintptr_t)packed) & 15) TNV3_FAIL(-1, "inpaintnet_fused_forward: the packed parameters must be 16-byte aligned");
+  if (n <= num_cus())                                    // latency form: one sequence per CU on eight waves (two per SIMD)
+    return L.launch(inpaintnet_fused_kernel<8>, n, 512, x, m, packed, out, n, (float*)nullptr);
   const int cap = 2 * num_cus();                         // two resident workgroups per CU (59 KB of LDS each); grid-stride beyond
-  return L.launch(inpaintnet_fused_kernel, n < cap ? n : cap, 256, x, m, packed, out, n, (float*)nullptr);
+  return L.launch(inpaintnet_fused_kernel<4>, n < cap ? n : cap, 256, x, m, packed, out, n, (float*)nullptr);
 }
 
 // ---- InpaintNet training step in three launches (kernels/inpaint_fused_train.h)
@@ -308,8 +310,9 @@ int inpaintnet_fused_forward_train_impl(Launcher& L, const float* x, const float
   if (!x || !m || !packed || !out || !acts || n <= 0) TNV3_FAIL(-1, "inpaintnet_fused_forward_train: bad argument");
   if (l != kIfL) TNV3_FAIL(-1, "inpaintnet_fused_forward_train: built for sequences of %d positions (got %d)", kIfL, l);
   if (((uintptr_t)packed) & 15) TNV3_FAIL(-1, "inpaintnet_fused_forward_train: the packed parameters must be 16-byte aligned");
+  if (n <= num_cus()) return L.launch(inpaintnet_fused_kernel<8>, n, 512, x, m, packed, out, n, acts);
   const int cap = 2 * num_cus();
-  return L.launch(inpaintnet_fused_kernel, n < cap ? n : cap, 256, x, m, packed, out, n, acts);
+  return L.launch(inpaintnet_fused_kernel<4>, n < cap ? n : cap, 256, x, m, packed, out, n, acts);
 }
 
 template <class Launcher>
