@@ -103,7 +103,9 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  *                                     6 = 5 re-tiled to 128 output channels x (4 x 32 pixels) per workgroup, the filter operand read
  *                                     straight from L2 into registers (kernels/conv3x3_wino6_mfma.h; Cout % 128 == 0, Cin > 8,
  *                                     W % 32 == 0; filters packed with layout 2); bit-identical to 2-5.
- *                                     -1 = tnv3_conv3x3_wino_pick(cin, cout): 6 where it applies, else 5 -- by channel counts only,
+ *                                     7 = the same kernel with a 64-channel x (4 x 64 pixels) workgroup tile (Cout % 64 == 0, Cin > 8,
+ *                                     W % 64 == 0; layout 2); bit-identical to 2-6.
+ *                                     -1 = tnv3_conv3x3_wino_pick(cin, cout): 6 for Cout % 128 == 0, 7 for Cout % 64 == 0 (both Cin > 8), else 5 -- by channel counts only,
  *                                     so a panel packed ahead of time is the one every call of that layer reads.
  *   `layout` of the pack calls: 0 = u[cin_pad][16][cout];  1 = u[cin_pad / 2][4][2][cout][4] (transform row major, the four xi of
  *                                     a row adjacent);  2 = u[cout / 32][cin_pad / 8][2][8][64][4] (the A operand in lane order). */

@@ -38,6 +38,9 @@ def main():
             if v in (6,) or 100 <= v < 120:
                 if cout % 128 or cin <= 8:
                     continue
+            if v in (7,) or 120 <= v < 130:
+                if cout % 64 or cin <= 8:
+                    continue
             u = ops.pack_wino_weights(wt, variant=v)      # the panel layout follows the kernel
             if v >= 10:                   # experimental arms live in libtnv3_diag.so (raw convolution, no affine)
                 y = torch.empty(10, cout, h, w, device=dev)

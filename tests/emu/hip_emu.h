@@ -303,6 +303,13 @@ inline tnv3_f2 tnv3_buf_load_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffse
   if (o + 8ull <= (unsigned long long)r.num_records) memcpy(&v, r.base + o, 8);
   return v;
 }
+typedef float tnv3_f4 __attribute__((ext_vector_type(4)));
+inline tnv3_f4 tnv3_buf_load_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
+  tnv3_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+  const unsigned long long o = (unsigned long long)voffset + soffset;
+  if (o + 16ull <= (unsigned long long)r.num_records) memcpy(&v, r.base + o, 16);
+  return v;
+}
 inline void tnv3_buf_store_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f2 v) {
   const unsigned long long o = (unsigned long long)voffset + soffset;
   if (o + 8ull <= (unsigned long long)r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 8);

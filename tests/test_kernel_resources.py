@@ -78,7 +78,8 @@ def test_conv_and_wgrad_budgets(resources):
     # variants 3 and 4 (one tile per workgroup), 5 (the streaming persistent kernel) and 6 (its 128-channel form with the filter operand
     # in registers -- which spilled 700+ registers until the two groups' programs were predicated instead of branched): the same budget
     for name in ("conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi0E", "conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi1ELi0ELi0ELi0E",
-                 "conv3x3_wino_stream_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi1E", "conv3x3_wino_a128_stream_kernelINS_9WinoV6CfgILi0ELi1ELi0ELi1ELi0E"):
+                 "conv3x3_wino_stream_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi1E", "conv3x3_wino_a128_stream_kernelINS_9WinoV6CfgILi0ELi1ELi0ELi1ELi0ELi1E",
+                 "conv3x3_wino_a128_stream_kernelINS_9WinoV6CfgILi0ELi1ELi0ELi1ELi0ELi2E"):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024

@@ -136,6 +136,12 @@ __device__ __forceinline__ tnv3_f2 tnv3_buf_load_f2(tnv3_rsrc_t r, unsigned voff
 __device__ __forceinline__ void tnv3_buf_store_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f2 v) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(tnv3_u2, v), r, (int)voffset, (int)soffset, 0);
 }
+// 16-byte load at base + voffset (per lane) + soffset (scalar / immediate): one 32-bit VGPR of address instead of a 64-bit pair per access
+typedef float tnv3_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned tnv3_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ tnv3_f4 tnv3_buf_load_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
+  return __builtin_bit_cast(tnv3_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, (int)soffset, 0));
+}
 #endif
 
 // Makes a per-lane value opaque to the optimiser at this point: what is derived from it afterwards cannot be hoisted out of the

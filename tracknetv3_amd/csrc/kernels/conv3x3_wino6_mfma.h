@@ -31,8 +31,12 @@ namespace tnv3 {
 
 constexpr int kWinoCinPadK = 24;     // = kWinoCinPad (tnv3_impl.h): packed filter rows are padded to a multiple of 24 input channels
 
-template <int DIAG_ = 0, int SWAP_ = 0, int PRIO_ = 0, int QB_ = 0, int ALATE_ = 0>
+template <int DIAG_ = 0, int SWAP_ = 0, int PRIO_ = 0, int QB_ = 0, int ALATE_ = 0, int WN_ = 1>
 struct WinoV6Cfg {
+  // WN = 1: 128 channels x 32 tiles (4 x 32 pixels) per workgroup -- variant 6.  WN = 2: 64 channels x 64 tiles (4 x 64 pixels) -- variant 7,
+  // the same kernel for layers with 64 output channels (the four 288 x 512 layers): the two waves of a channel block each load their own
+  // copy of the A quads (L1 hits), V of a chunk feeds 64 channels as in variant 5, but there is no filter stage in LDS, no ds_read for A,
+  // and the patch transform is the row-split, conflict-free one (two tile pairs per thread).
   // 1: "quad" V layout V[c][transform row R][tile][4] (the four xi of a row adjacent): ONE conflict-free ds_read_b128 feeds the B
   // operand of four MFMAs (8 instead of 32 LDS reads inside a wave's MFMA phase) and the transform stores a tile's row as one
   // ds_write_b128.  Every accumulator still sees its channel pairs in the same order => the same bits.
@@ -45,19 +49,23 @@ struct WinoV6Cfg {
   static constexpr int PRIO = PRIO_;                 // > 0: the MFMA-first group raises its priority (s_setprio) for its MFMA phase
   static constexpr int DIAG = DIAG_;                 // timing twins (WRONG results; libtnv3_diag.so): 10 no patch transform, 11 no raw DMA,
                                                      // 14 no A loads in the chunk loop, 13 none of the three
-  static constexpr int WM = 4, WN = 1, CC = 8;
-  static constexpr int NT = 2 * WM * WN * 64;        // 512 threads: waves 0-3 = xi group 0 (channel blocks 0-3), waves 4-7 = xi group 1
+  static constexpr int WN = WN_, WM = 4 / WN_, CC = 8;
+  static_assert(WN_ == 1 || WN_ == 2, "tile shapes");
+  static constexpr int NT = 2 * WM * WN * 64;        // 512 threads: waves 0-3 = xi group 0 (channel block wq / WN, tile half wq % WN), waves 4-7 = xi group 1
   static constexpr int MB = 32 * WM, TB = 32 * WN, PW = 32 * WN;
-  static constexpr int RW = PW + 8, RAWP = 6 * RW;   // raw halo tile per channel: 6 rows x 40 floats (columns w0-4 .. w0+35)
-  static constexpr int RAW_FLOATS = CC * RAWP;       // 1920 floats = 480 16-byte pieces: one per thread (32 idle)
-  static constexpr int RAW_STAGE = NT * 4;
-  static constexpr int VC = 16 * TB + 16;            // channel stride of V (padded: the transform's 8-byte stores of different channels miss each other's banks)
+  static constexpr int RW = PW + 8, RAWP = 6 * RW;   // raw halo tile per channel: 6 rows x (PW + 8) floats (columns w0-4 .. w0+PW+3)
+  static constexpr int RAW_FLOATS = CC * RAWP;       // WN = 1: 480 16-byte pieces (one per thread, 32 idle); WN = 2: 864 (two per thread)
+  static constexpr int NRAW = WN;
+  static constexpr int RAW_STAGE = NRAW * NT * 4;
+  static constexpr int VC = 16 * TB + (WN == 1 ? 16 : 0);   // channel stride of V (WN = 1: padded for the 8-byte stores of the non-quad form; WN = 2: LDS is full)
   static constexpr int V_FLOATS = CC * VC;
   static constexpr int XCH_FLOATS = (NT / 64) * 32 * 64;
   static constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * RAW_STAGE + XCH_FLOATS;
   static constexpr int A_CHUNK_FLOATS = 2 * 8 * 64 * 4;      // one (32-channel block, chunk) of the layout-2 panel: [xi group][q][lane][4]
-  static_assert(RAW_FLOATS / 4 <= NT, "one raw piece per thread");
-  static_assert(CC * 4 * 2 * (TB / 4) == NT, "one (channel, transform row, tile row, tile pair) per thread and chunk");
+  static_assert(RAW_FLOATS / 4 <= NRAW * NT, "every raw piece has a slot");
+  static_assert(CC * 4 * 2 * (TB / 4) == NT * WN, "WN (channel, transform row, tile row, tile pair) tasks per thread and chunk");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+  static_assert(WN == 1 || QB_ == 1, "the 64-channel form is built on the quad V layout");
 };
 
 template <class Cfg>
@@ -75,6 +83,8 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
   // and spill the 128 accumulators and the 32 filter registers between the two MFMA sites (700+ spills).
   const int grp_v = wave >> 2;
   const int half = lane >> 5, bl = lane & 31;
+  constexpr int WN = Cfg::WN, NRAW = Cfg::NRAW;
+  const int wm = wq / WN, wn = wq % WN;               // MFMA roles: 32-channel block, 32-tile half (WN = 2: tile row) of the workgroup tile
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
   const int tilesH = H / 4, tilesW = W / PW;
   const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
@@ -86,41 +96,54 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
   if (!walk.valid) return;
 
   // ---- raw LDS-DMA: piece e = tid of [CC][6][RW/4]; padding pieces and the 32 spare threads read out of range (= 0)
-  unsigned vo_r, vo_rn = kDmaOob;
-  auto raw_offset = [&](int h0, int w0) -> unsigned {
-    int e = tid;
-    TNV3_OPAQUE_V(e);                                 // recomputed per tile; nothing of it stays live across the chunk loop
-    const int c = e / (RAWP / 4), r = e - c * (RAWP / 4);
-    const int tr = r / (RW / 4), q = r - tr * (RW / 4);
-    const int gh = h0 - 1 + tr, gw = w0 - 4 + 4 * q;
-    const bool ok = e < Cfg::RAW_FLOATS / 4 && gh >= 0 && gh < H && gw >= 0 && gw < W;
-    return ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
+  unsigned vo_r[NRAW], vo_rn[NRAW];
+  auto raw_offset = [&](unsigned (&vo)[NRAW], int h0, int w0) {
+    int t_op = tid;
+    TNV3_OPAQUE_V(t_op);                              // recomputed per tile; nothing of it stays live across the chunk loop
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) {
+      const int e = t_op + i * NT;
+      const int c = e / (RAWP / 4), r = e - c * (RAWP / 4);
+      const int tr = r / (RW / 4), q = r - tr * (RW / 4);
+      const int gh = h0 - 1 + tr, gw = w0 - 4 + 4 * q;
+      const bool ok = e < Cfg::RAW_FLOATS / 4 && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      vo[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
+    }
   };
   int c_n = walk.n, c_h0 = walk.trow * 4, c_w0 = walk.tcol * PW, c_m0 = walk.mb * MB, c_pt = walk.pt;
-  vo_r = raw_offset(c_h0, c_w0);
+  raw_offset(vo_r, c_h0, c_w0);
   walk.next();
   bool have_next = walk.valid;
   int n_n = walk.n, n_h0 = walk.trow * 4, n_w0 = walk.tcol * PW, n_m0 = walk.mb * MB, n_pt = walk.pt;
-  if (have_next) vo_rn = raw_offset(n_h0, n_w0);
+#pragma unroll
+  for (int i = 0; i < NRAW; ++i) vo_rn[i] = kDmaOob;
+  if (have_next) raw_offset(vo_rn, n_h0, n_w0);
 
   const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);      // scalar: the LDS-DMA destination (M0) stays on the SALU
   const size_t x_step = (size_t)CC * HW;                            // floats per chunk of the input
-  auto dma_r = [&](const float* xp, int cvalid, unsigned vo, int sr) {
+  auto dma_r = [&](const float* xp, int cvalid, const unsigned (&vo)[NRAW], int sr) {
     if constexpr (Cfg::DIAG == 11 || Cfg::DIAG == 13) return;
     const tnv3_rsrc_t rr = tnv3_make_rsrc(xp, (unsigned)(cvalid < CC ? cvalid : CC) * (unsigned)HW * 4u);   // channels past Cin: beyond num_records, zero
-    tnv3_buf_dma16(rr, raw_s + sr * Cfg::RAW_STAGE + wbase * 4, vo);
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) tnv3_buf_dma16(rr, raw_s + sr * Cfg::RAW_STAGE + (i * NT + wbase) * 4, vo[i]);
   };
   // ---- A operand: this wave's slice of the layout-2 panel, chunk by chunk: [q = channel pair * 2 + xi quad][lane][4]
   const size_t a_step = Cfg::A_CHUNK_FLOATS;                         // floats from one chunk of a 32-channel block to the next
   auto a_base = [&](int m0) -> const float* {
-    return a.u + ((size_t)(m0 / 32 + wq) * nChunksPad) * Cfg::A_CHUNK_FLOATS + grp * (8 * 64 * 4);
+    return a.u + ((size_t)(m0 / 32 + wm) * nChunksPad) * Cfg::A_CHUNK_FLOATS + grp * (8 * 64 * 4);
   };
   const float* c_a = a_base(c_m0);
   const float* n_a = a_base(n_m0);
   const float* c_x = a.src + (size_t)c_n * Cin * HW;
   const float* n_x = a.src + (size_t)n_n * Cin * HW;
   f32x4 av[8];
-  auto load_a = [&](const float* p, int q) { av[q] = *reinterpret_cast<const f32x4*>(p + q * 256 + lane * 4); };
+  // through a buffer descriptor on the (scalar) slice base: the per-lane part of the address is ONE 32-bit register (lane * 16) and the
+  // quad index an immediate -- 64-bit per-lane pointers cost three register pairs and six VALU additions per chunk
+  const unsigned a_lane_b = (unsigned)lane * 16u;
+  auto load_a = [&](const float* p, int q) {
+    const tnv3_rsrc_t ra = tnv3_make_rsrc(p, 8u * 64u * 16u);
+    av[q] = tnv3_buf_load_f4(ra, a_lane_b, (unsigned)q * 1024u);
+  };
 
   // ---- patch transform: wave -> transform row R = 2 grp + (wq & 1) and channel half cs = wq >> 1; lane -> (channel, tile row,
   //      tile pair).  Lanes 4r .. 4r+3 are one run of four consecutive tile pairs; ds_read_b128 serves the lane groups
@@ -136,48 +159,65 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
   const int t_dst = Cfg::QB ? t_c * VC + tR * (TB * 4) + (t_tr * (TB / 2) + 2 * t_pj) * 4       // [c][R][tile][4]
                             : t_c * VC + (tR * 4) * TB + t_tr * (TB / 2) + 2 * t_pj;
   typedef float wf2 __attribute__((ext_vector_type(2)));
-  float txa[6], txb[6];
-  auto transform_read = [&](int stage) {                // patch columns 4pj+3 .. 4pj+8 of the two raw rows this transform row needs
+  // WN tasks per thread: tile pairs t_pj and (WN = 2) t_pj + 8 of the same (channel, tile row) -- 32 floats further along the raw rows
+  // (the second task is read and finished after the first one's stores: twelve live patch registers, not twenty-four)
+  float txa[1][6], txb[1][6];
+  auto transform_read_k = [&](int stage, int kk) {      // patch columns 4pj+3 .. 4pj+8 of the two raw rows this transform row needs
     if constexpr (Cfg::DIAG == 10 || Cfg::DIAG == 13) return;
-    const float* d = raw_s + stage * Cfg::RAW_STAGE;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(d + t_srcA), a1 = *reinterpret_cast<const f32x4*>(d + t_srcA + 4);
-    const wf2 a2 = *reinterpret_cast<const wf2*>(d + t_srcA + 8);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(d + t_srcB), b1 = *reinterpret_cast<const f32x4*>(d + t_srcB + 4);
-    const wf2 b2 = *reinterpret_cast<const wf2*>(d + t_srcB + 8);
-    txa[0] = a0[3]; txa[1] = a1[0]; txa[2] = a1[1]; txa[3] = a1[2]; txa[4] = a1[3]; txa[5] = a2[0];
-    txb[0] = b0[3]; txb[1] = b1[0]; txb[2] = b1[1]; txb[3] = b1[2]; txb[4] = b1[3]; txb[5] = b2[0];
+    const float* d = raw_s + stage * Cfg::RAW_STAGE + 32 * kk;
+#pragma unroll
+    for (int k = 0; k < 1; ++k) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(d + t_srcA + 32 * k), a1 = *reinterpret_cast<const f32x4*>(d + t_srcA + 32 * k + 4);
+      const wf2 a2 = *reinterpret_cast<const wf2*>(d + t_srcA + 32 * k + 8);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(d + t_srcB + 32 * k), b1 = *reinterpret_cast<const f32x4*>(d + t_srcB + 32 * k + 4);
+      const wf2 b2 = *reinterpret_cast<const wf2*>(d + t_srcB + 32 * k + 8);
+      txa[k][0] = a0[3]; txa[k][1] = a1[0]; txa[k][2] = a1[1]; txa[k][3] = a1[2]; txa[k][4] = a1[3]; txa[k][5] = a2[0];
+      txb[k][0] = b0[3]; txb[k][1] = b1[0]; txb[k][2] = b1[1]; txb[k][3] = b1[2]; txb[k][4] = b1[3]; txb[k][5] = b2[0];
+    }
   };
-  auto transform_finish = [&](int stage) {              // raw stage -> V stage of the same parity
+  auto transform_finish_k = [&](int stage, int kk) {    // raw stage -> V stage of the same parity
     if constexpr (Cfg::DIAG == 10 || Cfg::DIAG == 13) return;
-    float e[6];
-    if (tR == 1) {                                      // (B^T d) row 1 = d1 + d2; rows 0, 2, 3 = d0 - d2, d2 - d1, d1 - d3
 #pragma unroll
-      for (int j = 0; j < 6; ++j) e[j] = txa[j] + txb[j];
-    } else {
+    for (int k = 0; k < 1; ++k) {
+      float e[6];
+      if (tR == 1) {                                      // (B^T d) row 1 = d1 + d2; rows 0, 2, 3 = d0 - d2, d2 - d1, d1 - d3
 #pragma unroll
-      for (int j = 0; j < 6; ++j) e[j] = txa[j] - txb[j];
+        for (int j = 0; j < 6; ++j) e[j] = txa[k][j] + txb[k][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) e[j] = txa[k][j] - txb[k][j];
+      }
+      if constexpr (Cfg::QB) {                            // the four xi of this row, tile 2pj then tile 2pj + 1: two 16-byte stores
+        float* v = v_s + stage * Cfg::V_FLOATS + t_dst + 64 * kk;     // 16 tiles x 4 floats further
+        f32x4 o4;
+        o4[0] = e[0] - e[2]; o4[1] = e[1] + e[2]; o4[2] = e[2] - e[1]; o4[3] = e[1] - e[3];
+        *reinterpret_cast<f32x4*>(v) = o4;
+        o4[0] = e[2] - e[4]; o4[1] = e[3] + e[4]; o4[2] = e[4] - e[3]; o4[3] = e[3] - e[5];
+        *reinterpret_cast<f32x4*>(v + 4) = o4;
+      } else {
+        float* v = v_s + stage * Cfg::V_FLOATS + t_dst + 16 * kk;
+        wf2 o;
+        o[0] = e[0] - e[2]; o[1] = e[2] - e[4]; *reinterpret_cast<wf2*>(v + 0 * TB) = o;
+        o[0] = e[1] + e[2]; o[1] = e[3] + e[4]; *reinterpret_cast<wf2*>(v + 1 * TB) = o;
+        o[0] = e[2] - e[1]; o[1] = e[4] - e[3]; *reinterpret_cast<wf2*>(v + 2 * TB) = o;
+        o[0] = e[1] - e[3]; o[1] = e[3] - e[5]; *reinterpret_cast<wf2*>(v + 3 * TB) = o;
+      }
     }
-    float* v = v_s + stage * Cfg::V_FLOATS + t_dst;
-    if constexpr (Cfg::QB) {                              // the four xi of this row, tile 2pj then tile 2pj + 1: two 16-byte stores
-      f32x4 o4;
-      o4[0] = e[0] - e[2]; o4[1] = e[1] + e[2]; o4[2] = e[2] - e[1]; o4[3] = e[1] - e[3];
-      *reinterpret_cast<f32x4*>(v) = o4;
-      o4[0] = e[2] - e[4]; o4[1] = e[3] + e[4]; o4[2] = e[4] - e[3]; o4[3] = e[3] - e[5];
-      *reinterpret_cast<f32x4*>(v + 4) = o4;
-      return;
-    }
-    wf2 o;
-    o[0] = e[0] - e[2]; o[1] = e[2] - e[4]; *reinterpret_cast<wf2*>(v + 0 * TB) = o;
-    o[0] = e[1] + e[2]; o[1] = e[3] + e[4]; *reinterpret_cast<wf2*>(v + 1 * TB) = o;
-    o[0] = e[2] - e[1]; o[1] = e[4] - e[3]; *reinterpret_cast<wf2*>(v + 2 * TB) = o;
-    o[0] = e[1] - e[3]; o[1] = e[3] - e[5]; *reinterpret_cast<wf2*>(v + 3 * TB) = o;
   };
 
+  auto transform_read = [&](int stage) { transform_read_k(stage, 0); };
+  auto transform_finish = [&](int stage) {              // finishes task 0, then (WN = 2) reads and finishes task 1
+    transform_finish_k(stage, 0);
+    if constexpr (WN == 2) {
+      transform_read_k(stage, 1);
+      transform_finish_k(stage, 1);
+    }
+  };
   f32x16 acc[8];
   f32x16 zero16;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
-  const int b_off = Cfg::QB ? half * VC + (2 * grp) * (TB * 4) + bl * 4 : half * VC + (grp * 8) * TB + bl;
+  const int b_off = Cfg::QB ? half * VC + (2 * grp) * (TB * 4) + (wn * 32 + bl) * 4 : half * VC + (grp * 8) * TB + wn * 32 + bl;
   // One chunk of MFMAs: step s = (channel pair cp, xi x of this group); A from registers, B from the V stage four steps ahead.
   // Right behind the four MFMAs that consumed a quad, its registers are re-loaded with the NEXT chunk's quad from `anext` (always a
   // valid address: the last chunk of the last tile re-reads its own -- unconditional loads keep the MFMA stream one basic block).
@@ -186,20 +226,21 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
     const float* B = v_s + stage * Cfg::V_FLOATS + b_off;
     constexpr int NSTEP = (CC / 2) * 8;
     if constexpr (Cfg::QB) {                              // step s = (cp, x): B quad (cp, x >> 2) = one 16-byte read, two quads ahead
-      f32x4 bq[3];
-      auto read_quad = [&](int qd) { bq[qd % 3] = *reinterpret_cast<const f32x4*>(B + (2 * (qd >> 1)) * VC + (qd & 1) * (TB * 4)); };
+      constexpr int BR = WN == 2 ? 2 : 3;                 // quads in flight (the 64-channel form has no registers to spare: one quad = four MFMAs ahead)
+      f32x4 bq[BR];
+      auto read_quad = [&](int qd) { bq[qd % BR] = *reinterpret_cast<const f32x4*>(B + (2 * (qd >> 1)) * VC + (qd & 1) * (TB * 4)); };
       read_quad(0);
-      read_quad(1);
+      if constexpr (BR == 3) read_quad(1);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         // full fences: the read of quad q + 2 goes out BEFORE the four MFMAs of quad q (with class-only group barriers the scheduler
         // satisfied "one LDS read per group" with the read needed NEXT and the ring collapsed to read -> wait -> use)
-        if (q + 2 < 8) read_quad(q + 2);
+        if (q + BR - 1 < 8) read_quad(q + BR - 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int s = 4 * q + j;
-          acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bq[q % 3][j], FIRST && s < 8 ? zero16 : acc[s & 7], 0, 0, 0);
+          acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bq[q % BR][j], FIRST && s < 8 ? zero16 : acc[s & 7], 0, 0, 0);
         }
         if constexpr (Cfg::DIAG != 14 && Cfg::DIAG != 13 && !Cfg::ALATE) load_a(anext, q);
         __builtin_amdgcn_sched_barrier(0);
@@ -356,13 +397,14 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_a128_stream_kernel(const
     ++n_tiles_done;
     if (!have_next) break;
     c_n = n_n; c_h0 = n_h0; c_w0 = n_w0; c_m0 = n_m0; c_pt = n_pt; c_a = n_a; c_x = n_x;
-    vo_r = vo_rn;
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) vo_r[i] = vo_rn[i];
     walk.next();
     have_next = walk.valid;
     n_n = walk.n; n_h0 = walk.trow * 4; n_w0 = walk.tcol * PW; n_m0 = walk.mb * MB; n_pt = walk.pt;
     n_a = a_base(n_m0);
     n_x = a.src + (size_t)n_n * Cin * HW;
-    if (have_next) vo_rn = raw_offset(n_h0, n_w0);
+    if (have_next) raw_offset(vo_rn, n_h0, n_w0);
     stamp(7);
   }
   if constexpr (Cfg::DIAG == 7) {                       // [wave][10]: six chunk phases, write-out, tile advance, chunks, tiles

@@ -496,9 +496,9 @@ using WinoV5 = WinoV3Cfg<8, 0, 0, 0, 0, 0, 0, 1>;   // persistent workgroups, th
 // persistent launch: one workgroup per CU, a whole number of XCD rounds so that a workgroup's tiles all map to its XCD
 inline int wino_persistent_grid(int items) { const int g = std::max(8, num_cus() / 8 * 8); return items < g ? items : g; }
 // filter pack layout a kernel variant expects (tnv3_conv3x3_wino_layout)
-inline int conv3x3_wino_layout(int variant) { return (variant == 6 || (variant >= 100 && variant < 120)) ? 2 : ((variant == 4 || variant == 47 || variant == 44) ? 1 : 0); }
+inline int conv3x3_wino_layout(int variant) { return (variant == 6 || variant == 7 || (variant >= 100 && variant < 130)) ? 2 : ((variant == 4 || variant == 47 || variant == 44) ? 1 : 0); }
 // kernel variants whose epilogue can emit the BatchNorm batch statistics (tnv3_conv3x3_wino_has_stats)
-inline bool conv3x3_wino_has_stats(int variant) { return variant == 3 || variant == 4 || variant == 5 || variant == 6; }
+inline bool conv3x3_wino_has_stats(int variant) { return variant == 3 || variant == 4 || variant == 5 || variant == 6 || variant == 7; }
 constexpr int kWinoCinPad = 24;              // filter rows are padded to a multiple of both chunk sizes
 constexpr int kWinoDefaultVariant = 5;       // per-call `variant`: 5 streaming persistent kernel, 6 its 128-channel form with the filter operand
                                              // straight from L2 (conv3x3_wino6_mfma.h), 3 WinoV3, 2 WinoSplit, 4 WinoV4 (quad layouts),
@@ -506,7 +506,10 @@ constexpr int kWinoDefaultVariant = 5;       // per-call `variant`: 5 streaming 
 static_assert(kWinoCinPad == kWinoCinPadK, "conv3x3_wino6_mfma.h carries its own copy of the filter row padding");
 // What `variant` -1 means for a layer: by CHANNEL counts only, so that a filter panel packed ahead of the first forward (its
 // layout follows the variant) is the one every later call of that layer reads, whatever the image size.
-inline int conv3x3_wino_pick(int cin, int cout) { return (cout % WinoV6Cfg<>::MB == 0 && cin > WinoV6Cfg<>::CC) ? 6 : kWinoDefaultVariant; }
+inline int conv3x3_wino_pick(int cin, int cout) {
+  if (cin <= WinoV6Cfg<>::CC) return kWinoDefaultVariant;
+  return cout % 128 == 0 ? 6 : (cout % 64 == 0 ? 7 : kWinoDefaultVariant);      // 7: the same kernel with a 64-channel x 64-tile workgroup tile
+}
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
   return (size_t)round_up(cin, kWinoCinPad) * 16 * cout + kPackZeroTail;
@@ -545,6 +548,28 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
   if (stats && (scale || shift || mean)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue writes the raw convolution (no affine)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino: statistics buffer must be 8-byte aligned");
   const bool is_v6 = variant == 6 || (variant >= 100 && variant < 120);
+  const bool is_v7 = variant == 7 || (variant >= 120 && variant < 130);
+  if (is_v7) {     // the 64-channel form of kernel 6: 64 channels x (4 x 64 pixels) per workgroup, filters packed with layout 2
+    using V7 = WinoV6Cfg<0, 1, 0, 1, 0, 2>;
+    if (stats && (scale || shift || mean)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue writes the raw convolution (no affine)");
+    if (h % 4 || cout % V7::MB || w % V7::PW || cin <= V7::CC)
+      TNV3_FAIL(-1, "conv3x3_wino (variant 7): needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0, Cin > %d (got %d -> %d, %dx%d)", V7::MB, V7::PW, V7::CC, cin, cout, h, w);
+    if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino: inconsistent affine arguments");
+    if ((long)cin * h * w * 4 >= (1l << 31) || (long)V7::MB * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino (variant 7): one sample of the input / 64 output planes must stay below 2 GiB");
+    if ((bn_z != nullptr) != (bn_c4 != nullptr) || (bn_z && (!stats || addend || relu))) TNV3_FAIL(-1, "conv3x3_wino: inconsistent BatchNorm-backward statistics arguments");
+    if ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)u | (uintptr_t)bn_c4) & 15) != 0)
+      TNV3_FAIL(-1, "conv3x3_wino (variant 7): filters / mean / scale / shift must be 16-byte aligned");
+    const float* zeros7 = u + (size_t)round_up(cin, kWinoCinPad) * 16 * cout;
+    WinoArgs a7{src, u, zeros7, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, bn_z, bn_c4};
+    const long npt7 = (long)n * (h / 4) * (w / V7::PW);
+    if (npt7 > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino: too many pixel tiles");
+    const int grid7 = wino_persistent_grid(conv_grid_blocks(cout / V7::MB, (int)npt7));
+#ifdef TNV3_DIAG
+    if (variant == 121) return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 0, 0, 1, 0, 2>>, grid7, V7::NT, a7);     // younger waves' MFMAs first
+#endif
+    if (variant != 7) TNV3_FAIL(-1, "conv3x3_wino: unknown kernel variant %d", variant);
+    return L.launch(conv3x3_wino_a128_stream_kernel<V7>, grid7, V7::NT, a7);
+  }
   if (is_v6 ? (h % 4 != 0) : !conv3x3_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino: inconsistent affine arguments");

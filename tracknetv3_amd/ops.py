@@ -80,7 +80,7 @@ def wino_variant_has_stats(variant=None):
         variant = tuning.WINO_VARIANT
     lib = _lib.load()
     if int(variant) < 0:
-        return all(bool(lib.tnv3_conv3x3_wino_has_stats(int(lib.tnv3_conv3x3_wino_pick(ci, co)))) for ci, co in ((64, 64), (128, 128)))
+        return all(bool(lib.tnv3_conv3x3_wino_has_stats(int(lib.tnv3_conv3x3_wino_pick(ci, co)))) for ci, co in ((8, 64), (64, 64), (128, 128)))
     return bool(lib.tnv3_conv3x3_wino_has_stats(int(variant)))
 
 
