@@ -38,6 +38,11 @@ int tnv3_diag_conv3x3_forward(const float* src0, const float* wpack, float* dst,
 int tnv3_diag_conv3x3_wino_forward(const float* src, const float* u, float* dst, int n, int cin, int cout, int h, int w,
                                    int variant, tnv3_stream_t stream);
 
+/* tnv3_conv3x3_wgrad_wino with the timing twins of its third-generation kernel (kernels/wgrad_wino_mfma.h: WgradWino3Cfg<3, DIAG>):
+ * variant 101 no operand transforms, 102 no strip DMA, 103 no MFMAs (operand reads kept); 0-3 as in the product library. */
+int tnv3_diag_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes, int n, int cin,
+                                 int cout, int h, int w, int variant, tnv3_stream_t stream);
+
 /* What an instruction costs next to a stream of v_mfma_f32_32x32x2_f32 (kernels/coissue_probe.h): `blocks` workgroups of 8
  * waves (one per CU; waves w and w + 4 share a SIMD); waves 0-3 run role_a, waves 4-7 role_b, `iters` x 8 steps each; out
  * [blocks][8] uint64 = each wave's s_memtime cycles.  gsrc_1mb: any device buffer of >= 1 MiB (source of the LDS-DMA role). */

@@ -20,6 +20,7 @@ def load():
         for name, args in (("tnv3_diag_mfma_f32_probe", [p, i, i, p]),
                            ("tnv3_diag_conv3x3_forward", [p, p, p, i, i, i, i, i, i, i, p]),
                            ("tnv3_diag_conv3x3_wino_forward", [p, p, p, i, i, i, i, i, i, p]),
+                           ("tnv3_diag_conv3x3_wgrad_wino", [p, p, p, p, ctypes.c_size_t, i, i, i, i, i, i, p]),
                            ("tnv3_diag_coissue_probe", [p, p, i, i, i, i, p])):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = i, args
@@ -51,3 +52,16 @@ def conv3x3_wino_forward(x, u, y, variant):
 def coissue_probe(out_u64, gsrc, blocks, role_a, role_b, iters):
     check(load().tnv3_diag_coissue_probe(_lib.ptr(out_u64), _lib.ptr(gsrc), int(blocks), int(role_a), int(role_b), int(iters),
                                          _lib.stream_ptr(gsrc)))
+
+
+def conv3x3_wgrad_wino(x, dz, variant):
+    """dW through the diag library (timing twins 101-103 of the third-generation Winograd weight-gradient kernel: WRONG results)."""
+    import torch
+    from tracknetv3_amd import ops
+    n, cout, h, w = (int(v) for v in dz.shape)
+    cin = int(x.shape[1])
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dz.device)
+    ws = ops._workspace(_lib.load().tnv3_conv3x3_wgrad_wino_workspace_bytes(n, cin, cout, h, w), dz.device)
+    check(load().tnv3_diag_conv3x3_wgrad_wino(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8, n, cin, cout, h, w,
+                                              int(variant), _lib.stream_ptr(dz)))
+    return dw

@@ -1,10 +1,19 @@
 """A/B of the Winograd-form weight-gradient kernels (variant 0: one wave per SIMD, phases alternate; 1: two waves per SIMD,
-wave groups half a period apart) on TrackNet's plain-layer shapes, batch 10: ms per call (kernel + fold), executed TFLOP/s,
-bit-equality.  usage: wgrad_wino_ab.py [variant ...]"""
+wave groups half a period apart; 2 / 3: 16-byte operand reads, two / three raw stages; >= 100: timing twins through libtnv3_diag.so)
+on TrackNet's plain-layer shapes, batch 10: ms per call (kernel + fold), executed TFLOP/s, bit-equality.
+usage: wgrad_wino_ab.py [variant ...]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tracknetv3_amd import ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def wgrad(x, dz, v):
+    if v >= 100:
+        import diaglib
+        return diaglib.conv3x3_wgrad_wino(x, dz, v)
+    return ops.conv3x3_wgrad_wino(x, dz, variant=v)
 
 SHAPES = ((64, 64, 288, 512), (64, 128, 144, 256), (128, 128, 144, 256), (128, 256, 72, 128), (256, 256, 72, 128), (256, 512, 36, 64),
           (512, 512, 36, 64))
@@ -34,8 +43,8 @@ def main():
         row, ref = {}, None
         for rep in range(2):                      # second round: clocks settled, order effects visible
             for v in variants:
-                dw = ops.conv3x3_wgrad_wino(x, dz, variant=v)
-                ms = timeit(lambda: ops.conv3x3_wgrad_wino(x, dz, variant=v))
+                dw = wgrad(x, dz, v)
+                ms = timeit(lambda: wgrad(x, dz, v))
                 row[f"v{v}"] = {"ms": round(ms, 4), "executed_tflops": round(gf / ms, 1)}
                 if ref is None:
                     ref = dw

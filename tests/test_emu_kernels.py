@@ -420,7 +420,7 @@ def test_conv3x3_wino_128_channel_kernel_is_bit_identical_to_the_streaming_kerne
     x, wt = torch.relu(T((n, cin, h, w), 191)), T((cout, cin, 3, 3), 192, -0.3, 0.3)
     mean, scale, shift, add = T((cout,), 193), T((cout,), 194, 0.5, 1.5), T((cout,), 195), T((n, cout, h, w), 196)
     assert ops.wino_variant(-1, cin, cout) == 6 and ops.wino_layout(-1, cin, cout) == 2 and ops.wino_layout(6, cin, cout) == 2
-    assert ops.wino_variant(-1, cin, 64) == 7 and ops.wino_variant(-1, 8, cout) == 5 and ops.wino_variant(3, cin, cout) == 3
+    assert ops.wino_variant(-1, cin, 64) == 5 and ops.wino_variant(-1, 8, cout) == 5 and ops.wino_variant(3, cin, cout) == 3
     u3, u6 = ops.pack_wino_weights(wt, variant=3), ops.pack_wino_weights(wt, variant=6)
     assert u3.numel() == u6.numel() and not torch.equal(u3, u6)
     assert torch.equal(u3.sort().values, u6.sort().values)                      # the same numbers in another order
@@ -442,7 +442,8 @@ def test_conv3x3_wino_128_channel_kernel_is_bit_identical_to_the_streaming_kerne
             assert (got_full.double() - full).abs().max().item() <= 3e-6 * max(full.abs().max().item(), ref.abs().max().item())
 
 
-# variant 7: the same kernel with a 64-channel x 64-tile workgroup tile (two tile pairs per transform thread, two raw pieces per thread)
+# variant 7: the same kernel with a 64-channel x 64-tile workgroup tile (two tile pairs per transform thread, two raw pieces per thread);
+# selectable, not picked by -1 (measured 2-5 % slower than variant 5)
 WINO7_CASES = [(2, 16, 64, 8, 64), (1, 27, 64, 12, 192), (3, 20, 192, 4, 64), (1, 64, 64, 8, 128)]
 
 
@@ -452,7 +453,7 @@ def test_conv3x3_wino_64_channel_form_is_bit_identical_to_the_streaming_kernel(e
     n, cin, cout, h, w = case
     x, wt = torch.relu(T((n, cin, h, w), 391)), T((cout, cin, 3, 3), 392, -0.3, 0.3)
     mean, scale, shift, add = T((cout,), 393), T((cout,), 394, 0.5, 1.5), T((cout,), 395), T((n, cout, h, w), 396)
-    assert ops.wino_variant(-1, cin, cout) == 7 and ops.wino_layout(7, cin, cout) == 2
+    assert ops.wino_variant(-1, cin, cout) == (6 if cout % 128 == 0 and cin > 8 else 5) and ops.wino_layout(7, cin, cout) == 2
     u5, u7 = ops.pack_wino_weights(wt, variant=5), ops.pack_wino_weights(wt, variant=7)
     want = ops.conv3x3_wino(x, u5, cout, variant=5)
     want_full = ops.conv3x3_wino(x, u5, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=5)

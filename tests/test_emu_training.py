@@ -118,9 +118,9 @@ def _wgrad_wino_case(case, device):
     F.conv2d(x.double(), wd, padding=1).backward(dz.double())
     dw = ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))
     assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))), "split-K reduction must be deterministic"
-    # the two kernel generations accumulate every element in the same order: bit-identical gradients
-    assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=0))
-    assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=1))
+    # every kernel generation accumulates every element in the same order: bit-identical gradients
+    for v in (0, 1, 2, 3, 4, 5):
+        assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=v)), v
     return rel_err(dw.cpu(), wd.grad)
 
 

@@ -118,14 +118,14 @@ def test_conv3x3_wino_128_channel_kernel_vs_torch_and_streaming_kernel(gpu_devic
 
 @pytest.mark.parametrize("case", [(2, 16, 64, 8, 64), (1, 27, 64, 12, 192), (2, 27, 64, 288, 512), (2, 64, 64, 288, 512), (3, 20, 192, 4, 64)])
 def test_conv3x3_wino_64_channel_form_vs_streaming_kernel(gpu_device, case):
-    """Variant 7 (the 128-channel kernel's 64-channel x 64-tile form: what -1 picks for the 288 x 512 layers): bit-identical to variant 5
+    """Variant 7 (the 128-channel kernel's 64-channel x 64-tile form; selectable, -1 keeps variant 5 for 64-channel layers): bit-identical to variant 5
     -- plain, affine + addend + ReLU, statistics epilogue -- and run-to-run identical."""
     from tracknetv3_amd import ops
     n, cin, cout, h, w = case
     d = gpu_device
     x, wt = torch.relu(T((n, cin, h, w), 391)).to(d), T((cout, cin, 3, 3), 392, -0.3, 0.3).to(d)
     mean, scale, shift, add = T((cout,), 393).to(d), T((cout,), 394, 0.5, 1.5).to(d), T((cout,), 395).to(d), T((n, cout, h, w), 396).to(d)
-    assert ops.wino_variant(-1, cin, cout) == 7
+    assert ops.wino_variant(-1, cin, 64) == 5
     u5, u7 = ops.pack_wino_weights(wt, variant=5), ops.pack_wino_weights(wt, variant=7)
     assert torch.equal(ops.conv3x3_wino(x, u5, cout, variant=5), ops.conv3x3_wino(x, u7, cout, variant=7))
     full5 = ops.conv3x3_wino(x, u5, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=5)

@@ -83,8 +83,11 @@ def test_conv_and_wgrad_budgets(resources):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
-    k = _find(resources, "wgrad_wino2_mfma_kernel")                                     # Winograd weight gradient, two waves per SIMD
-    assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+    # Winograd weight gradient, two waves per SIMD: the role-split generations and the production kernel (every wave streams and transforms)
+    for name in ("wgrad_wino2_mfma_kernel", "wgrad_wino3_mfma_kernelINS_13WgradWino3CfgILi3ELi0ELi1E", "wgrad_wino5_mfma_kernelINS_13WgradWino5CfgILi3ELi0E"):
+        k = _find(resources, name)
+        assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+        assert k["LDS Size [bytes/block]"] <= 160 * 1024
     for name, occ in (("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi2ELi4ELi2ELi4E", 4), ("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi1ELi4ELi2ELi4E", 4),
                       ("dgrad_up2x_mfma_kernelINS_12DgradUp2xCfgILi2ELi2ELi4ELi1ELi2E", 4)):
         k = _find(resources, name)

@@ -508,7 +508,9 @@ static_assert(kWinoCinPad == kWinoCinPadK, "conv3x3_wino6_mfma.h carries its own
 // layout follows the variant) is the one every later call of that layer reads, whatever the image size.
 inline int conv3x3_wino_pick(int cin, int cout) {
   if (cin <= WinoV6Cfg<>::CC) return kWinoDefaultVariant;
-  return cout % 128 == 0 ? 6 : (cout % 64 == 0 ? 7 : kWinoDefaultVariant);      // 7: the same kernel with a 64-channel x 64-tile workgroup tile
+  // (7, the same kernel with a 64-channel x 64-tile workgroup tile, is parity-green but 2-5 % slower than 5 on every shape,
+  //  profiles/r03_wino7_ab.json: the gain of 6 is the 128-row tile -- half the patch transforms per MFMA -- not the operand path)
+  return cout % 128 == 0 ? 6 : kWinoDefaultVariant;
 }
 inline size_t conv3x3_wino_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
@@ -929,14 +931,33 @@ inline size_t wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w)
   return kWgradZeroBytes + (size_t)wgrad_wino_splitk(n, cin, cout, h, w) * 16 * cout * cin * sizeof(float);
 }
 
-constexpr int kWgradWinoDefaultVariant = 1;     // 1: two waves per SIMD, wave groups half a period apart; 0: the first kernel
+// 5: no roles -- every wave streams its MFMAs and transforms the next chunk between them (12 % over 1 on every TrackNet shape,
+// profiles/r03_wgrad_wino5_ab.json); 1: two waves per SIMD, wave groups half a period apart; 2-4: 1 with 16-byte operand reads, three
+// raw stages, the Yh transform moved into the MFMA phase (0-5 % over 1); 0: the first kernel.  All six are bit-identical.
+constexpr int kWgradWinoDefaultVariant = 5;
 template <class Launcher>
 int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
   const int grid = (a.Cout / 64) * (a.Cin / 64) * a.splitK;
   if (variant < 0) variant = kWgradWinoDefaultVariant;
   if (variant == 0) return L.launch(wgrad_wino_mfma_kernel, grid, WgradWinoCfg::NT, a);
-  if ((long)64 * a.H * a.W * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (variant 1): 64 channel planes must stay below 2 GiB");
-  return L.launch(wgrad_wino2_mfma_kernel, grid, WgradWino2Cfg::NT, a);
+  if ((long)64 * a.H * a.W * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (variants 1-3): 64 channel planes must stay below 2 GiB");
+  if (variant == 1) return L.launch(wgrad_wino2_mfma_kernel, grid, WgradWino2Cfg::NT, a);
+  if (variant == 2) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<2>>, grid, 512, a);
+  if (variant == 3) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3>>, grid, 512, a);
+  if (variant == 4) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 0, 1>>, grid, 512, a);
+  if (variant == 5) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<3>>, grid, 512, a);
+#ifdef TNV3_DIAG
+  if (variant == 101) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 1>>, grid, 512, a);   // no transforms
+  if (variant == 102) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 2>>, grid, 512, a);   // no DMA
+  if (variant == 103) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 3>>, grid, 512, a);   // no MFMAs
+  if (variant == 111) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 1, 1>>, grid, 512, a);   // the split schedule: no transforms
+  if (variant == 112) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 2, 1>>, grid, 512, a);   // no DMA
+  if (variant == 113) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 3, 1>>, grid, 512, a);   // no MFMAs
+  if (variant == 121) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<3, 1>>, grid, 512, a);   // kernel 4: no transforms
+  if (variant == 122) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<3, 2>>, grid, 512, a);   // no DMA
+  if (variant == 123) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<3, 3>>, grid, 512, a);   // no MFMAs
+#endif
+  TNV3_FAIL(-1, "conv3x3_wgrad_wino: unknown kernel variant %d", variant);
 }
 
 template <class Launcher>

@@ -68,7 +68,7 @@ def use_winograd_wgrad(cin, cout, h, w):
 # (tnv3_conv3x3_wino_layout / tnv3_conv3x3_wino_has_stats), never assumed here.
 WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 5 streaming persistent (default), 3 balanced, 4 quad layouts, 2 xi-split, 0 one wave per SIMD
 WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA staged kernels (parity-green, 8 % slower)
-WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))   # Winograd-form weight gradient: 0 the first kernel, 1 two waves / SIMD
+WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))   # Winograd-form weight gradient: -1 = 5 (every wave streams MFMAs and transforms), 1-4 role-split generations, 0 the first kernel
 
 
 # BatchNorm batch statistics from the convolution's epilogue (training forward): available in Winograd kernel variants 3, 4 and 5.
