@@ -706,7 +706,8 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad_wino3_mfma_kernel(const WgradWi
 //     Yh and V transforms of chunk q+1 -- results stored straight into the operand buffers -- and the four DMA pieces of chunk
 //     q+NST into the stage chunk q's strips left (always issued: beyond the last chunk every lane is out of range, so the waits
 //     are constant counts)
-// Per accumulator the K order is that of kernels 1-3: the same bits.  Operand layout and raw stages as in kernel 3.
+// Per accumulator the K order is that of kernels 1-3: the same bits.  Operand layout and raw stages as in kernel 3.  Unlike them
+// it takes any Cin (a partial last block of 64 input channels), which gives the stem layer (Cin = 27) the Winograd form too.
 template <int NST_ = 3, int DIAG_ = 0>
 struct WgradWino5Cfg : WgradWino3Cfg<NST_, DIAG_, 0> {};
 
@@ -723,7 +724,8 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad_wino5_mfma_kernel(const WgradWi
   const int wn = wq & 1, wm = wq >> 1;                      // wm: co half, wn: ci half
   const int half = lane >> 5, bl = lane & 31;
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
-  const int nCB = Cin / 64;
+  const int nCB = (Cin + 63) / 64;                         // the last ci block may be partial (the stem: Cin = 27): its missing channels
+                                                            // are out of the X descriptor's range (zeros) and are not stored
   int b = blockIdx.x;
   const int ks = b % a.splitK; b /= a.splitK;
   const int cb = b % nCB, mb = b / nCB;
@@ -753,6 +755,7 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad_wino5_mfma_kernel(const WgradWi
   }
   const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);
   const unsigned planes_dz = 64u * (unsigned)HW * 4u;
+  const unsigned planes_x = (unsigned)(Cin - ci0 < 64 ? Cin - ci0 : 64) * (unsigned)HW * 4u;
   // the cursor's chunk: descriptors and strip offsets now (scalar), the four pieces wherever the caller puts them; past the last
   // chunk (`left` <= 0) every lane is out of range: the stage is filled with zeros nobody reads
   struct DmaPlan { tnv3_rsrc_t r_dz, r_x; unsigned off_dz, off_x, border; float* rs; };
@@ -761,7 +764,7 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad_wino5_mfma_kernel(const WgradWi
     const bool dead = left <= 0;
     --left;
     d.r_dz = tnv3_make_rsrc(a.dz + ((size_t)(dead ? 0 : c_n) * Cout + co0) * HW, planes_dz);
-    d.r_x = tnv3_make_rsrc(a.x + ((size_t)(dead ? 0 : c_n) * Cin + ci0) * HW, planes_dz);
+    d.r_x = tnv3_make_rsrc(a.x + ((size_t)(dead ? 0 : c_n) * Cin + ci0) * HW, planes_x);
     d.off_dz = (unsigned)((2 * c_i * W + 16 * c_j) * 4);
     d.off_x = (unsigned)(((2 * c_i - 1) * W + 16 * c_j - 4) * 4);        // negative at the top-left corner: only out-of-image pieces
     d.border = dead ? 15u : ((c_i == 0 ? 1u : 0u) | (c_i == rowsT - 1 ? 2u : 0u) | (c_j == 0 ? 4u : 0u) | (c_j == segW - 1 ? 8u : 0u));
@@ -948,13 +951,15 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad_wino5_mfma_kernel(const WgradWi
   // partial slab: part[ks][xi][co][ci]
   float* slab = a.part + (size_t)ks * 16 * Cout * Cin;
   const int ci = ci0 + wn * 32 + bl;
+  if (ci < Cin) {
 #pragma unroll
-  for (int x = 0; x < 8; ++x)
+    for (int x = 0; x < 8; ++x)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      slab[((size_t)(grp * 8 + x) * Cout + co) * Cin + ci] = acc[x][r];
-    }
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        slab[((size_t)(grp * 8 + x) * Cout + co) * Cin + ci] = acc[x][r];
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

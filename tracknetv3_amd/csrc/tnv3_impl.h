@@ -906,12 +906,13 @@ int dgrad_up2x_wino_impl(Launcher& L, const float* dz, const float* u, float* ds
 }
 
 // ---- weight gradient of a plain layer in Winograd F(2x2, 3x3) form (kernels/wgrad_wino_mfma.h)
+// (Cin: any with kernel 5 -- a partial last block of 64 input channels; kernels 0-4 need Cin % 64 == 0)
 inline bool wgrad_wino_supported(int cin, int cout, int h, int w) {
-  return cin > 0 && cout > 0 && cin % 64 == 0 && cout % 64 == 0 && h % 2 == 0 && w % 16 == 0;
+  return cin > 0 && cout > 0 && cout % 64 == 0 && h % 2 == 0 && w % 16 == 0;
 }
 inline int wgrad_wino_fold_blocks(long elements) { const long b = (elements + 15) / 16; return (int)(b > 65536 ? 65536 : b); }   // 16 elements per block
 inline int wgrad_wino_splitk(int n, int cin, int cout, int h, int w) {
-  const int nb = (cout / 64) * (cin / 64);
+  const int nb = (cout / 64) * ((cin + 63) / 64);
   const long chunks = (long)n * (h / 2) * (w / 16);
   const int cus = num_cus();
   int best_sk = 1;
@@ -937,8 +938,9 @@ inline size_t wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w)
 constexpr int kWgradWinoDefaultVariant = 5;
 template <class Launcher>
 int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
-  const int grid = (a.Cout / 64) * (a.Cin / 64) * a.splitK;
+  const int grid = (a.Cout / 64) * ((a.Cin + 63) / 64) * a.splitK;
   if (variant < 0) variant = kWgradWinoDefaultVariant;
+  if (a.Cin % 64 && variant != 5) TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variants 0-4 need Cin %% 64 == 0 (got %d)", a.Cin);
   if (variant == 0) return L.launch(wgrad_wino_mfma_kernel, grid, WgradWinoCfg::NT, a);
   if ((long)64 * a.H * a.W * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (variants 1-3): 64 channel planes must stay below 2 GiB");
   if (variant == 1) return L.launch(wgrad_wino2_mfma_kernel, grid, WgradWino2Cfg::NT, a);
@@ -965,7 +967,7 @@ int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float*
                             int h, int w, int variant = -1) {
   if (!x || !dz || !dw || !ws || n <= 0) TNV3_FAIL(-1, "conv3x3_wgrad_wino: bad argument");
   if (!wgrad_wino_supported(cin, cout, h, w))
-    TNV3_FAIL(-1, "conv3x3_wgrad_wino: needs Cin %% 64 == 0, Cout %% 64 == 0, H %% 2 == 0, W %% 16 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
+    TNV3_FAIL(-1, "conv3x3_wgrad_wino: needs Cout %% 64 == 0, H %% 2 == 0, W %% 16 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
   if ((long)(cin > cout ? cin : cout) * h * w >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino: sample too large");
   if (((uintptr_t)ws) & 15) TNV3_FAIL(-1, "conv3x3_wgrad_wino: workspace must be 16-byte aligned");
   if (ws_bytes < wgrad_wino_workspace_bytes(n, cin, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad_wino: workspace too small");
@@ -1004,7 +1006,7 @@ inline int wgrad_up2x_wino_splitk(int n, int c0, int cout, int hl, int wl) {
   return best_sk;
 }
 // the skip half (a plain layer of c1 -> cout channels at full resolution) takes the Winograd-form kernel where that one wins
-inline bool wgrad_up2x_skip_wino(int c1, int cout, int h, int w) { return wgrad_wino_supported(c1, cout, h, w); }   // 64-multiples: Winograd form
+inline bool wgrad_up2x_skip_wino(int c1, int cout, int h, int w) { return c1 % 64 == 0 && wgrad_wino_supported(c1, cout, h, w); }   // 64-multiples: Winograd form
 inline size_t align16f(size_t floats) { return (floats + 3) / 4 * 4; }
 inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, int wl) {
   WgradUpLayout l;

@@ -621,7 +621,8 @@ def _wgrad_wino_variant(variant):
 
 def conv3x3_wgrad_wino(x, dz, variant=None):
     """dW[Cout][Cin][3][3] of a plain layer in Winograd F(2x2,3x3) form -- see tnv3_conv3x3_wgrad_wino.  variant: kernel for THIS
-    call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's default, 1 two waves per SIMD, 0 the first kernel)."""
+    call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's default = 5, every wave streams and transforms; 1-4 the role-split
+    generations; 0 the first kernel -- all bit-identical; a Cin that is not a multiple of 64 needs 5)."""
     lib = _lib.load()
     _f32(x, dz)
     _lib.dev_check(x, dz)
@@ -638,7 +639,12 @@ def conv3x3_wgrad_wino(x, dz, variant=None):
 
 def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None):
     """dW[Cout][C0+C1][3][3] of a decoder-entry layer (X = cat([upsample2x(x_low), skip], 1)), its upsampled channels at the
-    low resolution -- see tnv3_conv3x3_wgrad_up2x."""
+    low resolution -- see tnv3_conv3x3_wgrad_up2x.  wino_variant: an explicit number is the C entry's own (-1 default, 0 / 1 the
+    2x2-window forms, 2 .. 5 the 9-GEMM form with kernel 1 / 3 / 4 / 5 for the skip half); None follows tuning.WGRAD_WINO_VARIANT,
+    the PLAIN layers' kernel choice, keeping the 9-GEMM form (plain kernel 1 / 2 -> 2 / 3 here)."""
+    if wino_variant is None:
+        from . import tuning
+        wino_variant = {-1: -1, 0: 0, 1: 2, 2: 3}.get(int(tuning.WGRAD_WINO_VARIANT), int(tuning.WGRAD_WINO_VARIANT))
     lib = _lib.load()
     _f32(x_low, skip, dz)
     _lib.dev_check(x_low, skip, dz)
@@ -649,7 +655,7 @@ def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None):
     dw = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dz.device)
     ws = _workspace(lib.tnv3_conv3x3_wgrad_up2x_workspace_bytes(n, c0, c1, cout, h // 2, w // 2), dz.device)
     _lib.check(lib.tnv3_conv3x3_wgrad_up2x(_lib.ptr(x_low), _lib.ptr(skip), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8,
-                                           n, c0, c1, cout, h // 2, w // 2, _wgrad_wino_variant(wino_variant), _lib.stream_ptr(dz)))
+                                           n, c0, c1, cout, h // 2, w // 2, int(wino_variant), _lib.stream_ptr(dz)))
     return dw
 
 

@@ -52,11 +52,16 @@ def use_winograd(cin, cout, h, w):
 # The Winograd-form weight gradient is 1.35-1.5x faster than the direct kernel on every plain layer shape from 64
 # channels up (scripts/wgrad_wino_sweep.py).  (It used to lose on the 64-channel layers -- because of its split-K fold,
 # not the MFMA kernel: a few blocks walking hundreds of slabs serially; fixed in wgrad_wino_fold_kernel.)
-WINOGRAD_WGRAD_MIN_CH = int(os.environ.get("TNV3_WINO_WGRAD_MIN_CH", "64"))
+WINOGRAD_WGRAD_MIN_CH = int(os.environ.get("TNV3_WINO_WGRAD_MIN_CH", "64"))       # output channels
+WINOGRAD_WGRAD_MIN_CIN = int(os.environ.get("TNV3_WINO_WGRAD_MIN_CIN", "1"))     # input channels when not a multiple of 64 (65 = never)
 
 
 def use_winograd_wgrad(cin, cout, h, w):
-    if not WINOGRAD or cin < WINOGRAD_WGRAD_MIN_CH or cout < WINOGRAD_WGRAD_MIN_CH:
+    """The production kernel (variant 5 / -1) takes any Cin -- a partial block of 64 input channels: the stem layer (Cin = 27) costs a
+    64-channel layer's 0.53 ms instead of the direct kernel's 0.96 ms --; the older generations need 64-multiples on both sides."""
+    if not WINOGRAD or cout < WINOGRAD_WGRAD_MIN_CH:
+        return False
+    if cin % 64 and (WGRAD_WINO_VARIANT not in (-1, 5) or cin < WINOGRAD_WGRAD_MIN_CIN):
         return False
     from . import ops
     return ops.wgrad_wino_supported(cin, cout, h, w)
