@@ -184,11 +184,13 @@ int tnv3_dgrad_up2x_wino(const float* dz, const float* u, float* dx_low, int n, 
  * tnv3_conv3x3_wgrad up to fp32 rounding; deterministic (fixed-order split-K sum).
  *   supported: cout % 64 == 0, h % 2 == 0, w % 16 == 0, any cin with kernel 5 (a partial last block of 64 input channels: the stem
  *   layer), cin % 64 == 0 with kernels 0-4;  workspace 16-byte aligned, size from the query.
- *   `variant` (per call): -1 = the library's default (5);  5 = two waves per SIMD, every wave streams its MFMAs of a chunk and
- *   transforms its tile pair of the next chunk between them (16-byte operand reads, three raw stages);  1 = the wave groups half a
- *   period apart (one transforms while the other streams MFMAs), paired transforms, buffer-descriptor LDS-DMA;  2 / 3 = 1 with
- *   16-byte operand reads and two / three raw stages;  4 = 3 with the Yh transform moved into the MFMA phase;  0 = the first kernel
- *   (one wave per SIMD, transform and MFMA phases alternate).  All accumulate in the same order: bit-identical results. */
+ *   `variant` (per call): -1 = the library's default (1; 5 when cin % 64 != 0);  1 = two waves per SIMD, the wave groups half a
+ *   period apart (one transforms while the other streams MFMAs), paired transforms, buffer-descriptor LDS-DMA;  5 = every wave
+ *   streams its MFMAs of a chunk and transforms its tile pair of the next chunk between them (16-byte operand reads, three raw
+ *   stages: the fastest call, but its 240 registers and 160 KB of LDS leave no room for another stream's small kernels on the CU --
+ *   the training step is faster with 1);  6 = 5 with two raw stages (128 KB);  2 / 3 = 1 with 16-byte operand reads and two /
+ *   three raw stages;  4 = 3 with the Yh transform moved into the MFMA phase;  0 = the first kernel (one wave per SIMD, transform
+ *   and MFMA phases alternate).  All accumulate in the same order: bit-identical results. */
 int tnv3_conv3x3_wgrad_wino_supported(int cin, int cout, int h, int w);
 size_t tnv3_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w);
 int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes, int n, int cin, int cout,
@@ -201,7 +203,7 @@ int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* wo
  * Deterministic (split-K slabs reduced in a fixed order); workspace from the _workspace_bytes query, 16-byte aligned.
  * `wino_variant` (per call): -1 = the default -- upsampled half in the 9-GEMM Winograd form of tnv3_conv_up2x_wino_forward
  * (9 instead of 16 multiply-adds per low-res pixel; needs c0 % 128 == 0, cout % 64 == 0, w_low % 8 == 0, else the next), skip half
- * by the default kernel of tnv3_conv3x3_wgrad_wino;  2 .. 5 = the same with kernel 1 / 3 / 4 / 5 for the skip half;  1 = upsampled
+ * by the default kernel of tnv3_conv3x3_wgrad_wino;  2 .. 6 = the same with kernel 1 / 3 / 4 / 5 / 6 for the skip half;  1 = upsampled
  * half by four 2x2-window launches over the parity images of dz, skip half by kernel 1;  0 = 1 with the first Winograd kernel for
  * the skip half.  All compute the same gradient up to fp32 rounding. */
 size_t tnv3_conv3x3_wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int h_low, int w_low);

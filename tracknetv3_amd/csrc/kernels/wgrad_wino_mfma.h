@@ -889,6 +889,10 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad_wino5_mfma_kernel(const WgradWi
       }
       yh_read(st1, ya, yb);
       const DmaPlan d = dma_plan(st);                                     // chunk q+NST -> the stage of chunk q (read one iteration ago)
+      if constexpr (NST == 2) {                                           // two stages: the strips are due at the end of THIS iteration
+#pragma unroll
+        for (int p = 0; p <= NX; ++p) dma_piece(d, p);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (Cfg::DIAG != 3) {
 #pragma unroll
@@ -917,14 +921,16 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad_wino5_mfma_kernel(const WgradWi
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                // DS write
       }
       __builtin_amdgcn_sched_barrier(0);
-      dma_piece(d, 0);
+      if constexpr (NST > 2) dma_piece(d, 0);
       v_read(st1, xr, gc);                                                // (their registers: the operands of xi 0, 1 and the dZ rows)
       __builtin_amdgcn_sched_barrier(0);
       // xi 2, 3 while the X rows arrive
       pair_mfmas(2);
       __builtin_amdgcn_sched_barrier(0);
-      dma_piece(d, 1);
-      dma_piece(d, 2);
+      if constexpr (NST > 2) {
+        dma_piece(d, 1);
+        dma_piece(d, 2);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // xi 4 .. 7 + the V transform
       pair_mfmas(4);
@@ -937,7 +943,7 @@ __global__ void __launch_bounds__(Cfg::NT) wgrad_wino5_mfma_kernel(const WgradWi
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      dma_piece(d, 3);
+      if constexpr (NST > 2) dma_piece(d, 3);
       static_assert(NX == 3, "piece placement above");
       __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(kLater));                // strips of chunk q+2 landed (this wave's pieces)
       __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));                   // this wave's operand stores of chunk q+1 done

@@ -932,15 +932,21 @@ inline size_t wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w)
   return kWgradZeroBytes + (size_t)wgrad_wino_splitk(n, cin, cout, h, w) * 16 * cout * cin * sizeof(float);
 }
 
-// 5: no roles -- every wave streams its MFMAs and transforms the next chunk between them (12 % over 1 on every TrackNet shape,
-// profiles/r03_wgrad_wino5_ab.json); 1: two waves per SIMD, wave groups half a period apart; 2-4: 1 with 16-byte operand reads, three
-// raw stages, the Yh transform moved into the MFMA phase (0-5 % over 1); 0: the first kernel.  All six are bit-identical.
-constexpr int kWgradWinoDefaultVariant = 5;
+// 1: two waves per SIMD, wave groups half a period apart; 2-4: 1 with 16-byte operand reads, three raw stages, the Yh transform
+// moved into the MFMA phase (0-5 % over 1 per call); 5 / 6: no roles -- every wave streams its MFMAs and transforms the next chunk
+// between them (12 % / 8 % over 1 per call on every TrackNet shape, profiles/r03_wgrad_wino5_ab.json); 0: the first kernel.  All
+// bit-identical.  The default stays 1 although 5 is the fastest kernel: inside the training step the weight gradients run on the
+// side stream BESIDE the main stream's BatchNorm-backward passes, and those HBM-bound passes only co-reside with a workgroup that
+// leaves them registers and LDS -- kernel 1 (192 registers, 139 KB) leaves 128 registers per SIMD and 21 KB, kernels 5 / 6 (240
+// registers; 160 / 128 KB) 32 registers: the step is 32.3 ms with 1, 32.8 with 5, 32.6 with 6 (profiles/r03_train_wgrad_step_ab.txt).
+// A layer whose Cin is not a multiple of 64 (the stem, the last weight gradient of the step: nothing left to run beside it) takes 5.
+constexpr int kWgradWinoDefaultVariant = 1;
+inline int wgrad_wino_pick(int cin, int variant) { return variant >= 0 ? variant : (cin % 64 ? 5 : kWgradWinoDefaultVariant); }
 template <class Launcher>
 int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
   const int grid = (a.Cout / 64) * ((a.Cin + 63) / 64) * a.splitK;
-  if (variant < 0) variant = kWgradWinoDefaultVariant;
-  if (a.Cin % 64 && variant != 5) TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variants 0-4 need Cin %% 64 == 0 (got %d)", a.Cin);
+  variant = wgrad_wino_pick(a.Cin, variant);
+  if (a.Cin % 64 && variant != 5 && variant != 6) TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variants 0-4 need Cin %% 64 == 0 (got %d)", a.Cin);
   if (variant == 0) return L.launch(wgrad_wino_mfma_kernel, grid, WgradWinoCfg::NT, a);
   if ((long)64 * a.H * a.W * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (variants 1-3): 64 channel planes must stay below 2 GiB");
   if (variant == 1) return L.launch(wgrad_wino2_mfma_kernel, grid, WgradWino2Cfg::NT, a);
@@ -948,6 +954,7 @@ int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
   if (variant == 3) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3>>, grid, 512, a);
   if (variant == 4) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 0, 1>>, grid, 512, a);
   if (variant == 5) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<3>>, grid, 512, a);
+  if (variant == 6) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<2>>, grid, 512, a);      // 128 KB of LDS: small kernels of another stream fit beside it
 #ifdef TNV3_DIAG
   if (variant == 101) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 1>>, grid, 512, a);   // no transforms
   if (variant == 102) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 2>>, grid, 512, a);   // no DMA
@@ -974,7 +981,8 @@ int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float*
   const int sk = wgrad_wino_splitk(n, cin, cout, h, w);
   float* slabs = (float*)((char*)ws + kWgradZeroBytes);
   int rc;
-  if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
+  const bool zero_page = wgrad_wino_pick(cin, variant) == 0;                           // only the first kernel reads its borders from a zero page
+  if (zero_page && (rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
   WgradWinoArgs a{x, dz, (const float*)ws, slabs, n, cin, cout, h, w, sk};
   if ((rc = launch_wgrad_wino(L, a, variant))) return rc;
   return L.launch(wgrad_wino_fold_kernel, wgrad_wino_fold_blocks((long)cout * cin), 256, (const float*)slabs, dw, cout, cin, sk);
@@ -1067,7 +1075,8 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
   }
   if (wgrad_up2x_skip_wino(c1, cout, h, w)) {
     const int sk = wgrad_wino_splitk(n, c1, cout, h, w);
-    if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
+    if (wgrad_wino_pick(c1, wino_variant) == 0)                                        // only the first kernel reads a zero page
+      if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
     WgradWinoArgs a{skip, dz, (const float*)ws, slabs, n, c1, cout, h, w, sk};
     if ((rc = launch_wgrad_wino(L, a, wino_variant))) return rc;
     if ((rc = L.launch(wgrad_wino_fold_kernel, wgrad_wino_fold_blocks((long)cout * c1), 256, (const float*)slabs, dwskip, cout, c1, sk))) return rc;

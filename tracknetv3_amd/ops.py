@@ -621,8 +621,8 @@ def _wgrad_wino_variant(variant):
 
 def conv3x3_wgrad_wino(x, dz, variant=None):
     """dW[Cout][Cin][3][3] of a plain layer in Winograd F(2x2,3x3) form -- see tnv3_conv3x3_wgrad_wino.  variant: kernel for THIS
-    call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's default = 5, every wave streams and transforms; 1-4 the role-split
-    generations; 0 the first kernel -- all bit-identical; a Cin that is not a multiple of 64 needs 5)."""
+    call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's default = 1, or 5 when Cin % 64 != 0; 1-4 the role-split generations;
+    5 / 6 every wave streams and transforms; 0 the first kernel -- all bit-identical)."""
     lib = _lib.load()
     _f32(x, dz)
     _lib.dev_check(x, dz)

@@ -57,11 +57,12 @@ WINOGRAD_WGRAD_MIN_CIN = int(os.environ.get("TNV3_WINO_WGRAD_MIN_CIN", "1"))    
 
 
 def use_winograd_wgrad(cin, cout, h, w):
-    """The production kernel (variant 5 / -1) takes any Cin -- a partial block of 64 input channels: the stem layer (Cin = 27) costs a
-    64-channel layer's 0.53 ms instead of the direct kernel's 0.96 ms --; the older generations need 64-multiples on both sides."""
+    """Kernels 5 / 6 (what -1 picks when Cin % 64 != 0) take any Cin -- a partial block of 64 input channels: the stem layer (Cin = 27)
+    costs a 64-channel layer's 0.55 ms instead of the direct kernel's 0.96 ms, 0.36 ms of the step --; the older generations need
+    64-multiples on both sides."""
     if not WINOGRAD or cout < WINOGRAD_WGRAD_MIN_CH:
         return False
-    if cin % 64 and (WGRAD_WINO_VARIANT not in (-1, 5) or cin < WINOGRAD_WGRAD_MIN_CIN):
+    if cin % 64 and (WGRAD_WINO_VARIANT not in (-1, 5, 6) or cin < WINOGRAD_WGRAD_MIN_CIN):
         return False
     from . import ops
     return ops.wgrad_wino_supported(cin, cout, h, w)
@@ -73,7 +74,7 @@ def use_winograd_wgrad(cin, cout, h, w):
 # (tnv3_conv3x3_wino_layout / tnv3_conv3x3_wino_has_stats), never assumed here.
 WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 5 streaming persistent (default), 3 balanced, 4 quad layouts, 2 xi-split, 0 one wave per SIMD
 WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA staged kernels (parity-green, 8 % slower)
-WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))   # Winograd-form weight gradient: -1 = 5 (every wave streams MFMAs and transforms), 1-4 role-split generations, 0 the first kernel
+WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))   # Winograd-form weight gradient: -1 = 1 (5 for the stem), 1-4 role-split generations, 5 / 6 every wave streams and transforms, 0 the first kernel
 
 
 # BatchNorm batch statistics from the convolution's epilogue (training forward): available in Winograd kernel variants 3, 4 and 5.
