@@ -98,7 +98,7 @@ def _wgrad_up2x_case(case, device):
     for v in (0, 1):                             # the older kernel choices compute the same gradient
         dwv = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=v)
         assert rel_err(dwv.cpu(), dw.cpu().double()) <= 4e-6, v
-    for v in (2, 3, 4, 5, 6):                    # 9-GEMM form + another (bit-identical) generation of the skip half's kernel
+    for v in (2, 3, 4, 5, 6, 7):                 # 9-GEMM form + another (bit-identical) generation of the skip half's kernel
         assert torch.equal(dw, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=v)), v
     return rel_err(dw.cpu(), wd.grad), rel_err(dw.cpu()[:, :c0], wd.grad[:, :c0])
 
@@ -121,7 +121,7 @@ def _wgrad_wino_case(case, device):
     dw = ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))
     assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))), "split-K reduction must be deterministic"
     # every kernel generation accumulates every element in the same order: bit-identical gradients
-    for v in ((0, 1, 2, 3, 4, 5, 6) if cin % 64 == 0 else (5, 6)):        # a partial block of input channels (the stem): the production kernel only
+    for v in ((0, 1, 2, 3, 4, 5, 6, 7) if cin % 64 == 0 else (5, 6)):        # a partial block of input channels (the stem): the production kernel only
         assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=v)), v
     if cin % 64:
         with pytest.raises(Exception, match="Cin % 64"):

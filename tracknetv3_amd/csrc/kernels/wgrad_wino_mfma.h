@@ -222,7 +222,11 @@ struct WgradWino2Cfg {
   static_assert(DZ_RAW / 4 == NT && X_RAW % (4 * NT) == 0, "pieces must deal evenly");
 };
 
-inline __global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_kernel(const WgradWinoArgs a) {
+// SPLIT (variant 7): as in kernel 3's variant 4, the group in its MFMA phase also transforms Yh for the OTHER group inside its own
+// MFMA stream and the transforming group does V only -- here with kernel 2's 4-byte operand ring, i.e. inside its footprint (the
+// registers and LDS it leaves are what lets the other stream's BatchNorm passes run beside it, §3.1f of DESIGN.md).
+template <int SPLIT>
+__global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_kernel(const WgradWinoArgs a) {
   using Cfg = WgradWino2Cfg;
   constexpr int NT = Cfg::NT, TS = Cfg::TS, XW = Cfg::XW, NX = Cfg::NX;
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
@@ -283,7 +287,7 @@ inline __global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_ker
 
   // ---- transform of a tile pair: thread (channel ch, pair tp) of its group -> rows 2*grp, 2*grp+1 of Yh and V, tiles 2tp, 2tp+1
   const int tg = tid & 255, ch = tg >> 2, tp = tg & 3;
-  auto transform = [&](int stage, auto gc) {
+  auto yh_transform = [&](int stage, auto gc) {
     constexpr int G = decltype(gc)::value;
     const float* rs = raw_s + stage * Cfg::RAW_STAGE;
     {   // Yh = A dY A^T,  A = [1 0; 1 1; 1 -1; 0 -1]: rows (y0, y0 + y1 | y0 - y1, -y1), the same along the columns
@@ -306,6 +310,11 @@ inline __global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_ker
         oi[3 * 64 * TS] = -rr[0][1];           oi[3 * 64 * TS + 1] = -rr[1][1];
       }
     }
+  };
+  auto transform = [&](int stage, auto gc, bool with_yh) {          // with_yh: a compile-time constant at every call site
+    constexpr int G = decltype(gc)::value;
+    const float* rs = raw_s + stage * Cfg::RAW_STAGE;
+    if (with_yh) yh_transform(stage, gc);
     {   // V = B^T d B: strip rows G .. G+2 (patch rows d0,d1,d2 | d1,d2,d3), patch columns 4tp+3 .. 4tp+8 of the 24-float strip row
       const float* d = rs + Cfg::DZ_RAW + ch * (4 * XW) + G * XW + 4 * tp;
       float x[3][6];
@@ -342,9 +351,13 @@ inline __global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_ker
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
   const float* A = yh_s + (grp * 8) * 64 * TS + (wm * 32 + bl) * TS + half;
   const float* B = v_s + (grp * 8) * 64 * TS + (wn * 32 + bl) * TS + half;
-  auto mfma_chunk = [&]() {                                 // 4 tile pairs x this group's 8 xi; per accumulator the K order of kernel 1
+  // 4 tile pairs x this group's 8 xi; per accumulator the K order of kernel 1.  SPLIT: behind the first 12 steps, the Yh transform of
+  // the other group's rows from raw stage `yh_stage` (after the last chunk: of a stale strip, into rows nobody reads -- unconditional,
+  // so that the MFMA stream stays straight-line code)
+  auto mfma_chunk = [&](int yh_stage, auto gother) {
     constexpr int NSTEP = 4 * 8;
     constexpr int PF = 4, RING = PF + 1;
+    constexpr int CUT = SPLIT ? 12 : NSTEP;
     float av[RING], bv[RING];
     auto read_step = [&](int s) {
       const int t2 = s >> 3, xi = s & 7;
@@ -354,11 +367,23 @@ inline __global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_ker
 #pragma unroll
     for (int s = 0; s < PF; ++s) read_step(s);
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
+    for (int s = 0; s < CUT; ++s) {
       if (s + PF < NSTEP) read_step(s + PF);
       acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s & 7], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    if constexpr (SPLIT) {
+      __builtin_amdgcn_sched_barrier(0);
+      yh_transform(yh_stage, gother);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = CUT; s < NSTEP; ++s) {
+        if (s + PF < NSTEP) read_step(s + PF);
+        acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % RING], bv[s % RING], acc[s & 7], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
     }
   };
   auto phase_end = [&](bool dma_too) {                      // own LDS traffic (and, at the end of an odd phase, own DMAs) done; everybody
@@ -378,23 +403,25 @@ inline __global__ void __launch_bounds__(WgradWino2Cfg::NT) wgrad_wino2_mfma_ker
   }
   phase_end(true);
   // (one loop per group, each with a single MFMA site: the accumulators stay in place; both execute the same barriers)
+  using G0 = std::integral_constant<int, 0>;
+  using G1 = std::integral_constant<int, 1>;
   if (sgrp == 0) {
-    if (nMine > 0) transform(0, std::integral_constant<int, 0>{});
+    if (nMine > 0) transform(0, G0{}, true);
     phase_end(false);
     for (int q = 0; q < nMine; ++q) {
-      mfma_chunk();
+      mfma_chunk(q & 1, G1{});                              // SPLIT: + Yh rows 2, 3 of chunk q
       phase_end(true);
       if (q + 2 < nMine) dma_chunk(q & 1);
-      if (q + 1 < nMine) transform((q + 1) & 1, std::integral_constant<int, 0>{});
+      if (q + 1 < nMine) transform((q + 1) & 1, G0{}, !SPLIT);
       phase_end(false);
     }
   } else {
     phase_end(false);
     for (int q = 0; q < nMine; ++q) {
-      transform(q & 1, std::integral_constant<int, 1>{});
+      transform(q & 1, G1{}, !SPLIT);
       phase_end(true);
       if (q + 2 < nMine) dma_chunk(q & 1);
-      mfma_chunk();
+      mfma_chunk((q + 1) & 1, G0{});                        // SPLIT: + Yh rows 0, 1 of chunk q+1
       phase_end(false);
     }
   }

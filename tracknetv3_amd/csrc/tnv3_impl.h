@@ -949,7 +949,8 @@ int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
   if (a.Cin % 64 && variant != 5 && variant != 6) TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variants 0-4 need Cin %% 64 == 0 (got %d)", a.Cin);
   if (variant == 0) return L.launch(wgrad_wino_mfma_kernel, grid, WgradWinoCfg::NT, a);
   if ((long)64 * a.H * a.W * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (variants 1-3): 64 channel planes must stay below 2 GiB");
-  if (variant == 1) return L.launch(wgrad_wino2_mfma_kernel, grid, WgradWino2Cfg::NT, a);
+  if (variant == 1) return L.launch(wgrad_wino2_mfma_kernel<0>, grid, WgradWino2Cfg::NT, a);
+  if (variant == 7) return L.launch(wgrad_wino2_mfma_kernel<1>, grid, WgradWino2Cfg::NT, a);     // 1 + the Yh transform in the MFMA phase
   if (variant == 2) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<2>>, grid, 512, a);
   if (variant == 3) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3>>, grid, 512, a);
   if (variant == 4) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 0, 1>>, grid, 512, a);
