@@ -301,24 +301,39 @@ class TrackNet(nn.Module):
                     b.eval_scale()
 
     def _forward_eval_split(self, x):
-        """The eval forward with the batch split 6 : 4 over the current stream and a side stream (tuning.INFER_SPLIT).  Images are
-        independent in eval mode, so the outputs are those of _forward_eval to the last bit; the two halves' per-layer launches
-        overlap at their tails, where a single launch leaves CUs idle."""
+        """The eval forward with the batch split over the current stream and side streams (tuning.INFER_SPLIT_PARTS, default 6 : 4 over
+        two).  Images are independent in eval mode, so the outputs are those of _forward_eval to the last bit; the parts' per-layer
+        launches overlap at their tails, where a single launch leaves CUs idle."""
         dev = x.device
         n = int(x.shape[0])
-        n0 = (3 * n + 2) // 5
+        parts = tuning.INFER_SPLIT_PARTS
+        tot = sum(parts)
+        cuts, acc = [0], 0
+        for p in parts[:-1]:                                 # cumulative rounding: 6 : 4 of 10 -> 6 + 4, of 16 -> 10 + 6
+            acc += p
+            cuts.append(min(n, (acc * n + tot // 2) // tot))
+        cuts.append(n)
         main = torch.cuda.current_stream(dev)
-        side = _split_stream(dev)
-        self.prepare_eval()                                  # cached operands are built on this stream, before the side stream reads them
+        self.prepare_eval()                                  # cached operands are built on this stream, before the side streams read them
         ready = torch.cuda.Event()
         ready.record(main)                                   # x (and the caches) were produced on this stream
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            y1 = self._forward_eval(x[n0:])
-        y0 = self._forward_eval(x[:n0])
-        main.wait_stream(side)
-        y1.record_stream(main)                               # allocated on the side stream, consumed (and freed) on this one
-        return torch.cat((y0, y1), 0)
+        outs = [None] * len(parts)
+        sides = []
+        for i in range(1, len(parts)):
+            if cuts[i + 1] <= cuts[i]:
+                continue
+            side = _split_stream(dev, i - 1)
+            sides.append(side)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                outs[i] = self._forward_eval(x[cuts[i]:cuts[i + 1]])
+        outs[0] = self._forward_eval(x[:cuts[1]])
+        for side in sides:
+            main.wait_stream(side)
+        for y in outs[1:]:
+            if y is not None:
+                y.record_stream(main)                        # allocated on a side stream, consumed (and freed) on this one
+        return torch.cat([y for y in outs if y is not None], 0)
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_dim:
@@ -340,10 +355,10 @@ class TrackNet(nn.Module):
 _SPLIT_STREAMS = {}
 
 
-def _split_stream(dev):
-    """The side stream of the intra-batch split, one per device (the caching allocator pools memory per stream: a fresh stream per
+def _split_stream(dev, i=0):
+    """The i-th side stream of the intra-batch split, per device (the caching allocator pools memory per stream: a fresh stream per
     call would pay a hipMalloc for every activation)."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), i)
     if key not in _SPLIT_STREAMS:
         _SPLIT_STREAMS[key] = torch.cuda.Stream(dev)
     return _SPLIT_STREAMS[key]

@@ -84,7 +84,9 @@ BN_STATS_IN_EPILOGUE = os.environ.get("TNV3_BN_STATS_EPILOGUE", "1") != "0"
 # Inference: one batch is split over two HIP streams (6 : 4) -- its images are independent, and the second stream's launches fill
 # the CUs that the tail of every per-layer launch leaves idle (720 tiles on 256 CUs = 2.8 rounds: the last one is 81 % full).
 # Measured on the batch-10 288x512 forward: 9.91 -> 9.33 ms (profiles/r02_split_stream_probe.json); outputs are bit-identical.
+# Other shares and three or four streams are all slower (profiles/r03_infer_split_sweep.txt: 6,4 8.07 ms; 7,3 8.09; 4,4,2 8.15; 5,5 8.22).
 INFER_SPLIT = os.environ.get("TNV3_INFER_SPLIT", "1") != "0"
+INFER_SPLIT_PARTS = tuple(int(v) for v in os.environ.get("TNV3_INFER_SPLIT_PARTS", "6,4").split(",") if v.strip())   # shares of the batch, one stream each
 INFER_SPLIT_MIN_BATCH = 4
 INFER_SPLIT_MIN_PIXELS = 1 << 19          # batch x H x W below which the launches are too short to be worth a second stream
 
