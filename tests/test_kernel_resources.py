@@ -84,7 +84,7 @@ def test_conv_and_wgrad_budgets(resources):
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
     # Winograd weight gradient, two waves per SIMD: the role-split generations and the production kernel (every wave streams and transforms)
-    for name in ("wgrad_wino2_mfma_kernel", "wgrad_wino3_mfma_kernelINS_13WgradWino3CfgILi3ELi0ELi1E", "wgrad_wino5_mfma_kernelINS_13WgradWino5CfgILi3ELi0E"):
+    for name in ("wgrad_wino2_mfma_kernelILi0E", "wgrad_wino2_mfma_kernelILi1E", "wgrad_wino3_mfma_kernelINS_13WgradWino3CfgILi3ELi0ELi1E", "wgrad_wino5_mfma_kernelINS_13WgradWino5CfgILi3ELi0E"):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
