@@ -105,7 +105,7 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  *                                     W % 32 == 0; filters packed with layout 2); bit-identical to 2-5.
  *                                     7 = the same kernel with a 64-channel x (4 x 64 pixels) workgroup tile (Cout % 64 == 0, Cin > 8,
  *                                     W % 64 == 0; layout 2); bit-identical to 2-6.
- *                                     -1 = tnv3_conv3x3_wino_pick(cin, cout): 6 for Cout % 128 == 0, 7 for Cout % 64 == 0 (both Cin > 8), else 5 -- by channel counts only,
+ *                                     -1 = tnv3_conv3x3_wino_pick(cin, cout): 6 for Cout % 128 == 0 and Cin > 8, else 5 (7 measured 2-5 % slower) -- by channel counts only,
  *                                     so a panel packed ahead of time is the one every call of that layer reads.
  *   `layout` of the pack calls: 0 = u[cin_pad][16][cout];  1 = u[cin_pad / 2][4][2][cout][4] (transform row major, the four xi of
  *                                     a row adjacent);  2 = u[cout / 32][cin_pad / 8][2][8][64][4] (the A operand in lane order). */
@@ -118,6 +118,15 @@ int tnv3_conv3x3_wino_has_stats(int variant);  /* 1 when `variant` (-1 = the def
 int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, int layout, tnv3_stream_t stream);
 int tnv3_conv3x3_wino_pack_view(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip,
                                 int layout, tnv3_stream_t stream);
+/* The same for a list of panels in ONE launch (a training step re-packs the forward and data-gradient filters of every layer after
+ * each optimiser step): items[k] = the arguments of tnv3_conv3x3_wino_pack_view for panel k; `items` is HOST memory, read before
+ * the call returns.  Bit-identical to the one-panel calls. */
+typedef struct tnv3_wino_pack_item {
+  const float* w;   /* nn.Conv2d weight [cout_w][cin_w][3][3] (device) */
+  float* u;         /* panel of tnv3_conv3x3_wino_packed_floats(cin, cout) floats (device) */
+  int cout_w, cin_w, c_from, c_count, transpose_flip, layout;
+} tnv3_wino_pack_item;
+int tnv3_conv3x3_wino_pack_multi(const tnv3_wino_pack_item* items, int count, tnv3_stream_t stream);
 int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,
                               tnv3_stream_t stream);

@@ -266,6 +266,30 @@ def test_wino_pack_view_emulated(emu):
     _pack_view_case("cpu")
 
 
+def _pack_multi_case(device):
+    """tnv3_conv3x3_wino_pack_multi: a list of panels -- every layout, slices, data-gradient transposes, more panels than one table
+    holds -- in one call == the one-panel calls, bit for bit."""
+    from tracknetv3_amd import ops
+    ws = [T((64, 27, 3, 3), 411, -0.5, 0.5), T((128, 64, 3, 3), 412, -0.5, 0.5), T((64, 192, 3, 3), 413, -0.5, 0.5), T((256, 128, 3, 3), 414, -0.5, 0.5)]
+    ws = [w.to(device) for w in ws]
+    specs = [(ws[0], 0, False), (ws[1], 0, False), (ws[1], 0, True), (ws[2], 128, False), (ws[2], 128, True), (ws[3], 0, False), (ws[3], 0, True)]
+    specs = specs * 7                                             # 49 panels: two tables
+    got = ops.pack_wino_weights_multi(specs)
+    assert len(got) == len(specs)
+    layouts = set()
+    for (w, c_from, flip), u in zip(specs, got):
+        want = ops.pack_wino_weights(w, c_from=c_from, transpose_flip=flip)
+        assert u.shape == want.shape and torch.equal(u, want), (tuple(w.shape), c_from, flip)
+        cin, cout = (int(w.shape[0]), int(w.shape[1]) - c_from) if flip else (int(w.shape[1]) - c_from, int(w.shape[0]))
+        layouts.add(ops.wino_layout(None, cin, cout))
+    assert len(layouts) >= 2                                      # the streaming kernel's and the 128-channel kernel's panel orders
+    assert ops.pack_wino_weights_multi([]) == []
+
+
+def test_wino_pack_multi_emulated(emu):
+    _pack_multi_case("cpu")
+
+
 def test_argument_errors_are_reported(emu):
     from tracknetv3_amd import ops, _lib
     w = ops.pack_conv3x3_weights(T((64, 4, 3, 3), 1))

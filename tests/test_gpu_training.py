@@ -215,6 +215,39 @@ def test_train_then_eval_and_optimizer_step(gpu_device):
     assert (e1.cpu() - ref).abs().max().item() <= 1e-4
 
 
+def test_one_launch_filter_repack_equals_the_per_layer_packs(gpu_device, monkeypatch):
+    """Training steps with the stale Winograd panels rebuilt by ONE launch at the start of the forward (model.repack_wino_panels,
+    the default) == the same steps with every panel packed lazily in front of its convolution: the same parameters, bit for bit,
+    after three optimiser steps; and the one-launch path really ran (panels of both directions, every Winograd layer)."""
+    from tracknetv3_amd import ops, tuning
+    from tracknetv3_amd.utils.general import get_model
+    from tracknetv3_amd.utils.metric import WBCELoss
+    from test_emu_kernels import _pack_multi_case
+    _pack_multi_case(gpu_device)
+    x = nets.synth_input((2, 27, 32, 64), 5).to(gpu_device)
+    y = nets.disc_heatmaps(2, 8, 32, 64, 6).to(gpu_device)
+    sd = nets.synth_state(nets.tracknet_state_shapes(27, 8), 21, calibrated=True)
+    finals, counts = [], []
+    for multi in (True, False):
+        monkeypatch.setattr(tuning, "WINO_REPACK_MULTI", multi)
+        m = get_model("TrackNet", 8, "concat").to(gpu_device)
+        m.load_state_dict(sd)
+        m.train()
+        opt = torch.optim.SGD(m.parameters(), lr=1e-2)
+        real, n_multi = ops.pack_wino_weights_multi, []
+        monkeypatch.setattr(ops, "pack_wino_weights_multi", lambda specs, variant=None: (n_multi.append(len(specs)), real(specs, variant))[1])
+        for _ in range(3):
+            opt.zero_grad()
+            WBCELoss(m(x), y).backward()
+            opt.step()
+        monkeypatch.setattr(ops, "pack_wino_weights_multi", real)
+        finals.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+        counts.append(n_multi)
+    assert counts[1] == [] and len(counts[0]) == 2 and counts[0][0] == counts[0][1] >= 20, counts      # steps 2 and 3: forward + data-gradient panels
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
 def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
     """The training path recomputes the ReLU mask from z with the forward's gamma / beta; if a BN parameter was modified in
     place between forward and backward (version counter moved) it must take the mask from the saved activation instead.

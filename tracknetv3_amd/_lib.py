@@ -62,6 +62,7 @@ def _declare(lib):
     sig("tnv3_conv3x3_wino_pick", i, i, i)
     sig("tnv3_conv3x3_wino_pack", i, p, p, i, i, i, p)
     sig("tnv3_conv3x3_wino_pack_view", i, p, p, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino_pack_multi", i, p, i, p)
     sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_stats_tiles", lg, i, i, i, i)
     sig("tnv3_conv3x3_wino_forward_stats", i, p, p, p, p, p, i, i, i, i, i, i, p)
@@ -141,7 +142,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_dgrad_up2x", "tnv3_conv3x3_wgrad_up2x_workspace_bytes", "tnv3_conv3x3_wgrad_up2x",
            "tnv3_conv3x3_wgrad_wino_supported", "tnv3_conv3x3_wgrad_wino_workspace_bytes", "tnv3_conv3x3_wgrad_wino",
            "tnv3_conv3x3_wino_stats_tiles", "tnv3_conv3x3_wino_forward_stats", "tnv3_bn_train_forward_tiles",
-           "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_layout", "tnv3_conv3x3_wino_has_stats", "tnv3_conv3x3_wino_pick", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_forward"]
+           "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_layout", "tnv3_conv3x3_wino_has_stats", "tnv3_conv3x3_wino_pick", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_pack_multi", "tnv3_conv3x3_wino_forward"]
 
 
 def library_path():
@@ -237,7 +238,7 @@ def on_tensor_device(fn):
 
 def first_tensor(args):
     """The first tensor among the positional arguments, looking inside list / tuple arguments too (the multi-tensor ops --
-    grad_norm, adam_step, sgd_step, inpaintnet_pack -- take lists of tensors)."""
+    grad_norm, adam_step, sgd_step, inpaintnet_pack -- take lists of tensors, pack_wino_weights_multi a list of tuples)."""
     for a in args:
         if isinstance(a, torch.Tensor):
             return a
@@ -245,4 +246,8 @@ def first_tensor(args):
             for b in a:
                 if isinstance(b, torch.Tensor):
                     return b
+                if isinstance(b, (list, tuple)):             # pack_wino_weights_multi: a list of (weight, c_from, flip)
+                    for c in b:
+                        if isinstance(c, torch.Tensor):
+                            return c
     return None

@@ -80,6 +80,8 @@ def _train_forward_body(net, x):
     """conv -> BN(batch statistics) -> ReLU per Conv2DBlock up to the head's input; returns (saved records, head input, skips)."""
     saved = []          # per block: dict(x0, x1, up, z, a, mean, invstd)
     n = x.shape[0]
+    if tuning.WINO_REPACK_MULTI:
+        net.repack_wino_panels()        # the panels the optimiser step made stale, forward and backward ones, in one launch
 
     def block_fwd(blk, src0, src1=None, up=False):
         h = src0.shape[2] * (2 if up else 1)

@@ -525,10 +525,11 @@ __global__ void __launch_bounds__(Cfg::NT) conv3x3_wino_split_mfma_kernel(const 
 // layout 0: U[ci][xi][Cout];  layout 1 ("quad", conv3x3_wino3_mfma.h): U[ci / 2][xi / 4][ci % 2][Cout][xi % 4] (CinPad even);
 // layout 2 (conv3x3_wino6_mfma.h: the A operand in the order its lanes load it, Cout % 32 == 0, CinPad % 8 == 0):
 //   U[co / 32][ci / 8][xi / 8][q = (ci % 8 / 2) * 2 + (xi % 8) / 4][lane = (ci % 2) * 32 + co % 32][xi % 4]
-inline __global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad, long s_co,
-                                         long s_ci, int flip, int layout) {
+// (elements e0, e0 + stride, ... of one panel; shared by the one-panel kernel and the table-driven one)
+__device__ __forceinline__ void conv3x3_wino_pack_elements(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad,
+                                                           long s_co, long s_ci, int flip, int layout, long e0, long stride) {
   const long body = (long)CinPad * 16 * Cout, total = body + kPackZeroTail;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+  for (long e = e0; e < total; e += stride) {
     if (e >= body) { u[e] = 0.0f; continue; }
     int co, xi, ci;
     if (layout == 2) {
@@ -566,6 +567,37 @@ inline __global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, flo
     }
     u[e] = v;
   }
+}
+
+
+inline __global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int CinPad, long s_co,
+                                         long s_ci, int flip, int layout) {
+  conv3x3_wino_pack_elements(w, u, Cout, Cin, CinPad, s_co, s_ci, flip, layout, (long)blockIdx.x * blockDim.x + threadIdx.x,
+                             (long)gridDim.x * blockDim.x);
+}
+
+// Every stale filter panel of a training step in ONE launch (tnv3_conv3x3_wino_pack_multi): the step re-packs ~33 panels after each
+// optimiser step -- forward and data-gradient filters of every layer -- as 14-us launches strung along the main stream; the table
+// (kernel argument, by value) gives each panel a run of blocks.  Same arithmetic per element: the same bits as the one-panel kernel.
+constexpr int kWinoPackMaxItems = 40;
+struct WinoPackTable {
+  const float* w[kWinoPackMaxItems];
+  float* u[kWinoPackMaxItems];
+  long s_co[kWinoPackMaxItems], s_ci[kWinoPackMaxItems];
+  int cout[kWinoPackMaxItems], cin[kWinoPackMaxItems], cpad[kWinoPackMaxItems], flip[kWinoPackMaxItems], layout[kWinoPackMaxItems];
+  int first_block[kWinoPackMaxItems + 1];      // prefix sum of the panels' block counts
+  int count;
+};
+inline __global__ void __launch_bounds__(256) conv3x3_wino_pack_multi_kernel(const WinoPackTable t) {
+  int lo = 0, hi = t.count;                    // first_block[lo] <= blockIdx.x < first_block[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const int k = lo;
+  const long nb = t.first_block[k + 1] - t.first_block[k];
+  conv3x3_wino_pack_elements(t.w[k], t.u[k], t.cout[k], t.cin[k], t.cpad[k], t.s_co[k], t.s_ci[k], t.flip[k], t.layout[k],
+                             (long)((int)blockIdx.x - t.first_block[k]) * 256 + threadIdx.x, nb * 256);
 }
 
 }  // namespace tnv3

@@ -535,6 +535,45 @@ int conv3x3_wino_pack_view_impl(Launcher& L, const float* w, float* u, int cout_
   return L.launch(conv3x3_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w + (size_t)c_from * 9, u,
                   cout, cin, cpad, transpose_flip ? s_w_ci : s_w_co, transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0, layout);
 }
+// One launch for a list of panels (the C ABI's tnv3_wino_pack_item: the arguments of conv3x3_wino_pack_view_impl per panel).
+struct WinoPackItem { const float* w; float* u; int cout_w, cin_w, c_from, c_count, transpose_flip, layout; };
+template <class Launcher>
+int conv3x3_wino_pack_multi_impl(Launcher& L, const WinoPackItem* items, int count) {
+  if (!items || count < 0) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: bad argument");
+  for (int base = 0; base < count; base += kWinoPackMaxItems) {
+    WinoPackTable t;
+    t.count = count - base < kWinoPackMaxItems ? count - base : kWinoPackMaxItems;
+    t.first_block[0] = 0;
+    for (int k = 0; k < t.count; ++k) {
+      const WinoPackItem& it = items[base + k];
+      if (!it.w || !it.u || it.cout_w <= 0 || it.cin_w <= 0 || it.c_from < 0 || it.c_count <= 0 || it.c_from + it.c_count > it.cin_w || it.layout < 0 ||
+          it.layout > 2)
+        TNV3_FAIL(-1, "conv3x3_wino_pack_multi: bad item %d", base + k);
+      const int cout = it.transpose_flip ? it.c_count : it.cout_w, cin = it.transpose_flip ? it.cout_w : it.c_count;
+      if (it.layout == 2 && cout % 32) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layout 2 needs Cout %% 32 == 0 (item %d: %d)", base + k, cout);
+      const long s_w_co = (long)it.cin_w * 9, s_w_ci = 9;
+      t.w[k] = it.w + (size_t)it.c_from * 9;
+      t.u[k] = it.u;
+      t.cout[k] = cout; t.cin[k] = cin; t.cpad[k] = round_up(cin, kWinoCinPad);
+      t.s_co[k] = it.transpose_flip ? s_w_ci : s_w_co;
+      t.s_ci[k] = it.transpose_flip ? s_w_co : s_w_ci;
+      t.flip[k] = it.transpose_flip ? 1 : 0;
+      t.layout[k] = it.layout;
+      const long total = (long)t.cpad[k] * 16 * cout + kPackZeroTail;
+      const long blocks = (total + 255) / 256;
+      t.first_block[k + 1] = t.first_block[k] + (int)(blocks > 2048 ? 2048 : blocks);      // four elements per thread at most times 2048 blocks: grid-stride beyond
+    }
+    for (int k = t.count; k < kWinoPackMaxItems; ++k) {
+      t.w[k] = nullptr; t.u[k] = nullptr; t.s_co[k] = t.s_ci[k] = 0; t.cout[k] = t.cin[k] = t.cpad[k] = t.flip[k] = t.layout[k] = 0;
+      t.first_block[k + 1] = t.first_block[t.count];
+    }
+    if (t.count == 0) continue;
+    const int rc = L.launch(conv3x3_wino_pack_multi_kernel, t.first_block[t.count], 256, t);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 template <class Launcher>
 int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin, int layout = 0) {
   return conv3x3_wino_pack_view_impl(L, w, u, cout, cin, 0, cin, 0, layout);

@@ -52,6 +52,7 @@ class Conv2DBlock(nn.Module):
         self.conv = _Conv3x3Params(in_dim, out_dim)
         self.bn = _BatchNormParams(out_dim)
         self._cache = {}
+        self._wino_plan = set()          # Winograd panels requested so far: what repack_wino_panels() rebuilds in one launch
 
     def _versions(self, names):
         out = []
@@ -79,6 +80,7 @@ class Conv2DBlock(nn.Module):
             w = self.conv.weight.detach()
             hit = (ver, ops.pack_wino_weights(w, c_from=c_from))
             self._cache[key] = hit
+            self._wino_plan.add((key, int(c_from), False))
         return hit[1]
 
     def packed_wino_t(self, c_from=0):
@@ -90,7 +92,16 @@ class Conv2DBlock(nn.Module):
             w = self.conv.weight.detach()
             hit = (ver, ops.pack_wino_weights(w, c_from=c_from, transpose_flip=True))
             self._cache[key] = hit
+            self._wino_plan.add((key, int(c_from), True))
         return hit[1]
+
+    def stale_wino_panels(self):
+        """[(cache key, c_from, transpose_flip)] of the Winograd panels this block has been asked for (by the forward / backward paths
+        actually taken: the plan follows the shapes and tuning switches by construction) whose weight has changed since."""
+        if not self._wino_plan:
+            return []
+        ver = self._versions(["conv"])
+        return [it for it in self._wino_plan if self._cache.get(it[0], (None,))[0] != ver]
 
     def packed_up2x(self, c0):
         """(class filters of the first c0 = upsampled input channels, packed 3x3 filter of the remaining skip channels):
@@ -281,6 +292,24 @@ class TrackNet(nn.Module):
         for m in self.modules():
             if isinstance(m, Conv2DBlock):
                 m.invalidate_caches()
+
+    def repack_wino_panels(self):
+        """Rebuild, in ONE launch on the current stream, every Winograd filter panel (forward and data-gradient) the blocks have been
+        asked for before and whose weights changed since -- what a training step does after each optimiser step, otherwise as ~33
+        14-us launches strung along the main stream.  Purely an accelerator of the lazy per-block caches: a panel that is not in a
+        block's plan yet (first step, new shape) is packed by the call that needs it."""
+        todo = []
+        for m in self.modules():
+            if isinstance(m, Conv2DBlock):
+                for it in m.stale_wino_panels():
+                    todo.append((m, it))
+        if len(todo) < 2:
+            return 0
+        with torch.no_grad():
+            panels = ops.pack_wino_weights_multi([(m.conv.weight.detach(), c_from, flip) for m, (_, c_from, flip) in todo])
+        for (m, (key, _, _)), u in zip(todo, panels):
+            m._cache[key] = (m._versions(["conv"]), u)
+        return len(todo)
 
     def prepare_eval(self):
         """Build (on the current stream) every cached eval-mode operand -- packed filters, folded BN scales -- so that

@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/tracknetv3_hip.h).  Plumbing only: argument checks, output
 allocation from the PyTorch caching allocator, current-stream hand-off.  All arithmetic is in the HIP library."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -101,6 +103,38 @@ def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False, vari
     _lib.check(lib.tnv3_conv3x3_wino_pack_view(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count,
                                                int(bool(transpose_flip)), layout, _lib.stream_ptr(weight)))
     return u
+
+
+class _WinoPackItem(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("u", ctypes.c_void_p), ("cout_w", ctypes.c_int), ("cin_w", ctypes.c_int), ("c_from", ctypes.c_int),
+                ("c_count", ctypes.c_int), ("transpose_flip", ctypes.c_int), ("layout", ctypes.c_int)]
+
+
+def pack_wino_weights_multi(specs, variant=None):
+    """[pack_wino_weights(weight, c_from=c_from, transpose_flip=flip) for (weight, c_from, flip) in specs] in ONE launch
+    (tnv3_conv3x3_wino_pack_multi): the panels a training step rebuilds after every optimiser step.  All weights on one device;
+    ordered on that device's current stream.  Bit-identical to the one-panel calls."""
+    lib = _lib.load()
+    if not specs:
+        return []
+    items = (_WinoPackItem * len(specs))()
+    outs, keep = [], []
+    dev = specs[0][0].device
+    for k, (weight, c_from, flip) in enumerate(specs):
+        _f32(weight)
+        if weight.device != dev:
+            raise _lib.Tnv3Error("pack_wino_weights_multi: all weights must live on one device")
+        weight = weight.contiguous()
+        keep.append(weight)
+        cout_w, cin_w = int(weight.shape[0]), int(weight.shape[1])
+        c_count = cin_w - int(c_from)
+        cout, cin = (c_count, cout_w) if flip else (cout_w, c_count)
+        u = torch.empty(lib.tnv3_conv3x3_wino_packed_floats(cin, cout), dtype=torch.float32, device=dev)
+        outs.append(u)
+        items[k] = _WinoPackItem(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count, int(bool(flip)), wino_layout(variant, cin, cout))
+    _lib.dev_check(keep[0])
+    _lib.check(lib.tnv3_conv3x3_wino_pack_multi(ctypes.cast(items, ctypes.c_void_p), len(specs), _lib.stream_ptr(keep[0])))
+    return outs
 
 
 def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None, variant=None):
@@ -907,7 +941,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # The C ABI runs a call on its stream's device, but a tensor's *default* stream is the NULL stream (= "the calling thread's
 # current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
-_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
+_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pack_wino_weights_multi", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "bn_bwd_consts", "conv3x3_wino_dgrad_bnstats", "bn_relu_backward_tiles", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",

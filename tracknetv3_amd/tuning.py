@@ -77,6 +77,11 @@ WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA 
 WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))   # Winograd-form weight gradient: -1 = 1 (5 for the stem), 1-4 role-split generations, 5 / 6 every wave streams and transforms, 0 the first kernel
 
 
+# Training: all Winograd filter panels that the optimiser step made stale are rebuilt by one launch at the start of the forward
+# (model.TrackNet.repack_wino_panels) instead of one 14-us launch in front of every convolution / data gradient.
+WINO_REPACK_MULTI = os.environ.get("TNV3_WINO_REPACK_MULTI", "1") != "0"
+
+
 # BatchNorm batch statistics from the convolution's epilogue (training forward): available in Winograd kernel variants 3, 4 and 5.
 BN_STATS_IN_EPILOGUE = os.environ.get("TNV3_BN_STATS_EPILOGUE", "1") != "0"
 
