@@ -243,7 +243,8 @@ def test_one_launch_filter_repack_equals_the_per_layer_packs(gpu_device, monkeyp
         monkeypatch.setattr(ops, "pack_wino_weights_multi", real)
         finals.append({k: v.detach().clone() for k, v in m.state_dict().items()})
         counts.append(n_multi)
-    assert counts[1] == [] and len(counts[0]) == 2 and counts[0][0] == counts[0][1] >= 20, counts      # steps 2 and 3: forward + data-gradient panels
+    # steps 2 and 3, forward + data-gradient panels of the layers that are 64 pixels wide (the only Winograd ones at 32 x 64)
+    assert counts[1] == [] and len(counts[0]) == 2 and counts[0][0] == counts[0][1] >= 4, counts
     for k in finals[0]:
         assert torch.equal(finals[0][k], finals[1][k]), k
 

@@ -47,6 +47,7 @@ struct ConvUp2xWinoArgs {
 inline __global__ void __launch_bounds__(256) conv_up2x_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin,
                                                                       int c0, int c0pad) {
   const long total = (long)c0pad * Cout;
+  if (blockIdx.x == 0 && threadIdx.x < kPackZeroTail) u[(size_t)c0pad * 9 * Cout + threadIdx.x] = 0.0f;      // the zero tail behind the panel
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int co = (int)(e % Cout), ci = (int)(e / Cout);
     float g[3][3];

@@ -39,6 +39,7 @@ struct DgradUp2xWinoArgs {
 inline __global__ void __launch_bounds__(256) dgrad_up2x_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin,
                                                                        int c0, int copad) {
   const long total = (long)copad * c0;
+  if (blockIdx.x == 0 && threadIdx.x < kPackZeroTail) u[(size_t)copad * 9 * c0 + threadIdx.x] = 0.0f;        // the zero tail behind the panel
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int ci = (int)(e % c0), co = (int)(e / c0);
     float g[3][3];

@@ -898,8 +898,6 @@ int conv_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, in
   if (!w || !u || cout <= 0 || cin <= 0 || c0 <= 0 || c0 > cin) TNV3_FAIL(-1, "conv_up2x_wino_pack: bad argument");
   const int c0pad = round_up(c0, ConvUp2xWinoCfg::CC);
   const long total = (long)c0pad * cout;
-  int rc;
-  if ((rc = L.launch(fill_zero_kernel, 1, 256, u + (size_t)c0pad * 9 * cout, kPackZeroTail))) return rc;
   return L.launch(conv_up2x_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, c0, c0pad);
 }
 template <class Launcher>
@@ -928,8 +926,6 @@ int dgrad_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, i
   if (!w || !u || cout <= 0 || cin <= 0 || c0 <= 0 || c0 > cin) TNV3_FAIL(-1, "dgrad_up2x_wino_pack: bad argument");
   const int copad = round_up(cout, DgradUp2xWinoCfg::CC);
   const long total = (long)copad * c0;
-  int rc;
-  if ((rc = L.launch(fill_zero_kernel, 1, 256, u + (size_t)copad * 9 * c0, kPackZeroTail))) return rc;
   return L.launch(dgrad_up2x_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, c0, copad);
 }
 template <class Launcher>
