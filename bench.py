@@ -212,6 +212,8 @@ TRAIN_FLOPS_PER_SAMPLE = 678.2e9    # fwd + dgrad + wgrad (no dgrad f
 #   forward 98.7 (of 227.6), data gradient 96.6 (of 223.0), weight gradient 101.2 (of 227.6)
 # Round 2: all three passes of the upsampled halves run in Winograd forms that keep 9 of the 16 GEMMs (9/36 instead of 4/9 of
 # their 65.2 GFLOP each): forward 86.0, data gradient 83.9, weight gradient 88.5.
+# Round 3: the stem's weight gradient also runs in Winograd form, on a 64-channel block of which 27 channels are live: the pipe executes
+# 4.83 GFLOP there instead of the direct kernel's 4.59 -- 0.1 % of the total, the constant stays.
 TRAIN_FLOPS_EXECUTED_PER_SAMPLE_CLASS_FILTERS = 296.5e9
 TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 296.5e9 - 3 * 65.2e9 * (4 / 9 - 9 / 36)
 
