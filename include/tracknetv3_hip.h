@@ -34,7 +34,9 @@ extern "C" {
 #define TNV3_E_LAUNCH (-2)    /* HIP launch error */
 #define TNV3_ABI_VERSION 4   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
                                  3: `variant` argument on the Winograd-form weight gradients;
-                                 4: `sum_order` on tnv3_ensemble_frames (the reference's summation order, bit-exact) */
+                                 4: `sum_order` on tnv3_ensemble_frames (the reference's summation order, bit-exact); `variant` on the
+                                    9-GEMM decoder kernels; the fused InpaintNet training entries; tnv3_conv3x3_wino_pick / _has_stats /
+                                    _pack_multi; tnv3_conv3x3_wgrad_wino variants 2-7 and any Cin */
 
 typedef void* tnv3_stream_t;
 
