@@ -101,7 +101,7 @@ def _train_forward_body(net, x):
                                                bn.eps, bn.momentum, tile_stats=stats)
         bn.num_batches_tracked.add_(1)
         blk._cache.pop("aff", None)       # running_var was rewritten through a raw pointer: the folded eval scale is stale
-        saved.append(dict(blk=blk, x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,
+        saved.append(dict(blk=blk, idx=len(saved), x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,
                           bn_ver=(bn.weight._version, bn.bias._version)))
         return a
 
@@ -174,7 +174,10 @@ def _train_backward_body(ctx, dev, head_backward):
                 return ops.conv3x3_wgrad_up2x(rec["x0"], rec["x1"], dz)
             if rec["x1"] is None and not rec["up"] and tuning.use_winograd_wgrad(
                     int(rec["x0"].shape[1]), blk.conv.out_dim, int(dz.shape[2]), int(dz.shape[3])):
-                return ops.conv3x3_wgrad_wino(rec["x0"], dz)      # plain deep layer: Winograd-form weight gradient
+                # plain layer: Winograd-form weight gradient (tuning.WGRAD_WINO_TAIL, default 0: the no-role kernel for the first
+                # blocks, whose launches are the last of backward -- measured, no gain)
+                tail = rec["idx"] < tuning.WGRAD_WINO_TAIL and tuning.WGRAD_WINO_VARIANT < 0
+                return ops.conv3x3_wgrad_wino(rec["x0"], dz, variant=5 if tail else None)
             return ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
 
         if side is None:

@@ -68,6 +68,13 @@ def use_winograd_wgrad(cin, cout, h, w):
     return ops.wgrad_wino_supported(cin, cout, h, w)
 
 
+# The weight gradients of the first WGRAD_WINO_TAIL Conv2DBlocks (forward order: stem, down_block_1.conv_2, down_block_2.conv_1, ...)
+# are the last launches of backward, when the main stream is winding down -- the case where the no-role kernel (variant 5: +12 % per
+# call, full-CU footprint) might win.  Measured (scripts/train_tail_ab.sh, two repeats): 0 blocks 31.66 / 31.81 ms per step, 2: 31.74 /
+# 31.92, 4: 31.77 / 31.90, 7: 32.05 / 31.96, 10: 31.96 / 31.89 -- it does not; default 0.
+WGRAD_WINO_TAIL = int(os.environ.get("TNV3_WGRAD_WINO_TAIL", "0"))
+
+
 # Kernel-family choices are per-call arguments of the C ABI (no process-wide state inside the library); these are the
 # defaults the Python layer passes.  -1 = the library's default, resolved INSIDE the library (kWinoDefaultVariant: today 5, the
 # streaming persistent Winograd kernel; register-staged weight gradient) -- layout and capabilities of "-1" are queried from it
