@@ -47,7 +47,7 @@ def wgrad_stream(dev):
         return None
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _WGRAD_STREAMS:
-        _WGRAD_STREAMS[key] = torch.cuda.Stream(dev)
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(dev, priority=tuning.WGRAD_STREAM_PRIORITY)
     return _WGRAD_STREAMS[key]
 
 

@@ -75,6 +75,12 @@ def use_winograd_wgrad(cin, cout, h, w):
 WGRAD_WINO_TAIL = int(os.environ.get("TNV3_WGRAD_WINO_TAIL", "0"))
 
 
+# HIP priority of the side stream the weight gradients run on (0 = default, -1 = high: its workgroups are dispatched before the main
+# stream's when CUs free up).  Measured (scripts/train_prio_ab.sh): 31.59 / 31.73 ms per step at 0, 31.75 / 31.59 at -1 -- no effect:
+# both streams are saturated (profiles/r03_train_timeline.json), priority only reorders who waits.
+WGRAD_STREAM_PRIORITY = int(os.environ.get("TNV3_WGRAD_STREAM_PRIORITY", "0"))
+
+
 # Kernel-family choices are per-call arguments of the C ABI (no process-wide state inside the library); these are the
 # defaults the Python layer passes.  -1 = the library's default, resolved INSIDE the library (kWinoDefaultVariant: today 5, the
 # streaming persistent Winograd kernel; register-staged weight gradient) -- layout and capabilities of "-1" are queried from it
