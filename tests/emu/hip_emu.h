@@ -314,6 +314,10 @@ inline void tnv3_buf_store_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset,
   const unsigned long long o = (unsigned long long)voffset + soffset;
   if (o + 8ull <= (unsigned long long)r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 8);
 }
+inline void tnv3_buf_store_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f4 v) {
+  const unsigned long long o = (unsigned long long)voffset + soffset;
+  if (o + 16ull <= (unsigned long long)r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 16);
+}
 
 // atomics (the emulator is single-threaded: plain read-modify-write)
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

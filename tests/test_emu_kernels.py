@@ -542,3 +542,40 @@ def test_inpaintnet_fused_kernel_emulated_vs_layer_kernels_and_oracle(emu, monke
     with torch.no_grad():
         ref2 = nets.inpaintnet_forward(sd2, x, m)
     assert (net(x, m) - ref2).abs().max().item() <= 2e-6
+
+
+# ---- Winograd F(4x4, 3x3) form (kernels/conv3x3_wino43_mfma.h): another factorisation -> compared with fp64 torch, not bit-wise
+WINO43_CASES = [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (1, 27, 64, 8, 128), (1, 8, 64, 24, 64)]      # (n, cin, cout, h, w)
+
+
+def _wino43_case(case, device, tol=2e-5):        # F(4x4, 3x3) in fp32: 4e-6 (K = 27 x 9) .. 9e-6 (K = 256 x 9) of the output scale per layer (F(2x2) and direct: 3-5e-7)
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = case
+    x, wt = torch.relu(T((n, cin, h, w), 491)).to(device), T((cout, cin, 3, 3), 492, -0.3, 0.3).to(device)
+    mean, scale, shift = T((cout,), 493).to(device), T((cout,), 494, 0.5, 1.5).to(device), T((cout,), 495).to(device)
+    add = T((n, cout, h, w), 496).to(device)
+    assert ops.wino43_supported(cin, cout, h, w)
+    u = ops.pack_wino43_weights(wt)
+    ref = F.conv2d(x.double().cpu(), wt.double().cpu(), padding=1)
+    mag = ref.abs().max().item()
+    got = ops.conv3x3_wino43(x, u, cout)
+    assert (got.double().cpu() - ref).abs().max().item() <= tol * mag
+    full = torch.relu((ref + add.double().cpu() - mean.double().cpu()[None, :, None, None]) * scale.double().cpu()[None, :, None, None]
+                      + shift.double().cpu()[None, :, None, None])
+    got_full = ops.conv3x3_wino43(x, u, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add)
+    assert (got_full.double().cpu() - full).abs().max().item() <= tol * max(mag, full.abs().max().item())
+    assert torch.equal(got, ops.conv3x3_wino43(x, u, cout))                                   # deterministic
+    # the data gradient's filter: conv of dZ with the transposed, flipped weight == autograd's dX
+    dz = T((n, cout, h, w), 497).to(device)
+    xd = x.double().cpu().requires_grad_(True)
+    F.conv2d(xd, wt.double().cpu(), padding=1).backward(dz.double().cpu())
+    if cin % 64 == 0:
+        dx = ops.conv3x3_wino43(dz, ops.pack_wino43_weights(wt, transpose_flip=True), cin)
+        assert (dx.double().cpu() - xd.grad).abs().max().item() <= tol * xd.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("case", WINO43_CASES)
+def test_conv3x3_wino43_emulated_vs_torch(emu, monkeypatch, case):
+    for cus in ("2", "256"):
+        monkeypatch.setenv("TNV3_EMU_CUS", cus)
+        _wino43_case(case, "cpu")

@@ -274,3 +274,12 @@ def test_dgrad_up2x_wino_vs_autograd(gpu_device, case):
     from test_emu_kernels import _dgrad_up2x_wino_case
     e_ref, e_old = _dgrad_up2x_wino_case(*case, gpu_device)
     assert e_ref <= 3e-6 and e_old <= 4e-6, (e_ref, e_old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (2, 27, 64, 288, 512), (2, 64, 64, 288, 512), (3, 128, 128, 144, 256), (2, 256, 256, 72, 128)])
+def test_conv3x3_wino43_vs_torch(gpu_device, case):
+    """Winograd F(4x4, 3x3) forward kernel vs fp64 torch: plain, eval epilogue (affine + addend + ReLU), run-to-run identical, and as
+    the data gradient (transposed, flipped panel)."""
+    from test_emu_kernels import _wino43_case
+    _wino43_case(case, gpu_device)

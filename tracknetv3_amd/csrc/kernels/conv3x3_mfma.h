@@ -142,6 +142,9 @@ typedef unsigned tnv3_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ tnv3_f4 tnv3_buf_load_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
   return __builtin_bit_cast(tnv3_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, (int)soffset, 0));
 }
+__device__ __forceinline__ void tnv3_buf_store_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tnv3_u4, v), r, (int)voffset, (int)soffset, 0);
+}
 #endif
 
 // Makes a per-lane value opaque to the optimiser at this point: what is derived from it afterwards cannot be hoisted out of the

@@ -1,0 +1,410 @@
+// conv3x3_wino43_mfma.h -- the plain 3x3 'same' convolution in fused Winograd F(4x4, 3x3) form (tnv3_conv3x3_wino43_forward).
+//
+// F(2x2, 3x3) (conv3x3_wino*_mfma.h) multiplies 16 transform coefficients per 2x2 output tile -- 4 per output pixel instead of the
+// direct form's 9; F(4x4, 3x3) multiplies 36 per 4x4 tile -- 2.25 per pixel, 1.78x fewer MFMAs again.  Its transforms are no longer
+// adds only (B^T has the entries 4, -5, 2; G has 1/4, 1/6, 1/24; A^T has 2, 4, 8), which costs accuracy: on the whole TrackNet(27 -> 8)
+// forward at 288 x 512 the heat maps deviate from the fp64 forward by 3.1e-6 (F(2x2): 1.4e-6, direct fp32: see
+// profiles/r03_wino_f43_precision.json; the path's bar is 1e-4).  Same function as tnv3_conv3x3_wino_forward up to that rounding.
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A          d: 6x6 input patch (stride 4), Y: 4x4 outputs, 36 products per (co, ci, tile)
+//
+// Mapping.  Workgroup tile = 64 output channels x 32 tiles (2 tile rows x 16 tile columns = 8 x 64 pixels), 512 threads.  The 36
+// transform coefficients xi = (i, j) are dealt in four 3x3 blocks xg = (i / 3, j / 3); wave = (xg, 32-channel block wm) keeps the nine
+// xi of its block for 32 channels x 32 tiles: 144 accumulator registers (MFMA 32x32x2: M = channels, N = tiles, K = input channel pairs).
+//   * A operand (U = G g G^T) straight from L2 into registers, as in conv3x3_wino6_mfma.h: the panel is packed in lane order
+//     [32-channel block][chunk of 8 ci][xg][x9][lane = (k half, channel)][4 K steps]: nine 16-byte loads per wave and chunk, each
+//     quad re-loaded in place behind the MFMAs that consumed it.
+//   * B operand V = B^T d B in LDS as V[xg][x9][tile][12: (k half) x 4 K steps + pad]: ONE ds_read_b128 feeds the four K steps of a xi
+//     (tile stride 12 floats: conflict-free in the hardware's 16-lane groups); two stages (chunk k is consumed while k+1 is made).
+//   * no roles (wgrad_wino5_mfma_kernel's lesson): every wave streams its 36 MFMAs of chunk k and, between them, transforms HALF a
+//     patch of chunk k+1 -- thread = (channel, tile, row half rh): three rows of B^T d B from five raw rows, 72 fused multiply-adds,
+//     15 LDS reads, 18 stores -- and issues its LDS-DMA pieces of chunk k+2.
+//   * write-out: every wave turns its 3x3 block of M into its PARTIAL 4x4 output (A^T[:, I] M_IJ A[J, :]), the four xg waves of a channel
+//     block meet through LDS (in four rounds of four channels), wave xg finishes output row xg of every tile: 16-byte stores.
+// Needs Cout % 64 == 0, H % 8 == 0, W % 64 == 0.  Not bit-identical to the F(2x2) kernels (another factorisation); deterministic.
+#pragma once
+#include <type_traits>
+#include "conv3x3_wino3_mfma.h"
+
+namespace tnv3 {
+
+struct Wino43Cfg {
+  static constexpr int CC = 8, NT = 512, MB = 64, TB = 32;
+  static constexpr int TH = 8, TW = 64;                    // pixels per workgroup tile
+  static constexpr int RROWS = 10, RW = 80;                 // raw halo tile per channel: rows h0-1 .. h0+8; 80 floats per row = 20 pieces, the
+                                                            // first 18 = columns w0-4 .. w0+67 (row stride 80: the transform's 16-byte reads
+                                                            // of tile rows 0 / 1 then fall into disjoint bank ranges)
+  static constexpr int RAWP = RROWS * RW;                   // 800 floats per channel
+  static constexpr int RAW_STAGE = CC * RAWP;               // 6400 floats = 1600 pieces: three per thread + one more for wave 0
+  static constexpr int VT = 12;                             // floats per (xi, tile): [k half][4 K steps] + 4 pad
+  static constexpr int V_STAGE = 36 * TB * VT;              // 13824 floats
+  static constexpr int LDS_FLOATS = 2 * V_STAGE + 2 * RAW_STAGE;
+  static constexpr int A_CHUNK_FLOATS = 4 * 9 * 64 * 4;     // one (32-channel block, chunk) of the panel: [xg][x9][lane][4]
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
+
+inline size_t conv3x3_wino43_packed_floats(int cin, int cout) {
+  if (cin <= 0 || cout <= 0 || cout % 32) return 0;
+  return (size_t)(cout / 32) * ((cin + Wino43Cfg::CC - 1) / Wino43Cfg::CC) * Wino43Cfg::A_CHUNK_FLOATS + kPackZeroTail;
+}
+
+// G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]:  row i of G applied to (g0, g1, g2)
+__device__ __forceinline__ float wino43_g_row(int i, float g0, float g1, float g2) {
+  switch (i) {
+    case 0: return 0.25f * g0;
+    case 1: return (-1.0f / 6.0f) * ((g0 + g1) + g2);
+    case 2: return (-1.0f / 6.0f) * ((g0 - g1) + g2);
+    case 3: return (1.0f / 24.0f) * g0 + ((1.0f / 12.0f) * g1 + (1.0f / 6.0f) * g2);
+    case 4: return (1.0f / 24.0f) * g0 + ((-1.0f / 12.0f) * g1 + (1.0f / 6.0f) * g2);
+    default: return g2;
+  }
+}
+
+// w[..][3][3] (strides s_co / s_ci floats between output / input channels; flip: taps reversed -- the data gradient's filter) ->
+// panel u[co / 32][chunk][xg][x9][lane = (ci % 2) * 32 + co % 32][ci % 8 / 2], zero for ci >= Cin; then kPackZeroTail zeros.
+inline __global__ void __launch_bounds__(256) conv3x3_wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin,
+                                                                        long s_co, long s_ci, int flip) {
+  const int nch = (Cin + 7) / 8;
+  const long body = (long)(Cout / 32) * nch * Wino43Cfg::A_CHUNK_FLOATS, total = body + kPackZeroTail;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    if (e >= body) { u[e] = 0.0f; continue; }
+    const int s = (int)(e & 3), ln = (int)((e >> 2) & 63);
+    long r = e >> 8;
+    const int x9 = (int)(r % 9); r /= 9;
+    const int xg = (int)(r & 3); r >>= 2;
+    const int k = (int)(r % nch), mb32 = (int)(r / nch);
+    const int co = 32 * mb32 + (ln & 31), ci = 8 * k + 2 * s + (ln >> 5);
+    const int i = 3 * (xg >> 1) + x9 / 3, j = 3 * (xg & 1) + x9 % 3;
+    float v = 0.0f;
+    if (ci < Cin) {
+      const float* g = w + (long)co * s_co + (long)ci * s_ci;
+      float rowv[3];                                     // row i of G applied down the filter's columns
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float g0 = flip ? g[8 - c] : g[c], g1 = flip ? g[5 - c] : g[3 + c], g2 = flip ? g[2 - c] : g[6 + c];
+        rowv[c] = wino43_g_row(i, g0, g1, g2);
+      }
+      v = wino43_g_row(j, rowv[0], rowv[1], rowv[2]);
+    }
+    u[e] = v;
+  }
+}
+
+// One 1-D input transform B^T applied to six values, the three outputs of one half: rows 0..2 (RH = 0) or 3..5 (RH = 1).
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+template <int RH>
+__device__ __forceinline__ void wino43_bt_half(const float (&d)[6], float (&t)[3]) {
+  if (RH == 0) {
+    t[0] = fmaf(4.0f, d[0], fmaf(-5.0f, d[2], d[4]));
+    const float a = fmaf(-4.0f, d[2], d[4]), b = fmaf(-4.0f, d[1], d[3]);
+    t[1] = a + b;
+    t[2] = a - b;
+  } else {
+    const float c = d[4] - d[2], e = d[3] - d[1];
+    t[0] = fmaf(2.0f, e, c);
+    t[1] = fmaf(-2.0f, e, c);
+    t[2] = fmaf(4.0f, d[1], fmaf(-5.0f, d[3], d[5]));
+  }
+}
+// ... and all six outputs (the second pass along a row of the half-transformed patch)
+__device__ __forceinline__ void wino43_bt_full(const float (&d)[6], float (&t)[6]) {
+  t[0] = fmaf(4.0f, d[0], fmaf(-5.0f, d[2], d[4]));
+  const float a = fmaf(-4.0f, d[2], d[4]), b = fmaf(-4.0f, d[1], d[3]);
+  t[1] = a + b;
+  t[2] = a - b;
+  const float c = d[4] - d[2], e = d[3] - d[1];
+  t[3] = fmaf(2.0f, e, c);
+  t[4] = fmaf(-2.0f, e, c);
+  t[5] = fmaf(4.0f, d[1], fmaf(-5.0f, d[3], d[5]));
+}
+
+// Output transform: three M values of one half (J = 0: coefficients 0..2, J = 1: 3..5) -> their contribution to the four outputs.
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+template <int J>
+__device__ __forceinline__ void wino43_at_half(float m0, float m1, float m2, float (&o)[4]) {
+  if (J == 0) {
+    const float p = m1 + m2, q = m1 - m2;
+    o[0] = m0 + p; o[1] = q; o[2] = p; o[3] = q;
+  } else {
+    const float p = m0 + m1, q = m0 - m1;
+    o[0] = p; o[1] = 2.0f * q; o[2] = 4.0f * p; o[3] = fmaf(8.0f, q, m2);
+  }
+}
+
+inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const WinoArgs a) {
+  using Cfg = Wino43Cfg;
+  constexpr int CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, RW = Cfg::RW, RAWP = Cfg::RAWP, VT = Cfg::VT;
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  float* v_s = lds;                                   // two stages each
+  float* raw_s = lds + 2 * Cfg::V_STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
+  const int xg = swave & 3, wm = swave >> 2;
+  const int half = lane >> 5, bl = lane & 31;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+  const int tilesH = H / Cfg::TH, tilesW = W / Cfg::TW;
+  const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
+  const int nChunks = (Cin + CC - 1) / CC;
+
+  ConvTileWalk walk;
+  walk.init(blockIdx.x, gridDim.x, nMB, nPT, tilesH, tilesW);
+  if (!walk.valid) return;
+
+  const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);      // scalar: the LDS-DMA destination (M0) stays on the SALU
+  const size_t x_step = (size_t)CC * HW;
+  // ---- transform roles: thread = (channel t_c, tile t_t, row half rh); rh is wave-uniform (waves 0-3 / 4-7)
+  const int rh = swave >> 2;
+  const int tp = tid & 255, t_c = tp >> 5, t_t = tp & 31, t_tr = t_t >> 4, t_tc = t_t & 15;
+  const int t_src = t_c * RAWP + (4 * t_tr) * RW + 4 * t_tc;        // + row * RW: 16-byte aligned
+  const int t_dst = t_t * VT + (t_c & 1) * 4 + (t_c >> 1);           // + (xg * 9 + x9) * TB * VT
+  // ---- MFMA operands
+  const int b_off = (xg * 9) * TB * VT + bl * VT + half * 4;        // + x9 * TB * VT
+  const unsigned a_lane_b = (unsigned)lane * 16u;
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+
+  // Everything below is instantiated twice, for the wave's row half RH (waves 0-3 / 4-7), and selected by ONE scalar branch around
+  // the whole tile loop: the transform's code differs per half, and a branch inside the chunk loop would put the accumulators through
+  // phi copies between the two arms.
+  auto body = [&](auto rhc) {
+  constexpr int RH = decltype(rhc)::value;
+  f32x4 av[9];
+  f32x16 acc[9];
+  for (;;) {                                            // one pass per workgroup tile (no streaming through the tile boundary yet)
+    const int e_n = walk.n, e_h0 = walk.trow * Cfg::TH, e_w0 = walk.tcol * Cfg::TW, e_m0 = walk.mb * MB;
+    // raw LDS-DMA offsets of this tile: slot e = tid + i * 512 -> (channel, row, piece) of [CC][10][20]; pieces 18, 19 of a row and
+    // everything outside the image read out of range (= 0)
+    unsigned vo[4];
+    {
+      int t_op = tid;
+      TNV3_OPAQUE_V(t_op);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = t_op + i * NT;
+        const int c = e / 200, rem = e - c * 200;
+        const int r = rem / 20, q = rem - r * 20;
+        const int gh = e_h0 - 1 + r, gw = e_w0 - 4 + 4 * q;
+        const bool ok = e < 1600 && q < 18 && gh >= 0 && gh < H && gw >= 0 && gw < W;
+        vo[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
+      }
+    }
+    const float* xp = a.src + (size_t)e_n * Cin * HW;
+    auto dma_chunk = [&](int k, int stage) {            // chunk k of this tile -> raw stage
+      const int cvalid = Cin - k * CC;
+      const tnv3_rsrc_t rr = tnv3_make_rsrc(xp + (size_t)k * x_step, (unsigned)(cvalid < CC ? cvalid : CC) * (unsigned)HW * 4u);
+      float* rs = raw_s + stage * Cfg::RAW_STAGE;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tnv3_buf_dma16(rr, rs + (i * NT + wbase) * 4, vo[i]);
+      if (swave == 0) tnv3_buf_dma16(rr, rs + (3 * NT + wbase) * 4, vo[3]);     // slots 1536 .. 1599
+    };
+    const float* a_tile = a.u + ((size_t)(e_m0 / 32 + wm) * nChunks) * Cfg::A_CHUNK_FLOATS + xg * (9 * 256);
+    auto load_a = [&](int k, int x9) {
+      const tnv3_rsrc_t ra = tnv3_make_rsrc(a_tile + (size_t)k * Cfg::A_CHUNK_FLOATS, 9u * 1024u);
+      av[x9] = tnv3_buf_load_f4(ra, a_lane_b, (unsigned)x9 * 1024u);
+    };
+    // ---- the half-patch transform of one chunk (raw stage -> V stage of the same parity), in pieces that the chunk loop places between
+    //      its MFMA groups: rows 3 RH .. 3 RH + 2 of B^T d B from raw rows RH .. RH + 4 of the patch
+    float t[3][6];
+    auto column = [&](int c, float x0, float x1, float x2, float x3, float x4) {      // the 1-D transform down patch column c
+      float col[6], o[3];
+      if (RH == 0) { col[0] = x0; col[1] = x1; col[2] = x2; col[3] = x3; col[4] = x4; col[5] = 0.0f; }
+      else { col[0] = 0.0f; col[1] = x0; col[2] = x1; col[3] = x2; col[4] = x3; col[5] = x4; }
+      wino43_bt_half<RH>(col, o);
+      t[0][c] = o[0]; t[1][c] = o[1]; t[2][c] = o[2];
+    };
+    auto t_read_mid = [&](int stage, f32x4 (&q)[5]) {     // patch columns 1..4: one 16-byte read per raw row
+      const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src + RH * RW;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) q[r] = *reinterpret_cast<const f32x4*>(d + r * RW + 4);
+    };
+    auto t_cols_mid = [&](const f32x4 (&q)[5]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) column(1 + c, q[0][c], q[1][c], q[2][c], q[3][c], q[4][c]);
+    };
+    auto t_read_edge = [&](int stage, float (&e0)[5], float (&e5)[5]) {      // patch columns 0 and 5
+      const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src + RH * RW;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) { e0[r] = d[r * RW + 3]; e5[r] = d[r * RW + 8]; }
+    };
+    auto t_cols_edge = [&](const float (&e0)[5], const float (&e5)[5]) {
+      column(0, e0[0], e0[1], e0[2], e0[3], e0[4]);
+      column(5, e5[0], e5[1], e5[2], e5[3], e5[4]);
+    };
+    auto t_row = [&](int stage, int r) {                 // second pass along row r, results straight into V: xi = (3 RH + r, j)
+      float* vdst = v_s + stage * Cfg::V_STAGE + t_dst;
+      float o[6];
+      wino43_bt_full(t[r], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) vdst[((2 * RH + j / 3) * 9 + 3 * r + j % 3) * (TB * VT)] = o[j];      // block (RH, j / 3), x9 = 3 r + j % 3
+    };
+    auto transform_all = [&](int stage) {
+      f32x4 q[5];
+      float e0[5], e5[5];
+      t_read_mid(stage, q);
+      t_cols_mid(q);
+      t_read_edge(stage, e0, e5);
+      t_cols_edge(e0, e5);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) t_row(stage, r);
+    };
+    auto full_barrier = [&]() {
+      __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+      __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+      __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- pipeline fill: A of chunk 0, raw tiles of chunks 0 and 1, V of chunk 0
+#pragma unroll
+    for (int x = 0; x < 9; ++x) load_a(0, x);
+    dma_chunk(0, 0);
+    if (nChunks > 1) dma_chunk(1, 1);
+    full_barrier();
+    transform_all(0);
+    full_barrier();
+
+    // One chunk: the 36 MFMAs of chunk k (V stage k & 1) in five xi groups, and between the groups the half-patch transform of chunk
+    // k+1 (raw stage -> V stage of the other parity; after the last chunk: of a stale raw stage into a V stage nobody reads --
+    // unconditional, so that the stream stays straight-line code); the raw tile of chunk k+2 goes into raw stage k & 1, whose rows were
+    // consumed one chunk ago.
+    auto chunk_body = [&](int k, auto first_c) {
+      constexpr bool FIRST = decltype(first_c)::value;    // the tile's first chunk starts the accumulators from zero
+      const int sc = k & 1, sn = sc ^ 1;
+      const float* B = v_s + sc * Cfg::V_STAGE + b_off;
+      const int knext = k + 1 < nChunks ? k + 1 : k;      // (the last chunk re-loads its own A: unconditional loads)
+      f32x4 bq[4];                                      // ring: the quads of xi pair p in bq[2 (p & 1)], bq[2 (p & 1) + 1]
+      auto read_pair = [&](int p) {
+        bq[2 * (p & 1)] = *reinterpret_cast<const f32x4*>(B + (2 * p) * (TB * VT));
+        if (p < 4) bq[2 * (p & 1) + 1] = *reinterpret_cast<const f32x4*>(B + (2 * p + 1) * (TB * VT));
+      };
+      auto mfma_pair = [&](int p) {
+        const int x0 = 2 * p, x1 = p < 4 ? 2 * p + 1 : -1;
+        if (p + 1 < 5) read_pair(p + 1);                 // fenced: the next pair's reads go out before this pair's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x0][s], bq[2 * (p & 1)][s], FIRST && s == 0 ? zero16 : acc[x0], 0, 0, 0);
+          if (x1 >= 0) acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x1][s], bq[2 * (p & 1) + 1][s], FIRST && s == 0 ? zero16 : acc[x1], 0, 0, 0);
+        }
+        load_a(knext, x0);
+        if (x1 >= 0) load_a(knext, x1);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      f32x4 q[5];
+      float e0[5], e5[5];
+      read_pair(0);
+      if (k + 2 < nChunks) dma_chunk(k + 2, sc);
+      t_read_mid(sn, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair(0);
+      t_cols_mid(q);
+      t_read_edge(sn, e0, e5);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair(1);
+      t_cols_edge(e0, e5);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair(2);
+      t_row(sn, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair(3);
+      t_row(sn, 1);
+      t_row(sn, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair(4);
+      // this wave's raw pieces of chunk k+2 have landed (they are OLDER than the nine A loads issued since), its V stores are done
+      __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(9));
+      __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+      __builtin_amdgcn_s_barrier();
+    };
+    chunk_body(0, std::true_type{});
+    for (int k = 1; k < nChunks; ++k) chunk_body(k, std::false_type{});
+
+    // ---- write-out.  This wave's partial 4x4 output per (channel r of the lane, tile bl): P = A^T[:, I] M_IJ A[J, :] with
+    //      I = rows 3 (xg >> 1) .., J = columns 3 (xg & 1) ..; the four xg waves of a channel block exchange through LDS, wave xg
+    //      finishes output row xg.  Rounds of four channels r: the exchange of a round is 8 waves x 3 rows x 4 r x 16 bytes x 64 lanes = 96 KB.
+    float* xch = lds;                                    // [dst wave 8][src slot 3][r 4][lane 64][4]
+    const bool has_affine = a.scale != nullptr, has_mean = a.mean != nullptr, has_addend = a.addend != nullptr;
+    const int t_r = bl >> 4, t_col = bl & 15;
+    const int oh = e_h0 + 4 * t_r + xg, ow = e_w0 + 4 * t_col;
+    const unsigned lane_off_b = (unsigned)((wm * 32 + 4 * half) * HW + oh * W + ow) * 4u;
+    const size_t plane0 = ((size_t)e_n * Cout + e_m0) * HW;
+    const unsigned planes_b = (unsigned)MB * (unsigned)HW * 4u;
+    const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
+    const tnv3_rsrc_t r_add = tnv3_make_rsrc(has_addend ? a.addend + plane0 : a.dst + plane0, planes_b);
+    auto chan_off = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)HW * 4u; };
+    const int xi_i = xg >> 1, xi_j = xg & 1;
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {                     // channels r = 4 rd .. 4 rd + 3 of the lane's sixteen
+      float own[4][4];                                   // [r][output column]: this wave's own share of output row xg
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * rd + rr;
+        float wv[3][4];                                  // W[i][b] = sum_j M[i][j] A^T[b][j]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (xi_j) wino43_at_half<1>(acc[3 * i][r], acc[3 * i + 1][r], acc[3 * i + 2][r], wv[i]);
+          else wino43_at_half<0>(acc[3 * i][r], acc[3 * i + 1][r], acc[3 * i + 2][r], wv[i]);
+        }
+        float pr[4][4];                                  // P[a][b] = sum_i A^T[a][i] W[i][b]
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          float o[4];
+          if (xi_i) wino43_at_half<1>(wv[0][b], wv[1][b], wv[2][b], o);
+          else wino43_at_half<0>(wv[0][b], wv[1][b], wv[2][b], o);
+          pr[0][b] = o[0]; pr[1][b] = o[1]; pr[2][b] = o[2]; pr[3][b] = o[3];
+        }
+#pragma unroll
+        for (int arow = 0; arow < 4; ++arow) {
+          if (arow == xg) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) own[rr][b] = pr[arow][b];
+          } else {                                       // to wave (arow, wm): slot = this wave's rank among its three senders
+            const int slot = xg < arow ? xg : xg - 1;
+            f32x4 o4;
+            o4[0] = pr[arow][0]; o4[1] = pr[arow][1]; o4[2] = pr[arow][2]; o4[3] = pr[arow][3];
+            *reinterpret_cast<f32x4*>(xch + ((((wm * 4 + arow) * 3 + slot) * 4 + rr) * 64 + lane) * 4) = o4;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * rd + rr;
+        f32x4 v;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[b] = own[rr][b];
+#pragma unroll
+        for (int slot = 0; slot < 3; ++slot) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(xch + ((((wm * 4 + xg) * 3 + slot) * 4 + rr) * 64 + lane) * 4);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) v[b] += g[b];
+        }
+        if (has_addend) {
+          const f32x4 ad = tnv3_buf_load_f4(r_add, lane_off_b, chan_off(r));
+#pragma unroll
+          for (int b = 0; b < 4; ++b) v[b] += ad[b];
+        }
+        if (has_affine) {
+          const int ch = e_m0 + wm * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+          const float mu = has_mean ? a.mean[ch] : 0.0f, sc = a.scale[ch], sh = a.shift[ch];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) v[b] = (v[b] - mu) * sc + sh;
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) v[b] = v[b] > 0.0f ? v[b] : 0.0f;
+        }
+        tnv3_buf_store_f4(r_dst, lane_off_b, chan_off(r), v);
+      }
+      __syncthreads();
+    }
+
+    walk.next();
+    if (!walk.valid) break;
+  }
+  };
+  if (rh) body(std::integral_constant<int, 1>{}); else body(std::integral_constant<int, 0>{});
+}
+
+}  // namespace tnv3

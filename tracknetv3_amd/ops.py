@@ -105,6 +105,43 @@ def pack_wino_weights(weight, c_from=0, c_count=None, transpose_flip=False, vari
     return u
 
 
+def wino43_supported(cin, cout, h, w):
+    return bool(_lib.load().tnv3_conv3x3_wino43_supported(int(cin), int(cout), int(h), int(w)))
+
+
+def pack_wino43_weights(weight, c_from=0, transpose_flip=False):
+    """nn.Conv2d weight (Cout, Cin, 3, 3) -> Winograd F(4x4, 3x3) filter panel of its input channels c_from.. (transpose_flip: the
+    data gradient's filter) for conv3x3_wino43."""
+    lib = _lib.load()
+    _f32(weight)
+    weight = weight.contiguous()
+    _lib.dev_check(weight)
+    cout_w, cin_w = int(weight.shape[0]), int(weight.shape[1])
+    c_count = cin_w - int(c_from)
+    cout, cin = (c_count, cout_w) if transpose_flip else (cout_w, c_count)
+    u = torch.empty(lib.tnv3_conv3x3_wino43_packed_floats(cin, cout), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.tnv3_conv3x3_wino43_pack(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count, int(bool(transpose_flip)),
+                                            _lib.stream_ptr(weight)))
+    return u
+
+
+def conv3x3_wino43(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None):
+    """The plain layer in Winograd F(4x4, 3x3) form (tnv3_conv3x3_wino43_forward): act(((conv3x3(src) + addend) - mean) * scale + shift)."""
+    lib = _lib.load()
+    _f32(src, u, mean, scale, shift, addend)
+    _lib.dev_check(src, u, mean, scale, shift, addend)
+    n, cin, h, w = (int(v) for v in src.shape)
+    if u.numel() != lib.tnv3_conv3x3_wino43_packed_floats(cin, int(cout)):
+        raise _lib.Tnv3Error("conv3x3_wino43: filter panel does not match the channel counts")
+    out = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=src.device)
+    if addend is not None and tuple(addend.shape) != tuple(out.shape):
+        raise _lib.Tnv3Error("conv3x3_wino43: addend must have the output's shape")
+    if n:
+        _lib.check(lib.tnv3_conv3x3_wino43_forward(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(shift),
+                                                   _lib.ptr(out), n, cin, int(cout), h, w, int(bool(relu)), _lib.stream_ptr(src)))
+    return out
+
+
 class _WinoPackItem(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("u", ctypes.c_void_p), ("cout_w", ctypes.c_int), ("cin_w", ctypes.c_int), ("c_from", ctypes.c_int),
                 ("c_count", ctypes.c_int), ("transpose_flip", ctypes.c_int), ("layout", ctypes.c_int)]
@@ -941,7 +978,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # The C ABI runs a call on its stream's device, but a tensor's *default* stream is the NULL stream (= "the calling thread's
 # current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
-_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pack_wino_weights_multi", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
+_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pack_wino_weights_multi", "pack_wino43_weights", "conv3x3_wino43", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "bn_bwd_consts", "conv3x3_wino_dgrad_bnstats", "bn_relu_backward_tiles", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
