@@ -31,7 +31,7 @@ import torch  # noqa: E402
 SEQ_LEN, BG_MODE, H, W = 8, "concat", 288, 512
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (= fp32 vector peak)
 PEAK_HBM_GBPS = 8000.0
-KERNEL_SET = "wino_a128+wino_stream+up2x_wino"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
+KERNEL_SET = "wino43+wino_a128+wino_stream+up2x_wino"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
 ALG_BYTES_PER_SAMPLE = 693.55e6    # ideal-fusion fp32 bytes of one 27->8 forward
 
 
@@ -515,7 +515,7 @@ def main():
     # per-launch timing of the dominant kernel family: HIP events on the launch stream
     layers = conv_layer_table(in_dim, H, W)
     events = []
-    ops_conv, ops_up2x, ops_wino, ops_up2xw = ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino
+    ops_conv, ops_up2x, ops_wino, ops_up2xw, ops_w43 = ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino, ops.conv3x3_wino43
 
     def timed(kind, fn):
         def wrap(*a, **kw):
@@ -528,7 +528,7 @@ def main():
         return wrap
 
     timed_conv, timed_up2x, timed_wino = timed("conv", ops_conv), timed("up2x", ops_up2x), timed("conv", ops_wino)
-    timed_up2xw = timed("up2x", ops_up2xw)
+    timed_up2xw, timed_w43 = timed("up2x", ops_up2xw), timed("conv", ops_w43)
 
     def barrier():
         if world > 1:
@@ -571,9 +571,9 @@ def main():
         if split_on:
             for _ in range(min(args.warmup, 2)):
                 model(x)
-        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino = timed_conv, timed_up2x, timed_wino, timed_up2xw
+        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino, ops.conv3x3_wino43 = timed_conv, timed_up2x, timed_wino, timed_up2xw, timed_w43
         single_s = [block(args.steps) for _ in range(n_blocks)]
-        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino = ops_conv, ops_up2x, ops_wino, ops_up2xw
+        ops.conv3x3, ops.conv_up2x, ops.conv3x3_wino, ops.conv_up2x_wino, ops.conv3x3_wino43 = ops_conv, ops_up2x, ops_wino, ops_up2xw, ops_w43
     if not split_on:
         blocks_s = single_s
     dt = float(np.median(blocks_s))
@@ -623,12 +623,18 @@ def main():
         fl = np.array([conv_flops(c0, c1, co, h, w) * args.batch for (_, c0, c1, co, h, w, _) in layers])
         # multiply-adds the device executes: the upsampled channels (c0 of an `up` layer) cost 4 taps instead of 9, and the
         # plain halves that run in Winograd F(2x2,3x3) form cost 16 instead of 36 per 2x2 tile
+        # (Winograd F(4x4,3x3), where the eval forward uses it: 36 per 4x4 tile = 9/36 of the direct count)
+        def plain_frac(ci, co, h, w, skip_half=False):
+            if (not skip_half or ci >= _tuning.WINOGRAD_MIN_SKIP) and _tuning.use_wino43(ci, co, h, w):
+                return 9 / 36
+            return 16 / 36 if _tuning.use_winograd(ci, co, h, w) else 1.0
+
         def executed(c0, c1, co, h, w, up):
             if up:
-                skip = conv_flops(c1, 0, co, h, w) * (16 / 36 if _tuning.use_winograd(c1, co, h, w) else 1.0)
+                skip = conv_flops(c1, 0, co, h, w) * plain_frac(c1, co, h, w, skip_half=True)
                 up_frac = 9 / 36 if (_tuning.UP2X_WINO and ops.up2x_wino_supported(c0, co, h // 2, w // 2)) else 4 / 9
                 return conv_flops(c0, 0, co, h, w) * up_frac + skip
-            return conv_flops(c0, c1, co, h, w) * (16 / 36 if _tuning.use_winograd(c0, co, h, w) else 1.0)
+            return conv_flops(c0, c1, co, h, w) * plain_frac(c0, co, h, w)
         fl_exec = np.array([executed(c0, c1, co, h, w, up) * args.batch for (_, c0, c1, co, h, w, up) in layers])
         conv_ms = float(per_layer_ms.sum())
         effective = float(fl.sum() / conv_ms / 1e9)              # the reference's algorithmic FLOPs per second of conv-kernel time
@@ -685,8 +691,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch",
-                         "kernel": f"conv3x3_wino_stream_mfma_kernel<*> + conv_up2x_wino_stream_kernel + conv3x3_mfma_kernel<*> ({launches_per_step} "
-                                   "launches/step for the 17 conv layers, fp32 MFMA 32x32x2)",
+                         "kernel": f"conv3x3_wino43_kernel + conv3x3_wino_a128_stream_kernel<*> + conv3x3_wino_stream_mfma_kernel<*> + "
+                                   f"conv_up2x_wino_stream_kernel ({launches_per_step} launches/step for the 17 conv layers, fp32 MFMA 32x32x2)",
                          "measured": "second pass of the same K-step blocks with the whole batch on ONE stream (model.no_infer_split) and HIP "
                                      "events around every conv launch: a launch's duration is its own, not stretched by the other half's "
                                      "co-running launches; per layer the MEDIAN over all timed steps; `single_stream_ms_per_step` is "
@@ -703,7 +709,8 @@ def main():
                          "note": "`achieved` / `frac` = FLOPs the matrix pipe EXECUTES per second over the fp32 MFMA peak (an honest "
                                  "roofline position, <= 1).  The three decoder-entry layers evaluate their upsampled channels at the "
                                  "low resolution in a Winograd form that keeps 9 of the 16 GEMMs (9/36 of those multiply-adds) and the plain layers run in fused "
-                                 "Winograd F(2x2,3x3) form (16/36), so the executed count is `executed_gflop_per_step`; "
+                                 "Winograd form -- F(4x4,3x3) (36 products per 4x4 tile: 9/36) on the 288x512 / 144x256 / 72x128 levels from 32 input "
+                                 "channels up, F(2x2,3x3) (16/36) elsewhere --, so the executed count is `executed_gflop_per_step`; "
                                  "`effective_tflops` prices the same kernel time at the reference's algorithmic count "
                                  "(2*9*Cin*Cout*H*W per layer, SURVEY 8d) and may exceed the peak -- it is a speed-up over the direct "
                                  "form, not a roofline fraction",

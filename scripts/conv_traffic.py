@@ -8,7 +8,7 @@ import csv, json, sys, time
 def conv_sum(path, counter):
     tot, disp = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if any(k in r["kernel"] for k in ("conv3x3_mfma_kernel", "conv_up2x_mfma_kernel", "conv3x3_wino_mfma_kernel", "conv3x3_wino_split_mfma_kernel", "conv3x3_wino_v3_mfma_kernel", "conv3x3_wino_stream_mfma_kernel", "conv3x3_wino_a128_stream_kernel", "conv_up2x_wino_stream_kernel")) and r["counter"] == counter:
+        if any(k in r["kernel"] for k in ("conv3x3_mfma_kernel", "conv_up2x_mfma_kernel", "conv3x3_wino_mfma_kernel", "conv3x3_wino_split_mfma_kernel", "conv3x3_wino_v3_mfma_kernel", "conv3x3_wino_stream_mfma_kernel", "conv3x3_wino_a128_stream_kernel", "conv3x3_wino43_kernel", "conv_up2x_wino_stream_kernel")) and r["counter"] == counter:
             tot += float(r["sum"]); disp += int(r["dispatches"])
     return tot, disp
 
@@ -24,7 +24,7 @@ def main():
     fetch = 2.0 * fetch_raw                       # MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes
     json.dump({
         "commit": sys.argv[5] if len(sys.argv) > 5 else None, "taken_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
-        "kernel_set": "wino_a128+wino_stream+up2x_wino",
+        "kernel_set": "wino43+wino_a128+wino_stream+up2x_wino",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
                   f"bench.py --steps {steps - 1} --warmup 1 --blocks 1 --overlap-streams 0 --infer-split 0, MI355X (raw per-kernel sums: "
                   "the two CSVs given on the command line; made by scripts/conv_traffic.py)",

@@ -95,6 +95,16 @@ class Conv2DBlock(nn.Module):
             self._wino_plan.add((key, int(c_from), True))
         return hit[1]
 
+    def packed_wino43(self, c_from=0):
+        """Winograd F(4x4, 3x3) filter panel of input channels c_from.. (eval forward, ops.conv3x3_wino43)."""
+        key = ("w43", int(c_from))
+        ver = self._versions(["conv"])
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_wino43_weights(self.conv.weight.detach(), c_from=c_from))
+            self._cache[key] = hit
+        return hit[1]
+
     def stale_wino_panels(self):
         """[(cache key, c_from, transpose_flip)] of the Winograd panels this block has been asked for (by the forward / backward paths
         actually taken: the plan follows the shapes and tuning switches by construction) whose weight has changed since."""
@@ -162,6 +172,9 @@ class Conv2DBlock(nn.Module):
             wskip = self.packed_up2x(c0)[1]
         cfg = tuning.conv_config(self.conv.out_dim, c1, n, h, w)
         bn = self.bn
+        if affine and c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_wino43(c1, self.conv.out_dim, h, w):     # eval mode: the skip half in F(4x4, 3x3) form
+            return ops.conv3x3_wino43(skip, self.packed_wino43(c0), self.conv.out_dim, mean=bn.running_mean, scale=self.eval_scale(),
+                                      shift=bn.bias.detach(), relu=relu, addend=part)
         if affine and c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # eval mode: the skip half in Winograd form
             return ops.conv3x3_wino(skip, self.packed_wino(c0), self.conv.out_dim, mean=bn.running_mean, scale=self.eval_scale(),
                                     shift=bn.bias.detach(), relu=relu, addend=part)
@@ -201,6 +214,9 @@ class Conv2DBlock(nn.Module):
             return self.conv_up_skip(x, skip, int(n), relu=True, affine=True)
         h = x.shape[2] * (2 if up else 1)
         w = x.shape[3] * (2 if up else 1)
+        if skip is None and not up and tuning.use_wino43(self.conv.in_dim, self.conv.out_dim, int(h), int(w)):
+            return ops.conv3x3_wino43(x, self.packed_wino43(), self.conv.out_dim, mean=bn.running_mean, scale=self.eval_scale(),
+                                      shift=bn.bias.detach(), relu=True)
         if skip is None and not up and tuning.use_winograd(self.conv.in_dim, self.conv.out_dim, int(h), int(w)):
             return ops.conv3x3_wino(x, self.packed_wino(), self.conv.out_dim, mean=bn.running_mean, scale=self.eval_scale(),
                                     shift=bn.bias.detach(), relu=True)
@@ -323,10 +339,14 @@ class TrackNet(nn.Module):
                         b.packed_up2x(c0)
                         b.packed_up2x_wino(c0)
                         b.packed_wino(c0)
+                        if tuning.WINOGRAD and tuning.WINO43 and b.conv.out_dim % 64 == 0 and b.conv.in_dim - c0 >= tuning.WINO43_MIN_CIN:
+                            b.packed_wino43(c0)
                     else:
                         b.packed_weight()
                         if b.conv.in_dim >= tuning.WINOGRAD_MIN_CIN:
                             b.packed_wino()
+                        if tuning.WINOGRAD and tuning.WINO43 and b.conv.out_dim % 64 == 0 and b.conv.in_dim >= tuning.WINO43_MIN_CIN:
+                            b.packed_wino43()
                     b.eval_scale()
 
     def _forward_eval_split(self, x):

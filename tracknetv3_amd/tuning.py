@@ -42,6 +42,22 @@ WINOGRAD_MIN_CIN = int(os.environ.get("TNV3_WINO_MIN_CIN", "24"))      # measure
 WINOGRAD_MIN_SKIP = int(os.environ.get("TNV3_WINO_MIN_SKIP", "64"))     # skip half of a decoder entry (addend read in the epilogue)
 
 
+# Eval forward: plain layers (and the skip halves of the decoder entries) in Winograd F(4x4, 3x3) form where the shape allows it
+# (Cout % 64 == 0, H % 8 == 0, W % 64 == 0: the 288x512, 144x256 and 72x128 levels) -- 36 products per 4x4 output tile instead of
+# F(2x2)'s 16 per 2x2: 1.2-1.5x faster per layer from 64 input channels up (profiles/r03_wino43_ab.json; the 27-channel stem gains
+# nothing and stays), at ~4e-6 .. 1.2e-5 of the output scale per layer instead of 3-6e-7 (the whole network's heat maps stay
+# within 4e-6 of the fp64 forward: profiles/r03_wino_f43_precision.json).  TNV3_WINO43=0: F(2x2) everywhere.
+WINO43 = os.environ.get("TNV3_WINO43", "1") != "0"
+WINO43_MIN_CIN = int(os.environ.get("TNV3_WINO43_MIN_CIN", "32"))
+
+
+def use_wino43(cin, cout, h, w):
+    if not (WINOGRAD and WINO43) or cin < WINO43_MIN_CIN:
+        return False
+    from . import ops
+    return ops.wino43_supported(cin, cout, h, w)
+
+
 def use_winograd(cin, cout, h, w):
     if not WINOGRAD or cin < WINOGRAD_MIN_CIN:
         return False
