@@ -131,6 +131,20 @@ __device__ __forceinline__ void wino43_at_half(float m0, float m1, float m2, flo
   }
 }
 
+typedef float wf2 __attribute__((ext_vector_type(2)));
+// ... on a PAIR of channels at once (two-wide vectors: packed fp32 instructions)
+template <int J>
+__device__ __forceinline__ void wino43_at_half2(wf2 m0, wf2 m1, wf2 m2, wf2 (&o)[4]) {
+  if (J == 0) {
+    const wf2 p = m1 + m2, q = m1 - m2;
+    o[0] = m0 + p; o[1] = q; o[2] = p; o[3] = q;
+  } else {
+    const wf2 p = m0 + m1, q = m0 - m1;
+    o[0] = p; o[1] = 2.0f * q; o[2] = 4.0f * p;
+    o[3] = wf2{fmaf(8.0f, q[0], m2[0]), fmaf(8.0f, q[1], m2[1])};
+  }
+}
+
 inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const WinoArgs a) {
   using Cfg = Wino43Cfg;
   constexpr int CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, RW = Cfg::RW, RAWP = Cfg::RAWP, VT = Cfg::VT;
@@ -322,82 +336,103 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
 
     // ---- write-out.  This wave's partial 4x4 output per (channel r of the lane, tile bl): P = A^T[:, I] M_IJ A[J, :] with
     //      I = rows 3 (xg >> 1) .., J = columns 3 (xg & 1) ..; the four xg waves of a channel block exchange through LDS, wave xg
-    //      finishes output row xg.  Rounds of four channels r: the exchange of a round is 8 waves x 3 rows x 4 r x 16 bytes x 64 lanes = 96 KB.
-    float* xch = lds;                                    // [dst wave 8][src slot 3][r 4][lane 64][4]
+    //      finishes output row xg.  Four rounds of four channels r (the exchange of a round: 8 waves x 3 rows x 4 r x 16 bytes x 64
+    //      lanes = 96 KB, in the V stages); the arithmetic runs on channel PAIRS (r, r + 1: adjacent accumulator registers) as
+    //      two-wide vectors -- v_pk_add_f32 / v_pk_fma_f32, half the vector instructions.
+    float* xch = lds;                                    // [dst wave 8][src slot 3][pair 2][column half 2][lane 64][4]
     const bool has_affine = a.scale != nullptr, has_mean = a.mean != nullptr, has_addend = a.addend != nullptr;
     const int t_r = bl >> 4, t_col = bl & 15;
-    const int oh = e_h0 + 4 * t_r + xg, ow = e_w0 + 4 * t_col;
-    const unsigned lane_off_b = (unsigned)((wm * 32 + 4 * half) * HW + oh * W + ow) * 4u;
     const size_t plane0 = ((size_t)e_n * Cout + e_m0) * HW;
     const unsigned planes_b = (unsigned)MB * (unsigned)HW * 4u;
     const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
     const tnv3_rsrc_t r_add = tnv3_make_rsrc(has_addend ? a.addend + plane0 : a.dst + plane0, planes_b);
     auto chan_off = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)HW * 4u; };
-    const int xi_i = xg >> 1, xi_j = xg & 1;
+    auto writeout = [&](auto xgc) {
+      constexpr int XG = decltype(xgc)::value, XI = XG >> 1, XJ = XG & 1;
+      const int oh = e_h0 + 4 * t_r + XG, ow = e_w0 + 4 * t_col;
+      const unsigned lane_off_b = (unsigned)((RH * 32 + 4 * half) * HW + oh * W + ow) * 4u;      // (wm == RH: both are wave >> 2)
+      const int c4 = e_m0 + RH * 32 + 4 * half;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
 #pragma unroll
-    for (int rd = 0; rd < 4; ++rd) {                     // channels r = 4 rd .. 4 rd + 3 of the lane's sixteen
-      float own[4][4];                                   // [r][output column]: this wave's own share of output row xg
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int r = 4 * rd + rr;
-        float wv[3][4];                                  // W[i][b] = sum_j M[i][j] A^T[b][j]
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          if (xi_j) wino43_at_half<1>(acc[3 * i][r], acc[3 * i + 1][r], acc[3 * i + 2][r], wv[i]);
-          else wino43_at_half<0>(acc[3 * i][r], acc[3 * i + 1][r], acc[3 * i + 2][r], wv[i]);
-        }
-        float pr[4][4];                                  // P[a][b] = sum_i A^T[a][i] W[i][b]
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          float o[4];
-          if (xi_i) wino43_at_half<1>(wv[0][b], wv[1][b], wv[2][b], o);
-          else wino43_at_half<0>(wv[0][b], wv[1][b], wv[2][b], o);
-          pr[0][b] = o[0]; pr[1][b] = o[1]; pr[2][b] = o[2]; pr[3][b] = o[3];
-        }
-#pragma unroll
-        for (int arow = 0; arow < 4; ++arow) {
-          if (arow == xg) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) own[rr][b] = pr[arow][b];
-          } else {                                       // to wave (arow, wm): slot = this wave's rank among its three senders
-            const int slot = xg < arow ? xg : xg - 1;
-            f32x4 o4;
-            o4[0] = pr[arow][0]; o4[1] = pr[arow][1]; o4[2] = pr[arow][2]; o4[3] = pr[arow][3];
-            *reinterpret_cast<f32x4*>(xch + ((((wm * 4 + arow) * 3 + slot) * 4 + rr) * 64 + lane) * 4) = o4;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int r = 4 * rd + rr;
-        f32x4 v;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) v[b] = own[rr][b];
-#pragma unroll
-        for (int slot = 0; slot < 3; ++slot) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(xch + ((((wm * 4 + xg) * 3 + slot) * 4 + rr) * 64 + lane) * 4);
-#pragma unroll
-          for (int b = 0; b < 4; ++b) v[b] += g[b];
-        }
+      for (int rd = 0; rd < 4; ++rd) {                   // channels r = 4 rd .. 4 rd + 3 of the lane's sixteen
+        // this round's loads first: their latency hides behind the partial transforms and the exchange
+        f32x4 ad[4], mu4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, sc4 = f32x4{1.0f, 1.0f, 1.0f, 1.0f}, sh4 = mu4;
         if (has_addend) {
-          const f32x4 ad = tnv3_buf_load_f4(r_add, lane_off_b, chan_off(r));
 #pragma unroll
-          for (int b = 0; b < 4; ++b) v[b] += ad[b];
+          for (int rr = 0; rr < 4; ++rr) ad[rr] = tnv3_buf_load_f4(r_add, lane_off_b, chan_off(4 * rd + rr));
         }
         if (has_affine) {
-          const int ch = e_m0 + wm * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
-          const float mu = has_mean ? a.mean[ch] : 0.0f, sc = a.scale[ch], sh = a.shift[ch];
-#pragma unroll
-          for (int b = 0; b < 4; ++b) v[b] = (v[b] - mu) * sc + sh;
+          sc4 = *reinterpret_cast<const f32x4*>(a.scale + c4 + 8 * rd);
+          sh4 = *reinterpret_cast<const f32x4*>(a.shift + c4 + 8 * rd);
+          if (has_mean) mu4 = *reinterpret_cast<const f32x4*>(a.mean + c4 + 8 * rd);
         }
-        if (a.relu) {
+        wf2 own[2][4];                                   // [pair][output column]: this wave's own share of output row XG
 #pragma unroll
-          for (int b = 0; b < 4; ++b) v[b] = v[b] > 0.0f ? v[b] : 0.0f;
+        for (int pp = 0; pp < 2; ++pp) {
+          const int r0 = 4 * rd + 2 * pp;
+          wf2 wv[3][4];                                  // W[i][b] = sum_j M[i][j] A^T[b][j]
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const wf2 m0 = {acc[3 * i][r0], acc[3 * i][r0 + 1]}, m1 = {acc[3 * i + 1][r0], acc[3 * i + 1][r0 + 1]},
+                      m2 = {acc[3 * i + 2][r0], acc[3 * i + 2][r0 + 1]};
+            wino43_at_half2<XJ>(m0, m1, m2, wv[i]);
+          }
+          wf2 pr[4][4];                                  // P[a][b] = sum_i A^T[a][i] W[i][b]
+#pragma unroll
+          for (int b2 = 0; b2 < 4; ++b2) {
+            wf2 o[4];
+            wino43_at_half2<XI>(wv[0][b2], wv[1][b2], wv[2][b2], o);
+            pr[0][b2] = o[0]; pr[1][b2] = o[1]; pr[2][b2] = o[2]; pr[3][b2] = o[3];
+          }
+#pragma unroll
+          for (int arow = 0; arow < 4; ++arow) {
+            if (arow == XG) {
+#pragma unroll
+              for (int b2 = 0; b2 < 4; ++b2) own[pp][b2] = pr[arow][b2];
+            } else {                                     // to wave (arow, wm): slot = this wave's rank among its three senders
+              const int slot = XG < arow ? XG : XG - 1;
+              float* dst = xch + (((((RH * 4 + arow) * 3 + slot) * 2 + pp) * 2) * 64 + lane) * 4;
+              *reinterpret_cast<f32x4*>(dst) = f32x4{pr[arow][0][0], pr[arow][0][1], pr[arow][1][0], pr[arow][1][1]};
+              *reinterpret_cast<f32x4*>(dst + 64 * 4) = f32x4{pr[arow][2][0], pr[arow][2][1], pr[arow][3][0], pr[arow][3][1]};
+            }
+          }
         }
-        tnv3_buf_store_f4(r_dst, lane_off_b, chan_off(r), v);
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          wf2 v2[4];
+#pragma unroll
+          for (int b2 = 0; b2 < 4; ++b2) v2[b2] = own[pp][b2];
+#pragma unroll
+          for (int slot = 0; slot < 3; ++slot) {
+            const float* src = xch + (((((RH * 4 + XG) * 3 + slot) * 2 + pp) * 2) * 64 + lane) * 4;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(src), g1 = *reinterpret_cast<const f32x4*>(src + 64 * 4);
+            v2[0] += wf2{g0[0], g0[1]}; v2[1] += wf2{g0[2], g0[3]}; v2[2] += wf2{g1[0], g1[1]}; v2[3] += wf2{g1[2], g1[3]};
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int rr = 2 * pp + j, r = 4 * rd + rr;
+            f32x4 v = {v2[0][j], v2[1][j], v2[2][j], v2[3][j]};
+            if (has_addend) v += ad[rr];
+            if (has_affine) {
+              const float mu = mu4[rr], sc = sc4[rr], sh = sh4[rr];
+#pragma unroll
+              for (int b2 = 0; b2 < 4; ++b2) v[b2] = (v[b2] - mu) * sc + sh;
+            }
+            if (a.relu) {
+#pragma unroll
+              for (int b2 = 0; b2 < 4; ++b2) v[b2] = v[b2] > 0.0f ? v[b2] : 0.0f;
+            }
+            tnv3_buf_store_f4(r_dst, lane_off_b, chan_off(r), v);
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
+    };
+    switch (xg) {                                        // wave-uniform: one scalar branch around the whole write-out
+      case 0: writeout(std::integral_constant<int, 0>{}); break;
+      case 1: writeout(std::integral_constant<int, 1>{}); break;
+      case 2: writeout(std::integral_constant<int, 2>{}); break;
+      default: writeout(std::integral_constant<int, 3>{}); break;
     }
 
     walk.next();
