@@ -545,7 +545,7 @@ def test_inpaintnet_fused_kernel_emulated_vs_layer_kernels_and_oracle(emu, monke
 
 
 # ---- Winograd F(4x4, 3x3) form (kernels/conv3x3_wino43_mfma.h): another factorisation -> compared with fp64 torch, not bit-wise
-WINO43_CASES = [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (1, 27, 64, 8, 128), (1, 8, 64, 24, 64)]      # (n, cin, cout, h, w)
+WINO43_CASES = [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (1, 27, 64, 8, 128), (1, 8, 64, 24, 64), (2, 16, 64, 12, 64), (1, 24, 64, 4, 64)]      # (n, cin, cout, h, w); H % 8 == 4: half-empty last tile row
 
 
 def _wino43_case(case, device, tol=2e-5):        # F(4x4, 3x3) in fp32: 4e-6 (K = 27 x 9) .. 9e-6 (K = 256 x 9) of the output scale per layer (F(2x2) and direct: 3-5e-7)
@@ -569,9 +569,9 @@ def _wino43_case(case, device, tol=2e-5):        # F(4x4, 3x3) in fp32: 4e-6 (K 
     dz = T((n, cout, h, w), 497).to(device)
     xd = x.double().cpu().requires_grad_(True)
     F.conv2d(xd, wt.double().cpu(), padding=1).backward(dz.double().cpu())
-    if cin % 64 == 0:
+    if cin % 64 == 0:                                                  # (the rounding grows with sqrt(K): K = 9 Cout here, and dZ is signed)
         dx = ops.conv3x3_wino43(dz, ops.pack_wino43_weights(wt, transpose_flip=True), cin)
-        assert (dx.double().cpu() - xd.grad).abs().max().item() <= tol * xd.grad.abs().max().item()
+        assert (dx.double().cpu() - xd.grad).abs().max().item() <= tol * max(1.0, (cout / 256.0) ** 0.5) * xd.grad.abs().max().item()
 
 
 @pytest.mark.parametrize("case", WINO43_CASES)

@@ -277,7 +277,8 @@ def test_dgrad_up2x_wino_vs_autograd(gpu_device, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (2, 27, 64, 288, 512), (2, 64, 64, 288, 512), (3, 128, 128, 144, 256), (2, 256, 256, 72, 128)])
+@pytest.mark.parametrize("case", [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (2, 27, 64, 288, 512), (2, 64, 64, 288, 512), (3, 128, 128, 144, 256), (2, 256, 256, 72, 128),
+                                  (3, 512, 512, 36, 64), (2, 256, 512, 36, 64)])
 def test_conv3x3_wino43_vs_torch(gpu_device, case):
     """Winograd F(4x4, 3x3) forward kernel vs fp64 torch: plain, eval epilogue (affine + addend + ReLU), run-to-run identical, and as
     the data gradient (transposed, flipped panel)."""

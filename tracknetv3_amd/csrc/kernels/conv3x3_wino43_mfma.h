@@ -21,7 +21,7 @@
 //     15 LDS reads, 18 stores -- and issues its LDS-DMA pieces of chunk k+2.
 //   * write-out: every wave turns its 3x3 block of M into its PARTIAL 4x4 output (A^T[:, I] M_IJ A[J, :]), the four xg waves of a channel
 //     block meet through LDS (in four rounds of four channels), wave xg finishes output row xg of every tile: 16-byte stores.
-// Needs Cout % 64 == 0, H % 8 == 0, W % 64 == 0.  Not bit-identical to the F(2x2) kernels (another factorisation); deterministic.
+// Needs Cout % 64 == 0, H % 4 == 0, W % 64 == 0.  Not bit-identical to the F(2x2) kernels (another factorisation); deterministic.
 #pragma once
 #include <type_traits>
 #include "conv3x3_wino3_mfma.h"
@@ -157,7 +157,7 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
   const int xg = swave & 3, wm = swave >> 2;
   const int half = lane >> 5, bl = lane & 31;
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
-  const int tilesH = H / Cfg::TH, tilesW = W / Cfg::TW;
+  const int tilesH = (H + Cfg::TH - 1) / Cfg::TH, tilesW = W / Cfg::TW;      // H % 8 == 4: the last tile row's lower half is outside the image
   const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
   const int nChunks = (Cin + CC - 1) / CC;
 
@@ -186,38 +186,48 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
   constexpr int RH = decltype(rhc)::value;
   f32x4 av[9];
   f32x16 acc[9];
-  for (;;) {                                            // one pass per workgroup tile (no streaming through the tile boundary yet)
-    const int e_n = walk.n, e_h0 = walk.trow * Cfg::TH, e_w0 = walk.tcol * Cfg::TW, e_m0 = walk.mb * MB;
-    // raw LDS-DMA offsets of this tile: slot e = tid + i * 512 -> (channel, row, piece) of [CC][10][20]; pieces 18, 19 of a row and
-    // everything outside the image read out of range (= 0)
-    unsigned vo[4];
-    {
-      int t_op = tid;
-      TNV3_OPAQUE_V(t_op);
+  // ---- per-tile state of the loaders: raw LDS-DMA offsets (slot e = tid + i * 512 -> (channel, row, piece) of [CC][10][20]; pieces 18,
+  //      19 of a row and everything outside the image read out of range = 0), the image's input planes, this wave's panel slice
+  unsigned vo[4];
+  const float* xp;
+  const float* a_tile;
+  auto set_tile = [&](int t_n, int t_h0, int t_w0, int t_m0) {
+    int t_op = tid;
+    TNV3_OPAQUE_V(t_op);                                  // recomputed per tile; nothing of it stays live across the chunk loop
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int e = t_op + i * NT;
-        const int c = e / 200, rem = e - c * 200;
-        const int r = rem / 20, q = rem - r * 20;
-        const int gh = e_h0 - 1 + r, gw = e_w0 - 4 + 4 * q;
-        const bool ok = e < 1600 && q < 18 && gh >= 0 && gh < H && gw >= 0 && gw < W;
-        vo[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int e = t_op + i * NT;
+      const int c = e / 200, rem = e - c * 200;
+      const int r = rem / 20, q = rem - r * 20;
+      const int gh = t_h0 - 1 + r, gw = t_w0 - 4 + 4 * q;
+      const bool ok = e < 1600 && q < 18 && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      vo[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;
     }
-    const float* xp = a.src + (size_t)e_n * Cin * HW;
-    auto dma_chunk = [&](int k, int stage) {            // chunk k of this tile -> raw stage
-      const int cvalid = Cin - k * CC;
-      const tnv3_rsrc_t rr = tnv3_make_rsrc(xp + (size_t)k * x_step, (unsigned)(cvalid < CC ? cvalid : CC) * (unsigned)HW * 4u);
-      float* rs = raw_s + stage * Cfg::RAW_STAGE;
+    xp = a.src + (size_t)t_n * Cin * HW;
+    a_tile = a.u + ((size_t)(t_m0 / 32 + wm) * nChunks) * Cfg::A_CHUNK_FLOATS + xg * (9 * 256);
+  };
+  auto dma_chunk = [&](int k, int stage) {              // chunk k of the loaders' tile -> raw stage
+    const int cvalid = Cin - k * CC;
+    const tnv3_rsrc_t rr = tnv3_make_rsrc(xp + (size_t)k * x_step, (unsigned)(cvalid < CC ? cvalid : CC) * (unsigned)HW * 4u);
+    float* rs = raw_s + stage * Cfg::RAW_STAGE;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) tnv3_buf_dma16(rr, rs + (i * NT + wbase) * 4, vo[i]);
-      if (swave == 0) tnv3_buf_dma16(rr, rs + (3 * NT + wbase) * 4, vo[3]);     // slots 1536 .. 1599
-    };
-    const float* a_tile = a.u + ((size_t)(e_m0 / 32 + wm) * nChunks) * Cfg::A_CHUNK_FLOATS + xg * (9 * 256);
-    auto load_a = [&](int k, int x9) {
-      const tnv3_rsrc_t ra = tnv3_make_rsrc(a_tile + (size_t)k * Cfg::A_CHUNK_FLOATS, 9u * 1024u);
-      av[x9] = tnv3_buf_load_f4(ra, a_lane_b, (unsigned)x9 * 1024u);
-    };
+    for (int i = 0; i < 3; ++i) tnv3_buf_dma16(rr, rs + (i * NT + wbase) * 4, vo[i]);
+    if (swave == 0) tnv3_buf_dma16(rr, rs + (3 * NT + wbase) * 4, vo[3]);       // slots 1536 .. 1599
+  };
+  auto load_a = [&](int k, int x9) {
+    const tnv3_rsrc_t ra = tnv3_make_rsrc(a_tile + (size_t)k * Cfg::A_CHUNK_FLOATS, 9u * 1024u);
+    av[x9] = tnv3_buf_load_f4(ra, a_lane_b, (unsigned)x9 * 1024u);
+  };
+  auto issue_fill = [&]() {                              // pipeline fill of the loaders' tile: A of chunk 0, raw tiles of chunks 0 and 1
+#pragma unroll
+    for (int x = 0; x < 9; ++x) load_a(0, x);
+    dma_chunk(0, 0);
+    if (nChunks > 1) dma_chunk(1, 1);
+  };
+  set_tile(walk.n, walk.trow * Cfg::TH, walk.tcol * Cfg::TW, walk.mb * MB);
+  issue_fill();
+  for (;;) {                                            // one pass per workgroup tile
+    const int e_n = walk.n, e_h0 = walk.trow * Cfg::TH, e_w0 = walk.tcol * Cfg::TW, e_m0 = walk.mb * MB;
     // ---- the half-patch transform of one chunk (raw stage -> V stage of the same parity), in pieces that the chunk loop places between
     //      its MFMA groups: rows 3 RH .. 3 RH + 2 of B^T d B from raw rows RH .. RH + 4 of the patch
     float t[3][6];
@@ -269,11 +279,7 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
       __builtin_amdgcn_s_barrier();
     };
 
-    // ---- pipeline fill: A of chunk 0, raw tiles of chunks 0 and 1, V of chunk 0
-#pragma unroll
-    for (int x = 0; x < 9; ++x) load_a(0, x);
-    dma_chunk(0, 0);
-    if (nChunks > 1) dma_chunk(1, 1);
+    // ---- V of chunk 0 (its raw tiles and the A quads were requested before the previous tile's write-out)
     full_barrier();
     transform_all(0);
     full_barrier();
@@ -334,6 +340,15 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
     chunk_body(0, std::true_type{});
     for (int k = 1; k < nChunks; ++k) chunk_body(k, std::false_type{});
 
+    // ---- the NEXT tile's pipeline fill goes out now: the raw stages and the A registers are free, and the write-out below (which
+    //      exchanges through the V stages) hides the latency of these loads
+    walk.next();
+    const bool have_next = walk.valid;
+    if (have_next) {
+      set_tile(walk.n, walk.trow * Cfg::TH, walk.tcol * Cfg::TW, walk.mb * MB);
+      issue_fill();
+    }
+
     // ---- write-out.  This wave's partial 4x4 output per (channel r of the lane, tile bl): P = A^T[:, I] M_IJ A[J, :] with
     //      I = rows 3 (xg >> 1) .., J = columns 3 (xg & 1) ..; the four xg waves of a channel block exchange through LDS, wave xg
     //      finishes output row xg.  Four rounds of four channels r (the exchange of a round: 8 waves x 3 rows x 4 r x 16 bytes x 64
@@ -350,7 +365,8 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
     auto writeout = [&](auto xgc) {
       constexpr int XG = decltype(xgc)::value, XI = XG >> 1, XJ = XG & 1;
       const int oh = e_h0 + 4 * t_r + XG, ow = e_w0 + 4 * t_col;
-      const unsigned lane_off_b = (unsigned)((RH * 32 + 4 * half) * HW + oh * W + ow) * 4u;      // (wm == RH: both are wave >> 2)
+      // (wm == RH: both are wave >> 2; an output row below the image: out of the descriptor's range -- loads give 0, stores are dropped)
+      const unsigned lane_off_b = oh < H ? (unsigned)((RH * 32 + 4 * half) * HW + oh * W + ow) * 4u : kDmaOob;
       const int c4 = e_m0 + RH * 32 + 4 * half;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
 #pragma unroll
       for (int rd = 0; rd < 4; ++rd) {                   // channels r = 4 rd .. 4 rd + 3 of the lane's sixteen
@@ -435,8 +451,7 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
       default: writeout(std::integral_constant<int, 3>{}); break;
     }
 
-    walk.next();
-    if (!walk.valid) break;
+    if (!have_next) break;
   }
   };
   if (rh) body(std::integral_constant<int, 1>{}); else body(std::integral_constant<int, 0>{});

@@ -582,7 +582,7 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
 
 // ---- Winograd F(4x4, 3x3) form (kernels/conv3x3_wino43_mfma.h): 36 products per 4x4 output tile
 inline bool conv3x3_wino43_supported(int cin, int cout, int h, int w) {
-  return cin > 0 && cout > 0 && cout % Wino43Cfg::MB == 0 && h % Wino43Cfg::TH == 0 && w % Wino43Cfg::TW == 0;
+  return cin > 0 && cout > 0 && cout % Wino43Cfg::MB == 0 && h % 4 == 0 && w % Wino43Cfg::TW == 0;      // (H % 8 == 4: a half-empty last tile row)
 }
 // Panel of input channels c_from .. c_from + c_count - 1 of the nn.Conv2d weight w[cout_w][cin_w][3][3]: the forward filter
 // (Cout = cout_w, Cin = c_count) or, transpose_flip, the data gradient's (Cout = c_count, Cin = cout_w).
@@ -601,13 +601,13 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
                                 const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino43: bad argument");
   if (!conv3x3_wino43_supported(cin, cout, h, w))
-    TNV3_FAIL(-1, "conv3x3_wino43: needs Cout %% 64 == 0, H %% 8 == 0, W %% 64 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
+    TNV3_FAIL(-1, "conv3x3_wino43: needs Cout %% 64 == 0, H %% 4 == 0, W %% 64 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino43: inconsistent affine arguments");
   if ((long)cin * h * w * 4 >= (1l << 31) || (long)Wino43Cfg::MB * h * w * 4 >= (1l << 31))
     TNV3_FAIL(-1, "conv3x3_wino43: one sample of the input / 64 output planes must stay below 2 GiB");
   if ((((uintptr_t)u | (uintptr_t)src | (uintptr_t)dst | (uintptr_t)addend) & 15) != 0) TNV3_FAIL(-1, "conv3x3_wino43: pointers must be 16-byte aligned");
   WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, nullptr, nullptr, nullptr};
-  const long npt = (long)n * (h / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
+  const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino43: too many pixel tiles");
   return L.launch(conv3x3_wino43_kernel, wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt)), Wino43Cfg::NT, a);
 }

@@ -43,12 +43,11 @@ WINOGRAD_MIN_SKIP = int(os.environ.get("TNV3_WINO_MIN_SKIP", "64"))     # skip h
 
 
 # Eval forward: plain layers (and the skip halves of the decoder entries) in Winograd F(4x4, 3x3) form where the shape allows it
-# (Cout % 64 == 0, H % 8 == 0, W % 64 == 0: the 288x512, 144x256 and 72x128 levels) -- 36 products per 4x4 output tile instead of
-# F(2x2)'s 16 per 2x2: 1.2-1.5x faster per layer from 64 input channels up (profiles/r03_wino43_ab.json; the 27-channel stem gains
-# nothing and stays), at ~4e-6 .. 1.2e-5 of the output scale per layer instead of 3-6e-7 (the whole network's heat maps stay
+# (Cout % 64 == 0, H % 4 == 0, W % 64 == 0: every level of the 288x512 network) -- 36 products per 4x4 output tile instead of
+# F(2x2)'s 16 per 2x2: 1.1x (the 27-channel stem) to 1.5x (256 channels) faster per layer (profiles/r03_wino43_ab.json), at ~4e-6 .. 1.2e-5 of the output scale per layer instead of 3-6e-7 (the whole network's heat maps stay
 # within 4e-6 of the fp64 forward: profiles/r03_wino_f43_precision.json).  TNV3_WINO43=0: F(2x2) everywhere.
 WINO43 = os.environ.get("TNV3_WINO43", "1") != "0"
-WINO43_MIN_CIN = int(os.environ.get("TNV3_WINO43_MIN_CIN", "32"))
+WINO43_MIN_CIN = int(os.environ.get("TNV3_WINO43_MIN_CIN", "16"))
 
 
 def use_wino43(cin, cout, h, w):
