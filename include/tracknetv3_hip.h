@@ -122,7 +122,8 @@ int tnv3_conv3x3_wino_pack_view(const float* w, float* u, int cout_w, int cin_w,
                                 int layout, tnv3_stream_t stream);
 /* The same for a list of panels in ONE launch (a training step re-packs the forward and data-gradient filters of every layer after
  * each optimiser step): items[k] = the arguments of tnv3_conv3x3_wino_pack_view for panel k; `items` is HOST memory, read before
- * the call returns.  Bit-identical to the one-panel calls. */
+ * the call returns.  Bit-identical to the one-panel calls.  `layout` 0-2: F(2x2) panels; 3: the F(4x4, 3x3) panel of
+ * tnv3_conv3x3_wino43_pack (u then holds tnv3_conv3x3_wino43_packed_floats floats). */
 typedef struct tnv3_wino_pack_item {
   const float* w;   /* nn.Conv2d weight [cout_w][cin_w][3][3] (device) */
   float* u;         /* panel of tnv3_conv3x3_wino_packed_floats(cin, cout) floats (device) */

@@ -284,6 +284,11 @@ def _pack_multi_case(device):
         layouts.add(ops.wino_layout(None, cin, cout))
     assert len(layouts) >= 2                                      # the streaming kernel's and the 128-channel kernel's panel orders
     assert ops.pack_wino_weights_multi([]) == []
+    # F(4x4, 3x3) panels ride in the same launch (a fourth element 43 in the spec)
+    mixed = [(ws[1], 0, False, 43), (ws[1], 0, True, 43), (ws[2], 128, False, 43), (ws[3], 0, False, 22), (ws[0], 0, False, 43)]
+    for (w, c_from, flip, kind), u in zip(mixed, ops.pack_wino_weights_multi(mixed)):
+        want = (ops.pack_wino43_weights if kind == 43 else ops.pack_wino_weights)(w, c_from=c_from, transpose_flip=flip)
+        assert u.shape == want.shape and torch.equal(u, want), (tuple(w.shape), c_from, flip, kind)
 
 
 def test_wino_pack_multi_emulated(emu):

@@ -88,6 +88,10 @@ def test_conv_and_wgrad_budgets(resources):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
+    k = _find(resources, "conv3x3_wino43_kernelILi1ELi0E")                              # Winograd F(4x4, 3x3): 144 accumulators, two waves per SIMD;
+    # NO spill traffic: its chunk loop waits with a COUNTED vmcnt for its LDS-DMA pieces (nine A loads behind them may stay in flight)
+    assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+    assert k["LDS Size [bytes/block]"] <= 160 * 1024
     for name, occ in (("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi2ELi4ELi2ELi4E", 4), ("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi1ELi4ELi2ELi4E", 4),
                       ("dgrad_up2x_mfma_kernelINS_12DgradUp2xCfgILi2ELi2ELi4ELi1ELi2E", 4)):
         k = _find(resources, name)

@@ -209,7 +209,9 @@ def _train_backward_body(ctx, dev, head_backward):
             else:
                 g_low, w_skip_t = blk.packed_dgrad_up2x(c0)
                 d_low = ops.dgrad_up2x(dz, g_low, c0)
-            if skip_wino:
+            if skip_wino and tuning.use_wino43_dgrad(blk.conv.out_dim, c1, int(h), int(w)):
+                d_skip = ops.conv3x3_wino43(dz, blk.packed_wino43_t(c0), c1)
+            elif skip_wino:
                 d_skip = ops.conv3x3_wino(dz, blk.packed_wino_t(c0), c1)
             else:
                 cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))
@@ -223,6 +225,8 @@ def _train_backward_body(ctx, dev, head_backward):
                 c4 = ops.bn_bwd_consts(producer["mean"], producer["invstd"], pb.weight.detach(), pb.bias.detach())
                 dx, st = ops.conv3x3_wino_dgrad_bnstats(dz, blk.packed_wino_t(), c0, producer["z"], c4)
                 return dx, None, st
+            if tuning.use_wino43_dgrad(blk.conv.out_dim, c0, int(h), int(w)):
+                return ops.conv3x3_wino43(dz, blk.packed_wino43_t(), c0), None, None
             return ops.conv3x3_wino(dz, blk.packed_wino_t(), c0), None, None
         if c1 == 0 and c0 % 64:
             # gradient w.r.t. the network INPUT (9 / 27 channels; only when the caller asked for it -- train.py never does):

@@ -62,11 +62,12 @@ __device__ __forceinline__ float wino43_g_row(int i, float g0, float g1, float g
 
 // w[..][3][3] (strides s_co / s_ci floats between output / input channels; flip: taps reversed -- the data gradient's filter) ->
 // panel u[co / 32][chunk][xg][x9][lane = (ci % 2) * 32 + co % 32][ci % 8 / 2], zero for ci >= Cin; then kPackZeroTail zeros.
-inline __global__ void __launch_bounds__(256) conv3x3_wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin,
-                                                                        long s_co, long s_ci, int flip) {
+// (elements e0, e0 + stride, ... of one panel; shared by the one-panel kernel and the table-driven one of conv3x3_wino_mfma.h's twin below)
+__device__ __forceinline__ void conv3x3_wino43_pack_elements(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, long s_co, long s_ci,
+                                                             int flip, long e0, long stride) {
   const int nch = (Cin + 7) / 8;
   const long body = (long)(Cout / 32) * nch * Wino43Cfg::A_CHUNK_FLOATS, total = body + kPackZeroTail;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  for (long e = e0; e < total; e += stride) {
     if (e >= body) { u[e] = 0.0f; continue; }
     const int s = (int)(e & 3), ln = (int)((e >> 2) & 63);
     long r = e >> 8;
@@ -88,6 +89,23 @@ inline __global__ void __launch_bounds__(256) conv3x3_wino43_pack_kernel(const f
     }
     u[e] = v;
   }
+}
+inline __global__ void __launch_bounds__(256) conv3x3_wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin,
+                                                                        long s_co, long s_ci, int flip) {
+  conv3x3_wino43_pack_elements(w, u, Cout, Cin, s_co, s_ci, flip, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+}
+// Table-driven pack of panels of BOTH Winograd forms in one launch (layout 0-2: F(2x2) panels, conv3x3_wino_mfma.h; 3: F(4x4) panels)
+inline __global__ void __launch_bounds__(256) conv3x3_wino_pack_multi43_kernel(const WinoPackTable t) {
+  int lo = 0, hi = t.count;                    // first_block[lo] <= blockIdx.x < first_block[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const int k = lo;
+  const long nb = t.first_block[k + 1] - t.first_block[k];
+  const long e0 = (long)((int)blockIdx.x - t.first_block[k]) * 256 + threadIdx.x;
+  if (t.layout[k] == 3) conv3x3_wino43_pack_elements(t.w[k], t.u[k], t.cout[k], t.cin[k], t.s_co[k], t.s_ci[k], t.flip[k], e0, nb * 256);
+  else conv3x3_wino_pack_elements(t.w[k], t.u[k], t.cout[k], t.cin[k], t.cpad[k], t.s_co[k], t.s_ci[k], t.flip[k], t.layout[k], e0, nb * 256);
 }
 
 // One 1-D input transform B^T applied to six values, the three outputs of one half: rows 0..2 (RH = 0) or 3..5 (RH = 1).
@@ -132,6 +150,32 @@ __device__ __forceinline__ void wino43_at_half(float m0, float m1, float m2, flo
 }
 
 typedef float wf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wf2 wino43_fma2(float k, wf2 x, wf2 y) { return __builtin_elementwise_fma(wf2{k, k}, x, y); }      // v_pk_fma_f32
+// The 1-D input transforms on two lines at once (two patch columns in the first pass, two rows in the second): packed fp32 instructions
+template <int RH>
+__device__ __forceinline__ void wino43_bt_half2(const wf2 (&d)[6], wf2 (&t)[3]) {
+  if (RH == 0) {
+    t[0] = wino43_fma2(4.0f, d[0], wino43_fma2(-5.0f, d[2], d[4]));
+    const wf2 a = wino43_fma2(-4.0f, d[2], d[4]), b = wino43_fma2(-4.0f, d[1], d[3]);
+    t[1] = a + b;
+    t[2] = a - b;
+  } else {
+    const wf2 c = d[4] - d[2], e = d[3] - d[1];
+    t[0] = wino43_fma2(2.0f, e, c);
+    t[1] = wino43_fma2(-2.0f, e, c);
+    t[2] = wino43_fma2(4.0f, d[1], wino43_fma2(-5.0f, d[3], d[5]));
+  }
+}
+__device__ __forceinline__ void wino43_bt_full2(const wf2 (&d)[6], wf2 (&t)[6]) {
+  t[0] = wino43_fma2(4.0f, d[0], wino43_fma2(-5.0f, d[2], d[4]));
+  const wf2 a = wino43_fma2(-4.0f, d[2], d[4]), b = wino43_fma2(-4.0f, d[1], d[3]);
+  t[1] = a + b;
+  t[2] = a - b;
+  const wf2 c = d[4] - d[2], e = d[3] - d[1];
+  t[3] = wino43_fma2(2.0f, e, c);
+  t[4] = wino43_fma2(-2.0f, e, c);
+  t[5] = wino43_fma2(4.0f, d[1], wino43_fma2(-5.0f, d[3], d[5]));
+}
 // ... on a PAIR of channels at once (two-wide vectors: packed fp32 instructions)
 template <int J>
 __device__ __forceinline__ void wino43_at_half2(wf2 m0, wf2 m1, wf2 m2, wf2 (&o)[4]) {
@@ -141,11 +185,12 @@ __device__ __forceinline__ void wino43_at_half2(wf2 m0, wf2 m1, wf2 m2, wf2 (&o)
   } else {
     const wf2 p = m0 + m1, q = m0 - m1;
     o[0] = p; o[1] = 2.0f * q; o[2] = 4.0f * p;
-    o[3] = wf2{fmaf(8.0f, q[0], m2[0]), fmaf(8.0f, q[1], m2[1])};
+    o[3] = wino43_fma2(8.0f, q, m2);
   }
 }
 
-inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const WinoArgs a) {
+template <int EARLY, int PACKED_T = 0>
+__global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const WinoArgs a) {
   using Cfg = Wino43Cfg;
   constexpr int CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, RW = Cfg::RW, RAWP = Cfg::RAWP, VT = Cfg::VT;
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
@@ -218,14 +263,19 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
     const tnv3_rsrc_t ra = tnv3_make_rsrc(a_tile + (size_t)k * Cfg::A_CHUNK_FLOATS, 9u * 1024u);
     av[x9] = tnv3_buf_load_f4(ra, a_lane_b, (unsigned)x9 * 1024u);
   };
-  auto issue_fill = [&]() {                              // pipeline fill of the loaders' tile: A of chunk 0, raw tiles of chunks 0 and 1
-#pragma unroll
-    for (int x = 0; x < 9; ++x) load_a(0, x);
+  // pipeline fill of the loaders' tile: raw tiles of chunks 0 and 1 (HBM / L2 latency: requested BEFORE the previous tile's write-out) ...
+  auto issue_raw = [&]() {
     dma_chunk(0, 0);
     if (nChunks > 1) dma_chunk(1, 1);
   };
+  // ... and the A quads of chunk 0 (L2 hits; their 36 registers would be live through the write-out: requested after it)
+  auto issue_a = [&]() {
+#pragma unroll
+    for (int x = 0; x < 9; ++x) load_a(0, x);
+  };
   set_tile(walk.n, walk.trow * Cfg::TH, walk.tcol * Cfg::TW, walk.mb * MB);
-  issue_fill();
+  issue_raw();
+  issue_a();
   for (;;) {                                            // one pass per workgroup tile
     const int e_n = walk.n, e_h0 = walk.trow * Cfg::TH, e_w0 = walk.tcol * Cfg::TW, e_m0 = walk.mb * MB;
     // ---- the half-patch transform of one chunk (raw stage -> V stage of the same parity), in pieces that the chunk loop places between
@@ -238,7 +288,23 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
       wino43_bt_half<RH>(col, o);
       t[0][c] = o[0]; t[1][c] = o[1]; t[2][c] = o[2];
     };
-    auto t_read_mid = [&](int stage, f32x4 (&q)[5]) {     // patch columns 1..4: one 16-byte read per raw row
+    auto t_read_pair = [&](int stage, int c, wf2 (&q)[5]) {      // patch columns c, c + 1 (c = 1 or 3): one 8-byte read per raw row
+      const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src + RH * RW;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) q[r] = *reinterpret_cast<const wf2*>(d + r * RW + 3 + c);
+    };
+    auto column2 = [&](int ca, int cb, wf2 x0, wf2 x1, wf2 x2, wf2 x3, wf2 x4) {      // two patch columns at once
+      wf2 col[6], o[3];
+      const wf2 z = {0.0f, 0.0f};
+      if (RH == 0) { col[0] = x0; col[1] = x1; col[2] = x2; col[3] = x3; col[4] = x4; col[5] = z; }
+      else { col[0] = z; col[1] = x0; col[2] = x1; col[3] = x2; col[4] = x3; col[5] = x4; }
+      wino43_bt_half2<RH>(col, o);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { t[k][ca] = o[k][0]; t[k][cb] = o[k][1]; }
+    };
+    auto t_cols_pair = [&](int c, const wf2 (&q)[5]) { column2(c, c + 1, q[0], q[1], q[2], q[3], q[4]); };
+    // (the scalar form: patch columns 1..4 as one 16-byte read per raw row, four 1-D transforms)
+    auto t_read_mid = [&](int stage, f32x4 (&q)[5]) {
       const float* d = raw_s + stage * Cfg::RAW_STAGE + t_src + RH * RW;
 #pragma unroll
       for (int r = 0; r < 5; ++r) q[r] = *reinterpret_cast<const f32x4*>(d + r * RW + 4);
@@ -253,8 +319,24 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
       for (int r = 0; r < 5; ++r) { e0[r] = d[r * RW + 3]; e5[r] = d[r * RW + 8]; }
     };
     auto t_cols_edge = [&](const float (&e0)[5], const float (&e5)[5]) {
-      column(0, e0[0], e0[1], e0[2], e0[3], e0[4]);
-      column(5, e5[0], e5[1], e5[2], e5[3], e5[4]);
+      if (PACKED_T) {
+        column2(0, 5, wf2{e0[0], e5[0]}, wf2{e0[1], e5[1]}, wf2{e0[2], e5[2]}, wf2{e0[3], e5[3]}, wf2{e0[4], e5[4]});
+      } else {
+        column(0, e0[0], e0[1], e0[2], e0[3], e0[4]);
+        column(5, e5[0], e5[1], e5[2], e5[3], e5[4]);
+      }
+    };
+    auto t_rows01 = [&](int stage) {                     // second pass along rows 0 and 1 at once
+      float* vdst = v_s + stage * Cfg::V_STAGE + t_dst;
+      wf2 d[6], o[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) d[c] = wf2{t[0][c], t[1][c]};
+      wino43_bt_full2(d, o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        vdst[((2 * RH + j / 3) * 9 + j % 3) * (TB * VT)] = o[j][0];
+        vdst[((2 * RH + j / 3) * 9 + 3 + j % 3) * (TB * VT)] = o[j][1];
+      }
     };
     auto t_row = [&](int stage, int r) {                 // second pass along row r, results straight into V: xi = (3 RH + r, j)
       float* vdst = v_s + stage * Cfg::V_STAGE + t_dst;
@@ -311,25 +393,45 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
         if (x1 >= 0) load_a(knext, x1);
         __builtin_amdgcn_sched_barrier(0);
       };
-      f32x4 q[5];
       float e0[5], e5[5];
       read_pair(0);
       if (k + 2 < nChunks) dma_chunk(k + 2, sc);
-      t_read_mid(sn, q);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_pair(0);
-      t_cols_mid(q);
-      t_read_edge(sn, e0, e5);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_pair(1);
-      t_cols_edge(e0, e5);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_pair(2);
-      t_row(sn, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_pair(3);
-      t_row(sn, 1);
-      t_row(sn, 2);
+      if constexpr (PACKED_T) {                           // (8-byte reads, two-wide arithmetic: measured 2-4 % slower on the deep layers)
+        wf2 q[5];
+        t_read_pair(sn, 1, q);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(0);
+        t_cols_pair(1, q);
+        t_read_pair(sn, 3, q);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(1);
+        t_cols_pair(3, q);
+        t_read_edge(sn, e0, e5);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(2);
+        t_cols_edge(e0, e5);
+        t_rows01(sn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(3);
+        t_row(sn, 2);
+      } else {
+        f32x4 q[5];
+        t_read_mid(sn, q);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(0);
+        t_cols_mid(q);
+        t_read_edge(sn, e0, e5);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(1);
+        t_cols_edge(e0, e5);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(2);
+        t_row(sn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(3);
+        t_row(sn, 1);
+        t_row(sn, 2);
+      }
       __builtin_amdgcn_sched_barrier(0);
       mfma_pair(4);
       // this wave's raw pieces of chunk k+2 have landed (they are OLDER than the nine A loads issued since), its V stores are done
@@ -344,9 +446,9 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
     //      exchanges through the V stages) hides the latency of these loads
     walk.next();
     const bool have_next = walk.valid;
-    if (have_next) {
+    if (EARLY && have_next) {
       set_tile(walk.n, walk.trow * Cfg::TH, walk.tcol * Cfg::TW, walk.mb * MB);
-      issue_fill();
+      issue_raw();
     }
 
     // ---- write-out.  This wave's partial 4x4 output per (channel r of the lane, tile bl): P = A^T[:, I] M_IJ A[J, :] with
@@ -356,7 +458,10 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
     //      two-wide vectors -- v_pk_add_f32 / v_pk_fma_f32, half the vector instructions.
     float* xch = lds;                                    // [dst wave 8][src slot 3][pair 2][column half 2][lane 64][4]
     const bool has_affine = a.scale != nullptr, has_mean = a.mean != nullptr, has_addend = a.addend != nullptr;
-    const int t_r = bl >> 4, t_col = bl & 15;
+    int ln_w = lane;
+    TNV3_OPAQUE_V(ln_w);                                // the write-out's lane arithmetic is redone per tile, not kept live across the chunk loop
+    const int bl_w = ln_w & 31, half_w = ln_w >> 5;
+    const int t_r = bl_w >> 4, t_col = bl_w & 15;
     const size_t plane0 = ((size_t)e_n * Cout + e_m0) * HW;
     const unsigned planes_b = (unsigned)MB * (unsigned)HW * 4u;
     const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
@@ -366,8 +471,8 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
       constexpr int XG = decltype(xgc)::value, XI = XG >> 1, XJ = XG & 1;
       const int oh = e_h0 + 4 * t_r + XG, ow = e_w0 + 4 * t_col;
       // (wm == RH: both are wave >> 2; an output row below the image: out of the descriptor's range -- loads give 0, stores are dropped)
-      const unsigned lane_off_b = oh < H ? (unsigned)((RH * 32 + 4 * half) * HW + oh * W + ow) * 4u : kDmaOob;
-      const int c4 = e_m0 + RH * 32 + 4 * half;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
+      const unsigned lane_off_b = oh < H ? (unsigned)((RH * 32 + 4 * half_w) * HW + oh * W + ow) * 4u : kDmaOob;
+      const int c4 = e_m0 + RH * 32 + 4 * half_w;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
 #pragma unroll
       for (int rd = 0; rd < 4; ++rd) {                   // channels r = 4 rd .. 4 rd + 3 of the lane's sixteen
         // this round's loads first: their latency hides behind the partial transforms and the exchange
@@ -392,23 +497,25 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
                       m2 = {acc[3 * i + 2][r0], acc[3 * i + 2][r0 + 1]};
             wino43_at_half2<XJ>(m0, m1, m2, wv[i]);
           }
-          wf2 pr[4][4];                                  // P[a][b] = sum_i A^T[a][i] W[i][b]
 #pragma unroll
-          for (int b2 = 0; b2 < 4; ++b2) {
-            wf2 o[4];
-            wino43_at_half2<XI>(wv[0][b2], wv[1][b2], wv[2][b2], o);
-            pr[0][b2] = o[0]; pr[1][b2] = o[1]; pr[2][b2] = o[2]; pr[3][b2] = o[3];
-          }
+          for (int hb = 0; hb < 2; ++hb) {               // output columns 2 hb, 2 hb + 1 (half of P at a time: sixteen registers less)
+            wf2 pr[4][2];                                // P[a][b] = sum_i A^T[a][i] W[i][b]
 #pragma unroll
-          for (int arow = 0; arow < 4; ++arow) {
-            if (arow == XG) {
+            for (int bb = 0; bb < 2; ++bb) {
+              wf2 o[4];
+              wino43_at_half2<XI>(wv[0][2 * hb + bb], wv[1][2 * hb + bb], wv[2][2 * hb + bb], o);
+              pr[0][bb] = o[0]; pr[1][bb] = o[1]; pr[2][bb] = o[2]; pr[3][bb] = o[3];
+            }
 #pragma unroll
-              for (int b2 = 0; b2 < 4; ++b2) own[pp][b2] = pr[arow][b2];
-            } else {                                     // to wave (arow, wm): slot = this wave's rank among its three senders
-              const int slot = XG < arow ? XG : XG - 1;
-              float* dst = xch + (((((RH * 4 + arow) * 3 + slot) * 2 + pp) * 2) * 64 + lane) * 4;
-              *reinterpret_cast<f32x4*>(dst) = f32x4{pr[arow][0][0], pr[arow][0][1], pr[arow][1][0], pr[arow][1][1]};
-              *reinterpret_cast<f32x4*>(dst + 64 * 4) = f32x4{pr[arow][2][0], pr[arow][2][1], pr[arow][3][0], pr[arow][3][1]};
+            for (int arow = 0; arow < 4; ++arow) {
+              if (arow == XG) {
+                own[pp][2 * hb] = pr[arow][0];
+                own[pp][2 * hb + 1] = pr[arow][1];
+              } else {                                   // to wave (arow, wm): slot = this wave's rank among its three senders
+                const int slot = XG < arow ? XG : XG - 1;
+                float* dst = xch + ((((((RH * 4 + arow) * 3 + slot) * 2 + pp) * 2) + hb) * 64 + ln_w) * 4;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{pr[arow][0][0], pr[arow][0][1], pr[arow][1][0], pr[arow][1][1]};
+              }
             }
           }
         }
@@ -420,7 +527,7 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
           for (int b2 = 0; b2 < 4; ++b2) v2[b2] = own[pp][b2];
 #pragma unroll
           for (int slot = 0; slot < 3; ++slot) {
-            const float* src = xch + (((((RH * 4 + XG) * 3 + slot) * 2 + pp) * 2) * 64 + lane) * 4;
+            const float* src = xch + (((((RH * 4 + XG) * 3 + slot) * 2 + pp) * 2) * 64 + ln_w) * 4;
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(src), g1 = *reinterpret_cast<const f32x4*>(src + 64 * 4);
             v2[0] += wf2{g0[0], g0[1]}; v2[1] += wf2{g0[2], g0[3]}; v2[2] += wf2{g1[0], g1[1]}; v2[3] += wf2{g1[2], g1[3]};
           }
@@ -452,6 +559,11 @@ inline __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(co
     }
 
     if (!have_next) break;
+    if (!EARLY) {
+      set_tile(walk.n, walk.trow * Cfg::TH, walk.tcol * Cfg::TW, walk.mb * MB);
+      issue_raw();
+    }
+    issue_a();
   }
   };
   if (rh) body(std::integral_constant<int, 1>{}); else body(std::integral_constant<int, 0>{});

@@ -548,10 +548,10 @@ int conv3x3_wino_pack_multi_impl(Launcher& L, const WinoPackItem* items, int cou
     for (int k = 0; k < t.count; ++k) {
       const WinoPackItem& it = items[base + k];
       if (!it.w || !it.u || it.cout_w <= 0 || it.cin_w <= 0 || it.c_from < 0 || it.c_count <= 0 || it.c_from + it.c_count > it.cin_w || it.layout < 0 ||
-          it.layout > 2)
+          it.layout > 3)
         TNV3_FAIL(-1, "conv3x3_wino_pack_multi: bad item %d", base + k);
       const int cout = it.transpose_flip ? it.c_count : it.cout_w, cin = it.transpose_flip ? it.cout_w : it.c_count;
-      if (it.layout == 2 && cout % 32) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layout 2 needs Cout %% 32 == 0 (item %d: %d)", base + k, cout);
+      if (it.layout >= 2 && cout % 32) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layouts 2 and 3 need Cout %% 32 == 0 (item %d: %d)", base + k, cout);
       const long s_w_co = (long)it.cin_w * 9, s_w_ci = 9;
       t.w[k] = it.w + (size_t)it.c_from * 9;
       t.u[k] = it.u;
@@ -560,7 +560,7 @@ int conv3x3_wino_pack_multi_impl(Launcher& L, const WinoPackItem* items, int cou
       t.s_ci[k] = it.transpose_flip ? s_w_co : s_w_ci;
       t.flip[k] = it.transpose_flip ? 1 : 0;
       t.layout[k] = it.layout;
-      const long total = (long)t.cpad[k] * 16 * cout + kPackZeroTail;
+      const long total = it.layout == 3 ? (long)conv3x3_wino43_packed_floats(cin, cout) : (long)t.cpad[k] * 16 * cout + kPackZeroTail;      // layout 3: an F(4x4) panel
       const long blocks = (total + 255) / 256;
       t.first_block[k + 1] = t.first_block[k] + (int)(blocks > 2048 ? 2048 : blocks);      // four elements per thread at most times 2048 blocks: grid-stride beyond
     }
@@ -569,7 +569,7 @@ int conv3x3_wino_pack_multi_impl(Launcher& L, const WinoPackItem* items, int cou
       t.first_block[k + 1] = t.first_block[t.count];
     }
     if (t.count == 0) continue;
-    const int rc = L.launch(conv3x3_wino_pack_multi_kernel, t.first_block[t.count], 256, t);
+    const int rc = L.launch(conv3x3_wino_pack_multi43_kernel, t.first_block[t.count], 256, t);
     if (rc) return rc;
   }
   return 0;
@@ -609,7 +609,9 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
   WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, nullptr, nullptr, nullptr};
   const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino43: too many pixel tiles");
-  return L.launch(conv3x3_wino43_kernel, wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt)), Wino43Cfg::NT, a);
+  // <1, 0>: next tile's raw fill before the write-out, scalar input transform (the two-wide form <1, 1> measured 1-5 % slower on every
+  // shape, profiles/r03_wino43_transform_ab.txt; filling after the write-out <0, 0> 1-1.5 % slower)
+  return L.launch(conv3x3_wino43_kernel<1, 0>, wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt)), Wino43Cfg::NT, a);
 }
 
 template <class Launcher>

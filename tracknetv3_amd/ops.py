@@ -149,15 +149,18 @@ class _WinoPackItem(ctypes.Structure):
 
 def pack_wino_weights_multi(specs, variant=None):
     """[pack_wino_weights(weight, c_from=c_from, transpose_flip=flip) for (weight, c_from, flip) in specs] in ONE launch
-    (tnv3_conv3x3_wino_pack_multi): the panels a training step rebuilds after every optimiser step.  All weights on one device;
-    ordered on that device's current stream.  Bit-identical to the one-panel calls."""
+    (tnv3_conv3x3_wino_pack_multi): the panels a training step rebuilds after every optimiser step.  A fourth element 43 in a spec
+    asks for the F(4x4, 3x3) panel (pack_wino43_weights) instead.  All weights on one device; ordered on that device's current
+    stream.  Bit-identical to the one-panel calls."""
     lib = _lib.load()
     if not specs:
         return []
     items = (_WinoPackItem * len(specs))()
     outs, keep = [], []
     dev = specs[0][0].device
-    for k, (weight, c_from, flip) in enumerate(specs):
+    for k, spec in enumerate(specs):
+        weight, c_from, flip = spec[:3]
+        f43 = len(spec) > 3 and spec[3] == 43
         _f32(weight)
         if weight.device != dev:
             raise _lib.Tnv3Error("pack_wino_weights_multi: all weights must live on one device")
@@ -166,9 +169,11 @@ def pack_wino_weights_multi(specs, variant=None):
         cout_w, cin_w = int(weight.shape[0]), int(weight.shape[1])
         c_count = cin_w - int(c_from)
         cout, cin = (c_count, cout_w) if flip else (cout_w, c_count)
-        u = torch.empty(lib.tnv3_conv3x3_wino_packed_floats(cin, cout), dtype=torch.float32, device=dev)
+        floats = lib.tnv3_conv3x3_wino43_packed_floats(cin, cout) if f43 else lib.tnv3_conv3x3_wino_packed_floats(cin, cout)
+        u = torch.empty(floats, dtype=torch.float32, device=dev)
         outs.append(u)
-        items[k] = _WinoPackItem(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count, int(bool(flip)), wino_layout(variant, cin, cout))
+        items[k] = _WinoPackItem(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count, int(bool(flip)),
+                                 3 if f43 else wino_layout(variant, cin, cout))
     _lib.dev_check(keep[0])
     _lib.check(lib.tnv3_conv3x3_wino_pack_multi(ctypes.cast(items, ctypes.c_void_p), len(specs), _lib.stream_ptr(keep[0])))
     return outs

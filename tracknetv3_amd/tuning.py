@@ -50,6 +50,15 @@ WINO43 = os.environ.get("TNV3_WINO43", "1") != "0"
 WINO43_MIN_CIN = int(os.environ.get("TNV3_WINO43_MIN_CIN", "16"))
 
 
+# Training: the plain layers' data gradients (and the skip halves') through the same F(4x4, 3x3) kernel (the data gradient IS a plain
+# 3x3 convolution of dZ with the transposed, flipped filter).  TNV3_WINO43_DGRAD=0: the F(2x2) kernels.
+WINO43_DGRAD = os.environ.get("TNV3_WINO43_DGRAD", "1") != "0"
+
+
+def use_wino43_dgrad(cin, cout, h, w):
+    return WINO43_DGRAD and use_wino43(cin, cout, h, w)
+
+
 def use_wino43(cin, cout, h, w):
     if not (WINOGRAD and WINO43) or cin < WINO43_MIN_CIN:
         return False
