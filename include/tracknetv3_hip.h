@@ -141,6 +141,12 @@ size_t tnv3_conv3x3_wino43_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino43_pack(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip, tnv3_stream_t stream);
 int tnv3_conv3x3_wino43_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                                 const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, tnv3_stream_t stream);
+/* Training forward in that form: dst = conv3x3(src) + addend (raw), and from the same kernel's epilogue tile_stats[cout][tiles][2]
+ * (fp64 sum and sum of squares per channel and 8 x 64 pixel tile; tiles = tnv3_conv3x3_wino43_stats_tiles) for
+ * tnv3_bn_train_forward_tiles -- the F(4x4) twin of tnv3_conv3x3_wino_forward_stats.  Deterministic. */
+long tnv3_conv3x3_wino43_stats_tiles(int n, int h, int w);
+int tnv3_conv3x3_wino43_forward_stats(const float* src, const float* u, const float* addend, float* dst, double* tile_stats, int n, int cin,
+                                      int cout, int h, int w, tnv3_stream_t stream);
 
 int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,

@@ -570,6 +570,16 @@ def _wino43_case(case, device, tol=2e-5):        # F(4x4, 3x3) in fp32: 4e-6 (K 
     got_full = ops.conv3x3_wino43(x, u, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add)
     assert (got_full.double().cpu() - full).abs().max().item() <= tol * max(mag, full.abs().max().item())
     assert torch.equal(got, ops.conv3x3_wino43(x, u, cout))                                   # deterministic
+    # training forward: raw convolution + addend, and BatchNorm's batch statistics from the same launch's epilogue
+    z, st = ops.conv3x3_wino43_stats(x, u, cout, addend=add)
+    assert (z.double().cpu() - (ref + add.double().cpu())).abs().max().item() <= tol * max(mag, 1.0)
+    zd = z.double().cpu()
+    assert tuple(st.shape)[0] == cout and st.dtype == torch.float64
+    s1, s2 = st.cpu()[:, :, 0].sum(1), st.cpu()[:, :, 1].sum(1)
+    assert (s1 - zd.sum((0, 2, 3))).abs().max().item() <= 1e-9 * zd.abs().sum((0, 2, 3)).max().item()
+    assert (s2 - (zd * zd).sum((0, 2, 3))).abs().max().item() <= 1e-9 * (zd * zd).sum((0, 2, 3)).max().item()
+    z2, st2 = ops.conv3x3_wino43_stats(x, u, cout, addend=add)
+    assert torch.equal(z, z2) and torch.equal(st, st2)
     # the data gradient's filter: conv of dZ with the transposed, flipped weight == autograd's dX
     dz = T((n, cout, h, w), 497).to(device)
     xd = x.double().cpu().requires_grad_(True)

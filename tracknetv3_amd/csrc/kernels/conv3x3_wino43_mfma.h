@@ -189,7 +189,7 @@ __device__ __forceinline__ void wino43_at_half2(wf2 m0, wf2 m1, wf2 m2, wf2 (&o)
   }
 }
 
-template <int EARLY, int PACKED_T = 0>
+template <int EARLY, int PACKED_T = 0, int STATS = 0>
 __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const WinoArgs a) {
   using Cfg = Wino43Cfg;
   constexpr int CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, RW = Cfg::RW, RAWP = Cfg::RAWP, VT = Cfg::VT;
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
   issue_raw();
   issue_a();
   for (;;) {                                            // one pass per workgroup tile
-    const int e_n = walk.n, e_h0 = walk.trow * Cfg::TH, e_w0 = walk.tcol * Cfg::TW, e_m0 = walk.mb * MB;
+    const int e_n = walk.n, e_h0 = walk.trow * Cfg::TH, e_w0 = walk.tcol * Cfg::TW, e_m0 = walk.mb * MB, e_pt = walk.pt;
     // ---- the half-patch transform of one chunk (raw stage -> V stage of the same parity), in pieces that the chunk loop places between
     //      its MFMA groups: rows 3 RH .. 3 RH + 2 of B^T d B from raw rows RH .. RH + 4 of the patch
     float t[3][6];
@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
       // (wm == RH: both are wave >> 2; an output row below the image: out of the descriptor's range -- loads give 0, stores are dropped)
       const unsigned lane_off_b = oh < H ? (unsigned)((RH * 32 + 4 * half_w) * HW + oh * W + ow) * 4u : kDmaOob;
       const int c4 = e_m0 + RH * 32 + 4 * half_w;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
+      double* red = reinterpret_cast<double*>(lds + 8 * 3 * 2 * 2 * 64 * 4);      // STATS: [wave 8][half 2][16 r][2] behind the exchange region (4 KB of the V stages' last 12)
 #pragma unroll
       for (int rd = 0; rd < 4; ++rd) {                   // channels r = 4 rd .. 4 rd + 3 of the lane's sixteen
         // this round's loads first: their latency hides behind the partial transforms and the exchange
@@ -486,6 +487,7 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
           sh4 = *reinterpret_cast<const f32x4*>(a.shift + c4 + 8 * rd);
           if (has_mean) mu4 = *reinterpret_cast<const f32x4*>(a.mean + c4 + 8 * rd);
         }
+        double q1[STATS ? 4 : 1], q2[STATS ? 4 : 1];      // STATS: this lane's four pixels per channel of the round -- sum, sum of squares
         wf2 own[2][4];                                   // [pair][output column]: this wave's own share of output row XG
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
@@ -546,6 +548,46 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
               for (int b2 = 0; b2 < 4; ++b2) v[b2] = v[b2] > 0.0f ? v[b2] : 0.0f;
             }
             tnv3_buf_store_f4(r_dst, lane_off_b, chan_off(r), v);
+            if constexpr (STATS) {                        // (rows below the image do not count)
+              const bool in = oh < H;
+              q1[rr] = in ? ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]) : 0.0;
+              q2[rr] = in ? ((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1]) + ((double)v[2] * (double)v[2] + (double)v[3] * (double)v[3]) : 0.0;
+            }
+          }
+        }
+        if constexpr (STATS) {
+          // BatchNorm batch statistics from the epilogue's registers (model.py:9 in training mode): a half-wave holds 32 tiles x 4 pixels
+          // of the round's four channels.  Reduce-scatter over lane bits 4, 3 (the lane keeps the channels its bits select and adds the
+          // partner's copy), then plain exchanges over bits 2, 1, 0: every lane of an 8-lane run ends up with the half-wave's sum of
+          // channel 2 * bit4 + bit3 of the round.  The four xg waves (output rows) of a channel block are folded through LDS after the
+          // last round, in a fixed order.  fp64: deterministic.
+          {
+            const bool up = (bl_w & 16) != 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const double s1 = up ? q1[i] : q1[i + 2], k1 = up ? q1[i + 2] : q1[i];
+              const double s2 = up ? q2[i] : q2[i + 2], k2 = up ? q2[i + 2] : q2[i];
+              q1[i] = k1 + __shfl_xor(s1, 16, 64);
+              q2[i] = k2 + __shfl_xor(s2, 16, 64);
+            }
+          }
+          {
+            const bool up = (bl_w & 8) != 0;
+            const double s1 = up ? q1[0] : q1[1], k1 = up ? q1[1] : q1[0];
+            const double s2 = up ? q2[0] : q2[1], k2 = up ? q2[1] : q2[0];
+            q1[0] = k1 + __shfl_xor(s1, 8, 64);
+            q2[0] = k2 + __shfl_xor(s2, 8, 64);
+          }
+#pragma unroll
+          for (int o = 4; o > 0; o >>= 1) {
+            q1[0] += __shfl_xor(q1[0], o, 64);
+            q2[0] += __shfl_xor(q2[0], o, 64);
+          }
+          if ((bl_w & 7) == 0) {
+            const int rr = 2 * ((bl_w >> 4) & 1) + ((bl_w >> 3) & 1);
+            double* d = red + (((RH * 4 + XG) * 2 + half_w) * 16 + 4 * rd + rr) * 2;
+            d[0] = q1[0];
+            d[1] = q2[0];
           }
         }
         __syncthreads();
@@ -556,6 +598,25 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
       case 1: writeout(std::integral_constant<int, 1>{}); break;
       case 2: writeout(std::integral_constant<int, 2>{}); break;
       default: writeout(std::integral_constant<int, 3>{}); break;
+    }
+    if constexpr (STATS) {
+      __syncthreads();
+      if (tid < MB) {                                      // channel tid of this block: fold the four waves (output rows) that own its pixels
+        const double* red = reinterpret_cast<const double*>(lds + 8 * 3 * 2 * 2 * 64 * 4);
+        const int cwm = tid >> 5, q = tid & 31;
+        const int chalf = (q >> 2) & 1, cr = (q & 3) + 4 * (q >> 3);
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const double* d = red + (((cwm * 4 + g) * 2 + chalf) * 16 + cr) * 2;
+          s1 += d[0];
+          s2 += d[1];
+        }
+        double* o = a.stats + ((size_t)(e_m0 + tid) * nPT + e_pt) * 2;
+        o[0] = s1;
+        o[1] = s2;
+      }
+      __syncthreads();                                     // the fold has read `red`: the next tile's transform may overwrite the V stages
     }
 
     if (!have_next) break;

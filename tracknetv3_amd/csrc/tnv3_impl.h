@@ -596,21 +596,27 @@ int conv3x3_wino43_pack_impl(Launcher& L, const float* w, float* u, int cout_w, 
   return L.launch(conv3x3_wino43_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w + (size_t)c_from * 9, u, cout, cin,
                   transpose_flip ? s_w_ci : s_w_co, transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
 }
+inline long conv3x3_wino43_stats_tiles(int n, int h, int w) {
+  return (n <= 0 || h % 4 || w % Wino43Cfg::TW) ? 0 : (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
+}
 template <class Launcher>
 int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, const float* addend, const float* mean, const float* scale,
-                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu) {
+                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, double* stats = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino43: bad argument");
+  if (stats && (scale || shift || mean || relu)) TNV3_FAIL(-1, "conv3x3_wino43: the batch-statistics epilogue writes the raw convolution (no affine, no ReLU)");
+  if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino43: statistics buffer must be 8-byte aligned");
   if (!conv3x3_wino43_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino43: needs Cout %% 64 == 0, H %% 4 == 0, W %% 64 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino43: inconsistent affine arguments");
   if ((long)cin * h * w * 4 >= (1l << 31) || (long)Wino43Cfg::MB * h * w * 4 >= (1l << 31))
     TNV3_FAIL(-1, "conv3x3_wino43: one sample of the input / 64 output planes must stay below 2 GiB");
   if ((((uintptr_t)u | (uintptr_t)src | (uintptr_t)dst | (uintptr_t)addend) & 15) != 0) TNV3_FAIL(-1, "conv3x3_wino43: pointers must be 16-byte aligned");
-  WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, nullptr, nullptr, nullptr};
+  WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, nullptr, nullptr};
   const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino43: too many pixel tiles");
   // <1, 0>: next tile's raw fill before the write-out, scalar input transform (the two-wide form <1, 1> measured 1-5 % slower on every
   // shape, profiles/r03_wino43_transform_ab.txt; filling after the write-out <0, 0> 1-1.5 % slower)
+  if (stats) return L.launch(conv3x3_wino43_kernel<1, 0, 1>, wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt)), Wino43Cfg::NT, a);
   return L.launch(conv3x3_wino43_kernel<1, 0>, wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt)), Wino43Cfg::NT, a);
 }
 

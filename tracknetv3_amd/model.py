@@ -193,6 +193,8 @@ class Conv2DBlock(nn.Module):
         if affine:
             return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, mean=bn.running_mean, scale=self.eval_scale(),
                                shift=bn.bias.detach(), relu=relu, cfg=cfg)
+        if want_stats and c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_wino43_train(c1, self.conv.out_dim, h, w):   # training forward, F(4x4, 3x3)
+            return ops.conv3x3_wino43_stats(skip, self.packed_wino43(c0), self.conv.out_dim, addend=part)
         if c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # training forward: raw sums
             if want_stats and tuning.wino_has_stats():
                 return ops.conv3x3_wino_stats(skip, self.packed_wino(c0), self.conv.out_dim, addend=part)

@@ -142,6 +142,25 @@ def conv3x3_wino43(src, u, cout, mean=None, scale=None, shift=None, relu=False, 
     return out
 
 
+def conv3x3_wino43_stats(src, u, cout, addend=None):
+    """Training-mode forward of a plain layer in F(4x4, 3x3) form: (z, tile_stats) -- the raw convolution (+ addend) and the per-channel /
+    per-tile sums and sums of squares BatchNorm needs, from the same kernel's epilogue (tnv3_conv3x3_wino43_forward_stats)."""
+    lib = _lib.load()
+    _f32(src, u, addend)
+    _lib.dev_check(src, u, addend)
+    n, cin, h, w = (int(v) for v in src.shape)
+    tiles = int(lib.tnv3_conv3x3_wino43_stats_tiles(n, h, w))
+    if tiles <= 0 or u.numel() != lib.tnv3_conv3x3_wino43_packed_floats(cin, int(cout)):
+        raise _lib.Tnv3Error("conv3x3_wino43_stats: unsupported shape or filter panel mismatch")
+    out = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=src.device)
+    stats = torch.empty((int(cout), tiles, 2), dtype=torch.float64, device=src.device)
+    if addend is not None and tuple(addend.shape) != tuple(out.shape):
+        raise _lib.Tnv3Error("conv3x3_wino43_stats: addend must have the output's shape")
+    _lib.check(lib.tnv3_conv3x3_wino43_forward_stats(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(out), _lib.ptr(stats), n, cin,
+                                                     int(cout), h, w, _lib.stream_ptr(src)))
+    return out, stats
+
+
 class _WinoPackItem(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("u", ctypes.c_void_p), ("cout_w", ctypes.c_int), ("cin_w", ctypes.c_int), ("c_from", ctypes.c_int),
                 ("c_count", ctypes.c_int), ("transpose_flip", ctypes.c_int), ("layout", ctypes.c_int)]
@@ -983,7 +1002,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # The C ABI runs a call on its stream's device, but a tensor's *default* stream is the NULL stream (= "the calling thread's
 # current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
-_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pack_wino_weights_multi", "pack_wino43_weights", "conv3x3_wino43", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
+_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pack_wino_weights_multi", "pack_wino43_weights", "conv3x3_wino43", "conv3x3_wino43_stats", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "bn_bwd_consts", "conv3x3_wino_dgrad_bnstats", "bn_relu_backward_tiles", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",

@@ -59,6 +59,14 @@ def use_wino43_dgrad(cin, cout, h, w):
     return WINO43_DGRAD and use_wino43(cin, cout, h, w)
 
 
+# ... and the training forward (its epilogue takes BatchNorm's batch statistics like the F(2x2) kernels').  TNV3_WINO43_TRAIN=0: F(2x2).
+WINO43_TRAIN = os.environ.get("TNV3_WINO43_TRAIN", "1") != "0"
+
+
+def use_wino43_train(cin, cout, h, w):
+    return WINO43_TRAIN and BN_STATS_IN_EPILOGUE and use_wino43(cin, cout, h, w)
+
+
 def use_wino43(cin, cout, h, w):
     if not (WINOGRAD and WINO43) or cin < WINO43_MIN_CIN:
         return False
