@@ -218,6 +218,30 @@ TRAIN_FLOPS_EXECUTED_PER_SAMPLE_CLASS_FILTERS = 296.5e9
 TRAIN_FLOPS_EXECUTED_PER_SAMPLE = 296.5e9 - 3 * 65.2e9 * (4 / 9 - 9 / 36)
 
 
+def train_flops_executed_per_sample():
+    """What the matrix pipe executes per sample in one training step with the kernels the step dispatches to (tuning.*): per layer and
+    pass the direct count times 9/36 (Winograd F(4x4,3x3), and the 9-GEMM forms of the upsampled halves), 16/36 (F(2x2,3x3)) or 1."""
+    from tracknetv3_amd import tuning as t
+    total = 0.0
+    for name, c0, c1, co, h, w, up in conv_layer_table((SEQ_LEN + 1) * 3, H, W):
+        def frac(ci, use43):
+            if use43:
+                return 9 / 36
+            return 16 / 36 if t.use_winograd(ci, co, h, w) else 1.0
+        if up:
+            upf = conv_flops(c0, 0, co, h, w) * (9 / 36) * 3                                    # forward, data gradient, weight gradient
+            sk = conv_flops(c1, 0, co, h, w)
+            skip = sk * (frac(c1, t.use_wino43_train(c1, co, h, w)) + frac(c1, t.use_wino43_dgrad(co, c1, h, w)) + (16 / 36 if t.use_winograd_wgrad(c1, co, h, w) else 1.0))
+            total += upf + skip
+        else:
+            fl = conv_flops(c0, 0, co, h, w)
+            total += fl * frac(c0, t.use_wino43_train(c0, co, h, w))                                # forward
+            if name != "down_block_1.conv_1":
+                total += fl * frac(c0, t.use_wino43_dgrad(co, c0, h, w))                            # data gradient (none for the first layer)
+            total += fl * (16 / 36 if t.use_winograd_wgrad(c0, co, h, w) else 1.0)                  # weight gradient
+    return total
+
+
 STRONG_GLOBAL_BATCH = 80            # BASELINE configs[2]: global batch 80 = 8 GPUs x the reference's --batch_size 10 (README.md:144)
 
 
@@ -292,7 +316,7 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
             strong = {"error": f"{type(e).__name__}: {e}"}
     frames = world * batch * SEQ_LEN * steps
     ms = dt / steps * 1e3
-    tf_exec = TRAIN_FLOPS_EXECUTED_PER_SAMPLE * batch / (ms * 1e-3) / 1e12
+    tf_exec = train_flops_executed_per_sample() * batch / (ms * 1e-3) / 1e12
     tf_alg = TRAIN_FLOPS_PER_SAMPLE * batch / (ms * 1e-3) / 1e12
     return {
         "metric": "frames/sec (288x512, seq_len=8) TrackNet training", "value": round(frames / dt, 2), "unit": "frames/s",
@@ -312,8 +336,8 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
                              "reference's algorithmic FLOP count (SURVEY 8d: 678.2 GFLOP/sample) -- the upsampled channels of the "
                              "three decoder-entry layers run at the low resolution in all three passes, in Winograd forms that keep 9 of the 16 "
                              "GEMMs (9/36 of those MACs), the plain "
-                             "layers in fused Winograd F(2x2,3x3) form (16/36) in forward, data gradient and, from 64 channels, "
-                             "weight gradient"},
+                             "layers in fused Winograd form -- F(4x4,3x3) (9/36) in forward and data gradient, F(2x2,3x3) (16/36) in the "
+                             "weight gradient --, counted per layer from the dispatch rules (train_flops_executed_per_sample)"},
         "strong": strong, "dp_overlap": overlap, "final_loss": round(float(loss.item()), 6)}
 
 
