@@ -40,6 +40,7 @@ def resources(tmp_path_factory):
             if m and cur:
                 kernels[cur][m.group(1).strip()] = int(m.group(2))
     assert len(kernels) > 30
+    kernels["__asm__"] = [str(tmp / f"{fam}.s") for fam in _build.FAMILIES]
     return kernels
 
 
@@ -49,7 +50,53 @@ def _find(kernels, *needles):
     return hits[0]
 
 
+def _vregs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def _split_ops(text):
+    return [o.strip() for o in re.split(r",\s*(?![^\[]*\])", text)]
+
+
+def store_data_hazards(path, need=2):
+    """(line, store, clobbering instruction) of every >8-byte vector store whose data registers a VALU instruction writes within `need`
+    wait states.  gfx940+ needs two; hipcc's hazard recogniser skips buffer stores with an SGPR soffset (their extra issue cycle covers
+    one), and the F(4x4) kernel's statistics epilogue lost elements 0, 1 of a float4 to a v_add_f64 that way on an MI355X."""
+    lines = [l.split(";")[0].strip() for l in open(path)]
+    ins = [(i, l) for i, l in enumerate(lines) if l and not l.endswith(":") and not l.startswith(".")]
+    hits = []
+    for k, (i, l) in enumerate(ins):
+        m = re.match(r"((?:buffer|global|flat|scratch)_store_dwordx[34])\s+(.*)", l)
+        if not m:
+            continue
+        ops = _split_ops(m.group(2))
+        data = _vregs(ops[0]) if m.group(1).startswith("buffer") else _vregs(ops[1])
+        ws = 0
+        for (_, n) in ins[k + 1:k + 1 + need]:
+            if ws >= need:
+                break
+            mm = re.match(r"s_nop (\d+)", n)
+            if mm:
+                ws += int(mm.group(1)) + 1
+                continue
+            if n.startswith("v_") and _vregs(_split_ops(n.split(None, 1)[1])[0]) & data:
+                hits.append((i + 1, l, n))
+                break
+            ws += 1
+    return hits
+
+
+def test_no_valu_write_of_store_data_within_two_wait_states(resources):
+    hits = [(os.path.basename(p), h) for p in resources["__asm__"] for h in store_data_hazards(p)]
+    assert not hits, hits[:5]
+
+
 def test_no_vgpr_spills_anywhere(resources):
+    resources = {k: v for k, v in resources.items() if k != "__asm__"}
     bad = {k: v for k, v in resources.items() if v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)}
     assert not bad, list(bad)
 
@@ -88,10 +135,12 @@ def test_conv_and_wgrad_budgets(resources):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
-    k = _find(resources, "conv3x3_wino43_kernelILi1ELi0E")                              # Winograd F(4x4, 3x3): 144 accumulators, two waves per SIMD;
-    # NO spill traffic: its chunk loop waits with a COUNTED vmcnt for its LDS-DMA pieces (nine A loads behind them may stay in flight)
-    assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
-    assert k["LDS Size [bytes/block]"] <= 160 * 1024
+    for name in ("conv3x3_wino43_kernelILi1ELi0ELi0E", "conv3x3_wino43_kernelILi1ELi0ELi1E"):   # Winograd F(4x4, 3x3), plain / statistics epilogue:
+        # 144 accumulators, two waves per SIMD; NO spill traffic: its chunk loop waits with a COUNTED vmcnt for its LDS-DMA pieces (nine
+        # A loads behind them may stay in flight)
+        k = _find(resources, name)
+        assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+        assert k["LDS Size [bytes/block]"] <= 160 * 1024
     for name, occ in (("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi2ELi4ELi2ELi4E", 4), ("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi1ELi4ELi2ELi4E", 4),
                       ("dgrad_up2x_mfma_kernelINS_12DgradUp2xCfgILi2ELi2ELi4ELi1ELi2E", 4)):
         k = _find(resources, name)

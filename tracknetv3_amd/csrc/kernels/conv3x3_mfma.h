@@ -142,8 +142,13 @@ typedef unsigned tnv3_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ tnv3_f4 tnv3_buf_load_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
   return __builtin_bit_cast(tnv3_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, (int)soffset, 0));
 }
+// 16-byte store.  gfx950 HAZARD (measured, scripts/wino43_debug.py): a VALU write of the data registers in the instruction right after
+// a >8-byte buffer store corrupts the stored value -- the store reads its data over several cycles, gfx940+ needs TWO wait states, and
+// the compiler's hazard recogniser exempts the SGPR-soffset form (its extra issue cycle covers only one).  The s_nop takes the data
+// registers as operands: they stay live, and unwritten, until it has issued (tests/test_kernel_resources.py scans the ISA for the pattern).
 __device__ __forceinline__ void tnv3_buf_store_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tnv3_u4, v), r, (int)voffset, (int)soffset, 0);
+  asm volatile("s_nop 1" : : "v"(v) : "memory");
 }
 #endif
 
