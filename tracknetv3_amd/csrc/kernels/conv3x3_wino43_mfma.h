@@ -214,7 +214,12 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
   const size_t x_step = (size_t)CC * HW;
   // ---- transform roles: thread = (channel t_c, tile t_t, row half rh); rh is wave-uniform (waves 0-3 / 4-7)
   const int rh = swave >> 2;
-  const int tp = tid & 255, t_c = tp >> 5, t_t = tp & 31, t_tr = t_t >> 4, t_tc = t_t & 15;
+  // A half-wave (the lane group of a 4-byte LDS store: 32 banks) takes all 32 tiles, each with ONE of the chunk's channels, rotated by the
+  // tile: position j = c >> 1 of the tile's 16-byte quad = (t + t / 8 + half-wave) mod 4, so the 32 stores of an instruction hit 8 quads x
+  // 4 positions = 32 different banks (a fixed channel per half-wave put them on 8: 4-way conflicts, 54 % of the LDS cycles,
+  // profiles/r03_infer_sq_summary.json).  The 16-byte raw reads stay conflict-free: the channel's plane offset is 32 (c & 1) banks, the same for the whole half-wave.
+  const int tp = tid & 255, t_g = tp >> 5, t_t = tp & 31, t_tr = t_t >> 4, t_tc = t_t & 15;
+  const int t_c = 2 * (((t_t & 3) + (t_t >> 3) + t_g) & 3) + (t_g >> 2);
   const int t_src = t_c * RAWP + (4 * t_tr) * RW + 4 * t_tc;        // + row * RW: 16-byte aligned
   const int t_dst = t_t * VT + (t_c & 1) * 4 + (t_c >> 1);           // + (xg * 9 + x9) * TB * VT
   // ---- MFMA operands
