@@ -284,3 +284,39 @@ def test_conv3x3_wino43_vs_torch(gpu_device, case):
     the data gradient (transposed, flipped panel)."""
     from test_emu_kernels import _wino43_case
     _wino43_case(case, gpu_device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 20, 128, 16, 64), (2, 64, 64, 64, 128), (2, 128, 128, 32, 64)])
+def test_conv3x3_wino43_stats_output_is_repeatable_and_equals_the_plain_kernel(gpu_device, case):
+    """The statistics variant of the F(4x4) kernel writes the same z as the plain one, bit for bit, on every run, into NaN-prefilled
+    outputs.  (It once lost elements 0, 1 of some float4 stores to a v_add_f64 that overwrote the store's data registers one
+    instruction later -- nondeterministically, and only in this instantiation: DESIGN 3.1g.)"""
+    import torch
+    from tracknetv3_amd import ops
+    from test_emu_kernels import T
+    n, cin, cout, h, w = case
+    x, wt = torch.relu(T((n, cin, h, w), 491)).to(gpu_device), T((cout, cin, 3, 3), 492, -0.3, 0.3).to(gpu_device)
+    u = ops.pack_wino43_weights(wt)
+    y = ops.conv3x3_wino43(x, u, cout)
+    real_empty = torch.empty
+
+    def nan_empty(*a, **k):
+        t = real_empty(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+
+    first = None
+    for _ in range(12):
+        ops.torch.empty = nan_empty
+        try:
+            z, st = ops.conv3x3_wino43_stats(x, u, cout)
+        finally:
+            ops.torch.empty = real_empty
+        assert torch.equal(z, y)
+        if first is None:
+            first = st.clone()
+            zd = z.double()
+            assert torch.allclose(st[:, :, 0].sum(1), zd.sum((0, 2, 3)), rtol=1e-9, atol=1e-9 * float(zd.abs().sum()))
+            assert torch.allclose(st[:, :, 1].sum(1), (zd * zd).sum((0, 2, 3)), rtol=1e-9, atol=1e-9 * float((zd * zd).sum()))
+        else:
+            assert torch.equal(st, first)
