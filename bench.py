@@ -336,7 +336,8 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
                              "reference's algorithmic FLOP count (SURVEY 8d: 678.2 GFLOP/sample) -- the upsampled channels of the "
                              "three decoder-entry layers run at the low resolution in all three passes, in Winograd forms that keep 9 of the 16 "
                              "GEMMs (9/36 of those MACs), the plain "
-                             "layers in fused Winograd form -- F(4x4,3x3) (9/36) in forward and data gradient, F(2x2,3x3) (16/36) in the "
+                             "layers in fused Winograd form -- F(4x4,3x3) (9/36) in the data gradient (and in the forward with the opt-in "
+                             "TNV3_WINO43_TRAIN=1, which trades parity margin for 2.8 ms), F(2x2,3x3) (16/36) in the forward and the "
                              "weight gradient --, counted per layer from the dispatch rules (train_flops_executed_per_sample)"},
         "strong": strong, "dp_overlap": overlap, "final_loss": round(float(loss.item()), 6)}
 

@@ -62,32 +62,51 @@ __device__ __forceinline__ float wino43_g_row(int i, float g0, float g1, float g
 
 // w[..][3][3] (strides s_co / s_ci floats between output / input channels; flip: taps reversed -- the data gradient's filter) ->
 // panel u[co / 32][chunk][xg][x9][lane = (ci % 2) * 32 + co % 32][ci % 8 / 2], zero for ci >= Cin; then kPackZeroTail zeros.
-// (elements e0, e0 + stride, ... of one panel; shared by the one-panel kernel and the table-driven one of conv3x3_wino_mfma.h's twin below)
+// One work item = one (32-channel block, chunk, lane): it reads the 3x3 filters of the lane's four input channels ONCE, forms all 36
+// G g G^T entries of each and writes 36 float4 -- a wave's 64 lanes store 1 KB contiguous per (xg, x9).  (The first form took one item
+// per output float: 36 x the filter reads, three 64-bit divisions and two run-time switches each -- 0.79 ms for the ~40 panels of a
+// training step, profiles/r03_train_kernel_stats.csv; shared by the one-panel kernel and the table-driven one below.)
+inline long conv3x3_wino43_pack_items(int Cout, int Cin) { return (long)(Cout / 32) * ((Cin + 7) / 8) * 64 + kPackZeroTail / 4; }
 __device__ __forceinline__ void conv3x3_wino43_pack_elements(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, long s_co, long s_ci,
-                                                             int flip, long e0, long stride) {
+                                                             int flip, long q0, long stride) {
+  static_assert(kPackZeroTail % 4 == 0, "the zero tail is written as float4");
   const int nch = (Cin + 7) / 8;
-  const long body = (long)(Cout / 32) * nch * Wino43Cfg::A_CHUNK_FLOATS, total = body + kPackZeroTail;
-  for (long e = e0; e < total; e += stride) {
-    if (e >= body) { u[e] = 0.0f; continue; }
-    const int s = (int)(e & 3), ln = (int)((e >> 2) & 63);
-    long r = e >> 8;
-    const int x9 = (int)(r % 9); r /= 9;
-    const int xg = (int)(r & 3); r >>= 2;
-    const int k = (int)(r % nch), mb32 = (int)(r / nch);
-    const int co = 32 * mb32 + (ln & 31), ci = 8 * k + 2 * s + (ln >> 5);
-    const int i = 3 * (xg >> 1) + x9 / 3, j = 3 * (xg & 1) + x9 % 3;
-    float v = 0.0f;
-    if (ci < Cin) {
-      const float* g = w + (long)co * s_co + (long)ci * s_ci;
-      float rowv[3];                                     // row i of G applied down the filter's columns
+  const long quads = (long)(Cout / 32) * nch * 64;
+  f32x4* u4 = reinterpret_cast<f32x4*>(u);
+  for (long q = q0; q < quads + kPackZeroTail / 4; q += stride) {
+    if (q >= quads) { u4[quads * 36 + (q - quads)] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; continue; }
+    const int ln = (int)(q & 63);
+    const int r = (int)(q >> 6), k = r % nch, mb32 = r / nch;
+    const int co = 32 * mb32 + (ln & 31);
+    float rowv[4][6][3];                               // [channel s][row i of G applied down the filter's columns][column c]
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float g0 = flip ? g[8 - c] : g[c], g1 = flip ? g[5 - c] : g[3 + c], g2 = flip ? g[2 - c] : g[6 + c];
-        rowv[c] = wino43_g_row(i, g0, g1, g2);
+    for (int sx = 0; sx < 4; ++sx) {
+      const int ci = 8 * k + 2 * sx + (ln >> 5);
+      float f[9];
+      if (ci < Cin) {
+        const float* g = w + (long)co * s_co + (long)ci * s_ci;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) f[t] = flip ? g[8 - t] : g[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) f[t] = 0.0f;
       }
-      v = wino43_g_row(j, rowv[0], rowv[1], rowv[2]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rowv[sx][i][c] = wino43_g_row(i, f[c], f[3 + c], f[6 + c]);
     }
-    u[e] = v;
+    f32x4* dst = u4 + ((long)r * 36) * 64 + ln;        // (xg, x9) planes of 64 float4
+#pragma unroll
+    for (int xg = 0; xg < 4; ++xg)
+#pragma unroll
+      for (int x9 = 0; x9 < 9; ++x9) {
+        const int i = 3 * (xg >> 1) + x9 / 3, j = 3 * (xg & 1) + x9 % 3;
+        f32x4 v;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) v[sx] = wino43_g_row(j, rowv[sx][i][0], rowv[sx][i][1], rowv[sx][i][2]);
+        dst[(xg * 9 + x9) * 64] = v;
+      }
   }
 }
 inline __global__ void __launch_bounds__(256) conv3x3_wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin,

@@ -560,7 +560,9 @@ int conv3x3_wino_pack_multi_impl(Launcher& L, const WinoPackItem* items, int cou
       t.s_ci[k] = it.transpose_flip ? s_w_co : s_w_ci;
       t.flip[k] = it.transpose_flip ? 1 : 0;
       t.layout[k] = it.layout;
-      const long total = it.layout == 3 ? (long)conv3x3_wino43_packed_floats(cin, cout) : (long)t.cpad[k] * 16 * cout + kPackZeroTail;      // layout 3: an F(4x4) panel
+      if (it.layout == 3 && (((uintptr_t)it.u) & 15)) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: an F(4x4) panel must be 16-byte aligned (item %d)", base + k);
+      // work items: layout 3 (an F(4x4) panel) one per (32-channel block, chunk, lane) = 36 float4; the F(2x2) layouts one per float
+      const long total = it.layout == 3 ? conv3x3_wino43_pack_items(cout, cin) : (long)t.cpad[k] * 16 * cout + kPackZeroTail;
       const long blocks = (total + 255) / 256;
       t.first_block[k + 1] = t.first_block[k] + (int)(blocks > 2048 ? 2048 : blocks);      // four elements per thread at most times 2048 blocks: grid-stride beyond
     }
@@ -592,7 +594,8 @@ int conv3x3_wino43_pack_impl(Launcher& L, const float* w, float* u, int cout_w, 
   const int cout = transpose_flip ? c_count : cout_w, cin = transpose_flip ? cout_w : c_count;
   if (cout % 32) TNV3_FAIL(-1, "conv3x3_wino43_pack: needs Cout %% 32 == 0 (got %d)", cout);
   const long s_w_co = (long)cin_w * 9, s_w_ci = 9;
-  const long total = (long)conv3x3_wino43_packed_floats(cin, cout);
+  if (((uintptr_t)u) & 15) TNV3_FAIL(-1, "conv3x3_wino43_pack: the panel must be 16-byte aligned");
+  const long total = conv3x3_wino43_pack_items(cout, cin);      // one work item per (32-channel block, chunk, lane): 36 float4
   return L.launch(conv3x3_wino43_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w + (size_t)c_from * 9, u, cout, cin,
                   transpose_flip ? s_w_ci : s_w_co, transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
 }

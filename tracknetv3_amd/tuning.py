@@ -59,8 +59,12 @@ def use_wino43_dgrad(cin, cout, h, w):
     return WINO43_DGRAD and use_wino43(cin, cout, h, w)
 
 
-# ... and the training forward (its epilogue takes BatchNorm's batch statistics like the F(2x2) kernels').  TNV3_WINO43_TRAIN=0: F(2x2).
-WINO43_TRAIN = os.environ.get("TNV3_WINO43_TRAIN", "1") != "0"
+# The TRAINING forward through the F(4x4) kernel (its epilogue takes BatchNorm's batch statistics like the F(2x2) kernels') is OPT-IN
+# (TNV3_WINO43_TRAIN=1): 29.9 -> 27.1 ms per step, but batch-statistics BatchNorm amplifies the forward's ~1e-5 per-layer rounding --
+# at 288x512 the training-mode heat maps sit 9.0e-5 from the fp64 oracle (bar 1e-4; F(2x2): 1.6e-5) and the gradients at 2.3x
+# torch-fp32's own distance from fp64 (median 0.0140 vs 0.0061 of max|g|; F(2x2): 0.0058), and the 32x64 golden's median bound (3x)
+# fails at 4x.  The data gradients in F(4x4) form cost nothing measurable (median 0.0058, heat maps unchanged), so they stay on.
+WINO43_TRAIN = os.environ.get("TNV3_WINO43_TRAIN", "0") == "1"
 
 
 def use_wino43_train(cin, cout, h, w):
