@@ -594,3 +594,33 @@ def test_conv3x3_wino43_emulated_vs_torch(emu, monkeypatch, case):
     for cus in ("2", "256"):
         monkeypatch.setenv("TNV3_EMU_CUS", cus)
         _wino43_case(case, "cpu")
+
+
+def _wino43_panel_reference(w, c_from, flip):
+    """The F(4x4, 3x3) filter panel from its definition (numpy, fp64): U = G g G^T per (output, input) channel, laid out
+    [co / 32][chunk of 8 ci][xg = 3x3 block of the 6x6 xi][x9][lane = (ci % 2) * 32 + co % 32][ci % 8 / 2], zero for ci >= Cin."""
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
+    w = w.double().numpy()
+    f = w[:, c_from:, ::-1, ::-1].transpose(1, 0, 2, 3) if flip else w[:, c_from:]      # flip: the data gradient's transposed, reversed filter
+    cout, cin = f.shape[:2]
+    U = np.einsum("ia,ocab,jb->ocij", G, f, G)
+    out = np.zeros((cout // 32, (cin + 7) // 8, 4, 9, 64, 4))
+    for ci in range(cin):
+        for xg in range(4):
+            for x9 in range(9):
+                i, j = 3 * (xg >> 1) + x9 // 3, 3 * (xg & 1) + x9 % 3
+                out[:, ci // 8, xg, x9, (ci % 2) * 32:(ci % 2) * 32 + 32, (ci % 8) // 2] = U[:, ci, i, j].reshape(cout // 32, 32)
+    return out.ravel()
+
+
+@pytest.mark.parametrize("shape,c_from,flip", [((64, 27, 3, 3), 0, False), ((64, 64, 3, 3), 0, True), ((128, 64, 3, 3), 0, False), ((64, 192, 3, 3), 128, False),
+                                               ((64, 192, 3, 3), 128, True), ((64, 96, 3, 3), 37, False), ((96, 64, 3, 3), 0, True), ((64, 20, 3, 3), 3, False)])
+def test_wino43_pack_equals_its_definition(emu, shape, c_from, flip):
+    """tnv3_conv3x3_wino43_pack (one work item per lane quad: 36 float4 stores) against G g G^T in numpy: input-channel slices, partial last
+    chunks, the data gradient's transpose + flip, and the zero tail."""
+    from tracknetv3_amd import ops
+    w = T(shape, 411, -0.5, 0.5)
+    u = ops.pack_wino43_weights(w, c_from=c_from, transpose_flip=flip).double().numpy()
+    ref = _wino43_panel_reference(w, c_from, flip)
+    assert u.size == ref.size + 64 and (u[ref.size:] == 0).all()
+    assert np.abs(u[:ref.size] - ref).max() <= 1e-7
