@@ -64,6 +64,13 @@ namespace emu {
 
 enum { WAVE = 64, MAX_WAVES = 16 };
 
+// A work-item's vector-memory operations still "in flight" (lazy-DMA mode, below): LDS-DMA pieces carry their 16 bytes and LDS
+// destination, every other buffer load / store is a placeholder that only occupies its place in the in-order queue vmcnt counts.
+struct PendingVm {
+  void* dst = nullptr;
+  unsigned size = 0;
+  unsigned char data[16];
+};
 struct Fiber {
   void* sp = nullptr;
   char* stack = nullptr;
@@ -71,6 +78,7 @@ struct Fiber {
   bool wait_block = false;
   unsigned wait_gen = 0;
   emu_dim3 tid{};
+  std::vector<PendingVm> vm;      // oldest first
 };
 
 struct State {
@@ -82,12 +90,42 @@ struct State {
   unsigned wave_gen[MAX_WAVES], wave_count[MAX_WAVES], wave_size[MAX_WAVES];
   uint64_t xchg[MAX_WAVES][4][WAVE];   // per-wave exchange scratch
   std::function<void()> body;
+  bool lazy = false;            // lazy-DMA mode of this launch (below)
 };
 inline State& S() { static State s; return s; }
 
 inline unsigned flat_tid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
 inline unsigned lane_id() { return flat_tid() % WAVE; }
 inline unsigned wave_id() { return flat_tid() / WAVE; }
+
+// Lazy-DMA mode (TNV3_EMU_LAZY_DMA=1): an LDS-DMA piece lands as LATE as the program allows -- when its work-item executes an
+// s_waitcnt whose vmcnt leaves fewer operations in flight than are queued behind it, or at the end of the kernel -- instead of at issue
+// (the default: as EARLY as possible).  The two extremes bracket the hardware; a kernel whose counted waits are too weak, or that
+// relies on a barrier alone to publish a DMA, reads stale LDS in this mode and fails its parity test on the CPU.  __syncthreads() does
+// NOT complete them: hipcc emits `s_waitcnt lgkmcnt(0); s_barrier` for it on gfx950, no vmcnt.
+// Only meaningful for kernels whose vector-memory operations all go through the buffer helpers below (the Winograd families):
+// a plain pointer load cannot be intercepted, so it is missing from the queue that a counted wait counts.  Read per launch.
+inline bool lazy_dma() { return S().lazy; }
+inline void vm_retire(Fiber& f, size_t leave) {
+  if (f.vm.size() <= leave) return;
+  const size_t n = f.vm.size() - leave;
+  for (size_t i = 0; i < n; ++i)
+    if (f.vm[i].dst) memcpy(f.vm[i].dst, f.vm[i].data, f.vm[i].size);
+  f.vm.erase(f.vm.begin(), f.vm.begin() + n);
+}
+inline void vm_placeholder() {
+  if (lazy_dma()) S().cur->vm.emplace_back();
+}
+inline void vm_dma(void* dst, const void* src, unsigned size) {      // src == nullptr: zeros (out of the descriptor's range)
+  if (!lazy_dma()) {
+    if (src) memcpy(dst, src, size); else memset(dst, 0, size);
+    return;
+  }
+  PendingVm p;
+  p.dst = dst; p.size = size;
+  if (src) memcpy(p.data, src, size); else memset(p.data, 0, size);
+  S().cur->vm.push_back(p);
+}
 
 inline void yield() {
   State& s = S();
@@ -118,6 +156,7 @@ inline void fiber_entry() {
   State& s = S();
   threadIdx = s.cur->tid;
   s.body();
+  vm_retire(*s.cur, 0);          // s_endpgm: everything in flight completes
   s.cur->done = true;
   tnv3_emu_swap(&s.cur->sp, s.main_sp);
   abort();   // a finished fiber is never resumed
@@ -128,6 +167,7 @@ inline void launch(emu_dim3 grid, emu_dim3 block, std::function<void()> body) {
   State& s = S();
   const size_t STACK = 256 * 1024;
   s.nthreads = block.x * block.y * block.z;
+  { const char* e = getenv("TNV3_EMU_LAZY_DMA"); s.lazy = e && e[0] == '1'; }
   if (s.nthreads > MAX_WAVES * WAVE) { fprintf(stderr, "emu: block too large\n"); abort(); }
   gridDim = grid; blockDim = block;
   s.body = std::move(body);
@@ -146,7 +186,7 @@ inline void launch(emu_dim3 grid, emu_dim3 block, std::function<void()> body) {
     }
     for (unsigned i = 0; i < s.nthreads; ++i) {
       Fiber& f = s.fibers[i];
-      f.done = false; f.wait_block = false;
+      f.done = false; f.wait_block = false; f.vm.clear();
       f.tid = {i % block.x, (i / block.x) % block.y, i / (block.x * block.y)};
       // initial frame: six zeroed callee-saved registers, then the entry address that `ret` jumps to;
       // after that `ret`, rsp % 16 == 8 as the ABI requires at a function entry.
@@ -201,7 +241,10 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline unsigned long long __builtin_amdgcn_s_memtime() { return 0; }   // only the diag twins (never instantiated here) read the clock
-inline void __builtin_amdgcn_s_waitcnt(int) {}   // the emulated LDS DMA is synchronous
+// gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4 (expcnt imm[6:4], lgkmcnt imm[11:8]); LDS and scalar operations are synchronous here
+inline void __builtin_amdgcn_s_waitcnt(int imm) {
+  if (emu::lazy_dma()) emu::vm_retire(*emu::S().cur, (size_t)((imm & 15) | (((imm >> 14) & 3) << 4)));
+}
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline void __threadfence() {}
 
@@ -280,7 +323,7 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
 inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(1))) void* g, __attribute__((address_space(3))) void* l,
                                              unsigned size, int offset, unsigned) {
   const uintptr_t base = emu::wave_read((uintptr_t)l, 0);
-  memcpy((void*)(base + (uintptr_t)emu::lane_id() * size + offset), (const void*)((uintptr_t)g + offset), size);
+  emu::vm_dma((void*)(base + (uintptr_t)emu::lane_id() * size + offset), (const void*)((uintptr_t)g + offset), size);
 }
 
 // buffer_load ... lds through a raw buffer descriptor (kernels/conv3x3_wino3_mfma.h): LDS[base + lane*16] <- buffer[voffset..+16),
@@ -290,14 +333,14 @@ inline tnv3_rsrc_t tnv3_make_rsrc(const void* base, unsigned bytes) { return tnv
 inline void tnv3_buf_dma16(tnv3_rsrc_t r, float* lds_base, unsigned voffset) {
   const uintptr_t base = emu::wave_read((uintptr_t)lds_base, 0);
   void* dst = (void*)(base + (uintptr_t)emu::lane_id() * 16);
-  if ((unsigned long long)voffset + 16ull <= (unsigned long long)r.num_records) memcpy(dst, r.base + voffset, 16);
-  else memset(dst, 0, 16);
+  emu::vm_dma(dst, (unsigned long long)voffset + 16ull <= (unsigned long long)r.num_records ? r.base + voffset : nullptr, 16);
 }
 
 // 8-byte buffer load / store through a descriptor: address = base + voffset (per lane) + soffset (scalar); out-of-range loads give 0,
 // out-of-range stores are dropped
 typedef float tnv3_f2 __attribute__((ext_vector_type(2)));
 inline tnv3_f2 tnv3_buf_load_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
+  emu::vm_placeholder();
   tnv3_f2 v = {0.0f, 0.0f};
   const unsigned long long o = (unsigned long long)voffset + soffset;
   if (o + 8ull <= (unsigned long long)r.num_records) memcpy(&v, r.base + o, 8);
@@ -305,16 +348,19 @@ inline tnv3_f2 tnv3_buf_load_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffse
 }
 typedef float tnv3_f4 __attribute__((ext_vector_type(4)));
 inline tnv3_f4 tnv3_buf_load_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset) {
+  emu::vm_placeholder();
   tnv3_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
   const unsigned long long o = (unsigned long long)voffset + soffset;
   if (o + 16ull <= (unsigned long long)r.num_records) memcpy(&v, r.base + o, 16);
   return v;
 }
 inline void tnv3_buf_store_f2(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f2 v) {
+  emu::vm_placeholder();
   const unsigned long long o = (unsigned long long)voffset + soffset;
   if (o + 8ull <= (unsigned long long)r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 8);
 }
 inline void tnv3_buf_store_f4(tnv3_rsrc_t r, unsigned voffset, unsigned soffset, tnv3_f4 v) {
+  emu::vm_placeholder();
   const unsigned long long o = (unsigned long long)voffset + soffset;
   if (o + 16ull <= (unsigned long long)r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 16);
 }

@@ -624,3 +624,31 @@ def test_wino43_pack_equals_its_definition(emu, shape, c_from, flip):
     ref = _wino43_panel_reference(w, c_from, flip)
     assert u.size == ref.size + 64 and (u[ref.size:] == 0).all()
     assert np.abs(u[:ref.size] - ref).max() <= 1e-7
+
+
+@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "up2x_wino", "dgrad_up2x_wino"])
+def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
+    """The emulator's LDS-DMA normally lands at issue -- as early as possible.  TNV3_EMU_LAZY_DMA=1 is the other extreme: a piece lands
+    only when its work-item's counted s_waitcnt (or the kernel's end) forces it, and __syncthreads() forces nothing (hipcc emits no
+    vmcnt for it).  A wait that counts one operation too many, or a barrier trusted to publish a DMA, then reads stale LDS here.
+    (Mutation check when this was added: vmcnt(9) -> vmcnt(12) in the F(4x4) chunk loop passes the eager mode and fails this one.)"""
+    from tracknetv3_amd import tuning
+    monkeypatch.setenv("TNV3_EMU_LAZY_DMA", "1")
+    monkeypatch.setenv("TNV3_EMU_CUS", "2")              # persistent workgroups walk several tiles: the pipelines cross tile boundaries
+    if what == "wino_stream":
+        monkeypatch.setattr(tuning, "WINO_VARIANT", 5)
+        e_plain, e_full = _wino_case(1, 70, 64, 4, 128, "cpu")
+        assert e_plain <= 3e-6 and e_full <= 6e-6
+    elif what == "wino_a128":
+        monkeypatch.setattr(tuning, "WINO_VARIANT", 6)
+        e_plain, e_full = _wino_case(2, 12, 128, 8, 64, "cpu")
+        assert e_plain <= 3e-6 and e_full <= 6e-6
+    elif what == "wino43":
+        _wino43_case((2, 20, 128, 16, 64), "cpu")
+        _wino43_case((1, 27, 64, 8, 128), "cpu")
+    elif what == "up2x_wino":
+        e_ref, e_old = _up2x_wino_case(2, 20, 128, 4, 64, "cpu")
+        assert e_ref <= 3e-6 and e_old <= 4e-6
+    else:
+        e_ref, e_old = _dgrad_up2x_wino_case(*DGRAD_UP2X_WINO_CASES[1], "cpu")
+        assert e_ref <= 3e-6 and e_old <= 4e-6

@@ -456,3 +456,17 @@ def test_bn_statistics_from_the_conv_epilogue_emulated(emu, monkeypatch, case, v
         outs.append((a, mean, invstd, rm, rv))
     for p_, q_ in zip(outs[0], outs[1]):
         assert torch.allclose(p_, q_, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", [(1, 64, 64, 4, 16), (2, 27, 64, 6, 32)])
+def test_wgrad_wino_with_lds_dma_landing_late(emu, monkeypatch, case):
+    """Every Winograd weight-gradient generation with the emulator's LDS-DMA landing as late as the counted waits allow
+    (TNV3_EMU_LAZY_DMA=1, tests/emu/hip_emu.h): same bit-identical results, same error."""
+    monkeypatch.setenv("TNV3_EMU_LAZY_DMA", "1")
+    monkeypatch.setenv("TNV3_EMU_CUS", "2")
+    assert _wgrad_wino_case(case, "cpu") <= 4e-6
+
+
+def test_wgrad_up2x_wino_with_lds_dma_landing_late(emu, monkeypatch):
+    monkeypatch.setenv("TNV3_EMU_LAZY_DMA", "1")
+    _wgrad_up2x_case((1, 128, 64, 64, 4, 16), "cpu")
