@@ -145,3 +145,22 @@ def test_conv_and_wgrad_budgets(resources):
                       ("dgrad_up2x_mfma_kernelINS_12DgradUp2xCfgILi2ELi2ELi4ELi1ELi2E", 4)):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= occ and k["VGPRs Spill"] == 0, (name, k)
+
+
+def test_store_data_hazard_scanner_on_known_patterns(tmp_path):
+    """The scanner itself: the sequence that corrupted stores on the MI355X is reported, covered forms are not."""
+    cases = {
+        # (a) what hipcc emitted for the F(4x4) statistics epilogue: SGPR offset, VALU write of v[166:167] in the next instruction
+        "bad_next": ("buffer_store_dwordx4 v[166:169], v226, s[56:59], s8 offen\nv_add_f64 v[166:167], v[162:163], v[164:165]\n", 1),
+        # (b) one unrelated instruction in between is one wait state: still one short of two
+        "bad_one_between": ("buffer_store_dwordx4 v[146:149], v226, s[56:59], s6 offen\ns_mul_i32 s6, s74, 12\nv_cvt_f64_f32_e32 v[146:147], v147\n", 1),
+        "ok_two_between": ("buffer_store_dwordx4 v[146:149], v226, s[56:59], s6 offen\ns_mul_i32 s6, s74, 12\ns_mul_i32 s7, s74, 12\nv_mov_b32_e32 v146, 0\n", 0),
+        "ok_nop": ("buffer_store_dwordx4 v[10:13], v1, s[4:7], s8 offen\ns_nop 1\nv_mov_b32_e32 v10, 0\n", 0),
+        "ok_other_register": ("global_store_dwordx4 v[6:7], v[2:5], off\nv_mov_b32_e32 v6, 0\n", 0),      # the ADDRESS registers may be rewritten
+        "bad_global": ("global_store_dwordx4 v[6:7], v[2:5], off\nv_mov_b32_e32 v3, 0\n", 1),
+        "ok_8_bytes": ("buffer_store_dwordx2 v[2:3], v1, s[4:7], s8 offen\nv_mov_b32_e32 v2, 0\n", 0),
+    }
+    for name, (asm, want) in cases.items():
+        p = tmp_path / f"{name}.s"
+        p.write_text(asm)
+        assert len(store_data_hazards(str(p))) == want, name
