@@ -130,9 +130,10 @@ typedef struct tnv3_wino_pack_item {
   int cout_w, cin_w, c_from, c_count, transpose_flip, layout;
 } tnv3_wino_pack_item;
 int tnv3_conv3x3_wino_pack_multi(const tnv3_wino_pack_item* items, int count, tnv3_stream_t stream);
-/* The same layer in Winograd F(4x4, 3x3) form: 36 products per 4x4 output tile (2.25 per pixel; F(2x2): 4, direct: 9), transforms
- * with the constants 4, -5, 2 (input), 1/4, 1/6, 1/24 (filter), 2, 4, 8 (output) fused into the kernel.  Same function as
- * tnv3_conv3x3_wino_forward up to fp32 rounding (about 2x F(2x2)'s: the whole TrackNet forward's heat maps stay within 4e-6 of the
+/* The same layer in Winograd F(4x4, 3x3) form: 36 products per 4x4 output tile (2.25 per pixel; F(2x2): 4, direct: 9), the
+ * transforms of the interpolation points (0, +-3/4, +-3/2, infinity) fused into the kernel (a panel is only meaningful to the library
+ * version that packed it: pack with tnv3_conv3x3_wino43_pack, never by hand).  Same function as tnv3_conv3x3_wino_forward up to fp32
+ * rounding (1.0-1.6e-6 of the output scale per layer, F(2x2): 3-8e-7; the whole TrackNet forward's heat maps stay within 1.7e-6 of the
  * fp64 forward).  supported: Cout % 64 == 0, H % 4 == 0, W % 64 == 0.  The panel (its own layout, _packed_floats floats, 16-byte
  * aligned) is packed straight from the nn.Conv2d weight like tnv3_conv3x3_wino_pack_view: an input-channel slice, or transpose_flip
  * for the data gradient's filter.  addend / mean / scale / shift / relu as in tnv3_conv3x3_wino_forward. */
