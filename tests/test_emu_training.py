@@ -470,3 +470,50 @@ def test_wgrad_wino_with_lds_dma_landing_late(emu, monkeypatch, case):
 def test_wgrad_up2x_wino_with_lds_dma_landing_late(emu, monkeypatch):
     monkeypatch.setenv("TNV3_EMU_LAZY_DMA", "1")
     _wgrad_up2x_case((1, 128, 64, 64, 4, 16), "cpu")
+
+
+def test_one_launch_repack_skips_panels_only_the_eval_forward_reads(emu):
+    """model.repack_wino_panels() rebuilds the stale panels that were asked for SINCE THE LAST REPACK: after a validation pass the eval-only
+    panels (the F(4x4) forward panels when training runs the F(2x2) forward) are not rebuilt in front of every training step; the next eval
+    forward repacks them lazily.  Block-level, no forward needed."""
+    from tracknetv3_amd import ops
+    from tracknetv3_amd.model import Conv2DBlock, TrackNet
+    m = TrackNet(9, 3)
+    blocks = [b for b in m.modules() if isinstance(b, Conv2DBlock) and b.conv.out_dim % 64 == 0 and b.conv.in_dim >= 16][:3]
+    sizes, real = [], ops.pack_wino_weights_multi
+
+    def counting(specs, variant=None):
+        sizes.append(len(specs))
+        return real(specs, variant)
+    ops.pack_wino_weights_multi = counting
+    try:
+        def bump():                                  # what an optimiser step does to the version counters
+            with torch.no_grad():
+                for b in blocks:
+                    b.conv.weight.add_(0.0)
+
+        def train_use():
+            return [(b.packed_wino(), b.packed_wino43_t()) for b in blocks]
+
+        def eval_use():
+            return [b.packed_wino43() for b in blocks]
+        train_use()                                   # step 1: lazily packed, planned
+        bump()
+        assert m.repack_wino_panels() == 6 and sizes == [6]
+        train_use()
+        bump()
+        eval_use()                                    # validation: eval panels packed one by one, fresh
+        assert m.repack_wino_panels() == 6            # the training panels only
+        before = [b._cache[("w43", 0)][1].clone() for b in blocks]
+        train_use()
+        bump()
+        assert m.repack_wino_panels() == 6            # eval panels are stale now, but nobody asked for them since the last repack
+        train_use()
+        with torch.no_grad():
+            blocks[0].conv.weight.mul_(2.0)
+        new = eval_use()                              # the next validation repacks them lazily, from the current weights
+        assert torch.equal(new[0], 2.0 * before[0]) and torch.equal(new[1], before[1])
+        assert m.repack_wino_panels() == 2            # ... and the one block whose weight moved: its two training panels
+        assert sizes == [6, 6, 6, 2]
+    finally:
+        ops.pack_wino_weights_multi = real

@@ -52,7 +52,8 @@ class Conv2DBlock(nn.Module):
         self.conv = _Conv3x3Params(in_dim, out_dim)
         self.bn = _BatchNormParams(out_dim)
         self._cache = {}
-        self._wino_plan = set()          # Winograd panels requested so far: what repack_wino_panels() rebuilds in one launch
+        self._wino_plan = set()          # Winograd panels requested so far: what repack_wino_panels() rebuilds in one launch ...
+        self._wino_used = set()          # ... if they were asked for since the last repack (an eval-only panel is not rebuilt per training step)
 
     def _versions(self, names):
         out = []
@@ -81,6 +82,7 @@ class Conv2DBlock(nn.Module):
             hit = (ver, ops.pack_wino_weights(w, c_from=c_from))
             self._cache[key] = hit
             self._wino_plan.add((key, int(c_from), False))
+        self._wino_used.add((key, int(c_from), False))
         return hit[1]
 
     def packed_wino_t(self, c_from=0):
@@ -93,6 +95,7 @@ class Conv2DBlock(nn.Module):
             hit = (ver, ops.pack_wino_weights(w, c_from=c_from, transpose_flip=True))
             self._cache[key] = hit
             self._wino_plan.add((key, int(c_from), True))
+        self._wino_used.add((key, int(c_from), True))
         return hit[1]
 
     def packed_wino43(self, c_from=0):
@@ -104,6 +107,7 @@ class Conv2DBlock(nn.Module):
             hit = (ver, ops.pack_wino43_weights(self.conv.weight.detach(), c_from=c_from))
             self._cache[key] = hit
             self._wino_plan.add((key, int(c_from), False))
+        self._wino_used.add((key, int(c_from), False))
         return hit[1]
 
     def packed_wino43_t(self, c_from=0):
@@ -115,15 +119,18 @@ class Conv2DBlock(nn.Module):
             hit = (ver, ops.pack_wino43_weights(self.conv.weight.detach(), c_from=c_from, transpose_flip=True))
             self._cache[key] = hit
             self._wino_plan.add((key, int(c_from), True))
+        self._wino_used.add((key, int(c_from), True))
         return hit[1]
 
     def stale_wino_panels(self):
         """[(cache key, c_from, transpose_flip)] of the Winograd panels this block has been asked for (by the forward / backward paths
-        actually taken: the plan follows the shapes and tuning switches by construction) whose weight has changed since."""
+        actually taken: the plan follows the shapes and tuning switches by construction) since the last one-launch repack -- a panel only
+        the eval forward reads is not rebuilt in front of every training step; it is repacked lazily by the next eval forward -- whose
+        weight has changed since."""
         if not self._wino_plan:
             return []
         ver = self._versions(["conv"])
-        return [it for it in self._wino_plan if self._cache.get(it[0], (None,))[0] != ver]
+        return [it for it in self._wino_plan if it in self._wino_used and self._cache.get(it[0], (None,))[0] != ver]
 
     def packed_up2x(self, c0):
         """(class filters of the first c0 = upsampled input channels, packed 3x3 filter of the remaining skip channels):
@@ -340,6 +347,9 @@ class TrackNet(nn.Module):
                                                   for m, (key, c_from, flip) in todo])
         for (m, (key, _, _)), u in zip(todo, panels):
             m._cache[key] = (m._versions(["conv"]), u)
+        for m in self.modules():
+            if isinstance(m, Conv2DBlock):
+                m._wino_used.clear()
         return len(todo)
 
     def prepare_eval(self):
