@@ -51,10 +51,10 @@ inline size_t conv3x3_wino43_packed_floats(int cin, int cout) {
 // Interpolation points (0, +-s, +-2s, inf) with s = 3/4 instead of Lavin's s = 1.  Scaling the points changes nothing but the
 // constants of the transforms (the input transform keeps its instruction count, the output transform of the (0, +-s) half gains two
 // multiplies), yet it balances the magnitudes the transforms mix: fp32 error of a 64-channel layer 2.95e-7 -> 1.42e-7 rms
-// (4.97e-6 -> 1.46e-6 max) of the output scale, the network's eval heat maps 3.2e-6 -> 1.65e-6 from the fp64 forward (direct fp32:
-// 1.1e-6), training-mode heat maps at 288x512 8.3e-5 -> 4.0e-5 (profiles/r03_wino_f43_precision.json; a scan of symmetric pairs
+// (4.97e-6 -> 1.46e-6 max) of the output scale, the network's eval heat maps 3.1e-6 -> 1.6e-6 from the fp64 forward (direct fp32:
+// 1.1e-6), training-mode heat maps at 288x512 9.1e-5 -> 3.9e-5 (profiles/r03_wino_f43_precision.json; a scan of symmetric pairs
 // (a, b) puts the optimum at a = 0.65-0.75, b = 1.4-1.6 -- (3/4, 3/2) is within 7 % of it and every constant below is an exact
-// binary fraction).  kW43S = 1 gives Lavin's matrices back.
+// binary fraction).  kW43S = 1 gives Lavin's points back (with the columns of +-2 in A^T halved and their rows in G doubled).
 constexpr float kW43S = 0.75f;
 constexpr float kW43S2 = kW43S * kW43S, kW43S3 = kW43S2 * kW43S, kW43S4 = kW43S2 * kW43S2;
 // B^T (monic rows, the Toom-Cook construction): [4s^4 0 -5s^2 0 1 0; 0 -4s^3 -4s^2 s 1 0; 0 4s^3 -4s^2 -s 1 0; 0 -2s^3 -s^2 2s 1 0;
