@@ -38,6 +38,12 @@ int tnv3_diag_conv3x3_forward(const float* src0, const float* wpack, float* dst,
 int tnv3_diag_conv3x3_wino_forward(const float* src, const float* u, float* dst, int n, int cin, int cout, int h, int w,
                                    int variant, tnv3_stream_t stream);
 
+/* tnv3_conv3x3_wino43_forward (plain: no addend, no affine; results correct) with s_memtime totals per phase of one mid-grid
+ * workgroup in tl_out as uint64 [wave 8][8]: 0 tile fill (DMA wait + first transform + two barriers), 1 chunk loop, 2 next tile's
+ * offsets + raw issue, 3 write-out, 4 A issue + loop tail, 5 chunks, 6 tiles walked (scripts/wino43_timeline.py). */
+int tnv3_diag_conv3x3_wino43_timeline(const float* src, const float* u, float* dst, unsigned long long* tl_out, int n, int cin, int cout,
+                                      int h, int w, tnv3_stream_t stream);
+
 /* tnv3_conv3x3_wgrad_wino with the timing twins of its third-generation kernel (kernels/wgrad_wino_mfma.h: WgradWino3Cfg<3, DIAG>):
  * variant 101 no operand transforms, 102 no strip DMA, 103 no MFMAs (operand reads kept); 0-3 as in the product library. */
 int tnv3_diag_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes, int n, int cin,

@@ -224,7 +224,10 @@ __device__ __forceinline__ void wino43_at_half2(wf2 m0, wf2 m1, wf2 m2, wf2 (&o)
   }
 }
 
-template <int EARLY, int PACKED_T = 0, int STATS = 0>
+// TL = 1 (libtnv3_diag.so only): s_memtime totals per phase of one mid-grid workgroup, written as [wave 8][8] uint64 to a.stats
+// (tile fill: DMA wait + first transform + two barriers; chunk loop; next tile's offsets + raw issue; write-out; A issue + loop tail;
+// chunks; tiles) -- results stay correct.
+template <int EARLY, int PACKED_T = 0, int STATS = 0, int TL = 0>
 __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const WinoArgs a) {
   using Cfg = Wino43Cfg;
   constexpr int CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, TB = Cfg::TB, RW = Cfg::RW, RAWP = Cfg::RAWP, VT = Cfg::VT;
@@ -244,6 +247,17 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
   ConvTileWalk walk;
   walk.init(blockIdx.x, gridDim.x, nMB, nPT, tilesH, tilesW);
   if (!walk.valid) return;
+  unsigned long long tl_acc[5] = {0, 0, 0, 0, 0}, tl_last = 0;
+  int tl_chunks = 0, tl_tiles = 0;
+  auto tl_stamp = [&](int slot) {
+    if constexpr (TL != 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tl_acc[slot] += now - tl_last;
+      tl_last = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
   const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);      // scalar: the LDS-DMA destination (M0) stays on the SALU
   const size_t x_step = (size_t)CC * HW;
@@ -316,6 +330,7 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
   set_tile(walk.n, walk.trow * Cfg::TH, walk.tcol * Cfg::TW, walk.mb * MB);
   issue_raw();
   issue_a();
+  if constexpr (TL != 0) tl_last = __builtin_amdgcn_s_memtime();
   for (;;) {                                            // one pass per workgroup tile
     const int e_n = walk.n, e_h0 = walk.trow * Cfg::TH, e_w0 = walk.tcol * Cfg::TW, e_m0 = walk.mb * MB, e_pt = walk.pt;
     // ---- the half-patch transform of one chunk (raw stage -> V stage of the same parity), in pieces that the chunk loop places between
@@ -407,6 +422,7 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
     full_barrier();
     transform_all(0);
     full_barrier();
+    tl_stamp(0);
 
     // One chunk: the 36 MFMAs of chunk k (V stage k & 1) in five xi groups, and between the groups the half-patch transform of chunk
     // k+1 (raw stage -> V stage of the other parity; after the last chunk: of a stale raw stage into a V stage nobody reads --
@@ -483,6 +499,8 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
     };
     chunk_body(0, std::true_type{});
     for (int k = 1; k < nChunks; ++k) chunk_body(k, std::false_type{});
+    tl_stamp(1);
+    if constexpr (TL != 0) { tl_chunks += nChunks; ++tl_tiles; }
 
     // ---- the NEXT tile's pipeline fill goes out now: the raw stages and the A registers are free, and the write-out below (which
     //      exchanges through the V stages) hides the latency of these loads
@@ -492,6 +510,7 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
       set_tile(walk.n, walk.trow * Cfg::TH, walk.tcol * Cfg::TW, walk.mb * MB);
       issue_raw();
     }
+    tl_stamp(2);
 
     // ---- write-out.  This wave's partial 4x4 output per (channel r of the lane, tile bl): P = A^T[:, I] M_IJ A[J, :] with
     //      I = rows 3 (xg >> 1) .., J = columns 3 (xg & 1) ..; the four xg waves of a channel block exchange through LDS, wave xg
@@ -662,12 +681,24 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
       __syncthreads();                                     // the fold has read `red`: the next tile's transform may overwrite the V stages
     }
 
+    tl_stamp(3);
     if (!have_next) break;
     if (!EARLY) {
       set_tile(walk.n, walk.trow * Cfg::TH, walk.tcol * Cfg::TW, walk.mb * MB);
       issue_raw();
     }
     issue_a();
+    tl_stamp(4);
+  }
+  if constexpr (TL != 0) {
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.stats) + wave * 8;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o[i] = tl_acc[i];
+      o[5] = (unsigned long long)tl_chunks;
+      o[6] = (unsigned long long)tl_tiles;
+      o[7] = 0;
+    }
   }
   };
   if (rh) body(std::integral_constant<int, 1>{}); else body(std::integral_constant<int, 0>{});
