@@ -40,9 +40,10 @@ int tnv3_diag_conv3x3_wino_forward(const float* src, const float* u, float* dst,
 
 /* tnv3_conv3x3_wino43_forward (plain: no addend, no affine; results correct) with s_memtime totals per phase of one mid-grid
  * workgroup in tl_out as uint64 [wave 8][8]: 0 tile fill (DMA wait + first transform + two barriers), 1 chunk loop, 2 next tile's
- * offsets + raw issue, 3 write-out, 4 A issue + loop tail, 5 chunks, 6 tiles walked (scripts/wino43_timeline.py). */
+ * offsets + raw issue, 3 write-out, 4 A issue + loop tail, 5 chunks, 6 tiles walked (scripts/wino43_timeline.py).  variant 1: the
+ * product kernel's work; 2 output stores dropped, 3 no LDS exchange in the write-out, 4 both (WRONG results: what the write-out costs). */
 int tnv3_diag_conv3x3_wino43_timeline(const float* src, const float* u, float* dst, unsigned long long* tl_out, int n, int cin, int cout,
-                                      int h, int w, tnv3_stream_t stream);
+                                      int h, int w, int variant, tnv3_stream_t stream);
 
 /* tnv3_conv3x3_wgrad_wino with the timing twins of its third-generation kernel (kernels/wgrad_wino_mfma.h: WgradWino3Cfg<3, DIAG>):
  * variant 101 no operand transforms, 102 no strip DMA, 103 no MFMAs (operand reads kept); 0-3 as in the product library. */

@@ -20,7 +20,7 @@ def load():
         for name, args in (("tnv3_diag_mfma_f32_probe", [p, i, i, p]),
                            ("tnv3_diag_conv3x3_forward", [p, p, p, i, i, i, i, i, i, i, p]),
                            ("tnv3_diag_conv3x3_wino_forward", [p, p, p, i, i, i, i, i, i, p]),
-                           ("tnv3_diag_conv3x3_wino43_timeline", [p, p, p, p, i, i, i, i, i, p]),
+                           ("tnv3_diag_conv3x3_wino43_timeline", [p, p, p, p, i, i, i, i, i, i, p]),
                            ("tnv3_diag_conv3x3_wgrad_wino", [p, p, p, p, ctypes.c_size_t, i, i, i, i, i, i, p]),
                            ("tnv3_diag_coissue_probe", [p, p, i, i, i, i, p])):
             fn = getattr(lib, name)
@@ -50,11 +50,12 @@ def conv3x3_wino_forward(x, u, y, variant):
                                                 _lib.stream_ptr(x)))
 
 
-def conv3x3_wino43_timeline(x, u, y, tl):
-    """Plain F(4x4) forward (y correct) + phase totals of one mid-grid workgroup in tl (int64 tensor of 64 elements: [wave 8][8])."""
+def conv3x3_wino43_timeline(x, u, y, tl, variant=1):
+    """Plain F(4x4) forward (y correct for variant 1) + phase totals of one mid-grid workgroup in tl (int64 tensor of 64 elements:
+    [wave 8][8]); variants 2-4: the write-out without its stores / its LDS exchange / both (wrong results)."""
     n, cin, h, w = (int(v) for v in x.shape)
     check(load().tnv3_diag_conv3x3_wino43_timeline(_lib.ptr(x), _lib.ptr(u), _lib.ptr(y), _lib.ptr(tl), n, cin, int(y.shape[1]), h, w,
-                                                   _lib.stream_ptr(x)))
+                                                   int(variant), _lib.stream_ptr(x)))
 
 
 def coissue_probe(out_u64, gsrc, blocks, role_a, role_b, iters):

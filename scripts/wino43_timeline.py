@@ -34,6 +34,13 @@ def main():
             if i != 1:
                 d[f"cycles_per_tile_{nm}"] = round(raw[:, i].mean().item() / max(tiles, 1), 1)
         d["cycles_per_tile_outside_the_loop"] = round(sum(raw[:, i].mean().item() for i in (0, 2, 3, 4)) / max(tiles, 1), 1)
+        # what the write-out is made of: twins 2 (output stores dropped), 3 (no LDS exchange), 4 (neither) -- wrong results by design
+        for variant, nm in ((2, "no_stores"), (3, "no_lds_exchange"), (4, "neither")):
+            for _ in range(3):
+                diaglib.conv3x3_wino43_timeline(x, u, y, tl, variant)
+            torch.cuda.synchronize()
+            r2 = tl.cpu().reshape(8, 8).double()
+            d[f"write_out_{nm}"] = round(r2[:, 3].mean().item() / max(r2[:, 6].mean().item(), 1), 1)
         out[f"{cin}->{cout}@{h}x{w}"] = d
         print(f"{cin}->{cout}@{h}x{w}", json.dumps(d), flush=True)
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)

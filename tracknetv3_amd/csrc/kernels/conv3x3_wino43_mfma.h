@@ -226,7 +226,9 @@ __device__ __forceinline__ void wino43_at_half2(wf2 m0, wf2 m1, wf2 m2, wf2 (&o)
 
 // TL = 1 (libtnv3_diag.so only): s_memtime totals per phase of one mid-grid workgroup, written as [wave 8][8] uint64 to a.stats
 // (tile fill: DMA wait + first transform + two barriers; chunk loop; next tile's offsets + raw issue; write-out; A issue + loop tail;
-// chunks; tiles) -- results stay correct.
+// chunks; tiles) -- results stay correct.  TL = 2: the same with the output stores out of range (dropped by the descriptor's bounds
+// check), 3: without the LDS exchange of the write-out (no ds_write / ds_read of partial sums; barriers and arithmetic kept), 4: both --
+// WRONG results: what the write-out's 15-19 k cycles per tile are made of.
 template <int EARLY, int PACKED_T = 0, int STATS = 0, int TL = 0>
 __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const WinoArgs a) {
   using Cfg = Wino43Cfg;
@@ -533,7 +535,7 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
       constexpr int XG = decltype(xgc)::value, XI = XG >> 1, XJ = XG & 1;
       const int oh = e_h0 + 4 * t_r + XG, ow = e_w0 + 4 * t_col;
       // (wm == RH: both are wave >> 2; an output row below the image: out of the descriptor's range -- loads give 0, stores are dropped)
-      const unsigned lane_off_b = oh < H ? (unsigned)((RH * 32 + 4 * half_w) * HW + oh * W + ow) * 4u : kDmaOob;
+      const unsigned lane_off_b = (oh < H && TL != 2 && TL != 4) ? (unsigned)((RH * 32 + 4 * half_w) * HW + oh * W + ow) * 4u : kDmaOob;
       const int c4 = e_m0 + RH * 32 + 4 * half_w;          // channel of r = 0; r -> c4 + (r & 3) + 8 * (r >> 2)
       double* red = reinterpret_cast<double*>(lds + 8 * 3 * 2 * 2 * 64 * 4);      // STATS: [wave 8][half 2][16 r][2] behind the exchange region (4 KB of the V stages' last 12)
 #pragma unroll
@@ -578,7 +580,8 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
               } else {                                   // to wave (arow, wm): slot = this wave's rank among its three senders
                 const int slot = XG < arow ? XG : XG - 1;
                 float* dst = xch + ((((((RH * 4 + arow) * 3 + slot) * 2 + pp) * 2) + hb) * 64 + ln_w) * 4;
-                *reinterpret_cast<f32x4*>(dst) = f32x4{pr[arow][0][0], pr[arow][0][1], pr[arow][1][0], pr[arow][1][1]};
+                if (TL < 3) *reinterpret_cast<f32x4*>(dst) = f32x4{pr[arow][0][0], pr[arow][0][1], pr[arow][1][0], pr[arow][1][1]};
+                else own[pp][2 * hb] += pr[arow][0] + pr[arow][1];      // (keeps the arithmetic alive)
               }
             }
           }
@@ -592,6 +595,7 @@ __global__ void __launch_bounds__(Wino43Cfg::NT) conv3x3_wino43_kernel(const Win
 #pragma unroll
           for (int slot = 0; slot < 3; ++slot) {
             const float* src = xch + (((((RH * 4 + XG) * 3 + slot) * 2 + pp) * 2) * 64 + ln_w) * 4;
+            if (TL >= 3) continue;
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(src), g1 = *reinterpret_cast<const f32x4*>(src + 64 * 4);
             v2[0] += wf2{g0[0], g0[1]}; v2[1] += wf2{g0[2], g0[3]}; v2[2] += wf2{g1[0], g1[1]}; v2[3] += wf2{g1[2], g1[3]};
           }

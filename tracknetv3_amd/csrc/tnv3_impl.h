@@ -627,13 +627,20 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
 // Timeline twin of the F(4x4) kernel: the plain forward (results correct) + [8 waves][8] uint64 of s_memtime totals per phase in tl_out
 template <class Launcher>
 int conv3x3_wino43_timeline_impl(Launcher& L, const float* src, const float* u, float* dst, unsigned long long* tl_out, int n, int cin, int cout,
-                                 int h, int w) {
+                                 int h, int w, int variant) {
   if (!src || !u || !dst || !tl_out || n <= 0) TNV3_FAIL(-1, "conv3x3_wino43_timeline: bad argument");
   if (!conv3x3_wino43_supported(cin, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wino43_timeline: unsupported shape");
   if ((long)cin * h * w * 4 >= (1l << 31) || (long)Wino43Cfg::MB * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino43_timeline: sample too large");
   WinoArgs a{src, u, u, nullptr, nullptr, nullptr, nullptr, dst, n, cin, cout, h, w, 0, reinterpret_cast<double*>(tl_out), nullptr, nullptr};
   const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
-  return L.launch(conv3x3_wino43_kernel<1, 0, 0, 1>, wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt)), Wino43Cfg::NT, a);
+  const int grid = wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt));
+  switch (variant) {
+    case 1: return L.launch(conv3x3_wino43_kernel<1, 0, 0, 1>, grid, Wino43Cfg::NT, a);
+    case 2: return L.launch(conv3x3_wino43_kernel<1, 0, 0, 2>, grid, Wino43Cfg::NT, a);      // no output stores (WRONG results)
+    case 3: return L.launch(conv3x3_wino43_kernel<1, 0, 0, 3>, grid, Wino43Cfg::NT, a);      // no LDS exchange (WRONG results)
+    case 4: return L.launch(conv3x3_wino43_kernel<1, 0, 0, 4>, grid, Wino43Cfg::NT, a);      // neither
+    default: TNV3_FAIL(-1, "conv3x3_wino43_timeline: variant 1..4");
+  }
 }
 #endif
 
