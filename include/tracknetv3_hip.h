@@ -32,11 +32,13 @@ extern "C" {
 #define TNV3_OK 0
 #define TNV3_E_INVALID (-1)   /* bad argument / unsupported shape */
 #define TNV3_E_LAUNCH (-2)    /* HIP launch error */
-#define TNV3_ABI_VERSION 4   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
+#define TNV3_ABI_VERSION 5   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
                                  3: `variant` argument on the Winograd-form weight gradients;
                                  4: `sum_order` on tnv3_ensemble_frames (the reference's summation order, bit-exact); `variant` on the
                                     9-GEMM decoder kernels; the fused InpaintNet training entries; tnv3_conv3x3_wino_pick / _has_stats /
-                                    _pack_multi; tnv3_conv3x3_wgrad_wino variants 2-7 and any Cin */
+                                    _pack_multi; tnv3_conv3x3_wgrad_wino variants 2-7 and any Cin;
+                                 5: `variant` on the tnv3_conv3x3_wino43_* entries (0: the 16x16x4 one-wave-per-block kernel, 1: the
+                                    32x32x2 kernel); pack-multi layout 4 */
 
 typedef void* tnv3_stream_t;
 
@@ -122,8 +124,8 @@ int tnv3_conv3x3_wino_pack_view(const float* w, float* u, int cout_w, int cin_w,
                                 int layout, tnv3_stream_t stream);
 /* The same for a list of panels in ONE launch (a training step re-packs the forward and data-gradient filters of every layer after
  * each optimiser step): items[k] = the arguments of tnv3_conv3x3_wino_pack_view for panel k; `items` is HOST memory, read before
- * the call returns.  Bit-identical to the one-panel calls.  `layout` 0-2: F(2x2) panels; 3: the F(4x4, 3x3) panel of
- * tnv3_conv3x3_wino43_pack (u then holds tnv3_conv3x3_wino43_packed_floats floats). */
+ * the call returns.  Bit-identical to the one-panel calls.  `layout` 0-2: F(2x2) panels; 4 / 3: the F(4x4, 3x3) panel of
+ * tnv3_conv3x3_wino43_pack with variant 0 / 1 (u then holds tnv3_conv3x3_wino43_packed_floats floats). */
 typedef struct tnv3_wino_pack_item {
   const float* w;   /* nn.Conv2d weight [cout_w][cin_w][3][3] (device) */
   float* u;         /* panel of tnv3_conv3x3_wino_packed_floats(cin, cout) floats (device) */
@@ -136,18 +138,25 @@ int tnv3_conv3x3_wino_pack_multi(const tnv3_wino_pack_item* items, int count, tn
  * rounding (1.0-1.6e-6 of the output scale per layer, F(2x2): 3-8e-7; the whole TrackNet forward's heat maps stay within 1.7e-6 of the
  * fp64 forward).  supported: Cout % 64 == 0, H % 4 == 0, W % 64 == 0.  The panel (its own layout, _packed_floats floats, 16-byte
  * aligned) is packed straight from the nn.Conv2d weight like tnv3_conv3x3_wino_pack_view: an input-channel slice, or transpose_flip
- * for the data gradient's filter.  addend / mean / scale / shift / relu as in tnv3_conv3x3_wino_forward. */
+ * for the data gradient's filter.  addend / mean / scale / shift / relu as in tnv3_conv3x3_wino_forward; mean / scale / shift 16-byte
+ * aligned.  `variant` (pack and run a panel with the SAME one): 0 = kernels/conv3x3_wino43s_mfma.h -- 16x16x4 MFMAs, all 36 transform
+ * coefficients of a (16 channels x 16 tiles) block in one wave, one wave per SIMD, the output transform in registers; 1 = its
+ * predecessor kernels/conv3x3_wino43_mfma.h -- 32x32x2 MFMAs, four waves per block meeting through LDS (kept as the A/B twin).
+ * Same function, not bit-identical to each other. */
 int tnv3_conv3x3_wino43_supported(int cin, int cout, int h, int w);
-size_t tnv3_conv3x3_wino43_packed_floats(int cin, int cout);
-int tnv3_conv3x3_wino43_pack(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip, tnv3_stream_t stream);
+size_t tnv3_conv3x3_wino43_packed_floats(int cin, int cout, int variant);
+int tnv3_conv3x3_wino43_pack(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip, int variant,
+                             tnv3_stream_t stream);
 int tnv3_conv3x3_wino43_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
-                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, tnv3_stream_t stream);
+                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,
+                                tnv3_stream_t stream);
 /* Training forward in that form: dst = conv3x3(src) + addend (raw), and from the same kernel's epilogue tile_stats[cout][tiles][2]
- * (fp64 sum and sum of squares per channel and 8 x 64 pixel tile; tiles = tnv3_conv3x3_wino43_stats_tiles) for
+ * (fp64 sum and sum of squares per channel and pixel tile -- 4 x 64 pixels for variant 0, 8 x 64 for 1; tiles =
+ * tnv3_conv3x3_wino43_stats_tiles) for
  * tnv3_bn_train_forward_tiles -- the F(4x4) twin of tnv3_conv3x3_wino_forward_stats.  Deterministic. */
-long tnv3_conv3x3_wino43_stats_tiles(int n, int h, int w);
+long tnv3_conv3x3_wino43_stats_tiles(int n, int h, int w, int variant);
 int tnv3_conv3x3_wino43_forward_stats(const float* src, const float* u, const float* addend, float* dst, double* tile_stats, int n, int cin,
-                                      int cout, int h, int w, tnv3_stream_t stream);
+                                      int cout, int h, int w, int variant, tnv3_stream_t stream);
 
 int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,

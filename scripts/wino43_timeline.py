@@ -19,13 +19,13 @@ def main():
     for cin, cout, h, w in ((27, 64, 288, 512), (64, 64, 288, 512), (128, 128, 144, 256), (256, 256, 72, 128), (512, 512, 36, 64)):
         x = torch.relu(torch.randn(10, cin, h, w, device=dev))
         wt = (torch.rand(cout, cin, 3, 3, device=dev) - 0.5) * 0.1
-        u = ops.pack_wino43_weights(wt)
+        u = ops.pack_wino43_weights(wt, variant=1)
         y = torch.empty(10, cout, h, w, device=dev)
         tl = torch.zeros(64, dtype=torch.int64, device=dev)
         for _ in range(3):
             diaglib.conv3x3_wino43_timeline(x, u, y, tl)
         torch.cuda.synchronize()
-        ref = ops.conv3x3_wino43(x, u, cout)
+        ref = ops.conv3x3_wino43(x, u, cout, variant=1)
         raw = tl.cpu().reshape(8, 8).double()
         chunks, tiles = raw[:, 5].mean().item(), raw[:, 6].mean().item()
         d = {"tiles_walked": tiles, "chunks_per_tile": chunks / max(tiles, 1), "results_equal_the_product_kernel": bool(torch.equal(y, ref)),

@@ -330,10 +330,20 @@ inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(
 // zeros when the access is out of the descriptor's range (the hardware bounds check the kernels use for zero padding)
 struct tnv3_rsrc_t { const char* base; unsigned num_records; };
 inline tnv3_rsrc_t tnv3_make_rsrc(const void* base, unsigned bytes) { return tnv3_rsrc_t{(const char*)base, bytes}; }
+// The range check of a raw buffer's multi-dword access is PER DWORD (ISA: "Load/store-Dword-x{2,3,4} perform range-check on a per-dword
+// basis"): a piece that straddles the end of the descriptor's range keeps its leading in-range dwords (kernels/conv3x3_wino43s_mfma.h
+// relies on it for the last row of the last channel).  No 32-bit wrap: a voffset that "points before the base" is out of range entirely.
 inline void tnv3_buf_dma16(tnv3_rsrc_t r, float* lds_base, unsigned voffset) {
   const uintptr_t base = emu::wave_read((uintptr_t)lds_base, 0);
   void* dst = (void*)(base + (uintptr_t)emu::lane_id() * 16);
-  emu::vm_dma(dst, (unsigned long long)voffset + 16ull <= (unsigned long long)r.num_records ? r.base + voffset : nullptr, 16);
+  if ((unsigned long long)voffset + 16ull <= (unsigned long long)r.num_records) { emu::vm_dma(dst, r.base + voffset, 16); return; }
+  unsigned char tmp[16];
+  memset(tmp, 0, 16);
+  bool any = false;
+  for (int d = 0; d < 4; ++d)
+    if ((unsigned long long)voffset + 4ull * d + 4ull <= (unsigned long long)r.num_records) { memcpy(tmp + 4 * d, r.base + voffset + 4 * d, 4); any = true; }
+  if (!any) { emu::vm_dma(dst, nullptr, 16); return; }
+  emu::vm_dma(dst, tmp, 16);
 }
 
 // 8-byte buffer load / store through a descriptor: address = base + voffset (per lane) + soffset (scalar); out-of-range loads give 0,

@@ -549,12 +549,21 @@ def test_inpaintnet_fused_kernel_emulated_vs_layer_kernels_and_oracle(emu, monke
     assert (net(x, m) - ref2).abs().max().item() <= 2e-6
 
 
-# ---- Winograd F(4x4, 3x3) form (kernels/conv3x3_wino43_mfma.h): another factorisation -> compared with fp64 torch, not bit-wise
-WINO43_CASES = [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (1, 27, 64, 8, 128), (1, 8, 64, 24, 64), (2, 16, 64, 12, 64), (1, 24, 64, 4, 64)]      # (n, cin, cout, h, w); H % 8 == 4: half-empty last tile row
+# ---- Winograd F(4x4, 3x3) form (kernels/conv3x3_wino43s_mfma.h = variant 0, conv3x3_wino43_mfma.h = variant 1): another factorisation ->
+#      compared with fp64 torch, not bit-wise
+WINO43_CASES = [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (1, 27, 64, 8, 128), (1, 8, 64, 24, 64), (2, 16, 64, 12, 64), (1, 24, 64, 4, 64),
+                (1, 64, 64, 8, 64), (1, 64, 128, 12, 64), (3, 9, 64, 16, 128)]      # (n, cin, cout, h, w); H % 8 == 4: half-empty last tile row; Cin % 64 == 0: + the data gradient
 
 
-def _wino43_case(case, device, tol=2e-5):        # F(4x4, 3x3) in fp32: 4e-6 (K = 27 x 9) .. 9e-6 (K = 256 x 9) of the output scale per layer (F(2x2) and direct: 3-5e-7)
-    from tracknetv3_amd import ops
+def _wino43_case(case, device, tol=2e-5, variant=None):        # F(4x4, 3x3) in fp32: 4e-6 (K = 27 x 9) .. 9e-6 (K = 256 x 9) of the output scale per layer (F(2x2) and direct: 3-5e-7)
+    from tracknetv3_amd import ops, tuning
+    if variant is not None:
+        old = tuning.WINO43_VARIANT
+        tuning.WINO43_VARIANT = variant
+        try:
+            return _wino43_case(case, device, tol)
+        finally:
+            tuning.WINO43_VARIANT = old
     n, cin, cout, h, w = case
     x, wt = torch.relu(T((n, cin, h, w), 491)).to(device), T((cout, cin, 3, 3), 492, -0.3, 0.3).to(device)
     mean, scale, shift = T((cout,), 493).to(device), T((cout,), 494, 0.5, 1.5).to(device), T((cout,), 495).to(device)
@@ -589,18 +598,38 @@ def _wino43_case(case, device, tol=2e-5):        # F(4x4, 3x3) in fp32: 4e-6 (K 
         assert (dx.double().cpu() - xd.grad).abs().max().item() <= tol * max(1.0, (cout / 256.0) ** 0.5) * xd.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", WINO43_CASES)
-def test_conv3x3_wino43_emulated_vs_torch(emu, monkeypatch, case):
+def test_conv3x3_wino43_emulated_vs_torch(emu, monkeypatch, case, variant):
     for cus in ("2", "256"):
         monkeypatch.setenv("TNV3_EMU_CUS", cus)
-        _wino43_case(case, "cpu")
+        _wino43_case(case, "cpu", variant=variant)
 
 
-def _wino43_panel_reference(w, c_from, flip):
+def test_conv3x3_wino43_skip_half_slice_and_its_data_gradient(emu, monkeypatch):
+    """A decoder entry's skip half: the panel of input channels c_from.. (forward) and its transposed, flipped twin (the data gradient
+    towards those channels) through the F(4x4) kernel, both variants."""
+    from tracknetv3_amd import ops
+    monkeypatch.setenv("TNV3_EMU_CUS", "2")
+    n, c_up, c_skip, cout, h, w = 1, 8, 64, 64, 8, 64
+    wt = T((cout, c_up + c_skip, 3, 3), 511, -0.3, 0.3)
+    skip, dz = T((n, c_skip, h, w), 512), T((n, cout, h, w), 513)
+    ref = F.conv2d(skip.double(), wt.double()[:, c_up:], padding=1)
+    xd = skip.double().requires_grad_(True)
+    F.conv2d(xd, wt.double()[:, c_up:], padding=1).backward(dz.double())
+    for variant in (0, 1):
+        got = ops.conv3x3_wino43(skip, ops.pack_wino43_weights(wt, c_from=c_up, variant=variant), cout, variant=variant)
+        assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        dx = ops.conv3x3_wino43(dz, ops.pack_wino43_weights(wt, c_from=c_up, transpose_flip=True, variant=variant), c_skip, variant=variant)
+        assert (dx.double() - xd.grad).abs().max().item() <= 2e-5 * xd.grad.abs().max().item()
+
+
+def _wino43_panel_reference(w, c_from, flip, variant=1):
     """The F(4x4, 3x3) filter panel from its definition (numpy, fp64): U = G g G^T per (output, input) channel with the Toom-Cook G of the
     kernel's interpolation points (0, +-s, +-2s, infinity; s = 3/4) -- row of point p = [1 p p^2] / prod_{q != p} (p - q), times |p| for
     p != 0 (the kernel's A^T has those columns divided by |p|), the row of infinity [0 0 1] -- laid out
-    [co / 32][chunk of 8 ci][xg = 3x3 block of the 6x6 xi][x9][lane = (ci % 2) * 32 + co % 32][ci % 8 / 2], zero for ci >= Cin."""
+    [co / 32][chunk of 8 ci][xg = 3x3 block of the 6x6 xi][x9][lane = (ci % 2) * 32 + co % 32][ci % 8 / 2] (variant 1) or
+    [co / 16][chunk][pair = 3 i + j / 2][lane = (ci % 8 / 2) * 16 + co % 16][(ci % 2) * 2 + j % 2] (variant 0), zero for ci >= Cin."""
     sc = 0.75
     pts = [0.0, sc, -sc, 2 * sc, -2 * sc]
     G = np.array([[1.0, p, p * p] for p in pts] + [[0.0, 0.0, 1.0]])
@@ -610,6 +639,14 @@ def _wino43_panel_reference(w, c_from, flip):
     f = w[:, c_from:, ::-1, ::-1].transpose(1, 0, 2, 3) if flip else w[:, c_from:]      # flip: the data gradient's transposed, reversed filter
     cout, cin = f.shape[:2]
     U = np.einsum("ia,ocab,jb->ocij", G, f, G)
+    if variant == 0:
+        out = np.zeros((cout // 16, (cin + 7) // 8, 18, 64, 4))
+        for ci in range(cin):
+            g, sx = (ci % 8) // 2, ci % 2
+            for i in range(6):
+                for j in range(6):
+                    out[:, ci // 8, 3 * i + j // 2, g * 16:g * 16 + 16, sx * 2 + j % 2] = U[:, ci, i, j].reshape(cout // 16, 16)
+        return out.ravel()
     out = np.zeros((cout // 32, (cin + 7) // 8, 4, 9, 64, 4))
     for ci in range(cin):
         for xg in range(4):
@@ -621,18 +658,19 @@ def _wino43_panel_reference(w, c_from, flip):
 
 @pytest.mark.parametrize("shape,c_from,flip", [((64, 27, 3, 3), 0, False), ((64, 64, 3, 3), 0, True), ((128, 64, 3, 3), 0, False), ((64, 192, 3, 3), 128, False),
                                                ((64, 192, 3, 3), 128, True), ((64, 96, 3, 3), 37, False), ((96, 64, 3, 3), 0, True), ((64, 20, 3, 3), 3, False)])
-def test_wino43_pack_equals_its_definition(emu, shape, c_from, flip):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wino43_pack_equals_its_definition(emu, shape, c_from, flip, variant):
     """tnv3_conv3x3_wino43_pack (one work item per lane quad: 36 float4 stores) against G g G^T in numpy: input-channel slices, partial last
     chunks, the data gradient's transpose + flip, and the zero tail."""
     from tracknetv3_amd import ops
     w = T(shape, 411, -0.5, 0.5)
-    u = ops.pack_wino43_weights(w, c_from=c_from, transpose_flip=flip).double().numpy()
-    ref = _wino43_panel_reference(w, c_from, flip)
+    u = ops.pack_wino43_weights(w, c_from=c_from, transpose_flip=flip, variant=variant).double().numpy()
+    ref = _wino43_panel_reference(w, c_from, flip, variant)
     assert u.size == ref.size + 64 and (u[ref.size:] == 0).all()
     assert np.abs(u[:ref.size] - ref).max() <= 2e-7 * max(1.0, np.abs(ref).max())      # fp32 rounding of G g G^T
 
 
-@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "up2x_wino", "dgrad_up2x_wino"])
+@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "wino43_v1", "up2x_wino", "dgrad_up2x_wino"])
 def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
     """The emulator's LDS-DMA normally lands at issue -- as early as possible.  TNV3_EMU_LAZY_DMA=1 is the other extreme: a piece lands
     only when its work-item's counted s_waitcnt (or the kernel's end) forces it, and __syncthreads() forces nothing (hipcc emits no
@@ -649,9 +687,11 @@ def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
         monkeypatch.setattr(tuning, "WINO_VARIANT", 6)
         e_plain, e_full = _wino_case(2, 12, 128, 8, 64, "cpu")
         assert e_plain <= 3e-6 and e_full <= 6e-6
-    elif what == "wino43":
-        _wino43_case((2, 20, 128, 16, 64), "cpu")
-        _wino43_case((1, 27, 64, 8, 128), "cpu")
+    elif what in ("wino43", "wino43_v1"):
+        v = 1 if what == "wino43_v1" else 0
+        _wino43_case((2, 20, 128, 16, 64), "cpu", variant=v)
+        _wino43_case((1, 27, 64, 8, 128), "cpu", variant=v)
+        _wino43_case((3, 9, 64, 16, 128), "cpu", variant=v)
     elif what == "up2x_wino":
         e_ref, e_old = _up2x_wino_case(2, 20, 128, 4, 64, "cpu")
         assert e_ref <= 3e-6 and e_old <= 4e-6

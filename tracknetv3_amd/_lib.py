@@ -15,7 +15,7 @@ _c = ctypes
 _f32p = _c.c_void_p
 _lib = None
 _is_emulator = False
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Tnv3Error(RuntimeError):
@@ -64,11 +64,11 @@ def _declare(lib):
     sig("tnv3_conv3x3_wino_pack_view", i, p, p, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_pack_multi", i, p, i, p)
     sig("tnv3_conv3x3_wino43_supported", i, i, i, i, i)
-    sig("tnv3_conv3x3_wino43_packed_floats", sz, i, i)
-    sig("tnv3_conv3x3_wino43_pack", i, p, p, i, i, i, i, i, p)
-    sig("tnv3_conv3x3_wino43_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, p)
-    sig("tnv3_conv3x3_wino43_stats_tiles", lg, i, i, i)
-    sig("tnv3_conv3x3_wino43_forward_stats", i, p, p, p, p, p, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino43_packed_floats", sz, i, i, i)
+    sig("tnv3_conv3x3_wino43_pack", i, p, p, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino43_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino43_stats_tiles", lg, i, i, i, i)
+    sig("tnv3_conv3x3_wino43_forward_stats", i, p, p, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_stats_tiles", lg, i, i, i, i)
     sig("tnv3_conv3x3_wino_forward_stats", i, p, p, p, p, p, i, i, i, i, i, i, p)

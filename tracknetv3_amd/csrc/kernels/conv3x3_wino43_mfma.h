@@ -128,20 +128,6 @@ inline __global__ void __launch_bounds__(256) conv3x3_wino43_pack_kernel(const f
                                                                         long s_co, long s_ci, int flip) {
   conv3x3_wino43_pack_elements(w, u, Cout, Cin, s_co, s_ci, flip, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
-// Table-driven pack of panels of BOTH Winograd forms in one launch (layout 0-2: F(2x2) panels, conv3x3_wino_mfma.h; 3: F(4x4) panels)
-inline __global__ void __launch_bounds__(256) conv3x3_wino_pack_multi43_kernel(const WinoPackTable t) {
-  int lo = 0, hi = t.count;                    // first_block[lo] <= blockIdx.x < first_block[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (t.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
-  }
-  const int k = lo;
-  const long nb = t.first_block[k + 1] - t.first_block[k];
-  const long e0 = (long)((int)blockIdx.x - t.first_block[k]) * 256 + threadIdx.x;
-  if (t.layout[k] == 3) conv3x3_wino43_pack_elements(t.w[k], t.u[k], t.cout[k], t.cin[k], t.s_co[k], t.s_ci[k], t.flip[k], e0, nb * 256);
-  else conv3x3_wino_pack_elements(t.w[k], t.u[k], t.cout[k], t.cin[k], t.cpad[k], t.s_co[k], t.s_ci[k], t.flip[k], t.layout[k], e0, nb * 256);
-}
-
 // One 1-D input transform B^T applied to six values, the three outputs of one half: rows 0..2 (RH = 0) or 3..5 (RH = 1).
 //   (B^T above; Lavin's for s = 1: [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1])
 template <int RH>

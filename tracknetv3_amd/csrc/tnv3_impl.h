@@ -13,6 +13,7 @@
 #include "kernels/conv3x3_wino3_mfma.h"
 #include "kernels/conv3x3_wino6_mfma.h"
 #include "kernels/conv3x3_wino43_mfma.h"
+#include "kernels/conv3x3_wino43s_mfma.h"
 #include "kernels/conv1d_k3.h"
 #include "kernels/conv1d_mfma.h"
 #include "kernels/inpaint_fused.h"
@@ -548,10 +549,11 @@ int conv3x3_wino_pack_multi_impl(Launcher& L, const WinoPackItem* items, int cou
     for (int k = 0; k < t.count; ++k) {
       const WinoPackItem& it = items[base + k];
       if (!it.w || !it.u || it.cout_w <= 0 || it.cin_w <= 0 || it.c_from < 0 || it.c_count <= 0 || it.c_from + it.c_count > it.cin_w || it.layout < 0 ||
-          it.layout > 3)
+          it.layout > 4)
         TNV3_FAIL(-1, "conv3x3_wino_pack_multi: bad item %d", base + k);
       const int cout = it.transpose_flip ? it.c_count : it.cout_w, cin = it.transpose_flip ? it.cout_w : it.c_count;
-      if (it.layout >= 2 && cout % 32) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layouts 2 and 3 need Cout %% 32 == 0 (item %d: %d)", base + k, cout);
+      if ((it.layout == 2 || it.layout == 3) && cout % 32) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layouts 2 and 3 need Cout %% 32 == 0 (item %d: %d)", base + k, cout);
+      if (it.layout == 4 && cout % 16) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layout 4 needs Cout %% 16 == 0 (item %d: %d)", base + k, cout);
       const long s_w_co = (long)it.cin_w * 9, s_w_ci = 9;
       t.w[k] = it.w + (size_t)it.c_from * 9;
       t.u[k] = it.u;
@@ -560,9 +562,10 @@ int conv3x3_wino_pack_multi_impl(Launcher& L, const WinoPackItem* items, int cou
       t.s_ci[k] = it.transpose_flip ? s_w_co : s_w_ci;
       t.flip[k] = it.transpose_flip ? 1 : 0;
       t.layout[k] = it.layout;
-      if (it.layout == 3 && (((uintptr_t)it.u) & 15)) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: an F(4x4) panel must be 16-byte aligned (item %d)", base + k);
+      if (it.layout >= 3 && (((uintptr_t)it.u) & 15)) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: an F(4x4) panel must be 16-byte aligned (item %d)", base + k);
       // work items: layout 3 (an F(4x4) panel) one per (32-channel block, chunk, lane) = 36 float4; the F(2x2) layouts one per float
-      const long total = it.layout == 3 ? conv3x3_wino43_pack_items(cout, cin) : (long)t.cpad[k] * 16 * cout + kPackZeroTail;
+      const long total = it.layout == 4 ? conv3x3_wino43s_pack_items(cout, cin)
+                         : it.layout == 3 ? conv3x3_wino43_pack_items(cout, cin) : (long)t.cpad[k] * 16 * cout + kPackZeroTail;
       const long blocks = (total + 255) / 256;
       t.first_block[k + 1] = t.first_block[k] + (int)(blocks > 2048 ? 2048 : blocks);      // four elements per thread at most times 2048 blocks: grid-stride beyond
     }
@@ -582,30 +585,47 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
   return conv3x3_wino_pack_view_impl(L, w, u, cout, cin, 0, cin, 0, layout);
 }
 
-// ---- Winograd F(4x4, 3x3) form (kernels/conv3x3_wino43_mfma.h): 36 products per 4x4 output tile
+// ---- Winograd F(4x4, 3x3) form: 36 products per 4x4 output tile.  `variant` 0 = kernels/conv3x3_wino43s_mfma.h (16x16x4 MFMAs, all 36 xi
+//      of a block in one wave, one wave per SIMD, write-out in registers), 1 = kernels/conv3x3_wino43_mfma.h (32x32x2, four waves per xi block).
+//      The two read different filter panels: pack and run with the same variant.
+constexpr int kWino43Variants = 2;
+constexpr int kWino43SRing = 6;              // quads in variant 0's filter-operand ring (conv3x3_wino43s_kernel<.., AR>)
 inline bool conv3x3_wino43_supported(int cin, int cout, int h, int w) {
   return cin > 0 && cout > 0 && cout % Wino43Cfg::MB == 0 && h % 4 == 0 && w % Wino43Cfg::TW == 0;      // (H % 8 == 4: a half-empty last tile row)
+}
+static_assert(Wino43Cfg::MB == Wino43SCfg::MB && Wino43Cfg::TW == Wino43SCfg::TW && Wino43Cfg::TH == Wino43SCfg::TH, "the two F(4x4) kernels share their shape rules");
+inline size_t conv3x3_wino43_packed_floats_v(int cin, int cout, int variant) {
+  return variant == 0 ? conv3x3_wino43s_packed_floats(cin, cout) : variant == 1 ? conv3x3_wino43_packed_floats(cin, cout) : 0;
 }
 // Panel of input channels c_from .. c_from + c_count - 1 of the nn.Conv2d weight w[cout_w][cin_w][3][3]: the forward filter
 // (Cout = cout_w, Cin = c_count) or, transpose_flip, the data gradient's (Cout = c_count, Cin = cout_w).
 template <class Launcher>
-int conv3x3_wino43_pack_impl(Launcher& L, const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip) {
+int conv3x3_wino43_pack_impl(Launcher& L, const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip, int variant) {
   if (!w || !u || cout_w <= 0 || cin_w <= 0 || c_from < 0 || c_count <= 0 || c_from + c_count > cin_w) TNV3_FAIL(-1, "conv3x3_wino43_pack: bad argument");
+  if (variant < 0 || variant >= kWino43Variants) TNV3_FAIL(-1, "conv3x3_wino43_pack: unknown kernel variant %d", variant);
   const int cout = transpose_flip ? c_count : cout_w, cin = transpose_flip ? cout_w : c_count;
-  if (cout % 32) TNV3_FAIL(-1, "conv3x3_wino43_pack: needs Cout %% 32 == 0 (got %d)", cout);
+  if (cout % (variant == 0 ? 16 : 32)) TNV3_FAIL(-1, "conv3x3_wino43_pack: needs Cout %% %d == 0 (got %d)", variant == 0 ? 16 : 32, cout);
   const long s_w_co = (long)cin_w * 9, s_w_ci = 9;
   if (((uintptr_t)u) & 15) TNV3_FAIL(-1, "conv3x3_wino43_pack: the panel must be 16-byte aligned");
-  const long total = conv3x3_wino43_pack_items(cout, cin);      // one work item per (32-channel block, chunk, lane): 36 float4
-  return L.launch(conv3x3_wino43_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w + (size_t)c_from * 9, u, cout, cin,
-                  transpose_flip ? s_w_ci : s_w_co, transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
+  const long total = variant == 0 ? conv3x3_wino43s_pack_items(cout, cin) : conv3x3_wino43_pack_items(cout, cin);      // one work item per (channel block, chunk, lane)
+  const int grid = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+  if (variant == 0)
+    return L.launch(conv3x3_wino43s_pack_kernel, grid, 256, w + (size_t)c_from * 9, u, cout, cin, transpose_flip ? s_w_ci : s_w_co,
+                    transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
+  return L.launch(conv3x3_wino43_pack_kernel, grid, 256, w + (size_t)c_from * 9, u, cout, cin, transpose_flip ? s_w_ci : s_w_co,
+                  transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
 }
-inline long conv3x3_wino43_stats_tiles(int n, int h, int w) {
-  return (n <= 0 || h % 4 || w % Wino43Cfg::TW) ? 0 : (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
+// statistics tiles: variant 0 one per 4 x 64 pixels (a tile row of the workgroup tile; H % 8 == 4: the last one of an image is empty = zeros),
+// variant 1 one per 8 x 64
+inline long conv3x3_wino43_stats_tiles(int n, int h, int w, int variant) {
+  if (n <= 0 || h % 4 || w % Wino43Cfg::TW || variant < 0 || variant >= kWino43Variants) return 0;
+  return (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW) * (variant == 0 ? 2 : 1);
 }
 template <class Launcher>
 int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, const float* addend, const float* mean, const float* scale,
-                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, double* stats = nullptr) {
+                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant, double* stats = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino43: bad argument");
+  if (variant < 0 || variant >= kWino43Variants) TNV3_FAIL(-1, "conv3x3_wino43: unknown kernel variant %d", variant);
   if (stats && (scale || shift || mean || relu)) TNV3_FAIL(-1, "conv3x3_wino43: the batch-statistics epilogue writes the raw convolution (no affine, no ReLU)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino43: statistics buffer must be 8-byte aligned");
   if (!conv3x3_wino43_supported(cin, cout, h, w))
@@ -613,17 +633,44 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino43: inconsistent affine arguments");
   if ((long)cin * h * w * 4 >= (1l << 31) || (long)Wino43Cfg::MB * h * w * 4 >= (1l << 31))
     TNV3_FAIL(-1, "conv3x3_wino43: one sample of the input / 64 output planes must stay below 2 GiB");
-  if ((((uintptr_t)u | (uintptr_t)src | (uintptr_t)dst | (uintptr_t)addend) & 15) != 0) TNV3_FAIL(-1, "conv3x3_wino43: pointers must be 16-byte aligned");
+  if ((((uintptr_t)u | (uintptr_t)src | (uintptr_t)dst | (uintptr_t)addend | (uintptr_t)mean | (uintptr_t)scale | (uintptr_t)shift) & 15) != 0)
+    TNV3_FAIL(-1, "conv3x3_wino43: pointers must be 16-byte aligned");
+  if (conv3x3_wino43_packed_floats_v(cin, cout, variant) * 4 >= (1ul << 31)) TNV3_FAIL(-1, "conv3x3_wino43: the filter panel must stay below 2 GiB");
   WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, nullptr, nullptr};
   const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino43: too many pixel tiles");
+  const int grid = wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt));
+  if (variant == 0) {
+    if (stats) return L.launch(conv3x3_wino43s_kernel<1, kWino43SRing>, grid, Wino43SCfg::NT, a);
+    return L.launch(conv3x3_wino43s_kernel<0, kWino43SRing>, grid, Wino43SCfg::NT, a);
+  }
   // <1, 0>: next tile's raw fill before the write-out, scalar input transform (the two-wide form <1, 1> measured 1-5 % slower on every
   // shape, profiles/r03_wino43_transform_ab.txt; filling after the write-out <0, 0> 1-1.5 % slower)
-  if (stats) return L.launch(conv3x3_wino43_kernel<1, 0, 1>, wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt)), Wino43Cfg::NT, a);
-  return L.launch(conv3x3_wino43_kernel<1, 0>, wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt)), Wino43Cfg::NT, a);
+  if (stats) return L.launch(conv3x3_wino43_kernel<1, 0, 1>, grid, Wino43Cfg::NT, a);
+  return L.launch(conv3x3_wino43_kernel<1, 0>, grid, Wino43Cfg::NT, a);
 }
 
 #ifdef TNV3_DIAG
+// Timeline / timing twins of the 16x16x4 F(4x4) kernel: the plain forward + [4 waves][8] uint64 of s_memtime totals (prologue, steps,
+// write-outs, steps walked, tiles walked) in tl_out.  ring: 6, 9 or 18 quads in the A ring; mask: conv3x3_wino43s_kernel's DG bits (0 = the
+// product kernel's work, results correct).
+template <class Launcher>
+int conv3x3_wino43s_timeline_impl(Launcher& L, const float* src, const float* u, float* dst, unsigned long long* tl_out, int n, int cin, int cout,
+                                  int h, int w, int ring, int mask) {
+  if (!src || !u || !dst || !tl_out || n <= 0) TNV3_FAIL(-1, "conv3x3_wino43s_timeline: bad argument");
+  if (!conv3x3_wino43_supported(cin, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wino43s_timeline: unsupported shape");
+  if ((long)cin * h * w * 4 >= (1l << 31) || (long)Wino43Cfg::MB * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino43s_timeline: sample too large");
+  WinoArgs a{src, u, u, nullptr, nullptr, nullptr, nullptr, dst, n, cin, cout, h, w, 0, reinterpret_cast<double*>(tl_out), nullptr, nullptr};
+  const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
+  const int grid = wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt));
+#define TNV3_W43S_TWIN(R, M) if (ring == R && mask == M) return L.launch(conv3x3_wino43s_kernel<0, R, 1, M>, grid, Wino43SCfg::NT, a)
+  TNV3_W43S_TWIN(6, 0); TNV3_W43S_TWIN(9, 0); TNV3_W43S_TWIN(18, 0);
+  TNV3_W43S_TWIN(6, 1); TNV3_W43S_TWIN(6, 2); TNV3_W43S_TWIN(6, 3); TNV3_W43S_TWIN(6, 4); TNV3_W43S_TWIN(6, 7); TNV3_W43S_TWIN(6, 15);
+  TNV3_W43S_TWIN(6, 16); TNV3_W43S_TWIN(6, 32); TNV3_W43S_TWIN(18, 3); TNV3_W43S_TWIN(18, 7);
+#undef TNV3_W43S_TWIN
+  TNV3_FAIL(-1, "conv3x3_wino43s_timeline: no twin for ring %d / mask %d", ring, mask);
+}
+
 // Timeline twin of the F(4x4) kernel: the plain forward (results correct) + [8 waves][8] uint64 of s_memtime totals per phase in tl_out
 template <class Launcher>
 int conv3x3_wino43_timeline_impl(Launcher& L, const float* src, const float* u, float* dst, unsigned long long* tl_out, int n, int cin, int cout,

@@ -109,55 +109,65 @@ def wino43_supported(cin, cout, h, w):
     return bool(_lib.load().tnv3_conv3x3_wino43_supported(int(cin), int(cout), int(h), int(w)))
 
 
-def pack_wino43_weights(weight, c_from=0, transpose_flip=False):
+def wino43_variant(variant=None):
+    """Kernel variant of the F(4x4, 3x3) entries (None: tuning.WINO43_VARIANT): 0 = 16x16x4 MFMAs, all 36 transform coefficients of a block in
+    one wave; 1 = the 32x32x2 kernel.  A panel must be packed and run with the same variant."""
+    from . import tuning
+    return int(tuning.WINO43_VARIANT if variant is None else variant)
+
+
+def pack_wino43_weights(weight, c_from=0, transpose_flip=False, variant=None):
     """nn.Conv2d weight (Cout, Cin, 3, 3) -> Winograd F(4x4, 3x3) filter panel of its input channels c_from.. (transpose_flip: the
-    data gradient's filter) for conv3x3_wino43."""
+    data gradient's filter) for conv3x3_wino43 (same variant)."""
     lib = _lib.load()
+    variant = wino43_variant(variant)
     _f32(weight)
     weight = weight.contiguous()
     _lib.dev_check(weight)
     cout_w, cin_w = int(weight.shape[0]), int(weight.shape[1])
     c_count = cin_w - int(c_from)
     cout, cin = (c_count, cout_w) if transpose_flip else (cout_w, c_count)
-    u = torch.empty(lib.tnv3_conv3x3_wino43_packed_floats(cin, cout), dtype=torch.float32, device=weight.device)
+    u = torch.empty(lib.tnv3_conv3x3_wino43_packed_floats(cin, cout, variant), dtype=torch.float32, device=weight.device)
     _lib.check(lib.tnv3_conv3x3_wino43_pack(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count, int(bool(transpose_flip)),
-                                            _lib.stream_ptr(weight)))
+                                            variant, _lib.stream_ptr(weight)))
     return u
 
 
-def conv3x3_wino43(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None):
+def conv3x3_wino43(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None, variant=None):
     """The plain layer in Winograd F(4x4, 3x3) form (tnv3_conv3x3_wino43_forward): act(((conv3x3(src) + addend) - mean) * scale + shift)."""
     lib = _lib.load()
+    variant = wino43_variant(variant)
     _f32(src, u, mean, scale, shift, addend)
     _lib.dev_check(src, u, mean, scale, shift, addend)
     n, cin, h, w = (int(v) for v in src.shape)
-    if u.numel() != lib.tnv3_conv3x3_wino43_packed_floats(cin, int(cout)):
+    if u.numel() != lib.tnv3_conv3x3_wino43_packed_floats(cin, int(cout), variant):
         raise _lib.Tnv3Error("conv3x3_wino43: filter panel does not match the channel counts")
     out = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=src.device)
     if addend is not None and tuple(addend.shape) != tuple(out.shape):
         raise _lib.Tnv3Error("conv3x3_wino43: addend must have the output's shape")
     if n:
         _lib.check(lib.tnv3_conv3x3_wino43_forward(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(shift),
-                                                   _lib.ptr(out), n, cin, int(cout), h, w, int(bool(relu)), _lib.stream_ptr(src)))
+                                                   _lib.ptr(out), n, cin, int(cout), h, w, int(bool(relu)), variant, _lib.stream_ptr(src)))
     return out
 
 
-def conv3x3_wino43_stats(src, u, cout, addend=None):
+def conv3x3_wino43_stats(src, u, cout, addend=None, variant=None):
     """Training-mode forward of a plain layer in F(4x4, 3x3) form: (z, tile_stats) -- the raw convolution (+ addend) and the per-channel /
     per-tile sums and sums of squares BatchNorm needs, from the same kernel's epilogue (tnv3_conv3x3_wino43_forward_stats)."""
     lib = _lib.load()
     _f32(src, u, addend)
     _lib.dev_check(src, u, addend)
     n, cin, h, w = (int(v) for v in src.shape)
-    tiles = int(lib.tnv3_conv3x3_wino43_stats_tiles(n, h, w))
-    if tiles <= 0 or u.numel() != lib.tnv3_conv3x3_wino43_packed_floats(cin, int(cout)):
+    variant = wino43_variant(variant)
+    tiles = int(lib.tnv3_conv3x3_wino43_stats_tiles(n, h, w, variant))
+    if tiles <= 0 or u.numel() != lib.tnv3_conv3x3_wino43_packed_floats(cin, int(cout), variant):
         raise _lib.Tnv3Error("conv3x3_wino43_stats: unsupported shape or filter panel mismatch")
     out = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=src.device)
     stats = torch.empty((int(cout), tiles, 2), dtype=torch.float64, device=src.device)
     if addend is not None and tuple(addend.shape) != tuple(out.shape):
         raise _lib.Tnv3Error("conv3x3_wino43_stats: addend must have the output's shape")
     _lib.check(lib.tnv3_conv3x3_wino43_forward_stats(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(out), _lib.ptr(stats), n, cin,
-                                                     int(cout), h, w, _lib.stream_ptr(src)))
+                                                     int(cout), h, w, variant, _lib.stream_ptr(src)))
     return out, stats
 
 
@@ -188,11 +198,12 @@ def pack_wino_weights_multi(specs, variant=None):
         cout_w, cin_w = int(weight.shape[0]), int(weight.shape[1])
         c_count = cin_w - int(c_from)
         cout, cin = (c_count, cout_w) if flip else (cout_w, c_count)
-        floats = lib.tnv3_conv3x3_wino43_packed_floats(cin, cout) if f43 else lib.tnv3_conv3x3_wino_packed_floats(cin, cout)
+        v43 = wino43_variant(None)
+        floats = lib.tnv3_conv3x3_wino43_packed_floats(cin, cout, v43) if f43 else lib.tnv3_conv3x3_wino_packed_floats(cin, cout)
         u = torch.empty(floats, dtype=torch.float32, device=dev)
         outs.append(u)
         items[k] = _WinoPackItem(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count, int(bool(flip)),
-                                 3 if f43 else wino_layout(variant, cin, cout))
+                                 (4 if v43 == 0 else 3) if f43 else wino_layout(variant, cin, cout))
     _lib.dev_check(keep[0])
     _lib.check(lib.tnv3_conv3x3_wino_pack_multi(ctypes.cast(items, ctypes.c_void_p), len(specs), _lib.stream_ptr(keep[0])))
     return outs

@@ -48,6 +48,10 @@ WINOGRAD_MIN_SKIP = int(os.environ.get("TNV3_WINO_MIN_SKIP", "64"))     # skip h
 # within 1.7e-6 of the fp64 forward, the direct fp32 forward's level: profiles/r03_wino_f43_precision.json).  TNV3_WINO43=0: F(2x2) everywhere.
 WINO43 = os.environ.get("TNV3_WINO43", "1") != "0"
 WINO43_MIN_CIN = int(os.environ.get("TNV3_WINO43_MIN_CIN", "16"))
+# Which F(4x4) kernel: 0 = kernels/conv3x3_wino43s_mfma.h (16x16x4 MFMAs, all 36 transform coefficients of a block in one wave, one wave per
+# SIMD, the output transform in registers), 1 = its predecessor kernels/conv3x3_wino43_mfma.h (32x32x2; four waves per block exchange through
+# LDS).  Read when a panel is packed and when it is run: do not change it between the two.
+WINO43_VARIANT = int(os.environ.get("TNV3_WINO43_VARIANT", "0"))
 
 
 # Training: the plain layers' data gradients (and the skip halves') through the same F(4x4, 3x3) kernel (the data gradient IS a plain
