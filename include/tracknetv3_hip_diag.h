@@ -45,13 +45,14 @@ int tnv3_diag_conv3x3_wino_forward(const float* src, const float* u, float* dst,
 int tnv3_diag_conv3x3_wino43_timeline(const float* src, const float* u, float* dst, unsigned long long* tl_out, int n, int cin, int cout,
                                       int h, int w, int variant, tnv3_stream_t stream);
 
-/* The 16x16x4 F(4x4) kernel (tnv3_conv3x3_wino43_forward variant 0; plain: no addend, no affine) with s_memtime totals of one mid-grid
- * workgroup in tl_out as uint64 [wave 4][8]: 0 prologue, 1 steps, 2 write-outs, 3 steps walked, 4 tiles walked
- * (scripts/wino43s_timeline.py).  ring: quads in the filter-operand ring (6, 9, 18).  mask 0: the product kernel's work (results
- * correct); else timing twins (WRONG results): bit 0 no raw DMA, 1 no patch transform, 2 no A loads, 3 no B reads, 4 no MFMAs, 5 no
- * output stores (only the combinations scripts/wino43s_timeline.py uses are instantiated). */
+/* The 16x16x4 F(4x4) kernel (tnv3_conv3x3_wino43_forward variant 0 / 2; plain: no addend, no affine) with s_memtime totals of one mid-grid
+ * workgroup in tl_out as uint64 [wave 8][8]: 0 prologue, 1 steps, 2 write-outs, 3 steps walked, 4 tiles walked
+ * (scripts/wino43s_timeline.py).  cbw: 4 = 64 channels x 2 tile rows per workgroup, 8 = 128 x 1; grow: filter quads of the next
+ * step requested at the end of a step (5 = a uniform five-pair ring); ts: first slot of the patch transform.  mask 0: the product kernel's work (results correct);
+ * else timing twins (WRONG results): bit 0 no raw DMA, 1 no patch transform, 2 no A loads, 3 no B reads, 4 no MFMAs, 5 no output
+ * stores (only the combinations scripts/wino43s_timeline.py uses are instantiated). */
 int tnv3_diag_conv3x3_wino43s_timeline(const float* src, const float* u, float* dst, unsigned long long* tl_out, int n, int cin, int cout,
-                                       int h, int w, int ring, int mask, tnv3_stream_t stream);
+                                       int h, int w, int cbw, int grow, int ts, int mask, tnv3_stream_t stream);
 
 /* tnv3_conv3x3_wgrad_wino with the timing twins of its third-generation kernel (kernels/wgrad_wino_mfma.h: WgradWino3Cfg<3, DIAG>):
  * variant 101 no operand transforms, 102 no strip DMA, 103 no MFMAs (operand reads kept); 0-3 as in the product library. */

@@ -21,7 +21,7 @@ def load():
                            ("tnv3_diag_conv3x3_forward", [p, p, p, i, i, i, i, i, i, i, p]),
                            ("tnv3_diag_conv3x3_wino_forward", [p, p, p, i, i, i, i, i, i, p]),
                            ("tnv3_diag_conv3x3_wino43_timeline", [p, p, p, p, i, i, i, i, i, i, p]),
-                           ("tnv3_diag_conv3x3_wino43s_timeline", [p, p, p, p, i, i, i, i, i, i, i, p]),
+                           ("tnv3_diag_conv3x3_wino43s_timeline", [p, p, p, p, i, i, i, i, i, i, i, i, i, p]),
                            ("tnv3_diag_conv3x3_wgrad_wino", [p, p, p, p, ctypes.c_size_t, i, i, i, i, i, i, p]),
                            ("tnv3_diag_coissue_probe", [p, p, i, i, i, i, p])):
             fn = getattr(lib, name)
@@ -77,9 +77,9 @@ def conv3x3_wgrad_wino(x, dz, variant):
     return dw
 
 
-def conv3x3_wino43s_timeline(x, u, y, tl, ring=6, mask=0):
-    """The 16x16x4 F(4x4) forward (y correct for mask 0) + phase totals of one mid-grid workgroup in tl (int64 tensor of 32 elements:
-    [wave 4][8] = prologue, steps, write-outs, steps walked, tiles walked); mask: timing twins (wrong results)."""
+def conv3x3_wino43s_timeline(x, u, y, tl, cbw=4, grow=13, ts=12, mask=0):
+    """The 16x16x4 F(4x4) forward (y correct for mask 0) + phase totals of one mid-grid workgroup in tl (int64 tensor of 64 elements:
+    [wave 8][8] = prologue, steps, write-outs, steps walked, tiles walked); mask: timing twins (wrong results)."""
     n, cin, h, w = (int(v) for v in x.shape)
     check(load().tnv3_diag_conv3x3_wino43s_timeline(_lib.ptr(x), _lib.ptr(u), _lib.ptr(y), _lib.ptr(tl), n, cin, int(y.shape[1]), h, w,
-                                                    int(ring), int(mask), _lib.stream_ptr(x)))
+                                                    int(cbw), int(grow), int(ts), int(mask), _lib.stream_ptr(x)))

@@ -9,7 +9,7 @@ from tracknetv3_amd import ops
 
 SHAPES = ((27, 64, 288, 512), (64, 64, 288, 512), (64, 128, 144, 256), (128, 128, 144, 256), (128, 256, 72, 128), (256, 256, 72, 128), (256, 512, 36, 64),
           (512, 512, 36, 64), (512, 256, 72, 128), (256, 128, 144, 256), (128, 64, 288, 512))
-VARIANTS = tuple(int(v) for v in sys.argv[1:]) or (0, 1)
+VARIANTS = tuple(int(v) for v in sys.argv[1:]) or (0, 2, 1)
 
 
 def timeit(fn, reps=10):
@@ -48,8 +48,10 @@ def main():
             for v in VARIANTS:
                 ms = timeit(fns[v])
                 row[f"v{v}"] = {"ms": round(ms, 4), "executed_tflops": round(gf_exec / ms, 1), "of_mfma_peak": round(gf_exec / ms / 157.3, 3)}
-        if 0 in VARIANTS and 1 in VARIANTS:
-            row["speedup_v0_over_v1"] = round(row["v1"]["ms"] / row["v0"]["ms"], 3)
+        if 1 in VARIANTS:
+            for v in VARIANTS:
+                if v != 1:
+                    row[f"speedup_v{v}_over_v1"] = round(row["v1"]["ms"] / row[f"v{v}"]["ms"], 3)
         out[f"{cin}->{cout}@{h}x{w}"] = row
         print(f"{cin}->{cout}@{h}x{w}", json.dumps(row), flush=True)
     od = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

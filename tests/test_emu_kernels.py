@@ -552,7 +552,7 @@ def test_inpaintnet_fused_kernel_emulated_vs_layer_kernels_and_oracle(emu, monke
 # ---- Winograd F(4x4, 3x3) form (kernels/conv3x3_wino43s_mfma.h = variant 0, conv3x3_wino43_mfma.h = variant 1): another factorisation ->
 #      compared with fp64 torch, not bit-wise
 WINO43_CASES = [(1, 16, 64, 8, 64), (2, 20, 128, 16, 64), (1, 27, 64, 8, 128), (1, 8, 64, 24, 64), (2, 16, 64, 12, 64), (1, 24, 64, 4, 64),
-                (1, 64, 64, 8, 64), (1, 64, 128, 12, 64), (3, 9, 64, 16, 128)]      # (n, cin, cout, h, w); H % 8 == 4: half-empty last tile row; Cin % 64 == 0: + the data gradient
+                (1, 64, 64, 8, 64), (1, 64, 128, 12, 64), (3, 9, 64, 16, 128), (3, 17, 128, 12, 128), (2, 8, 256, 8, 64)]      # (n, cin, cout, h, w); H % 8 == 4: half-empty last tile row; Cin % 64 == 0: + the data gradient
 
 
 def _wino43_case(case, device, tol=2e-5, variant=None):        # F(4x4, 3x3) in fp32: 4e-6 (K = 27 x 9) .. 9e-6 (K = 256 x 9) of the output scale per layer (F(2x2) and direct: 3-5e-7)
@@ -598,7 +598,7 @@ def _wino43_case(case, device, tol=2e-5, variant=None):        # F(4x4, 3x3) in 
         assert (dx.double().cpu() - xd.grad).abs().max().item() <= tol * max(1.0, (cout / 256.0) ** 0.5) * xd.grad.abs().max().item()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("case", WINO43_CASES)
 def test_conv3x3_wino43_emulated_vs_torch(emu, monkeypatch, case, variant):
     for cus in ("2", "256"):
@@ -617,7 +617,7 @@ def test_conv3x3_wino43_skip_half_slice_and_its_data_gradient(emu, monkeypatch):
     ref = F.conv2d(skip.double(), wt.double()[:, c_up:], padding=1)
     xd = skip.double().requires_grad_(True)
     F.conv2d(xd, wt.double()[:, c_up:], padding=1).backward(dz.double())
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         got = ops.conv3x3_wino43(skip, ops.pack_wino43_weights(wt, c_from=c_up, variant=variant), cout, variant=variant)
         assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
         dx = ops.conv3x3_wino43(dz, ops.pack_wino43_weights(wt, c_from=c_up, transpose_flip=True, variant=variant), c_skip, variant=variant)
@@ -639,7 +639,7 @@ def _wino43_panel_reference(w, c_from, flip, variant=1):
     f = w[:, c_from:, ::-1, ::-1].transpose(1, 0, 2, 3) if flip else w[:, c_from:]      # flip: the data gradient's transposed, reversed filter
     cout, cin = f.shape[:2]
     U = np.einsum("ia,ocab,jb->ocij", G, f, G)
-    if variant == 0:
+    if variant != 1:
         out = np.zeros((cout // 16, (cin + 7) // 8, 18, 64, 4))
         for ci in range(cin):
             g, sx = (ci % 8) // 2, ci % 2
@@ -658,7 +658,7 @@ def _wino43_panel_reference(w, c_from, flip, variant=1):
 
 @pytest.mark.parametrize("shape,c_from,flip", [((64, 27, 3, 3), 0, False), ((64, 64, 3, 3), 0, True), ((128, 64, 3, 3), 0, False), ((64, 192, 3, 3), 128, False),
                                                ((64, 192, 3, 3), 128, True), ((64, 96, 3, 3), 37, False), ((96, 64, 3, 3), 0, True), ((64, 20, 3, 3), 3, False)])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_wino43_pack_equals_its_definition(emu, shape, c_from, flip, variant):
     """tnv3_conv3x3_wino43_pack (one work item per lane quad: 36 float4 stores) against G g G^T in numpy: input-channel slices, partial last
     chunks, the data gradient's transpose + flip, and the zero tail."""
@@ -670,7 +670,7 @@ def test_wino43_pack_equals_its_definition(emu, shape, c_from, flip, variant):
     assert np.abs(u[:ref.size] - ref).max() <= 2e-7 * max(1.0, np.abs(ref).max())      # fp32 rounding of G g G^T
 
 
-@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "wino43_v1", "up2x_wino", "dgrad_up2x_wino"])
+@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "wino43_v1", "wino43_v2", "up2x_wino", "dgrad_up2x_wino"])
 def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
     """The emulator's LDS-DMA normally lands at issue -- as early as possible.  TNV3_EMU_LAZY_DMA=1 is the other extreme: a piece lands
     only when its work-item's counted s_waitcnt (or the kernel's end) forces it, and __syncthreads() forces nothing (hipcc emits no
@@ -687,8 +687,8 @@ def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
         monkeypatch.setattr(tuning, "WINO_VARIANT", 6)
         e_plain, e_full = _wino_case(2, 12, 128, 8, 64, "cpu")
         assert e_plain <= 3e-6 and e_full <= 6e-6
-    elif what in ("wino43", "wino43_v1"):
-        v = 1 if what == "wino43_v1" else 0
+    elif what in ("wino43", "wino43_v1", "wino43_v2"):
+        v = {"wino43": 0, "wino43_v1": 1, "wino43_v2": 2}[what]
         _wino43_case((2, 20, 128, 16, 64), "cpu", variant=v)
         _wino43_case((1, 27, 64, 8, 128), "cpu", variant=v)
         _wino43_case((3, 9, 64, 16, 128), "cpu", variant=v)

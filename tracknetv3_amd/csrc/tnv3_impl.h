@@ -586,16 +586,18 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
 }
 
 // ---- Winograd F(4x4, 3x3) form: 36 products per 4x4 output tile.  `variant` 0 = kernels/conv3x3_wino43s_mfma.h (16x16x4 MFMAs, all 36 xi
-//      of a block in one wave, one wave per SIMD, write-out in registers), 1 = kernels/conv3x3_wino43_mfma.h (32x32x2, four waves per xi block).
-//      The two read different filter panels: pack and run with the same variant.
-constexpr int kWino43Variants = 2;
-constexpr int kWino43SRing = 6;              // quads in variant 0's filter-operand ring (conv3x3_wino43s_kernel<.., AR>)
+//      of a block in one wave, write-out in registers; the 128-channel workgroup geometry where Cout % 128 == 0, else the 64-channel one),
+//      2 = the same kernel, 64-channel geometry always; 1 = kernels/conv3x3_wino43_mfma.h (32x32x2, four waves per xi block).
+//      Variants 0 and 2 read one panel layout, 1 another: pack and run with the same variant.
+constexpr int kWino43Variants = 3;
+constexpr int kWino43SGrow = 13;             // the 16x16x4 kernel's step schedule (conv3x3_wino43s_kernel<.., GROW, TS>): filter quads of the next step
+constexpr int kWino43STs = 12;               // requested at the end of a step; first slot of the patch transform
 inline bool conv3x3_wino43_supported(int cin, int cout, int h, int w) {
   return cin > 0 && cout > 0 && cout % Wino43Cfg::MB == 0 && h % 4 == 0 && w % Wino43Cfg::TW == 0;      // (H % 8 == 4: a half-empty last tile row)
 }
-static_assert(Wino43Cfg::MB == Wino43SCfg::MB && Wino43Cfg::TW == Wino43SCfg::TW && Wino43Cfg::TH == Wino43SCfg::TH, "the two F(4x4) kernels share their shape rules");
+static_assert(Wino43Cfg::MB == Wino43SCfg<4>::MB && Wino43Cfg::TW == Wino43SCfg<4>::TW && Wino43Cfg::TH == Wino43SCfg<4>::TH, "the F(4x4) kernels share their shape rules");
 inline size_t conv3x3_wino43_packed_floats_v(int cin, int cout, int variant) {
-  return variant == 0 ? conv3x3_wino43s_packed_floats(cin, cout) : variant == 1 ? conv3x3_wino43_packed_floats(cin, cout) : 0;
+  return (variant == 0 || variant == 2) ? conv3x3_wino43s_packed_floats(cin, cout) : variant == 1 ? conv3x3_wino43_packed_floats(cin, cout) : 0;
 }
 // Panel of input channels c_from .. c_from + c_count - 1 of the nn.Conv2d weight w[cout_w][cin_w][3][3]: the forward filter
 // (Cout = cout_w, Cin = c_count) or, transpose_flip, the data gradient's (Cout = c_count, Cin = cout_w).
@@ -603,24 +605,25 @@ template <class Launcher>
 int conv3x3_wino43_pack_impl(Launcher& L, const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip, int variant) {
   if (!w || !u || cout_w <= 0 || cin_w <= 0 || c_from < 0 || c_count <= 0 || c_from + c_count > cin_w) TNV3_FAIL(-1, "conv3x3_wino43_pack: bad argument");
   if (variant < 0 || variant >= kWino43Variants) TNV3_FAIL(-1, "conv3x3_wino43_pack: unknown kernel variant %d", variant);
+  const bool s16 = variant != 1;
   const int cout = transpose_flip ? c_count : cout_w, cin = transpose_flip ? cout_w : c_count;
-  if (cout % (variant == 0 ? 16 : 32)) TNV3_FAIL(-1, "conv3x3_wino43_pack: needs Cout %% %d == 0 (got %d)", variant == 0 ? 16 : 32, cout);
+  if (cout % (s16 ? 16 : 32)) TNV3_FAIL(-1, "conv3x3_wino43_pack: needs Cout %% %d == 0 (got %d)", s16 ? 16 : 32, cout);
   const long s_w_co = (long)cin_w * 9, s_w_ci = 9;
   if (((uintptr_t)u) & 15) TNV3_FAIL(-1, "conv3x3_wino43_pack: the panel must be 16-byte aligned");
-  const long total = variant == 0 ? conv3x3_wino43s_pack_items(cout, cin) : conv3x3_wino43_pack_items(cout, cin);      // one work item per (channel block, chunk, lane)
+  const long total = s16 ? conv3x3_wino43s_pack_items(cout, cin) : conv3x3_wino43_pack_items(cout, cin);      // one work item per (channel block, chunk, lane)
   const int grid = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
-  if (variant == 0)
+  if (s16)
     return L.launch(conv3x3_wino43s_pack_kernel, grid, 256, w + (size_t)c_from * 9, u, cout, cin, transpose_flip ? s_w_ci : s_w_co,
                     transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
   return L.launch(conv3x3_wino43_pack_kernel, grid, 256, w + (size_t)c_from * 9, u, cout, cin, transpose_flip ? s_w_ci : s_w_co,
                   transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
 }
-// statistics tiles: variant 0 one per 4 x 64 pixels (a tile row of the workgroup tile; H % 8 == 4: the last one of an image is empty = zeros),
-// variant 1 one per 8 x 64
+// statistics tiles: variants 0 / 2 one per 4 x 64 pixels, variant 1 one per 8 x 64
 inline long conv3x3_wino43_stats_tiles(int n, int h, int w, int variant) {
   if (n <= 0 || h % 4 || w % Wino43Cfg::TW || variant < 0 || variant >= kWino43Variants) return 0;
-  return (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW) * (variant == 0 ? 2 : 1);
+  return variant == 1 ? (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW) : (long)n * (h / 4) * (w / Wino43Cfg::TW);
 }
+inline bool conv3x3_wino43s_wide(int cout, int variant) { return variant == 0 && cout % 128 == 0; }      // the 128-channel workgroup geometry
 template <class Launcher>
 int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                                 const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant, double* stats = nullptr) {
@@ -637,13 +640,21 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
     TNV3_FAIL(-1, "conv3x3_wino43: pointers must be 16-byte aligned");
   if (conv3x3_wino43_packed_floats_v(cin, cout, variant) * 4 >= (1ul << 31)) TNV3_FAIL(-1, "conv3x3_wino43: the filter panel must stay below 2 GiB");
   WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, nullptr, nullptr};
+  if (variant != 1) {
+    const bool wide = conv3x3_wino43s_wide(cout, variant);
+    const long npt = wide ? (long)n * (h / 4) * (w / 64) : (long)n * ((h + 7) / 8) * (w / 64);
+    if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino43: too many pixel tiles");
+    const int grid = wino_persistent_grid(conv_grid_blocks(cout / (wide ? 128 : 64), (int)npt));
+    if (wide) {
+      if (stats) return L.launch(conv3x3_wino43s_kernel<8, 1, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
+      return L.launch(conv3x3_wino43s_kernel<8, 0, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
+    }
+    if (stats) return L.launch(conv3x3_wino43s_kernel<4, 1, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
+    return L.launch(conv3x3_wino43s_kernel<4, 0, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
+  }
   const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino43: too many pixel tiles");
   const int grid = wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt));
-  if (variant == 0) {
-    if (stats) return L.launch(conv3x3_wino43s_kernel<1, kWino43SRing>, grid, Wino43SCfg::NT, a);
-    return L.launch(conv3x3_wino43s_kernel<0, kWino43SRing>, grid, Wino43SCfg::NT, a);
-  }
   // <1, 0>: next tile's raw fill before the write-out, scalar input transform (the two-wide form <1, 1> measured 1-5 % slower on every
   // shape, profiles/r03_wino43_transform_ab.txt; filling after the write-out <0, 0> 1-1.5 % slower)
   if (stats) return L.launch(conv3x3_wino43_kernel<1, 0, 1>, grid, Wino43Cfg::NT, a);
@@ -651,24 +662,27 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
 }
 
 #ifdef TNV3_DIAG
-// Timeline / timing twins of the 16x16x4 F(4x4) kernel: the plain forward + [4 waves][8] uint64 of s_memtime totals (prologue, steps,
-// write-outs, steps walked, tiles walked) in tl_out.  ring: 6, 9 or 18 quads in the A ring; mask: conv3x3_wino43s_kernel's DG bits (0 = the
-// product kernel's work, results correct).
+// Timeline / timing twins of the 16x16x4 F(4x4) kernel: the plain forward + [8 waves][8] uint64 of s_memtime totals (prologue, steps,
+// write-outs, steps walked, tiles walked) in tl_out.  cbw: 4 / 8 (geometry); grow, ts: the step schedule; mask: conv3x3_wino43s_kernel's
+// DG bits (0 = the product kernel's work, results correct).
 template <class Launcher>
 int conv3x3_wino43s_timeline_impl(Launcher& L, const float* src, const float* u, float* dst, unsigned long long* tl_out, int n, int cin, int cout,
-                                  int h, int w, int ring, int mask) {
+                                  int h, int w, int cbw, int grow, int ts, int mask) {
   if (!src || !u || !dst || !tl_out || n <= 0) TNV3_FAIL(-1, "conv3x3_wino43s_timeline: bad argument");
-  if (!conv3x3_wino43_supported(cin, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wino43s_timeline: unsupported shape");
+  if (!conv3x3_wino43_supported(cin, cout, h, w) || (cbw == 8 && cout % 128)) TNV3_FAIL(-1, "conv3x3_wino43s_timeline: unsupported shape");
   if ((long)cin * h * w * 4 >= (1l << 31) || (long)Wino43Cfg::MB * h * w * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wino43s_timeline: sample too large");
   WinoArgs a{src, u, u, nullptr, nullptr, nullptr, nullptr, dst, n, cin, cout, h, w, 0, reinterpret_cast<double*>(tl_out), nullptr, nullptr};
-  const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
-  const int grid = wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt));
-#define TNV3_W43S_TWIN(R, M) if (ring == R && mask == M) return L.launch(conv3x3_wino43s_kernel<0, R, 1, M>, grid, Wino43SCfg::NT, a)
-  TNV3_W43S_TWIN(6, 0); TNV3_W43S_TWIN(9, 0); TNV3_W43S_TWIN(18, 0);
-  TNV3_W43S_TWIN(6, 1); TNV3_W43S_TWIN(6, 2); TNV3_W43S_TWIN(6, 3); TNV3_W43S_TWIN(6, 4); TNV3_W43S_TWIN(6, 7); TNV3_W43S_TWIN(6, 15);
-  TNV3_W43S_TWIN(6, 16); TNV3_W43S_TWIN(6, 32); TNV3_W43S_TWIN(18, 3); TNV3_W43S_TWIN(18, 7);
+  const bool wide = cbw == 8;
+  const long npt = wide ? (long)n * (h / 4) * (w / 64) : (long)n * ((h + 7) / 8) * (w / 64);
+  const int grid = wino_persistent_grid(conv_grid_blocks(cout / (wide ? 128 : 64), (int)npt));
+#define TNV3_W43S_TWIN(C, G, T, M) if (cbw == C && grow == G && ts == T && mask == M) return L.launch(conv3x3_wino43s_kernel<C, 0, G, T, 1, M>, grid, Wino43SBase::NT, a)
+  TNV3_W43S_TWIN(4, 13, 12, 0); TNV3_W43S_TWIN(4, 5, 3, 0); TNV3_W43S_TWIN(4, 10, 10, 0); TNV3_W43S_TWIN(4, 15, 14, 0); TNV3_W43S_TWIN(4, 13, 6, 0);
+  TNV3_W43S_TWIN(8, 13, 12, 0); TNV3_W43S_TWIN(8, 5, 3, 0); TNV3_W43S_TWIN(8, 15, 14, 0);
+  TNV3_W43S_TWIN(4, 13, 12, 1); TNV3_W43S_TWIN(4, 13, 12, 2); TNV3_W43S_TWIN(4, 13, 12, 3); TNV3_W43S_TWIN(4, 13, 12, 4); TNV3_W43S_TWIN(4, 13, 12, 15);
+  TNV3_W43S_TWIN(4, 13, 12, 16);
+  TNV3_W43S_TWIN(8, 13, 12, 1); TNV3_W43S_TWIN(8, 13, 12, 2); TNV3_W43S_TWIN(8, 13, 12, 3);
 #undef TNV3_W43S_TWIN
-  TNV3_FAIL(-1, "conv3x3_wino43s_timeline: no twin for ring %d / mask %d", ring, mask);
+  TNV3_FAIL(-1, "conv3x3_wino43s_timeline: no twin for geometry %d / grow %d / ts %d / mask %d", cbw, grow, ts, mask);
 }
 
 // Timeline twin of the F(4x4) kernel: the plain forward (results correct) + [8 waves][8] uint64 of s_memtime totals per phase in tl_out

@@ -111,7 +111,8 @@ def wino43_supported(cin, cout, h, w):
 
 def wino43_variant(variant=None):
     """Kernel variant of the F(4x4, 3x3) entries (None: tuning.WINO43_VARIANT): 0 = 16x16x4 MFMAs, all 36 transform coefficients of a block in
-    one wave; 1 = the 32x32x2 kernel.  A panel must be packed and run with the same variant."""
+    one wave (128-channel workgroups where Cout % 128 == 0), 2 = the same with 64-channel workgroups always; 1 = the 32x32x2 kernel.  0 and 2
+    read one panel layout, 1 another: pack and run a panel with the same variant."""
     from . import tuning
     return int(tuning.WINO43_VARIANT if variant is None else variant)
 
@@ -203,7 +204,7 @@ def pack_wino_weights_multi(specs, variant=None):
         u = torch.empty(floats, dtype=torch.float32, device=dev)
         outs.append(u)
         items[k] = _WinoPackItem(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count, int(bool(flip)),
-                                 (4 if v43 == 0 else 3) if f43 else wino_layout(variant, cin, cout))
+                                 (3 if v43 == 1 else 4) if f43 else wino_layout(variant, cin, cout))
     _lib.dev_check(keep[0])
     _lib.check(lib.tnv3_conv3x3_wino_pack_multi(ctypes.cast(items, ctypes.c_void_p), len(specs), _lib.stream_ptr(keep[0])))
     return outs
