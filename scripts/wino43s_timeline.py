@@ -11,8 +11,9 @@ from tracknetv3_amd import ops
 import diaglib
 
 # (geometry cbw, grow, ts, mask)
-TWINS = ((4, 13, 12, 0), (4, 5, 3, 0), (4, 10, 10, 0), (4, 15, 14, 0), (4, 13, 6, 0), (4, 13, 12, 1), (4, 13, 12, 2), (4, 13, 12, 3), (4, 13, 12, 4), (4, 13, 12, 15),
-         (4, 13, 12, 16), (8, 13, 12, 0), (8, 5, 3, 0), (8, 15, 14, 0), (8, 13, 12, 1), (8, 13, 12, 2), (8, 13, 12, 3))
+TWINS = ((4, 10, 10, 0), (4, 5, 3, 0), (4, 13, 12, 0), (4, 8, 8, 0), (4, 12, 4, 0), (4, 10, 10, 1), (4, 10, 10, 2), (4, 10, 10, 3), (4, 10, 10, 4), (4, 10, 10, 15),
+         (4, 10, 10, 16), (8, 10, 10, 0), (8, 5, 4, 0), (8, 13, 12, 0), (8, 10, 28, 0), (8, 16, 40, 0), (8, 10, 10, 1), (8, 10, 10, 2), (8, 10, 10, 3), (8, 10, 10, 4),
+         (8, 10, 10, 15), (8, 10, 10, 16))
 SHAPES = ((27, 64, 288, 512), (64, 64, 288, 512), (128, 128, 144, 256), (256, 256, 72, 128), (512, 512, 36, 64))
 
 

@@ -48,27 +48,33 @@
 namespace tnv3 {
 
 struct Wino43SBase {
-  static constexpr int CC = 8, NT = 512, TW = 64, RQ = 17, PAIRS = 18;
-  static constexpr int A_CHUNK_FLOATS = PAIRS * 64 * 4;   // one (16-channel block, chunk) of the panel
+  static constexpr int NT = 512, TW = 64, RQ = 17, PAIRS = 18;
+  static constexpr int A_CHUNK_FLOATS = PAIRS * 64 * 4;   // one (16-channel block, chunk of 8 input channels) of the panel
   static constexpr int B_RING = 3, B_DIST = 2;
-  static constexpr int NV = 3, NR = 2;
+  static constexpr int NR = 2;
+  static constexpr int CC = 8;                            // the panel's chunk (the kernels' step: CC * KB channels)
 };
 template <int CBW_>
 struct Wino43SCfg : Wino43SBase {
   static_assert(CBW_ == 4 || CBW_ == 8, "16-channel blocks per workgroup");
   static constexpr int CBW = CBW_, TRW = 8 / CBW_;        // tile rows per workgroup
+  static constexpr int KB = CBW_ / 4;                     // 8-channel blocks per step: 1 (64 x 2 rows) / 2 (128 x 1 row: 16 channels per step,
+  static constexpr int SC = 8 * KB;                       // so that every thread still has half a patch to transform in every step)
+  static constexpr int NP = PAIRS * KB;                   // operand pairs (xi pair, 8-channel block) = A quads = B quads per wave and step
+  static constexpr int NV = CBW_ == 4 ? 3 : 2;            // V stages: 3 = the transform runs two steps ahead and the next step's first B quads are
+                                                          // read before the step's barrier; 2 (LDS: 16-channel stages) = one step ahead
   static constexpr int MB = 16 * CBW, TB = 16 * TRW, TH = 4 * TRW;
   static constexpr int RROWS = TH + 2;                    // raw halo tile per channel: rows h0-1 .. h0+TH, 17 pieces from column w0-1
   static constexpr int RPLANE = (RROWS * RQ + 15) / 16 * 16;      // pieces per channel plane: a multiple of 16 pieces, so that the two channels a
                                                                   // 16-lane read group touches fall into disjoint bank ranges
-  static constexpr int RAW_SLOTS = CC * RPLANE;           // pieces per stage: 1408 (2.75 per thread) / 896 (1.75)
+  static constexpr int RAW_SLOTS = SC * RPLANE;           // pieces per stage: 1408 (2.75 per thread) / 1792 (3.5)
   static constexpr int RAW_STAGE = RAW_SLOTS * 4;         // floats
   static constexpr int NDMA = (RAW_SLOTS + NT - 1) / NT;  // DMA instructions per wave and step; the last one: the first DMA_LAST_WAVES waves
   static constexpr int DMA_LAST_WAVES = (RAW_SLOTS - (NDMA - 1) * NT) / 64;
   static_assert((RAW_SLOTS - (NDMA - 1) * NT) % 64 == 0, "the last DMA instruction splits on a wave boundary");
-  static constexpr int V_PAIR = TRW * 256;                // floats per xi pair: [tile row][g 4][tile column 16][4]
-  static constexpr int V_STAGE = PAIRS * V_PAIR;          // 36 KB / 18 KB
-  static constexpr int LDS_FLOATS = NV * V_STAGE + NR * RAW_STAGE;      // 155,648 / 83,968 bytes
+  static constexpr int V_PAIR = TRW * 256;                // floats per operand pair: [tile row][g 4][tile column 16][4]
+  static constexpr int V_STAGE = NP * V_PAIR;             // 36 KB
+  static constexpr int LDS_FLOATS = NV * V_STAGE + NR * RAW_STAGE;      // 155,648 / 131,072 bytes
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
   static_assert(PAIRS % B_RING == 0, "rings are indexed statically");
 };
@@ -161,35 +167,38 @@ __device__ __forceinline__ void wino43s_at6(float m0, float m1, float m2, float 
   o[3] = fmaf(kW43_4S2, q2, fmaf(kW43S2, q1, m5));
 }
 
-// CBW: geometry (above).  GROW, TS: the step's schedule.  A quad (one per xi pair, 18 per step) is named by its pair; the quads of the next
-// step's first GROW pairs are requested in the LAST slots of a step -- when the patch transform (slots TS .. TS + 16) has released its
-// registers -- and the others five pairs ahead of their MFMAs.  Why: vmcnt retires in order, so a filter load issued after the step's raw
-// DMA (slots 0 ..: HBM latency, ~3700 cycles at 288 x 512 under load) cannot be consumed before that DMA has landed; with a uniform
-// five-pair ring the MFMAs of pair 5 waited for it (+2100 cycles per step at 288 x 512, +1450 at 144 x 256, nothing where the input
-// sits in L2: profiles/r04_wino43s_two_waves_twins_before_grow.json).  Now the first load younger than the DMA feeds pair GROW.
+// CBW: geometry (above).  GROW, TS: the step's schedule.  A quad (one per operand pair, NP per step) is named by its pair; the quads of
+// the next step's first GROW pairs are requested in the LAST slots of a step -- when the patch transform (slots TS .. TS + 16) has
+// released its registers -- and the others five pairs ahead of their MFMAs.  Why: vmcnt retires in order, so a filter load issued after
+// the step's raw DMA (slots 0 ..: HBM latency, ~3700 cycles at 288 x 512 under load) cannot be consumed before that DMA has landed; with
+// a uniform five-pair ring the MFMAs of pair 5 waited for it (+2100 cycles per step at 288 x 512, +1450 at 144 x 256, nothing where
+// the input sits in L2: profiles/r04_wino43s_two_waves_twins_before_grow.json).  Now the first load younger than the DMA feeds pair GROW.
 // TL = 1 (libtnv3_diag.so only): s_memtime totals of one mid-grid workgroup, [wave 8][8] uint64 to a.stats: 0 prologue, 1 steps,
 // 2 write-outs, 3 steps walked, 4 tiles walked.  DG (diag only, WRONG results): timing twins -- bit 0 no raw DMA after the prologue,
 // bit 1 no patch transform, bit 2 no A loads (the ring keeps the prologue's quads), bit 3 no B reads, bit 4 no MFMAs, bit 5 no output stores.
-template <int CBW, int STATS = 0, int GROW = 13, int TS = 12, int TL = 0, int DG = 0>
+template <int CBW, int STATS = 0, int GROW = 10, int TS = 10, int TL = 0, int DG = 0>
 __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const WinoArgs a) {
   using Cfg = Wino43SCfg<CBW>;
-  constexpr int CC = Cfg::CC, NT = Cfg::NT, MB = Cfg::MB, V_STAGE = Cfg::V_STAGE, RAW_STAGE = Cfg::RAW_STAGE, V_PAIR = Cfg::V_PAIR;
+  constexpr int SC = Cfg::SC, KB = Cfg::KB, NP = Cfg::NP, NV = Cfg::NV, NSLOT = 2 * NP;
+  constexpr int NT = Cfg::NT, MB = Cfg::MB, V_STAGE = Cfg::V_STAGE, RAW_STAGE = Cfg::RAW_STAGE, V_PAIR = Cfg::V_PAIR;
   constexpr int A_DIST = 5, RQ = Cfg::RQ, T_PIECES = 17, GPS = 3;      // GPS: grow loads per slot
-  constexpr int GS = 36 - (GROW + GPS - 1) / GPS;                     // first slot of the grow phase
-  static_assert(GROW >= A_DIST && GROW <= 16 && TS >= Cfg::NDMA && TS + T_PIECES <= 36, "step schedule");
+  constexpr int GS = NSLOT - (GROW + GPS - 1) / GPS;                  // first slot of the grow phase
+  constexpr int TD = NV - 1;                                          // the transform's lead over the MFMAs, in steps
+  static_assert(GROW >= A_DIST && GROW <= 16 && TS >= Cfg::NDMA && TS + T_PIECES <= NSLOT, "step schedule");
   static_assert((GROW - 1) < (GS >> 1), "a grow load refills the quad of a pair this step has finished");
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   float* v_s = lds;
-  float* raw_s = lds + Cfg::NV * V_STAGE;
+  float* raw_s = lds + NV * V_STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int swave = __builtin_amdgcn_readfirstlane(wave);
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
   const int tilesH = (H + Cfg::TH - 1) / Cfg::TH, tilesW = W / Cfg::TW;
   const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
-  const int nChunks = (Cin + CC - 1) / CC;
+  const int nChunks = (Cin + SC - 1) / SC;               // steps per tile
+  const int nCh8 = (Cin + 7) / 8;                        // the panel's chunks
 
-  // Three cursors walk the same list of (tile, chunk) steps: M (the MFMAs), T (the patch transform: two steps ahead), D (the raw DMA: three
+  // Three cursors walk the same list of (tile, chunk) steps: M (the MFMAs), T (the patch transform: TD steps ahead), D (the raw DMA: TD + 1
   // ahead).  Their tile walks are copies; only the mutable fields cost scalar registers.  (The filter loads run one step ahead of M: the
   // next step's panel slice follows from M's own fields.)
   ConvTileWalk wM, wT, wD;
@@ -214,24 +223,14 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);
   // ---- MFMA role: wave = (16-channel block cb, tile row tr)
   const int cb = swave % CBW, tr = swave / CBW;
-  // ---- transform role: thread = half patch (channel ci = 2 g + s, tile row ttr, tile column tc, row half rh); lane bits (tc & 7, s,
-  //      tc >> 3, g & 1), wave bits (g >> 1, rh, [ttr | group]): the 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...) then hold
-  //      tile columns {0-3, 12-15} of one channel and {4-11} of its neighbour (planes a multiple of 16 pieces apart: 16 different
-  //      16-byte bank groups), and the 16 lanes of a ds_write_b64 group hold 8 tile columns x 2 s = 32 different banks.
-  //      CBW = 8 has half as many half patches as threads: wave group (swave >> 2) transforms the steps of its own parity.
-  const int t_tc = (lane & 7) | ((lane >> 1) & 8), t_s = (lane >> 3) & 1, t_g = ((lane >> 5) & 1) | ((swave & 1) << 1);
-  const int t_rh = (swave >> 1) & 1, t_tr = CBW == 4 ? swave >> 2 : 0, t_grp = swave >> 2;
-  const int t_ci = 2 * t_g + t_s;
-  const int t_src = t_ci * (Cfg::RPLANE * 4) + ((4 * t_tr + t_rh) * RQ + t_tc) * 4;      // + row * 68 floats; second piece + 4
-  const int t_dst = (9 * t_rh) * V_PAIR + t_tr * 256 + t_g * 64 + t_tc * 4 + t_s * 2;     // + pair * V_PAIR
   const int b_lane = tr * 256 + lane * 4;                                                 // + pair * V_PAIR
   const unsigned a_lane_b = (unsigned)lane * 16u;
-  const tnv3_rsrc_t r_panel = tnv3_make_rsrc(a.u, (unsigned)((size_t)(Cout / 16) * nChunks * Cfg::A_CHUNK_FLOATS * 4));
+  const tnv3_rsrc_t r_panel = tnv3_make_rsrc(a.u, (unsigned)((size_t)(Cout / 16) * nCh8 * Cfg::A_CHUNK_FLOATS * 4));
 
   f32x4 acc[36];                                        // [xi = 6 i + j], register r = channel 4 (lane >> 4) + r
-  f32x4 aq[18], bq[Cfg::B_RING];
+  f32x4 aq[NP], bq[Cfg::B_RING];
 
-  // ---- D cursor: per-tile piece offsets.  Slot e = tid + i * 512 -> (channel c, row, piece q) of [CC][RPLANE]; the pad pieces of a
+  // ---- D cursor: per-tile piece offsets.  Slot e = tid + i * 512 -> (channel c, row, piece q) of [SC][RPLANE]; the pad pieces of a
   //      plane, rows outside the image and channels >= Cin read out of the descriptor's range = zeros.
   unsigned voD[Cfg::NDMA];
   tnv3_rsrc_t r_srcD;
@@ -253,65 +252,67 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   };
   auto dma_piece = [&](int i, int stage) {              // piece i of chunk kD of the D tile -> raw stage
     if (i < Cfg::NDMA - 1 || swave < Cfg::DMA_LAST_WAVES)
-      tnv3_buf_dma16(r_srcD, raw_s + stage * RAW_STAGE + (i * NT + wbase) * 4, voD[i] + (unsigned)kD * (unsigned)(CC * 4) * (unsigned)HW);
+      tnv3_buf_dma16(r_srcD, raw_s + stage * RAW_STAGE + (i * NT + wbase) * 4, voD[i] + (unsigned)kD * (unsigned)(SC * 4) * (unsigned)HW);
   };
   auto adv_d = [&]() {
     if (++kD >= nChunks) { kD = 0; wD.next(); set_d(); }
   };
+  auto full_barrier = [&]() {
+    __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
+    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // Everything below is instantiated per wave group (waves 0-3 / 4-7: the two waves of every SIMD) and selected by ONE scalar branch: a
+  // group is one row half RH of the patch transform (its code differs per half), and a branch inside the step loop would put the
+  // accumulators through phi copies.
+  auto body = [&](auto grpc) {
+  constexpr int RH = decltype(grpc)::value;
+  // ---- transform role: thread = half patch (channel ci = 8 kb + 2 g + s, tile row ttr, tile column tc, row half RH); lane bits (tc & 7, s,
+  //      tc >> 3, g & 1), wave bits (g >> 1, ttr | kb, RH): the 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...) then hold
+  //      tile columns {0-3, 12-15} of one channel and {4-11} of its neighbour (planes a multiple of 16 pieces apart: 16 different
+  //      16-byte bank groups), and the 16 lanes of a ds_write_b64 group hold 8 tile columns x 2 s = 32 different banks.
+  const int t_tc = (lane & 7) | ((lane >> 1) & 8), t_s = (lane >> 3) & 1, t_g = ((lane >> 5) & 1) | ((swave & 1) << 1);
+  const int t_x = (swave >> 1) & 1, t_tr = CBW == 4 ? t_x : 0, t_kb = CBW == 4 ? 0 : t_x;
+  const int t_ci = 8 * t_kb + 2 * t_g + t_s;
+  const int t_src = t_ci * (Cfg::RPLANE * 4) + ((4 * t_tr + RH) * RQ + t_tc) * 4;                       // + row * 68 floats; second piece + 4
+  const int t_dst = (t_kb * 18 + 9 * RH) * V_PAIR + t_tr * 256 + t_g * 64 + t_tc * 4 + t_s * 2;         // + pair * V_PAIR
 
   // ---- T cursor: the transform of half a patch, in pieces (the step places one piece behind an MFMA slot)
   float* t_raw = nullptr;      // raw stage + t_src
   float* t_v = nullptr;        // V stage + t_dst
-  bool zl = false, zr = false, fix_corner = false, t_on = true;
-  int t_par = 0;               // parity of the T cursor's step
+  bool zl = false, zr = false, fix_corner = false;
   auto set_t = [&](int raw_stage, int v_stage) {
     t_raw = raw_s + raw_stage * RAW_STAGE + t_src;
     t_v = v_s + v_stage * V_STAGE + t_dst;
     zl = wT.tcol == 0 && t_tc == 0;                      // the column left of the image: zero, but the shifted piece holds the previous row's end
     zr = wT.tcol == tilesW - 1 && t_tc == 15;            // the column right of it
     fix_corner = wT.valid && wT.trow == 0 && wT.tcol == 0 && kT == 0;
-    t_on = CBW == 4 || t_par == t_grp;
   };
   f32x4 tq0[5];
   wf2 tq1[5];
   float tt[3][6];
   auto t_piece = [&](auto pc) {
     constexpr int P = decltype(pc)::value;
-    if (!t_on) {                                         // (wave-uniform) an idle step: what the pieces would define is declared dead, so that
-#ifndef TNV3_EMU                                         // none of it stays live around the step loop (48 registers; no instruction is emitted)
-      if constexpr (P == 0) {
-#pragma unroll
-        for (int r = 0; r < 5; ++r) asm volatile("" : "=v"(tq0[r]));
-      } else if constexpr (P == 5) {
-#pragma unroll
-        for (int r = 0; r < 5; ++r) asm volatile("" : "=v"(tq1[r]));
-      } else if constexpr (P < 8) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) asm volatile("" : "=v"(tt[r][P < 5 ? P - 1 : P - 2]));
-      }
-#endif
-      return;
-    }
-    if constexpr (P == 0) {                              // raw rows rh .. rh + 4 of the patch
+    if constexpr (P == 0) {                              // raw rows RH .. RH + 4 of the patch, columns 0-3
 #pragma unroll
       for (int r = 0; r < 5; ++r) tq0[r] = *reinterpret_cast<const f32x4*>(t_raw + r * (RQ * 4));
       if (fix_corner) {                                  // scalar branch, taken once per image: the piece before the image's first element
-        if (lane == 0 && (swave & 1) == 0 && t_tr == 0) {      // (patch row 1 of channel 0, tile column 0: BOTH row halves read it -- as their row 1 / row 0)
+        if (lane == 0 && (swave & 3) == 0) {             // (patch row 1 of channel 0, tile (0, 0): BOTH row halves read it -- as their row 1 / row 0)
           const tnv3_rsrc_t ri = tnv3_make_rsrc(a.src + (size_t)wT.n * Cin * HW, (unsigned)Cin * (unsigned)HW * 4u);
           const f32x4 x = tnv3_buf_load_f4(ri, 0u, 0u);
-          const f32x4 fx = f32x4{0.0f, x[0], x[1], x[2]};
-          if (t_rh) tq0[0] = fx; else tq0[1] = fx;
+          tq0[1 - RH] = f32x4{0.0f, x[0], x[1], x[2]};
         }
       }
     } else if constexpr (P == 5) {                       // (patch columns 4, 5: read once columns 0-3 have released their registers)
 #pragma unroll
       for (int r = 0; r < 5; ++r) tq1[r] = *reinterpret_cast<const wf2*>(t_raw + r * (RQ * 4) + 4);
-    } else if constexpr (P < 8) {                        // first pass, down patch column c: rows 3 rh .. 3 rh + 2 of B^T d
+    } else if constexpr (P < 8) {                        // first pass, down patch column c: rows 3 RH .. 3 RH + 2 of B^T d
       constexpr int c = P < 5 ? P - 1 : P - 2;
       float x[5], o[3];
 #pragma unroll
       for (int r = 0; r < 5; ++r) x[r] = c < 4 ? tq0[r][c < 4 ? c : 0] : tq1[r][c < 4 ? 0 : c - 4];
-      if (t_rh) {
+      if constexpr (RH == 1) {
         const float d[6] = {0.0f, x[0], x[1], x[2], x[3], x[4]};
         wino43_bt_half<1>(d, o);
       } else {
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         if constexpr (c == 5) v = zr ? 0.0f : v;
         tt[r][c] = v;
       }
-    } else {                                             // second pass along row 3 rh + r, results straight into V: pair 3 (3 rh + r) + j / 2
+    } else {                                             // second pass along row 3 RH + r, results straight into V: pair 3 (3 RH + r) + j / 2
       constexpr int r = (P - 8) / 3, sub = (P - 8) % 3;
       const float(&d)[6] = tt[r];
       float* vd = t_v + (3 * r) * V_PAIR;
@@ -348,28 +349,25 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     }
   };
   auto adv_t = [&]() {
-    t_par ^= 1;
     if (++kT >= nChunks) { kT = 0; wT.next(); }
   };
 
-  // ---- A / B operand streams
-  auto a_soff = [&](int mb, int k) -> unsigned {        // byte offset of this wave's (16-channel block, chunk) in the panel
-    return (unsigned)((mb * CBW + cb) * nChunks + k) * (unsigned)(Cfg::A_CHUNK_FLOATS * 4);
+  // ---- A / B operand streams.  Operand pair q = kb * 18 + p of step k: the panel's chunk k * KB + kb (beyond the last: out of the
+  //      descriptor's range = zeros), xi pair p.
+  auto a_base = [&](int mb, int k) -> unsigned {        // byte offset of this wave's (16-channel block, first chunk of step k) in the panel
+    return (unsigned)((mb * CBW + cb) * nCh8 + k * KB) * (unsigned)(Cfg::A_CHUNK_FLOATS * 4);
   };
-  auto a_soff_next = [&]() -> unsigned {                // ... of the step after M's: the next chunk, or the next tile's first (the walk's channel-block rule)
-    if (kM + 1 < nChunks) return a_soff(wM.mb, kM + 1);
+  // (a chunk beyond the panel's last -- the second half of a 16-channel step when Cin % 16 <= 8 -- must read zeros: through the LANE offset,
+  //  the scalar offset of a buffer access is not range-checked)
+  auto a_lane_of = [&](int k, int q) -> unsigned { return (KB == 1 || q < 18 || k * KB + 1 < nCh8) ? a_lane_b : kDmaOob; };
+  auto next_mb = [&]() -> int {                          // the channel block of the tile after M's (the walk's rule)
     int mb = wM.mb + wM.d_mb;
     if (mb >= nMB) mb -= nMB;
-    return a_soff(mb, 0);
-  };
-  auto full_barrier = [&]() {
-    __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
-    __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
-    __builtin_amdgcn_s_barrier();
+    return mb;
   };
 
-  // ---- prologue: raw(0), raw(1) -> V(0); raw(2); V(1); the operand rings of step 0
-  int sv = 0, sr = 0;                                    // V stage of step sigma = sigma % 3, raw stage of raw(sigma) = sigma & 1
+  // ---- prologue: the first TD + 1 raw tiles, the first TD V stages, the operand quads of step 0
+  int sv = 0, sr = 0;                                    // V stage of step sigma = sigma % NV, raw stage of raw(sigma) = sigma & 1
   set_d();
 #pragma unroll
   for (int i = 0; i < Cfg::NDMA; ++i) dma_piece(i, 0);
@@ -381,66 +379,79 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   set_t(0, 0);
   wino43s_for<0, T_PIECES>(t_piece);
   adv_t();
-  full_barrier();
+  if constexpr (NV == 3) {
+    full_barrier();
 #pragma unroll
-  for (int i = 0; i < Cfg::NDMA; ++i) dma_piece(i, 0);
-  adv_d();
-  set_t(1, 1);
-  wino43s_for<0, T_PIECES>(t_piece);
-  adv_t();
+    for (int i = 0; i < Cfg::NDMA; ++i) dma_piece(i, 0);
+    adv_d();
+    set_t(1, 1);
+    wino43s_for<0, T_PIECES>(t_piece);
+    adv_t();
+  }
   {
-    const unsigned s0 = a_soff(wM.mb, 0);
+    const unsigned s0 = a_base(wM.mb, 0);
 #pragma unroll
-    for (int p = 0; p < GROW; ++p) aq[p] = tnv3_buf_load_f4(r_panel, a_lane_b, s0 + (unsigned)p * 1024u);
+    for (int q = 0; q < GROW; ++q) aq[q] = tnv3_buf_load_f4(r_panel, a_lane_of(0, q), s0 + (unsigned)q * 1024u);
   }
   full_barrier();
+  if constexpr (NV == 3) {
 #pragma unroll
-  for (int p = 0; p < Cfg::B_DIST; ++p) bq[p] = *reinterpret_cast<const f32x4*>(v_s + p * V_PAIR + b_lane);
+    for (int q = 0; q < Cfg::B_DIST; ++q) bq[q] = *reinterpret_cast<const f32x4*>(v_s + q * V_PAIR + b_lane);
+  }
   tl_stamp(0);
-
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
-  // ---- one step: chunk kM of the M tile.  36 slots of two MFMAs (xi pair p, K step s).  Slot 2 p first issues the B read of pair p + 2
-  //      and the A load of pair p + 5 (if that is one of this step's pairs GROW .. 17); slots 0 .. carry the DMA pieces, TS .. the
-  //      transform pieces, GS .. 35 the A loads of the next step's pairs 0 .. GROW - 1.
+  // ---- one step: chunk kM of the M tile.  2 NP slots of two MFMAs (operand pair q, K step s).  Slot 2 q first issues the B read of pair
+  //      q + 2 and the A load of pair q + 5 (if that is one of this step's pairs GROW .. NP - 1); slots 0 .. carry the DMA pieces, TS ..
+  //      the transform pieces, GS .. the A loads of the next step's pairs 0 .. GROW - 1.
   auto step = [&](auto first_c) {
     constexpr bool FIRST = decltype(first_c)::value;
-    const int svn = sv == 2 ? 0 : sv + 1, svt = svn == 2 ? 0 : svn + 1;
+    int svn, svt;
+    if constexpr (NV == 3) { svn = sv == 2 ? 0 : sv + 1; svt = svn == 2 ? 0 : svn + 1; } else { svn = sv ^ 1; svt = svn; }
     const float* bM = v_s + sv * V_STAGE + b_lane;
     const float* bN = v_s + svn * V_STAGE + b_lane;
-    const unsigned soM = a_soff(wM.mb, kM), soA = a_soff_next();      // (past the last step: a slice nobody uses, inside the panel)
-    set_t(sr, svt);
-    const int srd = sr ^ 1;
-    wino43s_for<0, 36>([&](auto ic) {
-      constexpr int IDX = decltype(ic)::value, p = IDX >> 1, s = IDX & 1;
+    const bool last_k = kM + 1 >= nChunks;
+    const unsigned soM = a_base(wM.mb, kM), soA = last_k ? a_base(next_mb(), 0) : a_base(wM.mb, kM + 1);
+    const int kA = last_k ? 0 : kM + 1;                  // (past the last step: a slice nobody uses, inside the panel)
+    const unsigned a_lane_hi = a_lane_of(kM, 18);        // lane offset of this step's second 8-channel block
+    const int srt = (sr + TD) & 1, srd = srt ^ 1;        // raw stages of the transform's / the DMA's step
+    set_t(srt, svt);
+    if constexpr (NV == 2) {                             // (no V stage to spare: this step's first B quads after the barrier that published them)
+#pragma unroll
+      for (int q = 0; q < Cfg::B_DIST; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bM + q * V_PAIR);
+    }
+    wino43s_for<0, NSLOT>([&](auto ic) {
+      constexpr int IDX = decltype(ic)::value, q = IDX >> 1, s = IDX & 1, p = q % 18;
       if constexpr (s == 0) {
-        constexpr int pb = p + Cfg::B_DIST, pa = p + A_DIST;
-        if constexpr ((DG & 8) == 0) bq[pb % Cfg::B_RING] = *reinterpret_cast<const f32x4*>((pb < 18 ? bM : bN) + (pb % 18) * V_PAIR);
-        if constexpr ((DG & 4) == 0 && pa >= GROW && pa < 18) aq[pa] = tnv3_buf_load_f4(r_panel, a_lane_b, soM + (unsigned)pa * 1024u);
+        constexpr int qb = q + Cfg::B_DIST, qa = q + A_DIST;
+        if constexpr ((DG & 8) == 0 && (qb < NP || NV == 3))
+          bq[qb % Cfg::B_RING] = *reinterpret_cast<const f32x4*>((qb < NP ? bM : bN) + (qb % NP) * V_PAIR);
+        if constexpr ((DG & 4) == 0 && qa >= GROW && qa < NP) aq[qa] = tnv3_buf_load_f4(r_panel, qa < 18 ? a_lane_b : a_lane_hi, soM + (unsigned)qa * 1024u);
         __builtin_amdgcn_sched_barrier(0);
       }
-      const f32x4& av = aq[p];
-      const f32x4& bv = bq[p % Cfg::B_RING];
+      const f32x4& av = aq[q];
+      const f32x4& bv = bq[q % Cfg::B_RING];
+      constexpr bool ZERO = FIRST && q < 18 && s == 0;   // a tile's first K step starts the accumulator
       if constexpr ((DG & 16) != 0) {
-        if constexpr (FIRST && s == 0) { acc[2 * p] = f32x4{av[0], bv[0], 0.0f, 0.0f}; acc[2 * p + 1] = f32x4{av[1], bv[1], 0.0f, 0.0f}; }
+        if constexpr (ZERO) { acc[2 * p] = f32x4{av[0], bv[0], 0.0f, 0.0f}; acc[2 * p + 1] = f32x4{av[1], bv[1], 0.0f, 0.0f}; }
       } else {
-        acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * s], bv[2 * s], FIRST && s == 0 ? zero4 : acc[2 * p], 0, 0, 0);
-        acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * s + 1], bv[2 * s + 1], FIRST && s == 0 ? zero4 : acc[2 * p + 1], 0, 0, 0);
+        acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * s], bv[2 * s], ZERO ? zero4 : acc[2 * p], 0, 0, 0);
+        acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * s + 1], bv[2 * s + 1], ZERO ? zero4 : acc[2 * p + 1], 0, 0, 0);
       }
       if constexpr (IDX < Cfg::NDMA) { if constexpr ((DG & 1) == 0) dma_piece(IDX, srd); }
       if constexpr (IDX >= TS && IDX - TS < T_PIECES) { if constexpr ((DG & 2) == 0) t_piece(std::integral_constant<int, IDX - TS>{}); }
       if constexpr (IDX >= GS && (DG & 4) == 0) {
 #pragma unroll
-        for (int j = (IDX - GS) * GPS; j < (IDX - GS + 1) * GPS && j < GROW; ++j) aq[j] = tnv3_buf_load_f4(r_panel, a_lane_b, soA + (unsigned)j * 1024u);
+        for (int j = (IDX - GS) * GPS; j < (IDX - GS + 1) * GPS && j < GROW; ++j) aq[j] = tnv3_buf_load_f4(r_panel, a_lane_of(kA, j), soA + (unsigned)j * 1024u);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    // this wave's raw pieces of step sigma + 3 have landed (they are OLDER than the step's 18 A loads), its V stores are done
-    __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only((DG & 4) ? 0 : 18));
+    // this wave's raw pieces of the DMA's step have landed (they are OLDER than the step's NP A loads), its V stores are done
+    __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only((DG & 4) ? 0 : NP));
     __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    sv = svn; sr = srd;
+    sv = svn; sr ^= 1;
     adv_d();
     adv_t();
     if constexpr (TL != 0) ++tl_steps;
@@ -535,6 +546,8 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     wM.next();
     if (!wM.valid) break;
   }
+  };
+  if (swave >> 2) body(std::integral_constant<int, 1>{}); else body(std::integral_constant<int, 0>{});
   if constexpr (TL != 0) {
     if (blockIdx.x == gridDim.x / 2 && lane == 0) {
       unsigned long long* o = reinterpret_cast<unsigned long long*>(a.stats) + wave * 8;

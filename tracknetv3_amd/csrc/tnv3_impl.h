@@ -590,8 +590,8 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
 //      2 = the same kernel, 64-channel geometry always; 1 = kernels/conv3x3_wino43_mfma.h (32x32x2, four waves per xi block).
 //      Variants 0 and 2 read one panel layout, 1 another: pack and run with the same variant.
 constexpr int kWino43Variants = 3;
-constexpr int kWino43SGrow = 13;             // the 16x16x4 kernel's step schedule (conv3x3_wino43s_kernel<.., GROW, TS>): filter quads of the next step
-constexpr int kWino43STs = 12;               // requested at the end of a step; first slot of the patch transform
+constexpr int kWino43SGrow = 10;             // the 16x16x4 kernel's step schedule (conv3x3_wino43s_kernel<.., GROW, TS>): filter quads of the next step
+constexpr int kWino43STs = 10;               // requested at the end of a step; first slot of the patch transform
 inline bool conv3x3_wino43_supported(int cin, int cout, int h, int w) {
   return cin > 0 && cout > 0 && cout % Wino43Cfg::MB == 0 && h % 4 == 0 && w % Wino43Cfg::TW == 0;      // (H % 8 == 4: a half-empty last tile row)
 }
@@ -676,11 +676,12 @@ int conv3x3_wino43s_timeline_impl(Launcher& L, const float* src, const float* u,
   const long npt = wide ? (long)n * (h / 4) * (w / 64) : (long)n * ((h + 7) / 8) * (w / 64);
   const int grid = wino_persistent_grid(conv_grid_blocks(cout / (wide ? 128 : 64), (int)npt));
 #define TNV3_W43S_TWIN(C, G, T, M) if (cbw == C && grow == G && ts == T && mask == M) return L.launch(conv3x3_wino43s_kernel<C, 0, G, T, 1, M>, grid, Wino43SBase::NT, a)
-  TNV3_W43S_TWIN(4, 13, 12, 0); TNV3_W43S_TWIN(4, 5, 3, 0); TNV3_W43S_TWIN(4, 10, 10, 0); TNV3_W43S_TWIN(4, 15, 14, 0); TNV3_W43S_TWIN(4, 13, 6, 0);
-  TNV3_W43S_TWIN(8, 13, 12, 0); TNV3_W43S_TWIN(8, 5, 3, 0); TNV3_W43S_TWIN(8, 15, 14, 0);
-  TNV3_W43S_TWIN(4, 13, 12, 1); TNV3_W43S_TWIN(4, 13, 12, 2); TNV3_W43S_TWIN(4, 13, 12, 3); TNV3_W43S_TWIN(4, 13, 12, 4); TNV3_W43S_TWIN(4, 13, 12, 15);
-  TNV3_W43S_TWIN(4, 13, 12, 16);
-  TNV3_W43S_TWIN(8, 13, 12, 1); TNV3_W43S_TWIN(8, 13, 12, 2); TNV3_W43S_TWIN(8, 13, 12, 3);
+  TNV3_W43S_TWIN(4, 10, 10, 0); TNV3_W43S_TWIN(4, 5, 3, 0); TNV3_W43S_TWIN(4, 13, 12, 0); TNV3_W43S_TWIN(4, 8, 8, 0); TNV3_W43S_TWIN(4, 12, 4, 0);
+  TNV3_W43S_TWIN(8, 10, 10, 0); TNV3_W43S_TWIN(8, 5, 4, 0); TNV3_W43S_TWIN(8, 13, 12, 0); TNV3_W43S_TWIN(8, 10, 28, 0); TNV3_W43S_TWIN(8, 16, 40, 0);
+  TNV3_W43S_TWIN(4, 10, 10, 1); TNV3_W43S_TWIN(4, 10, 10, 2); TNV3_W43S_TWIN(4, 10, 10, 3); TNV3_W43S_TWIN(4, 10, 10, 4); TNV3_W43S_TWIN(4, 10, 10, 15);
+  TNV3_W43S_TWIN(4, 10, 10, 16);
+  TNV3_W43S_TWIN(8, 10, 10, 1); TNV3_W43S_TWIN(8, 10, 10, 2); TNV3_W43S_TWIN(8, 10, 10, 3); TNV3_W43S_TWIN(8, 10, 10, 4); TNV3_W43S_TWIN(8, 10, 10, 15);
+  TNV3_W43S_TWIN(8, 10, 10, 16);
 #undef TNV3_W43S_TWIN
   TNV3_FAIL(-1, "conv3x3_wino43s_timeline: no twin for geometry %d / grow %d / ts %d / mask %d", cbw, grow, ts, mask);
 }
