@@ -142,13 +142,14 @@ int tnv3_conv3x3_wino_pack_multi(const tnv3_wino_pack_item* items, int count, tn
  * aligned.  `variant` (pack and run a panel with the SAME one): 0 = kernels/conv3x3_wino43s_mfma.h -- 16x16x4 MFMAs, all 36 transform
  * coefficients of a (16 channels x 16 tiles) block in one wave, one wave per SIMD, the output transform in registers; 1 = its
  * predecessor kernels/conv3x3_wino43_mfma.h -- 32x32x2 MFMAs, four waves per block meeting through LDS (kept as the A/B twin).
- * Same function, not bit-identical to each other. */
+ * Same function, not bit-identical to each other.  pool_dst (optional, variants 0 / 2): [n][cout][h/2][w/2] = MaxPool2d(2, 2) of dst
+ * (model.py:59,61,63) from the write-out's registers -- bit-identical to tnv3_maxpool2x2 on dst, without its pass. */
 int tnv3_conv3x3_wino43_supported(int cin, int cout, int h, int w);
 size_t tnv3_conv3x3_wino43_packed_floats(int cin, int cout, int variant);
 int tnv3_conv3x3_wino43_pack(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip, int variant,
                              tnv3_stream_t stream);
 int tnv3_conv3x3_wino43_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
-                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,
+                                const float* shift, float* dst, float* pool_dst, int n, int cin, int cout, int h, int w, int relu, int variant,
                                 tnv3_stream_t stream);
 /* Training forward in that form: dst = conv3x3(src) + addend (raw), and from the same kernel's epilogue tile_stats[cout][tiles][2]
  * (fp64 sum and sum of squares per channel and pixel tile -- 4 x 64 pixels for variant 0, 8 x 64 for 1; tiles =

@@ -579,6 +579,9 @@ def _wino43_case(case, device, tol=2e-5, variant=None):        # F(4x4, 3x3) in 
     got_full = ops.conv3x3_wino43(x, u, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add)
     assert (got_full.double().cpu() - full).abs().max().item() <= tol * max(mag, full.abs().max().item())
     assert torch.equal(got, ops.conv3x3_wino43(x, u, cout))                                   # deterministic
+    # the pooled second output (MaxPool2d(2, 2) from the write-out's registers; variant 1: the separate pass): bit-identical to that pass
+    y2, pooled = ops.conv3x3_wino43(x, u, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, pool=True)
+    assert torch.equal(y2, got_full) and torch.equal(pooled, ops.maxpool2x2(got_full))
     # training forward: raw convolution + addend, and BatchNorm's batch statistics from the same launch's epilogue
     z, st = ops.conv3x3_wino43_stats(x, u, cout, addend=add)
     assert (z.double().cpu() - (ref + add.double().cpu())).abs().max().item() <= tol * max(mag, 1.0)

@@ -135,7 +135,13 @@ def test_conv_and_wgrad_budgets(resources):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
-    for name in ("conv3x3_wino43_kernelILi1ELi0ELi0E", "conv3x3_wino43_kernelILi1ELi0ELi1E"):   # Winograd F(4x4, 3x3), plain / statistics epilogue:
+    # the 16x16x4 F(4x4) kernel (variant 0), both geometries, plain / statistics epilogue: 144 accumulators + named filter quads + the patch
+    # transform in 256 registers, two waves per SIMD, no spill traffic (its steps end in a COUNTED vmcnt)
+    for name in ("conv3x3_wino43s_kernelILi4ELi0E", "conv3x3_wino43s_kernelILi4ELi1E", "conv3x3_wino43s_kernelILi8ELi0E", "conv3x3_wino43s_kernelILi8ELi1E"):
+        k = _find(resources, name)
+        assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+        assert k["LDS Size [bytes/block]"] <= 160 * 1024
+    for name in ("conv3x3_wino43_kernelILi1ELi0ELi0E", "conv3x3_wino43_kernelILi1ELi0ELi1E"):   # its 32x32x2 predecessor (variant 1), plain / statistics epilogue:
         # 144 accumulators, two waves per SIMD; NO spill traffic: its chunk loop waits with a COUNTED vmcnt for its LDS-DMA pieces (nine
         # A loads behind them may stay in flight)
         k = _find(resources, name)

@@ -66,7 +66,7 @@ def _declare(lib):
     sig("tnv3_conv3x3_wino43_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wino43_packed_floats", sz, i, i, i)
     sig("tnv3_conv3x3_wino43_pack", i, p, p, i, i, i, i, i, i, p)
-    sig("tnv3_conv3x3_wino43_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino43_forward", i, p, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino43_stats_tiles", lg, i, i, i, i)
     sig("tnv3_conv3x3_wino43_forward_stats", i, p, p, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)

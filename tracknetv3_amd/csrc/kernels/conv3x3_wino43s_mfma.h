@@ -470,6 +470,10 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
     const tnv3_rsrc_t r_add = tnv3_make_rsrc(has_addend ? a.addend + plane0 : a.dst + plane0, planes_b);
     const unsigned lane_off_b = oh < H ? (unsigned)((4 * g) * HW + oh * W + ow) * 4u : kDmaOob;      // (a tile row below the image: loads give 0, stores are dropped)
+    // MaxPool2d(2, 2) of the block as a second output (the down blocks' last layers): a lane's 4x4 pixels are 2x2 pooled ones
+    const bool has_pool = !STATS && a.pool_dst != nullptr;
+    const tnv3_rsrc_t r_pool = tnv3_make_rsrc(has_pool ? a.pool_dst + plane0 / 4 : a.dst + plane0, planes_b / 4);
+    const unsigned pool_off_b = oh < H ? (unsigned)((4 * g) * (HW >> 2) + (oh >> 1) * (W >> 1) + (ow >> 1)) * 4u : kDmaOob;
     f32x4 mu4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, sc4 = f32x4{1.0f, 1.0f, 1.0f, 1.0f}, sh4 = mu4;
     if (has_affine) {
       sc4 = *reinterpret_cast<const f32x4*>(a.scale + e_m0 + 4 * g);
@@ -492,6 +496,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         wv[0][j] = o[0]; wv[1][j] = o[1]; wv[2][j] = o[2]; wv[3][j] = o[3];
       }
       double s1 = 0.0, s2 = 0.0;
+      f32x4 pv = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int ar = 0; ar < 4; ++ar) {
         float o[4];
@@ -508,6 +513,14 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
           for (int b2 = 0; b2 < 4; ++b2) v[b2] = v[b2] > 0.0f ? v[b2] : 0.0f;
         }
         tnv3_buf_store_f4(r_dst, (DG & 32) ? kDmaOob : lane_off_b, ch_b + (unsigned)(ar * W) * 4u, v);
+        if (has_pool) {                                  // (maxpool2x2_kernel's comparison order and NaN rule: bit-identical to the separate pass)
+          if ((ar & 1) == 0) pv = v;
+          else {
+            auto mx = [](float m, float x) { return (x > m || x != x) ? x : m; };
+            const wf2 o2 = {mx(mx(mx(pv[0], pv[1]), v[0]), v[1]), mx(mx(mx(pv[2], pv[3]), v[2]), v[3])};
+            tnv3_buf_store_f2(r_pool, pool_off_b, ch_b / 4 + (unsigned)((ar >> 1) * (W >> 1)) * 4u, o2);
+          }
+        }
         if constexpr (STATS) {
           s1 += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
           s2 += ((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1]) + ((double)v[2] * (double)v[2] + (double)v[3] * (double)v[3]);

@@ -48,6 +48,8 @@ struct WinoArgs {
   // bn_relu_bwd_partial_kernel would make over dA and z, taken from the epilogue's registers instead.
   const float* bn_z;
   const float* bn_c4;
+  float* pool_dst;      // optional (conv3x3_wino43s_kernel only) [N][Cout][H/2][W/2]: MaxPool2d(2, 2) of the values written to dst (model.py:59,61,63),
+                        // taken from the write-out's registers
 };
 
 template <int WM_, int WN_, int CC_, int DIAG_ = 0>

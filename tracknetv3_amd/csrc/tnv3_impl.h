@@ -626,8 +626,11 @@ inline long conv3x3_wino43_stats_tiles(int n, int h, int w, int variant) {
 inline bool conv3x3_wino43s_wide(int cout, int variant) { return variant == 0 && cout % 128 == 0; }      // the 128-channel workgroup geometry
 template <class Launcher>
 int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, const float* addend, const float* mean, const float* scale,
-                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant, double* stats = nullptr) {
+                                const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant, double* stats = nullptr,
+                                float* pool_dst = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino43: bad argument");
+  if (pool_dst && (variant == 1 || stats)) TNV3_FAIL(-1, "conv3x3_wino43: the pooled second output belongs to kernel variants 0 / 2 without statistics");
+  if (pool_dst && (((uintptr_t)pool_dst) & 7)) TNV3_FAIL(-1, "conv3x3_wino43: the pooled output must be 8-byte aligned");
   if (variant < 0 || variant >= kWino43Variants) TNV3_FAIL(-1, "conv3x3_wino43: unknown kernel variant %d", variant);
   if (stats && (scale || shift || mean || relu)) TNV3_FAIL(-1, "conv3x3_wino43: the batch-statistics epilogue writes the raw convolution (no affine, no ReLU)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino43: statistics buffer must be 8-byte aligned");
@@ -639,7 +642,7 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
   if ((((uintptr_t)u | (uintptr_t)src | (uintptr_t)dst | (uintptr_t)addend | (uintptr_t)mean | (uintptr_t)scale | (uintptr_t)shift) & 15) != 0)
     TNV3_FAIL(-1, "conv3x3_wino43: pointers must be 16-byte aligned");
   if (conv3x3_wino43_packed_floats_v(cin, cout, variant) * 4 >= (1ul << 31)) TNV3_FAIL(-1, "conv3x3_wino43: the filter panel must stay below 2 GiB");
-  WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, nullptr, nullptr};
+  WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, nullptr, nullptr, pool_dst};
   if (variant != 1) {
     const bool wide = conv3x3_wino43s_wide(cout, variant);
     const long npt = wide ? (long)n * (h / 4) * (w / 64) : (long)n * ((h + 7) / 8) * (w / 64);

@@ -228,7 +228,16 @@ class Conv2DBlock(nn.Module):
             self._cache["aff"] = hit
         return hit[1]
 
-    def forward_eval(self, x, skip=None, up=False):
+    def forward_eval(self, x, skip=None, up=False, pool=False):
+        """pool: returns (y, maxpool2x2(y)) -- from the F(4x4) kernel's write-out where that kernel runs the layer, else a separate pass."""
+        if pool:
+            h, w = int(x.shape[2]), int(x.shape[3])
+            if skip is None and not up and tuning.FUSE_POOL and tuning.use_wino43(self.conv.in_dim, self.conv.out_dim, h, w):
+                bn = self.bn
+                return ops.conv3x3_wino43(x, self.packed_wino43(), self.conv.out_dim, mean=bn.running_mean, scale=self.eval_scale(),
+                                          shift=bn.bias.detach(), relu=True, pool=True)
+            y = self.forward_eval(x, skip=skip, up=up)
+            return y, ops.maxpool2x2(y)
         bn = self.bn
         n = x.shape[0]
         if up and skip is not None:
@@ -307,17 +316,18 @@ class TrackNet(nn.Module):
 
     # -- eval: 17 fused conv+BN+ReLU kernels, 3 pools, 1 head; upsample+concat folded into the consumer's loader
     @staticmethod
-    def _chain_eval(blocks, x, skip=None, up=False):
+    def _chain_eval(blocks, x, skip=None, up=False, pool=False):
+        """pool: (y, maxpool2x2(y)) of the chain's last layer."""
         x = blocks[0].forward_eval(x, skip=skip, up=up)
-        for b in blocks[1:]:
+        for b in blocks[1:-1]:
             x = b.forward_eval(x)
-        return x
+        return blocks[-1].forward_eval(x, pool=pool)
 
     def _forward_eval(self, x):
-        x1 = self._chain_eval(self.down_block_1.blocks(), x)
-        x2 = self._chain_eval(self.down_block_2.blocks(), ops.maxpool2x2(x1))
-        x3 = self._chain_eval(self.down_block_3.blocks(), ops.maxpool2x2(x2))
-        x = self._chain_eval(self.bottleneck.blocks(), ops.maxpool2x2(x3))
+        x1, p1 = self._chain_eval(self.down_block_1.blocks(), x, pool=True)
+        x2, p2 = self._chain_eval(self.down_block_2.blocks(), p1, pool=True)
+        x3, p3 = self._chain_eval(self.down_block_3.blocks(), p2, pool=True)
+        x = self._chain_eval(self.bottleneck.blocks(), p3)
         x = self._chain_eval(self.up_block_1.blocks(), x, skip=x3, up=True)
         x = self._chain_eval(self.up_block_2.blocks(), x, skip=x2, up=True)
         x = self._chain_eval(self.up_block_3.blocks(), x, skip=x1, up=True)

@@ -134,8 +134,9 @@ def pack_wino43_weights(weight, c_from=0, transpose_flip=False, variant=None):
     return u
 
 
-def conv3x3_wino43(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None, variant=None):
-    """The plain layer in Winograd F(4x4, 3x3) form (tnv3_conv3x3_wino43_forward): act(((conv3x3(src) + addend) - mean) * scale + shift)."""
+def conv3x3_wino43(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None, variant=None, pool=False):
+    """The plain layer in Winograd F(4x4, 3x3) form (tnv3_conv3x3_wino43_forward): act(((conv3x3(src) + addend) - mean) * scale + shift).
+    pool: returns (out, maxpool2x2(out)) -- the pooled tensor from the kernel's write-out (variants 0 / 2; variant 1: a separate pass)."""
     lib = _lib.load()
     variant = wino43_variant(variant)
     _f32(src, u, mean, scale, shift, addend)
@@ -146,9 +147,13 @@ def conv3x3_wino43(src, u, cout, mean=None, scale=None, shift=None, relu=False, 
     out = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=src.device)
     if addend is not None and tuple(addend.shape) != tuple(out.shape):
         raise _lib.Tnv3Error("conv3x3_wino43: addend must have the output's shape")
+    fused = pool and variant != 1
+    pooled = torch.empty((n, int(cout), h // 2, w // 2), dtype=torch.float32, device=src.device) if fused else None
     if n:
         _lib.check(lib.tnv3_conv3x3_wino43_forward(_lib.ptr(src), _lib.ptr(u), _lib.ptr(addend), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(shift),
-                                                   _lib.ptr(out), n, cin, int(cout), h, w, int(bool(relu)), variant, _lib.stream_ptr(src)))
+                                                   _lib.ptr(out), _lib.ptr(pooled), n, cin, int(cout), h, w, int(bool(relu)), variant, _lib.stream_ptr(src)))
+    if pool:
+        return out, (pooled if fused else maxpool2x2(out))
     return out
 
 

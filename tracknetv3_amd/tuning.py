@@ -52,6 +52,9 @@ WINO43_MIN_CIN = int(os.environ.get("TNV3_WINO43_MIN_CIN", "16"))
 # SIMD, the output transform in registers), 1 = its predecessor kernels/conv3x3_wino43_mfma.h (32x32x2; four waves per block exchange through
 # LDS).  Read when a panel is packed and when it is run: do not change it between the two.
 WINO43_VARIANT = int(os.environ.get("TNV3_WINO43_VARIANT", "0"))
+# MaxPool2d(2, 2) behind the down blocks' last layers as a second output of the F(4x4) kernel's write-out (variants 0 / 2; bit-identical to the
+# separate pass).  TNV3_FUSE_POOL=0: the separate maxpool2x2 launches.
+FUSE_POOL = os.environ.get("TNV3_FUSE_POOL", "1") != "0"
 
 
 # Training: the plain layers' data gradients (and the skip halves') through the same F(4x4, 3x3) kernel (the data gradient IS a plain
