@@ -176,7 +176,8 @@ __device__ __forceinline__ void wino43s_at6(float m0, float m1, float m2, float 
 // TL = 1 (libtnv3_diag.so only): s_memtime totals of one mid-grid workgroup, [wave 8][8] uint64 to a.stats: 0 prologue, 1 steps,
 // 2 write-outs, 3 steps walked, 4 tiles walked.  DG (diag only, WRONG results): timing twins -- bit 0 no raw DMA after the prologue,
 // bit 1 no patch transform, bit 2 no A loads (the ring keeps the prologue's quads), bit 3 no B reads, bit 4 no MFMAs, bit 5 no output stores.
-template <int CBW, int STATS = 0, int GROW = 10, int TS = 10, int TL = 0, int DG = 0>
+// POOL = 1: a.pool_dst receives MaxPool2d(2, 2) of the block.
+template <int CBW, int STATS = 0, int GROW = 10, int TS = 10, int TL = 0, int DG = 0, int POOL = 0>
 __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const WinoArgs a) {
   using Cfg = Wino43SCfg<CBW>;
   constexpr int SC = Cfg::SC, KB = Cfg::KB, NP = Cfg::NP, NV = Cfg::NV, NSLOT = 2 * NP;
@@ -471,18 +472,17 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     const tnv3_rsrc_t r_add = tnv3_make_rsrc(has_addend ? a.addend + plane0 : a.dst + plane0, planes_b);
     const unsigned lane_off_b = oh < H ? (unsigned)((4 * g) * HW + oh * W + ow) * 4u : kDmaOob;      // (a tile row below the image: loads give 0, stores are dropped)
     // MaxPool2d(2, 2) of the block as a second output (the down blocks' last layers): a lane's 4x4 pixels are 2x2 pooled ones
-    const bool has_pool = !STATS && a.pool_dst != nullptr;
+    constexpr bool has_pool = POOL != 0;               // (its own instantiation: the descriptor and the kept row would cost the plain kernel spills)
     const tnv3_rsrc_t r_pool = tnv3_make_rsrc(has_pool ? a.pool_dst + plane0 / 4 : a.dst + plane0, planes_b / 4);
-    const unsigned pool_off_b = oh < H ? (unsigned)((4 * g) * (HW >> 2) + (oh >> 1) * (W >> 1) + (ow >> 1)) * 4u : kDmaOob;
-    f32x4 mu4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, sc4 = f32x4{1.0f, 1.0f, 1.0f, 1.0f}, sh4 = mu4;
-    if (has_affine) {
-      sc4 = *reinterpret_cast<const f32x4*>(a.scale + e_m0 + 4 * g);
-      sh4 = *reinterpret_cast<const f32x4*>(a.shift + e_m0 + 4 * g);
-      if (has_mean) mu4 = *reinterpret_cast<const f32x4*>(a.mean + e_m0 + 4 * g);
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const unsigned ch_b = (unsigned)r * (unsigned)HW * 4u;
+      float mu = 0.0f, sc = 1.0f, sh = 0.0f;            // per channel, requested where they are used (as 16-byte loads ahead of the loop they held 12 registers)
+      if (has_affine) {
+        sc = a.scale[e_m0 + 4 * g + r];
+        sh = a.shift[e_m0 + 4 * g + r];
+        if (has_mean) mu = a.mean[e_m0 + 4 * g + r];
+      }
       f32x4 ad[4];
       if (has_addend) {
 #pragma unroll
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         wv[0][j] = o[0]; wv[1][j] = o[1]; wv[2][j] = o[2]; wv[3][j] = o[3];
       }
       double s1 = 0.0, s2 = 0.0;
-      f32x4 pv = {0.0f, 0.0f, 0.0f, 0.0f};
+      wf2 pv = {0.0f, 0.0f};
 #pragma unroll
       for (int ar = 0; ar < 4; ++ar) {
         float o[4];
@@ -504,7 +504,6 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         f32x4 v = {o[0], o[1], o[2], o[3]};
         if (has_addend) v += ad[ar];
         if (has_affine) {
-          const float mu = mu4[r], sc = sc4[r], sh = sh4[r];
 #pragma unroll
           for (int b2 = 0; b2 < 4; ++b2) v[b2] = (v[b2] - mu) * sc + sh;
         }
@@ -514,11 +513,11 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         }
         tnv3_buf_store_f4(r_dst, (DG & 32) ? kDmaOob : lane_off_b, ch_b + (unsigned)(ar * W) * 4u, v);
         if (has_pool) {                                  // (maxpool2x2_kernel's comparison order and NaN rule: bit-identical to the separate pass)
-          if ((ar & 1) == 0) pv = v;
+          auto mx = [](float m, float x) { return (x > m || x != x) ? x : m; };
+          if ((ar & 1) == 0) pv = wf2{mx(v[0], v[1]), mx(v[2], v[3])};
           else {
-            auto mx = [](float m, float x) { return (x > m || x != x) ? x : m; };
-            const wf2 o2 = {mx(mx(mx(pv[0], pv[1]), v[0]), v[1]), mx(mx(mx(pv[2], pv[3]), v[2]), v[3])};
-            tnv3_buf_store_f2(r_pool, pool_off_b, ch_b / 4 + (unsigned)((ar >> 1) * (W >> 1)) * 4u, o2);
+            const unsigned pool_off_b = oh < H ? (lane_off_b >> 2) + (unsigned)ow : kDmaOob;      // bytes: ((4 g) HW / 4 + (oh / 2) (W / 2) + ow / 2) * 4 = (4 g) HW + oh W + 2 ow
+            tnv3_buf_store_f2(r_pool, pool_off_b, ch_b / 4 + (unsigned)((ar >> 1) * (W >> 1)) * 4u, wf2{mx(mx(pv[0], v[0]), v[1]), mx(mx(pv[1], v[2]), v[3])});
           }
         }
         if constexpr (STATS) {

@@ -590,7 +590,7 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
 //      2 = the same kernel, 64-channel geometry always; 1 = kernels/conv3x3_wino43_mfma.h (32x32x2, four waves per xi block).
 //      Variants 0 and 2 read one panel layout, 1 another: pack and run with the same variant.
 constexpr int kWino43Variants = 3;
-constexpr int kWino43SGrow = 10;             // the 16x16x4 kernel's step schedule (conv3x3_wino43s_kernel<.., GROW, TS>): filter quads of the next step
+constexpr int kWino43SGrow = 9;              // the 16x16x4 kernel's step schedule (conv3x3_wino43s_kernel<.., GROW, TS>): filter quads of the next step
 constexpr int kWino43STs = 10;               // requested at the end of a step; first slot of the patch transform
 inline bool conv3x3_wino43_supported(int cin, int cout, int h, int w) {
   return cin > 0 && cout > 0 && cout % Wino43Cfg::MB == 0 && h % 4 == 0 && w % Wino43Cfg::TW == 0;      // (H % 8 == 4: a half-empty last tile row)
@@ -650,9 +650,11 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
     const int grid = wino_persistent_grid(conv_grid_blocks(cout / (wide ? 128 : 64), (int)npt));
     if (wide) {
       if (stats) return L.launch(conv3x3_wino43s_kernel<8, 1, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
+      if (pool_dst) return L.launch(conv3x3_wino43s_kernel<8, 0, kWino43SGrow, kWino43STs, 0, 0, 1>, grid, Wino43SBase::NT, a);
       return L.launch(conv3x3_wino43s_kernel<8, 0, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
     }
     if (stats) return L.launch(conv3x3_wino43s_kernel<4, 1, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
+    if (pool_dst) return L.launch(conv3x3_wino43s_kernel<4, 0, kWino43SGrow, kWino43STs, 0, 0, 1>, grid, Wino43SBase::NT, a);
     return L.launch(conv3x3_wino43s_kernel<4, 0, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
   }
   const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
