@@ -116,9 +116,12 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
 int tnv3_conv3x3_wino_pick(int cin, int cout); /* the kernel variant that `variant` = -1 means for these channel counts */
-int tnv3_conv3x3_wino_layout(int variant);     /* filter pack layout (0, 1 or 2) the kernel `variant` (>= 0) reads */
-int tnv3_conv3x3_wino_has_stats(int variant);  /* 1 when `variant` (-1 = the default kernel) can emit BatchNorm batch statistics from its
-                                                  epilogue (tnv3_conv3x3_wino_forward_stats), else 0 */
+/* The three helpers below take a RESOLVED variant (>= 0): -1 means different kernels for different channel counts, so resolve it with
+ * tnv3_conv3x3_wino_pick(cin, cout) first -- with -1 they fail (TNV3_E_INVALID / 0 tiles) instead of guessing a kernel the launcher
+ * would not run (a statistics buffer of half the size, a panel in the wrong layout). */
+int tnv3_conv3x3_wino_layout(int variant);     /* filter pack layout (0, 1 or 2) the kernel `variant` reads */
+int tnv3_conv3x3_wino_has_stats(int variant);  /* 1 when `variant` can emit BatchNorm batch statistics from its epilogue
+                                                  (tnv3_conv3x3_wino_forward_stats), else 0 */
 int tnv3_conv3x3_wino_pack(const float* w, float* u, int cout, int cin, int layout, tnv3_stream_t stream);
 int tnv3_conv3x3_wino_pack_view(const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip,
                                 int layout, tnv3_stream_t stream);

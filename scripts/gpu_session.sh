@@ -19,6 +19,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
+export TNV3_REPORT_DIR="$PWD/gpurun_out"      # the parity tests write their measurement reports there
 PARTS="${PARTS:-smoke pytest infer train profinfer proftrain pmc}"
 REPO=$PWD
 OUT=$PWD/gpurun_out

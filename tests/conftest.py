@@ -66,3 +66,22 @@ def gpu_device():
     _lib.load()          # must be the real HIP library; raises loudly otherwise
     assert not _lib.is_emulator()
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=[1, 0], ids=["f43fwd", "f22fwd"])
+def train_fwd(request, monkeypatch):
+    """Both training forwards: the F(4x4) kernel's statistics epilogue (tuning.WINO43_TRAIN, the default) and the F(2x2) kernels'."""
+    from tracknetv3_amd import tuning
+    monkeypatch.setattr(tuning, "WINO43_TRAIN", bool(request.param))
+    return int(request.param)
+
+
+def write_report(name, obj):
+    """Measurement reports of the parity tests: written only when TNV3_REPORT_DIR names a directory (scripts/gpu_session.sh sets it)."""
+    import json
+    out = os.environ.get("TNV3_REPORT_DIR")
+    if not out:
+        return
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, name), "w") as f:
+        json.dump(obj, f, indent=1)

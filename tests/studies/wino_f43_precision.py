@@ -8,7 +8,7 @@ Runs the oracle's TrackNet(27 -> 8).eval() forward at 288 x 512 with every 3x3 c
     the kernel's (0, +-3/4, +-3/2, inf),
 in eval mode (1 x 288 x 512) and in TRAINING mode (2 x 288 x 512: batch-statistics BatchNorm amplifies the rounding), and compares the heat
 maps with the fp64 direct forward.  The parity bar of the path is 1e-4 on the heat maps (the HIP F(2x2) kernels
-measure 1.6-2.5e-5).  usage: python tests/study_wino_f43_precision.py [out.json]   (CPU, ~2 minutes; imports oracle/: test tooling)"""
+measure 1.6-2.5e-5).  usage: python tests/studies/wino_f43_precision.py [out.json]   (CPU, ~2 minutes; imports oracle/: test tooling)"""
 import json
 import os
 import sys
@@ -16,7 +16,7 @@ import sys
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import nets  # noqa: E402
 
 BT = {2: torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64),

@@ -4,7 +4,7 @@
 dW = G^T [ sum over images and tiles of (A dY A^T) * (B^T d B) ] G -- 36 products per 4x4 output tile instead of F(2x2)'s 64 -- evaluated
 in fp32 (transforms and the tile sum; torch's blocked summation, so the absolute figures are optimistic for a sequential MFMA chain, the
 RATIOS between the forms are what counts) against fp64 autograd, on two layer shapes of the network at batch 10, with Lavin's
-interpolation points and with the forward kernel's (0, +-3/4, +-3/2, inf).  usage: python tests/study_wino_f43_wgrad_precision.py [out.json]
+interpolation points and with the forward kernel's (0, +-3/4, +-3/2, inf).  usage: python tests/studies/wino_f43_wgrad_precision.py [out.json]
 (CPU, ~1 minute)"""
 import json
 import sys

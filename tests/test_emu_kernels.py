@@ -701,3 +701,16 @@ def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
     else:
         e_ref, e_old = _dgrad_up2x_wino_case(*DGRAD_UP2X_WINO_CASES[1], "cpu")
         assert e_ref <= 3e-6 and e_old <= 4e-6
+
+
+def test_wino_helpers_refuse_the_unresolved_variant(emu):
+    """tnv3_conv3x3_wino_{stats_tiles, layout, has_stats}(-1) used to fall back to kernel 5 while the launchers resolve -1 through
+    tnv3_conv3x3_wino_pick (kernel 6 for Cout % 128 == 0): a C caller following the header got half the statistics buffer / the wrong panel
+    layout.  The helpers now fail on -1; resolved variants answer as before."""
+    lib = emu.load()
+    assert lib.tnv3_conv3x3_wino_layout(-1) < 0 and b"wino_pick" in lib.tnv3_last_error()
+    assert lib.tnv3_conv3x3_wino_has_stats(-1) < 0
+    assert lib.tnv3_conv3x3_wino_stats_tiles(2, 8, 64, -1) == 0
+    v = lib.tnv3_conv3x3_wino_pick(64, 128)
+    assert v == 6 and lib.tnv3_conv3x3_wino_layout(v) == 2 and lib.tnv3_conv3x3_wino_has_stats(v) == 1
+    assert lib.tnv3_conv3x3_wino_stats_tiles(2, 8, 64, v) == 2 * 2 * 2 and lib.tnv3_conv3x3_wino_stats_tiles(2, 8, 64, 5) == 2 * 2 * 1

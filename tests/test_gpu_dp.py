@@ -57,12 +57,15 @@ def _worker(rank, world, port, out, backend="gloo"):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("f43fwd", ["1", "0"], ids=["f43fwd", "f22fwd"])
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_two_rank_train_step_equals_sequential_shard_oracle(gpu_device, backend):
+def test_two_rank_train_step_equals_sequential_shard_oracle(gpu_device, backend, f43fwd, monkeypatch):
     """gloo: both ranks on cuda:0 (runs on the 1-GPU test box).  nccl: the RCCL path itself -- one GPU per rank, bucketed
-    all-reduce on the side stream, per-bucket timing -- needs two visible GPUs and is skipped otherwise."""
+    all-reduce on the side stream, per-bucket timing -- needs two visible GPUs and is skipped otherwise.  With either training
+    forward (the spawned ranks read TNV3_WINO43_TRAIN)."""
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("the RCCL leg needs two GPUs")
+    monkeypatch.setenv("TNV3_WINO43_TRAIN", f43fwd)
     world, port = 2, _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()

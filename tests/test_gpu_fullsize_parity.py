@@ -35,20 +35,14 @@ def _host_threads():
 
 
 def _report(name, obj):
-    out = os.path.join(ROOT, "gpurun_out")
-    try:
-        os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, name), "w") as f:
-            json.dump(obj, f, indent=1)
-    except OSError:
-        pass
+    from conftest import write_report
+    write_report(name, obj)
 
 
-def test_tracknet_train_step_288x512_27to8_vs_fp64_oracle(gpu_device):
-    """train.py:92-95 (forward in train mode, WBCELoss, backward) at the production shape, batch 2."""
+def _fullsize_train_step(gpu_device, n, tag):
     from tracknetv3_amd.model import TrackNet
     from tracknetv3_amd.utils.metric import WBCELoss
-    in_dim, out_dim, n, h, w, seed = 27, 8, 2, 288, 512, 31
+    in_dim, out_dim, h, w, seed = 27, 8, 288, 512, 31
     sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=True)
     m = TrackNet(in_dim, out_dim)
     m.load_state_dict(sd, strict=True)
@@ -69,6 +63,9 @@ def test_tracknet_train_step_288x512_27to8_vs_fp64_oracle(gpu_device):
     e_loss, e_heat = abs(loss.item() - l64.item()), (p.detach().cpu().double() - p64).abs().max().item()
     assert e_loss <= 2e-5, e_loss
     assert e_heat <= 1e-4, e_heat
+    # per-channel sums of the heat maps (a bias the max norm would not show)
+    ch = (p.detach().cpu().double().sum((0, 2, 3)) - p64.sum((0, 2, 3))).abs() / p64.sum((0, 2, 3)).abs().clamp_min(1e-30)
+    assert ch.max().item() <= 1e-4, ch
     after = m.state_dict()
     for k, v in st64.items():
         if "num_batches" in k:
@@ -80,16 +77,27 @@ def test_tracknet_train_step_288x512_27to8_vs_fp64_oracle(gpu_device):
     params = dict(m.named_parameters())
     mine = np.array([rel_err(params[k].grad.cpu(), g64[k]) for k in names])
     ref = np.array([rel_err(g32[k], g64[k]) for k in names])
-    _report("fullsize_train_parity.json", {"loss_abs_err": e_loss, "heatmap_max_abs_err": e_heat,
-                                           "oracle_fp32_heatmap_err": (p32.double() - p64).abs().max().item(),
-                                           "grad_rel_err": {k: [float(a), float(b)] for k, a, b in zip(names, mine, ref)},
-                                           "worst": [names[int(mine.argmax())], float(mine.max()), float(ref.max())],
-                                           "median": [float(np.median(mine)), float(np.median(ref))]})
+    _report(f"fullsize_train_parity_{tag}.json", {"batch": n, "loss_abs_err": e_loss, "heatmap_max_abs_err": e_heat,
+                                                  "heatmap_channel_sum_rel_err": float(ch.max().item()),
+                                                  "oracle_fp32_heatmap_err": (p32.double() - p64).abs().max().item(),
+                                                  "grad_rel_err": {k: [float(a), float(b)] for k, a, b in zip(names, mine, ref)},
+                                                  "worst": [names[int(mine.argmax())], float(mine.max()), float(ref.max())],
+                                                  "median": [float(np.median(mine)), float(np.median(ref))]})
     # every parameter: within 3x the torch-fp32 oracle's own deviation from fp64 (taken over all parameters) + 2e-4
     assert mine.max() <= 3 * ref.max() + 2e-4, (names[int(mine.argmax())], mine.max(), ref.max())
     assert np.median(mine) <= 3 * np.median(ref) + 1e-4, (np.median(mine), np.median(ref))
     for k, a, b in zip(names, mine, ref):              # and no single tensor far outside its own fp32 noise
         assert a <= 10 * b + 5e-4, (k, a, b)
+
+
+def test_tracknet_train_step_288x512_27to8_vs_fp64_oracle(gpu_device, train_fwd):
+    """train.py:92-95 (forward in train mode, WBCELoss, backward) at the production shape, batch 2, with either training forward."""
+    _fullsize_train_step(gpu_device, 2, "n2_f43fwd" if train_fwd else "n2_f22fwd")
+
+
+def test_tracknet_train_step_288x512_batch10_vs_fp64_oracle(gpu_device):
+    """The same at BASELINE configs[2]'s per-GPU batch of 10 (default settings): the fp64 and fp32 oracles on the host cores take ~2 minutes."""
+    _fullsize_train_step(gpu_device, 10, "n10_default")
 
 
 @pytest.mark.parametrize("case", [(2, 64, 0, 64, 288, 512), (1, 128, 64, 64, 288, 512)], ids=["64to64", "dual192to64"])

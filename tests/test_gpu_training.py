@@ -146,7 +146,7 @@ def test_wbce_head_pool_upsample_mixup(gpu_device):
 
 
 @pytest.mark.parametrize("name", ["tracknet_9_3_32x64.npz", "tracknet_27_8_32x64_cal.npz"])
-def test_tracknet_train_step_vs_reference_golden(gpu_device, name):
+def test_tracknet_train_step_vs_reference_golden(gpu_device, name, train_fwd):
     """forward(train) + WBCELoss + backward: loss / heat maps / BN buffers vs the reference golden, gradients vs the
     fp64 oracle with a tolerance tied to the fp32 reference's own deviation from fp64."""
     from tracknetv3_amd.model import TrackNet
@@ -185,7 +185,7 @@ def test_tracknet_train_step_vs_reference_golden(gpu_device, name):
         assert abs(params[name_].grad.double().abs().max().item() - st[2]) <= 0.1 * st[2] + 1e-12
 
 
-def test_train_then_eval_and_optimizer_step(gpu_device):
+def test_train_then_eval_and_optimizer_step(gpu_device, train_fwd):
     """Adam on the module's leaf parameters (train.py:85-96 protocol) changes the loss the right way and the eval path
     picks up the new weights / running stats (cache invalidation)."""
     from tracknetv3_amd.utils.general import get_model
@@ -317,7 +317,7 @@ def test_tracknet_trainer_single_rank(gpu_device):
     assert int(net.down_block_1.conv_1.bn.num_batches_tracked) == 5
 
 
-def test_baseline_config1_train_forward_wbce_288x512(gpu_device):
+def test_baseline_config1_train_forward_wbce_288x512(gpu_device, train_fwd):
     """BASELINE configs[0]: TrackNet seq_len=3 bg_mode='' batch 2, 288x512, train-mode forward + WBCE (the reference's
     CPU-runnable plumbing case) -- GPU path vs the oracle evaluated here on the host CPU, plus backward sanity."""
     from tracknetv3_amd.utils.general import get_model
@@ -514,35 +514,3 @@ def test_bn_backward_sums_from_the_data_gradient_epilogue(gpu_device, case):
     """The data-gradient launch that also takes BatchNorm + ReLU backward's two sums (kernels 5 and 6) at small and network shapes."""
     from test_emu_training import _bn_bwd_epilogue_case
     _bn_bwd_epilogue_case(case, gpu_device)
-
-
-def test_train_step_with_the_optin_f43_forward(gpu_device, monkeypatch):
-    """TNV3_WINO43_TRAIN=1 (the training forward through the F(4x4) kernel's statistics epilogue; default off, tuning.py): loss, heat maps
-    and BatchNorm buffers inside the default path's bounds on the calibrated 32x64 golden, gradients inside a WIDER bound than the
-    default path's -- 6x torch-fp32's own median distance from fp64 instead of 3x (measured: 4x; the default path: 1x)."""
-    from tracknetv3_amd import tuning
-    from tracknetv3_amd.model import TrackNet
-    from tracknetv3_amd.utils.metric import WBCELoss
-    monkeypatch.setattr(tuning, "WINO43_TRAIN", True)
-    g = np.load(os.path.join(GOLDEN, "tracknet_27_8_32x64_cal.npz"))
-    in_dim, out_dim, n, h, w, seed, cal = (int(v) for v in g["meta"])
-    assert tuning.use_wino43_train(64, 64, h, w)
-    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=bool(cal))
-    m = TrackNet(in_dim, out_dim)
-    m.load_state_dict(sd, strict=True)
-    m = m.to(gpu_device).train()
-    x = nets.synth_input((n, in_dim, h, w), seed + 1000)
-    y = nets.disc_heatmaps(n, out_dim, h, w, seed + 2000)
-    p = m(x.to(gpu_device))
-    loss = WBCELoss(p, y.to(gpu_device))
-    loss.backward()
-    assert abs(loss.item() - float(g["train_loss"])) <= 2e-5
-    assert np.abs(p.detach().cpu().numpy() - g["train_out"]).max() <= 1e-4
-    _, _, g64, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float64)
-    _, _, g32, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float32)
-    names = [str(s) for s in g["grad_names"]]
-    params = dict(m.named_parameters())
-    mine = np.array([rel_err(params[k].grad.cpu(), g64[k]) for k in names])
-    ref = np.array([rel_err(g32[k], g64[k]) for k in names])
-    assert np.median(mine) <= 6 * np.median(ref) + 1e-4, (np.median(mine), np.median(ref))
-    assert mine.max() <= 6 * max(ref.max(), float(g["grad_ref32_vs_64_worst"])) + 2e-4

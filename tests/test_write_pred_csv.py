@@ -58,3 +58,10 @@ def test_write_pred_csv_ragged_columns_raise_like_pandas(tmp_path):
         write_pred_csv(d, str(tmp_path / "x.csv"))
     with pytest.raises(ValueError, match="same length"):
         pd.DataFrame(d)
+
+
+def test_a_column_mixing_bools_and_ints_prints_like_pandas_object_column(tmp_path):
+    """bool is an int, so [1, True] matched neither the all-bool nor the all-int rule and was printed as floats; pandas keeps
+    an object column and prints str() per element."""
+    d = {'Frame': [0, 1, 2], 'Visibility': [1, True, 0], 'X': [5, 6, 7], 'Y': [False, 3, True]}
+    assert _mine(d, tmp_path / "a.csv", False) == _ref_bytes(d, tmp_path / "b.csv", False)

@@ -100,11 +100,11 @@ class Conv2DBlock(nn.Module):
 
     def packed_wino43(self, c_from=0):
         """Winograd F(4x4, 3x3) filter panel of input channels c_from.. (ops.conv3x3_wino43)."""
-        key = ("w43", int(c_from))
+        key = ("w43", int(c_from), ops.wino43_variant(None))       # (the panel layout follows the kernel variant)
         ver = self._versions(["conv"])
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, ops.pack_wino43_weights(self.conv.weight.detach(), c_from=c_from))
+            hit = (ver, ops.pack_wino43_weights(self.conv.weight.detach(), c_from=c_from, variant=key[2]))
             self._cache[key] = hit
             self._wino_plan.add((key, int(c_from), False))
         self._wino_used.add((key, int(c_from), False))
@@ -112,11 +112,11 @@ class Conv2DBlock(nn.Module):
 
     def packed_wino43_t(self, c_from=0):
         """F(4x4, 3x3) panel of the data gradient's filter w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw]."""
-        key = ("w43t", int(c_from))
+        key = ("w43t", int(c_from), ops.wino43_variant(None))
         ver = self._versions(["conv"])
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, ops.pack_wino43_weights(self.conv.weight.detach(), c_from=c_from, transpose_flip=True))
+            hit = (ver, ops.pack_wino43_weights(self.conv.weight.detach(), c_from=c_from, transpose_flip=True, variant=key[2]))
             self._cache[key] = hit
             self._wino_plan.add((key, int(c_from), True))
         self._wino_used.add((key, int(c_from), True))
@@ -353,7 +353,9 @@ class TrackNet(nn.Module):
         if len(todo) < 2:
             return 0
         with torch.no_grad():
-            panels = ops.pack_wino_weights_multi([(m.conv.weight.detach(), c_from, flip, 43 if key[0] in ("w43", "w43t") else 22)
+            # (the layout a panel is rebuilt in is the one its cache key recorded, not what the tuning switches say now)
+            panels = ops.pack_wino_weights_multi([(m.conv.weight.detach(), c_from, flip, 43 if key[0] in ("w43", "w43t") else 22,
+                                                   (3 if key[2] == 1 else 4) if key[0] in ("w43", "w43t") else key[2])
                                                   for m, (key, c_from, flip) in todo])
         for (m, (key, _, _)), u in zip(todo, panels):
             m._cache[key] = (m._versions(["conv"]), u)

@@ -185,7 +185,8 @@ class _WinoPackItem(ctypes.Structure):
 def pack_wino_weights_multi(specs, variant=None):
     """[pack_wino_weights(weight, c_from=c_from, transpose_flip=flip) for (weight, c_from, flip) in specs] in ONE launch
     (tnv3_conv3x3_wino_pack_multi): the panels a training step rebuilds after every optimiser step.  A fourth element 43 in a spec
-    asks for the F(4x4, 3x3) panel (pack_wino43_weights) instead.  All weights on one device; ordered on that device's current
+    asks for the F(4x4, 3x3) panel (pack_wino43_weights) instead; a fifth names the pack layout (0-4) explicitly instead of deriving it
+    from the tuning switches.  All weights on one device; ordered on that device's current
     stream.  Bit-identical to the one-panel calls."""
     lib = _lib.load()
     if not specs:
@@ -204,12 +205,13 @@ def pack_wino_weights_multi(specs, variant=None):
         cout_w, cin_w = int(weight.shape[0]), int(weight.shape[1])
         c_count = cin_w - int(c_from)
         cout, cin = (c_count, cout_w) if flip else (cout_w, c_count)
-        v43 = wino43_variant(None)
+        layout = int(spec[4]) if len(spec) > 4 else None
+        v43 = (1 if layout == 3 else 0) if (f43 and layout is not None) else wino43_variant(None)
         floats = lib.tnv3_conv3x3_wino43_packed_floats(cin, cout, v43) if f43 else lib.tnv3_conv3x3_wino_packed_floats(cin, cout)
         u = torch.empty(floats, dtype=torch.float32, device=dev)
         outs.append(u)
         items[k] = _WinoPackItem(_lib.ptr(weight), _lib.ptr(u), cout_w, cin_w, int(c_from), c_count, int(bool(flip)),
-                                 (3 if v43 == 1 else 4) if f43 else wino_layout(variant, cin, cout))
+                                 layout if layout is not None else ((3 if v43 == 1 else 4) if f43 else wino_layout(variant, cin, cout)))
     _lib.dev_check(keep[0])
     _lib.check(lib.tnv3_conv3x3_wino_pack_multi(ctypes.cast(items, ctypes.c_void_p), len(specs), _lib.stream_ptr(keep[0])))
     return outs

@@ -66,13 +66,12 @@ def use_wino43_dgrad(cin, cout, h, w):
     return WINO43_DGRAD and use_wino43(cin, cout, h, w)
 
 
-# The TRAINING forward through the F(4x4) kernel (its epilogue takes BatchNorm's batch statistics like the F(2x2) kernels') is OPT-IN
-# (TNV3_WINO43_TRAIN=1): 29.9 -> 27.1 ms per step, but batch-statistics BatchNorm amplifies the forward's per-layer rounding -- at
-# 288x512 the training-mode heat maps sit 4.6e-5 from the fp64 oracle (bar 1e-4; F(2x2): 1.6e-5; 9.0e-5 before the kernel's
-# interpolation points were scaled by 3/4) and the gradients at 1.6x torch-fp32's own distance from fp64 (median 0.0098 vs 0.0061 of
-# max|g|; F(2x2): 0.0058).  All bounds pass with it, but the full GPU suite has not run in that configuration: default off this round.
-# The data gradients in F(4x4) form cost nothing measurable (median 0.0058, heat maps unchanged), so they stay on.
-WINO43_TRAIN = os.environ.get("TNV3_WINO43_TRAIN", "0") == "1"
+# The TRAINING forward through the F(4x4) kernel (its epilogue takes BatchNorm's batch statistics like the F(2x2) kernels').  Batch-statistics
+# BatchNorm amplifies the forward's per-layer rounding, so this is the configuration with the least margin: at 288x512 the training-mode
+# heat maps sit 4-5e-5 from the fp64 oracle (bar 1e-4; F(2x2) forward: 1.6e-5) and the gradients at ~1.6x torch-fp32's own distance from
+# fp64 (profiles/r04_fullsize_train_parity_*.json: batch 2 with either forward, batch 10 with this one).  Default since round 4: the
+# driver's GPU suite runs every training parity test with both forwards (tests/conftest.py::train_fwd).  TNV3_WINO43_TRAIN=0: F(2x2).
+WINO43_TRAIN = os.environ.get("TNV3_WINO43_TRAIN", "1") != "0"
 
 
 def use_wino43_train(cin, cout, h, w):
@@ -148,7 +147,16 @@ BN_STATS_IN_EPILOGUE = os.environ.get("TNV3_BN_STATS_EPILOGUE", "1") != "0"
 # Measured on the batch-10 288x512 forward: 9.91 -> 9.33 ms (profiles/r02_split_stream_probe.json); outputs are bit-identical.
 # Other shares and three or four streams are all slower (profiles/r03_infer_split_sweep.txt: 6,4 8.07 ms; 7,3 8.09; 4,4,2 8.15; 5,5 8.22).
 INFER_SPLIT = os.environ.get("TNV3_INFER_SPLIT", "1") != "0"
-INFER_SPLIT_PARTS = tuple(int(v) for v in os.environ.get("TNV3_INFER_SPLIT_PARTS", "6,4").split(",") if v.strip())   # shares of the batch, one stream each
+def _split_parts(text):
+    """Shares of the batch, one stream each: positive integers, at least one -- anything else falls back to 6 : 4."""
+    try:
+        parts = tuple(int(v) for v in text.split(",") if v.strip())
+    except ValueError:
+        return (6, 4)
+    return parts if parts and all(p > 0 for p in parts) else (6, 4)
+
+
+INFER_SPLIT_PARTS = _split_parts(os.environ.get("TNV3_INFER_SPLIT_PARTS", "6,4"))
 INFER_SPLIT_MIN_BATCH = 4
 INFER_SPLIT_MIN_PIXELS = 1 << 19          # batch x H x W below which the launches are too short to be worth a second stream
 

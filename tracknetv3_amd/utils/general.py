@@ -73,6 +73,8 @@ def write_pred_csv(pred_dict, save_file, save_inpaint_mask=False):
             return ['True' if v else 'False' for v in vals]
         if all(isinstance(v, int) and not isinstance(v, bool) for v in vals):
             return [str(v) for v in vals]
+        if all(isinstance(v, int) for v in vals):                          # bools mixed with ints: an object column in pandas, str() per element
+            return [str(v) for v in vals]
         if not all(v is None or isinstance(v, (int, float)) for v in vals):
             raise TypeError('write_pred_csv: columns must hold numbers')
         f32 = all(k == 'float32' for k in kinds)
