@@ -196,11 +196,16 @@ int tnv3_conv_up2x_forward(const float* src_low, const float* wq, float* dst, in
  * filters above (36 in the reference's direct form).  Persistent streaming kernel, output transform in registers.
  *   supported: c0 > 8, cout % 64 == 0, h_low % 2 == 0, w_low % 64 == 0.  u from tnv3_conv_up2x_wino_pack (the layer's
  *   nn.Conv2d weight, its first c0 input channels), 16-byte aligned.  Same function up to fp32 rounding.
- *   variant (also of tnv3_dgrad_up2x_wino): -1 / 0 = the older waves of each SIMD run their MFMA phase first (production), 1 = the
- *   younger ones (round 2's order); bit-identical results, a scheduling choice only. */
-int tnv3_conv_up2x_wino_supported(int c0, int cout, int h_low, int w_low);
-size_t tnv3_conv_up2x_wino_packed_floats(int c0, int cout);
-int tnv3_conv_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, tnv3_stream_t stream);
+ *   variant (also of tnv3_dgrad_up2x_wino): -1 / 0 = the older waves of each SIMD run their MFMA phase first, 1 = the
+ *   younger ones (round 2's order); bit-identical results, a scheduling choice only.
+ *   variant 2 (forward only): Winograd F(4x4, 3x3) on the 16x16x4 kernel (kernels/conv3x3_wino43s_mfma.h, MODE 1).  With Lavin's
+ *   points (0, +-1, +-2, inf) the transform row of the point -1 vanishes on an upsampled signal and the rows of +-2 are proportional:
+ *   25 of the 36 products per 4x4 output tile remain -- 6.25 multiply-adds per low-resolution pixel and channel pair.  Its own panel
+ *   (pack with variant 2); supported: c0 > 0, cout % 64 == 0, h_low % 2 == 0, w_low % 32 == 0.  Not bit-identical to 0 / 1 (another
+ *   factorisation: 1-5e-6 of the output scale from the fp64 result). */
+int tnv3_conv_up2x_wino_supported(int c0, int cout, int h_low, int w_low, int variant);
+size_t tnv3_conv_up2x_wino_packed_floats(int c0, int cout, int variant);
+int tnv3_conv_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, int variant, tnv3_stream_t stream);
 int tnv3_conv_up2x_wino_forward(const float* src_low, const float* u, float* dst, int n, int c0, int cout, int h_low, int w_low,
                                 int variant, tnv3_stream_t stream);
 

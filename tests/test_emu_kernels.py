@@ -146,16 +146,18 @@ def test_conv_up2x_emulated_vs_torch(emu, case):
 UP2X_WINO_CASES = [(1, 12, 64, 2, 64), (2, 20, 128, 4, 64), (1, 70, 64, 2, 128), (3, 16, 192, 6, 64)]
 
 
-def _up2x_wino_case(n, c0, cout, hl, wl, device):
-    """The upsampled half in Winograd form (9 of 16 GEMMs) against fp64 torch on the materialised upsampled tensor and against
-    the class-filter kernel (conv_up2x)."""
+def _up2x_wino_case(n, c0, cout, hl, wl, device, variant=0):
+    """The upsampled half in Winograd form (variant 0: 9 of the 16 F(2x2) GEMMs; 2: 25 of the 36 F(4x4) products) against fp64 torch on the
+    materialised upsampled tensor and against the class-filter kernel (conv_up2x)."""
     from tracknetv3_amd import ops
-    assert ops.up2x_wino_supported(c0, cout, hl, wl)
+    assert ops.up2x_wino_supported(c0, cout, hl, wl, variant)
     xl = torch.relu(T((n, c0, hl, wl), 71))
     w = T((cout, c0 + 8, 3, 3), 73, -0.3, 0.3)
     up = xl.repeat_interleave(2, 2).repeat_interleave(2, 3)
     ref = F.conv2d(up.double(), w[:, :c0].double(), padding=1)
-    got = ops.conv_up2x_wino(xl.to(device), ops.pack_up2x_wino_weights(w.to(device), c0), cout)
+    u = ops.pack_up2x_wino_weights(w.to(device), c0, variant=variant)
+    got = ops.conv_up2x_wino(xl.to(device), u, cout, variant=variant)
+    assert torch.equal(got, ops.conv_up2x_wino(xl.to(device), u, cout, variant=variant))          # deterministic
     old = ops.conv_up2x(xl.to(device), ops.pack_up2x_weights(w.to(device), c0), cout)
     s = ref.abs().max()
     return ((got.cpu().double() - ref).abs().max() / s).item(), ((got - old).abs().max().cpu().double() / s).item()
@@ -169,13 +171,30 @@ def test_conv_up2x_wino_emulated_vs_torch(emu, monkeypatch, case, cus):
     assert e_ref <= 3e-6 and e_old <= 4e-6, (e_ref, e_old)
 
 
+# the F(4x4) form (25 of the 36 products, 16x16x4 kernel): + odd chunk counts of the 16-channel steps (128-channel geometry), 32-wide low-resolution
+# rows, a low-resolution height that is not a multiple of 4 (a half-empty last tile row of the 64-channel geometry), c0 <= 8
+UP2X_WINO43_CASES = UP2X_WINO_CASES + [(2, 24, 128, 6, 32), (1, 8, 64, 2, 32), (3, 40, 256, 4, 96), (1, 33, 64, 10, 32)]
+
+
+@pytest.mark.parametrize("cus", [256, 2])
+@pytest.mark.parametrize("case", UP2X_WINO43_CASES)
+def test_conv_up2x_wino43_emulated_vs_torch(emu, monkeypatch, case, cus):
+    """Lavin's interpolation points (the point -1 has to be one of them): 1-5e-6 of the output scale."""
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+    e_ref, e_old = _up2x_wino_case(*case, "cpu", variant=2)
+    assert e_ref <= 1.5e-5 and e_old <= 1.5e-5, (e_ref, e_old)
+
+
 def test_conv_up2x_wino_unsupported_shapes_are_refused(emu):
     from tracknetv3_amd import _lib, ops
-    assert not ops.up2x_wino_supported(8, 64, 4, 64) and not ops.up2x_wino_supported(16, 64, 3, 64) and not ops.up2x_wino_supported(16, 64, 4, 32)
-    assert not ops.up2x_wino_supported(16, 96, 4, 64)
+    assert not ops.up2x_wino_supported(8, 64, 4, 64, 0) and not ops.up2x_wino_supported(16, 64, 3, 64, 0) and not ops.up2x_wino_supported(16, 64, 4, 32, 0)
+    assert not ops.up2x_wino_supported(16, 96, 4, 64, 0) and not ops.up2x_wino_supported(16, 96, 4, 64, 2) and not ops.up2x_wino_supported(16, 64, 3, 64, 2)
+    assert ops.up2x_wino_supported(8, 64, 4, 32, 2) and not ops.up2x_wino_supported(8, 64, 4, 48, 2)
     w = T((64, 24, 3, 3), 73, -0.3, 0.3)
     with pytest.raises(_lib.Tnv3Error):
-        ops.conv_up2x_wino(T((1, 16, 4, 32), 1), ops.pack_up2x_wino_weights(w, 16), 64)
+        ops.conv_up2x_wino(T((1, 16, 4, 32), 1), ops.pack_up2x_wino_weights(w, 16, variant=0), 64, variant=0)
+    with pytest.raises(_lib.Tnv3Error):                   # a panel of the other variant
+        ops.conv_up2x_wino(T((1, 16, 4, 64), 1), ops.pack_up2x_wino_weights(w, 16, variant=0), 64, variant=2)
 
 
 # (n, c0, cout, h_low, w_low): two / three / nine chunks of output channels, one / two ci blocks, borders on all sides
@@ -673,7 +692,7 @@ def test_wino43_pack_equals_its_definition(emu, shape, c_from, flip, variant):
     assert np.abs(u[:ref.size] - ref).max() <= 2e-7 * max(1.0, np.abs(ref).max())      # fp32 rounding of G g G^T
 
 
-@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "wino43_v1", "wino43_v2", "up2x_wino", "dgrad_up2x_wino"])
+@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "wino43_v1", "wino43_v2", "up2x_wino", "up2x_wino43", "dgrad_up2x_wino"])
 def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
     """The emulator's LDS-DMA normally lands at issue -- as early as possible.  TNV3_EMU_LAZY_DMA=1 is the other extreme: a piece lands
     only when its work-item's counted s_waitcnt (or the kernel's end) forces it, and __syncthreads() forces nothing (hipcc emits no
@@ -698,6 +717,10 @@ def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
     elif what == "up2x_wino":
         e_ref, e_old = _up2x_wino_case(2, 20, 128, 4, 64, "cpu")
         assert e_ref <= 3e-6 and e_old <= 4e-6
+    elif what == "up2x_wino43":
+        for case in ((2, 20, 128, 4, 64), (3, 40, 64, 6, 64)):
+            e_ref, e_old = _up2x_wino_case(*case, "cpu", variant=2)
+            assert e_ref <= 1.5e-5 and e_old <= 1.5e-5
     else:
         e_ref, e_old = _dgrad_up2x_wino_case(*DGRAD_UP2X_WINO_CASES[1], "cpu")
         assert e_ref <= 3e-6 and e_old <= 4e-6

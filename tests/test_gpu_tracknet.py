@@ -68,6 +68,15 @@ def test_conv_up2x_wino_vs_torch(gpu_device, case):
     assert e_ref <= 3e-6 and e_old <= 4e-6, (e_ref, e_old)
 
 
+@pytest.mark.parametrize("case", UP2X_WINO_CASES + [(2, 24, 128, 6, 32), (1, 8, 64, 2, 32), (1, 33, 64, 10, 32), (2, 512, 256, 36, 64), (1, 128, 64, 144, 256),
+                                  (3, 256, 128, 72, 128), (10, 128, 64, 144, 256)])
+def test_conv_up2x_wino43_vs_torch(gpu_device, case):
+    """The upsampled half in F(4x4, 3x3) form (25 of the 36 products, Lavin's points) against fp64 torch and the class-filter kernel: small
+    shapes with every border case, the three decoder entries of the network, batch 10."""
+    e_ref, e_old = _up2x_wino_case(*case, gpu_device, variant=2)
+    assert e_ref <= 3e-5 and e_old <= 3e-5, (e_ref, e_old)
+
+
 @pytest.mark.parametrize("case", UP2X_CASES + [(2, 512, 256, 36, 64), (1, 128, 64, 144, 256), (2, 256, 128, 9, 40)])
 def test_dgrad_up2x_vs_autograd(gpu_device, case):
     assert _dgrad_up2x_case(*case, gpu_device) <= 3e-6

@@ -48,15 +48,21 @@
 namespace tnv3 {
 
 struct Wino43SBase {
-  static constexpr int NT = 512, TW = 64, RQ = 17, PAIRS = 18;
-  static constexpr int A_CHUNK_FLOATS = PAIRS * 64 * 4;   // one (16-channel block, chunk of 8 input channels) of the panel
+  static constexpr int NT = 512, TW = 64;
   static constexpr int B_RING = 3, B_DIST = 2;
   static constexpr int NR = 2;
   static constexpr int CC = 8;                            // the panel's chunk (the kernels' step: CC * KB channels)
 };
-template <int CBW_>
+// MODE 0: the plain layer (36 xi = 18 pairs; raw tile of the input itself).  MODE 1: the UPSAMPLED half of a decoder-entry layer
+// (model.py:65,67,69: conv3x3 over nn.Upsample(2)(x_low)) computed from the low-resolution tensor -- 25 xi = 13 pairs (the last one
+// half empty), see the section "upsampled half" below.
+template <int CBW_, int MODE_ = 0>
 struct Wino43SCfg : Wino43SBase {
   static_assert(CBW_ == 4 || CBW_ == 8, "16-channel blocks per workgroup");
+  static constexpr int MODE = MODE_;
+  static constexpr int NXI = MODE_ ? 25 : 36, PAIRS = (NXI + 1) / 2;
+  static constexpr int A_CHUNK_FLOATS = PAIRS * 64 * 4;   // one (16-channel block, chunk of 8 input channels) of the panel
+  static constexpr int RQ = MODE_ ? 9 : 17;               // pieces per raw row: 17 from column w0 - 1 / 9 from low-resolution column w0 / 2 - 1
   static constexpr int CBW = CBW_, TRW = 8 / CBW_;        // tile rows per workgroup
   static constexpr int KB = CBW_ / 4;                     // 8-channel blocks per step: 1 (64 x 2 rows) / 2 (128 x 1 row: 16 channels per step,
   static constexpr int SC = 8 * KB;                       // so that every thread still has half a patch to transform in every step)
@@ -64,24 +70,24 @@ struct Wino43SCfg : Wino43SBase {
   static constexpr int NV = CBW_ == 4 ? 3 : 2;            // V stages: 3 = the transform runs two steps ahead and the next step's first B quads are
                                                           // read before the step's barrier; 2 (LDS: 16-channel stages) = one step ahead
   static constexpr int MB = 16 * CBW, TB = 16 * TRW, TH = 4 * TRW;
-  static constexpr int RROWS = TH + 2;                    // raw halo tile per channel: rows h0-1 .. h0+TH, 17 pieces from column w0-1
-  static constexpr int RPLANE = (RROWS * RQ + 15) / 16 * 16;      // pieces per channel plane: a multiple of 16 pieces, so that the two channels a
-                                                                  // 16-lane read group touches fall into disjoint bank ranges
+  static constexpr int RROWS = MODE_ ? TH / 2 + 2 : TH + 2;      // raw halo tile per channel: rows h0-1 .. h0+TH / low-resolution rows h0/2-1 .. h0/2+TH/2
+  // pieces per channel plane.  MODE 0: a multiple of 16 pieces, so that the two channels a 16-lane group of a ds_read_b128 touches fall into
+  // disjoint bank ranges; MODE 1 (8-byte reads, 32-lane groups): 8 mod 16 pieces = 32 mod 64 banks between the group's two channels
+  static constexpr int RPLANE = MODE_ ? (RROWS * RQ + 7) / 16 * 16 + 8 : (RROWS * RQ + 15) / 16 * 16;
   static constexpr int RAW_SLOTS = SC * RPLANE;           // pieces per stage: 1408 (2.75 per thread) / 1792 (3.5)
   static constexpr int RAW_STAGE = RAW_SLOTS * 4;         // floats
   static constexpr int NDMA = (RAW_SLOTS + NT - 1) / NT;  // DMA instructions per wave and step; the last one: the first DMA_LAST_WAVES waves
-  static constexpr int DMA_LAST_WAVES = (RAW_SLOTS - (NDMA - 1) * NT) / 64;
-  static_assert((RAW_SLOTS - (NDMA - 1) * NT) % 64 == 0, "the last DMA instruction splits on a wave boundary");
+  static constexpr int DMA_LAST_WAVES = (RAW_SLOTS - (NDMA - 1) * NT + 63) / 64;      // (a partial last wave: its surplus lanes are out of range)
   static constexpr int V_PAIR = TRW * 256;                // floats per operand pair: [tile row][g 4][tile column 16][4]
   static constexpr int V_STAGE = NP * V_PAIR;             // 36 KB
   static constexpr int LDS_FLOATS = NV * V_STAGE + NR * RAW_STAGE;      // 155,648 / 131,072 bytes
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-  static_assert(PAIRS % B_RING == 0, "rings are indexed statically");
+  static constexpr bool B_ACROSS = NV == 3 && NP % B_RING == 0;      // the next step's first B quads are read before this step's barrier
 };
 
 inline size_t conv3x3_wino43s_packed_floats(int cin, int cout) {
   if (cin <= 0 || cout <= 0 || cout % 16) return 0;
-  return (size_t)(cout / 16) * ((cin + Wino43SBase::CC - 1) / Wino43SBase::CC) * Wino43SBase::A_CHUNK_FLOATS + kPackZeroTail;
+  return (size_t)(cout / 16) * ((cin + Wino43SBase::CC - 1) / Wino43SBase::CC) * (18 * 64 * 4) + kPackZeroTail;
 }
 
 // w[..][3][3] -> panel u[co / 16][chunk][pair = 3 i + j / 2][lane = (g = ci % 8 / 2) * 16 + co % 16][(s = ci % 2) * 2 + j % 2] for
@@ -135,6 +141,63 @@ inline __global__ void __launch_bounds__(256) conv3x3_wino43s_pack_kernel(const 
   conv3x3_wino43s_pack_elements(w, u, Cout, Cin, s_co, s_ci, flip, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
 
+// ---- upsampled half (MODE 1): U'[i'][j'] = G' g G'^T over the indices (0, 1, e, o, 5) with G' = [1/4 0 0; -1/3 -1/3 -1/3; -1/12 -1/3 -1/3;
+//      -1/6 -1/6 -2/3; 0 0 1] -- rows 0 and infinity of Lavin's G, twice its row of the point 1 (the patch transform carries c - 4 b, half
+//      of B^T's row), and -3 G[2] +- G[-2] for the even / odd output rows (the rows of +-2 of B^T E are -3 (b - c) and (b - c)).
+//      Panel u[co / 16][chunk][pair 13][lane = (ci % 8 / 2) * 16 + co % 16][(ci % 2) * 2 + slot]: pairs 0-4 = ((0, j'), (1, j')),
+//      5-9 = ((e, j'), (o, j')), 10-12 = ((5, 0), (5, 1)), ((5, e), (5, o)), ((5, 5), zero); the first c0 input channels of w[Cout][Cin][3][3].
+__device__ __forceinline__ float wino43u_g_row(int i, float g0, float g1, float g2) {
+  switch (i) {
+    case 0: return 0.25f * g0;
+    case 1: return (-1.0f / 3.0f) * ((g0 + g1) + g2);
+    case 2: return (-1.0f / 12.0f) * g0 + (-1.0f / 3.0f) * (g1 + g2);
+    case 3: return (-1.0f / 6.0f) * (g0 + g1) + (-2.0f / 3.0f) * g2;
+    default: return g2;
+  }
+}
+inline size_t conv_up2x_wino43_packed_floats(int c0, int cout) {
+  if (c0 <= 0 || cout <= 0 || cout % 16) return 0;
+  return (size_t)(cout / 16) * ((c0 + 7) / 8) * (13 * 64 * 4) + kPackZeroTail;
+}
+inline long conv_up2x_wino43_pack_items(int Cout, int c0) { return (long)(Cout / 16) * ((c0 + 7) / 8) * 64 + kPackZeroTail / 4; }
+inline __global__ void __launch_bounds__(256) conv_up2x_wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int c0) {
+  const int nch = (c0 + 7) / 8;
+  const long quads = (long)(Cout / 16) * nch * 64;
+  f32x4* u4 = reinterpret_cast<f32x4*>(u);
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads + kPackZeroTail / 4; q += (long)gridDim.x * 256) {
+    if (q >= quads) { u4[quads * 13 + (q - quads)] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; continue; }
+    const int ln = (int)(q & 63);
+    const int r = (int)(q >> 6), k = r % nch, cb = r / nch;
+    const int co = 16 * cb + (ln & 15), g = ln >> 4;
+    float uu[2][5][5];                                  // [s][i'][j']
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const int ci = 8 * k + 2 * g + sx;
+      float f[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) f[t] = ci < c0 ? w[((size_t)co * Cin + ci) * 9 + t] : 0.0f;
+      float rowv[5][3];                                 // G' applied down the filter's columns
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rowv[i][c] = wino43u_g_row(i, f[c], f[3 + c], f[6 + c]);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) uu[sx][i][j] = wino43u_g_row(j, rowv[i][0], rowv[i][1], rowv[i][2]);
+    }
+    f32x4* dst = u4 + ((long)r * 13) * 64 + ln;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      dst[j * 64] = f32x4{uu[0][0][j], uu[0][1][j], uu[1][0][j], uu[1][1][j]};
+      dst[(5 + j) * 64] = f32x4{uu[0][2][j], uu[0][3][j], uu[1][2][j], uu[1][3][j]};
+    }
+    dst[10 * 64] = f32x4{uu[0][4][0], uu[0][4][1], uu[1][4][0], uu[1][4][1]};
+    dst[11 * 64] = f32x4{uu[0][4][2], uu[0][4][3], uu[1][4][2], uu[1][4][3]};
+    dst[12 * 64] = f32x4{uu[0][4][4], 0.0f, uu[1][4][4], 0.0f};
+  }
+}
+
 // Table-driven pack of panels of BOTH Winograd forms in one launch (layout 0-2: F(2x2) panels, conv3x3_wino_mfma.h; 3: F(4x4) panels of the 32x32x2 kernel; 4: of the 16x16x4 kernel)
 inline __global__ void __launch_bounds__(256) conv3x3_wino_pack_multi43_kernel(const WinoPackTable t) {
   int lo = 0, hi = t.count;                    // first_block[lo] <= blockIdx.x < first_block[hi]
@@ -177,12 +240,14 @@ __device__ __forceinline__ void wino43s_at6(float m0, float m1, float m2, float 
 // 2 write-outs, 3 steps walked, 4 tiles walked.  DG (diag only, WRONG results): timing twins -- bit 0 no raw DMA after the prologue,
 // bit 1 no patch transform, bit 2 no A loads (the ring keeps the prologue's quads), bit 3 no B reads, bit 4 no MFMAs, bit 5 no output stores.
 // POOL = 1: a.pool_dst receives MaxPool2d(2, 2) of the block.
-template <int CBW, int STATS = 0, int GROW = 10, int TS = 10, int TL = 0, int DG = 0, int POOL = 0>
+template <int CBW, int STATS = 0, int GROW = 10, int TS = 10, int TL = 0, int DG = 0, int POOL = 0, int MODE = 0>
 __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const WinoArgs a) {
-  using Cfg = Wino43SCfg<CBW>;
-  constexpr int SC = Cfg::SC, KB = Cfg::KB, NP = Cfg::NP, NV = Cfg::NV, NSLOT = 2 * NP;
+  using Cfg = Wino43SCfg<CBW, MODE>;
+  static_assert(MODE == 0 || (STATS == 0 && POOL == 0), "the upsampled half writes plain partial sums");
+  constexpr int SC = Cfg::SC, KB = Cfg::KB, NP = Cfg::NP, NV = Cfg::NV, NSLOT = 2 * NP, PAIRS = Cfg::PAIRS, NXI = Cfg::NXI;
   constexpr int NT = Cfg::NT, MB = Cfg::MB, V_STAGE = Cfg::V_STAGE, RAW_STAGE = Cfg::RAW_STAGE, V_PAIR = Cfg::V_PAIR;
-  constexpr int A_DIST = 5, RQ = Cfg::RQ, T_PIECES = 17, GPS = 3;      // GPS: grow loads per slot
+  constexpr int A_DIST = 5, RQ = Cfg::RQ, T_PIECES = MODE ? 5 : 17, GPS = 3;      // GPS: grow loads per slot
+  constexpr bool B_ACROSS = Cfg::B_ACROSS;
   constexpr int GS = NSLOT - (GROW + GPS - 1) / GPS;                  // first slot of the grow phase
   constexpr int TD = NV - 1;                                          // the transform's lead over the MFMAs, in steps
   static_assert(GROW >= A_DIST && GROW <= 16 && TS >= Cfg::NDMA && TS + T_PIECES <= NSLOT, "step schedule");
@@ -193,7 +258,8 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int swave = __builtin_amdgcn_readfirstlane(wave);
-  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;      // (H, W: the OUTPUT's; MODE 1 reads its source at half of both)
+  const int SH = H >> MODE, SW = W >> MODE, SHW = SH * SW;
   const int tilesH = (H + Cfg::TH - 1) / Cfg::TH, tilesW = W / Cfg::TW;
   const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
   const int nChunks = (Cin + SC - 1) / SC;               // steps per tile
@@ -228,7 +294,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   const unsigned a_lane_b = (unsigned)lane * 16u;
   const tnv3_rsrc_t r_panel = tnv3_make_rsrc(a.u, (unsigned)((size_t)(Cout / 16) * nCh8 * Cfg::A_CHUNK_FLOATS * 4));
 
-  f32x4 acc[36];                                        // [xi = 6 i + j], register r = channel 4 (lane >> 4) + r
+  f32x4 acc[2 * PAIRS];                                 // [xi], register r = channel 4 (lane >> 4) + r
   f32x4 aq[NP], bq[Cfg::B_RING];
 
   // ---- D cursor: per-tile piece offsets.  Slot e = tid + i * 512 -> (channel c, row, piece q) of [SC][RPLANE]; the pad pieces of a
@@ -238,22 +304,22 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   auto set_d = [&]() {
     int t_op = tid;
     TNV3_OPAQUE_V(t_op);
-    const int h0 = wD.trow * Cfg::TH, w0 = wD.tcol * Cfg::TW;
+    const int h0 = (wD.trow * Cfg::TH) >> MODE, w0 = (wD.tcol * Cfg::TW) >> MODE;      // in the source's pixels
 #pragma unroll
     for (int i = 0; i < Cfg::NDMA; ++i) {
       const int e = t_op + i * NT;
       const int c = e / Cfg::RPLANE, rem = e - c * Cfg::RPLANE;
       const int r = rem / RQ, q = rem - r * RQ;
       const int gh = h0 - 1 + r, gw = w0 - 1 + 4 * q;
-      const bool ok = wD.valid && e < Cfg::RAW_SLOTS && rem < Cfg::RROWS * RQ && gh >= 0 && gh < H;
-      voD[i] = ok ? (unsigned)(c * HW + gh * W + gw) * 4u : kDmaOob;      // (channel 0, row 0, column -1: wraps beyond the range = zeros; see fix_corner)
+      const bool ok = wD.valid && e < Cfg::RAW_SLOTS && rem < Cfg::RROWS * RQ && gh >= 0 && gh < SH;
+      voD[i] = ok ? (unsigned)(c * SHW + gh * SW + gw) * 4u : kDmaOob;      // (channel 0, row 0, column -1: wraps beyond the range = zeros; see fix_corner)
     }
     const int nn = wD.valid ? wD.n : 0;
-    r_srcD = tnv3_make_rsrc(a.src + (size_t)nn * Cin * HW, (unsigned)Cin * (unsigned)HW * 4u);
+    r_srcD = tnv3_make_rsrc(a.src + (size_t)nn * Cin * SHW, (unsigned)Cin * (unsigned)SHW * 4u);
   };
   auto dma_piece = [&](int i, int stage) {              // piece i of chunk kD of the D tile -> raw stage
     if (i < Cfg::NDMA - 1 || swave < Cfg::DMA_LAST_WAVES)
-      tnv3_buf_dma16(r_srcD, raw_s + stage * RAW_STAGE + (i * NT + wbase) * 4, voD[i] + (unsigned)kD * (unsigned)(SC * 4) * (unsigned)HW);
+      tnv3_buf_dma16(r_srcD, raw_s + stage * RAW_STAGE + (i * NT + wbase) * 4, voD[i] + (unsigned)kD * (unsigned)(SC * 4) * (unsigned)SHW);
   };
   auto adv_d = [&]() {
     if (++kD >= nChunks) { kD = 0; wD.next(); set_d(); }
@@ -276,8 +342,10 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   const int t_tc = (lane & 7) | ((lane >> 1) & 8), t_s = (lane >> 3) & 1, t_g = ((lane >> 5) & 1) | ((swave & 1) << 1);
   const int t_x = (swave >> 1) & 1, t_tr = CBW == 4 ? t_x : 0, t_kb = CBW == 4 ? 0 : t_x;
   const int t_ci = 8 * t_kb + 2 * t_g + t_s;
-  const int t_src = t_ci * (Cfg::RPLANE * 4) + ((4 * t_tr + RH) * RQ + t_tc) * 4;                       // + row * 68 floats; second piece + 4
-  const int t_dst = (t_kb * 18 + 9 * RH) * V_PAIR + t_tr * 256 + t_g * 64 + t_tc * 4 + t_s * 2;         // + pair * V_PAIR
+  // MODE 0: raw rows 4 ttr + RH .., piece tc (+ row * 68 floats; second piece + 4); V pairs 9 RH ..
+  // MODE 1: low-resolution raw rows 2 ttr + RH .., floats 2 tc .. 2 tc + 3 (+ row * 36 floats); V pairs 0-4 (RH 0) / 5-12 (RH 1)
+  const int t_src = t_ci * (Cfg::RPLANE * 4) + (MODE ? ((2 * t_tr + RH) * RQ) * 4 + 2 * t_tc : ((4 * t_tr + RH) * RQ + t_tc) * 4);
+  const int t_dst = (t_kb * PAIRS + (MODE ? 5 : 9) * RH) * V_PAIR + t_tr * 256 + t_g * 64 + t_tc * 4 + t_s * 2;         // + pair * V_PAIR
 
   // ---- T cursor: the transform of half a patch, in pieces (the step places one piece behind an MFMA slot)
   float* t_raw = nullptr;      // raw stage + t_src
@@ -293,9 +361,63 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   f32x4 tq0[5];
   wf2 tq1[5];
   float tt[3][6];
+  wf2 ulo[3], uhi[3];                                    // MODE 1: the thread's three low-resolution rows, columns (-1, 0) and (1, 2) of the patch
+  float uc[2][4], uw[2][4];
   auto t_piece = [&](auto pc) {
     constexpr int P = decltype(pc)::value;
-    if constexpr (P == 0) {                              // raw rows RH .. RH + 4 of the patch, columns 0-3
+    if constexpr (MODE == 1) {
+      // ---- upsampled half.  The 6 x 6 patch of the upsampled tensor is E l E^T of a 4 x 4 low-resolution patch l (rows / columns
+      //      a, b, b, c, c, e).  With Lavin's points (0, +-1, +-2, inf) B^T E has the rows (4 a - 5 b + c), (2 c - 8 b), 0, -3 (b - c), (b - c),
+      //      (4 b - 5 c + e): the point -1 vanishes, +-2 are proportional.  Five products per axis remain -- indices (0, 1, e, o, 5), where e / o
+      //      carry the SAME transformed value b - c against two filters (for the even / the odd output rows: A^T's columns of +-2 differ in
+      //      the sign of the odd rows) -- 25 of the 36.  Row half RH = 0: indices 0, 1 from rows (a, b, c); RH = 1: e / o, 5 from (b, c, e).
+      if constexpr (P == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          ulo[r] = *reinterpret_cast<const wf2*>(t_raw + r * (RQ * 4));
+          uhi[r] = *reinterpret_cast<const wf2*>(t_raw + r * (RQ * 4) + 2);
+        }
+        if (fix_corner) {                                // the piece before the image's first element (channel 0, low-resolution row 0)
+          if (lane < 2 && (swave & 3) == 0) {            // (that piece = columns -1 .. 2: all of tile column 0's row and the first half of tile column 1's)
+            const tnv3_rsrc_t ri = tnv3_make_rsrc(a.src + (size_t)wT.n * Cin * SHW, (unsigned)Cin * (unsigned)SHW * 4u);
+            const f32x4 x = tnv3_buf_load_f4(ri, 0u, 0u);
+            const bool l0 = lane == 0;                   // (selects, not branches: the compiler turned the branchy form into an indexed scratch store)
+            ulo[1 - RH] = wf2{l0 ? 0.0f : x[1], l0 ? x[0] : x[2]};
+            uhi[1 - RH] = wf2{l0 ? x[1] : uhi[1 - RH][0], l0 ? x[2] : uhi[1 - RH][1]};
+          }
+        }
+      } else if constexpr (P == 1) {                     // down the patch's four columns
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const float r0 = x < 2 ? ulo[0][x & 1] : uhi[0][x & 1], r1 = x < 2 ? ulo[1][x & 1] : uhi[1][x & 1], r2 = x < 2 ? ulo[2][x & 1] : uhi[2][x & 1];
+          float c0, c1;
+          if constexpr (RH == 0) { c0 = fmaf(4.0f, r0, fmaf(-5.0f, r1, r2)); c1 = fmaf(-4.0f, r1, r2); }      // (a, b, c) -> 4 a - 5 b + c,  c - 4 b
+          else { c0 = r0 - r1; c1 = fmaf(4.0f, r0, fmaf(-5.0f, r1, r2)); }                                  // (b, c, e) -> b - c,  4 b - 5 c + e
+          if (x == 0) { c0 = zl ? 0.0f : c0; c1 = zl ? 0.0f : c1; }
+          if (x == 3) { c0 = zr ? 0.0f : c0; c1 = zr ? 0.0f : c1; }
+          uc[0][x] = c0; uc[1][x] = c1;
+        }
+      } else if constexpr (P == 2 || P == 3) {           // along a row: (p0 .. p3) -> the values of indices 0, 1, e = o, 5
+        constexpr int k = P - 2;
+        const float p0 = uc[k][0], p1 = uc[k][1], p2 = uc[k][2], p3 = uc[k][3];
+        uw[k][0] = fmaf(4.0f, p0, fmaf(-5.0f, p1, p2));
+        uw[k][1] = fmaf(-4.0f, p1, p2);
+        uw[k][2] = p1 - p2;
+        uw[k][3] = fmaf(4.0f, p1, fmaf(-5.0f, p2, p3));
+      } else {                                           // V pairs: (0, j') with (1, j') -- (e, j') with (o, j') -- row 5 in three pairs
+        auto jv = [](int j) constexpr { return j < 2 ? j : (j < 4 ? 2 : 3); };      // j' = (0, 1, e, o, 5) -> the row pass's value
+        if constexpr (RH == 0) {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) *reinterpret_cast<wf2*>(t_v + j * V_PAIR) = wf2{uw[0][jv(j)], uw[1][jv(j)]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) *reinterpret_cast<wf2*>(t_v + j * V_PAIR) = wf2{uw[0][jv(j)], uw[0][jv(j)]};
+          *reinterpret_cast<wf2*>(t_v + 5 * V_PAIR) = wf2{uw[1][0], uw[1][1]};
+          *reinterpret_cast<wf2*>(t_v + 6 * V_PAIR) = wf2{uw[1][2], uw[1][2]};
+          *reinterpret_cast<wf2*>(t_v + 7 * V_PAIR) = wf2{uw[1][3], 0.0f};
+        }
+      }
+    } else if constexpr (P == 0) {                       // raw rows RH .. RH + 4 of the patch, columns 0-3
 #pragma unroll
       for (int r = 0; r < 5; ++r) tq0[r] = *reinterpret_cast<const f32x4*>(t_raw + r * (RQ * 4));
       if (fix_corner) {                                  // scalar branch, taken once per image: the piece before the image's first element
@@ -360,7 +482,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   };
   // (a chunk beyond the panel's last -- the second half of a 16-channel step when Cin % 16 <= 8 -- must read zeros: through the LANE offset,
   //  the scalar offset of a buffer access is not range-checked)
-  auto a_lane_of = [&](int k, int q) -> unsigned { return (KB == 1 || q < 18 || k * KB + 1 < nCh8) ? a_lane_b : kDmaOob; };
+  auto a_lane_of = [&](int k, int q) -> unsigned { return (KB == 1 || q < PAIRS || k * KB + 1 < nCh8) ? a_lane_b : kDmaOob; };
   auto next_mb = [&]() -> int {                          // the channel block of the tile after M's (the walk's rule)
     int mb = wM.mb + wM.d_mb;
     if (mb >= nMB) mb -= nMB;
@@ -395,7 +517,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     for (int q = 0; q < GROW; ++q) aq[q] = tnv3_buf_load_f4(r_panel, a_lane_of(0, q), s0 + (unsigned)q * 1024u);
   }
   full_barrier();
-  if constexpr (NV == 3) {
+  if constexpr (B_ACROSS) {
 #pragma unroll
     for (int q = 0; q < Cfg::B_DIST; ++q) bq[q] = *reinterpret_cast<const f32x4*>(v_s + q * V_PAIR + b_lane);
   }
@@ -414,30 +536,31 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     const bool last_k = kM + 1 >= nChunks;
     const unsigned soM = a_base(wM.mb, kM), soA = last_k ? a_base(next_mb(), 0) : a_base(wM.mb, kM + 1);
     const int kA = last_k ? 0 : kM + 1;                  // (past the last step: a slice nobody uses, inside the panel)
-    const unsigned a_lane_hi = a_lane_of(kM, 18);        // lane offset of this step's second 8-channel block
+    const unsigned a_lane_hi = a_lane_of(kM, PAIRS);     // lane offset of this step's second 8-channel block
     const int srt = (sr + TD) & 1, srd = srt ^ 1;        // raw stages of the transform's / the DMA's step
     set_t(srt, svt);
-    if constexpr (NV == 2) {                             // (no V stage to spare: this step's first B quads after the barrier that published them)
+    if constexpr (!B_ACROSS) {                           // (no V stage to spare, or a pair count the ring does not divide: this step's first B quads after the barrier)
 #pragma unroll
       for (int q = 0; q < Cfg::B_DIST; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bM + q * V_PAIR);
     }
     wino43s_for<0, NSLOT>([&](auto ic) {
-      constexpr int IDX = decltype(ic)::value, q = IDX >> 1, s = IDX & 1, p = q % 18;
+      constexpr int IDX = decltype(ic)::value, q = IDX >> 1, s = IDX & 1, p = q % PAIRS;
       if constexpr (s == 0) {
         constexpr int qb = q + Cfg::B_DIST, qa = q + A_DIST;
-        if constexpr ((DG & 8) == 0 && (qb < NP || NV == 3))
+        if constexpr ((DG & 8) == 0 && (qb < NP || B_ACROSS))
           bq[qb % Cfg::B_RING] = *reinterpret_cast<const f32x4*>((qb < NP ? bM : bN) + (qb % NP) * V_PAIR);
-        if constexpr ((DG & 4) == 0 && qa >= GROW && qa < NP) aq[qa] = tnv3_buf_load_f4(r_panel, qa < 18 ? a_lane_b : a_lane_hi, soM + (unsigned)qa * 1024u);
+        if constexpr ((DG & 4) == 0 && qa >= GROW && qa < NP) aq[qa] = tnv3_buf_load_f4(r_panel, qa < PAIRS ? a_lane_b : a_lane_hi, soM + (unsigned)qa * 1024u);
         __builtin_amdgcn_sched_barrier(0);
       }
       const f32x4& av = aq[q];
       const f32x4& bv = bq[q % Cfg::B_RING];
-      constexpr bool ZERO = FIRST && q < 18 && s == 0;   // a tile's first K step starts the accumulator
+      constexpr bool ZERO = FIRST && q < PAIRS && s == 0;   // a tile's first K step starts the accumulator
       if constexpr ((DG & 16) != 0) {
         if constexpr (ZERO) { acc[2 * p] = f32x4{av[0], bv[0], 0.0f, 0.0f}; acc[2 * p + 1] = f32x4{av[1], bv[1], 0.0f, 0.0f}; }
       } else {
         acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * s], bv[2 * s], ZERO ? zero4 : acc[2 * p], 0, 0, 0);
-        acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * s + 1], bv[2 * s + 1], ZERO ? zero4 : acc[2 * p + 1], 0, 0, 0);
+        if constexpr (2 * p + 1 < NXI)                   // (25 xi: the last pair is half empty)
+          acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * s + 1], bv[2 * s + 1], ZERO ? zero4 : acc[2 * p + 1], 0, 0, 0);
       }
       if constexpr (IDX < Cfg::NDMA) { if constexpr ((DG & 1) == 0) dma_piece(IDX, srd); }
       if constexpr (IDX >= TS && IDX - TS < T_PIECES) { if constexpr ((DG & 2) == 0) t_piece(std::integral_constant<int, IDX - TS>{}); }
@@ -469,6 +592,34 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     const size_t plane0 = ((size_t)wM.n * Cout + e_m0) * HW;
     const unsigned planes_b = 16u * (unsigned)HW * 4u;
     const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
+    if constexpr (MODE == 1) {
+      // upsampled half: Y = A'^T M' A' over the indices (0, 1, e, o, 5) with A'^T = [1 1 1 0 0; 0 1 0 2 0; 0 1 4 0 0; 0 1 0 8 1]; M'[i'][j'] =
+      // acc[2 j' + i'] (i' = 0, 1), acc[10 + 2 j' + (i' - 2)] (i' = e, o), acc[20 + j'] (i' = 5).  Plain partial sums: the skip half's launch adds them.
+      const unsigned lane_off_u = oh < H ? (unsigned)((4 * g) * HW + oh * W + ow) * 4u : kDmaOob;
+      auto at5 = [](float q0, float q1, float qe, float qo, float q5, float (&o)[4]) {
+        o[0] = (q0 + q1) + qe;
+        o[1] = fmaf(2.0f, qo, q1);
+        o[2] = fmaf(4.0f, qe, q1);
+        o[3] = fmaf(8.0f, qo, q1) + q5;
+      };
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float wv[4][5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          float o[4];
+          at5(acc[2 * j][r], acc[2 * j + 1][r], acc[10 + 2 * j][r], acc[11 + 2 * j][r], acc[20 + j][r], o);
+          wv[0][j] = o[0]; wv[1][j] = o[1]; wv[2][j] = o[2]; wv[3][j] = o[3];
+        }
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) {
+          float o[4];
+          at5(wv[ar][0], wv[ar][1], wv[ar][2], wv[ar][3], wv[ar][4], o);
+          tnv3_buf_store_f4(r_dst, (DG & 32) ? kDmaOob : lane_off_u, (unsigned)r * (unsigned)HW * 4u + (unsigned)(ar * W) * 4u, f32x4{o[0], o[1], o[2], o[3]});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     const tnv3_rsrc_t r_add = tnv3_make_rsrc(has_addend ? a.addend + plane0 : a.dst + plane0, planes_b);
     const unsigned lane_off_b = oh < H ? (unsigned)((4 * g) * HW + oh * W + ow) * 4u : kDmaOob;      // (a tile row below the image: loads give 0, stores are dropped)
     // MaxPool2d(2, 2) of the block as a second output (the down blocks' last layers): a lane's 4x4 pixels are 2x2 pooled ones
@@ -542,6 +693,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         }
       }
       __builtin_amdgcn_sched_barrier(0);                // one channel at a time
+    }
     }
   };
 

@@ -1017,12 +1017,18 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
 }
 
 // ---- the upsampled half of a decoder-entry layer in Winograd form: 9 of the 16 GEMMs (kernels/conv_up2x_wino_mfma.h)
-inline bool conv_up2x_wino_supported(int c0, int cout, int hl, int wl) {
-  return c0 > ConvUp2xWinoCfg::CC && cout > 0 && cout % 64 == 0 && hl > 0 && wl > 0 && hl % 2 == 0 && wl % ConvUp2xWinoCfg::TW == 0 &&
+// `variant` -1 / 0 / 1: the 9-GEMM F(2x2) kernel (kernels/conv_up2x_wino_mfma.h; 1 = the other wave group's MFMAs first); 2 = F(4x4, 3x3) with 25
+// of the 36 products on the 16x16x4 kernel (kernels/conv3x3_wino43s_mfma.h, MODE 1).  0 / 1 and 2 read different panels.
+inline bool conv_up2x_wino_supported(int c0, int cout, int hl, int wl, int variant = -1) {
+  if (variant == 2)
+    return c0 > 0 && cout > 0 && cout % 64 == 0 && hl > 0 && wl > 0 && hl % 2 == 0 && wl % 32 == 0 && (long)64 * 4 * hl * wl * 4 < (1l << 31) &&
+           (long)c0 * hl * wl * 4 < (1l << 31) && conv_up2x_wino43_packed_floats(c0, cout) * 4 < (1ul << 31);
+  return variant <= 1 && c0 > ConvUp2xWinoCfg::CC && cout > 0 && cout % 64 == 0 && hl > 0 && wl > 0 && hl % 2 == 0 && wl % ConvUp2xWinoCfg::TW == 0 &&
          (long)64 * 4 * hl * wl * 4 < (1l << 31) && (long)c0 * hl * wl * 4 < (1l << 31) && (long)cout * 9 * 8 * 4 < (1l << 31);
 }
-inline size_t conv_up2x_wino_packed_floats(int c0, int cout) {
+inline size_t conv_up2x_wino_packed_floats(int c0, int cout, int variant = -1) {
   if (c0 <= 0 || cout <= 0) return 0;
+  if (variant == 2) return conv_up2x_wino43_packed_floats(c0, cout);
   return (size_t)round_up(c0, ConvUp2xWinoCfg::CC) * 9 * cout + kPackZeroTail;
 }
 template <class Launcher>
@@ -1032,10 +1038,29 @@ int conv_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, in
   const long total = (long)c0pad * cout;
   return L.launch(conv_up2x_wino_pack_kernel, (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256), 256, w, u, cout, cin, c0, c0pad);
 }
+constexpr int kWino43UGrow = 9, kWino43UTs = 6;       // the upsampled half's step schedule (13 operand pairs per 8 channels)
+// variant 2's launches (instantiated by the Winograd translation unit only: the kernel is built with that family's compiler flags)
+template <class Launcher>
+int conv_up2x_wino43_pack_launch(Launcher& L, const float* w, float* u, int cout, int cin, int c0) {
+  if (cout % 16 || (((uintptr_t)u) & 15)) TNV3_FAIL(-1, "conv_up2x_wino_pack: variant 2 needs Cout %% 16 == 0 and a 16-byte aligned panel");
+  const long items = conv_up2x_wino43_pack_items(cout, c0);
+  return L.launch(conv_up2x_wino43_pack_kernel, (int)((items + 255) / 256 > 65535 ? 65535 : (items + 255) / 256), 256, w, u, cout, cin, c0);
+}
+template <class Launcher>
+int conv_up2x_wino43_forward_launch(Launcher& L, const float* src, const float* u, float* dst, int n, int c0, int cout, int hl, int wl) {
+  if ((((uintptr_t)dst | (uintptr_t)u) & 15) || (((uintptr_t)src) & 3)) TNV3_FAIL(-1, "conv_up2x_wino: misaligned pointer");
+  WinoArgs a{src, u, u, nullptr, nullptr, nullptr, nullptr, dst, n, c0, cout, 2 * hl, 2 * wl, 0, nullptr, nullptr, nullptr, nullptr};
+  const bool wide = cout % 128 == 0;
+  const long npt = wide ? (long)n * (hl / 2) * (wl / 32) : (long)n * ((hl + 3) / 4) * (wl / 32);
+  if (npt > (1l << 28)) TNV3_FAIL(-1, "conv_up2x_wino: too many tiles");
+  const int grid = wino_persistent_grid(conv_grid_blocks(cout / (wide ? 128 : 64), (int)npt));
+  if (wide) return L.launch(conv3x3_wino43s_kernel<8, 0, kWino43UGrow, kWino43UTs, 0, 0, 0, 1>, grid, Wino43SBase::NT, a);
+  return L.launch(conv3x3_wino43s_kernel<4, 0, kWino43UGrow, kWino43UTs, 0, 0, 0, 1>, grid, Wino43SBase::NT, a);
+}
 template <class Launcher>
 int conv_up2x_wino_forward_impl(Launcher& L, const float* src, const float* u, float* dst, int n, int c0, int cout, int hl, int wl, int variant = -1) {
   if (!src || !u || !dst || n <= 0 || variant > 1) TNV3_FAIL(-1, "conv_up2x_wino: bad argument");
-  if (!conv_up2x_wino_supported(c0, cout, hl, wl))
+  if (!conv_up2x_wino_supported(c0, cout, hl, wl, variant))
     TNV3_FAIL(-1, "conv_up2x_wino: needs C0 > 8, Cout %% 64 == 0, H_low %% 2 == 0, W_low %% 64 == 0 (got %d -> %d, %dx%d)", c0, cout, hl, wl);
   if ((((uintptr_t)dst) & 7) || (((uintptr_t)u | (uintptr_t)src) & 15)) TNV3_FAIL(-1, "conv_up2x_wino: misaligned pointer");
   ConvUp2xWinoArgs a{src, u, dst, n, c0, cout, hl, wl, variant == 1 ? 1 : 0};

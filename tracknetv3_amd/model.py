@@ -144,13 +144,15 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
-    def packed_up2x_wino(self, c0):
-        """U' of the first c0 (upsampled) input channels for the Winograd form of the low-resolution half (ops.conv_up2x_wino)."""
-        key = ("up2xw", int(c0))
+    def packed_up2x_wino(self, c0, variant=None):
+        """U' of the first c0 (upsampled) input channels for the Winograd form of the low-resolution half (ops.conv_up2x_wino; the panel
+        follows the kernel variant)."""
+        v = 2 if ops.up2x_wino_variant(variant) == 2 else 0
+        key = ("up2xw", int(c0), v)
         ver = self._versions(["conv"])
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, ops.pack_up2x_wino_weights(self.conv.weight.detach(), c0))
+            hit = (ver, ops.pack_up2x_wino_weights(self.conv.weight.detach(), c0, variant=v))
             self._cache[key] = hit
         return hit[1]
 
@@ -181,8 +183,11 @@ class Conv2DBlock(nn.Module):
         forward, Winograd skip half): returns (z, tile_stats) -- BatchNorm's batch statistics from the kernel's epilogue."""
         c0, c1 = int(x_low.shape[1]), int(skip.shape[1])
         h, w = int(skip.shape[2]), int(skip.shape[3])
-        if tuning.UP2X_WINO and ops.up2x_wino_supported(c0, self.conv.out_dim, h // 2, w // 2):
-            part = ops.conv_up2x_wino(x_low, self.packed_up2x_wino(c0), self.conv.out_dim)     # 9 of the 16 Winograd GEMMs
+        uv = ops.up2x_wino_variant(tuning.UP2X_WINO_VARIANT if affine else tuning.UP2X_WINO_VARIANT_TRAIN)
+        if tuning.UP2X_WINO and not ops.up2x_wino_supported(c0, self.conv.out_dim, h // 2, w // 2, uv):
+            uv = 0
+        if tuning.UP2X_WINO and ops.up2x_wino_supported(c0, self.conv.out_dim, h // 2, w // 2, uv):
+            part = ops.conv_up2x_wino(x_low, self.packed_up2x_wino(c0, uv), self.conv.out_dim, variant=uv)     # 9 of the 16 F(2x2) GEMMs / 25 of the 36 F(4x4) products
             wskip = None
         else:
             wq, wskip = self.packed_up2x(c0)

@@ -284,29 +284,40 @@ def conv_up2x(src_low, wq, cout, cfg=-1):
     return out
 
 
-def up2x_wino_supported(c0, cout, hl, wl):
-    return bool(_lib.load().tnv3_conv_up2x_wino_supported(int(c0), int(cout), int(hl), int(wl)))
+def up2x_wino_variant(variant=None):
+    """Kernel of the upsampled half's forward (None: tuning.UP2X_WINO_VARIANT): 0 / 1 the 9-GEMM F(2x2) kernel, 2 the 25-product F(4x4) form on
+    the 16x16x4 kernel.  0 / 1 and 2 read different panels: pack and run with the same one."""
+    from . import tuning
+    v = int(tuning.UP2X_WINO_VARIANT if variant is None else variant)
+    return 0 if v < 0 else v
 
 
-def pack_up2x_wino_weights(weight, c0):
+def up2x_wino_supported(c0, cout, hl, wl, variant=None):
+    return bool(_lib.load().tnv3_conv_up2x_wino_supported(int(c0), int(cout), int(hl), int(wl), up2x_wino_variant(variant)))
+
+
+def pack_up2x_wino_weights(weight, c0, variant=None):
     """U' of the first c0 (upsampled) input channels of a decoder-entry layer's weight (tnv3_conv_up2x_wino_pack)."""
     lib = _lib.load()
     _f32(weight)
+    weight = weight.contiguous()
     _lib.dev_check(weight)
+    variant = up2x_wino_variant(variant)
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
-    u = torch.empty(lib.tnv3_conv_up2x_wino_packed_floats(int(c0), cout), dtype=torch.float32, device=weight.device)
-    _lib.check(lib.tnv3_conv_up2x_wino_pack(_lib.ptr(weight), _lib.ptr(u), cout, cin, int(c0), _lib.stream_ptr(weight)))
+    u = torch.empty(lib.tnv3_conv_up2x_wino_packed_floats(int(c0), cout, 2 if variant == 2 else 0), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.tnv3_conv_up2x_wino_pack(_lib.ptr(weight), _lib.ptr(u), cout, cin, int(c0), 2 if variant == 2 else 0, _lib.stream_ptr(weight)))
     return u
 
 
-def conv_up2x_wino(src_low, u, cout, variant=-1):
-    """Partial sums of conv3x3 over the nearest-2x upsampling of src_low in Winograd form, 9 of 16 GEMMs (tnv3_conv_up2x_wino_forward).
-    variant: which wave group runs its MFMAs first (-1 / 0 the older waves: production; 1 round 2's order); same bits."""
+def conv_up2x_wino(src_low, u, cout, variant=None):
+    """Partial sums of conv3x3 over the nearest-2x upsampling of src_low in Winograd form (tnv3_conv_up2x_wino_forward): 9 of the 16 F(2x2)
+    GEMMs (variant 0; 1 = the other wave group's MFMAs first) or 25 of the 36 F(4x4) products (variant 2)."""
     lib = _lib.load()
     _f32(src_low, u)
     _lib.dev_check(src_low, u)
+    variant = up2x_wino_variant(variant)
     n, c0, hl, wl = (int(v) for v in src_low.shape)
-    if u.numel() != lib.tnv3_conv_up2x_wino_packed_floats(c0, int(cout)):
+    if u.numel() != lib.tnv3_conv_up2x_wino_packed_floats(c0, int(cout), 2 if variant == 2 else 0):
         raise _lib.Tnv3Error("conv_up2x_wino: filter buffer does not match the channel counts")
     out = torch.empty((n, int(cout), 2 * hl, 2 * wl), dtype=torch.float32, device=src_low.device)
     if n:

@@ -164,6 +164,11 @@ INFER_SPLIT_MIN_PIXELS = 1 << 19          # batch x H x W below which the launch
 # Upsampled half of the decoder-entry layers: Winograd form with 9 of the 16 GEMMs (kernels/conv_up2x_wino_mfma.h) instead of the
 # four pre-summed 2x2 class filters (conv_up2x_mfma.h): 0.79 -> 0.50 ms per layer at batch 10 (profiles/r02_up2x_wino_ab.json).
 UP2X_WINO = os.environ.get("TNV3_UP2X_WINO", "1") != "0"
+# ... and which Winograd form: 0 = 9 of the 16 F(2x2) GEMMs (kernels/conv_up2x_wino_mfma.h), 2 = 25 of the 36 F(4x4) products on the 16x16x4
+# kernel (kernels/conv3x3_wino43s_mfma.h MODE 1: Lavin's points, 1-5e-6 of the output scale from fp64 -- an addend of the skip half's launch).
+# The eval forward and the training forward choose separately (batch-statistics BatchNorm amplifies the forward's rounding).
+UP2X_WINO_VARIANT = int(os.environ.get("TNV3_UP2X_WINO_VARIANT", "2"))
+UP2X_WINO_VARIANT_TRAIN = int(os.environ.get("TNV3_UP2X_WINO_VARIANT_TRAIN", "0"))
 
 
 # BatchNorm + ReLU backward: the two per-channel sums of block L (sum g, sum g * xhat) taken in the epilogue of the Winograd data-gradient
