@@ -31,7 +31,18 @@ import torch  # noqa: E402
 SEQ_LEN, BG_MODE, H, W = 8, "concat", 288, 512
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (= fp32 vector peak)
 PEAK_HBM_GBPS = 8000.0
-KERNEL_SET = "wino43+wino_a128+wino_stream+up2x_wino"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match)
+KERNEL_SET = "wino43s+up2x_wino43s"   # the conv kernel families of the eval forward (profiles/conv_traffic.json must match, and so must the library)
+
+
+def lib_sha256():
+    """sha256 of the libtnv3_hip.so this process loaded: counter files (profiles/conv_traffic.json) are replayed only for the same build."""
+    import hashlib
+    from tracknetv3_amd import _build
+    try:
+        with open(_build.LIB, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
 ALG_BYTES_PER_SAMPLE = 693.55e6    # SURVEY 8d: ideal-fusion fp32 bytes of one 27->8 forward
 
 
@@ -136,7 +147,7 @@ def cpu_baseline(mode="infer", budget_s=40.0):
     1-thread figure beside the best multi-thread one.
     * infer: configs[1] as written -- eval forward, batch 10, 288x512 (80 frames per run).
     * train: configs[2] shard reduced to batch 2 (a bounded sample: a batch-10 CPU step takes ~1 min) -- mixup with injected
-      draws, forward in train mode, WBCE, backward (autograd), no optimiser.
+      draws, forward in train mode, WBCE, backward (autograd), torch.optim.Adam(lr=1e-3) step on the 53 tensors (train.py:84-96).
     Threads: a short scan at the measured batch over {16, 32, 64, physical cores} keeps the fastest -- running on every SMT thread of a
     2-socket host is several times SLOWER for these shapes (oneDNN), which would flatter the GPU.  Returns frames/s."""
     from oracle import nets
@@ -153,11 +164,19 @@ def cpu_baseline(mode="infer", budget_s=40.0):
             nets.tracknet_forward(sd, x, training=False)
         return time.time() - t
 
+    opt_state = {}
+
     def train_step(x, y):
         t = time.time()
         lam = np.linspace(0.55, 0.95, x.shape[0])
         xm, ym = nets.mixup_injected(x, y, lam, list(range(x.shape[0]))[::-1])
-        nets.tracknet_train_step_grads(sd, xm, ym, torch.float32)
+        _, _, grads, _ = nets.tracknet_train_step_grads(sd, xm, ym, torch.float32)
+        if "opt" not in opt_state:                      # the optimiser step of train.py:96 on the oracle's own tensors
+            opt_state["names"] = list(grads.keys())
+            opt_state["opt"] = torch.optim.Adam([sd[k] for k in opt_state["names"]], lr=1e-3)
+        for k in opt_state["names"]:
+            sd[k].grad = grads[k].to(sd[k].dtype)
+        opt_state["opt"].step()
         return time.time() - t
 
     n = 10 if mode == "infer" else 2
@@ -191,7 +210,7 @@ def cpu_baseline(mode="infer", budget_s=40.0):
         t1 = float(np.median([fwd(x1), fwd(x1)]))
         torch.set_num_threads(best)
         one = {"value": round(SEQ_LEN / t1, 3), "unit": "frames/s", "sample": f"batch 1, median of 2 runs ({t1:.1f} s each)"}
-    what = "eval forward" if mode == "infer" else ("train step (mixup + forward(train) + WBCE + backward, no optimiser; a BOUNDED sample: "
+    what = "eval forward" if mode == "infer" else ("train step (mixup + forward(train) + WBCE + backward + Adam step; a BOUNDED sample: "
                                                    "batch 2 instead of 10 -- a batch-10 CPU step takes about a minute and the thread "
                                                    "scan alone would exhaust the leg's budget; frames/s is per-sample work, so the "
                                                    "figure is comparable)")
@@ -229,7 +248,10 @@ def train_flops_executed_per_sample():
                 return 9 / 36
             return 16 / 36 if t.use_winograd(ci, co, h, w) else 1.0
         if up:
-            upf = conv_flops(c0, 0, co, h, w) * (9 / 36) * 3                                    # forward, data gradient, weight gradient
+            from tracknetv3_amd import ops as _ops
+            uvt = _ops.up2x_wino_variant(t.UP2X_WINO_VARIANT_TRAIN)
+            f_fwd = 6.25 / 36 if (uvt == 2 and _ops.up2x_wino_supported(c0, co, h // 2, w // 2, 2)) else 9 / 36
+            upf = conv_flops(c0, 0, co, h, w) * (f_fwd + 2 * 9 / 36)                           # forward; data gradient, weight gradient (9-GEMM forms)
             sk = conv_flops(c1, 0, co, h, w)
             skip = sk * (frac(c1, t.use_wino43_train(c1, co, h, w)) + frac(c1, t.use_wino43_dgrad(co, c1, h, w)) + (16 / 36 if t.use_winograd_wgrad(c1, co, h, w) else 1.0))
             total += upf + skip
@@ -262,8 +284,7 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
     trainer = TrackNetTrainer(model, opt, alpha=0.5, seed=13)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        ctl_barrier(dev)
         torch.cuda.synchronize(dev)
 
     def data(n, salt):
@@ -280,10 +301,7 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
             loss = trainer.step(x, y)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+        dt = ctl_max([dt], dev)[0]
         return dt, loss
 
     x, y = data(batch, 0)
@@ -344,12 +362,104 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
 
 def bench_train(args, dev, rank, world):
     import torch.distributed as dist
+    rccl = _CTL["rccl"]
+    if rccl is not None and not rccl["ok"]:
+        if rank == 0:
+            print(json.dumps({"metric": "frames/sec (288x512, seq_len=8) TrackNet training", "value": None, "n_gpus": world,
+                              "error": "RCCL first contact failed: " + str(rccl.get("error")), "rccl": rccl}), flush=True)
+        sys.stdout.flush()
+        os._exit(3)
     out = train_leg(dev, rank, world, args.batch, args.steps, args.warmup, record_timing=True, strong_steps=args.strong_steps)
+    out["rccl"] = rccl
     if rank == 0:
         out["cpu_baseline"] = cpu_baseline("train", budget_s=30.0) if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+# ---- control plane of an N > 1 run.  The bench's OWN barriers and reductions of timings go through a gloo group (host tensors): they are
+#      measurement plumbing and must not depend on the transport under test.  RCCL is used where the product uses it -- the gradient
+#      all-reduce of the training step (tracknetv3_amd/parallel.py) -- after one watched first contact: if communicator set-up or the
+#      first all-reduce does not finish in RCCL_WATCHDOG_S seconds, the rank reports who hung (rank, device, NCCL_DEBUG tail), the training
+#      leg becomes {"error": ...}, the inference leg (no collective in its data path) is still measured, and the process leaves through
+#      os._exit (a thread stuck inside the communicator cannot be joined).  HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) is set for every
+#      rank: this host driver has no legacy IPC handles, and RCCL's intra-node transport fails without it (hipIpcGetMemHandle: invalid argument).
+RCCL_WATCHDOG_S = float(os.environ.get("TNV3_RCCL_WATCHDOG_S", "60"))
+_CTL = {"group": None, "rccl": None}
+
+
+def _dev_sync(dev):
+    if getattr(dev, "type", "cuda") == "cuda":
+        torch.cuda.synchronize(dev)
+
+
+def ctl_barrier(dev):
+    _dev_sync(dev)
+    if _CTL["group"] is not None:
+        import torch.distributed as dist
+        dist.barrier(group=_CTL["group"])
+
+
+def ctl_max(vals, dev):
+    if _CTL["group"] is None:
+        return [float(v) for v in vals]
+    import torch.distributed as dist
+    t = torch.tensor(list(vals), dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTL["group"])
+    return [float(v) for v in t.tolist()]
+
+
+def _nccl_debug_tail(rank, lines=12):
+    path = os.environ.get("NCCL_DEBUG_FILE", "").replace("%r", str(rank)).replace("%h", "host").replace("%p", str(os.getpid()))
+    try:
+        with open(path) as f:
+            return f.read().splitlines()[-lines:]
+    except OSError:
+        return []
+
+
+def rccl_first_contact(dev, rank, world, backend):
+    """One all-reduce over the default (RCCL) group under a watchdog.  Returns {"ok": True, "first_allreduce_ms": ...} or
+    {"ok": False, "error": ..., "rank": ..., "nccl_debug_tail": [...]}; every rank learns the verdict of all (gloo MIN)."""
+    import threading
+    import torch.distributed as dist
+    res = {}
+
+    def probe():
+        try:
+            t = torch.ones(1 << 20, device=dev if backend == "nccl" else "cpu")      # (gloo: the --share-gpus test mode, host tensors)
+            _dev_sync(dev)
+            t0 = time.perf_counter()
+            dist.all_reduce(t)
+            _dev_sync(dev)
+            res["ms"] = (time.perf_counter() - t0) * 1e3
+            res["ok"] = bool(abs(float(t[0].item()) - world) < 1e-3)
+            if not res["ok"]:
+                res["error"] = f"all-reduce of ones over {world} ranks returned {float(t[0].item())}"
+        except Exception as e:  # noqa: BLE001
+            res["ok"], res["error"] = False, f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=probe, daemon=True)
+    th.start()
+    th.join(RCCL_WATCHDOG_S)
+    if th.is_alive():
+        res = {"ok": False, "error": f"no answer from the first {backend} all-reduce within {RCCL_WATCHDOG_S:.0f} s (communicator set-up or the collective hangs)",
+               "hung": True}
+    mine = 1.0 if res.get("ok") else 0.0
+    flags = torch.tensor([mine], dtype=torch.float64)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=_CTL["group"])
+    out = {"ok": bool(flags.item() > 0.5), "backend": backend, "watchdog_s": RCCL_WATCHDOG_S}
+    if res.get("ok"):
+        out["first_allreduce_ms"] = round(res["ms"], 2)
+    if not out["ok"]:
+        out["error"] = res.get("error", "another rank failed its first contact")
+        out["rank"], out["device"], out["hung_here"] = rank, str(dev), bool(res.get("hung"))
+        out["nccl_debug_tail"] = _nccl_debug_tail(rank)
+        print(f"[bench] rank {rank} on {dev}: RCCL first contact FAILED: {out['error']}", file=sys.stderr, flush=True)
+        for line in out["nccl_debug_tail"]:
+            print(f"[bench] rank {rank} NCCL: {line}", file=sys.stderr, flush=True)
+    return out
 
 
 def self_spawn(n, share_gpus=False):
@@ -366,6 +476,8 @@ def self_spawn(n, share_gpus=False):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("NCCL_DEBUG", "WARN")                   # what a failed first contact prints (rccl_first_contact reads the tail)
+    env.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "tnv3_bench_nccl_%r.log"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print("[bench] spawning: " + " ".join(cmd), file=sys.stderr, flush=True)
@@ -511,12 +623,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=max(120.0, 4 * RCCL_WATCHDOG_S)))
         else:
             dist.init_process_group("gloo")
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+        _CTL["group"] = dist.new_group(backend="gloo")       # the bench's own barriers / reductions: never the transport under test
+        _CTL["rccl"] = rccl_first_contact(dev, rank, world, args.backend)
     n_gpus = world
 
     from tracknetv3_amd import _lib, ops
@@ -527,8 +643,7 @@ def main():
 
     if args.tune and rank == 0:
         tune(dev, args.batch, [os.path.join(ROOT, "gpurun_out", "conv_tuning.json")])
-    if world > 1:
-        dist.barrier()
+    ctl_barrier(dev)
 
     if args.mode == "train":
         return bench_train(args, dev, rank, world)
@@ -556,16 +671,11 @@ def main():
     timed_up2xw, timed_w43 = timed("up2x", ops_up2xw), timed("conv", ops_w43)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        ctl_barrier(dev)
         torch.cuda.synchronize(dev)
 
     def max_over_ranks(vals):
-        if world == 1:
-            return [float(v) for v in vals]
-        t = torch.tensor(list(vals), device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return [float(v) for v in t.tolist()]
+        return ctl_max(vals, dev)
 
     def block(n_steps):
         """Exactly n_steps forward passes between barrier + synchronize on both sides; seconds, max over ranks."""
@@ -657,7 +767,13 @@ def main():
         def executed(c0, c1, co, h, w, up):
             if up:
                 skip = conv_flops(c1, 0, co, h, w) * plain_frac(c1, co, h, w, skip_half=True)
-                up_frac = 9 / 36 if (_tuning.UP2X_WINO and ops.up2x_wino_supported(c0, co, h // 2, w // 2)) else 4 / 9
+                uv = ops.up2x_wino_variant(_tuning.UP2X_WINO_VARIANT)
+                if _tuning.UP2X_WINO and ops.up2x_wino_supported(c0, co, h // 2, w // 2, uv):
+                    up_frac = (6.25 if uv == 2 else 9) / 36          # 25 of the 36 F(4x4) products per 4x4 tile / 9 of the 16 F(2x2) GEMMs
+                elif _tuning.UP2X_WINO and ops.up2x_wino_supported(c0, co, h // 2, w // 2, 0):
+                    up_frac = 9 / 36
+                else:
+                    up_frac = 4 / 9
                 return conv_flops(c0, 0, co, h, w) * up_frac + skip
             return conv_flops(c0, c1, co, h, w) * plain_frac(c0, co, h, w)
         fl_exec = np.array([executed(c0, c1, co, h, w, up) * args.batch for (_, c0, c1, co, h, w, up) in layers])
@@ -687,10 +803,13 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "conv_traffic.json")) as f:
                 tj = json.load(f)
-            if int(tj.get("conv_launches_per_step", -1)) == launches_per_step and tj.get("kernel_set") == KERNEL_SET:
+            sha = lib_sha256()
+            if (int(tj.get("conv_launches_per_step", -1)) == launches_per_step and tj.get("kernel_set") == KERNEL_SET and sha is not None
+                    and tj.get("lib_sha256") == sha):
                 traffic = float(tj["traffic_bytes_per_launch"])
-                traffic_src = {"file": "profiles/conv_traffic.json", "commit": tj.get("commit"), "taken_utc": tj.get("taken_utc"),
-                               "note": "PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE over the conv launches of this same command"}
+                traffic_src = {"file": "profiles/conv_traffic.json", "commit": tj.get("commit"), "taken_utc": tj.get("taken_utc"), "lib_sha": sha,
+                               "note": "PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE over the conv launches of this same command, taken on "
+                                       "the library with this sha256 (the one loaded now); any other build reports null"}
         except (OSError, KeyError, ValueError, TypeError):
             pass
         to_ms = lambda sec: round(sec / args.steps * 1e3, 4)      # noqa: E731
@@ -716,8 +835,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch",
-                         "kernel": f"conv3x3_wino43_kernel + conv3x3_wino_a128_stream_kernel<*> + conv3x3_wino_stream_mfma_kernel<*> + "
-                                   f"conv_up2x_wino_stream_kernel ({launches_per_step} launches/step for the 17 conv layers, fp32 MFMA 32x32x2)",
+                         "kernel": f"conv3x3_wino43s_kernel<CBW 4 | 8, MODE 0 plain | 1 upsampled half> ({launches_per_step} launches/step for the 17 "
+                                   f"conv layers, fp32 MFMA 16x16x4)",
+                         "lib_sha256": lib_sha256(),
                          "measured": "second pass of the same K-step blocks with the whole batch on ONE stream (model.no_infer_split) and HIP "
                                      "events around every conv launch: a launch's duration is its own, not stretched by the other half's "
                                      "co-running launches; per layer the MEDIAN over all timed steps; `single_stream_ms_per_step` is "
@@ -732,10 +852,10 @@ def main():
                          "effective_tflops": round(effective, 2),
                          "speedup_vs_direct_flops": round(float(fl.sum() / fl_exec.sum()), 3),
                          "note": "`achieved` / `frac` = FLOPs the matrix pipe EXECUTES per second over the fp32 MFMA peak (an honest "
-                                 "roofline position, <= 1).  The three decoder-entry layers evaluate their upsampled channels at the "
-                                 "low resolution in a Winograd form that keeps 9 of the 16 GEMMs (9/36 of those multiply-adds) and the plain layers run in fused "
-                                 "Winograd form -- F(4x4,3x3) (36 products per 4x4 tile: 9/36) on the 288x512 / 144x256 / 72x128 levels from 32 input "
-                                 "channels up, F(2x2,3x3) (16/36) elsewhere --, so the executed count is `executed_gflop_per_step`; "
+                                 "roofline position, <= 1).  Every 3x3 layer of the eval forward runs in fused Winograd F(4x4,3x3) form on the "
+                                 "16x16x4 kernel: the 14 plain layers and the 3 skip halves with 36 products per 4x4 output tile (9/36 of the "
+                                 "direct multiply-adds), the 3 upsampled halves of the decoder entries at the low resolution with 25 of the 36 "
+                                 "(6.25/36), so the executed count is `executed_gflop_per_step`; "
                                  "`effective_tflops` prices the same kernel time at the reference's algorithmic count "
                                  "(2*9*Cin*Cout*H*W per layer, SURVEY 8d) and may exceed the peak -- it is a speed-up over the direct "
                                  "form, not a roofline fraction",
@@ -751,14 +871,19 @@ def main():
     train = None
     del model, x
     torch.cuda.empty_cache()
+    rccl = _CTL["rccl"]
     if args.train_steps > 0:
-        try:
-            train = train_leg(dev, rank, world, args.batch, args.train_steps, 2, record_timing=True, strong_steps=args.strong_steps)
-        except Exception as e:  # noqa: BLE001 -- the inference line must survive a failing training leg (e.g. a collective error)
-            train = {"error": f"{type(e).__name__}: {e}"}
+        if rccl is not None and not rccl["ok"]:            # the collective never came up: the inference line above stands, the training leg says why
+            train = {"error": "RCCL first contact failed: " + str(rccl.get("error"))}
+        else:
+            try:
+                train = train_leg(dev, rank, world, args.batch, args.train_steps, 2, record_timing=True, strong_steps=args.strong_steps)
+            except Exception as e:  # noqa: BLE001 -- the inference line must survive a failing training leg (e.g. a collective error)
+                train = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     if rank == 0:
         out["train"] = train
+        out["rccl"] = rccl
         if args.extras and n_gpus == 1:
             for key, leg in (("inpaintnet", inpaintnet_leg), ("e2e", e2e_leg)):
                 try:
@@ -774,7 +899,10 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        ctl_barrier(dev)
+        if rccl is not None and not rccl["ok"]:
+            sys.stdout.flush()
+            os._exit(3)                                    # a thread may still sit inside the communicator: no clean teardown; non-zero for the launcher
         dist.destroy_process_group()
 
 

@@ -1,5 +1,5 @@
 """profiles/conv_traffic.json from the two PMC passes (rocpd_pmc.py CSVs of `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`).
-usage: conv_traffic.py <fetch_pmc.csv> <write_pmc.csv> <steps_in_the_profiled_run> <out.json> [commit]
+usage: conv_traffic.py <fetch_pmc.csv> <write_pmc.csv> <steps_in_the_profiled_run> <out.json> [commit] [sha256 of the library that ran]
 bench.py reports `roofline.traffic` from this file only when its launch list (`conv_launches_per_step`, `kernel_set`) matches
 the run, together with the commit / time recorded here."""
 import csv, json, sys, time
@@ -8,14 +8,16 @@ import csv, json, sys, time
 def conv_sum(path, counter):
     tot, disp = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if any(k in r["kernel"] for k in ("conv3x3_mfma_kernel", "conv_up2x_mfma_kernel", "conv3x3_wino_mfma_kernel", "conv3x3_wino_split_mfma_kernel", "conv3x3_wino_v3_mfma_kernel", "conv3x3_wino_stream_mfma_kernel", "conv3x3_wino_a128_stream_kernel", "conv3x3_wino43_kernel", "conv_up2x_wino_stream_kernel")) and r["counter"] == counter:
+        if any(k in r["kernel"] for k in ("conv3x3_mfma_kernel", "conv_up2x_mfma_kernel", "conv3x3_wino_mfma_kernel", "conv3x3_wino_split_mfma_kernel", "conv3x3_wino_v3_mfma_kernel", "conv3x3_wino_stream_mfma_kernel", "conv3x3_wino_a128_stream_kernel", "conv3x3_wino43_kernel", "conv3x3_wino43s_kernel", "conv_up2x_wino_stream_kernel")) and r["counter"] == counter:
             tot += float(r["sum"]); disp += int(r["dispatches"])
     return tot, disp
 
 
 # bytes the 20 conv launches of a batch-10 288x512 step must write: (4 x 64 ch @288x512 + 4 x 128 @144x256 + 6 x 256 @72x128 + 3 x 512 @36x64
 # layer outputs) + the three decoder-entry partial sums (256 @72x128, 128 @144x256, 64 @288x512), fp32
-KNOWN_WRITE = 10 * 4.0 * (4 * 64 * 288 * 512 + 4 * 128 * 144 * 256 + 6 * 256 * 72 * 128 + 3 * 512 * 36 * 64 + 256 * 72 * 128 + 128 * 144 * 256 + 64 * 288 * 512)
+# (+ round 4: the three pooled tensors the down blocks' last layers write from their write-out: 64 @144x256, 128 @72x128, 256 @36x64)
+KNOWN_WRITE = 10 * 4.0 * (4 * 64 * 288 * 512 + 4 * 128 * 144 * 256 + 6 * 256 * 72 * 128 + 3 * 512 * 36 * 64 + 256 * 72 * 128 + 128 * 144 * 256 + 64 * 288 * 512
+                          + 64 * 144 * 256 + 128 * 72 * 128 + 256 * 36 * 64)
 
 
 def main():
@@ -29,7 +31,7 @@ def main():
     fetch = 2.0 * fetch_raw                       # MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes
     json.dump({
         "commit": sys.argv[5] if len(sys.argv) > 5 else None, "taken_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
-        "kernel_set": "wino43+wino_a128+wino_stream+up2x_wino",
+        "kernel_set": "wino43s+up2x_wino43s", "lib_sha256": sys.argv[6] if len(sys.argv) > 6 else None,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
                   f"bench.py --steps {steps - 1} --warmup 1 --blocks 1 --overlap-streams 0 --infer-split 0, MI355X (raw per-kernel sums: "
                   "the two CSVs given on the command line; made by scripts/conv_traffic.py)",

@@ -15,4 +15,5 @@ run sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VAL
 run tcc TCC_HIT_sum TCC_MISS_sum
 cd $REPO
 for d in sq1 sq2 sq3 tcc; do for f in $(find $OUT/pmc_$d -name "*.db" 2>/dev/null); do python scripts/rocpd_pmc.py $f $OUT/pmc_${d}.csv; python scripts/rocpd_summary.py $f $OUT/pmc_${d}_kernel_stats.csv; done; tail -3 $OUT/pmc_$d.err; done
+python scripts/sq_summary.py $OUT 3 > $OUT/infer_sq_summary.json 2>> $OUT/pmc_tcc.err
 find $OUT -name "*.db" -delete

@@ -27,6 +27,7 @@ mkdir -p $OUT
 LOG=$OUT/session.log
 : > $LOG
 has() { [[ " $PARTS " == *" $1 "* ]]; }
+sha256sum tracknetv3_amd/libtnv3_hip.so | cut -d" " -f1 > $OUT/lib_sha256.txt      # which build this session measured
 if has host; then
   python -c "import cv2; print('cv2', cv2.__version__)" > $OUT/cv2_probe.txt 2>&1
   nproc > $OUT/host.txt; grep -m1 "model name" /proc/cpuinfo >> $OUT/host.txt; rocm-smi --showproductname 2>/dev/null | head -20 >> $OUT/host.txt

@@ -41,6 +41,10 @@ def main():
             "mfma_instructions": g("SQ_INSTS_MFMA"), "gui_active_cycles": g("GRBM_GUI_ACTIVE"),
         }
         out[k] = row
+    try:                                              # which build the counters describe (scripts/gpu_session.sh writes it next to them)
+        out["lib_sha256"] = open(os.path.join(base, "lib_sha256.txt")).read().strip()
+    except OSError:
+        out["lib_sha256"] = None
     print(json.dumps(out, indent=1))
 
 

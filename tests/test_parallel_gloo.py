@@ -82,3 +82,44 @@ def test_shard_range_covers_batch():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _watchdog_worker(rank, world, port, out, hang_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    bench._CTL["group"] = dist.new_group(backend="gloo")
+    bench.RCCL_WATCHDOG_S = 2.0
+    if rank == hang_rank:                                  # this rank's "collective" does not come up in time
+        real = dist.all_reduce
+
+        def slow(t, *a, **kw):
+            if not kw.get("group") and not a[1:]:
+                time.sleep(5.0)
+            return real(t, *a, **kw)
+        dist.all_reduce = slow
+    rep = bench.rccl_first_contact(torch.device("cpu"), rank, world, "gloo")
+    out[rank] = rep
+    time.sleep(4.0)                                        # let the late all-reduce of the hung rank finish before the group goes away
+    os._exit(0)
+
+
+@pytest.mark.parametrize("hang_rank", [-1, 1])
+def test_bench_first_contact_watchdog_reports_instead_of_hanging(hang_rank):
+    """bench.py's RCCL first-contact insurance on the gloo stand-in: a healthy group reports ok with a timing; a rank whose first
+    all-reduce does not answer within the watchdog makes EVERY rank report the failure (with the rank that hung) instead of hanging
+    the record."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_watchdog_worker, args=(world, port, out, hang_rank), nprocs=world, join=True)
+        r0, r1 = dict(out[0]), dict(out[1])
+    if hang_rank < 0:
+        assert r0["ok"] and r1["ok"] and r0["first_allreduce_ms"] > 0
+    else:
+        assert not r0["ok"] and not r1["ok"]
+        assert "within 2 s" in r0["error"] and r1["hung_here"] and r0["watchdog_s"] == 2.0
