@@ -37,8 +37,9 @@ extern "C" {
                                  4: `sum_order` on tnv3_ensemble_frames (the reference's summation order, bit-exact); `variant` on the
                                     9-GEMM decoder kernels; the fused InpaintNet training entries; tnv3_conv3x3_wino_pick / _has_stats /
                                     _pack_multi; tnv3_conv3x3_wgrad_wino variants 2-7 and any Cin;
-                                 5: `variant` on the tnv3_conv3x3_wino43_* entries (0: the 16x16x4 one-wave-per-block kernel, 1: the
-                                    32x32x2 kernel); pack-multi layout 4 */
+                                 5: `variant` on the tnv3_conv3x3_wino43_* and tnv3_conv_up2x_wino_* entries (0 / 2: the MFMA 16x16x4
+                                    kernels, 1: the 32x32x2 kernel); `pool_dst` on tnv3_conv3x3_wino43_forward; pack-multi layout 4;
+                                    tnv3_conv3x3_wgrad_wino variant 8 (F(4x4)), the default where h % 4 == 0 */
 
 typedef void* tnv3_stream_t;
 
@@ -228,18 +229,23 @@ int tnv3_dgrad_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c
 int tnv3_dgrad_up2x_wino(const float* dz, const float* u, float* dx_low, int n, int c0, int cout, int h_low, int w_low, int variant,
                          tnv3_stream_t stream);
 
-/* Weight gradient of a plain layer (single source, no upsampling) in Winograd F(2x2, 3x3) form: dw[cout][cin][3][3] =
- * G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- 16 instead of 36 multiply-adds per (co, ci, 2x2 tile); same gradient as
- * tnv3_conv3x3_wgrad up to fp32 rounding; deterministic (fixed-order split-K sum).
- *   supported: cout % 64 == 0, h % 2 == 0, w % 16 == 0, any cin with kernel 5 (a partial last block of 64 input channels: the stem
- *   layer), cin % 64 == 0 with kernels 0-4;  workspace 16-byte aligned, size from the query.
- *   `variant` (per call): -1 = the library's default (1; 5 when cin % 64 != 0);  1 = two waves per SIMD, the wave groups half a
+/* Weight gradient of a plain layer (single source, no upsampling) in Winograd form: dw[cout][cin][3][3] =
+ * G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- per (co, ci) 36 multiply-adds per 4x4 tile in F(4x4, 3x3) form (2.25 per pixel), 16
+ * per 2x2 tile in F(2x2, 3x3) form (4 per pixel), where the direct form spends 9 per pixel; same gradient as tnv3_conv3x3_wgrad up to
+ * fp32 rounding (F(2x2): 6e-7, F(4x4): 2-4e-6 of max|dw| at batch 10); deterministic (fixed-order split-K sum).
+ *   supported: cout % 64 == 0, h % 2 == 0, w % 16 == 0; any cin with kernels 5 / 6 / 8 (a partial last block of input channels: the
+ *   stem layer), cin % 64 == 0 with kernels 0-4 and 7; kernel 8 needs h % 4 == 0;  workspace 16-byte aligned, size from the query
+ *   (it covers every variant).
+ *   `variant` (per call): -1 = the library's default: 8 where h % 4 == 0, else 1 (5 when cin % 64 != 0);
+ *   8 = F(4x4, 3x3) with the interpolation points of tnv3_conv3x3_wino43_forward (kernels/wgrad_wino43_mfma.h): 64 co x 32 ci per
+ *   workgroup, MFMA 16x16x4 with K = the four 4x4 tiles of a 4 x 16 pixel strip, both operands transformed in the shadow of the
+ *   MFMAs, split-K slabs of 9 taps -- 1.45-1.5x faster than 1 on every TrackNet shape, 2.6x on the stem;
+ *   the F(2x2) kernels: 1 = two waves per SIMD, the wave groups half a
  *   period apart (one transforms while the other streams MFMAs), paired transforms, buffer-descriptor LDS-DMA;  5 = every wave
  *   streams its MFMAs of a chunk and transforms its tile pair of the next chunk between them (16-byte operand reads, three raw
- *   stages: the fastest call, but its 240 registers and 160 KB of LDS leave no room for another stream's small kernels on the CU --
- *   the training step is faster with 1);  6 = 5 with two raw stages (128 KB);  2 / 3 = 1 with 16-byte operand reads and two /
- *   three raw stages;  4 = 3 with the Yh transform moved into the MFMA phase;  0 = the first kernel (one wave per SIMD, transform
- *   and MFMA phases alternate).  All accumulate in the same order: bit-identical results. */
+ *   stages);  6 = 5 with two raw stages (128 KB);  2 / 3 = 1 with 16-byte operand reads and two /
+ *   three raw stages;  4 = 3 with the Yh transform moved into the MFMA phase;  7 = 1 with it;  0 = the first kernel (one wave per
+ *   SIMD, transform and MFMA phases alternate).  Kernels 0-7 accumulate in the same order: bit-identical results. */
 int tnv3_conv3x3_wgrad_wino_supported(int cin, int cout, int h, int w);
 size_t tnv3_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w);
 int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes, int n, int cin, int cout,
@@ -252,7 +258,8 @@ int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* wo
  * Deterministic (split-K slabs reduced in a fixed order); workspace from the _workspace_bytes query, 16-byte aligned.
  * `wino_variant` (per call): -1 = the default -- upsampled half in the 9-GEMM Winograd form of tnv3_conv_up2x_wino_forward
  * (9 instead of 16 multiply-adds per low-res pixel; needs c0 % 128 == 0, cout % 64 == 0, w_low % 8 == 0, else the next), skip half
- * by the default kernel of tnv3_conv3x3_wgrad_wino;  2 .. 6 = the same with kernel 1 / 3 / 4 / 5 / 6 for the skip half;  1 = upsampled
+ * by the default kernel of tnv3_conv3x3_wgrad_wino (the F(4x4) kernel 8 where h % 4 == 0);  8 = the same;  2 .. 7 = the same with
+ * the F(2x2) kernel 1 / 3 / 4 / 5 / 6 / 7 for the skip half;  1 = upsampled
  * half by four 2x2-window launches over the parity images of dz, skip half by kernel 1;  0 = 1 with the first Winograd kernel for
  * the skip half.  All compute the same gradient up to fp32 rounding. */
 size_t tnv3_conv3x3_wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int h_low, int w_low);

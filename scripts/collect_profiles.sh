@@ -22,7 +22,7 @@ for f in up2x_wino_ab dgrad_up2x_ab wgrad_up_sweep wgrad_wino_ab; do [ -f $O/$f.
 # (the library that ran on the GPU box is the one in the tree: the session ships the tree; its sha256 keys the counters to the build)
 python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json ${COMMIT:-$(git rev-parse --short HEAD)} $(cat $O/lib_sha256.txt 2>/dev/null || sha256sum tracknetv3_amd/libtnv3_hip.so | cut -d" " -f1)
 [ -f $O/lib_sha256.txt ] && cp $O/lib_sha256.txt $P/${R}_lib_sha256.txt
-for f in wino43_variant_ab up2x_wino43_ab wino43s_timeline; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
+for f in wino43_variant_ab up2x_wino43_ab wino43s_timeline wgrad_wino43_ab; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
 for f in fullsize_train_parity_n2_f43fwd fullsize_train_parity_n2_f22fwd fullsize_train_parity_n10_default; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
 [ -f $O/infer_sq_summary.json ] && cp $O/infer_sq_summary.json $P/${R}_infer_sq_summary.json
 cp $O/session.log $P/${R}_session_final.log

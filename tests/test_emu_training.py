@@ -92,14 +92,22 @@ def _wgrad_up2x_case(case, device):
     wd = T((cout, c0 + c1, 3, 3), 34, -0.3, 0.3).double().requires_grad_(True)
     x = torch.cat([xl.repeat_interleave(2, 2).repeat_interleave(2, 3), skip], 1)
     F.conv2d(x.double(), wd, padding=1).backward(dz.double())
-    dw = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device))
-    dw2 = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device))
+    dw = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=2)      # 9-GEMM form + F(2x2) kernel 1 for the skip half
+    dw2 = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=2)
     assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
     for v in (0, 1):                             # the older kernel choices compute the same gradient
         dwv = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=v)
         assert rel_err(dwv.cpu(), dw.cpu().double()) <= 4e-6, v
-    for v in (2, 3, 4, 5, 6, 7):                 # 9-GEMM form + another (bit-identical) generation of the skip half's kernel
+    for v in (3, 4, 5, 6, 7):                    # 9-GEMM form + another (bit-identical) F(2x2) generation of the skip half's kernel
         assert torch.equal(dw, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=v)), v
+    # the default (-1): the skip half by the F(4x4) kernel where it applies (H % 4 == 0, C1 % 64 == 0) -- same upsampled half, deterministic
+    dwd = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=-1)
+    assert torch.equal(dwd, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device)))
+    assert torch.equal(dwd, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=8))
+    assert torch.equal(dwd[:, :c0], dw[:, :c0])
+    if (2 * hl) % 4 or c1 % 64:
+        assert torch.equal(dwd, dw)
+    assert rel_err(dwd.cpu(), wd.grad) <= 8e-6
     return rel_err(dw.cpu(), wd.grad), rel_err(dw.cpu()[:, :c0], wd.grad[:, :c0])
 
 
@@ -118,15 +126,63 @@ def _wgrad_wino_case(case, device):
     x, dz = torch.relu(T((n, cin, h, w), 51)), T((n, cout, h, w), 52)
     wd = T((cout, cin, 3, 3), 53, -0.3, 0.3).double().requires_grad_(True)
     F.conv2d(x.double(), wd, padding=1).backward(dz.double())
-    dw = ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))
-    assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device))), "split-K reduction must be deterministic"
-    # every kernel generation accumulates every element in the same order: bit-identical gradients
+    f22 = 1 if cin % 64 == 0 else 5
+    dw = ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=f22)
+    assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=f22)), "split-K reduction must be deterministic"
+    # the default (-1): the F(4x4) kernel where it applies (H % 4 == 0), else the F(2x2) generation above
+    dwd = ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=-1)
+    assert torch.equal(dwd, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device)))
+    assert torch.equal(dwd, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=8) if h % 4 == 0 else dw)
+    # every F(2x2) kernel generation accumulates every element in the same order: bit-identical gradients
     for v in ((0, 1, 2, 3, 4, 5, 6, 7) if cin % 64 == 0 else (5, 6)):        # a partial block of input channels (the stem): the production kernel only
         assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=v)), v
     if cin % 64:
         with pytest.raises(Exception, match="Cin % 64"):
             ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=1)
     return rel_err(dw.cpu(), wd.grad)
+
+
+# F(4x4) weight gradient (kernel variant 8; H % 4 == 0): not bit-identical to the F(2x2) generations -- against fp64 autograd.
+# (n, cin, cout, h, w): 27 = the stem (a partial block of 32 input channels), 100 = three full blocks + a partial one; (3, 64, 64, 8, 48):
+# strips over images, tile rows and columns; borders on every side
+WGRAD_WINO43_CASES = [(1, 64, 64, 4, 16), (2, 64, 128, 8, 32), (2, 27, 64, 8, 32), (1, 100, 64, 4, 16), (3, 64, 64, 8, 48), (1, 32, 64, 12, 64)]
+
+
+def _wgrad_wino43_case(case, device):
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = case
+    x, dz = torch.relu(T((n, cin, h, w), 51)), T((n, cout, h, w), 52)
+    wd = T((cout, cin, 3, 3), 53, -0.3, 0.3).double().requires_grad_(True)
+    F.conv2d(x.double(), wd, padding=1).backward(dz.double())
+    dw = ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=8)
+    assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=8)), "split-K reduction must be deterministic"
+    return rel_err(dw.cpu(), wd.grad)
+
+
+@pytest.mark.parametrize("case", WGRAD_WINO43_CASES)
+def test_wgrad_wino43_emulated_vs_autograd(emu, case):
+    assert _wgrad_wino43_case(case, "cpu") <= 8e-6
+
+
+@pytest.mark.parametrize("cus", [1, 2, 3, 5])
+def test_wgrad_wino43_long_strip_walks_emulated(emu, monkeypatch, cus):
+    """Few CUs -> small split-K -> every workgroup walks many strips (column, tile-row and image carries of the cursors; loads two steps
+    ahead; shares of 1, 2 strips and uneven shares)."""
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+    assert _wgrad_wino43_case((3, 64, 64, 8, 48), "cpu") <= 8e-6
+    assert _wgrad_wino43_case((2, 27, 64, 4, 32), "cpu") <= 8e-6
+
+
+def test_wgrad_wino43_with_lds_dma_landing_late(emu, monkeypatch):
+    monkeypatch.setenv("TNV3_EMU_LAZY_DMA", "1")
+    monkeypatch.setenv("TNV3_EMU_CUS", "2")
+    assert _wgrad_wino43_case((2, 27, 64, 8, 32), "cpu") <= 8e-6
+
+
+def test_wgrad_wino43_refuses_heights_that_are_not_a_multiple_of_four(emu):
+    from tracknetv3_amd import ops
+    with pytest.raises(Exception, match="H % 4"):
+        ops.conv3x3_wgrad_wino(T((1, 64, 6, 16), 1), T((1, 64, 6, 16), 2), variant=8)
 
 
 # emulator-only: 5 and 7 strips of work -> split-K counts whose quarters are uneven / partly empty in the fold kernel
@@ -504,7 +560,7 @@ def test_one_launch_repack_skips_panels_only_the_eval_forward_reads(emu):
         bump()
         eval_use()                                    # validation: eval panels packed one by one, fresh
         assert m.repack_wino_panels() == 6            # the training panels only
-        before = [b._cache[("w43", 0)][1].clone() for b in blocks]
+        before = [b._cache[("w43", 0, ops.wino43_variant(None))][1].clone() for b in blocks]
         train_use()
         bump()
         assert m.repack_wino_panels() == 6            # eval panels are stale now, but nobody asked for them since the last repack

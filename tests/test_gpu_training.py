@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from conftest import GOLDEN
 from oracle import nets
-from test_emu_training import T, WGRAD_UP2X_CASES, WGRAD_WINO_CASES, _wgrad_up2x_case, _wgrad_wino_case, rel_err
+from test_emu_training import T, WGRAD_UP2X_CASES, WGRAD_WINO43_CASES, WGRAD_WINO_CASES, _wgrad_up2x_case, _wgrad_wino43_case, _wgrad_wino_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -90,6 +90,13 @@ def test_wgrad_up2x_vs_autograd(gpu_device, case):
 @pytest.mark.parametrize("case", WGRAD_WINO_CASES + [(2, 256, 256, 72, 128), (1, 512, 512, 36, 64), (2, 128, 256, 18, 64)])
 def test_wgrad_wino_vs_autograd(gpu_device, case):
     assert _wgrad_wino_case(case, gpu_device) <= 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WGRAD_WINO43_CASES + [(2, 256, 256, 72, 128), (1, 512, 512, 36, 64), (2, 128, 256, 20, 64), (2, 27, 64, 288, 512)])
+def test_wgrad_wino43_vs_autograd(gpu_device, case):
+    """The F(4x4) weight gradient (kernel variant 8) against fp64 autograd, up to the stem at full size (long strip walks per workgroup)."""
+    assert _wgrad_wino43_case(case, gpu_device) <= 8e-6
 
 
 def test_wbce_head_pool_upsample_mixup(gpu_device):

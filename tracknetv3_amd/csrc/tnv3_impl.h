@@ -25,6 +25,7 @@
 #include "kernels/train_ops.h"
 #include "kernels/wgrad3x3_mfma.h"
 #include "kernels/wgrad_wino_mfma.h"
+#include "kernels/wgrad_wino43_mfma.h"
 
 namespace tnv3 {
 
@@ -1119,11 +1120,41 @@ inline int wgrad_wino_splitk(int n, int cin, int cout, int h, int w) {
   }
   return best_sk;
 }
+// ... and in F(4x4, 3x3) form (kernels/wgrad_wino43_mfma.h; kernel variant 8): 64 co x 32 ci per workgroup, a K unit = one strip of 4 x 16 pixels
+constexpr int kWgradWino43Variant = 8;
+inline bool wgrad_wino43_supported(int cin, int cout, int h, int w) {
+  return cin > 0 && cout > 0 && cout % 64 == 0 && h % 4 == 0 && w % 16 == 0 && (long)(cin > cout ? cin : cout) * h * w * 4 < (1l << 31);
+}
+inline int wgrad_wino43_splitk(int n, int cin, int cout, int h, int w) {
+  const int nb = (cout / WgradWino43Cfg::MB) * ((cin + WgradWino43Cfg::CB - 1) / WgradWino43Cfg::CB);
+  const long strips = (long)n * (h / 4) * (w / 16);
+  const int cus = num_cus();
+  int best_sk = 1;
+  double best = 1e300;
+  const long cap = strips < 4096 ? strips : 4096;
+  for (int sk = 1; sk <= cap; ++sk) {
+    const long blocks = (long)nb * sk;
+    if (sk > 1 && blocks > 16l * cus) break;
+    // one workgroup per CU; ~8 step-times of prologue, G^T S G and the slab write per workgroup
+    const double cost = (double)((blocks + cus - 1) / cus) * ((double)((strips + sk - 1) / sk) + 8.0);
+    if (cost < best - 1e-9) { best = cost; best_sk = sk; }
+  }
+  return best_sk;
+}
+inline size_t wgrad_wino_slab_floats(int n, int cin, int cout, int h, int w) {      // either form fits
+  size_t f = (size_t)wgrad_wino_splitk(n, cin, cout, h, w) * 16 * cout * cin;
+  if (wgrad_wino43_supported(cin, cout, h, w)) {
+    const size_t f43 = (size_t)wgrad_wino43_splitk(n, cin, cout, h, w) * 9 * cout * cin;
+    if (f43 > f) f = f43;
+  }
+  return f;
+}
 inline size_t wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w) {
   if (n <= 0 || !wgrad_wino_supported(cin, cout, h, w)) return 0;
-  return kWgradZeroBytes + (size_t)wgrad_wino_splitk(n, cin, cout, h, w) * 16 * cout * cin * sizeof(float);
+  return kWgradZeroBytes + wgrad_wino_slab_floats(n, cin, cout, h, w) * sizeof(float);
 }
 
+// The F(2x2) generations (what variant -1 takes where the F(4x4) kernel does not apply: H % 4 != 0):
 // 1: two waves per SIMD, wave groups half a period apart; 2-4: 1 with 16-byte operand reads, three raw stages, the Yh transform
 // moved into the MFMA phase (0-5 % over 1 per call); 5 / 6: no roles -- every wave streams its MFMAs and transforms the next chunk
 // between them (12 % / 8 % over 1 per call on every TrackNet shape, profiles/r03_wgrad_wino5_ab.json); 0: the first kernel.  All
@@ -1171,9 +1202,18 @@ int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float*
   if ((long)(cin > cout ? cin : cout) * h * w >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino: sample too large");
   if (((uintptr_t)ws) & 15) TNV3_FAIL(-1, "conv3x3_wgrad_wino: workspace must be 16-byte aligned");
   if (ws_bytes < wgrad_wino_workspace_bytes(n, cin, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad_wino: workspace too small");
-  const int sk = wgrad_wino_splitk(n, cin, cout, h, w);
   float* slabs = (float*)((char*)ws + kWgradZeroBytes);
   int rc;
+  if (variant < 0 && wgrad_wino43_supported(cin, cout, h, w)) variant = kWgradWino43Variant;      // the default wherever it applies
+  if (variant == kWgradWino43Variant) {
+    if (!wgrad_wino43_supported(cin, cout, h, w))
+      TNV3_FAIL(-1, "conv3x3_wgrad_wino (variant 8, F(4x4)): needs Cout %% 64 == 0, H %% 4 == 0, W %% 16 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
+    const int sk43 = wgrad_wino43_splitk(n, cin, cout, h, w);
+    WgradWinoArgs a43{x, dz, (const float*)ws, slabs, n, cin, cout, h, w, sk43};
+    if ((rc = L.launch(wgrad_wino43_kernel, (cout / WgradWino43Cfg::MB) * ((cin + WgradWino43Cfg::CB - 1) / WgradWino43Cfg::CB) * sk43, WgradWino43Cfg::NT, a43))) return rc;
+    return L.launch(wgrad_wino43_fold_kernel, grid_for((long)9 * cout * cin, 64, 8192), 256, (const float*)slabs, dw, cout, cin, sk43);
+  }
+  const int sk = wgrad_wino_splitk(n, cin, cout, h, w);
   const bool zero_page = wgrad_wino_pick(cin, variant) == 0;                           // only the first kernel reads its borders from a zero page
   if (zero_page && (rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
   WgradWinoArgs a{x, dz, (const float*)ws, slabs, n, cin, cout, h, w, sk};
@@ -1218,7 +1258,7 @@ inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, 
   l.d4 = off;      off += align16f((size_t)4 * cout * c0 * 4);
   l.dwskip = off;  off += align16f((size_t)cout * c1 * 9);
   size_t s_up = (size_t)l.up.splitK * cout * c0 * 4, s_skip = (size_t)l.skip.splitK * cout * c1 * 9;
-  if (wgrad_up2x_skip_wino(c1, cout, 2 * hl, 2 * wl)) s_skip = (size_t)wgrad_wino_splitk(n, c1, cout, 2 * hl, 2 * wl) * 16 * cout * c1;
+  if (wgrad_up2x_skip_wino(c1, cout, 2 * hl, 2 * wl)) s_skip = wgrad_wino_slab_floats(n, c1, cout, 2 * hl, 2 * wl);
   l.up_wino_sk = wgrad_up2x_wino_supported(c0, cout, hl, wl) ? wgrad_up2x_wino_splitk(n, c0, cout, hl, wl) : 0;
   const size_t s_up9 = (size_t)l.up_wino_sk * 9 * cout * c0;
   if (s_up9 > s_up) s_up = s_up9;
@@ -1266,7 +1306,13 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
     if (rc) return rc;
     if ((rc = reduce(d4 + (size_t)im * cout * c0 * 4, (long)cout * c0 * 4, l.up.splitK))) return rc;
   }
-  if (wgrad_up2x_skip_wino(c1, cout, h, w)) {
+  if (wgrad_up2x_skip_wino(c1, cout, h, w) && (wino_variant == kWgradWino43Variant || wino_variant < 0) && wgrad_wino43_supported(c1, cout, h, w)) {
+    const int sk43 = wgrad_wino43_splitk(n, c1, cout, h, w);
+    WgradWinoArgs a43{skip, dz, (const float*)ws, slabs, n, c1, cout, h, w, sk43};
+    if ((rc = L.launch(wgrad_wino43_kernel, (cout / WgradWino43Cfg::MB) * ((c1 + WgradWino43Cfg::CB - 1) / WgradWino43Cfg::CB) * sk43, WgradWino43Cfg::NT, a43))) return rc;
+    if ((rc = L.launch(wgrad_wino43_fold_kernel, grid_for((long)9 * cout * c1, 64, 8192), 256, (const float*)slabs, dwskip, cout, c1, sk43))) return rc;
+  } else if (wgrad_up2x_skip_wino(c1, cout, h, w)) {
+    if (wino_variant == kWgradWino43Variant) wino_variant = -1;
     const int sk = wgrad_wino_splitk(n, c1, cout, h, w);
     if (wgrad_wino_pick(c1, wino_variant) == 0)                                        // only the first kernel reads a zero page
       if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;

@@ -737,17 +737,20 @@ def wgrad_wino_supported(cin, cout, h, w):
     return bool(_lib.load().tnv3_conv3x3_wgrad_wino_supported(int(cin), int(cout), int(h), int(w)))
 
 
-def _wgrad_wino_variant(variant):
+def _wgrad_wino_variant(variant, h=0):
     if variant is None:
         from . import tuning
         variant = tuning.WGRAD_WINO_VARIANT
+        if int(variant) == 8 and h % 4:      # the F(4x4) kernel walks 4-row strips; other heights take the library's F(2x2) default
+            variant = -1
     return int(variant)
 
 
 def conv3x3_wgrad_wino(x, dz, variant=None):
-    """dW[Cout][Cin][3][3] of a plain layer in Winograd F(2x2,3x3) form -- see tnv3_conv3x3_wgrad_wino.  variant: kernel for THIS
+    """dW[Cout][Cin][3][3] of a plain layer in Winograd form -- see tnv3_conv3x3_wgrad_wino.  variant: kernel for THIS
     call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's default = 1, or 5 when Cin % 64 != 0; 1-4 the role-split generations;
-    5 / 6 every wave streams and transforms; 0 the first kernel -- all bit-identical)."""
+    5 / 6 every wave streams and transforms; 0 the first kernel -- all F(2x2, 3x3), bit-identical; 8: the F(4x4, 3x3) kernel,
+    H % 4 == 0, any Cin)."""
     lib = _lib.load()
     _f32(x, dz)
     _lib.dev_check(x, dz)
@@ -758,7 +761,7 @@ def conv3x3_wgrad_wino(x, dz, variant=None):
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dz.device)
     ws = _workspace(lib.tnv3_conv3x3_wgrad_wino_workspace_bytes(n, cin, cout, h, w), dz.device)
     _lib.check(lib.tnv3_conv3x3_wgrad_wino(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8, n, cin, cout, h, w,
-                                           _wgrad_wino_variant(variant), _lib.stream_ptr(dz)))
+                                           _wgrad_wino_variant(variant, h), _lib.stream_ptr(dz)))
     return dw
 
 

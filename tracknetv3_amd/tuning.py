@@ -105,7 +105,7 @@ def use_winograd_wgrad(cin, cout, h, w):
     64-multiples on both sides."""
     if not WINOGRAD or cout < WINOGRAD_WGRAD_MIN_CH:
         return False
-    if cin % 64 and (WGRAD_WINO_VARIANT not in (-1, 5, 6) or cin < WINOGRAD_WGRAD_MIN_CIN):
+    if cin % 64 and (WGRAD_WINO_VARIANT not in (-1, 5, 6, 8) or cin < WINOGRAD_WGRAD_MIN_CIN):
         return False
     from . import ops
     return ops.wgrad_wino_supported(cin, cout, h, w)
@@ -130,7 +130,13 @@ WGRAD_STREAM_PRIORITY = int(os.environ.get("TNV3_WGRAD_STREAM_PRIORITY", "0"))
 # (tnv3_conv3x3_wino_layout / tnv3_conv3x3_wino_has_stats), never assumed here.
 WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 5 streaming persistent (default), 3 balanced, 4 quad layouts, 2 xi-split, 0 one wave per SIMD
 WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA staged kernels (parity-green, 8 % slower)
-WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))   # Winograd-form weight gradient: -1 = 1 (5 for the stem), 1-4 role-split generations, 5 / 6 every wave streams and transforms, 0 the first kernel
+# Winograd-form weight gradient of the plain layers (and the skip half of the decoder-entry layers): -1 = the library's pick -- the
+# F(4x4) kernel (8) where H % 4 == 0, else F(2x2) kernel 1 (5 for the stem); 8 the F(4x4) kernel (other heights fall back to -1);
+# 1-4 the role-split F(2x2) generations, 5 / 6 every wave streams and transforms, 0 the first kernel.
+# Measured per call at batch 10 (profiles/r04_wgrad_wino43_ab.json): 8 is 1.45-1.51x faster than 1 on every plain shape (0.396 vs
+# 0.598 ms at 64 -> 64 @ 288x512), 2.56x on the stem (0.237 vs 0.605 ms: blocks of 32 input channels instead of 64); the training step
+# 26.11 -> 23.59 ms.  Its gradient is 2-4e-6 (max) / 3-6e-7 (rms) of max|dW| from the F(2x2) one.
+WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))
 
 
 # Training: all Winograd filter panels that the optimiser step made stale are rebuilt by one launch at the start of the forward
