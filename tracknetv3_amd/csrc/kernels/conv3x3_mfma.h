@@ -156,8 +156,12 @@ __device__ __forceinline__ void tnv3_buf_store_f4(tnv3_rsrc_t r, unsigned voffse
 // enclosing loop (the persistent kernel's per-tile code would otherwise park ~80 loop-invariant VGPRs across the MFMA loop).
 #ifdef TNV3_EMU
 #define TNV3_OPAQUE_V(x) ((void)0)
+#define TNV3_OPAQUE_S(x) ((void)0)
+#define TNV3_NO_IF_CONVERSION() ((void)0)
 #else
 #define TNV3_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#define TNV3_OPAQUE_S(x) asm volatile("" : "+s"(x))                 /* the same for a wave-uniform value */
+#define TNV3_NO_IF_CONVERSION() asm volatile("" ::: "memory")      /* inside a conditional block: it cannot be speculated into selects */
 #endif
 
 constexpr unsigned kDmaOob = 0x80000000u;      // voffset of a padding lane: beyond any descriptor (num_records < 2^31)

@@ -625,74 +625,93 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     // MaxPool2d(2, 2) of the block as a second output (the down blocks' last layers): a lane's 4x4 pixels are 2x2 pooled ones
     constexpr bool has_pool = POOL != 0;               // (its own instantiation: the descriptor and the kept row would cost the plain kernel spills)
     const tnv3_rsrc_t r_pool = tnv3_make_rsrc(has_pool ? a.pool_dst + plane0 / 4 : a.dst + plane0, planes_b / 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned ch_b = (unsigned)r * (unsigned)HW * 4u;
-      float mu = 0.0f, sc = 1.0f, sh = 0.0f;            // per channel, requested where they are used (as 16-byte loads ahead of the loop they held 12 registers)
-      if (has_affine) {
-        sc = a.scale[e_m0 + 4 * g + r];
-        sh = a.shift[e_m0 + 4 * g + r];
-        if (has_mean) mu = a.mean[e_m0 + 4 * g + r];
-      }
-      f32x4 ad[4];
-      if (has_addend) {
-#pragma unroll
-        for (int ar = 0; ar < 4; ++ar) ad[ar] = tnv3_buf_load_f4(r_add, lane_off_b, ch_b + (unsigned)(ar * W) * 4u);
-      }
-      float wv[4][6];                                    // W[a][j] = sum_i A^T[a][i] M[i][j]
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        float o[4];
-        wino43s_at6(acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r], o);
-        wv[0][j] = o[0]; wv[1][j] = o[1]; wv[2][j] = o[2]; wv[3][j] = o[3];
-      }
-      double s1 = 0.0, s2 = 0.0;
-      wf2 pv = {0.0f, 0.0f};
-#pragma unroll
-      for (int ar = 0; ar < 4; ++ar) {
-        float o[4];
-        wino43s_at6(wv[ar][0], wv[ar][1], wv[ar][2], wv[ar][3], wv[ar][4], wv[ar][5], o);
-        f32x4 v = {o[0], o[1], o[2], o[3]};
-        if (has_addend) v += ad[ar];
+    // The epilogue's options are wave-uniform run-time arguments.  Tested per row of four outputs they cost ~30 instructions of selects
+    // between the variants (51 per row against the transform's 11: 920 of a 64-channel tile's 1960 vector instructions per thread,
+    // 3.4 per MFMA in profiles/r04_infer_sq_summary.json), and one instantiated copy of the write-out per combination costs the kernels
+    // 20-170 spilled registers.  So the arithmetic is unconditional on NEUTRAL constants instead: mean 0 / scale 1 / shift 0 without
+    // BatchNorm, and the ReLU as an integer max with 0 or INT_MIN (one instruction; -0 and negative NaNs -> +0).
+    {
+      constexpr bool AFF = !STATS;
+      int relu_floor = (!STATS && a.relu) ? 0 : (int)0x80000000;
+      TNV3_OPAQUE_S(relu_floor);                         // (or the compiler turns the max back into max-with-0 + a select on a.relu)
+      auto pool_store = [&](int ar, unsigned ch_b, const f32x4& v, wf2& pv) {      // (maxpool2x2_kernel's comparison order and NaN rule: bit-identical to the separate pass)
+        auto mx = [](float m, float x) { return (x > m || x != x) ? x : m; };
+        if ((ar & 1) == 0) pv = wf2{mx(v[0], v[1]), mx(v[2], v[3])};
+        else {
+          const unsigned pool_off_b = oh < H ? (lane_off_b >> 2) + (unsigned)ow : kDmaOob;      // bytes: ((4 g) HW / 4 + (oh / 2) (W / 2) + ow / 2) * 4 = (4 g) HW + oh W + 2 ow
+          tnv3_buf_store_f2(r_pool, pool_off_b, ch_b / 4 + (unsigned)((ar >> 1) * (W >> 1)) * 4u, wf2{mx(mx(pv[0], v[0]), v[1]), mx(mx(pv[1], v[2]), v[3])});
+        }
+      };
+      // per-channel constants: requested ONE channel ahead of their use (all four ahead of the loop held 12 registers; requested where they
+      // are used, each channel waited a global-load latency for them)
+      float mu_n = 0.0f, sc_n = 1.0f, sh_n = 0.0f;
+      auto load_consts = [&](int r) {
         if (has_affine) {
-#pragma unroll
-          for (int b2 = 0; b2 < 4; ++b2) v[b2] = (v[b2] - mu) * sc + sh;
+          sc_n = a.scale[e_m0 + 4 * g + r];
+          sh_n = a.shift[e_m0 + 4 * g + r];
+          if (has_mean) mu_n = a.mean[e_m0 + 4 * g + r];
         }
-        if (!STATS && a.relu) {
+      };
+      if constexpr (AFF) load_consts(0);
 #pragma unroll
-          for (int b2 = 0; b2 < 4; ++b2) v[b2] = v[b2] > 0.0f ? v[b2] : 0.0f;
+      for (int r = 0; r < 4; ++r) {
+        const unsigned ch_b = (unsigned)r * (unsigned)HW * 4u;
+        const float mu = mu_n, sc = sc_n, sh = sh_n;
+        if constexpr (AFF) {
+          if (r < 3) load_consts(r + 1);
         }
-        tnv3_buf_store_f4(r_dst, (DG & 32) ? kDmaOob : lane_off_b, ch_b + (unsigned)(ar * W) * 4u, v);
-        if (has_pool) {                                  // (maxpool2x2_kernel's comparison order and NaN rule: bit-identical to the separate pass)
-          auto mx = [](float m, float x) { return (x > m || x != x) ? x : m; };
-          if ((ar & 1) == 0) pv = wf2{mx(v[0], v[1]), mx(v[2], v[3])};
-          else {
-            const unsigned pool_off_b = oh < H ? (lane_off_b >> 2) + (unsigned)ow : kDmaOob;      // bytes: ((4 g) HW / 4 + (oh / 2) (W / 2) + ow / 2) * 4 = (4 g) HW + oh W + 2 ow
-            tnv3_buf_store_f2(r_pool, pool_off_b, ch_b / 4 + (unsigned)((ar >> 1) * (W >> 1)) * 4u, wf2{mx(mx(pv[0], v[0]), v[1]), mx(mx(pv[1], v[2]), v[3])});
+        f32x4 ad[4];
+        if (has_addend) {
+#pragma unroll
+          for (int ar = 0; ar < 4; ++ar) ad[ar] = tnv3_buf_load_f4(r_add, lane_off_b, ch_b + (unsigned)(ar * W) * 4u);
+        }
+        float wv[4][6];                                    // W[a][j] = sum_i A^T[a][i] M[i][j]
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          float o[4];
+          wino43s_at6(acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r], o);
+          wv[0][j] = o[0]; wv[1][j] = o[1]; wv[2][j] = o[2]; wv[3][j] = o[3];
+        }
+        double s1 = 0.0, s2 = 0.0;
+        wf2 pv = {0.0f, 0.0f};
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) {
+          float o[4];
+          wino43s_at6(wv[ar][0], wv[ar][1], wv[ar][2], wv[ar][3], wv[ar][4], wv[ar][5], o);
+          f32x4 v = {o[0], o[1], o[2], o[3]};
+          if (has_addend) {
+            TNV3_NO_IF_CONVERSION();                     // a real scalar branch: as a select the four adds cost four more instructions per row
+            v += ad[ar];
+          }
+          if constexpr (AFF) {
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) v[b2] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, (v[b2] - mu) * sc + sh), relu_floor));
+          }
+          tnv3_buf_store_f4(r_dst, (DG & 32) ? kDmaOob : lane_off_b, ch_b + (unsigned)(ar * W) * 4u, v);
+          if (has_pool) pool_store(ar, ch_b, v, pv);
+          if constexpr (STATS) {
+            s1 += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+            s2 += ((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1]) + ((double)v[2] * (double)v[2] + (double)v[3] * (double)v[3]);
           }
         }
         if constexpr (STATS) {
-          s1 += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
-          s2 += ((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1]) + ((double)v[2] * (double)v[2] + (double)v[3] * (double)v[3]);
-        }
-      }
-      if constexpr (STATS) {
-        // BatchNorm batch statistics (model.py:9 in training mode) from the epilogue's registers: the 16 lanes of a lane group hold the 16
-        // tile columns of channel 4 g + r.  Butterflies over lane bits 3..0 in a fixed order, fp64: deterministic.  One statistics tile =
-        // 4 x 64 pixels (this wave's tile row).
+          // BatchNorm batch statistics (model.py:9 in training mode) from the epilogue's registers: the 16 lanes of a lane group hold the 16
+          // tile columns of channel 4 g + r.  Butterflies over lane bits 3..0 in a fixed order, fp64: deterministic.  One statistics tile =
+          // 4 x 64 pixels (this wave's tile row).
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          s1 += __shfl_xor(s1, o, 64);
-          s2 += __shfl_xor(s2, o, 64);
+          for (int o = 8; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+          }
+          if (tc == 0 && oh < H) {
+            const long st_tile = ((long)wM.n * (H >> 2) + (oh >> 2)) * tilesW + wM.tcol;
+            double* o = a.stats + ((size_t)(e_m0 + 4 * g + r) * ((size_t)a.N * (H >> 2) * tilesW) + st_tile) * 2;
+            o[0] = s1;
+            o[1] = s2;
+          }
         }
-        if (tc == 0 && oh < H) {
-          const long st_tile = ((long)wM.n * (H >> 2) + (oh >> 2)) * tilesW + wM.tcol;
-          double* o = a.stats + ((size_t)(e_m0 + 4 * g + r) * ((size_t)a.N * (H >> 2) * tilesW) + st_tile) * 2;
-          o[0] = s1;
-          o[1] = s2;
-        }
+        __builtin_amdgcn_sched_barrier(0);                // one channel at a time
       }
-      __builtin_amdgcn_sched_barrier(0);                // one channel at a time
     }
     }
   };
