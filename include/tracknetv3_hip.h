@@ -39,7 +39,9 @@ extern "C" {
                                     _pack_multi; tnv3_conv3x3_wgrad_wino variants 2-7 and any Cin;
                                  5: `variant` on the tnv3_conv3x3_wino43_* and tnv3_conv_up2x_wino_* entries (0 / 2: the MFMA 16x16x4
                                     kernels, 1: the 32x32x2 kernel); `pool_dst` on tnv3_conv3x3_wino43_forward; pack-multi layout 4;
-                                    tnv3_conv3x3_wgrad_wino variant 8 (F(4x4)), the default where h % 4 == 0 */
+                                    tnv3_conv3x3_wgrad_wino variant 8 (F(4x4)), the default where h % 4 == 0; the measured-and-rejected
+                                    generations (tnv3_conv3x3_wino_forward 0 / 2 / 4, tnv3_conv3x3_wgrad_wino 0 / 3 / 4 / 6 / 7) left the
+                                    product library: they are refused here and stay dispatchable in libtnv3_diag.so */
 
 typedef void* tnv3_stream_t;
 
@@ -97,23 +99,22 @@ int tnv3_conv3x3_forward_add(const float* src0, const float* src1, const float* 
  *                                     (u for cout_w x c_count) or, transpose_flip != 0, as the data gradient's filter
  *                                     w'[ci][co][kh][kw] = w[co][c_from + ci][2-kh][2-kw] (u for c_count x cout_w): no host-side
  *                                     slice / flip / transpose copies (model.py:8 weight layout) */
-/*   `variant` of tnv3_conv3x3_wino_forward (per call): -1 = the library's default (5);  2 = xi-split kernel, two waves per SIMD;
- *                                     3 = the same tile with buffer-descriptor DMA and a paired patch transform (6-12 % faster);  4 = 3 with the
- *                                     "quad" operand layouts (one LDS read per four MFMAs; needs filters packed with
- *                                     layout 1: ask tnv3_conv3x3_wino_layout);  5 = 3 as persistent workgroups (one per CU walking the tile
+/*   `variant` of tnv3_conv3x3_wino_forward (per call): the dispatchable kernels since ABI 5 are
+ *                                     3 = 64 channels x (4 x 64 pixels) per workgroup, two waves per SIMD, buffer-descriptor LDS-DMA and a
+ *                                     paired patch transform;  5 = 3 as persistent workgroups (one per CU walking the tile
  *                                     list, the chunk pipeline running through the tile boundaries: no per-tile launch, set-up, first-DMA
- *                                     wait or first transform; Cin <= 8 runs as 3);  0 = one wave per SIMD, transform as its own phase.  (1, the round-1 kernel with
- *                                     the transform interleaved into the MFMA stream, was removed: TNV3_E_INVALID.)  Variants 2, 3,
- *                                     4, 5 are bit-identical to each other; all compute the same function.
+ *                                     wait or first transform; Cin <= 8 runs as 3);
  *                                     6 = 5 re-tiled to 128 output channels x (4 x 32 pixels) per workgroup, the filter operand read
  *                                     straight from L2 into registers (kernels/conv3x3_wino6_mfma.h; Cout % 128 == 0, Cin > 8,
- *                                     W % 32 == 0; filters packed with layout 2); bit-identical to 2-5.
+ *                                     W % 32 == 0; filters packed with layout 2);
  *                                     7 = the same kernel with a 64-channel x (4 x 64 pixels) workgroup tile (Cout % 64 == 0, Cin > 8,
- *                                     W % 64 == 0; layout 2); bit-identical to 2-6.
+ *                                     W % 64 == 0; layout 2).  3, 5, 6, 7 are bit-identical to each other.
  *                                     -1 = tnv3_conv3x3_wino_pick(cin, cout): 6 for Cout % 128 == 0 and Cin > 8, else 5 (7 measured 2-5 % slower) -- by channel counts only,
  *                                     so a panel packed ahead of time is the one every call of that layer reads.
+ *                                     (0, 2, 4 -- the generations 3 was derived from -- are measurement twins of libtnv3_diag.so since
+ *                                     ABI 5 and are refused here; 1 was removed in round 2.)
  *   `layout` of the pack calls: 0 = u[cin_pad][16][cout];  1 = u[cin_pad / 2][4][2][cout][4] (transform row major, the four xi of
- *                                     a row adjacent);  2 = u[cout / 32][cin_pad / 8][2][8][64][4] (the A operand in lane order). */
+ *                                     a row adjacent: the diagnostic library's kernel 4);  2 = u[cout / 32][cin_pad / 8][2][8][64][4] (the A operand in lane order). */
 size_t tnv3_conv3x3_wino_packed_floats(int cin, int cout);
 int tnv3_conv3x3_wino_supported(int cin, int cout, int h, int w);
 int tnv3_conv3x3_wino_pick(int cin, int cout); /* the kernel variant that `variant` = -1 means for these channel counts */
@@ -240,12 +241,11 @@ int tnv3_dgrad_up2x_wino(const float* dz, const float* u, float* dx_low, int n, 
  *   8 = F(4x4, 3x3) with the interpolation points of tnv3_conv3x3_wino43_forward (kernels/wgrad_wino43_mfma.h): 64 co x 32 ci per
  *   workgroup, MFMA 16x16x4 with K = the four 4x4 tiles of a 4 x 16 pixel strip, both operands transformed in the shadow of the
  *   MFMAs, split-K slabs of 9 taps -- 1.45-1.5x faster than 1 on every TrackNet shape, 2.6x on the stem;
- *   the F(2x2) kernels: 1 = two waves per SIMD, the wave groups half a
- *   period apart (one transforms while the other streams MFMAs), paired transforms, buffer-descriptor LDS-DMA;  5 = every wave
- *   streams its MFMAs of a chunk and transforms its tile pair of the next chunk between them (16-byte operand reads, three raw
- *   stages);  6 = 5 with two raw stages (128 KB);  2 / 3 = 1 with 16-byte operand reads and two /
- *   three raw stages;  4 = 3 with the Yh transform moved into the MFMA phase;  7 = 1 with it;  0 = the first kernel (one wave per
- *   SIMD, transform and MFMA phases alternate).  Kernels 0-7 accumulate in the same order: bit-identical results. */
+ *   the F(2x2) kernels: 1 = two waves per SIMD, the wave groups half a period apart (one transforms while the other streams MFMAs),
+ *   paired transforms, buffer-descriptor LDS-DMA;  2 = 1 with 16-byte operand reads;  5 = every wave streams its MFMAs of a chunk and
+ *   transforms its tile pair of the next chunk between them (16-byte operand reads, three raw stages; any cin).  1, 2 and 5 accumulate
+ *   in the same order: bit-identical results.  (0, 3, 4, 6, 7 -- earlier / rejected generations -- are measurement twins of
+ *   libtnv3_diag.so since ABI 5 and are refused here.) */
 int tnv3_conv3x3_wgrad_wino_supported(int cin, int cout, int h, int w);
 size_t tnv3_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int cout, int h, int w);
 int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes, int n, int cin, int cout,
@@ -258,10 +258,9 @@ int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* wo
  * Deterministic (split-K slabs reduced in a fixed order); workspace from the _workspace_bytes query, 16-byte aligned.
  * `wino_variant` (per call): -1 = the default -- upsampled half in the 9-GEMM Winograd form of tnv3_conv_up2x_wino_forward
  * (9 instead of 16 multiply-adds per low-res pixel; needs c0 % 128 == 0, cout % 64 == 0, w_low % 8 == 0, else the next), skip half
- * by the default kernel of tnv3_conv3x3_wgrad_wino (the F(4x4) kernel 8 where h % 4 == 0);  8 = the same;  2 .. 7 = the same with
- * the F(2x2) kernel 1 / 3 / 4 / 5 / 6 / 7 for the skip half;  1 = upsampled
- * half by four 2x2-window launches over the parity images of dz, skip half by kernel 1;  0 = 1 with the first Winograd kernel for
- * the skip half.  All compute the same gradient up to fp32 rounding. */
+ * by the default kernel of tnv3_conv3x3_wgrad_wino (the F(4x4) kernel 8 where h % 4 == 0);  8 = the same;  2 / 5 = the same with
+ * the F(2x2) kernel 1 / 5 for the skip half;  1 = upsampled half by four 2x2-window launches over the parity images of dz, skip half
+ * by kernel 1.  All compute the same gradient up to fp32 rounding.  (0, 3, 4, 6, 7 are refused since ABI 5: libtnv3_diag.so.) */
 size_t tnv3_conv3x3_wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int h_low, int w_low);
 int tnv3_conv3x3_wgrad_up2x(const float* x_low, const float* skip, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
                             int n, int c0, int c1, int cout, int h_low, int w_low, int wino_variant, tnv3_stream_t stream);

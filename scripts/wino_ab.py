@@ -26,7 +26,7 @@ def timeit(fn, reps=10):
 
 def main():
     dev = torch.device("cuda", 0)
-    variants = [int(v) for v in sys.argv[1:]] or [2, 3]
+    variants = [int(v) for v in sys.argv[1:]] or [3, 5]
     out = {}
     for cin, cout, h, w in SHAPES:
         x = torch.relu(torch.randn(10, cin, h, w, device=dev))
@@ -42,7 +42,7 @@ def main():
                 if cout % 64 or cin <= 8:
                     continue
             u = ops.pack_wino_weights(wt, variant=v)      # the panel layout follows the kernel
-            if v >= 10:                   # experimental arms live in libtnv3_diag.so (raw convolution, no affine)
+            if v >= 10 or v in (0, 2, 4):  # experimental arms and the rejected generations live in libtnv3_diag.so (raw convolution, no affine)
                 y = torch.empty(10, cout, h, w, device=dev)
                 run = lambda: diaglib.conv3x3_wino_forward(x, u, y, v)       # noqa: E731
                 run()

@@ -95,11 +95,10 @@ def _wgrad_up2x_case(case, device):
     dw = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=2)      # 9-GEMM form + F(2x2) kernel 1 for the skip half
     dw2 = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=2)
     assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
-    for v in (0, 1):                             # the older kernel choices compute the same gradient
-        dwv = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=v)
-        assert rel_err(dwv.cpu(), dw.cpu().double()) <= 4e-6, v
-    for v in (3, 4, 5, 6, 7):                    # 9-GEMM form + another (bit-identical) F(2x2) generation of the skip half's kernel
-        assert torch.equal(dw, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=v)), v
+    dwv = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=1)      # the upsampled half by the four 2x2-window launches
+    assert rel_err(dwv.cpu(), dw.cpu().double()) <= 4e-6
+    # 9-GEMM form + the other (bit-identical) F(2x2) generation of the skip half's kernel
+    assert torch.equal(dw, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=5))
     # the default (-1): the skip half by the F(4x4) kernel where it applies (H % 4 == 0, C1 % 64 == 0) -- same upsampled half, deterministic
     dwd = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=-1)
     assert torch.equal(dwd, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device)))
@@ -134,8 +133,11 @@ def _wgrad_wino_case(case, device):
     assert torch.equal(dwd, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device)))
     assert torch.equal(dwd, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=8) if h % 4 == 0 else dw)
     # every F(2x2) kernel generation accumulates every element in the same order: bit-identical gradients
-    for v in ((0, 1, 2, 3, 4, 5, 6, 7) if cin % 64 == 0 else (5, 6)):        # a partial block of input channels (the stem): the production kernel only
+    for v in ((1, 2, 5) if cin % 64 == 0 else (5,)):        # a partial block of input channels (the stem): kernel 5 only
         assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=v)), v
+    for v in (0, 3, 4, 6, 7):                               # measurement twins of libtnv3_diag.so since ABI 5
+        with pytest.raises(Exception, match="libtnv3_diag"):
+            ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=v)
     if cin % 64:
         with pytest.raises(Exception, match="Cin % 64"):
             ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=1)

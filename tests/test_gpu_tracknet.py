@@ -82,7 +82,7 @@ def test_dgrad_up2x_vs_autograd(gpu_device, case):
     assert _dgrad_up2x_case(*case, gpu_device) <= 3e-6
 
 
-@pytest.mark.parametrize("variant", [2, 0, 3, 4, 5], ids=["xisplit", "onewave", "balanced", "quad", "persistent"])
+@pytest.mark.parametrize("variant", [3, 5], ids=["balanced", "persistent"])      # (0 / 2 / 4: measurement twins of libtnv3_diag.so since ABI 5)
 @pytest.mark.parametrize("case", WINO_CASES + [(2, 256, 256, 72, 128), (1, 512, 512, 36, 64), (1, 64, 64, 288, 512), (3, 27, 64, 8, 192)])
 def test_conv3x3_wino_vs_torch(monkeypatch, gpu_device, case, variant):
     from tracknetv3_amd import ops

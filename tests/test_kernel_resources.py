@@ -117,30 +117,34 @@ def test_conv_and_wgrad_budgets(resources):
         assert k["VGPRs"] + k.get("AGPRs", 0) <= 512 and k["Occupancy [waves/SIMD]"] >= 1
     k = _find(resources, "wgrad3x3_mfma_kernel", "WgradCfgILi4ELi2ELi4ELi32ELi4E")        # 2x2-window, 8 waves: two per SIMD
     assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs Spill"] == 0
-    k = _find(resources, "conv3x3_wino_mfma_kernelINS_7WinoCfgILi2ELi2ELi8ELi0E")      # 256 accumulators: one wave per SIMD, no spills,
-    assert k["VGPRs Spill"] == 0 and k["SGPRs Spill"] == 0 and k["LDS Size [bytes/block]"] <= 160 * 1024   # three + one + two stages in LDS
-    k = _find(resources, "conv3x3_wino_split_mfma_kernelINS_12WinoSplitCfgILi8ELi0E")  # production: 128 accumulators, TWO waves per SIMD
-    assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0
-    assert k["LDS Size [bytes/block]"] <= 160 * 1024                                    # two filter + two V + two raw stages
+    # (the one-wave and xi-split F(2x2) generations -- variants 0 / 2 / 4 -- and the weight-gradient generations 0 / 3 / 4 / 6 / 7 left the product
+    #  library with ABI 5: libtnv3_diag.so only)
+    assert not any("conv3x3_wino_mfma_kernelINS_7WinoCfg" in n or "conv3x3_wino_split_mfma_kernel" in n for n in resources)
     # variants 3 and 4 (one tile per workgroup), 5 (the streaming persistent kernel) and 6 (its 128-channel form with the filter operand
     # in registers -- which spilled 700+ registers until the two groups' programs were predicated instead of branched): the same budget
-    for name in ("conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi0E", "conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi1ELi0ELi0ELi0E",
+    for name in ("conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi0E",
                  "conv3x3_wino_stream_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi1E", "conv3x3_wino_a128_stream_kernelINS_9WinoV6CfgILi0ELi1ELi0ELi1ELi0ELi1E",
                  "conv3x3_wino_a128_stream_kernelINS_9WinoV6CfgILi0ELi1ELi0ELi1ELi0ELi2E"):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
     # Winograd weight gradient, two waves per SIMD: the role-split generations and the production kernel (every wave streams and transforms)
-    for name in ("wgrad_wino2_mfma_kernelILi0E", "wgrad_wino2_mfma_kernelILi1E", "wgrad_wino3_mfma_kernelINS_13WgradWino3CfgILi3ELi0ELi1E", "wgrad_wino5_mfma_kernelINS_13WgradWino5CfgILi3ELi0E"):
+    for name in ("wgrad_wino2_mfma_kernelILi0E", "wgrad_wino3_mfma_kernelINS_13WgradWino3CfgILi2ELi0ELi0E", "wgrad_wino5_mfma_kernelINS_13WgradWino5CfgILi3ELi0E"):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
     # the 16x16x4 F(4x4) kernel (variant 0), both geometries, plain / statistics epilogue: 144 accumulators + named filter quads + the patch
     # transform in 256 registers, two waves per SIMD, no spill traffic (its steps end in a COUNTED vmcnt)
-    for name in ("conv3x3_wino43s_kernelILi4ELi0E", "conv3x3_wino43s_kernelILi4ELi1E", "conv3x3_wino43s_kernelILi8ELi0E", "conv3x3_wino43s_kernelILi8ELi1E"):
-        k = _find(resources, name)
-        assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+    # (every instantiation: geometry 4 / 8 x plain / statistics / pooled second output / the upsampled halves' 25-product form)
+    w43s = {n: k for n, k in resources.items() if "conv3x3_wino43s_kernelILi" in n}
+    assert len(w43s) >= 8 and all(any(f"conv3x3_wino43s_kernelILi{c}ELi{st}E" in n for n in w43s) for c in (4, 8) for st in (0, 1)), sorted(w43s)
+    for name, k in w43s.items():
+        assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, (name, k)
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
+    # the F(4x4) weight gradient: 144 accumulators + both operand transforms, two waves per SIMD, its strips end in counted vmcnt waits
+    k = _find(resources, "wgrad_wino43_kernel")
+    assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+    assert k["LDS Size [bytes/block]"] <= 160 * 1024
     for name in ("conv3x3_wino43_kernelILi1ELi0ELi0E", "conv3x3_wino43_kernelILi1ELi0ELi1E"):   # its 32x32x2 predecessor (variant 1), plain / statistics epilogue:
         # 144 accumulators, two waves per SIMD; NO spill traffic: its chunk loop waits with a COUNTED vmcnt for its LDS-DMA pieces (nine
         # A loads behind them may stay in flight)

@@ -16,12 +16,12 @@ SRC = os.path.join(PKG_DIR, "csrc", "tnv3_capi.hip")
 LIB = os.path.join(PKG_DIR, "libtnv3_hip.so")
 DIAG_LIB = os.path.join(PKG_DIR, "libtnv3_diag.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
-FAMILIES = ("MISC", "CONV", "WINO", "UP2X", "WGRAD", "TRAIN")
+FAMILIES = ("MISC", "CONV", "WINO", "WINO43", "UP2X", "WGRAD", "TRAIN")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-cuda-compat"]
 # Per-family extras.  The Winograd kernels are compiled without the SLP vectoriser: it pairs the fp32 adds of the patch / output
 # transforms into v_pk_add_f32 at the price of a v_mov per operand pair (61 instead of 56 vector instructions per chunk) and of
 # ~40 temporaries in the output transform, which pushed the persistent kernel past its 256-register budget (26 spills).
-FAMILY_FLAGS = {"WINO": ["-fno-slp-vectorize"], "DIAG": ["-fno-slp-vectorize"]}
+FAMILY_FLAGS = {"WINO": ["-fno-slp-vectorize"], "WINO43": ["-fno-slp-vectorize"], "DIAG": ["-fno-slp-vectorize"]}
 
 
 def _sources():

@@ -1,5 +1,5 @@
 // tnv3_capi.hip -- libtnv3_hip.so: gfx950 kernels + C ABI (include/tracknetv3_hip.h).
-// Built by tracknetv3_amd/_build.py: this file is compiled once per kernel family (-DTNV3_TU_MISC, _CONV, _WINO, _UP2X, _WGRAD,
+// Built by tracknetv3_amd/_build.py: this file is compiled once per kernel family (-DTNV3_TU_MISC, _CONV, _WINO, _WINO43, _UP2X, _WGRAD,
 // _TRAIN; hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c, in parallel) and the objects are linked into one shared library.
 // With -DTNV3_DIAG -DTNV3_TU_DIAG it becomes libtnv3_diag.so (include/tracknetv3_hip_diag.h: timing twins, MFMA probe).
 #include <hip/hip_runtime.h>

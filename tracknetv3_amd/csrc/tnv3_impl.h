@@ -853,10 +853,14 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     case 5:                                      // one chunk per tile cannot stream: the variant-3 kernel takes Cin <= 8
       if (cin <= WinoV5::CC) return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3>, conv_grid_blocks(cout / WinoV3::MB, (int)npt), WinoV3::NT, a);
       return L.launch(conv3x3_wino_stream_mfma_kernel<WinoV5>, wino_persistent_grid(conv_grid_blocks(cout / WinoV5::MB, (int)npt)), WinoV5::NT, a);
-    case 4: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV4>, conv_grid_blocks(cout / WinoV4::MB, (int)npt), WinoV4::NT, a);
     case 3: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV3>, conv_grid_blocks(cout / WinoV3::MB, (int)npt), WinoV3::NT, a);
+#ifdef TNV3_DIAG      // measured and rejected generations: A/B twins in libtnv3_diag.so only since ABI 5
+    case 4: return L.launch(conv3x3_wino_v3_mfma_kernel<WinoV4>, conv_grid_blocks(cout / WinoV4::MB, (int)npt), WinoV4::NT, a);
     case 2: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplit>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
     case 0: return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
+#else
+    case 4: case 2: case 0: TNV3_FAIL(-1, "conv3x3_wino: kernel variant %d is a measurement twin of libtnv3_diag.so since ABI 5 (dispatchable: 3, 5, 6, 7)", variant);
+#endif
     default: TNV3_FAIL(-1, "conv3x3_wino: unknown kernel variant %d", variant);
   }
 }
@@ -1169,17 +1173,23 @@ template <class Launcher>
 int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
   const int grid = (a.Cout / 64) * ((a.Cin + 63) / 64) * a.splitK;
   variant = wgrad_wino_pick(a.Cin, variant);
-  if (a.Cin % 64 && variant != 5 && variant != 6) TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variants 0-4 need Cin %% 64 == 0 (got %d)", a.Cin);
+#ifndef TNV3_DIAG
+  if (variant == 0 || variant == 3 || variant == 4 || variant == 6 || variant == 7)
+    TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variant %d is a measurement twin of libtnv3_diag.so since ABI 5 (dispatchable: 1, 2, 5, 8)", variant);
+#endif
+  if (a.Cin % 64 && variant != 5 && variant != 6) TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variants 1 and 2 need Cin %% 64 == 0 (got %d)", a.Cin);
+#ifdef TNV3_DIAG
   if (variant == 0) return L.launch(wgrad_wino_mfma_kernel, grid, WgradWinoCfg::NT, a);
+#endif
   if ((long)64 * a.H * a.W * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (variants 1-3): 64 channel planes must stay below 2 GiB");
   if (variant == 1) return L.launch(wgrad_wino2_mfma_kernel<0>, grid, WgradWino2Cfg::NT, a);
-  if (variant == 7) return L.launch(wgrad_wino2_mfma_kernel<1>, grid, WgradWino2Cfg::NT, a);     // 1 + the Yh transform in the MFMA phase
   if (variant == 2) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<2>>, grid, 512, a);
+  if (variant == 5) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<3>>, grid, 512, a);
+#ifdef TNV3_DIAG      // measured and rejected generations: A/B twins in libtnv3_diag.so only since ABI 5
+  if (variant == 7) return L.launch(wgrad_wino2_mfma_kernel<1>, grid, WgradWino2Cfg::NT, a);     // 1 + the Yh transform in the MFMA phase
   if (variant == 3) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3>>, grid, 512, a);
   if (variant == 4) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 0, 1>>, grid, 512, a);
-  if (variant == 5) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<3>>, grid, 512, a);
   if (variant == 6) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<2>>, grid, 512, a);      // 128 KB of LDS: small kernels of another stream fit beside it
-#ifdef TNV3_DIAG
   if (variant == 101) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 1>>, grid, 512, a);   // no transforms
   if (variant == 102) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 2>>, grid, 512, a);   // no DMA
   if (variant == 103) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<3, 3>>, grid, 512, a);   // no MFMAs
