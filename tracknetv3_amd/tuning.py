@@ -151,7 +151,8 @@ BN_STATS_IN_EPILOGUE = os.environ.get("TNV3_BN_STATS_EPILOGUE", "1") != "0"
 # Inference: one batch is split over two HIP streams (6 : 4) -- its images are independent, and the second stream's launches fill
 # the CUs that the tail of every per-layer launch leaves idle (720 tiles on 256 CUs = 2.8 rounds: the last one is 81 % full).
 # Measured on the batch-10 288x512 forward: 9.91 -> 9.33 ms (profiles/r02_split_stream_probe.json); outputs are bit-identical.
-# Other shares and three or four streams are all slower (profiles/r03_infer_split_sweep.txt: 6,4 8.07 ms; 7,3 8.09; 4,4,2 8.15; 5,5 8.22).
+# Other shares and three or four streams are all slower (profiles/r03_infer_split_sweep.txt: 6,4 8.07 ms; 7,3 8.09; 4,4,2 8.15; 5,5 8.22;
+# re-swept on round 4's kernels: 6,4 5.27-5.30 ms; 7,3 5.30; 5,5 5.38; 4,3,3 5.46; 4,4,2 5.47; 5,3,2 5.48; 8,2 5.63; 3,3,2,2 5.72).
 INFER_SPLIT = os.environ.get("TNV3_INFER_SPLIT", "1") != "0"
 def _split_parts(text):
     """Shares of the batch, one stream each: positive integers, at least one -- anything else falls back to 6 : 4."""
