@@ -247,20 +247,25 @@ def train_flops_executed_per_sample():
             if use43:
                 return 9 / 36
             return 16 / 36 if t.use_winograd(ci, co, h, w) else 1.0
+
+        def wfrac(ci):                                   # weight gradient: F(4x4) kernel 8, an F(2x2) kernel, or the direct form
+            if t.use_wino43_wgrad(ci, co, h, w):
+                return 9 / 36
+            return 16 / 36 if t.use_winograd_wgrad(ci, co, h, w) else 1.0
         if up:
             from tracknetv3_amd import ops as _ops
             uvt = _ops.up2x_wino_variant(t.UP2X_WINO_VARIANT_TRAIN)
             f_fwd = 6.25 / 36 if (uvt == 2 and _ops.up2x_wino_supported(c0, co, h // 2, w // 2, 2)) else 9 / 36
             upf = conv_flops(c0, 0, co, h, w) * (f_fwd + 2 * 9 / 36)                           # forward; data gradient, weight gradient (9-GEMM forms)
             sk = conv_flops(c1, 0, co, h, w)
-            skip = sk * (frac(c1, t.use_wino43_train(c1, co, h, w)) + frac(c1, t.use_wino43_dgrad(co, c1, h, w)) + (16 / 36 if t.use_winograd_wgrad(c1, co, h, w) else 1.0))
+            skip = sk * (frac(c1, t.use_wino43_train(c1, co, h, w)) + frac(c1, t.use_wino43_dgrad(co, c1, h, w)) + wfrac(c1))
             total += upf + skip
         else:
             fl = conv_flops(c0, 0, co, h, w)
             total += fl * frac(c0, t.use_wino43_train(c0, co, h, w))                                # forward
             if name != "down_block_1.conv_1":
                 total += fl * frac(c0, t.use_wino43_dgrad(co, c0, h, w))                            # data gradient (none for the first layer)
-            total += fl * (16 / 36 if t.use_winograd_wgrad(c0, co, h, w) else 1.0)                  # weight gradient
+            total += fl * wfrac(c0)                                                                 # weight gradient
     return total
 
 
@@ -353,10 +358,10 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
                              "passes count against it) over the fp32 MFMA peak; `effective_tflops` prices the same time at the "
                              "reference's algorithmic FLOP count (SURVEY 8d: 678.2 GFLOP/sample) -- the upsampled channels of the "
                              "three decoder-entry layers run at the low resolution in all three passes, in Winograd forms that keep 9 of the 16 "
-                             "GEMMs (9/36 of those MACs), the plain "
-                             "layers in fused Winograd form -- F(4x4,3x3) (9/36) in the data gradient (and in the forward with the opt-in "
-                             "TNV3_WINO43_TRAIN=1, which trades parity margin for 2.8 ms), F(2x2,3x3) (16/36) in the forward and the "
-                             "weight gradient --, counted per layer from the dispatch rules (train_flops_executed_per_sample)"},
+                             "F(2x2) GEMMs (9/36 of those MACs), the plain layers and the skip halves in fused Winograd F(4x4,3x3) form (9/36) in "
+                             "all three passes (forward with the statistics epilogue, data gradient, weight gradient) --, counted per layer "
+                             "from the dispatch rules (train_flops_executed_per_sample: a knob that moves a pass to F(2x2) or the direct form "
+                             "moves its count to 16/36 or 1)"},
         "strong": strong, "dp_overlap": overlap, "final_loss": round(float(loss.item()), 6)}
 
 

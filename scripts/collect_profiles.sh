@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the summaries of the last scripts/gpu_session.sh evidence session (PARTS="host smoke pytest infer train ab fixed decoder profinfer proftrain pmc sq") from gpurun_out/ (scratch) into profiles/ (tracked).
-set -eu
+set -u
 cd "$(dirname "$0")/.."
 R=${ROUND:-r04}
 O=gpurun_out
@@ -15,15 +15,15 @@ cp $O/prof_train_kernel_stats.csv $P/${R}_train_kernel_stats.csv
 cp $O/pmc_fetch_pmc.csv $P/${R}_infer_pmc_fetch_size.csv
 cp $O/pmc_write_pmc.csv $P/${R}_infer_pmc_write_size.csv
 for f in sq1 sq2 sq3 tcc; do cp $O/pmc_$f.csv $P/${R}_infer_pmc_$f.csv; done
-for f in r02_wino_variants_ab2.json r02_wino_stream_twins.json r02_wino_fixed_cost.json; do [ -f $O/$f ] && cp $O/$f $P/$f; done
-for f in up2x_wino_ab dgrad_up2x_ab wgrad_up_sweep wgrad_wino_ab; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
-[ -f $O/fullsize_train_parity.json ] && cp $O/fullsize_train_parity.json $P/${R}_fullsize_train_parity.json
-[ -f $O/e2e_real_network_report.json ] && cp $O/e2e_real_network_report.json $P/${R}_e2e_real_network_report.json
+# optional parts: only what THIS session wrote (gpurun_out/ keeps the files of earlier sessions and rounds; lib_sha256.txt is written when a session starts)
+fresh() { [ -f "$1" ] && [ "$1" -nt $O/lib_sha256.txt ]; }
+for f in up2x_wino_ab dgrad_up2x_ab wgrad_up_sweep wgrad_wino_ab; do fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
+fresh $O/e2e_real_network_report.json && cp $O/e2e_real_network_report.json $P/${R}_e2e_real_network_report.json
 # (the library that ran on the GPU box is the one in the tree: the session ships the tree; its sha256 keys the counters to the build)
 python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json ${COMMIT:-$(git rev-parse --short HEAD)} $(cat $O/lib_sha256.txt 2>/dev/null || sha256sum tracknetv3_amd/libtnv3_hip.so | cut -d" " -f1)
 [ -f $O/lib_sha256.txt ] && cp $O/lib_sha256.txt $P/${R}_lib_sha256.txt
-for f in wino43_variant_ab up2x_wino43_ab wino43s_timeline wgrad_wino43_ab; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
-for f in fullsize_train_parity_n2_f43fwd fullsize_train_parity_n2_f22fwd fullsize_train_parity_n10_default; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
+for f in wino43_variant_ab up2x_wino43_ab wino43s_timeline wgrad_wino43_ab; do fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
+for f in fullsize_train_parity_n2_f43fwd fullsize_train_parity_n2_f22fwd fullsize_train_parity_n10_default; do fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
 [ -f $O/infer_sq_summary.json ] && cp $O/infer_sq_summary.json $P/${R}_infer_sq_summary.json
 cp $O/session.log $P/${R}_session_final.log
 echo "profiles/ refreshed from $O"

@@ -111,6 +111,11 @@ def use_winograd_wgrad(cin, cout, h, w):
     return ops.wgrad_wino_supported(cin, cout, h, w)
 
 
+def use_wino43_wgrad(cin, cout, h, w):
+    """Whether the Winograd-form weight gradient of this layer runs the F(4x4) kernel (variant 8: the library's pick for -1 where H % 4 == 0)."""
+    return use_winograd_wgrad(cin, cout, h, w) and WGRAD_WINO_VARIANT in (-1, 8) and h % 4 == 0
+
+
 # The weight gradients of the first WGRAD_WINO_TAIL Conv2DBlocks (forward order: stem, down_block_1.conv_2, down_block_2.conv_1, ...)
 # are the last launches of backward, when the main stream is winding down -- the case where the no-role kernel (variant 5: +12 % per
 # call, full-CU footprint) might win.  Measured (scripts/train_tail_ab.sh, two repeats): 0 blocks 31.66 / 31.81 ms per step, 2: 31.74 /
