@@ -311,6 +311,24 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
 
     x, y = data(batch, 0)
     dt, loss = timed_steps(x, y, steps, warmup)
+    replicas = None
+    if world > 1:
+        # data parallelism's invariant after K averaged updates: every rank holds the same bits.  One int64 checksum per rank over the
+        # parameters' bit patterns (and one over rank 0-independent state: Adam's moments), gathered over the gloo control group.
+        def checksum(tensors):
+            acc = torch.zeros((), dtype=torch.int64, device=dev)
+            for k, t in enumerate(tensors):
+                acc += (t.detach().contiguous().view(torch.int32).to(torch.int64) * (k + 1)).sum()
+            return int(acc.item())
+        mine = torch.tensor([checksum(model.parameters()),
+                             checksum([v for st in opt.state.values() for v in st.values() if torch.is_tensor(v) and v.dtype == torch.float32 and v.is_cuda])],
+                            dtype=torch.int64)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine, group=_CTL["group"])
+        replicas = {"identical": bool(all(torch.equal(c, allc[0]) for c in allc)), "ranks": world,
+                    "bucket_copies": int(trainer.reducer.copies) if trainer.reducer is not None else None,
+                    "note": "int64 checksums of the parameters' and Adam moments' bit patterns after the timed steps, equal on every rank; "
+                            "bucket_copies: gradients that were copied into an all-reduce bucket instead of being written there by their kernel"}
     overlap = None
     if record_timing and world > 1:
         timed = TrackNetTrainer(model, opt, alpha=0.5, seed=14, record_timing=True)
@@ -362,7 +380,7 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
                              "all three passes (forward with the statistics epilogue, data gradient, weight gradient) --, counted per layer "
                              "from the dispatch rules (train_flops_executed_per_sample: a knob that moves a pass to F(2x2) or the direct form "
                              "moves its count to 16/36 or 1)"},
-        "strong": strong, "dp_overlap": overlap, "final_loss": round(float(loss.item()), 6)}
+        "strong": strong, "dp_overlap": overlap, "replicas": replicas, "final_loss": round(float(loss.item()), 6)}
 
 
 def bench_train(args, dev, rank, world):

@@ -98,14 +98,19 @@ def inpaintnet_state_shapes():
     return d
 
 
-def synth_state(shapes, seed, calibrated=False):
+def synth_state(shapes, seed, calibrated=False, gain=None, var_range=None):
     """Deterministic synthetic state_dict from the portable PRNG.
 
     Conv/linear weights ~ U(-b, b) with b = 1/sqrt(fan_in) (the PyTorch default
     bound).  ``calibrated=False``: BN gamma=1, beta=0, rm=0, rv=1
     (fresh-module values).  ``calibrated=True``: non-trivial gamma/beta/rm/rv so
-    that the BN arithmetic is actually exercised.
+    that the BN arithmetic is actually exercised.  ``gain`` / ``var_range``
+    (calibrated only; defaults 2.4 and (0.5, 2.0), the values every golden fixture
+    was made with) are what the precision sweep varies: the conv weights' gain and
+    the range the BN running variances are drawn from.
     """
+    gain_cal = 2.4 if gain is None else float(gain)
+    v_lo, v_hi = (0.5, 2.0) if var_range is None else (float(var_range[0]), float(var_range[1]))
     sd = OrderedDict()
     for name, (shape, dtype) in shapes.items():
         s = prng.name_seed(name, seed)
@@ -118,12 +123,12 @@ def synth_state(shapes, seed, calibrated=False):
         elif name.endswith("running_mean"):
             sd[name] = torch.from_numpy(prng.uniform(shape, s, -0.2, 0.2)) if calibrated else torch.zeros(shape)
         elif name.endswith("running_var"):
-            sd[name] = torch.from_numpy(prng.uniform(shape, s, 0.5, 2.0)) if calibrated else torch.ones(shape)
+            sd[name] = torch.from_numpy(prng.uniform(shape, s, v_lo, v_hi)) if calibrated else torch.ones(shape)
         elif name.endswith(".weight"):
             fan_in = int(np.prod(shape[1:]))
             b = 1.0 / math.sqrt(fan_in)
-            gain = 2.4 if calibrated else 1.0   # keeps activations O(1) through 17 ReLU layers
-            sd[name] = torch.from_numpy(prng.uniform(shape, s, -b * gain, b * gain))
+            g = gain_cal if calibrated else 1.0   # 2.4 keeps activations O(1) through 17 ReLU layers
+            sd[name] = torch.from_numpy(prng.uniform(shape, s, -b * g, b * g))
         elif name.endswith(".bias"):
             # fan_in of the matching weight
             wshape = shapes[name[:-4] + "weight"][0]

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, backend="gloo"):
+def _worker(rank, world, port, out, backend="gloo", batch=4, direct=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -43,13 +43,17 @@ def _worker(rank, world, port, out, backend="gloo"):
             net.load_state_dict(sd, strict=True)           # rank 1 starts from random init: broadcast must fix it
         net = net.to(dev)
         opt = torch.optim.SGD(net.parameters(), lr=1.0)    # lr 1, no momentum: parameter delta == -averaged gradient
-        tr = TrackNetTrainer(net, opt, alpha=0.0, bucket_bytes=4 << 20, record_timing=(backend == "nccl"))
+        tr = TrackNetTrainer(net, opt, alpha=0.0, bucket_bytes=4 << 20, record_timing=(backend == "nccl"), direct_grads=direct)
         assert tr.reducer is not None and tr.reducer.num_buckets() >= 8
-        x = nets.synth_input((4, 9, 64, 128), 1013)
-        y = nets.disc_heatmaps(4, 3, 64, 128, 2013)
-        lo, hi = shard_range(4, rank, world)
+        x = nets.synth_input((batch, 9, 64, 128), 1013)
+        y = nets.disc_heatmaps(batch, 3, 64, 128, 2013)
+        lo, hi = shard_range(batch, rank, world)
         loss = tr.step(x[lo:hi].to(dev), y[lo:hi].to(dev))
         torch.cuda.synchronize()
+        # backward's kernels wrote every gradient into its all-reduce bucket (no copy); p.grad IS the bucket view
+        assert tr.reducer.copies == (0 if direct else 53), tr.reducer.copies
+        for p_ in net.parameters():
+            assert p_.grad.data_ptr() == tr.reducer.dest(p_).data_ptr()
         out[rank] = dict(loss=float(loss), overlap=tr.overlap_report(), params={k: v.detach().cpu() for k, v in net.named_parameters()},
                          grads={k: v.grad.detach().cpu() for k, v in net.named_parameters()},
                          bn={k: v.detach().cpu() for k, v in net.state_dict().items() if "running_" in k})
@@ -96,12 +100,63 @@ def test_two_rank_train_step_equals_sequential_shard_oracle(gpu_device, backend,
     mine, ref = np.array(mine), np.array(ref)
     # Both are fp32 evaluations of an ill-conditioned quantity (BatchNorm over a few hundred samples per channel in the
     # deepest layers).  The MFMA accumulates each output as ONE sequential fp32 chain over K = 9*Cin <= 6912 terms, oneDNN
-    # in blocks, so ours sits a small constant factor above torch-fp32's deviation from fp64 -- bound it at 6x.
-    assert mine.max() <= 6 * ref.max() + 2e-4 and np.median(mine) <= 6 * np.median(ref) + 1e-4, (mine.max(), ref.max(), np.median(mine), np.median(ref))
+    # in blocks, so ours sits a small constant factor above torch-fp32's deviation from fp64 (measured 1.3-1.6x) -- bound it at 3x.
+    assert mine.max() <= 3 * ref.max() + 2e-4 and np.median(mine) <= 3 * np.median(ref) + 1e-4, (mine.max(), ref.max(), np.median(mine), np.median(ref))
     # BatchNorm running statistics stay LOCAL to each rank (no SyncBN): rank r holds the stats of shard r
     for r, got in ((0, r0["bn"]), (1, r1["bn"])):
         for k, v in got.items():
             assert torch.allclose(v.double(), stats[r][k], rtol=2e-4, atol=2e-6), (r, k)
+
+
+def test_eight_rank_train_step_equals_sequential_eight_shard_oracle(gpu_device):
+    """BASELINE configs[2]'s rank count with the REAL kernels: eight ranks share cuda:0 over gloo (RCCL refuses two ranks on one
+    device; on an 8-GPU node the same calls run over RCCL), global batch 8 at 64x128, one sample per rank.  Must equal the DP
+    definition: the oracle runs the eight shards one after the other (local BatchNorm), averages the gradient sets, applies one SGD step.
+    Also: every gradient is written by its kernel into the all-reduce bucket (copies == 0), and the replicas end bit-identical."""
+    world, port, batch = 8, _free_port(), 8
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out, "gloo", batch), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 13, calibrated=True)
+    x = nets.synth_input((batch, 9, 64, 128), 1013)
+    y = nets.disc_heatmaps(batch, 3, 64, 128, 2013)
+    g64, g32 = [], []
+    for r in range(world):
+        l, _, g, st = nets.tracknet_train_step_grads(sd, x[r:r + 1], y[r:r + 1], torch.float64)
+        _, _, gf, _ = nets.tracknet_train_step_grads(sd, x[r:r + 1], y[r:r + 1], torch.float32)
+        g64.append(g); g32.append(gf)
+        assert abs(res[r]["loss"] - l.item()) <= 2e-5, (r, res[r]["loss"], l.item())
+        for k, v in res[r]["bn"].items():                   # BatchNorm running statistics stay local: rank r holds shard r's
+            assert torch.allclose(v.double(), st[k], rtol=2e-4, atol=2e-6), (r, k)
+    mine, ref = [], []
+    for name in g64[0]:
+        avg64 = sum(g[name] for g in g64) / world
+        avg32 = sum(g[name].double() for g in g32) / world
+        for r in range(1, world):
+            assert torch.equal(res[0]["grads"][name], res[r]["grads"][name]), f"rank {r} holds a different averaged gradient for {name}"
+            assert torch.equal(res[0]["params"][name], res[r]["params"][name]), f"replica {r} diverged on {name}"
+        assert torch.equal(res[0]["params"][name], sd[name] - res[0]["grads"][name]), f"SGD(lr=1) update of {name}"
+        scale = avg64.abs().max().item() + 1e-30
+        mine.append((res[0]["grads"][name].double() - avg64).abs().max().item() / scale)
+        ref.append((avg32 - avg64).abs().max().item() / scale)
+    mine, ref = np.array(mine), np.array(ref)
+    assert mine.max() <= 3 * ref.max() + 2e-4 and np.median(mine) <= 3 * np.median(ref) + 1e-4, (mine.max(), ref.max(), np.median(mine), np.median(ref))
+
+
+def test_bucket_written_gradients_equal_copied_gradients(gpu_device):
+    """The destination hook changes WHERE a gradient is written, not its value: two ranks with the kernels writing into the buckets and
+    two ranks with the round-4 behaviour (fresh tensors, copied in) end with bit-identical parameters and gradients."""
+    runs = []
+    for direct in (True, False):
+        world, port = 2, _free_port()
+        with mp.Manager() as mgr:
+            out = mgr.dict()
+            mp.spawn(_worker, args=(world, port, out, "gloo", 4, direct), nprocs=world, join=True)
+            runs.append(out[0])
+    for name in runs[0]["grads"]:
+        assert torch.equal(runs[0]["grads"][name], runs[1]["grads"][name]), name
+        assert torch.equal(runs[0]["params"][name], runs[1]["params"][name]), name
 
 
 def test_ops_follow_the_tensor_device_not_the_current_device(gpu_device):
@@ -177,4 +232,36 @@ def test_bench_spawns_and_verifies_its_own_ranks(gpu_device):
     assert "error" not in t, t
     assert t["n_gpus"] == 2 and t["config"]["global_batch"] == 20 and t["config"]["parallelism"] == "dp2"
     assert t["dp_overlap"] is not None and len(t["dp_overlap"]["buckets"]) >= 3 and t["dp_overlap"]["allreduce_ms_total"] > 0
+
+
+def test_bench_eight_rank_dress_rehearsal(gpu_device):
+    """BASELINE configs[2] as the driver will launch it on an 8-GPU node -- `python bench.py --gpus 8` -- rehearsed on however many GPUs
+    this box has: with fewer than eight the ranks share them over gloo (--share-gpus), so everything but RCCL itself runs: the launcher,
+    the rendezvous of eight ranks, the gloo control plane, the weak leg (batch 10 per rank) and the strong leg (global batch 80 = 8
+    shards of 10: the same shard), the bucketed overlap report, and the replica check after the steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    eight = torch.cuda.device_count() >= 8
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--mode", "train", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--strong-steps", "1"]
+    if not eight:
+        cmd.append("--share-gpus")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    t = json.loads(lines[0])
+    assert "error" not in t, t
+    assert t["n_gpus"] == 8 and t["config"]["global_batch"] == 80 and t["config"]["batch_per_gpu"] == 10 and t["config"]["parallelism"] == "dp8"
+    assert t["config"]["rccl_world_size"] == 8 and t["scaling"] == "weak" and t["value"] > 0
+    st = t["strong"]
+    assert st["global_batch"] == 80 and st["batch_per_gpu"] == 10 and st["n_gpus"] == 8 and st["scaling"] == "strong"
+    ov = t["dp_overlap"]
+    assert ov is not None and len(ov["buckets"]) >= 3 and ov["allreduce_ms_total"] > 0
+    assert sum(b["bytes"] for b in ov["buckets"]) >= 4 * 11_341_000
+    assert t["replicas"]["identical"] is True and t["replicas"]["ranks"] == 8 and t["replicas"]["bucket_copies"] == 0, t["replicas"]
+    assert t["rccl"]["ok"] and t["rccl"]["backend"] == ("nccl" if eight else "gloo")
 

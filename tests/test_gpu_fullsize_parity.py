@@ -39,6 +39,12 @@ def _report(name, obj):
     write_report(name, obj)
 
 
+# Regression thresholds of the training-mode heat maps (bar: 1e-4, BASELINE north_star).  Measured on MI355X, rounds 4-5: the default
+# F(4x4) training forward 4.5-4.6e-5 at N = 2 and N = 10, the F(2x2) forward 1.6e-5, torch-fp32 itself 1.7e-5 -- a kernel edit that
+# drifts past 1.3x of that is noticed here, long before the bar (tests/test_gpu_precision_sweep.py sweeps seeds and weight scales).
+HEAT_BOUND = {"f43": 6e-5, "f22": 2.5e-5}
+
+
 def _fullsize_train_step(gpu_device, n, tag):
     from tracknetv3_amd.model import TrackNet
     from tracknetv3_amd.utils.metric import WBCELoss
@@ -62,7 +68,7 @@ def _fullsize_train_step(gpu_device, n, tag):
         torch.set_num_threads(old)
     e_loss, e_heat = abs(loss.item() - l64.item()), (p.detach().cpu().double() - p64).abs().max().item()
     assert e_loss <= 2e-5, e_loss
-    assert e_heat <= 1e-4, e_heat
+    assert e_heat <= HEAT_BOUND["f22" if tag.endswith("f22fwd") else "f43"], e_heat
     # per-channel sums of the heat maps (a bias the max norm would not show)
     ch = (p.detach().cpu().double().sum((0, 2, 3)) - p64.sum((0, 2, 3))).abs() / p64.sum((0, 2, 3)).abs().clamp_min(1e-30)
     assert ch.max().item() <= 1e-4, ch
@@ -83,11 +89,12 @@ def _fullsize_train_step(gpu_device, n, tag):
                                                   "grad_rel_err": {k: [float(a), float(b)] for k, a, b in zip(names, mine, ref)},
                                                   "worst": [names[int(mine.argmax())], float(mine.max()), float(ref.max())],
                                                   "median": [float(np.median(mine)), float(np.median(ref))]})
-    # every parameter: within 3x the torch-fp32 oracle's own deviation from fp64 (taken over all parameters) + 2e-4
-    assert mine.max() <= 3 * ref.max() + 2e-4, (names[int(mine.argmax())], mine.max(), ref.max())
-    assert np.median(mine) <= 3 * np.median(ref) + 1e-4, (np.median(mine), np.median(ref))
+    # every parameter: within 2x the torch-fp32 oracle's own deviation from fp64 (taken over all parameters) + 2e-4 (measured: 1.3x at the
+    # worst tensor, 1.5-1.6x in the median)
+    assert mine.max() <= 2 * ref.max() + 2e-4, (names[int(mine.argmax())], mine.max(), ref.max())
+    assert np.median(mine) <= 2 * np.median(ref) + 1e-4, (np.median(mine), np.median(ref))
     for k, a, b in zip(names, mine, ref):              # and no single tensor far outside its own fp32 noise
-        assert a <= 10 * b + 5e-4, (k, a, b)
+        assert a <= 4 * b + 5e-4, (k, a, b)
 
 
 def test_tracknet_train_step_288x512_27to8_vs_fp64_oracle(gpu_device, train_fwd):

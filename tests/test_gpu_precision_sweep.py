@@ -1,0 +1,203 @@
+"""GPU: the fp32 margin as a TESTED property, and full-size parity for every network `get_model` can build.
+
+* precision sweep: the 288x512 eval forward and the N = 2 training step of TrackNet(27, 8) against the fp64 host oracle over
+  3 seeds x conv-weight gain {1.0, 2.4, 4.0} x BatchNorm running-variance range {0.5-2, 0.05-0.5} ("trained-like
+  ranges" -- random-init logits are tiny and hide error).  Every row also carries the torch-fp32 oracle's own distance from fp64:
+  where the activations explode (gain 4 in eval mode: logits of 1e3-1e9, heat maps saturated, the few pixels near the threshold
+  move by more than 1e-4 in ANY fp32 evaluation) the bound is relative to that, elsewhere it is absolute.
+* channel plans: `get_model('TrackNet', L, bg)` for (3, ''), (8, ''), (8, 'subtract'), (8, 'subtract_concat') at 288x512 --
+  in_dim 9 / 24 / 8 / 32 (utils/general.py:66-74) take different stem kernels (Cin < 16: the direct MFMA forward and weight
+  gradient; 24 / 32: Winograd F(4x4) with a partial channel block) that the 27-channel benchmark model never runs.
+The measured tables are written to $TNV3_REPORT_DIR (profiles/r05_precision_sweep_*.json).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+H, W = 288, 512
+SEEDS = (31, 47, 59)
+GAINS = (1.0, 2.4, 4.0)
+VAR_RANGES = ((0.5, 2.0), (0.05, 0.5))
+
+# Bounds = 1.5x the worst value of the round-5 sweep on MI355X (profiles/r05_precision_sweep_eval.json / _train.json), rounded up.
+EVAL_HEAT_ABS = 4e-5          # eval heat maps vs fp64 where the network is not saturated
+EVAL_VS_FP32 = 3.0            # ... and at most this many times torch-fp32's own distance elsewhere
+EVAL_LOGIT_REL = 2e-5         # eval logits, relative to max|logit|
+TRAIN_HEAT_ABS = 7e-5         # training-mode heat maps (batch-statistics BatchNorm amplifies the forward's rounding)
+
+
+def _host_threads():
+    return max(1, min(32, (os.cpu_count() or 2) // 2))
+
+
+def _report(name, obj):
+    from conftest import write_report
+    write_report(name, obj)
+
+
+def _model(in_dim, out_dim, sd, dev):
+    from tracknetv3_amd.model import TrackNet
+    m = TrackNet(in_dim, out_dim)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev)
+
+
+def _gpu_logits(m, x):
+    """The eval forward's pre-sigmoid output: the head kernel with its sigmoid switched off (same launch, same arithmetic before it)."""
+    from tracknetv3_amd import ops
+    real = ops.head1x1_sigmoid
+    try:
+        ops.head1x1_sigmoid = lambda a, w, b, apply_sigmoid=True, out=None: real(a, w, b, apply_sigmoid=False, out=out)
+        return m(x)
+    finally:
+        ops.head1x1_sigmoid = real
+
+
+def _eval_row(dev, in_dim, out_dim, seed, gain, var_range, n=2):
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=True, gain=gain, var_range=var_range)
+    x = nets.synth_input((n, in_dim, H, W), seed + 1000)
+    m = _model(in_dim, out_dim, sd, dev).eval()
+    with torch.no_grad():
+        p = m(x.to(dev)).cpu().double()
+        z = _gpu_logits(m, x.to(dev)).cpu().double()
+        sd64 = {k: (v.double() if v.dtype != torch.int64 else v) for k, v in sd.items()}
+        z64 = nets.tracknet_forward(sd64, x.double(), training=False, return_logits=True)
+        z32 = nets.tracknet_forward(sd, x, training=False, return_logits=True).double()
+    p64, p32 = torch.sigmoid(z64), torch.sigmoid(z32)
+    zmax = z64.abs().max().item()
+    return {"seed": seed, "gain": gain, "var_range": list(var_range), "max_abs_logit": zmax,
+            "heat_err": (p - p64).abs().max().item(), "heat_err_torch_fp32": (p32 - p64).abs().max().item(),
+            "logit_rel_err": (z - z64).abs().max().item() / (zmax + 1e-30),
+            "logit_rel_err_torch_fp32": (z32 - z64).abs().max().item() / (zmax + 1e-30),
+            "heat_range": [p64.min().item(), p64.max().item()]}
+
+
+def test_precision_sweep_eval_forward_288x512(gpu_device):
+    """18 networks: the eval forward (F(4x4) everywhere, 25-of-36 upsampled halves) stays inside the bounds above for every one."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(_host_threads())
+    rows = []
+    try:
+        for seed in SEEDS:
+            for gain in GAINS:
+                for vr in VAR_RANGES:
+                    rows.append(_eval_row(gpu_device, 27, 8, seed, gain, vr))
+    finally:
+        torch.set_num_threads(old)
+    worst = {k: max(r[k] for r in rows) for k in ("heat_err", "heat_err_torch_fp32", "logit_rel_err", "logit_rel_err_torch_fp32")}
+    _report("precision_sweep_eval.json", {"shape": [2, 27, H, W], "rows": rows, "worst": worst,
+                                          "bounds": {"heat_abs": EVAL_HEAT_ABS, "heat_vs_fp32": EVAL_VS_FP32, "logit_rel": EVAL_LOGIT_REL}})
+    for r in rows:
+        assert r["heat_err"] <= max(EVAL_HEAT_ABS, EVAL_VS_FP32 * r["heat_err_torch_fp32"]), r
+        assert r["logit_rel_err"] <= EVAL_LOGIT_REL, r
+        assert r["heat_err"] <= 1e-4 or r["heat_err_torch_fp32"] > 3e-5, r      # north_star's bar wherever fp32 itself can meet it
+
+
+def _train_row(dev, in_dim, out_dim, seed, gain, n=2, want32=False):
+    from tracknetv3_amd.utils.metric import WBCELoss
+    sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=True, gain=gain)
+    x = nets.synth_input((n, in_dim, H, W), seed + 1000)
+    y = nets.disc_heatmaps(n, out_dim, H, W, seed + 2000)
+    m = _model(in_dim, out_dim, sd, dev).train()
+    p = m(x.to(dev))
+    loss = WBCELoss(p, y.to(dev))
+    loss.backward()
+    torch.cuda.synchronize(dev)
+    l64, p64, g64, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float64)
+    names = list(g64.keys())
+    params = dict(m.named_parameters())
+
+    def rel(a, b):
+        return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-30)
+    mine = np.array([rel(params[k].grad.cpu(), g64[k]) for k in names])
+    row = {"seed": seed, "gain": gain, "loss_abs_err": abs(loss.item() - l64.item()),
+           "heat_err": (p.detach().cpu().double() - p64).abs().max().item(),
+           "heat_range": [p64.min().item(), p64.max().item()],
+           "grad_rel_err_max": float(mine.max()), "grad_rel_err_median": float(np.median(mine)), "grad_worst": names[int(mine.argmax())]}
+    if want32:
+        _, p32, g32, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float32)
+        ref = np.array([rel(g32[k], g64[k]) for k in names])
+        row.update({"heat_err_torch_fp32": (p32.double() - p64).abs().max().item(), "grad_rel_err_max_torch_fp32": float(ref.max()),
+                    "grad_rel_err_median_torch_fp32": float(np.median(ref)),
+                    "grad_per_tensor_over_fp32_max": float((mine / (ref + 1e-30)).max())})
+        row["_mine"], row["_ref"], row["_names"] = mine, ref, names
+    return row
+
+
+def test_precision_sweep_train_step_288x512(gpu_device):
+    """Nine networks through the default training forward (F(4x4) with the statistics epilogue): heat maps inside TRAIN_HEAT_ABS of the
+    fp64 oracle, the loss inside 2e-5, the worst gradient tensor inside 6e-2 of its own scale (torch-fp32 itself: 2.5e-2)."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(_host_threads())
+    rows = []
+    try:
+        for seed in SEEDS:
+            for gain in GAINS:
+                rows.append(_train_row(gpu_device, 27, 8, seed, gain, want32=(gain == 2.4)))
+    finally:
+        torch.set_num_threads(old)
+    for r in rows:
+        for k in ("_mine", "_ref", "_names"):
+            r.pop(k, None)
+    worst = {k: max(r[k] for r in rows) for k in ("heat_err", "loss_abs_err", "grad_rel_err_max", "grad_rel_err_median")}
+    _report("precision_sweep_train.json", {"shape": [2, 27, H, W], "rows": rows, "worst": worst, "bounds": {"heat_abs": TRAIN_HEAT_ABS}})
+    for r in rows:
+        assert r["heat_err"] <= TRAIN_HEAT_ABS, r
+        assert r["loss_abs_err"] <= 2e-5, r
+        assert r["grad_rel_err_max"] <= 6e-2 and r["grad_rel_err_median"] <= 2e-2, r
+        if "heat_err_torch_fp32" in r:
+            assert r["grad_rel_err_max"] <= 2 * r["grad_rel_err_max_torch_fp32"] + 2e-4, r
+            assert r["grad_rel_err_median"] <= 2 * r["grad_rel_err_median_torch_fp32"] + 1e-4, r
+
+
+PLANS = [(3, ""), (8, ""), (8, "subtract"), (8, "subtract_concat")]
+
+
+@pytest.mark.parametrize("plan", PLANS, ids=["L3_rgb_9to3", "L8_rgb_24to8", "L8_subtract_8to8", "L8_subtract_concat_32to8"])
+def test_every_channel_plan_eval_and_train_step_288x512(gpu_device, plan):
+    """BASELINE configs[0]'s model (seq_len 3, bg_mode '': 9 -> 3) and the other plans of utils/general.py:66-74 at their REAL size,
+    N = 2: eval forward <= 2.5e-5, one training step (loss, heat maps, all 53 gradients with torch-fp32's distance as the yardstick)
+    and the stem's weight gradient on its own at K = 2 x 288 x 512 against fp64."""
+    from tracknetv3_amd import ops, tuning
+    from tracknetv3_amd.utils.general import get_model
+    seq_len, bg = plan
+    in_dim, out_dim = nets.tracknet_dims(seq_len, bg)
+    net = get_model("TrackNet", seq_len, bg)
+    assert (net.in_dim, net.out_dim) == (in_dim, out_dim)
+    old = torch.get_num_threads()
+    torch.set_num_threads(_host_threads())
+    try:
+        ev = _eval_row(gpu_device, in_dim, out_dim, 31, 2.4, (0.5, 2.0))
+        assert ev["heat_err"] <= 2.5e-5 and ev["logit_rel_err"] <= EVAL_LOGIT_REL, ev
+        tr = _train_row(gpu_device, in_dim, out_dim, 31, 2.4, want32=True)
+        mine, ref, names = tr.pop("_mine"), tr.pop("_ref"), tr.pop("_names")
+        assert tr["loss_abs_err"] <= 2e-5 and tr["heat_err"] <= TRAIN_HEAT_ABS, tr
+        assert mine.max() <= 2 * ref.max() + 2e-4, (names[int(mine.argmax())], mine.max(), ref.max())
+        assert np.median(mine) <= 2 * np.median(ref) + 1e-4, (np.median(mine), np.median(ref))
+        for k, a, b in zip(names, mine, ref):
+            assert a <= 4 * b + 5e-4, (k, a, b)
+        # the stem's weight gradient alone, through the kernel the training step dispatches for this Cin
+        x = nets.synth_input((2, in_dim, H, W), 77)
+        dz = torch.from_numpy(nets.prng.uniform((2, 64, H, W), 78, -1.0, 1.0))
+        wd = torch.zeros((64, in_dim, 3, 3), dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), wd, padding=1).backward(dz.double())
+        wino = tuning.use_winograd_wgrad(in_dim, 64, H, W)
+        xd, dzd = x.to(gpu_device), dz.to(gpu_device)
+        dw = (ops.conv3x3_wgrad_wino(xd, dzd) if wino else ops.conv3x3_wgrad(xd, dzd)).cpu()
+        e_dw = (dw.double() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
+        assert e_dw <= 2e-5, (wino, e_dw)
+        if wino:                                             # and the direct kernel on the same operands (the Cin < 16 plans' path)
+            e_dir = (ops.conv3x3_wgrad(xd, dzd).cpu().double() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
+            assert e_dir <= 2e-5, e_dir
+    finally:
+        torch.set_num_threads(old)
+    tr["stem_wgrad_rel_err"], tr["stem_wgrad_kernel"] = e_dw, ("winograd" if wino else "direct")
+    _report(f"channel_plan_{in_dim}to{out_dim}.json", {"plan": {"seq_len": seq_len, "bg_mode": bg, "in_dim": in_dim, "out_dim": out_dim},
+                                                        "eval": ev, "train": tr})

@@ -73,6 +73,72 @@ def test_two_rank_gradient_allreduce_and_sharding():
         assert not np.array_equal(r0["lam"], r1["lam"]), "each rank draws its own mixup lambdas"
 
 
+def _worker8(rank, world, port, out):
+    """BASELINE configs[2]'s rank count: 8 ranks, global batch 80.  Gradients are WRITTEN INTO the reducer's bucket views (what the
+    backward kernels do through autograd_ops' destination hook), so no copy may happen."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from tracknetv3_amd import autograd_ops, parallel
+        from tracknetv3_amd.utils.general import get_model
+        torch.manual_seed(100 + rank)
+        net = get_model("TrackNet", 8, "concat")            # the benchmark's model: 27 -> 8
+        parallel.broadcast_module(net, 0)
+        order = autograd_ops.grad_ready_order(net)
+        red = parallel.GradAllReducer(order, bucket_bytes=12 << 20)
+        assert red.world == 8 and 3 <= red.num_buckets() <= 8
+        for p in order:                                     # every slot 256 bytes into its bucket (the device allocator aligns the bucket
+            v = red.dest(p)                                 # itself to 512 bytes; the host allocator to 64), no overlap
+            base = red.buckets[red.slot[id(p)][0]]["flat"].data_ptr()
+            assert v.shape == p.shape and v.is_contiguous() and (v.data_ptr() - base) % 256 == 0 and v.data_ptr() % 16 == 0
+        spans = sorted((red.dest(p).data_ptr(), red.dest(p).data_ptr() + 4 * p.numel()) for p in order)
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+        gen = torch.Generator().manual_seed(7 + rank)
+        checks = {}
+        for step in range(2):                               # the second step reuses the buckets (no stale arrival counts)
+            for p in order:
+                g = torch.randn(p.shape, generator=gen)
+                if p.numel() <= 4096:                       # (all-gathering the big ones 8 ways would dominate the test)
+                    checks[id(p)] = g.clone()
+                view = red.dest(p)
+                view.copy_(g)                               # the "kernel" writes the gradient where the collective reads it
+                got = red.on_grad(p, view)
+                assert got.data_ptr() == view.data_ptr()
+            red.on_backward_end()
+            assert red.copies == 0, "a gradient written into its destination must not be copied again"
+            for p in order:
+                if id(p) in checks:
+                    other = [torch.empty_like(checks[id(p)]) for _ in range(world)]
+                    dist.all_gather(other, checks[id(p)])
+                    assert torch.allclose(red.dest(p), sum(other) / world, atol=1e-6), "bucket average mismatch"
+        # a gradient that arrives somewhere else (a caller's own tensor) is still copied in -- and counted
+        red.on_grad(order[0], torch.ones(order[0].shape))
+        assert red.copies == 1
+        red.reset()
+        lo, hi = parallel.shard_range(80, rank, world)
+        w0 = torch.cat([p.detach().reshape(-1)[:8] for p in net.parameters()])
+        pads = sum(b["flat"].numel() for b in red.buckets) - sum(p.numel() for p in order)
+        out[rank] = dict(shard=(lo, hi), w0=w0, buckets=red.num_buckets(), pad_floats=pads)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_bucket_views_and_global_batch_80():
+    """The rank count and global batch of BASELINE configs[2] on the gloo stand-in (RCCL replaces it on the GPUs with the same calls)."""
+    world, port = 8, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker8, args=(world, port, out), nprocs=world, join=True)
+        res = [dict(out[r]) for r in range(world)]
+    assert [r["shard"] for r in res] == [(10 * r, 10 * r + 10) for r in range(world)]      # 80 = 8 x the reference's batch of 10
+    for r in res[1:]:
+        assert torch.equal(r["w0"], res[0]["w0"]), "broadcast_module must make the eight replicas identical"
+        assert r["buckets"] == res[0]["buckets"]
+    assert 0 <= res[0]["pad_floats"] < 53 * 64
+
+
 def test_shard_range_covers_batch():
     from tracknetv3_amd.parallel import shard_range
     for gb in (1, 7, 10, 80, 81):

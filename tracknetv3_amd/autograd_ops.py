@@ -18,6 +18,7 @@ from . import tuning
 
 _grad_ready_hook = None
 _backward_end_hook = None
+_grad_dest_hook = None
 
 # Weight gradients on a side HIP stream: wgrad(L) depends only on dZ(L), while the main chain continues with
 # dgrad(L) -> BN backward(L-1) -> ...  Two independent chains in flight let the HBM-bound BN passes and the tails of
@@ -51,11 +52,13 @@ def wgrad_stream(dev):
     return _WGRAD_STREAMS[key]
 
 
-def set_grad_ready_hook(fn, end_fn=None):
+def set_grad_ready_hook(fn, end_fn=None, dest_fn=None):
     """fn(param, grad) -> grad-or-replacement is called inside backward as soon as `grad` is final; end_fn() runs
-    once after the last gradient of the step (None disables both)."""
-    global _grad_ready_hook, _backward_end_hook
-    _grad_ready_hook, _backward_end_hook = fn, end_fn
+    once after the last gradient of the step (None disables both).  dest_fn(param) -> tensor-or-None names where the kernel that
+    produces `param`'s gradient should WRITE it (the data-parallel reducer returns the parameter's view of its flat all-reduce bucket:
+    the gradient then needs no copy into the bucket); fn still sees every gradient."""
+    global _grad_ready_hook, _backward_end_hook, _grad_dest_hook
+    _grad_ready_hook, _backward_end_hook, _grad_dest_hook = fn, end_fn, dest_fn
 
 
 def grad_ready_order(net):
@@ -125,15 +128,19 @@ def _train_forward_body(net, x):
 
 
 def _train_backward_body(ctx, dev, head_backward):
-    """Everything behind the loss: `head_backward()` -> (da, dW_head, db_head), then per block in reverse BN+ReLU backward,
+    """Everything behind the loss: `head_backward((dW destination, db destination))` -> (da, dW_head, db_head), then per block in reverse BN+ReLU backward,
     data gradient, weight gradient (side stream).  Returns the tuple autograd expects after the non-tensor arguments."""
     net, saved = ctx.net, ctx.saved
     if saved is None:
         raise RuntimeError("TrackNet backward ran twice over the same forward: the training node frees its activations at the "
                            "end of backward (retain_graph=True is not supported); run the forward again")
     hook = _grad_ready_hook
+    dest_fn = _grad_dest_hook
     grads = {}
     keep = []
+
+    def dest(param):
+        return dest_fn(param) if dest_fn is not None else None
 
     def done(param, g):
         if hook is not None:
@@ -147,7 +154,7 @@ def _train_backward_body(ctx, dev, head_backward):
     if dev.type == "cuda":
         _BACKWARD_STREAMS[dev.index if dev.index is not None else 0] = \
             [torch.cuda.current_stream(dev)] + ([side] if side is not None else [])
-    da, dw_head, db_head = head_backward()
+    da, dw_head, db_head = head_backward((dest(net.predictor.weight), dest(net.predictor.bias)))
     done(net.predictor.weight, dw_head)
     done(net.predictor.bias, db_head)
 
@@ -164,23 +171,24 @@ def _train_backward_body(ctx, dev, head_backward):
         same = bn_unchanged(rec)
         if da_stats is not None:
             dz, dgamma, dbeta = ops.bn_relu_backward_tiles(da, rec["z"], blk.bn.weight.detach(), blk.bn.bias.detach(), rec["mean"],
-                                                           rec["invstd"], da_stats)
+                                                           rec["invstd"], da_stats, out=(dest(blk.bn.weight), dest(blk.bn.bias)))
         else:
             dz, dgamma, dbeta = ops.bn_relu_backward(da, None if same else rec["a"], rec["z"], blk.bn.weight.detach(), rec["mean"],
-                                                     rec["invstd"], beta=blk.bn.bias.detach())
+                                                     rec["invstd"], beta=blk.bn.bias.detach(), out=(dest(blk.bn.weight), dest(blk.bn.bias)))
         done(blk.bn.weight, dgamma)
         done(blk.bn.bias, dbeta)
 
         def wgrad():
+            out = dest(blk.conv.weight)                   # (the reducer's bucket view, or None: a fresh tensor)
             if rec["up"] and rec["x1"] is not None:       # decoder entry: upsampled channels at the low resolution
-                return ops.conv3x3_wgrad_up2x(rec["x0"], rec["x1"], dz)
+                return ops.conv3x3_wgrad_up2x(rec["x0"], rec["x1"], dz, out=out)
             if rec["x1"] is None and not rec["up"] and tuning.use_winograd_wgrad(
                     int(rec["x0"].shape[1]), blk.conv.out_dim, int(dz.shape[2]), int(dz.shape[3])):
                 # plain layer: Winograd-form weight gradient (tuning.WGRAD_WINO_TAIL, default 0: the no-role kernel for the first
                 # blocks, whose launches are the last of backward -- measured, no gain)
                 tail = rec["idx"] < tuning.WGRAD_WINO_TAIL and tuning.WGRAD_WINO_VARIANT < 0
-                return ops.conv3x3_wgrad_wino(rec["x0"], dz, variant=5 if tail else None)
-            return ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"])
+                return ops.conv3x3_wgrad_wino(rec["x0"], dz, variant=5 if tail else None, out=out)
+            return ops.conv3x3_wgrad(rec["x0"], dz, src1=rec["x1"], up0=rec["up"], out=out)
 
         if side is None:
             dw = wgrad()
@@ -298,7 +306,7 @@ class _TrackNetTrain(torch.autograd.Function):
         dp = dp.contiguous()
         (p_out,) = ctx.saved_tensors
         net, head_in = ctx.net, ctx.head_in
-        dx, pgrads = _train_backward_body(ctx, dp.device, lambda: ops.head_backward(dp, p_out, head_in, net.predictor.weight.detach()))
+        dx, pgrads = _train_backward_body(ctx, dp.device, lambda out: ops.head_backward(dp, p_out, head_in, net.predictor.weight.detach(), out=out))
         return (None, dx) + pgrads
 
 
@@ -324,7 +332,7 @@ class _TrackNetTrainLoss(torch.autograd.Function):
         net, head_in = ctx.net, ctx.head_in
         up = dloss.reshape(-1).contiguous().float()
         dx, pgrads = _train_backward_body(
-            ctx, up.device, lambda: ops.head_wbce_backward(y, p_out, head_in, net.predictor.weight.detach(), up, ctx.reduce))
+            ctx, up.device, lambda out: ops.head_wbce_backward(y, p_out, head_in, net.predictor.weight.detach(), up, ctx.reduce, out=out))
         return (None, dx, None, None) + pgrads
 
 

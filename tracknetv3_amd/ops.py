@@ -605,6 +605,20 @@ def _workspace(nbytes, device):
     return torch.empty((int(nbytes) + 7) // 8, dtype=torch.int64, device=device)
 
 
+def _grad_out(shape, device, out, what):
+    """The tensor a gradient kernel writes: `out` when the caller names a destination (the data-parallel reducer hands out views of its
+    flat all-reduce buckets, so a gradient is born where the collective reads it -- no copy), else a fresh one.  A destination must be a
+    contiguous fp32 tensor of the gradient's element count on the gradient's device, 16-byte aligned (some folds store float4)."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    n = 1
+    for v in shape:
+        n *= int(v)
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n or out.device != device or out.data_ptr() % 16:
+        raise _lib.Tnv3Error(f"{what}: `out` must be a contiguous, 16-byte aligned fp32 tensor of {n} elements on {device}")
+    return out.view(shape)
+
+
 def bn_train_forward(z, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=0.1, tile_stats=None):
     """Training-mode BatchNorm2d + ReLU on the raw conv output; updates running stats in place.
     Returns (a, save_mean, save_invstd).  tile_stats: the (C, tiles, 2) float64 sums the producing convolution's epilogue left
@@ -631,9 +645,10 @@ def bn_train_forward(z, gamma, beta, running_mean, running_var, eps=BN_EPS, mome
     return a, mean, invstd
 
 
-def bn_relu_backward(da, a, z, gamma, mean, invstd, inplace=True, beta=None):
+def bn_relu_backward(da, a, z, gamma, mean, invstd, inplace=True, beta=None, out=None):
     """Returns (dz, dgamma, dbeta); dz overwrites da when inplace.  With a=None the ReLU mask is recomputed from z, gamma,
-    beta and the saved statistics (bit-identical to a > 0; gamma / beta must be the forward call's values)."""
+    beta and the saved statistics (bit-identical to a > 0; gamma / beta must be the forward call's values).  out: (dgamma, dbeta)
+    destinations (either may be None)."""
     lib = _lib.load()
     if a is None and beta is None:
         raise _lib.Tnv3Error("bn_relu_backward: needs the forward output a or beta")
@@ -641,8 +656,8 @@ def bn_relu_backward(da, a, z, gamma, mean, invstd, inplace=True, beta=None):
     _lib.dev_check(da, a, z, gamma, beta, mean, invstd)
     n, c, h, w = (int(v) for v in z.shape)
     dz = da if inplace else torch.empty_like(da)
-    dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
-    dbeta = torch.empty_like(dgamma)
+    dgamma = _grad_out((c,), z.device, out[0] if out else None, "bn_relu_backward")
+    dbeta = _grad_out((c,), z.device, out[1] if out else None, "bn_relu_backward")
     ws = _workspace(lib.tnv3_bn_workspace_bytes(c), z.device)
     _lib.check(lib.tnv3_bn_relu_backward(_lib.ptr(da), _lib.ptr(a), _lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
                                          _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel() * 8, n, c,
@@ -680,8 +695,9 @@ def conv3x3_wino_dgrad_bnstats(dz, u, cout, bn_z, bn_c4, variant=None):
     return da, stats
 
 
-def bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, tile_stats, inplace=True):
-    """bn_relu_backward with the two per-channel sums already taken per pixel tile by conv3x3_wino_dgrad_bnstats: one pass over (dA, z)."""
+def bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, tile_stats, inplace=True, out=None):
+    """bn_relu_backward with the two per-channel sums already taken per pixel tile by conv3x3_wino_dgrad_bnstats: one pass over (dA, z).
+    out: (dgamma, dbeta) destinations."""
     lib = _lib.load()
     _f32(da, z, gamma, beta, mean, invstd)
     _lib.dev_check(da, z, gamma, beta, mean, invstd, tile_stats)
@@ -689,8 +705,8 @@ def bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, tile_stats, inplace
         raise _lib.Tnv3Error("bn_relu_backward_tiles: tile_stats must be a contiguous float64 tensor")
     n, c, h, w = (int(v) for v in z.shape)
     dz = da if inplace else torch.empty_like(da)
-    dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
-    dbeta = torch.empty_like(dgamma)
+    dgamma = _grad_out((c,), z.device, out[0] if out else None, "bn_relu_backward_tiles")
+    dbeta = _grad_out((c,), z.device, out[1] if out else None, "bn_relu_backward_tiles")
     ws = _workspace(lib.tnv3_bn_workspace_bytes(c), z.device)
     _lib.check(lib.tnv3_bn_relu_backward_tiles(_lib.ptr(da), _lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
                                                _lib.ptr(tile_stats), int(tile_stats.shape[1]), _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta),
@@ -713,16 +729,16 @@ def conv3x3_dgrad(dz, wpack_t, c0, c1=0, cfg=-1):
     return dx0, dx1
 
 
-def conv3x3_wgrad(src0, dz, src1=None, up0=False, variant=None):
+def conv3x3_wgrad(src0, dz, src1=None, up0=False, variant=None, out=None):
     """dW[Cout][C0+C1][3][3] for X = cat([up2x?(src0), src1], 1).  variant: kernel family for THIS call (None:
-    tuning.WGRAD_VARIANT; 0 register-staged, 1 LDS-DMA staged)."""
+    tuning.WGRAD_VARIANT; 0 register-staged, 1 LDS-DMA staged).  out: where dW is written (see _grad_out)."""
     lib = _lib.load()
     _f32(src0, src1, dz)
     _lib.dev_check(src0, src1, dz)
     n, cout, h, w = (int(v) for v in dz.shape)
     c0 = int(src0.shape[1])
     c1 = int(src1.shape[1]) if src1 is not None else 0
-    dw = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dz.device)
+    dw = _grad_out((cout, c0 + c1, 3, 3), dz.device, out, "conv3x3_wgrad")
     if variant is None:
         from . import tuning
         variant = tuning.WGRAD_VARIANT
@@ -746,7 +762,7 @@ def _wgrad_wino_variant(variant, h=0):
     return int(variant)
 
 
-def conv3x3_wgrad_wino(x, dz, variant=None):
+def conv3x3_wgrad_wino(x, dz, variant=None, out=None):
     """dW[Cout][Cin][3][3] of a plain layer in Winograd form -- see tnv3_conv3x3_wgrad_wino.  variant: kernel for THIS
     call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's default = 1, or 5 when Cin % 64 != 0; 1-4 the role-split generations;
     5 / 6 every wave streams and transforms; 0 the first kernel -- all F(2x2, 3x3), bit-identical; 8: the F(4x4, 3x3) kernel,
@@ -758,21 +774,26 @@ def conv3x3_wgrad_wino(x, dz, variant=None):
     cin = int(x.shape[1])
     if tuple(x.shape) != (n, cin, h, w):
         raise _lib.Tnv3Error("conv3x3_wgrad_wino: x and dz must share batch and spatial size")
-    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dz.device)
+    dw = _grad_out((cout, cin, 3, 3), dz.device, out, "conv3x3_wgrad_wino")
     ws = _workspace(lib.tnv3_conv3x3_wgrad_wino_workspace_bytes(n, cin, cout, h, w), dz.device)
     _lib.check(lib.tnv3_conv3x3_wgrad_wino(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8, n, cin, cout, h, w,
                                            _wgrad_wino_variant(variant, h), _lib.stream_ptr(dz)))
     return dw
 
 
-def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None):
+_WGRAD_UP2X_OF_PLAIN = {-1: -1, 1: 2, 2: 2, 5: 5, 8: 8}      # tuning.WGRAD_WINO_VARIANT -> tnv3_conv3x3_wgrad_up2x's own numbering
+
+
+def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None, out=None):
     """dW[Cout][C0+C1][3][3] of a decoder-entry layer (X = cat([upsample2x(x_low), skip], 1)), its upsampled channels at the
-    low resolution -- see tnv3_conv3x3_wgrad_up2x.  wino_variant: an explicit number is the C entry's own (-1 default, 0 / 1 the
-    2x2-window forms, 2 .. 5 the 9-GEMM form with kernel 1 / 3 / 4 / 5 for the skip half); None follows tuning.WGRAD_WINO_VARIANT,
-    the PLAIN layers' kernel choice, keeping the 9-GEMM form (plain kernel 1 / 2 -> 2 / 3 here)."""
+    low resolution -- see tnv3_conv3x3_wgrad_up2x.  wino_variant: an explicit number is the C entry's own (-1 / 8: the library's default
+    for the skip half -- F(4x4) where it applies -- with the Winograd form of the upsampled half; 2 / 5: F(2x2) kernel 1 / 5 for the skip half;
+    1: kernel 1 and the upsampled half by the four 2x2-window launches); None follows tuning.WGRAD_WINO_VARIANT, the PLAIN layers' kernel
+    choice (dispatchable: -1, 1, 2, 5, 8), keeping the Winograd form of the upsampled half: the plain kernels 1 and 2 both map to 2 here (the
+    skip half has no kernel-2 form), 5 and 8 to themselves."""
     if wino_variant is None:
         from . import tuning
-        wino_variant = {-1: -1, 0: 0, 1: 2, 2: 3}.get(int(tuning.WGRAD_WINO_VARIANT), int(tuning.WGRAD_WINO_VARIANT))
+        wino_variant = _WGRAD_UP2X_OF_PLAIN[int(tuning.WGRAD_WINO_VARIANT)]
     lib = _lib.load()
     _f32(x_low, skip, dz)
     _lib.dev_check(x_low, skip, dz)
@@ -780,7 +801,7 @@ def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None):
     c0, c1 = int(x_low.shape[1]), int(skip.shape[1])
     if tuple(x_low.shape[2:]) != (h // 2, w // 2) or tuple(skip.shape[2:]) != (h, w):
         raise _lib.Tnv3Error("conv3x3_wgrad_up2x: x_low must be half the size of skip / dz")
-    dw = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dz.device)
+    dw = _grad_out((cout, c0 + c1, 3, 3), dz.device, out, "conv3x3_wgrad_up2x")
     ws = _workspace(lib.tnv3_conv3x3_wgrad_up2x_workspace_bytes(n, c0, c1, cout, h // 2, w // 2), dz.device)
     _lib.check(lib.tnv3_conv3x3_wgrad_up2x(_lib.ptr(x_low), _lib.ptr(skip), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8,
                                            n, c0, c1, cout, h // 2, w // 2, int(wino_variant), _lib.stream_ptr(dz)))
@@ -812,8 +833,8 @@ def wbce_backward(p, y, upstream, reduce=True):
     return dp
 
 
-def head_backward(dp, p, a, weight):
-    """Backward of p = sigmoid(conv1x1(a) + b): returns (da, dW (L,64,1,1), db (L,))."""
+def head_backward(dp, p, a, weight, out=None):
+    """Backward of p = sigmoid(conv1x1(a) + b): returns (da, dW (L,64,1,1), db (L,)).  out: (dW, db) destinations."""
     lib = _lib.load()
     _f32(dp, p, a, weight)
     _lib.dev_check(dp, p, a, weight)
@@ -821,8 +842,8 @@ def head_backward(dp, p, a, weight):
     if int(a.shape[1]) != 64:
         raise _lib.Tnv3Error("head_backward: expects 64 input channels")
     da = torch.empty_like(a)
-    dw = torch.empty((l, 64, 1, 1), dtype=torch.float32, device=p.device)
-    db = torch.empty(l, dtype=torch.float32, device=p.device)
+    dw = _grad_out((l, 64, 1, 1), p.device, out[0] if out else None, "head backward")
+    db = _grad_out((l,), p.device, out[1] if out else None, "head backward")
     ws = _workspace(lib.tnv3_head_backward_workspace_bytes(l), p.device)
     _lib.check(lib.tnv3_head_backward(_lib.ptr(dp), _lib.ptr(p), _lib.ptr(a), _lib.ptr(weight), _lib.ptr(da), _lib.ptr(dw),
                                       _lib.ptr(db), _lib.ptr(ws), ws.numel() * 8, n, l, h * w, _lib.stream_ptr(p)))
@@ -846,8 +867,8 @@ def head1x1_sigmoid_wbce(x, weight, bias, y, reduce=True):
     return p, loss
 
 
-def head_wbce_backward(y, p, a, weight, upstream, reduce=True):
-    """Backward of head + sigmoid + WBCELoss without a dP tensor: returns (da, dW (L,64,1,1), db (L,))."""
+def head_wbce_backward(y, p, a, weight, upstream, reduce=True, out=None):
+    """Backward of head + sigmoid + WBCELoss without a dP tensor: returns (da, dW (L,64,1,1), db (L,)).  out: (dW, db) destinations."""
     lib = _lib.load()
     _f32(y, p, a, weight, upstream)
     _lib.dev_check(y, p, a, weight, upstream)
@@ -855,8 +876,8 @@ def head_wbce_backward(y, p, a, weight, upstream, reduce=True):
     if int(a.shape[1]) != 64:
         raise _lib.Tnv3Error("head_wbce_backward: expects 64 input channels")
     da = torch.empty_like(a)
-    dw = torch.empty((l, 64, 1, 1), dtype=torch.float32, device=p.device)
-    db = torch.empty(l, dtype=torch.float32, device=p.device)
+    dw = _grad_out((l, 64, 1, 1), p.device, out[0] if out else None, "head backward")
+    db = _grad_out((l,), p.device, out[1] if out else None, "head backward")
     ws = _workspace(lib.tnv3_head_backward_workspace_bytes(l), p.device)
     _lib.check(lib.tnv3_head_wbce_backward(_lib.ptr(y), _lib.ptr(p), _lib.ptr(a), _lib.ptr(weight), _lib.ptr(upstream), _lib.ptr(da),
                                            _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), ws.numel() * 8, n, l, h * w, int(bool(reduce)),

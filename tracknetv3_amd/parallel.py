@@ -47,25 +47,38 @@ class GradAllReducer:
             self._close(cur, cur_n)
         self.pending = []
         self.arrived = [0] * len(self.buckets)
+        self.copies = 0                               # gradients that had to be copied into their bucket (0 when the kernels write there)
+
+    SLOT_ALIGN = 64      # floats: every parameter's slot starts 256-byte aligned, so a kernel can write its gradient straight into it
 
     def _close(self, plist, total):
-        flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        a = self.SLOT_ALIGN
+        padded = sum((p.numel() + a - 1) // a * a for p in plist)
+        flat = torch.zeros(padded, dtype=torch.float32, device=self.device)      # (the pad floats stay zero: they ride along in the all-reduce)
         b = len(self.buckets)
         off = 0
         for p in plist:
             self.slot[id(p)] = (b, off, p.numel(), tuple(p.shape))
-            off += p.numel()
+            off += (p.numel() + a - 1) // a * a
         self.buckets.append(dict(flat=flat, count=len(plist)))
 
     def num_buckets(self):
         return len(self.buckets)
 
-    # grad-ready hook: copy into the bucket, hand the bucket VIEW to autograd, launch the collective when full
+    def dest(self, param):
+        """The parameter's view of its bucket: where backward's kernels write the gradient (autograd_ops' destination hook)."""
+        b, off, n, shape = self.slot[id(param)]
+        return self.buckets[b]["flat"][off:off + n].view(shape)
+
+    # grad-ready hook: the gradient is in the bucket already when the producing kernel wrote it there (dest), else it is copied in;
+    # hand the bucket VIEW to autograd, launch the collective when the bucket is full
     def on_grad(self, param, grad):
         b, off, n, shape = self.slot[id(param)]
         flat = self.buckets[b]["flat"]
         view = flat[off:off + n].view(shape)
-        view.copy_(grad)
+        if grad.data_ptr() != view.data_ptr():
+            view.copy_(grad)
+            self.copies += 1
         self.arrived[b] += 1
         if self.arrived[b] == self.buckets[b]["count"]:
             self._launch(b)
@@ -153,11 +166,13 @@ class TrackNetTrainer:
     train.py:94 is what would serialise 8 GPUs).  With `device_rng` (default) the mixup draws come from the device-side Philox
     generator, and with `optim.FusedAdam` the update is one launch: a step then issues no H2D copy at all."""
 
-    def __init__(self, net, optimizer, alpha=0.0, seed=13, group=None, bucket_bytes=12 << 20, record_timing=False, device_rng=True):
+    def __init__(self, net, optimizer, alpha=0.0, seed=13, group=None, bucket_bytes=12 << 20, record_timing=False, device_rng=True,
+                 direct_grads=True):
         from .utils.metric import WBCELoss
         self.device_rng, self.seed, self.steps_done = bool(device_rng), int(seed), 0
         self.fused_loss = hasattr(net, "predictor") and hasattr(net, "down_block_1")      # TrackNet: loss fused into the head
         self.record_timing = bool(record_timing)
+        self.direct_grads = bool(direct_grads)         # backward's kernels write the gradients into the all-reduce buckets (no copy)
         self.last_timing = None
         self.net, self.opt, self.alpha, self.loss_fn = net, optimizer, alpha, WBCELoss
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -181,7 +196,8 @@ class TrackNetTrainer:
         timing = self.record_timing and x.is_cuda
         if self.reducer is not None:
             self.reducer.begin_step()
-            autograd_ops.set_grad_ready_hook(self.reducer.on_grad, self.reducer.on_backward_end)
+            autograd_ops.set_grad_ready_hook(self.reducer.on_grad, self.reducer.on_backward_end,
+                                             self.reducer.dest if self.direct_grads else None)
         try:
             self.net.train()
             if self.fused_loss:
@@ -200,7 +216,7 @@ class TrackNetTrainer:
                 self.reducer.reset()      # a bucket half-filled by a failed backward must not trigger early next step
             raise
         finally:
-            autograd_ops.set_grad_ready_hook(None, None)
+            autograd_ops.set_grad_ready_hook(None, None, None)
         self.opt.step()
         return loss.detach()
 
