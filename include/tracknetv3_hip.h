@@ -32,7 +32,7 @@ extern "C" {
 #define TNV3_OK 0
 #define TNV3_E_INVALID (-1)   /* bad argument / unsupported shape */
 #define TNV3_E_LAUNCH (-2)    /* HIP launch error */
-#define TNV3_ABI_VERSION 5   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
+#define TNV3_ABI_VERSION 6   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
                                  3: `variant` argument on the Winograd-form weight gradients;
                                  4: `sum_order` on tnv3_ensemble_frames (the reference's summation order, bit-exact); `variant` on the
                                     9-GEMM decoder kernels; the fused InpaintNet training entries; tnv3_conv3x3_wino_pick / _has_stats /
@@ -41,7 +41,9 @@ extern "C" {
                                     kernels, 1: the 32x32x2 kernel); `pool_dst` on tnv3_conv3x3_wino43_forward; pack-multi layout 4;
                                     tnv3_conv3x3_wgrad_wino variant 8 (F(4x4)), the default where h % 4 == 0; the measured-and-rejected
                                     generations (tnv3_conv3x3_wino_forward 0 / 2 / 4, tnv3_conv3x3_wgrad_wino 0 / 3 / 4 / 6 / 7) left the
-                                    product library: they are refused here and stay dispatchable in libtnv3_diag.so */
+                                    product library: they are refused here and stay dispatchable in libtnv3_diag.so;
+                                 6: `up_variant` on tnv3_conv3x3_wgrad_up2x (the upsampled half's 25-of-36 F(4x4) weight gradient), `variant` 2
+                                    on tnv3_dgrad_up2x_wino (its data gradient on the 16x16x4 kernel) */
 
 typedef void* tnv3_stream_t;
 
@@ -256,14 +258,16 @@ int tnv3_conv3x3_wgrad_wino(const float* x, const float* dz, float* dw, void* wo
  * windows against x_low (16 instead of 36 taps per low-res pixel), the c1 skip channels as an ordinary 3x3 weight gradient.
  *   x_low [n][c0][h_low][w_low], skip [n][c1][2*h_low][2*w_low], dz [n][cout][2*h_low][2*w_low];  w_low % 4 == 0.
  * Deterministic (split-K slabs reduced in a fixed order); workspace from the _workspace_bytes query, 16-byte aligned.
- * `wino_variant` (per call): -1 = the default -- upsampled half in the 9-GEMM Winograd form of tnv3_conv_up2x_wino_forward
- * (9 instead of 16 multiply-adds per low-res pixel; needs c0 % 128 == 0, cout % 64 == 0, w_low % 8 == 0, else the next), skip half
- * by the default kernel of tnv3_conv3x3_wgrad_wino (the F(4x4) kernel 8 where h % 4 == 0);  8 = the same;  2 / 5 = the same with
- * the F(2x2) kernel 1 / 5 for the skip half;  1 = upsampled half by four 2x2-window launches over the parity images of dz, skip half
- * by kernel 1.  All compute the same gradient up to fp32 rounding.  (0, 3, 4, 6, 7 are refused since ABI 5: libtnv3_diag.so.) */
+ * `up_variant` (per call; ABI 6) -- the form of the upsampled half: -1 = the fastest the shape allows; 2 = the 25-of-36 Winograd F(4x4)
+ * form (kernels/wgrad_up2x_wino43_mfma.h: 6.25 multiply-adds per low-res pixel; needs cout % 64 == 0, h_low % 2 == 0, w_low % 8 == 0, any
+ * c0); 1 = the 9-GEMM F(2x2) form of tnv3_conv_up2x_wino_forward (9 per low-res pixel; c0 % 128 == 0, cout % 64 == 0, w_low % 8 == 0);
+ * 0 = four 2x2-window launches over the parity images of dz (16).  A form the shape does not allow falls to the next lower one.
+ * `wino_variant` (per call) -- the kernel of the skip half: -1 / 8 = the default kernel of tnv3_conv3x3_wgrad_wino (the F(4x4) kernel 8
+ * where h % 4 == 0); 2 / 5 = the F(2x2) kernel 1 / 5; 1 = kernel 1, and with up_variant -1 the 2x2-window launches for the upsampled half
+ * (ABI 5's meaning of 1).  All compute the same gradient up to fp32 rounding.  (0, 3, 4, 6, 7 are refused since ABI 5: libtnv3_diag.so.) */
 size_t tnv3_conv3x3_wgrad_up2x_workspace_bytes(int n, int c0, int c1, int cout, int h_low, int w_low);
 int tnv3_conv3x3_wgrad_up2x(const float* x_low, const float* skip, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
-                            int n, int c0, int c1, int cout, int h_low, int w_low, int wino_variant, tnv3_stream_t stream);
+                            int n, int c0, int c1, int cout, int h_low, int w_low, int wino_variant, int up_variant, tnv3_stream_t stream);
 
 /* ---- head + pooling (model.py:54-55,59,61,63,71-72) ----------------------------------------------------- */
 

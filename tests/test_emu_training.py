@@ -81,7 +81,8 @@ def _wgrad_case(case, ops):
 
 WGRAD_UP2X_CASES = [(1, 8, 16, 64, 4, 20), (2, 32, 32, 128, 3, 36), (1, 64, 32, 64, 6, 32),    # (n, c0, c1, cout, h_low, w_low)
                     (1, 64, 128, 128, 2, 16),                                              # skip half on the Winograd-form kernel
-                    (1, 128, 64, 64, 4, 16), (2, 128, 16, 128, 3, 24), (1, 256, 64, 64, 2, 8)]   # c0 % 128 == 0: upsampled half in the 9-GEMM form
+                    (1, 128, 64, 64, 4, 16), (2, 128, 16, 128, 3, 24), (1, 256, 64, 64, 2, 8),   # c0 % 128 == 0: upsampled half in the 9-GEMM form
+                    (2, 40, 16, 64, 4, 24), (1, 33, 64, 128, 6, 8), (3, 8, 16, 64, 2, 40)]        # partial blocks of 32 input channels in the 25-of-36 form
 
 
 def _wgrad_up2x_case(case, device):
@@ -92,21 +93,29 @@ def _wgrad_up2x_case(case, device):
     wd = T((cout, c0 + c1, 3, 3), 34, -0.3, 0.3).double().requires_grad_(True)
     x = torch.cat([xl.repeat_interleave(2, 2).repeat_interleave(2, 3), skip], 1)
     F.conv2d(x.double(), wd, padding=1).backward(dz.double())
-    dw = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=2)      # 9-GEMM form + F(2x2) kernel 1 for the skip half
-    dw2 = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=2)
+    xl, skip, dz = xl.to(device), skip.to(device), dz.to(device)
+    dw = ops.conv3x3_wgrad_up2x(xl, skip, dz, wino_variant=2, up_variant=1)      # 9-GEMM form (where c0 % 128 == 0) + F(2x2) kernel 1 for the skip half
+    dw2 = ops.conv3x3_wgrad_up2x(xl, skip, dz, wino_variant=2, up_variant=1)
     assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
-    dwv = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=1)      # the upsampled half by the four 2x2-window launches
+    dwv = ops.conv3x3_wgrad_up2x(xl, skip, dz, wino_variant=1)                    # ABI 5's meaning of 1: the upsampled half by the four 2x2-window launches
+    assert torch.equal(dwv, ops.conv3x3_wgrad_up2x(xl, skip, dz, wino_variant=2, up_variant=0))
     assert rel_err(dwv.cpu(), dw.cpu().double()) <= 4e-6
     # 9-GEMM form + the other (bit-identical) F(2x2) generation of the skip half's kernel
-    assert torch.equal(dw, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=5))
-    # the default (-1): the skip half by the F(4x4) kernel where it applies (H % 4 == 0, C1 % 64 == 0) -- same upsampled half, deterministic
-    dwd = ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=-1)
-    assert torch.equal(dwd, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device)))
-    assert torch.equal(dwd, ops.conv3x3_wgrad_up2x(xl.to(device), skip.to(device), dz.to(device), wino_variant=8))
+    assert torch.equal(dw, ops.conv3x3_wgrad_up2x(xl, skip, dz, wino_variant=5, up_variant=1))
+    # the skip half by the F(4x4) kernel where it applies (H % 4 == 0, C1 % 64 == 0) -- same upsampled half, deterministic
+    dwd = ops.conv3x3_wgrad_up2x(xl, skip, dz, wino_variant=-1, up_variant=1)
+    assert torch.equal(dwd, ops.conv3x3_wgrad_up2x(xl, skip, dz, wino_variant=8, up_variant=1))
     assert torch.equal(dwd[:, :c0], dw[:, :c0])
     if (2 * hl) % 4 or c1 % 64:
         assert torch.equal(dwd, dw)
     assert rel_err(dwd.cpu(), wd.grad) <= 8e-6
+    # the default: the upsampled half in the 25-of-36 F(4x4) form where the shape allows it (Hl % 2 == 0, Wl % 8 == 0, any c0) -- same skip half
+    dwf = ops.conv3x3_wgrad_up2x(xl, skip, dz)
+    assert torch.equal(dwf, ops.conv3x3_wgrad_up2x(xl, skip, dz, wino_variant=-1, up_variant=2)), "deterministic"
+    assert torch.equal(dwf[:, c0:], dwd[:, c0:])
+    if hl % 2 or wl % 8:
+        assert torch.equal(dwf, dwd)
+    assert rel_err(dwf.cpu(), wd.grad) <= 8e-6 and rel_err(dwf.cpu()[:, :c0], wd.grad[:, :c0]) <= 8e-6, (rel_err(dwf.cpu(), wd.grad), rel_err(dwf.cpu()[:, :c0], wd.grad[:, :c0]))
     return rel_err(dw.cpu(), wd.grad), rel_err(dw.cpu()[:, :c0], wd.grad[:, :c0])
 
 

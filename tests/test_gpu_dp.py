@@ -110,10 +110,11 @@ def test_two_rank_train_step_equals_sequential_shard_oracle(gpu_device, backend,
 
 def test_eight_rank_train_step_equals_sequential_eight_shard_oracle(gpu_device):
     """BASELINE configs[2]'s rank count with the REAL kernels: eight ranks share cuda:0 over gloo (RCCL refuses two ranks on one
-    device; on an 8-GPU node the same calls run over RCCL), global batch 8 at 64x128, one sample per rank.  Must equal the DP
+    device; on an 8-GPU node the same calls run over RCCL), global batch 16 at 64x128, two samples per rank (with ONE, the deepest
+    BatchNorm layers see 128 values per channel and any two fp32 evaluations differ by 7e-2 of max|g| on single tensors).  Must equal the DP
     definition: the oracle runs the eight shards one after the other (local BatchNorm), averages the gradient sets, applies one SGD step.
     Also: every gradient is written by its kernel into the all-reduce bucket (copies == 0), and the replicas end bit-identical."""
-    world, port, batch = 8, _free_port(), 8
+    world, port, batch = 8, _free_port(), 16
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_worker, args=(world, port, out, "gloo", batch), nprocs=world, join=True)
@@ -123,8 +124,8 @@ def test_eight_rank_train_step_equals_sequential_eight_shard_oracle(gpu_device):
     y = nets.disc_heatmaps(batch, 3, 64, 128, 2013)
     g64, g32 = [], []
     for r in range(world):
-        l, _, g, st = nets.tracknet_train_step_grads(sd, x[r:r + 1], y[r:r + 1], torch.float64)
-        _, _, gf, _ = nets.tracknet_train_step_grads(sd, x[r:r + 1], y[r:r + 1], torch.float32)
+        l, _, g, st = nets.tracknet_train_step_grads(sd, x[2 * r:2 * r + 2], y[2 * r:2 * r + 2], torch.float64)
+        _, _, gf, _ = nets.tracknet_train_step_grads(sd, x[2 * r:2 * r + 2], y[2 * r:2 * r + 2], torch.float32)
         g64.append(g); g32.append(gf)
         assert abs(res[r]["loss"] - l.item()) <= 2e-5, (r, res[r]["loss"], l.item())
         for k, v in res[r]["bn"].items():                   # BatchNorm running statistics stay local: rank r holds shard r's

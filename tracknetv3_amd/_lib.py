@@ -15,7 +15,7 @@ _c = ctypes
 _f32p = _c.c_void_p
 _lib = None
 _is_emulator = False
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Tnv3Error(RuntimeError):
@@ -54,7 +54,7 @@ def _declare(lib):
     sig("tnv3_pack_dgrad_up2x_weights", i, p, p, i, i, i, p)
     sig("tnv3_dgrad_up2x", i, p, p, p, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wgrad_up2x_workspace_bytes", sz, i, i, i, i, i, i)
-    sig("tnv3_conv3x3_wgrad_up2x", i, p, p, p, p, p, sz, i, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wgrad_up2x", i, p, p, p, p, p, sz, i, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_packed_floats", sz, i, i)
     sig("tnv3_conv3x3_wino_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wino_layout", i, i)

@@ -141,17 +141,26 @@ inline __global__ void __launch_bounds__(256) conv3x3_wino43s_pack_kernel(const 
   conv3x3_wino43s_pack_elements(w, u, Cout, Cin, s_co, s_ci, flip, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
 
-// ---- upsampled half (MODE 1): U'[i'][j'] = G' g G'^T over the indices (0, 1, e, o, 5) with G' = [1/4 0 0; -1/3 -1/3 -1/3; -1/12 -1/3 -1/3;
-//      -1/6 -1/6 -2/3; 0 0 1] -- rows 0 and infinity of Lavin's G, twice its row of the point 1 (the patch transform carries c - 4 b, half
-//      of B^T's row), and -3 G[2] +- G[-2] for the even / odd output rows (the rows of +-2 of B^T E are -3 (b - c) and (b - c)).
+// ---- upsampled half (MODE 1).  Interpolation points (0, +-1, +-b, inf) with b^2 = kU43B: the upsampled signal's polynomial is
+//      (1 + x) l(x^2), so the point -1 vanishes for ANY b and the rows of +-b stay proportional -- b is free, and it sets the precision:
+//      the row of the point 0 / inf of B^T E is (B a - (1 + B) b_ + c) / (B b_ - (1 + B) c + e), B = b^2 (amplification 2 (1 + B): 10 with
+//      Lavin's b = 2), and the columns of +-b of A^T carry b^2 / b^3 into output rows 2 / 3.  Swept in fp32 emulation on upsampled post-ReLU
+//      inputs (tests/studies/up2x_points_study.py, profiles/r05_up2x_points_study.json): max error vs fp64 relative to the output scale
+//      0.9-1.0e-5 at B = 4 (Lavin), 6-8e-6 for B in 2 .. 3.5 (rms 5.4e-7 -> 5.0e-7; the error sits in output row / column 3), 1.0-1.3e-5
+//      at B = 1.5 (the points +-1 and +-b close in: G's rows grow as 1 / (B - 1)); the plain layers' set (0, +-3/4, +-3/2, inf), which has no
+//      point -1 and keeps all 36 products, reaches 2.4e-6.  kU43B = 2.75 (exact in binary, as is 1 + B).  U'[i'][j'] = G' g G'^T over the indices (0, 1, e, o, 5) with G' = [1/B 0 0; (1 1 1) / (1 - B); -(1 B B) / (B (B - 1));
+//      -(1 1 B) / (B - 1); 0 0 1] -- rows 0 and infinity of Toom-Cook's G, twice its row of the point 1 (the patch transform carries
+//      c - B b_, half of B^T's row), and the two combinations of G[+b], G[-b] that meet the SAME transformed value b_ - c for the even / odd
+//      output rows (A^T's columns of +-b differ in the sign of the odd rows).
 //      Panel u[co / 16][chunk][pair 13][lane = (ci % 8 / 2) * 16 + co % 16][(ci % 2) * 2 + slot]: pairs 0-4 = ((0, j'), (1, j')),
 //      5-9 = ((e, j'), (o, j')), 10-12 = ((5, 0), (5, 1)), ((5, e), (5, o)), ((5, 5), zero); the first c0 input channels of w[Cout][Cin][3][3].
+constexpr float kU43B = 2.75f, kU43B1 = 1.0f + kU43B;
 __device__ __forceinline__ float wino43u_g_row(int i, float g0, float g1, float g2) {
   switch (i) {
-    case 0: return 0.25f * g0;
-    case 1: return (-1.0f / 3.0f) * ((g0 + g1) + g2);
-    case 2: return (-1.0f / 12.0f) * g0 + (-1.0f / 3.0f) * (g1 + g2);
-    case 3: return (-1.0f / 6.0f) * (g0 + g1) + (-2.0f / 3.0f) * g2;
+    case 0: return (1.0f / kU43B) * g0;
+    case 1: return (1.0f / (1.0f - kU43B)) * ((g0 + g1) + g2);
+    case 2: return (-1.0f / (kU43B * (kU43B - 1.0f))) * g0 + (-1.0f / (kU43B - 1.0f)) * (g1 + g2);
+    case 3: return (-1.0f / (kU43B - 1.0f)) * (g0 + g1) + (-kU43B / (kU43B - 1.0f)) * g2;
     default: return g2;
   }
 }
@@ -367,10 +376,11 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     constexpr int P = decltype(pc)::value;
     if constexpr (MODE == 1) {
       // ---- upsampled half.  The 6 x 6 patch of the upsampled tensor is E l E^T of a 4 x 4 low-resolution patch l (rows / columns
-      //      a, b, b, c, c, e).  With Lavin's points (0, +-1, +-2, inf) B^T E has the rows (4 a - 5 b + c), (2 c - 8 b), 0, -3 (b - c), (b - c),
-      //      (4 b - 5 c + e): the point -1 vanishes, +-2 are proportional.  Five products per axis remain -- indices (0, 1, e, o, 5), where e / o
-      //      carry the SAME transformed value b - c against two filters (for the even / the odd output rows: A^T's columns of +-2 differ in
-      //      the sign of the odd rows) -- 25 of the 36.  Row half RH = 0: indices 0, 1 from rows (a, b, c); RH = 1: e / o, 5 from (b, c, e).
+      //      a, b, b, c, c, e).  With the points (0, +-1, +-sqrt(B), inf), B = kU43B, B^T E has the rows (B a - (1 + B) b + c), 2 (c - B b), 0,
+      //      -(1 + sqrt B) (b - c), (sqrt B - 1) (b - c), (B b - (1 + B) c + e): the point -1 vanishes, +-sqrt B are proportional.  Five products per
+      //      axis remain -- indices (0, 1, e, o, 5), where e / o carry the SAME transformed value b - c against two filters (for the even / the
+      //      odd output rows: A^T's columns of +-sqrt B differ in the sign of the odd rows) -- 25 of the 36.  Row half RH = 0: indices 0, 1 from
+      //      rows (a, b, c); RH = 1: e / o, 5 from (b, c, e).
       if constexpr (P == 0) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -391,8 +401,8 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         for (int x = 0; x < 4; ++x) {
           const float r0 = x < 2 ? ulo[0][x & 1] : uhi[0][x & 1], r1 = x < 2 ? ulo[1][x & 1] : uhi[1][x & 1], r2 = x < 2 ? ulo[2][x & 1] : uhi[2][x & 1];
           float c0, c1;
-          if constexpr (RH == 0) { c0 = fmaf(4.0f, r0, fmaf(-5.0f, r1, r2)); c1 = fmaf(-4.0f, r1, r2); }      // (a, b, c) -> 4 a - 5 b + c,  c - 4 b
-          else { c0 = r0 - r1; c1 = fmaf(4.0f, r0, fmaf(-5.0f, r1, r2)); }                                  // (b, c, e) -> b - c,  4 b - 5 c + e
+          if constexpr (RH == 0) { c0 = fmaf(kU43B, r0, fmaf(-kU43B1, r1, r2)); c1 = fmaf(-kU43B, r1, r2); }      // (a, b, c) -> B a - (1 + B) b + c,  c - B b
+          else { c0 = r0 - r1; c1 = fmaf(kU43B, r0, fmaf(-kU43B1, r1, r2)); }                                   // (b, c, e) -> b - c,  B b - (1 + B) c + e
           if (x == 0) { c0 = zl ? 0.0f : c0; c1 = zl ? 0.0f : c1; }
           if (x == 3) { c0 = zr ? 0.0f : c0; c1 = zr ? 0.0f : c1; }
           uc[0][x] = c0; uc[1][x] = c1;
@@ -400,10 +410,10 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
       } else if constexpr (P == 2 || P == 3) {           // along a row: (p0 .. p3) -> the values of indices 0, 1, e = o, 5
         constexpr int k = P - 2;
         const float p0 = uc[k][0], p1 = uc[k][1], p2 = uc[k][2], p3 = uc[k][3];
-        uw[k][0] = fmaf(4.0f, p0, fmaf(-5.0f, p1, p2));
-        uw[k][1] = fmaf(-4.0f, p1, p2);
+        uw[k][0] = fmaf(kU43B, p0, fmaf(-kU43B1, p1, p2));
+        uw[k][1] = fmaf(-kU43B, p1, p2);
         uw[k][2] = p1 - p2;
-        uw[k][3] = fmaf(4.0f, p1, fmaf(-5.0f, p2, p3));
+        uw[k][3] = fmaf(kU43B, p1, fmaf(-kU43B1, p2, p3));
       } else {                                           // V pairs: (0, j') with (1, j') -- (e, j') with (o, j') -- row 5 in three pairs
         auto jv = [](int j) constexpr { return j < 2 ? j : (j < 4 ? 2 : 3); };      // j' = (0, 1, e, o, 5) -> the row pass's value
         if constexpr (RH == 0) {
@@ -593,14 +603,14 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     const unsigned planes_b = 16u * (unsigned)HW * 4u;
     const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
     if constexpr (MODE == 1) {
-      // upsampled half: Y = A'^T M' A' over the indices (0, 1, e, o, 5) with A'^T = [1 1 1 0 0; 0 1 0 2 0; 0 1 4 0 0; 0 1 0 8 1]; M'[i'][j'] =
+      // upsampled half: Y = A'^T M' A' over the indices (0, 1, e, o, 5) with A'^T = [1 1 1 0 0; 0 1 0 1 0; 0 1 B 0 0; 0 1 0 B 1], B = kU43B; M'[i'][j'] =
       // acc[2 j' + i'] (i' = 0, 1), acc[10 + 2 j' + (i' - 2)] (i' = e, o), acc[20 + j'] (i' = 5).  Plain partial sums: the skip half's launch adds them.
       const unsigned lane_off_u = oh < H ? (unsigned)((4 * g) * HW + oh * W + ow) * 4u : kDmaOob;
       auto at5 = [](float q0, float q1, float qe, float qo, float q5, float (&o)[4]) {
         o[0] = (q0 + q1) + qe;
-        o[1] = fmaf(2.0f, qo, q1);
-        o[2] = fmaf(4.0f, qe, q1);
-        o[3] = fmaf(8.0f, qo, q1) + q5;
+        o[1] = q1 + qo;
+        o[2] = fmaf(kU43B, qe, q1);
+        o[3] = fmaf(kU43B, qo, q1) + q5;
       };
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -26,6 +26,7 @@
 #include "kernels/wgrad3x3_mfma.h"
 #include "kernels/wgrad_wino_mfma.h"
 #include "kernels/wgrad_wino43_mfma.h"
+#include "kernels/wgrad_up2x_wino43_mfma.h"
 
 namespace tnv3 {
 
@@ -1235,7 +1236,27 @@ int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float*
 using WgradA4 = WgradCfg<4, 2, 4, 32, 4>;   // 2x2 tap window: 128 co x 64 ci, 8 waves (4 taps reuse a staged tile less than 9 do,
                                             // so the ci block is doubled to keep the flops per staged byte)
 using WgradB4 = WgradCfg<2, 2, 4, 32, 4>;
-struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; int up_wino_sk; };
+struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; int up_wino_sk, up_w43_sk; };
+// the upsampled half in the 25-of-36 F(4x4) form (kernels/wgrad_up2x_wino43_mfma.h): any c0, a K unit = one strip of 4 x 16 output pixels
+inline bool wgrad_up2x_wino43_supported(int c0, int cout, int hl, int wl) {
+  return c0 > 0 && cout > 0 && cout % 64 == 0 && hl > 0 && hl % 2 == 0 && wl > 0 && wl % 8 == 0 &&
+         (long)(c0 > 4 * cout ? c0 : 4 * cout) * hl * wl * 4 < (1l << 31);
+}
+inline int wgrad_up2x_wino43_splitk(int n, int c0, int cout, int hl, int wl) {
+  const int nb = (cout / WgradUp2xWino43Cfg::MB) * ((c0 + WgradUp2xWino43Cfg::CB - 1) / WgradUp2xWino43Cfg::CB);
+  const long strips = (long)n * (hl / 2) * (wl / 8);
+  const int cus = num_cus();
+  int best_sk = 1;
+  double best = 1e300;
+  const long cap = strips < 4096 ? strips : 4096;
+  for (int sk = 1; sk <= cap; ++sk) {
+    const long blocks = (long)nb * sk;
+    if (sk > 1 && blocks > 16l * cus) break;
+    const double cost = (double)((blocks + cus - 1) / cus) * ((double)((strips + sk - 1) / sk) + 8.0);      // as wgrad_wino43_splitk
+    if (cost < best - 1e-9) { best = cost; best_sk = sk; }
+  }
+  return best_sk;
+}
 // the upsampled half in the 9-GEMM Winograd form (kernels/wgrad_wino_mfma.h: wgrad_up2x_wino_mfma_kernel)
 inline bool wgrad_up2x_wino_supported(int c0, int cout, int hl, int wl) {
   return c0 > 0 && c0 % WgradUp2xWinoCfg::CB == 0 && cout > 0 && cout % 64 == 0 && hl > 0 && wl > 0 && wl % 8 == 0 &&
@@ -1272,6 +1293,9 @@ inline WgradUpLayout wgrad_up2x_layout(int n, int c0, int c1, int cout, int hl, 
   l.up_wino_sk = wgrad_up2x_wino_supported(c0, cout, hl, wl) ? wgrad_up2x_wino_splitk(n, c0, cout, hl, wl) : 0;
   const size_t s_up9 = (size_t)l.up_wino_sk * 9 * cout * c0;
   if (s_up9 > s_up) s_up = s_up9;
+  l.up_w43_sk = wgrad_up2x_wino43_supported(c0, cout, hl, wl) ? wgrad_up2x_wino43_splitk(n, c0, cout, hl, wl) : 0;
+  const size_t s_up25 = (size_t)l.up_w43_sk * 9 * cout * c0;
+  if (s_up25 > s_up) s_up = s_up25;
   l.slabs = off;   off += align16f(s_up > s_skip ? s_up : s_skip);
   l.total = off * sizeof(float);
   return l;
@@ -1295,21 +1319,31 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
   float *zp = base + l.zp, *d4 = base + l.d4, *dwskip = base + l.dwskip, *slabs = base + l.slabs;
   const int h = 2 * hl, w = 2 * wl;
   int rc;
+  // up_variant: -1 = the fastest form the shape allows (2, else 1, else 0); 2 = the 25-of-36 F(4x4) form; 1 = the 9-GEMM F(2x2) form;
+  // 0 = four 2x2-window launches over the parity images of dz.  An explicit form the shape does not allow falls to the next lower one.
+  const bool up25 = (up_variant < 0 || up_variant >= 2) && l.up_w43_sk > 0;
+  if (up25) up_variant = 2;
   const long s2d_items = (long)n * cout * h * (w / 4);
-  if (!(up_variant != 0 && l.up_wino_sk > 0))
+  if (!up25 && !(up_variant != 0 && l.up_wino_sk > 0))
     if ((rc = L.launch(space_to_depth2_kernel, grid_for(s2d_items, 256, 32768), 256, dz, zp, (long)n * cout, h, w))) return rc;
   auto reduce = [&](float* out, long nel, int parts) -> int {
     if ((nel & 3) == 0) return L.launch(sum_partials_vec4_kernel, grid_for(nel / 4, 256, 8192), 256, (const float*)slabs, out, nel / 4, parts);
     return L.launch(sum_partials_kernel, grid_for(nel, 256, 4096), 256, (const float*)slabs, out, nel, parts);
   };
-  const bool up9 = up_variant != 0 && l.up_wino_sk > 0;    // upsampled half: 9-GEMM Winograd form (default) or the four 2x2-window launches
+  const bool up9 = !up25 && up_variant != 0 && l.up_wino_sk > 0;    // upsampled half: 9-GEMM Winograd form or the four 2x2-window launches
+  if (up25) {
+    WgradUp2xWinoArgs ua{x_low, dz, slabs, n, c0, cout, hl, wl, l.up_w43_sk};
+    const int grid = (cout / WgradUp2xWino43Cfg::MB) * ((c0 + WgradUp2xWino43Cfg::CB - 1) / WgradUp2xWino43Cfg::CB) * l.up_w43_sk;
+    if ((rc = L.launch(wgrad_up2x_wino43_kernel, grid, WgradUp2xWino43Cfg::NT, ua))) return rc;
+    if ((rc = L.launch(wgrad_wino43_fold_kernel, grid_for((long)9 * cout * c0, 64, 8192), 256, (const float*)slabs, d4, cout, c0, l.up_w43_sk))) return rc;
+  }
   if (up9) {
     WgradUp2xWinoArgs ua{x_low, dz, slabs, n, c0, cout, hl, wl, l.up_wino_sk};
     if ((rc = L.launch(wgrad_up2x_wino_mfma_kernel, (cout / 64) * (c0 / WgradUp2xWinoCfg::CB) * l.up_wino_sk, WgradUp2xWinoCfg::NT, ua))) return rc;
     if ((rc = L.launch(wgrad_up2x_wino_fold_kernel, grid_for((long)cout * c0, 256, 4096), 256, (const float*)slabs, d4, cout, c0, l.up_wino_sk))) return rc;
   }
   const size_t img = (size_t)n * cout * hl * wl;
-  for (int im = 0; !up9 && im < 4; ++im) {                              // parity image (pr, pc) = (im >> 1, im & 1): 2x2 window at (pr, pc)
+  for (int im = 0; !up9 && !up25 && im < 4; ++im) {                              // parity image (pr, pc) = (im >> 1, im & 1): 2x2 window at (pr, pc)
     WgradArgs a{x_low, (const float*)nullptr, zp + im * img, slabs, n, c0, 0, cout, hl, wl, 0, l.up.splitK, (const float*)ws, im >> 1, im & 1};
     const int grid = l.up.nMB * l.up.nCB * l.up.splitK;
     rc = l.up.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB4>, grid, WgradB4::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA4>, grid, WgradA4::NT, a);
@@ -1336,7 +1370,7 @@ int conv3x3_wgrad_up2x_impl(Launcher& L, const float* x_low, const float* skip, 
     if (rc) return rc;
     if ((rc = reduce(dwskip, (long)cout * c1 * 9, l.skip.splitK))) return rc;
   }
-  if (up9) return L.launch(wgrad_up2x_join_kernel, grid_for((long)cout * (c0 + c1) * 9, 256, 8192), 256, (const float*)d4, (const float*)dwskip, dw, cout, c0, c1);
+  if (up9 || up25) return L.launch(wgrad_up2x_join_kernel, grid_for((long)cout * (c0 + c1) * 9, 256, 8192), 256, (const float*)d4, (const float*)dwskip, dw, cout, c0, c1);
   return L.launch(wgrad_up2x_assemble_kernel, grid_for((long)cout * (c0 + c1) * 9, 256, 8192), 256, (const float*)d4, (const float*)dwskip, dw, cout, c0, c1);
 }
 

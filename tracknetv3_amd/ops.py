@@ -784,16 +784,19 @@ def conv3x3_wgrad_wino(x, dz, variant=None, out=None):
 _WGRAD_UP2X_OF_PLAIN = {-1: -1, 1: 2, 2: 2, 5: 5, 8: 8}      # tuning.WGRAD_WINO_VARIANT -> tnv3_conv3x3_wgrad_up2x's own numbering
 
 
-def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None, out=None):
+def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None, out=None, up_variant=None):
     """dW[Cout][C0+C1][3][3] of a decoder-entry layer (X = cat([upsample2x(x_low), skip], 1)), its upsampled channels at the
     low resolution -- see tnv3_conv3x3_wgrad_up2x.  wino_variant: an explicit number is the C entry's own (-1 / 8: the library's default
     for the skip half -- F(4x4) where it applies -- with the Winograd form of the upsampled half; 2 / 5: F(2x2) kernel 1 / 5 for the skip half;
     1: kernel 1 and the upsampled half by the four 2x2-window launches); None follows tuning.WGRAD_WINO_VARIANT, the PLAIN layers' kernel
     choice (dispatchable: -1, 1, 2, 5, 8), keeping the Winograd form of the upsampled half: the plain kernels 1 and 2 both map to 2 here (the
-    skip half has no kernel-2 form), 5 and 8 to themselves."""
+    skip half has no kernel-2 form), 5 and 8 to themselves.  up_variant: the form of the upsampled half (None: tuning.WGRAD_UP2X_VARIANT;
+    -1 the fastest the shape allows, 2 the 25-of-36 F(4x4) form, 1 the 9-GEMM F(2x2) form, 0 four 2x2-window launches)."""
+    from . import tuning
     if wino_variant is None:
-        from . import tuning
         wino_variant = _WGRAD_UP2X_OF_PLAIN[int(tuning.WGRAD_WINO_VARIANT)]
+    if up_variant is None:
+        up_variant = tuning.WGRAD_UP2X_VARIANT
     lib = _lib.load()
     _f32(x_low, skip, dz)
     _lib.dev_check(x_low, skip, dz)
@@ -804,7 +807,7 @@ def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None, out=None):
     dw = _grad_out((cout, c0 + c1, 3, 3), dz.device, out, "conv3x3_wgrad_up2x")
     ws = _workspace(lib.tnv3_conv3x3_wgrad_up2x_workspace_bytes(n, c0, c1, cout, h // 2, w // 2), dz.device)
     _lib.check(lib.tnv3_conv3x3_wgrad_up2x(_lib.ptr(x_low), _lib.ptr(skip), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(ws), ws.numel() * 8,
-                                           n, c0, c1, cout, h // 2, w // 2, int(wino_variant), _lib.stream_ptr(dz)))
+                                           n, c0, c1, cout, h // 2, w // 2, int(wino_variant), int(up_variant), _lib.stream_ptr(dz)))
     return dw
 
 

@@ -144,6 +144,12 @@ WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA 
 WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))
 
 
+# Weight gradient of the decoder entries' upsampled halves: -1 = the fastest form the shape allows -- 2, the 25-of-36 F(4x4) form
+# (kernels/wgrad_up2x_wino43_mfma.h, round 5: 6.25 multiply-adds per low-resolution pixel, any c0), else 1, the 9-GEMM F(2x2) form
+# (9; c0 % 128 == 0), else 0, four 2x2-window launches (16).  The weight gradient is a leaf: nothing amplifies its rounding.
+WGRAD_UP2X_VARIANT = int(os.environ.get("TNV3_WGRAD_UP2X_VARIANT", "-1"))
+
+
 # Training: all Winograd filter panels that the optimiser step made stale are rebuilt by one launch at the start of the forward
 # (model.TrackNet.repack_wino_panels) instead of one 14-us launch in front of every convolution / data gradient.
 WINO_REPACK_MULTI = os.environ.get("TNV3_WINO_REPACK_MULTI", "1") != "0"
