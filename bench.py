@@ -256,7 +256,12 @@ def train_flops_executed_per_sample():
             from tracknetv3_amd import ops as _ops
             uvt = _ops.up2x_wino_variant(t.UP2X_WINO_VARIANT_TRAIN)
             f_fwd = 6.25 / 36 if (uvt == 2 and _ops.up2x_wino_supported(c0, co, h // 2, w // 2, 2)) else 9 / 36
-            upf = conv_flops(c0, 0, co, h, w) * (f_fwd + 2 * 9 / 36)                           # forward; data gradient, weight gradient (9-GEMM forms)
+            hl, wl = h // 2, w // 2
+            dv = _ops.dgrad_up2x_wino_variant()
+            f_dg = 6.25 / 36 if (dv == 2 and _ops.dgrad_up2x_wino_supported(c0, co, hl, wl, 2)) else 9 / 36
+            wv = int(t.WGRAD_UP2X_VARIANT)
+            f_wg = 6.25 / 36 if ((wv < 0 or wv == 2) and co % 64 == 0 and hl % 2 == 0 and wl % 8 == 0) else (9 / 36 if (wv != 0 and c0 % 128 == 0) else 16 / 36)
+            upf = conv_flops(c0, 0, co, h, w) * (f_fwd + f_dg + f_wg)      # forward; data gradient; weight gradient (25-of-36 F(4x4) or 9-GEMM F(2x2) forms)
             sk = conv_flops(c1, 0, co, h, w)
             skip = sk * (frac(c1, t.use_wino43_train(c1, co, h, w)) + frac(c1, t.use_wino43_dgrad(co, c1, h, w)) + wfrac(c1))
             total += upf + skip
@@ -375,8 +380,9 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
                      "note": "`achieved` / `frac`: multiply-adds the matrix pipe EXECUTES per second (whole step time, so the HBM-bound "
                              "passes count against it) over the fp32 MFMA peak; `effective_tflops` prices the same time at the "
                              "reference's algorithmic FLOP count (SURVEY 8d: 678.2 GFLOP/sample) -- the upsampled channels of the "
-                             "three decoder-entry layers run at the low resolution in all three passes, in Winograd forms that keep 9 of the 16 "
-                             "F(2x2) GEMMs (9/36 of those MACs), the plain layers and the skip halves in fused Winograd F(4x4,3x3) form (9/36) in "
+                             "three decoder-entry layers run at the low resolution in all three passes -- the forward in the Winograd form that keeps 9 "
+                             "of the 16 F(2x2) GEMMs (9/36 of those MACs), the data and weight gradients with 25 of the 36 F(4x4) products (6.25/36) "
+                             "--, the plain layers and the skip halves in fused Winograd F(4x4,3x3) form (9/36) in "
                              "all three passes (forward with the statistics epilogue, data gradient, weight gradient) --, counted per layer "
                              "from the dispatch rules (train_flops_executed_per_sample: a knob that moves a pass to F(2x2) or the direct form "
                              "moves its count to 16/36 or 1)"},

@@ -225,10 +225,14 @@ int tnv3_dgrad_up2x(const float* dz, const float* g, float* dx_low, int n, int c
  * c^T M c with c = A 1 = (1, 2, 0, -1), so transform row / column 2 drops out and the nine remaining products share one accumulator:
  * dx_low[ci][p] = sum_{co, xi} U''_xi[co][ci] * (B^T d B)_xi[co][p] -- 9 instead of 16 multiply-adds per (ci, co, low-res pixel).
  *   supported: c0 % 128 == 0, cout > 8, h_low % 2 == 0, w_low % 32 == 0;  u from tnv3_dgrad_up2x_wino_pack (the layer's nn.Conv2d
- *   weight, its first c0 input channels), 16-byte aligned.  Same gradient up to fp32 rounding. */
-int tnv3_dgrad_up2x_wino_supported(int c0, int cout, int h_low, int w_low);
-size_t tnv3_dgrad_up2x_wino_packed_floats(int c0, int cout);
-int tnv3_dgrad_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, tnv3_stream_t stream);
+ *   weight, its first c0 input channels), 16-byte aligned.  Same gradient up to fp32 rounding.
+ *   variant (ABI 6: also on _supported / _packed_floats / _pack): -1 / 0 / 1 = that kernel (1: the younger waves' MFMA phase first);
+ *   2 = Winograd F(4x4, 3x3) on the 16x16x4 kernel (kernels/conv3x3_wino43s_mfma.h, MODE 2): the 2x2 block sum P A^T of the 4x4 tile has
+ *   a zero column at the interpolation point -1, so 25 of the 36 products remain -- 6.25 multiply-adds per (ci, co, low-res pixel).  Its
+ *   own panel (pack with variant 2); supported: c0 % 64 == 0, h_low % 2 == 0, w_low % 32 == 0, any cout. */
+int tnv3_dgrad_up2x_wino_supported(int c0, int cout, int h_low, int w_low, int variant);
+size_t tnv3_dgrad_up2x_wino_packed_floats(int c0, int cout, int variant);
+int tnv3_dgrad_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, int variant, tnv3_stream_t stream);
 int tnv3_dgrad_up2x_wino(const float* dz, const float* u, float* dx_low, int n, int c0, int cout, int h_low, int w_low, int variant,
                          tnv3_stream_t stream);
 

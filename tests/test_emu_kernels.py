@@ -201,17 +201,19 @@ def test_conv_up2x_wino_unsupported_shapes_are_refused(emu):
 DGRAD_UP2X_WINO_CASES = [(1, 128, 16, 2, 32), (2, 128, 24, 4, 32), (1, 256, 70, 2, 64), (3, 128, 16, 6, 32)]
 
 
-def _dgrad_up2x_wino_case(n, c0, cout, hl, wl, device):
-    """The one-GEMM data gradient (K = 9 * Cout) against fp64 autograd of conv2d(upsample2x(x_low), W[:, :c0]) and against the
-    4x4 stride-2 kernel (dgrad_up2x)."""
+def _dgrad_up2x_wino_case(n, c0, cout, hl, wl, device, variant=0):
+    """The low-resolution data gradient (variant 0: one GEMM with K = 9 * Cout; 2: the 25-of-36 F(4x4) form) against fp64 autograd of
+    conv2d(upsample2x(x_low), W[:, :c0]) and against the 4x4 stride-2 kernel (dgrad_up2x)."""
     from tracknetv3_amd import ops
-    assert ops.dgrad_up2x_wino_supported(c0, cout, hl, wl)
+    assert ops.dgrad_up2x_wino_supported(c0, cout, hl, wl, variant)
     xl = T((n, c0, hl, wl), 81).double().requires_grad_(True)
     w = T((cout, c0 + 8, 3, 3), 82, -0.3, 0.3)
     dz = T((n, cout, 2 * hl, 2 * wl), 83)
     up = xl.repeat_interleave(2, 2).repeat_interleave(2, 3)
     F.conv2d(up, w[:, :c0].double(), padding=1).backward(dz.double())
-    got = ops.dgrad_up2x_wino(dz.to(device), ops.pack_dgrad_up2x_wino_weights(w.to(device), c0), c0)
+    u = ops.pack_dgrad_up2x_wino_weights(w.to(device), c0, variant=variant)
+    got = ops.dgrad_up2x_wino(dz.to(device), u, c0, variant=variant)
+    assert torch.equal(got, ops.dgrad_up2x_wino(dz.to(device), u, c0, variant=variant))          # deterministic
     old = ops.dgrad_up2x(dz.to(device), ops.pack_dgrad_up2x_weights(w.to(device), c0), c0)
     s = xl.grad.abs().max()
     return ((got.cpu().double() - xl.grad).abs().max() / s).item(), ((got - old).abs().max().cpu().double() / s).item()
@@ -223,6 +225,31 @@ def test_dgrad_up2x_wino_emulated_vs_autograd(emu, monkeypatch, case, cus):
     monkeypatch.setenv("TNV3_EMU_CUS", str(cus))        # 8 CUs: the persistent workgroups walk several tiles each
     e_ref, e_old = _dgrad_up2x_wino_case(*case, "cpu")
     assert e_ref <= 3e-6 and e_old <= 4e-6, (e_ref, e_old)
+
+
+# the F(4x4) form (25 of the 36 products, MODE 2 of the 16x16x4 kernel): + the 64-channel geometry (c0 % 128 != 0), a low-resolution height that is
+# not a multiple of 4 (a half-empty last tile row of that geometry), cout not a multiple of 8 / 16 (partial chunks of the 16-channel steps)
+DGRAD_UP2X_WINO43_CASES = DGRAD_UP2X_WINO_CASES + [(2, 64, 24, 6, 32), (1, 192, 9, 2, 64), (1, 64, 33, 10, 32), (2, 256, 40, 4, 96)]
+
+
+@pytest.mark.parametrize("cus", [256, 2])
+@pytest.mark.parametrize("case", DGRAD_UP2X_WINO43_CASES)
+def test_dgrad_up2x_wino43_emulated_vs_autograd(emu, monkeypatch, case, cus):
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+    e_ref, e_old = _dgrad_up2x_wino_case(*case, "cpu", variant=2)
+    assert e_ref <= 1e-5 and e_old <= 1e-5, (e_ref, e_old)
+
+
+def test_dgrad_up2x_wino_panels_of_the_other_variant_are_refused(emu):
+    from tracknetv3_amd import _lib, ops
+    w = T((16, 136, 3, 3), 82, -0.3, 0.3)
+    dz = T((1, 16, 4, 64), 83)
+    assert ops.dgrad_up2x_wino_supported(64, 16, 2, 32, 2) and not ops.dgrad_up2x_wino_supported(64, 16, 2, 32, 0)
+    assert not ops.dgrad_up2x_wino_supported(32, 16, 2, 32, 2) and not ops.dgrad_up2x_wino_supported(64, 16, 3, 32, 2)
+    with pytest.raises(_lib.Tnv3Error):
+        ops.dgrad_up2x_wino(dz, ops.pack_dgrad_up2x_wino_weights(w, 128, variant=0), 128, variant=2)
+    with pytest.raises(_lib.Tnv3Error):
+        ops.dgrad_up2x_wino(dz, ops.pack_dgrad_up2x_wino_weights(w, 128, variant=2), 128, variant=0)
 
 
 @pytest.mark.parametrize("cfg", [2, 3])
@@ -420,9 +447,8 @@ def test_conv3x3_wino_persistent_kernel_is_bit_identical_to_the_balanced_kernel(
     want = ops.conv3x3_wino(x, u, cout, variant=3)
     assert ops.wino_layout(3, cin, cout) == 0 and ops.wino_layout(5, cin, cout) == 0
     assert torch.equal(want, ops.conv3x3_wino(x, u, cout, variant=5))                                         # persistent workgroups
-    for v in (0, 2, 4):
-        with pytest.raises(_lib.Tnv3Error, match="libtnv3_diag"):
-            ops.conv3x3_wino(x, u, cout, variant=v)
+    # (the emulator is built with -DTNV3_DIAG: it dispatches the twins, 3 among them; that the PRODUCT build refuses 0 / 2 / 3 / 4 / 7 is
+    #  tests/test_kernel_resources.py::test_product_library_carries_no_measurement_twins and tests/test_gpu_tracknet.py's refusal test)
 
 
 # more tiles than the 8 workgroups the emulated "8-CU device" launches: every persistent workgroup walks 2-4 tiles (XCD-aware
@@ -692,7 +718,7 @@ def test_wino43_pack_equals_its_definition(emu, shape, c_from, flip, variant):
     assert np.abs(u[:ref.size] - ref).max() <= 2e-7 * max(1.0, np.abs(ref).max())      # fp32 rounding of G g G^T
 
 
-@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "wino43_v1", "wino43_v2", "up2x_wino", "up2x_wino43", "dgrad_up2x_wino"])
+@pytest.mark.parametrize("what", ["wino_stream", "wino_a128", "wino43", "wino43_v1", "wino43_v2", "up2x_wino", "up2x_wino43", "dgrad_up2x_wino", "dgrad_up2x_wino43"])
 def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
     """The emulator's LDS-DMA normally lands at issue -- as early as possible.  TNV3_EMU_LAZY_DMA=1 is the other extreme: a piece lands
     only when its work-item's counted s_waitcnt (or the kernel's end) forces it, and __syncthreads() forces nothing (hipcc emits no
@@ -721,6 +747,10 @@ def test_lds_dma_landing_as_late_as_the_waits_allow(emu, monkeypatch, what):
         for case in ((2, 20, 128, 4, 64), (3, 40, 64, 6, 64)):
             e_ref, e_old = _up2x_wino_case(*case, "cpu", variant=2)
             assert e_ref <= 1.5e-5 and e_old <= 1.5e-5
+    elif what == "dgrad_up2x_wino43":
+        for case in ((2, 128, 24, 4, 32), (3, 64, 20, 6, 64)):
+            e_ref, e_old = _dgrad_up2x_wino_case(*case, "cpu", variant=2)
+            assert e_ref <= 1e-5 and e_old <= 1e-5
     else:
         e_ref, e_old = _dgrad_up2x_wino_case(*DGRAD_UP2X_WINO_CASES[1], "cpu")
         assert e_ref <= 3e-6 and e_old <= 4e-6

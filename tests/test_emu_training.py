@@ -115,7 +115,8 @@ def _wgrad_up2x_case(case, device):
     assert torch.equal(dwf[:, c0:], dwd[:, c0:])
     if hl % 2 or wl % 8:
         assert torch.equal(dwf, dwd)
-    assert rel_err(dwf.cpu(), wd.grad) <= 8e-6 and rel_err(dwf.cpu()[:, :c0], wd.grad[:, :c0]) <= 8e-6, (rel_err(dwf.cpu(), wd.grad), rel_err(dwf.cpu()[:, :c0], wd.grad[:, :c0]))
+    # (the 25-of-36 form: 4-8e-6 of max|dW| from fp64 where the 9-GEMM F(2x2) form has 5e-7 -- a leaf gradient, nothing amplifies it)
+    assert rel_err(dwf.cpu(), wd.grad) <= 1.5e-5 and rel_err(dwf.cpu()[:, :c0], wd.grad[:, :c0]) <= 1.5e-5, (rel_err(dwf.cpu(), wd.grad), rel_err(dwf.cpu()[:, :c0], wd.grad[:, :c0]))
     return rel_err(dw.cpu(), wd.grad), rel_err(dw.cpu()[:, :c0], wd.grad[:, :c0])
 
 
@@ -142,9 +143,11 @@ def _wgrad_wino_case(case, device):
     assert torch.equal(dwd, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device)))
     assert torch.equal(dwd, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=8) if h % 4 == 0 else dw)
     # every F(2x2) kernel generation accumulates every element in the same order: bit-identical gradients
-    for v in ((1, 2, 5) if cin % 64 == 0 else (5,)):        # a partial block of input channels (the stem): kernel 5 only
+    from tracknetv3_amd import _lib
+    twins = _lib.is_emulator()                              # the emulator is built with -DTNV3_DIAG and dispatches the measurement twins too
+    for v in (((1, 2, 5) if twins else (1, 5)) if cin % 64 == 0 else (5,)):        # a partial block of input channels (the stem): kernel 5 only
         assert torch.equal(dw, ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=v)), v
-    for v in (0, 3, 4, 6, 7):                               # measurement twins of libtnv3_diag.so since ABI 5
+    for v in (() if twins else (0, 2, 3, 4, 6, 7)):         # measurement twins of libtnv3_diag.so since ABI 5 / 6: the product library refuses them
         with pytest.raises(Exception, match="libtnv3_diag"):
             ops.conv3x3_wgrad_wino(x.to(device), dz.to(device), variant=v)
     if cin % 64:
@@ -658,7 +661,8 @@ def test_gradient_kernels_write_into_caller_named_destinations_emulated(emu):
 @pytest.mark.parametrize("plain_variant", [1, 2, 5, 8, -1])
 def test_wgrad_up2x_follows_every_dispatchable_plain_variant_emulated(emu, monkeypatch, plain_variant):
     """tuning.WGRAD_WINO_VARIANT names the PLAIN layers' kernel; the decoder-entry weight gradient must run for each
-    dispatchable value (it crashed training for 2: the C entry has no skip-half kernel 2)."""
+    dispatchable value (it crashed training for 2: the C entry has no skip-half kernel 2; since ABI 6 kernel 2 is a twin of libtnv3_diag.so --
+    which the emulator dispatches -- and the environment knob refuses it when tuning.py is imported)."""
     from tracknetv3_amd import ops, tuning
     monkeypatch.setattr(tuning, "WGRAD_WINO_VARIANT", plain_variant)
     xl, skip, dz = T((1, 128, 4, 16), 31), T((1, 64, 8, 32), 32), T((1, 64, 8, 32), 33)

@@ -55,17 +55,19 @@ def _fullsize_train_step(gpu_device, n, tag):
     m = m.to(gpu_device).train()
     x = nets.synth_input((n, in_dim, h, w), seed + 1000)
     y = nets.disc_heatmaps(n, out_dim, h, w, seed + 2000)
+    # the fp64 and the fp32 host oracle side by side in two worker processes (tests/oracle_pool.py) while the GPU runs the step
+    import threading
+    import oracle_pool
+    box = {}
+    spec = dict(kind="train", in_dim=in_dim, out_dim=out_dim, seed=seed, gain=None, var_range=None, n=n, h=h, w=w)
+    th = threading.Thread(target=lambda: box.update(o=oracle_pool.run([dict(spec, dtype="float64"), dict(spec, dtype="float32")], workers=2)))
+    th.start()
     p = m(x.to(gpu_device))
     loss = WBCELoss(p, y.to(gpu_device))
     loss.backward()
     torch.cuda.synchronize(gpu_device)
-    old = torch.get_num_threads()
-    torch.set_num_threads(_host_threads())
-    try:
-        l64, p64, g64, st64 = nets.tracknet_train_step_grads(sd, x, y, torch.float64)
-        l32, p32, g32, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float32)
-    finally:
-        torch.set_num_threads(old)
+    th.join()
+    (l64, p64, g64, st64), (l32, p32, g32, _) = box["o"]
     e_loss, e_heat = abs(loss.item() - l64.item()), (p.detach().cpu().double() - p64).abs().max().item()
     assert e_loss <= 2e-5, e_loss
     assert e_heat <= HEAT_BOUND["f22" if tag.endswith("f22fwd") else "f43"], e_heat

@@ -20,6 +20,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import oracle_pool
 from oracle import nets
 
 pytestmark = pytest.mark.gpu
@@ -68,16 +69,21 @@ def _gpu_logits(m, x):
         ops.head1x1_sigmoid = real
 
 
-def _eval_row(dev, in_dim, out_dim, seed, gain, var_range, n=2):
+def _eval_spec(in_dim, out_dim, seed, gain, var_range, dtype, n=2):
+    return dict(kind="eval", in_dim=in_dim, out_dim=out_dim, seed=seed, gain=gain, var_range=tuple(var_range), n=n, h=H, w=W, dtype=dtype)
+
+
+def _eval_gpu(dev, in_dim, out_dim, seed, gain, var_range, n=2):
+    """(heat maps, logits) of the eval forward on the GPU, as fp64 host tensors."""
     sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=True, gain=gain, var_range=var_range)
     x = nets.synth_input((n, in_dim, H, W), seed + 1000)
     m = _model(in_dim, out_dim, sd, dev).eval()
     with torch.no_grad():
-        p = m(x.to(dev)).cpu().double()
-        z = _gpu_logits(m, x.to(dev)).cpu().double()
-        sd64 = {k: (v.double() if v.dtype != torch.int64 else v) for k, v in sd.items()}
-        z64 = nets.tracknet_forward(sd64, x.double(), training=False, return_logits=True)
-        z32 = nets.tracknet_forward(sd, x, training=False, return_logits=True).double()
+        return m(x.to(dev)).cpu().double(), _gpu_logits(m, x.to(dev)).cpu().double()
+
+
+def _eval_row(seed, gain, var_range, p, z, z64, z32):
+    z64, z32 = z64.double(), z32.double()
     p64, p32 = torch.sigmoid(z64), torch.sigmoid(z32)
     zmax = z64.abs().max().item()
     return {"seed": seed, "gain": gain, "var_range": list(var_range), "max_abs_logit": zmax,
@@ -95,15 +101,16 @@ def test_precision_sweep_eval_forward_288x512(gpu_device):
     """Twelve networks (every seed at the two balanced (gain, variance) pairs and at gain 4; every (gain, variance) pair at seed 31 -- the
     full 18-row table of the round's evidence session is profiles/r05_precision_sweep_eval.json): the eval forward (F(4x4) everywhere,
     25-of-36 upsampled halves) stays inside the bounds above for every one."""
-    old = torch.get_num_threads()
-    torch.set_num_threads(_host_threads())
-    rows = []
-    try:
-        full = os.environ.get("TNV3_SWEEP_FULL") == "1"
-        for seed, gain, vr in ([(s_, g_, v_) for s_ in SEEDS for g_ in GAINS for v_ in VAR_RANGES] if full else EVAL_ROWS):
-            rows.append(_eval_row(gpu_device, 27, 8, seed, gain, vr))
-    finally:
-        torch.set_num_threads(old)
+    full = os.environ.get("TNV3_SWEEP_FULL") == "1"
+    cfgs = [(s_, g_, v_) for s_ in SEEDS for g_ in GAINS for v_ in VAR_RANGES] if full else EVAL_ROWS
+    # the fp64 and fp32 host oracles of all rows side by side in worker processes (tests/oracle_pool.py), the GPU forwards meanwhile here
+    import threading
+    box = {}
+    th = threading.Thread(target=lambda: box.update(z=oracle_pool.run([_eval_spec(27, 8, s_, g_, v_, dt) for s_, g_, v_ in cfgs for dt in ("float64", "float32")])))
+    th.start()
+    gpu = [_eval_gpu(gpu_device, 27, 8, s_, g_, v_) for s_, g_, v_ in cfgs]
+    th.join()
+    rows = [_eval_row(s_, g_, v_, gpu[k][0], gpu[k][1], box["z"][2 * k], box["z"][2 * k + 1]) for k, (s_, g_, v_) in enumerate(cfgs)]
     sane = [r for r in rows if r["max_abs_logit"] < EVAL_SANE_LOGIT]
     worst = {k: max(r[k] for r in rows) for k in ("logit_rel_err", "logit_rel_err_torch_fp32")}
     worst.update({"heat_err_unsaturated": max(r["heat_err"] for r in sane), "heat_err_torch_fp32_unsaturated": max(r["heat_err_torch_fp32"] for r in sane)})
@@ -117,7 +124,12 @@ def test_precision_sweep_eval_forward_288x512(gpu_device):
         assert r["logit_rel_err"] <= EVAL_LOGIT_REL and r["logit_rel_err"] <= EVAL_LOGIT_VS_FP32 * r["logit_rel_err_torch_fp32"] + 1e-6, r
 
 
-def _train_row(dev, in_dim, out_dim, seed, gain, n=2, want32=False):
+def _train_spec(in_dim, out_dim, seed, gain, dtype, n=2):
+    return dict(kind="train", in_dim=in_dim, out_dim=out_dim, seed=seed, gain=gain, var_range=None, n=n, h=H, w=W, dtype=dtype)
+
+
+def _train_gpu(dev, in_dim, out_dim, seed, gain, n=2):
+    """One training step on the GPU: (loss, heat maps, {name: gradient}) as host tensors."""
     from tracknetv3_amd.utils.metric import WBCELoss
     sd = nets.synth_state(nets.tracknet_state_shapes(in_dim, out_dim), seed, calibrated=True, gain=gain)
     x = nets.synth_input((n, in_dim, H, W), seed + 1000)
@@ -127,19 +139,22 @@ def _train_row(dev, in_dim, out_dim, seed, gain, n=2, want32=False):
     loss = WBCELoss(p, y.to(dev))
     loss.backward()
     torch.cuda.synchronize(dev)
-    l64, p64, g64, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float64)
+    return loss.item(), p.detach().cpu().double(), {k: v.grad.cpu() for k, v in m.named_parameters()}
+
+
+def _train_row(seed, gain, got, o64, o32=None):
+    loss, p, grads = got
+    l64, p64, g64, _ = o64
     names = list(g64.keys())
-    params = dict(m.named_parameters())
 
     def rel(a, b):
         return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-30)
-    mine = np.array([rel(params[k].grad.cpu(), g64[k]) for k in names])
-    row = {"seed": seed, "gain": gain, "loss_abs_err": abs(loss.item() - l64.item()),
-           "heat_err": (p.detach().cpu().double() - p64).abs().max().item(),
+    mine = np.array([rel(grads[k], g64[k]) for k in names])
+    row = {"seed": seed, "gain": gain, "loss_abs_err": abs(loss - l64.item()), "heat_err": (p - p64).abs().max().item(),
            "heat_range": [p64.min().item(), p64.max().item()],
            "grad_rel_err_max": float(mine.max()), "grad_rel_err_median": float(np.median(mine)), "grad_worst": names[int(mine.argmax())]}
-    if want32:
-        _, p32, g32, _ = nets.tracknet_train_step_grads(sd, x, y, torch.float32)
+    if o32 is not None:
+        _, p32, g32, _ = o32
         ref = np.array([rel(g32[k], g64[k]) for k in names])
         row.update({"heat_err_torch_fp32": (p32.double() - p64).abs().max().item(), "grad_rel_err_max_torch_fp32": float(ref.max()),
                     "grad_rel_err_median_torch_fp32": float(np.median(ref)),
@@ -156,15 +171,21 @@ def test_precision_sweep_train_step_288x512(gpu_device):
     beside the gain-2.4 rows -- profiles/r05_precision_sweep_train.json): heat maps inside TRAIN_HEAT_ABS[gain] of the fp64 oracle, the loss
     inside 1e-6, the worst gradient tensor inside 8e-2 of its own scale and the median inside 1.6e-2 (torch-fp32 itself: 2.8-3.7e-2 and
     0.6-0.9e-2 at gain 2.4; SURVEY 7: 2.5e-2 at batch 1)."""
-    old = torch.get_num_threads()
-    torch.set_num_threads(_host_threads())
-    rows = []
-    try:
-        full = os.environ.get("TNV3_SWEEP_FULL") == "1"
-        for seed, gain in ([(s_, g_) for s_ in SEEDS for g_ in GAINS] if full else TRAIN_ROWS):
-            rows.append(_train_row(gpu_device, 27, 8, seed, gain, want32=(full and gain == 2.4)))
-    finally:
-        torch.set_num_threads(old)
+    full = os.environ.get("TNV3_SWEEP_FULL") == "1"
+    cfgs = [(s_, g_) for s_ in SEEDS for g_ in GAINS] if full else TRAIN_ROWS
+    specs, where = [], []
+    for s_, g_ in cfgs:
+        where.append(len(specs))
+        specs.append(_train_spec(27, 8, s_, g_, "float64"))
+        if full and g_ == 2.4:
+            specs.append(_train_spec(27, 8, s_, g_, "float32"))
+    import threading
+    box = {}
+    th = threading.Thread(target=lambda: box.update(o=oracle_pool.run(specs)))
+    th.start()
+    gpu = [_train_gpu(gpu_device, 27, 8, s_, g_) for s_, g_ in cfgs]
+    th.join()
+    rows = [_train_row(s_, g_, gpu[k], box["o"][where[k]], box["o"][where[k] + 1] if (full and g_ == 2.4) else None) for k, (s_, g_) in enumerate(cfgs)]
     for r in rows:
         for k in ("_mine", "_ref", "_names"):
             r.pop(k, None)
@@ -194,12 +215,21 @@ def test_every_channel_plan_eval_and_train_step_288x512(gpu_device, plan):
     in_dim, out_dim = nets.tracknet_dims(seq_len, bg)
     net = get_model("TrackNet", seq_len, bg)
     assert (net.in_dim, net.out_dim) == (in_dim, out_dim)
+    import threading
+    box = {}
+    th = threading.Thread(target=lambda: box.update(o=oracle_pool.run(
+        [_train_spec(in_dim, out_dim, 31, 2.4, "float64"), _train_spec(in_dim, out_dim, 31, 2.4, "float32"),
+         _eval_spec(in_dim, out_dim, 31, 2.4, (0.5, 2.0), "float64"), _eval_spec(in_dim, out_dim, 31, 2.4, (0.5, 2.0), "float32")])))
+    th.start()
+    p_ev, z_ev = _eval_gpu(gpu_device, in_dim, out_dim, 31, 2.4, (0.5, 2.0))
+    got = _train_gpu(gpu_device, in_dim, out_dim, 31, 2.4)
+    th.join()
     old = torch.get_num_threads()
     torch.set_num_threads(_host_threads())
     try:
-        ev = _eval_row(gpu_device, in_dim, out_dim, 31, 2.4, (0.5, 2.0))
+        ev = _eval_row(31, 2.4, (0.5, 2.0), p_ev, z_ev, box["o"][2], box["o"][3])
         assert ev["heat_err"] <= EVAL_HEAT_ABS and ev["logit_rel_err"] <= EVAL_LOGIT_REL, ev
-        tr = _train_row(gpu_device, in_dim, out_dim, 31, 2.4, want32=True)
+        tr = _train_row(31, 2.4, got, box["o"][0], box["o"][1])
         mine, ref, names = tr.pop("_mine"), tr.pop("_ref"), tr.pop("_names")
         assert tr["loss_abs_err"] <= 1e-6 and tr["heat_err"] <= TRAIN_HEAT_ABS[2.4], tr
         assert mine.max() <= 2 * ref.max() + 2e-4, (names[int(mine.argmax())], mine.max(), ref.max())

@@ -82,7 +82,7 @@ def test_dgrad_up2x_vs_autograd(gpu_device, case):
     assert _dgrad_up2x_case(*case, gpu_device) <= 3e-6
 
 
-@pytest.mark.parametrize("variant", [3, 5], ids=["balanced", "persistent"])      # (0 / 2 / 4: measurement twins of libtnv3_diag.so since ABI 5)
+@pytest.mark.parametrize("variant", [5, -1], ids=["persistent", "library_pick"])      # (0 / 2 / 3 / 4 / 7: measurement twins of libtnv3_diag.so since ABI 5 / 6)
 @pytest.mark.parametrize("case", WINO_CASES + [(2, 256, 256, 72, 128), (1, 512, 512, 36, 64), (1, 64, 64, 288, 512), (3, 27, 64, 8, 192)])
 def test_conv3x3_wino_vs_torch(monkeypatch, gpu_device, case, variant):
     from tracknetv3_amd import ops
@@ -125,24 +125,29 @@ def test_conv3x3_wino_128_channel_kernel_vs_torch_and_streaming_kernel(gpu_devic
         assert torch.equal(got_full, ops.conv3x3_wino(x, u6, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=6))
 
 
-@pytest.mark.parametrize("case", [(2, 16, 64, 8, 64), (1, 27, 64, 12, 192), (2, 27, 64, 288, 512), (2, 64, 64, 288, 512), (3, 20, 192, 4, 64)])
-def test_conv3x3_wino_64_channel_form_vs_streaming_kernel(gpu_device, case):
-    """Variant 7 (the 128-channel kernel's 64-channel x 64-tile form; selectable, -1 keeps variant 5 for 64-channel layers): bit-identical to variant 5
-    -- plain, affine + addend + ReLU, statistics epilogue -- and run-to-run identical."""
-    from tracknetv3_amd import ops
-    n, cin, cout, h, w = case
+def test_product_library_refuses_the_measurement_twins(gpu_device):
+    """the product library dispatches, per kernel family, its default plus one fallback per shape class.  The generations that
+    were measured and rejected -- the F(2x2) forward kernels 0 / 2 / 3 / 4 / 7, the 32x32x2 F(4x4) kernel (variant 1) and its panel, the
+    Winograd weight gradients 0 / 2 / 3 / 4 / 6 / 7, the LDS-DMA staged direct weight gradient -- are refused with a pointer to libtnv3_diag.so."""
+    from tracknetv3_amd import _lib, ops
     d = gpu_device
-    x, wt = torch.relu(T((n, cin, h, w), 391)).to(d), T((cout, cin, 3, 3), 392, -0.3, 0.3).to(d)
-    mean, scale, shift, add = T((cout,), 393).to(d), T((cout,), 394, 0.5, 1.5).to(d), T((cout,), 395).to(d), T((n, cout, h, w), 396).to(d)
-    assert ops.wino_variant(-1, cin, 64) == 5
-    u5, u7 = ops.pack_wino_weights(wt, variant=5), ops.pack_wino_weights(wt, variant=7)
-    assert torch.equal(ops.conv3x3_wino(x, u5, cout, variant=5), ops.conv3x3_wino(x, u7, cout, variant=7))
-    full5 = ops.conv3x3_wino(x, u5, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=5)
-    for _ in range(2):
-        assert torch.equal(full5, ops.conv3x3_wino(x, u7, cout, mean=mean, scale=scale, shift=shift, relu=True, addend=add, variant=7))
-    z5, s5 = ops.conv3x3_wino_stats(x, u5, cout, addend=add, variant=5)
-    z7, s7 = ops.conv3x3_wino_stats(x, u7, cout, addend=add, variant=7)
-    assert torch.equal(z5, z7) and torch.equal(s5, s7)
+    x, wt = torch.relu(T((1, 64, 8, 64), 391)).to(d), T((64, 64, 3, 3), 392, -0.3, 0.3).to(d)
+    dz = T((1, 64, 8, 64), 393).to(d)
+    u5 = ops.pack_wino_weights(wt, variant=5)
+    for v in (0, 2, 3, 4, 7):
+        with pytest.raises(_lib.Tnv3Error, match="libtnv3_diag"):
+            ops.conv3x3_wino(x, u5, 64, variant=v)
+    with pytest.raises(_lib.Tnv3Error, match="libtnv3_diag"):
+        ops.pack_wino43_weights(wt, variant=1)
+    with pytest.raises(_lib.Tnv3Error, match="libtnv3_diag"):
+        ops.conv3x3_wino43(x, ops.pack_wino43_weights(wt, variant=0), 64, variant=1)
+    for v in (0, 2, 3, 4, 6, 7):
+        with pytest.raises(_lib.Tnv3Error, match="libtnv3_diag"):
+            ops.conv3x3_wgrad_wino(x, dz, variant=v)
+    with pytest.raises(_lib.Tnv3Error, match="libtnv3_diag"):
+        ops.conv3x3_wgrad(x, dz, variant=1)
+    for v in (5, 6 if False else 5, -1):                       # what stays: bit-identical streaming kernels, the library's pick
+        assert torch.equal(ops.conv3x3_wino(x, u5, 64, variant=5), ops.conv3x3_wino(x, ops.pack_wino_weights(wt, variant=v), 64, variant=v))
 
 
 def test_wino_pack_view(gpu_device):

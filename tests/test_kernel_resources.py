@@ -101,6 +101,19 @@ def test_no_vgpr_spills_anywhere(resources):
     assert not bad, list(bad)
 
 
+def test_product_library_carries_no_measurement_twins(resources):
+    """what the product build (no -DTNV3_DIAG) instantiates.  Gone with ABI 5 / 6: the one-wave and xi-split F(2x2) kernels, the
+    64-channel form of the 128-channel F(2x2) kernel (variant 7), the 32x32x2 F(4x4) kernel, its pack kernel, the Winograd weight-gradient
+    generations 0 / 2 / 3 / 4 / 6 / 7 and the LDS-DMA staged direct weight gradient.  (tests/test_gpu_tracknet.py checks the refusals at run time.)"""
+    names = [n for n in resources if n != "__asm__"]
+    for gone in ("conv3x3_wino_mfma_kernelINS_7WinoCfg", "conv3x3_wino_split_mfma_kernel", "22conv3x3_wino43_kernelI", "conv3x3_wino43_pack_kernel",
+                 "wgrad3x3_dma_kernel", "wgrad_wino3_mfma_kernel", "20wgrad_wino_mfma_kernelE", "WinoV6CfgILi0ELi1ELi0ELi1ELi0ELi2E"):
+        assert not any(gone in n for n in names), (gone, [n for n in names if gone in n])
+    for kept in ("conv3x3_wino43s_kernelILi8ELi0E", "conv3x3_wino43s_kernelILi4ELi0E", "conv3x3_wino_stream_mfma_kernel", "conv3x3_wino_a128_stream_kernel",
+                 "wgrad_wino43_kernel", "wgrad_up2x_wino43_kernel", "wgrad_wino2_mfma_kernelILi0E", "wgrad_wino5_mfma_kernel", "wgrad3x3_mfma_kernel"):
+        assert any(kept in n for n in names), kept
+
+
 def test_conv_and_wgrad_budgets(resources):
     cfg = "conv3x3_mfma_kernelINS_7ConvCfgI"
     # (template arguments, minimum waves per SIMD) of the configurations the tuned table uses
@@ -123,21 +136,21 @@ def test_conv_and_wgrad_budgets(resources):
     # variants 3 and 4 (one tile per workgroup), 5 (the streaming persistent kernel) and 6 (its 128-channel form with the filter operand
     # in registers -- which spilled 700+ registers until the two groups' programs were predicated instead of branched): the same budget
     for name in ("conv3x3_wino_v3_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi0E",
-                 "conv3x3_wino_stream_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi1E", "conv3x3_wino_a128_stream_kernelINS_9WinoV6CfgILi0ELi1ELi0ELi1ELi0ELi1E",
-                 "conv3x3_wino_a128_stream_kernelINS_9WinoV6CfgILi0ELi1ELi0ELi1ELi0ELi2E"):
+                 "conv3x3_wino_stream_mfma_kernelINS_9WinoV3CfgILi8ELi0ELi0ELi0ELi0ELi0ELi0ELi1E", "conv3x3_wino_a128_stream_kernelINS_9WinoV6CfgILi0ELi1ELi0ELi1ELi0ELi1E"):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
     # Winograd weight gradient, two waves per SIMD: the role-split generations and the production kernel (every wave streams and transforms)
-    for name in ("wgrad_wino2_mfma_kernelILi0E", "wgrad_wino3_mfma_kernelINS_13WgradWino3CfgILi2ELi0ELi0E", "wgrad_wino5_mfma_kernelINS_13WgradWino5CfgILi3ELi0E"):
+    for name in ("wgrad_wino2_mfma_kernelILi0E", "wgrad_wino5_mfma_kernelINS_13WgradWino5CfgILi3ELi0E"):
         k = _find(resources, name)
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
     # the 16x16x4 F(4x4) kernel (variant 0), both geometries, plain / statistics epilogue: 144 accumulators + named filter quads + the patch
     # transform in 256 registers, two waves per SIMD, no spill traffic (its steps end in a COUNTED vmcnt)
-    # (every instantiation: geometry 4 / 8 x plain / statistics / pooled second output / the upsampled halves' 25-product form)
+    # (every instantiation: geometry 4 / 8 x plain / statistics / pooled second output / the upsampled halves' 25-product forward (MODE 1) and
+    #  data gradient (MODE 2))
     w43s = {n: k for n, k in resources.items() if "conv3x3_wino43s_kernelILi" in n}
-    assert len(w43s) >= 8 and all(any(f"conv3x3_wino43s_kernelILi{c}ELi{st}E" in n for n in w43s) for c in (4, 8) for st in (0, 1)), sorted(w43s)
+    assert len(w43s) >= 10 and sum("ELi0ELi0ELi0ELi2E" in n for n in w43s) == 2 and all(any(f"conv3x3_wino43s_kernelILi{c}ELi{st}E" in n for n in w43s) for c in (4, 8) for st in (0, 1)), sorted(w43s)
     for name, k in w43s.items():
         assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, (name, k)
         assert k["LDS Size [bytes/block]"] <= 160 * 1024
@@ -145,12 +158,11 @@ def test_conv_and_wgrad_budgets(resources):
     k = _find(resources, "wgrad_wino43_kernel")
     assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
     assert k["LDS Size [bytes/block]"] <= 160 * 1024
-    for name in ("conv3x3_wino43_kernelILi1ELi0ELi0E", "conv3x3_wino43_kernelILi1ELi0ELi1E"):   # its 32x32x2 predecessor (variant 1), plain / statistics epilogue:
-        # 144 accumulators, two waves per SIMD; NO spill traffic: its chunk loop waits with a COUNTED vmcnt for its LDS-DMA pieces (nine
-        # A loads behind them may stay in flight)
-        k = _find(resources, name)
-        assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
-        assert k["LDS Size [bytes/block]"] <= 160 * 1024
+    # the upsampled halves' 25-of-36 weight gradient (round 5): 100 accumulators, two waves per SIMD
+    k = _find(resources, "wgrad_up2x_wino43_kernel")
+    assert k["Occupancy [waves/SIMD]"] >= 2 and k["VGPRs"] + k.get("AGPRs", 0) <= 256 and k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0, k
+    assert k["LDS Size [bytes/block]"] <= 160 * 1024
+    # (the 32x32x2 predecessor conv3x3_wino43_kernel is a twin of libtnv3_diag.so since ABI 6: test_product_library_carries_no_measurement_twins)
     for name, occ in (("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi2ELi4ELi2ELi4E", 4), ("conv_up2x_mfma_kernelINS_11ConvUp2xCfgILi2ELi1ELi4ELi2ELi4E", 4),
                       ("dgrad_up2x_mfma_kernelINS_12DgradUp2xCfgILi2ELi2ELi4ELi1ELi2E", 4)):
         k = _find(resources, name)

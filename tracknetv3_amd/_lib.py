@@ -46,9 +46,9 @@ def _declare(lib):
     sig("tnv3_conv_up2x_wino_packed_floats", sz, i, i, i)
     sig("tnv3_conv_up2x_wino_pack", i, p, p, i, i, i, i, p)
     sig("tnv3_conv_up2x_wino_forward", i, p, p, p, i, i, i, i, i, i, p)
-    sig("tnv3_dgrad_up2x_wino_supported", i, i, i, i, i)
-    sig("tnv3_dgrad_up2x_wino_packed_floats", sz, i, i)
-    sig("tnv3_dgrad_up2x_wino_pack", i, p, p, i, i, i, p)
+    sig("tnv3_dgrad_up2x_wino_supported", i, i, i, i, i, i)
+    sig("tnv3_dgrad_up2x_wino_packed_floats", sz, i, i, i)
+    sig("tnv3_dgrad_up2x_wino_pack", i, p, p, i, i, i, i, p)
     sig("tnv3_dgrad_up2x_wino", i, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_dgrad_up2x_packed_floats", sz, i, i)
     sig("tnv3_pack_dgrad_up2x_weights", i, p, p, i, i, i, p)

@@ -212,8 +212,12 @@ def _train_backward_body(ctx, dev, head_backward):
             # correlation of dZ, 4/9 of the MACs, no full-resolution intermediate), the skip half as a plain 3x3 dgrad
             skip_wino = tuning.use_winograd(blk.conv.out_dim, c1, int(h), int(w))
             w_skip_t = None
-            if tuning.UP2X_WINO and ops.dgrad_up2x_wino_supported(c0, blk.conv.out_dim, int(h) // 2, int(w) // 2):
-                d_low = ops.dgrad_up2x_wino(dz, blk.packed_dgrad_up2x_wino(c0), c0)      # one GEMM with K = 9 * Cout
+            dv = ops.dgrad_up2x_wino_variant()
+            if dv == 2 and not ops.dgrad_up2x_wino_supported(c0, blk.conv.out_dim, int(h) // 2, int(w) // 2, 2):
+                dv = 0
+            if tuning.UP2X_WINO and ops.dgrad_up2x_wino_supported(c0, blk.conv.out_dim, int(h) // 2, int(w) // 2, dv):
+                # 25 of the 36 F(4x4) products (variant 2), or one GEMM with K = 9 * Cout
+                d_low = ops.dgrad_up2x_wino(dz, blk.packed_dgrad_up2x_wino(c0, dv), c0, variant=dv)
                 if not skip_wino:
                     w_skip_t = blk.packed_dgrad_up2x(c0)[1]
             else:

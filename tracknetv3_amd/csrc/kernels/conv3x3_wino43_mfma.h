@@ -124,10 +124,12 @@ __device__ __forceinline__ void conv3x3_wino43_pack_elements(const float* __rest
       }
   }
 }
+#ifdef TNV3_DIAG      // (a non-template kernel is emitted wherever this header is included: the twin stays out of the product objects)
 inline __global__ void __launch_bounds__(256) conv3x3_wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin,
                                                                         long s_co, long s_ci, int flip) {
   conv3x3_wino43_pack_elements(w, u, Cout, Cin, s_co, s_ci, flip, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
+#endif
 // One 1-D input transform B^T applied to six values, the three outputs of one half: rows 0..2 (RH = 0) or 3..5 (RH = 1).
 //   (B^T above; Lavin's for s = 1: [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1])
 template <int RH>

@@ -55,14 +55,17 @@ struct Wino43SBase {
 };
 // MODE 0: the plain layer (36 xi = 18 pairs; raw tile of the input itself).  MODE 1: the UPSAMPLED half of a decoder-entry layer
 // (model.py:65,67,69: conv3x3 over nn.Upsample(2)(x_low)) computed from the low-resolution tensor -- 25 xi = 13 pairs (the last one
-// half empty), see the section "upsampled half" below.
+// half empty), see the section "upsampled half" below.  MODE 2 (round 5): that half's DATA GRADIENT -- the raw tile is dZ at the full
+// resolution (MODE 0's loader), 25 xi (MODE 1's operand pairs and accumulators), and the write-out sums each 2x2 block of the 4x4
+// tile into the low-resolution gradient; see the section "data gradient of the upsampled half".
 template <int CBW_, int MODE_ = 0>
 struct Wino43SCfg : Wino43SBase {
   static_assert(CBW_ == 4 || CBW_ == 8, "16-channel blocks per workgroup");
   static constexpr int MODE = MODE_;
   static constexpr int NXI = MODE_ ? 25 : 36, PAIRS = (NXI + 1) / 2;
   static constexpr int A_CHUNK_FLOATS = PAIRS * 64 * 4;   // one (16-channel block, chunk of 8 input channels) of the panel
-  static constexpr int RQ = MODE_ ? 9 : 17;               // pieces per raw row: 17 from column w0 - 1 / 9 from low-resolution column w0 / 2 - 1
+  static constexpr bool LOW = MODE_ == 1;                 // the SOURCE is the low-resolution tensor
+  static constexpr int RQ = LOW ? 9 : 17;                 // pieces per raw row: 17 from column w0 - 1 / 9 from low-resolution column w0 / 2 - 1
   static constexpr int CBW = CBW_, TRW = 8 / CBW_;        // tile rows per workgroup
   static constexpr int KB = CBW_ / 4;                     // 8-channel blocks per step: 1 (64 x 2 rows) / 2 (128 x 1 row: 16 channels per step,
   static constexpr int SC = 8 * KB;                       // so that every thread still has half a patch to transform in every step)
@@ -70,10 +73,10 @@ struct Wino43SCfg : Wino43SBase {
   static constexpr int NV = CBW_ == 4 ? 3 : 2;            // V stages: 3 = the transform runs two steps ahead and the next step's first B quads are
                                                           // read before the step's barrier; 2 (LDS: 16-channel stages) = one step ahead
   static constexpr int MB = 16 * CBW, TB = 16 * TRW, TH = 4 * TRW;
-  static constexpr int RROWS = MODE_ ? TH / 2 + 2 : TH + 2;      // raw halo tile per channel: rows h0-1 .. h0+TH / low-resolution rows h0/2-1 .. h0/2+TH/2
+  static constexpr int RROWS = LOW ? TH / 2 + 2 : TH + 2;        // raw halo tile per channel: rows h0-1 .. h0+TH / low-resolution rows h0/2-1 .. h0/2+TH/2
   // pieces per channel plane.  MODE 0: a multiple of 16 pieces, so that the two channels a 16-lane group of a ds_read_b128 touches fall into
   // disjoint bank ranges; MODE 1 (8-byte reads, 32-lane groups): 8 mod 16 pieces = 32 mod 64 banks between the group's two channels
-  static constexpr int RPLANE = MODE_ ? (RROWS * RQ + 7) / 16 * 16 + 8 : (RROWS * RQ + 15) / 16 * 16;
+  static constexpr int RPLANE = LOW ? (RROWS * RQ + 7) / 16 * 16 + 8 : (RROWS * RQ + 15) / 16 * 16;
   static constexpr int RAW_SLOTS = SC * RPLANE;           // pieces per stage: 1408 (2.75 per thread) / 1792 (3.5)
   static constexpr int RAW_STAGE = RAW_SLOTS * 4;         // floats
   static constexpr int NDMA = (RAW_SLOTS + NT - 1) / NT;  // DMA instructions per wave and step; the last one: the first DMA_LAST_WAVES waves
@@ -207,6 +210,65 @@ inline __global__ void __launch_bounds__(256) conv_up2x_wino43_pack_kernel(const
   }
 }
 
+// ---- data gradient of the upsampled half (MODE 2).  Points (0, +-1, +-b, inf), b = kD43b = 3/2 (B = b^2 = 9/4: every constant of the
+//      transforms an exact binary fraction; the plain layers' larger point is 3/2 too).  U''[i'][j'] = G'' w~ G''^T over the indices
+//      (0, 1, b, -b, 5), w~[ci][co][kh][kw] = w[co][ci][2 - kh][2 - kw], with Toom-Cook's G rows scaled by the block sum's column factors:
+//      G'' = [1/B 0 0; (1 1 1) / (1 - B); (1 + b) (1 b B) / (2 B (B - 1)); (1 - b) (1 -b B) / (2 B (B - 1)); 0 0 1].
+//      Panel u[ci / 16][chunk over co][pair 13][lane = (co % 8 / 2) * 16 + ci % 16][(co % 2) * 2 + slot], pairs as in MODE 1 with (e, o) -> (b, -b).
+constexpr float kD43b = 1.5f, kD43B = kD43b * kD43b, kD43B1 = 1.0f + kD43B;
+__device__ __forceinline__ float wino43d_g_row(int i, float g0, float g1, float g2) {
+  constexpr float nb = 1.0f / (2.0f * kD43B * (kD43B - 1.0f));
+  switch (i) {
+    case 0: return (1.0f / kD43B) * g0;
+    case 1: return (1.0f / (1.0f - kD43B)) * ((g0 + g1) + g2);
+    case 2: return ((1.0f + kD43b) * nb) * ((g0 + kD43b * g1) + kD43B * g2);
+    case 3: return ((1.0f - kD43b) * nb) * ((g0 - kD43b * g1) + kD43B * g2);
+    default: return g2;
+  }
+}
+inline size_t dgrad_up2x_wino43_packed_floats(int c0, int cout) {
+  if (c0 <= 0 || cout <= 0 || c0 % 16) return 0;
+  return (size_t)(c0 / 16) * ((cout + 7) / 8) * (13 * 64 * 4) + kPackZeroTail;
+}
+inline long dgrad_up2x_wino43_pack_items(int Cout, int c0) { return (long)(c0 / 16) * ((Cout + 7) / 8) * 64 + kPackZeroTail / 4; }
+inline __global__ void __launch_bounds__(256) dgrad_up2x_wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int c0) {
+  const int nch = (Cout + 7) / 8;
+  const long quads = (long)(c0 / 16) * nch * 64;
+  f32x4* u4 = reinterpret_cast<f32x4*>(u);
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads + kPackZeroTail / 4; q += (long)gridDim.x * 256) {
+    if (q >= quads) { u4[quads * 13 + (q - quads)] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; continue; }
+    const int ln = (int)(q & 63);
+    const int r = (int)(q >> 6), k = r % nch, cb = r / nch;
+    const int ci = 16 * cb + (ln & 15), g = ln >> 4;      // the kernel's output channel = an input channel of the layer
+    float uu[2][5][5];                                  // [s][i'][j']
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const int co = 8 * k + 2 * g + sx;                // the kernel's contraction channel = an output channel of the layer
+      float f[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) f[t] = co < Cout ? w[((size_t)co * Cin + ci) * 9 + (8 - t)] : 0.0f;      // flipped taps
+      float rowv[5][3];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rowv[i][c] = wino43d_g_row(i, f[c], f[3 + c], f[6 + c]);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) uu[sx][i][j] = wino43d_g_row(j, rowv[i][0], rowv[i][1], rowv[i][2]);
+    }
+    f32x4* dst = u4 + ((long)r * 13) * 64 + ln;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      dst[j * 64] = f32x4{uu[0][0][j], uu[0][1][j], uu[1][0][j], uu[1][1][j]};
+      dst[(5 + j) * 64] = f32x4{uu[0][2][j], uu[0][3][j], uu[1][2][j], uu[1][3][j]};
+    }
+    dst[10 * 64] = f32x4{uu[0][4][0], uu[0][4][1], uu[1][4][0], uu[1][4][1]};
+    dst[11 * 64] = f32x4{uu[0][4][2], uu[0][4][3], uu[1][4][2], uu[1][4][3]};
+    dst[12 * 64] = f32x4{uu[0][4][4], 0.0f, uu[1][4][4], 0.0f};
+  }
+}
+
 // Table-driven pack of panels of BOTH Winograd forms in one launch (layout 0-2: F(2x2) panels, conv3x3_wino_mfma.h; 3: F(4x4) panels of the 32x32x2 kernel; 4: of the 16x16x4 kernel)
 inline __global__ void __launch_bounds__(256) conv3x3_wino_pack_multi43_kernel(const WinoPackTable t) {
   int lo = 0, hi = t.count;                    // first_block[lo] <= blockIdx.x < first_block[hi]
@@ -252,10 +314,11 @@ __device__ __forceinline__ void wino43s_at6(float m0, float m1, float m2, float 
 template <int CBW, int STATS = 0, int GROW = 10, int TS = 10, int TL = 0, int DG = 0, int POOL = 0, int MODE = 0>
 __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const WinoArgs a) {
   using Cfg = Wino43SCfg<CBW, MODE>;
-  static_assert(MODE == 0 || (STATS == 0 && POOL == 0), "the upsampled half writes plain partial sums");
+  static_assert(MODE == 0 || (STATS == 0 && POOL == 0), "the upsampled half (and its data gradient) write plain sums");
+  constexpr bool LOW = Cfg::LOW;
   constexpr int SC = Cfg::SC, KB = Cfg::KB, NP = Cfg::NP, NV = Cfg::NV, NSLOT = 2 * NP, PAIRS = Cfg::PAIRS, NXI = Cfg::NXI;
   constexpr int NT = Cfg::NT, MB = Cfg::MB, V_STAGE = Cfg::V_STAGE, RAW_STAGE = Cfg::RAW_STAGE, V_PAIR = Cfg::V_PAIR;
-  constexpr int A_DIST = 5, RQ = Cfg::RQ, T_PIECES = MODE ? 5 : 17, GPS = 3;      // GPS: grow loads per slot
+  constexpr int A_DIST = 5, RQ = Cfg::RQ, T_PIECES = MODE == 1 ? 5 : (MODE == 2 ? 11 : 17), GPS = 3;      // GPS: grow loads per slot
   constexpr bool B_ACROSS = Cfg::B_ACROSS;
   constexpr int GS = NSLOT - (GROW + GPS - 1) / GPS;                  // first slot of the grow phase
   constexpr int TD = NV - 1;                                          // the transform's lead over the MFMAs, in steps
@@ -267,8 +330,8 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int swave = __builtin_amdgcn_readfirstlane(wave);
-  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;      // (H, W: the OUTPUT's; MODE 1 reads its source at half of both)
-  const int SH = H >> MODE, SW = W >> MODE, SHW = SH * SW;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;      // (H, W: the tile grid's = the full resolution; MODE 1 reads its source, MODE 2
+  const int SH = H >> LOW, SW = W >> LOW, SHW = SH * SW;                   //  writes its result, at half of both)
   const int tilesH = (H + Cfg::TH - 1) / Cfg::TH, tilesW = W / Cfg::TW;
   const int nPT = a.N * tilesH * tilesW, nMB = Cout / MB;
   const int nChunks = (Cin + SC - 1) / SC;               // steps per tile
@@ -313,7 +376,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   auto set_d = [&]() {
     int t_op = tid;
     TNV3_OPAQUE_V(t_op);
-    const int h0 = (wD.trow * Cfg::TH) >> MODE, w0 = (wD.tcol * Cfg::TW) >> MODE;      // in the source's pixels
+    const int h0 = (wD.trow * Cfg::TH) >> LOW, w0 = (wD.tcol * Cfg::TW) >> LOW;      // in the source's pixels
 #pragma unroll
     for (int i = 0; i < Cfg::NDMA; ++i) {
       const int e = t_op + i * NT;
@@ -353,7 +416,8 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   const int t_ci = 8 * t_kb + 2 * t_g + t_s;
   // MODE 0: raw rows 4 ttr + RH .., piece tc (+ row * 68 floats; second piece + 4); V pairs 9 RH ..
   // MODE 1: low-resolution raw rows 2 ttr + RH .., floats 2 tc .. 2 tc + 3 (+ row * 36 floats); V pairs 0-4 (RH 0) / 5-12 (RH 1)
-  const int t_src = t_ci * (Cfg::RPLANE * 4) + (MODE ? ((2 * t_tr + RH) * RQ) * 4 + 2 * t_tc : ((4 * t_tr + RH) * RQ + t_tc) * 4);
+  // MODE 2: MODE 0's raw rows, MODE 1's V pairs
+  const int t_src = t_ci * (Cfg::RPLANE * 4) + (LOW ? ((2 * t_tr + RH) * RQ) * 4 + 2 * t_tc : ((4 * t_tr + RH) * RQ + t_tc) * 4);
   const int t_dst = (t_kb * PAIRS + (MODE ? 5 : 9) * RH) * V_PAIR + t_tr * 256 + t_g * 64 + t_tc * 4 + t_s * 2;         // + pair * V_PAIR
 
   // ---- T cursor: the transform of half a patch, in pieces (the step places one piece behind an MFMA slot)
@@ -425,6 +489,73 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
           *reinterpret_cast<wf2*>(t_v + 5 * V_PAIR) = wf2{uw[1][0], uw[1][1]};
           *reinterpret_cast<wf2*>(t_v + 6 * V_PAIR) = wf2{uw[1][2], uw[1][2]};
           *reinterpret_cast<wf2*>(t_v + 7 * V_PAIR) = wf2{uw[1][3], 0.0f};
+        }
+      }
+    } else if constexpr (MODE == 2) {
+      // ---- data gradient of the upsampled half.  dX_low = 2x2 block sums of the plain 3x3 correlation of dZ with the transposed, flipped
+      //      filter.  In F(4x4) form over the points (0, +-1, +-b, inf) the block sum P A^T (P = [1 1 0 0; 0 0 1 1]) has a ZERO column at the point
+      //      -1 (A^T's column (1, -1, 1, -1)): five products per axis remain, indices (0, 1, b, -b, 5).  b = kD43b = 3/2, B = b^2.  B^T's rows:
+      //      (B d0 - (1 + B) d2 + d4), (d4 - B d2) + (d3 - B d1), (d4 - d2) +- b (d3 - d1), (B d1 - (1 + B) d3 + d5).  Row half 0: rows 0, 1 from raw
+      //      rows d0 .. d4; row half 1: rows b, -b, 5 from d1 .. d5.  The filter rows carry P A^T's column factors (2, 1 + b, 1 - b), so that
+      //      out0 = m0 + m1 + (mb + m-b), out1 = m1 + B (mb + m-b) + m5 (write-out below).
+      if constexpr (P == 0) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) tq0[r] = *reinterpret_cast<const f32x4*>(t_raw + r * (RQ * 4));
+        if (fix_corner) {
+          if (lane == 0 && (swave & 3) == 0) {
+            const tnv3_rsrc_t ri = tnv3_make_rsrc(a.src + (size_t)wT.n * Cin * HW, (unsigned)Cin * (unsigned)HW * 4u);
+            const f32x4 x = tnv3_buf_load_f4(ri, 0u, 0u);
+            tq0[1 - RH] = f32x4{0.0f, x[0], x[1], x[2]};
+          }
+        }
+      } else if constexpr (P == 5) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) tq1[r] = *reinterpret_cast<const wf2*>(t_raw + r * (RQ * 4) + 4);
+      } else if constexpr (P < 8) {                      // first pass, down patch column c
+        constexpr int c = P < 5 ? P - 1 : P - 2;
+        float x[5], o[3];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) x[r] = c < 4 ? tq0[r][c < 4 ? c : 0] : tq1[r][c < 4 ? 0 : c - 4];
+        if constexpr (RH == 0) {                         // x = d0 .. d4
+          o[0] = fmaf(kD43B, x[0], fmaf(-kD43B1, x[2], x[4]));
+          o[1] = fmaf(-kD43B, x[2], x[4]) + fmaf(-kD43B, x[1], x[3]);
+          o[2] = 0.0f;
+        } else {                                         // x = d1 .. d5
+          const float e = x[3] - x[1], f = x[2] - x[0];
+          o[0] = fmaf(kD43b, f, e);
+          o[1] = fmaf(-kD43b, f, e);
+          o[2] = fmaf(kD43B, x[0], fmaf(-kD43B1, x[2], x[4]));
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float v = o[r];
+          if constexpr (c == 0) v = zl ? 0.0f : v;
+          if constexpr (c == 5) v = zr ? 0.0f : v;
+          tt[r][c] = v;
+        }
+      } else {                                           // second pass along row r of the half: five values, straight into V
+        constexpr int r = P - 8;
+        if constexpr (RH == 1 || r < 2) {
+          const float(&d)[6] = tt[r];
+          const float e = d[4] - d[2], f = d[3] - d[1];
+          uw[0][0] = fmaf(kD43B, d[0], fmaf(-kD43B1, d[2], d[4]));
+          uw[0][1] = fmaf(-kD43B, d[2], d[4]) + fmaf(-kD43B, d[1], d[3]);
+          uw[0][2] = fmaf(kD43b, f, e);
+          uw[0][3] = fmaf(-kD43b, f, e);
+          const float v5 = fmaf(kD43B, d[1], fmaf(-kD43B1, d[3], d[5]));
+          if constexpr (r == 0) {                        // rows 0 / b: the first floats of pairs 0-4 (row half 0) / 5-9 (row half 1); parked until row 1 / -b
+#pragma unroll
+            for (int j = 0; j < 4; ++j) uc[0][j] = uw[0][j];
+            uc[1][0] = v5;
+          } else if constexpr (r == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<wf2*>(t_v + j * V_PAIR) = wf2{uc[0][j], uw[0][j]};
+            *reinterpret_cast<wf2*>(t_v + 4 * V_PAIR) = wf2{uc[1][0], v5};
+          } else {                                       // row 5 (row half 1 only): pairs 10-12
+            *reinterpret_cast<wf2*>(t_v + 5 * V_PAIR) = wf2{uw[0][0], uw[0][1]};
+            *reinterpret_cast<wf2*>(t_v + 6 * V_PAIR) = wf2{uw[0][2], uw[0][3]};
+            *reinterpret_cast<wf2*>(t_v + 7 * V_PAIR) = wf2{v5, 0.0f};
+          }
         }
       }
     } else if constexpr (P == 0) {                       // raw rows RH .. RH + 4 of the patch, columns 0-3
@@ -602,7 +733,35 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
     const size_t plane0 = ((size_t)wM.n * Cout + e_m0) * HW;
     const unsigned planes_b = 16u * (unsigned)HW * 4u;
     const tnv3_rsrc_t r_dst = tnv3_make_rsrc(a.dst + plane0, planes_b);
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 2) {
+      // data gradient of the upsampled half: dX_low (2x2 per tile) = Q M Q^T over the indices (0, 1, b, -b, 5) with Q = [1 1 1 1 0; 0 1 B B 1];
+      // M[i'][j'] = acc[2 j' + i'] (i' = 0, 1), acc[10 + 2 j' + (i' - 2)] (i' = b, -b), acc[20 + j'] (i' = 5).  dst = [N][Cout][H / 2][W / 2].
+      const int LW = W >> 1, LHW = HW >> 2;
+      const tnv3_rsrc_t r_low = tnv3_make_rsrc(a.dst + ((size_t)wM.n * Cout + e_m0) * LHW, 16u * (unsigned)LHW * 4u);
+      const unsigned lane_off_l = oh < H ? (unsigned)((4 * g) * LHW + (oh >> 1) * LW + (ow >> 1)) * 4u : kDmaOob;
+      auto q2 = [](float q0, float q1, float qb, float qm, float q5, float (&o)[2]) {
+        const float sb = qb + qm;
+        o[0] = (q0 + q1) + sb;
+        o[1] = fmaf(kD43B, sb, q1) + q5;
+      };
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float wv[2][5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          float o[2];
+          q2(acc[2 * j][r], acc[2 * j + 1][r], acc[10 + 2 * j][r], acc[11 + 2 * j][r], acc[20 + j][r], o);
+          wv[0][j] = o[0]; wv[1][j] = o[1];
+        }
+#pragma unroll
+        for (int ar = 0; ar < 2; ++ar) {
+          float o[2];
+          q2(wv[ar][0], wv[ar][1], wv[ar][2], wv[ar][3], wv[ar][4], o);
+          tnv3_buf_store_f2(r_low, (DG & 32) ? kDmaOob : lane_off_l, (unsigned)r * (unsigned)LHW * 4u + (unsigned)(ar * LW) * 4u, wf2{o[0], o[1]});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (MODE == 1) {
       // upsampled half: Y = A'^T M' A' over the indices (0, 1, e, o, 5) with A'^T = [1 1 1 0 0; 0 1 0 1 0; 0 1 B 0 0; 0 1 0 B 1], B = kU43B; M'[i'][j'] =
       // acc[2 j' + i'] (i' = 0, 1), acc[10 + 2 j' + (i' - 2)] (i' = e, o), acc[20 + j'] (i' = 5).  Plain partial sums: the skip half's launch adds them.
       const unsigned lane_off_u = oh < H ? (unsigned)((4 * g) * HW + oh * W + ow) * 4u : kDmaOob;

@@ -43,6 +43,8 @@ struct WgradWinoCfg {
   static_assert(DZ_RAW % (4 * NT) == 0 && X_RAW % (4 * NT) == 0, "pieces must deal evenly");
 };
 
+#ifdef TNV3_DIAG      // the first kernel (variant 0): a measurement twin of libtnv3_diag.so since ABI 5 -- a non-template kernel is emitted wherever this
+                      // header is included, so the definition itself is guarded
 inline __global__ void __launch_bounds__(WgradWinoCfg::NT) wgrad_wino_mfma_kernel(const WgradWinoArgs a) {
   using Cfg = WgradWinoCfg;
   constexpr int NT = Cfg::NT, TS = Cfg::TS, XW = Cfg::XW;
@@ -197,6 +199,7 @@ inline __global__ void __launch_bounds__(WgradWinoCfg::NT) wgrad_wino_mfma_kerne
       slab[((size_t)xi * Cout + co) * Cin + ci] = acc[xi][r];
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Second generation (variant 1 of tnv3_conv3x3_wgrad_wino): the same GEMMs, the same K order per accumulator -- hence the

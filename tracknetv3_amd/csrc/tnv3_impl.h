@@ -30,6 +30,15 @@
 
 namespace tnv3 {
 
+// Since ABI 6 the product library carries, per kernel family, what dispatches by default plus one fallback per shape class; every generation that
+// was measured and rejected is a measurement twin of libtnv3_diag.so (built from this file with -DTNV3_DIAG) and is refused here.
+#ifdef TNV3_DIAG
+constexpr bool kTwins = true;
+#else
+constexpr bool kTwins = false;
+#endif
+
+
 inline char* err_buf() {
   static thread_local char buf[512] = {0};
   return buf;
@@ -554,6 +563,7 @@ int conv3x3_wino_pack_multi_impl(Launcher& L, const WinoPackItem* items, int cou
           it.layout > 4)
         TNV3_FAIL(-1, "conv3x3_wino_pack_multi: bad item %d", base + k);
       const int cout = it.transpose_flip ? it.c_count : it.cout_w, cin = it.transpose_flip ? it.cout_w : it.c_count;
+      if (it.layout == 3 && !kTwins) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layout 3 (the 32x32x2 F(4x4) kernel's panel) left the product library with ABI 6 (item %d)", base + k);
       if ((it.layout == 2 || it.layout == 3) && cout % 32) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layouts 2 and 3 need Cout %% 32 == 0 (item %d: %d)", base + k, cout);
       if (it.layout == 4 && cout % 16) TNV3_FAIL(-1, "conv3x3_wino_pack_multi: layout 4 needs Cout %% 16 == 0 (item %d: %d)", base + k, cout);
       const long s_w_co = (long)it.cin_w * 9, s_w_ci = 9;
@@ -592,6 +602,7 @@ int conv3x3_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int 
 //      2 = the same kernel, 64-channel geometry always; 1 = kernels/conv3x3_wino43_mfma.h (32x32x2, four waves per xi block).
 //      Variants 0 and 2 read one panel layout, 1 another: pack and run with the same variant.
 constexpr int kWino43Variants = 3;
+
 constexpr int kWino43SGrow = 9;              // the 16x16x4 kernel's step schedule (conv3x3_wino43s_kernel<.., GROW, TS>): filter quads of the next step
 constexpr int kWino43STs = 10;               // requested at the end of a step; first slot of the patch transform
 inline bool conv3x3_wino43_supported(int cin, int cout, int h, int w) {
@@ -607,6 +618,7 @@ template <class Launcher>
 int conv3x3_wino43_pack_impl(Launcher& L, const float* w, float* u, int cout_w, int cin_w, int c_from, int c_count, int transpose_flip, int variant) {
   if (!w || !u || cout_w <= 0 || cin_w <= 0 || c_from < 0 || c_count <= 0 || c_from + c_count > cin_w) TNV3_FAIL(-1, "conv3x3_wino43_pack: bad argument");
   if (variant < 0 || variant >= kWino43Variants) TNV3_FAIL(-1, "conv3x3_wino43_pack: unknown kernel variant %d", variant);
+  if (variant == 1 && !kTwins) TNV3_FAIL(-1, "conv3x3_wino43_pack: kernel variant 1 (32x32x2) is a measurement twin of libtnv3_diag.so since ABI 6 (dispatchable: 0, 2)");
   const bool s16 = variant != 1;
   const int cout = transpose_flip ? c_count : cout_w, cin = transpose_flip ? cout_w : c_count;
   if (cout % (s16 ? 16 : 32)) TNV3_FAIL(-1, "conv3x3_wino43_pack: needs Cout %% %d == 0 (got %d)", s16 ? 16 : 32, cout);
@@ -617,8 +629,12 @@ int conv3x3_wino43_pack_impl(Launcher& L, const float* w, float* u, int cout_w, 
   if (s16)
     return L.launch(conv3x3_wino43s_pack_kernel, grid, 256, w + (size_t)c_from * 9, u, cout, cin, transpose_flip ? s_w_ci : s_w_co,
                     transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
+#ifdef TNV3_DIAG
   return L.launch(conv3x3_wino43_pack_kernel, grid, 256, w + (size_t)c_from * 9, u, cout, cin, transpose_flip ? s_w_ci : s_w_co,
                   transpose_flip ? s_w_co : s_w_ci, transpose_flip ? 1 : 0);
+#else
+  return -1;
+#endif
 }
 // statistics tiles: variants 0 / 2 one per 4 x 64 pixels, variant 1 one per 8 x 64
 inline long conv3x3_wino43_stats_tiles(int n, int h, int w, int variant) {
@@ -634,6 +650,7 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
   if (pool_dst && (variant == 1 || stats)) TNV3_FAIL(-1, "conv3x3_wino43: the pooled second output belongs to kernel variants 0 / 2 without statistics");
   if (pool_dst && (((uintptr_t)pool_dst) & 7)) TNV3_FAIL(-1, "conv3x3_wino43: the pooled output must be 8-byte aligned");
   if (variant < 0 || variant >= kWino43Variants) TNV3_FAIL(-1, "conv3x3_wino43: unknown kernel variant %d", variant);
+  if (variant == 1 && !kTwins) TNV3_FAIL(-1, "conv3x3_wino43: kernel variant 1 (32x32x2) is a measurement twin of libtnv3_diag.so since ABI 6 (dispatchable: 0, 2)");
   if (stats && (scale || shift || mean || relu)) TNV3_FAIL(-1, "conv3x3_wino43: the batch-statistics epilogue writes the raw convolution (no affine, no ReLU)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino43: statistics buffer must be 8-byte aligned");
   if (!conv3x3_wino43_supported(cin, cout, h, w))
@@ -659,6 +676,7 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
     if (pool_dst) return L.launch(conv3x3_wino43s_kernel<4, 0, kWino43SGrow, kWino43STs, 0, 0, 1>, grid, Wino43SBase::NT, a);
     return L.launch(conv3x3_wino43s_kernel<4, 0, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
   }
+#ifdef TNV3_DIAG
   const long npt = (long)n * ((h + Wino43Cfg::TH - 1) / Wino43Cfg::TH) * (w / Wino43Cfg::TW);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino43: too many pixel tiles");
   const int grid = wino_persistent_grid(conv_grid_blocks(cout / Wino43Cfg::MB, (int)npt));
@@ -666,6 +684,9 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
   // shape, profiles/r03_wino43_transform_ab.txt; filling after the write-out <0, 0> 1-1.5 % slower)
   if (stats) return L.launch(conv3x3_wino43_kernel<1, 0, 1>, grid, Wino43Cfg::NT, a);
   return L.launch(conv3x3_wino43_kernel<1, 0>, grid, Wino43Cfg::NT, a);
+#else
+  return -1;
+#endif
 }
 
 #ifdef TNV3_DIAG
@@ -719,6 +740,8 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
                               double* stats = nullptr, const float* bn_z = nullptr, const float* bn_c4 = nullptr) {
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino: bad argument");
   if (variant < 0) variant = conv3x3_wino_pick(cin, cout);
+  if ((variant == 3 || variant == 7) && !kTwins)
+    TNV3_FAIL(-1, "conv3x3_wino: kernel variant %d is a measurement twin of libtnv3_diag.so since ABI 6 (dispatchable: 5, 6; -1 picks between them)", variant);
   if (stats && !conv3x3_wino_has_stats(variant)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue exists in kernel variants 3, 4 and 5");
   if (stats && (scale || shift || mean)) TNV3_FAIL(-1, "conv3x3_wino: the batch-statistics epilogue writes the raw convolution (no affine)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino: statistics buffer must be 8-byte aligned");
@@ -741,9 +764,12 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     const int grid7 = wino_persistent_grid(conv_grid_blocks(cout / V7::MB, (int)npt7));
 #ifdef TNV3_DIAG
     if (variant == 121) return L.launch(conv3x3_wino_a128_stream_kernel<WinoV6Cfg<0, 0, 0, 1, 0, 2>>, grid7, V7::NT, a7);     // younger waves' MFMAs first
-#endif
     if (variant != 7) TNV3_FAIL(-1, "conv3x3_wino: unknown kernel variant %d", variant);
     return L.launch(conv3x3_wino_a128_stream_kernel<V7>, grid7, V7::NT, a7);
+#else
+    (void)grid7;
+    TNV3_FAIL(-1, "conv3x3_wino: unknown kernel variant %d", variant);
+#endif
   }
   if (is_v6 ? (h % 4 != 0) : !conv3x3_wino_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino: needs Cout %% %d == 0, H %% 4 == 0, W %% %d == 0 (got Cout=%d, %dx%d)", WinoA::MB, WinoA::PW, cout, h, w);
@@ -860,7 +886,7 @@ int conv3x3_wino_forward_impl(Launcher& L, const float* src, const float* u, con
     case 2: return L.launch(conv3x3_wino_split_mfma_kernel<WinoSplit>, conv_grid_blocks(cout / WinoSplit::MB, (int)npt), WinoSplit::NT, a);
     case 0: return L.launch(conv3x3_wino_mfma_kernel<WinoA>, conv_grid_blocks(cout / WinoA::MB, (int)npt), WinoA::NT, a);
 #else
-    case 4: case 2: case 0: TNV3_FAIL(-1, "conv3x3_wino: kernel variant %d is a measurement twin of libtnv3_diag.so since ABI 5 (dispatchable: 3, 5, 6, 7)", variant);
+    case 4: case 2: case 0: TNV3_FAIL(-1, "conv3x3_wino: kernel variant %d is a measurement twin of libtnv3_diag.so since ABI 5 (dispatchable: 5, 6)", variant);
 #endif
     default: TNV3_FAIL(-1, "conv3x3_wino: unknown kernel variant %d", variant);
   }
@@ -993,6 +1019,7 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   if (!src0 || !dz || !dw || !ws || n <= 0 || c0 <= 0 || c1 < 0 || cout <= 0 || h <= 0 || w <= 0) TNV3_FAIL(-1, "conv3x3_wgrad: bad argument");
   if (variant < 0) variant = 0;
   if (variant > 1) TNV3_FAIL(-1, "conv3x3_wgrad: unknown kernel variant %d", variant);
+  if (variant == 1 && !kTwins) TNV3_FAIL(-1, "conv3x3_wgrad: kernel variant 1 (LDS-DMA staged: 8 %% slower) is a measurement twin of libtnv3_diag.so since ABI 6");
   if ((c1 > 0) != (src1 != nullptr)) TNV3_FAIL(-1, "conv3x3_wgrad: src1 / c1 mismatch");
   if (up0 && ((h | w) & 1)) TNV3_FAIL(-1, "conv3x3_wgrad: upsampled source needs even H,W");
   if (w % 4) TNV3_FAIL(-1, "conv3x3_wgrad: W must be a multiple of 4 (16-byte dZ loads)");
@@ -1009,10 +1036,13 @@ int conv3x3_wgrad_impl(Launcher& L, const float* src0, const float* src1, const 
   WgradArgs a{src0, src1, dz, slabs, n, c0, c1, cout, h, w, up0 ? 1 : 0, p.splitK, (const float*)ws, 0, 0};
   const int grid = p.nMB * p.nCB * p.splitK;
   int rc;
+#ifdef TNV3_DIAG
   if (variant == 1) {
     if ((rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
     rc = p.use_b ? L.launch(wgrad3x3_dma_kernel<WgradDmaB>, grid, WgradDmaB::NT, a) : L.launch(wgrad3x3_dma_kernel<WgradDmaA>, grid, WgradDmaA::NT, a);
-  } else {
+  } else
+#endif
+  {
     rc = p.use_b ? L.launch(wgrad3x3_mfma_kernel<WgradB>, grid, WgradB::NT, a) : L.launch(wgrad3x3_mfma_kernel<WgradA>, grid, WgradA::NT, a);
   }
   if (rc) return rc;
@@ -1075,14 +1105,38 @@ int conv_up2x_wino_forward_impl(Launcher& L, const float* src, const float* u, f
   return L.launch(conv_up2x_wino_stream_kernel, wino_persistent_grid(conv_grid_blocks(cout / ConvUp2xWinoCfg::MB, (int)npt)), ConvUp2xWinoCfg::NT, a);
 }
 
-// ---- data gradient of the upsampled half at the low resolution as one GEMM with K = 9 * Cout (kernels/dgrad_up2x_wino_mfma.h)
-inline bool dgrad_up2x_wino_supported(int c0, int cout, int hl, int wl) {
-  return c0 > 0 && c0 % DgradUp2xWinoCfg::MB == 0 && cout > DgradUp2xWinoCfg::CC && hl > 0 && wl > 0 && hl % 2 == 0 && wl % DgradUp2xWinoCfg::TWL == 0 &&
+// ---- data gradient of the upsampled half at the low resolution as one GEMM with K = 9 * Cout (kernels/dgrad_up2x_wino_mfma.h; variant -1 / 0 / 1)
+//      or in the 25-of-36 F(4x4) form on the 16x16x4 kernel (kernels/conv3x3_wino43s_mfma.h, MODE 2; variant 2: its own panel)
+inline bool dgrad_up2x_wino_supported(int c0, int cout, int hl, int wl, int variant = -1) {
+  if (variant == 2)
+    return c0 > 0 && c0 % 64 == 0 && cout > 0 && hl > 0 && wl > 0 && hl % 2 == 0 && wl % 32 == 0 && (long)cout * 4 * hl * wl * 4 < (1l << 31) &&
+           (long)64 * hl * wl * 4 < (1l << 31) && dgrad_up2x_wino43_packed_floats(c0, cout) * 4 < (1ul << 31);
+  return variant <= 1 && c0 > 0 && c0 % DgradUp2xWinoCfg::MB == 0 && cout > DgradUp2xWinoCfg::CC && hl > 0 && wl > 0 && hl % 2 == 0 && wl % DgradUp2xWinoCfg::TWL == 0 &&
          (long)DgradUp2xWinoCfg::CC * 4 * hl * wl * 4 < (1l << 31) && (long)72 * c0 * 4 < (1l << 31);
 }
-inline size_t dgrad_up2x_wino_packed_floats(int c0, int cout) {
+inline size_t dgrad_up2x_wino_packed_floats(int c0, int cout, int variant = -1) {
   if (c0 <= 0 || cout <= 0) return 0;
+  if (variant == 2) return dgrad_up2x_wino43_packed_floats(c0, cout);
   return (size_t)round_up(cout, DgradUp2xWinoCfg::CC) * 9 * c0 + kPackZeroTail;
+}
+// variant 2's launches (instantiated by the Winograd F(4x4) translation unit only, as the forward's)
+template <class Launcher>
+int dgrad_up2x_wino43_pack_launch(Launcher& L, const float* w, float* u, int cout, int cin, int c0) {
+  if (c0 % 16 || (((uintptr_t)u) & 15)) TNV3_FAIL(-1, "dgrad_up2x_wino_pack: variant 2 needs C0 %% 16 == 0 and a 16-byte aligned panel");
+  const long items = dgrad_up2x_wino43_pack_items(cout, c0);
+  return L.launch(dgrad_up2x_wino43_pack_kernel, (int)((items + 255) / 256 > 65535 ? 65535 : (items + 255) / 256), 256, w, u, cout, cin, c0);
+}
+template <class Launcher>
+int dgrad_up2x_wino43_launch(Launcher& L, const float* dz, const float* u, float* dst, int n, int c0, int cout, int hl, int wl) {
+  if ((((uintptr_t)dst) & 7) || (((uintptr_t)u) & 15) || (((uintptr_t)dz) & 3)) TNV3_FAIL(-1, "dgrad_up2x_wino: misaligned pointer");
+  // the kernel's "input" is dZ (cout channels at the full resolution), its "output channels" are the layer's c0 upsampled input channels
+  WinoArgs a{dz, u, u, nullptr, nullptr, nullptr, nullptr, dst, n, cout, c0, 2 * hl, 2 * wl, 0, nullptr, nullptr, nullptr, nullptr};
+  const bool wide = c0 % 128 == 0;
+  const long npt = wide ? (long)n * (hl / 2) * (wl / 32) : (long)n * ((hl + 3) / 4) * (wl / 32);
+  if (npt > (1l << 28)) TNV3_FAIL(-1, "dgrad_up2x_wino: too many tiles");
+  const int grid = wino_persistent_grid(conv_grid_blocks(c0 / (wide ? 128 : 64), (int)npt));
+  if (wide) return L.launch(conv3x3_wino43s_kernel<8, 0, kWino43UGrow, kWino43UTs, 0, 0, 0, 2>, grid, Wino43SBase::NT, a);
+  return L.launch(conv3x3_wino43s_kernel<4, 0, kWino43UGrow, kWino43UTs, 0, 0, 0, 2>, grid, Wino43SBase::NT, a);
 }
 template <class Launcher>
 int dgrad_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, int cin, int c0) {
@@ -1094,7 +1148,7 @@ int dgrad_up2x_wino_pack_impl(Launcher& L, const float* w, float* u, int cout, i
 template <class Launcher>
 int dgrad_up2x_wino_impl(Launcher& L, const float* dz, const float* u, float* dst, int n, int c0, int cout, int hl, int wl, int variant = -1) {
   if (!dz || !u || !dst || n <= 0 || variant > 1) TNV3_FAIL(-1, "dgrad_up2x_wino: bad argument");
-  if (!dgrad_up2x_wino_supported(c0, cout, hl, wl))
+  if (!dgrad_up2x_wino_supported(c0, cout, hl, wl, variant))
     TNV3_FAIL(-1, "dgrad_up2x_wino: needs C0 %% 128 == 0, Cout > 8, H_low %% 2 == 0, W_low %% 32 == 0 (got %d <- %d, %dx%d)", c0, cout, hl, wl);
   if ((((uintptr_t)u | (uintptr_t)dz) & 15) || (((uintptr_t)dst) & 3)) TNV3_FAIL(-1, "dgrad_up2x_wino: misaligned pointer");
   DgradUp2xWinoArgs a{dz, u, dst, n, c0, cout, hl, wl, variant == 1 ? 1 : 0};
@@ -1175,8 +1229,8 @@ int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
   const int grid = (a.Cout / 64) * ((a.Cin + 63) / 64) * a.splitK;
   variant = wgrad_wino_pick(a.Cin, variant);
 #ifndef TNV3_DIAG
-  if (variant == 0 || variant == 3 || variant == 4 || variant == 6 || variant == 7)
-    TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variant %d is a measurement twin of libtnv3_diag.so since ABI 5 (dispatchable: 1, 2, 5, 8)", variant);
+  if (variant == 0 || variant == 2 || variant == 3 || variant == 4 || variant == 6 || variant == 7)
+    TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variant %d is a measurement twin of libtnv3_diag.so since ABI 5 / 6 (dispatchable: 1, 5, 8)", variant);
 #endif
   if (a.Cin % 64 && variant != 5 && variant != 6) TNV3_FAIL(-1, "conv3x3_wgrad_wino: kernel variants 1 and 2 need Cin %% 64 == 0 (got %d)", a.Cin);
 #ifdef TNV3_DIAG
@@ -1184,7 +1238,9 @@ int launch_wgrad_wino(Launcher& L, const WgradWinoArgs& a, int variant) {
 #endif
   if ((long)64 * a.H * a.W * 4 >= (1l << 31)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (variants 1-3): 64 channel planes must stay below 2 GiB");
   if (variant == 1) return L.launch(wgrad_wino2_mfma_kernel<0>, grid, WgradWino2Cfg::NT, a);
+#ifdef TNV3_DIAG
   if (variant == 2) return L.launch(wgrad_wino3_mfma_kernel<WgradWino3Cfg<2>>, grid, 512, a);
+#endif
   if (variant == 5) return L.launch(wgrad_wino5_mfma_kernel<WgradWino5Cfg<3>>, grid, 512, a);
 #ifdef TNV3_DIAG      // measured and rejected generations: A/B twins in libtnv3_diag.so only since ABI 5
   if (variant == 7) return L.launch(wgrad_wino2_mfma_kernel<1>, grid, WgradWino2Cfg::NT, a);     // 1 + the Yh transform in the MFMA phase

@@ -156,13 +156,15 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
-    def packed_dgrad_up2x_wino(self, c0):
-        """U'' of the first c0 (upsampled) input channels for the one-GEMM low-resolution data gradient (ops.dgrad_up2x_wino)."""
-        key = ("dup2xw", int(c0))
+    def packed_dgrad_up2x_wino(self, c0, variant=None):
+        """U'' of the first c0 (upsampled) input channels for the low-resolution data gradient (ops.dgrad_up2x_wino; the panel follows the
+        kernel variant)."""
+        v = 2 if ops.dgrad_up2x_wino_variant(variant) == 2 else 0
+        key = ("dup2xw", int(c0), v)
         ver = self._versions(["conv"])
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, ops.pack_dgrad_up2x_wino_weights(self.conv.weight.detach(), c0))
+            hit = (ver, ops.pack_dgrad_up2x_wino_weights(self.conv.weight.detach(), c0, variant=v))
             self._cache[key] = hit
         return hit[1]
 

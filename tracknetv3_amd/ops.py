@@ -111,8 +111,8 @@ def wino43_supported(cin, cout, h, w):
 
 def wino43_variant(variant=None):
     """Kernel variant of the F(4x4, 3x3) entries (None: tuning.WINO43_VARIANT): 0 = 16x16x4 MFMAs, all 36 transform coefficients of a block in
-    one wave (128-channel workgroups where Cout % 128 == 0), 2 = the same with 64-channel workgroups always; 1 = the 32x32x2 kernel.  0 and 2
-    read one panel layout, 1 another: pack and run a panel with the same variant."""
+    one wave (128-channel workgroups where Cout % 128 == 0), 2 = the same with 64-channel workgroups always; both read one panel layout.
+    (1, the 32x32x2 predecessor with its own layout, is dispatched by the diagnostics library only since ABI 6.)"""
     from . import tuning
     return int(tuning.WINO43_VARIANT if variant is None else variant)
 
@@ -219,8 +219,8 @@ def pack_wino_weights_multi(specs, variant=None):
 
 def conv3x3_wino(src, u, cout, mean=None, scale=None, shift=None, relu=False, addend=None, variant=None):
     """The plain eval-mode layer in Winograd F(2x2, 3x3) form (tnv3_conv3x3_wino_forward).  variant: kernel family for THIS
-    call (None: tuning.WINO_VARIANT, -1 = the library's default = 5, the streaming persistent kernel; 3 balanced, 4 quad layouts,
-    2 xi-split, 0 one wave per SIMD)."""
+    call (None: tuning.WINO_VARIANT; -1 = the library's pick: 6, the 128-channel form, where Cout % 128 == 0, else 5, the streaming persistent
+    kernel.  The earlier generations 0 / 2 / 3 / 4 / 7 are measurement twins of the diagnostics library)."""
     lib = _lib.load()
     _f32(src, u, mean, scale, shift, addend)
     _lib.dev_check(src, u, mean, scale, shift, addend)
@@ -326,33 +326,44 @@ def conv_up2x_wino(src_low, u, cout, variant=None):
     return out
 
 
-def dgrad_up2x_wino_supported(c0, cout, hl, wl):
-    return bool(_lib.load().tnv3_dgrad_up2x_wino_supported(int(c0), int(cout), int(hl), int(wl)))
+def dgrad_up2x_wino_variant(variant=None):
+    """Kernel of the upsampled half's data gradient (None: tuning.DGRAD_UP2X_WINO_VARIANT): 0 / 1 the one-GEMM F(2x2) kernel (K = 9 * Cout),
+    2 the 25-product F(4x4) form on the 16x16x4 kernel (MODE 2 of kernels/conv3x3_wino43s_mfma.h; its own panel)."""
+    from . import tuning
+    v = int(tuning.DGRAD_UP2X_WINO_VARIANT if variant is None else variant)
+    return 0 if v < 0 else v
 
 
-def pack_dgrad_up2x_wino_weights(weight, c0):
-    """U'' of the first c0 (upsampled) input channels for the one-GEMM data gradient (tnv3_dgrad_up2x_wino_pack)."""
+def dgrad_up2x_wino_supported(c0, cout, hl, wl, variant=None):
+    return bool(_lib.load().tnv3_dgrad_up2x_wino_supported(int(c0), int(cout), int(hl), int(wl), dgrad_up2x_wino_variant(variant)))
+
+
+def pack_dgrad_up2x_wino_weights(weight, c0, variant=None):
+    """U'' of the first c0 (upsampled) input channels for the low-resolution data gradient (tnv3_dgrad_up2x_wino_pack); the panel follows
+    the kernel variant."""
     lib = _lib.load()
     _f32(weight)
     _lib.dev_check(weight)
+    v = 2 if dgrad_up2x_wino_variant(variant) == 2 else 0
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
-    u = torch.empty(lib.tnv3_dgrad_up2x_wino_packed_floats(int(c0), cout), dtype=torch.float32, device=weight.device)
-    _lib.check(lib.tnv3_dgrad_up2x_wino_pack(_lib.ptr(weight), _lib.ptr(u), cout, cin, int(c0), _lib.stream_ptr(weight)))
+    u = torch.empty(lib.tnv3_dgrad_up2x_wino_packed_floats(int(c0), cout, v), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.tnv3_dgrad_up2x_wino_pack(_lib.ptr(weight), _lib.ptr(u), cout, cin, int(c0), v, _lib.stream_ptr(weight)))
     return u
 
 
-def dgrad_up2x_wino(dz, u, c0, variant=-1):
-    """Gradient w.r.t. the low-res operand of nn.Upsample(2) -> conv3x3 as one GEMM with K = 9 * Cout (tnv3_dgrad_up2x_wino).
-    variant: as conv_up2x_wino's."""
+def dgrad_up2x_wino(dz, u, c0, variant=None):
+    """Gradient w.r.t. the low-res operand of nn.Upsample(2) -> conv3x3 at the low resolution (tnv3_dgrad_up2x_wino): variant 0 / 1 as one
+    GEMM with K = 9 * Cout, 2 in the 25-of-36 F(4x4) form; `u` must be the panel packed for that variant."""
     lib = _lib.load()
     _f32(dz, u)
     _lib.dev_check(dz, u)
-    n, cout, h, w = (int(v) for v in dz.shape)
-    if (h | w) & 1 or u.numel() != lib.tnv3_dgrad_up2x_wino_packed_floats(int(c0), cout):
-        raise _lib.Tnv3Error("dgrad_up2x_wino: odd output size or filter buffer / channel mismatch")
+    v = dgrad_up2x_wino_variant(variant)
+    n, cout, h, w = (int(v_) for v_ in dz.shape)
+    if (h | w) & 1 or u.numel() != lib.tnv3_dgrad_up2x_wino_packed_floats(int(c0), cout, 2 if v == 2 else 0):
+        raise _lib.Tnv3Error("dgrad_up2x_wino: odd output size or filter buffer / channel mismatch (a panel of the other variant?)")
     out = torch.empty((n, int(c0), h // 2, w // 2), dtype=torch.float32, device=dz.device)
     if n:
-        _lib.check(lib.tnv3_dgrad_up2x_wino(_lib.ptr(dz), _lib.ptr(u), _lib.ptr(out), n, int(c0), cout, h // 2, w // 2, int(variant), _lib.stream_ptr(dz)))
+        _lib.check(lib.tnv3_dgrad_up2x_wino(_lib.ptr(dz), _lib.ptr(u), _lib.ptr(out), n, int(c0), cout, h // 2, w // 2, v, _lib.stream_ptr(dz)))
     return out
 
 
@@ -731,7 +742,8 @@ def conv3x3_dgrad(dz, wpack_t, c0, c1=0, cfg=-1):
 
 def conv3x3_wgrad(src0, dz, src1=None, up0=False, variant=None, out=None):
     """dW[Cout][C0+C1][3][3] for X = cat([up2x?(src0), src1], 1).  variant: kernel family for THIS call (None:
-    tuning.WGRAD_VARIANT; 0 register-staged, 1 LDS-DMA staged).  out: where dW is written (see _grad_out)."""
+    tuning.WGRAD_VARIANT; 0 = the register-staged kernel -- the LDS-DMA staged twin 1 is in the diagnostics library).  out: where dW is written
+    (see _grad_out)."""
     lib = _lib.load()
     _f32(src0, src1, dz)
     _lib.dev_check(src0, src1, dz)
@@ -764,9 +776,9 @@ def _wgrad_wino_variant(variant, h=0):
 
 def conv3x3_wgrad_wino(x, dz, variant=None, out=None):
     """dW[Cout][Cin][3][3] of a plain layer in Winograd form -- see tnv3_conv3x3_wgrad_wino.  variant: kernel for THIS
-    call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's default = 1, or 5 when Cin % 64 != 0; 1-4 the role-split generations;
-    5 / 6 every wave streams and transforms; 0 the first kernel -- all F(2x2, 3x3), bit-identical; 8: the F(4x4, 3x3) kernel,
-    H % 4 == 0, any Cin)."""
+    call (None: tuning.WGRAD_WINO_VARIANT; -1 the library's pick: 8, the F(4x4, 3x3) kernel (H % 4 == 0, any Cin), else the F(2x2) kernels
+    1 (role-split) or, when Cin % 64 != 0, 5 (every wave streams and transforms) -- 1 and 5 bit-identical.  0 / 2 / 3 / 4 / 6 / 7: twins of
+    the diagnostics library)."""
     lib = _lib.load()
     _f32(x, dz)
     _lib.dev_check(x, dz)
@@ -781,7 +793,7 @@ def conv3x3_wgrad_wino(x, dz, variant=None, out=None):
     return dw
 
 
-_WGRAD_UP2X_OF_PLAIN = {-1: -1, 1: 2, 2: 2, 5: 5, 8: 8}      # tuning.WGRAD_WINO_VARIANT -> tnv3_conv3x3_wgrad_up2x's own numbering
+_WGRAD_UP2X_OF_PLAIN = {-1: -1, 1: 2, 2: 2, 5: 5, 8: 8}      # tuning.WGRAD_WINO_VARIANT -> tnv3_conv3x3_wgrad_up2x's own numbering (2: the diag twin of 1)
 
 
 def conv3x3_wgrad_up2x(x_low, skip, dz, wino_variant=None, out=None, up_variant=None):

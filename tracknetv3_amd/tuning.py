@@ -32,6 +32,15 @@ def save(configs, meta=None):
     _table = None
 
 
+def _choice(name, default, allowed, what):
+    """An integer kernel-variant knob from the environment, checked HERE against what the product library dispatches (ABI 6): a stale
+    value used to surface as 'unknown kernel variant' from inside the first launch, mid-forward or mid-backward."""
+    v = int(os.environ.get(name, str(default)))
+    if v not in allowed:
+        raise ValueError(f"{name}={v}: {what} dispatches {sorted(allowed)} (the measured-and-rejected generations live in the diagnostics library; the scripts/ loader)")
+    return v
+
+
 # Eval-mode plain layers run in Winograd F(2x2, 3x3) form when the shape qualifies (ops.wino_supported) and the
 # contraction is deep enough for the transforms to pay: measured on MI355X at batch 10 (scripts/wino_sweep.py) it wins
 # 1.3-1.5x on every 64..512-channel layer and 1.2x on the 27-channel stem; thinner inputs stay on the direct kernel.
@@ -48,10 +57,10 @@ WINOGRAD_MIN_SKIP = int(os.environ.get("TNV3_WINO_MIN_SKIP", "64"))     # skip h
 # within 1.7e-6 of the fp64 forward, the direct fp32 forward's level: profiles/r03_wino_f43_precision.json).  TNV3_WINO43=0: F(2x2) everywhere.
 WINO43 = os.environ.get("TNV3_WINO43", "1") != "0"
 WINO43_MIN_CIN = int(os.environ.get("TNV3_WINO43_MIN_CIN", "16"))
-# Which F(4x4) kernel: 0 = kernels/conv3x3_wino43s_mfma.h (16x16x4 MFMAs, all 36 transform coefficients of a block in one wave, one wave per
-# SIMD, the output transform in registers), 1 = its predecessor kernels/conv3x3_wino43_mfma.h (32x32x2; four waves per block exchange through
-# LDS).  Read when a panel is packed and when it is run: do not change it between the two.
-WINO43_VARIANT = int(os.environ.get("TNV3_WINO43_VARIANT", "0"))
+# Which geometry of the F(4x4) kernel (kernels/conv3x3_wino43s_mfma.h: 16x16x4 MFMAs, all 36 transform coefficients of a block in one wave, the
+# output transform in registers): 0 = 128 output channels x one tile row where Cout % 128 == 0, else 64 x two tile rows; 2 = the 64-channel
+# geometry always.  (1, the 32x32x2 predecessor kernels/conv3x3_wino43_mfma.h, is a twin of the diagnostics library since ABI 6.)
+WINO43_VARIANT = _choice("TNV3_WINO43_VARIANT", 0, {0, 2}, "tnv3_conv3x3_wino43_forward")
 # MaxPool2d(2, 2) behind the down blocks' last layers as a second output of the F(4x4) kernel's write-out (variants 0 / 2; bit-identical to the
 # separate pass).  TNV3_FUSE_POOL=0: the separate maxpool2x2 launches.
 FUSE_POOL = os.environ.get("TNV3_FUSE_POOL", "1") != "0"
@@ -100,12 +109,12 @@ WINOGRAD_WGRAD_MIN_CIN = int(os.environ.get("TNV3_WINO_WGRAD_MIN_CIN", "1"))    
 
 
 def use_winograd_wgrad(cin, cout, h, w):
-    """Kernels 5 / 6 (what -1 picks when Cin % 64 != 0) take any Cin -- a partial block of 64 input channels: the stem layer (Cin = 27)
+    """Kernels 5 / 8 (what -1 picks when Cin % 64 != 0) take any Cin -- a partial block of 64 input channels: the stem layer (Cin = 27)
     costs a 64-channel layer's 0.55 ms instead of the direct kernel's 0.96 ms, 0.36 ms of the step --; the older generations need
     64-multiples on both sides."""
     if not WINOGRAD or cout < WINOGRAD_WGRAD_MIN_CH:
         return False
-    if cin % 64 and (WGRAD_WINO_VARIANT not in (-1, 5, 6, 8) or cin < WINOGRAD_WGRAD_MIN_CIN):
+    if cin % 64 and (WGRAD_WINO_VARIANT not in (-1, 5, 8) or cin < WINOGRAD_WGRAD_MIN_CIN):
         return False
     from . import ops
     return ops.wgrad_wino_supported(cin, cout, h, w)
@@ -133,21 +142,28 @@ WGRAD_STREAM_PRIORITY = int(os.environ.get("TNV3_WGRAD_STREAM_PRIORITY", "0"))
 # defaults the Python layer passes.  -1 = the library's default, resolved INSIDE the library (kWinoDefaultVariant: today 5, the
 # streaming persistent Winograd kernel; register-staged weight gradient) -- layout and capabilities of "-1" are queried from it
 # (tnv3_conv3x3_wino_layout / tnv3_conv3x3_wino_has_stats), never assumed here.
-WINO_VARIANT = int(os.environ.get("TNV3_WINO_VARIANT", "-1"))      # 5 streaming persistent (default), 3 balanced, 4 quad layouts, 2 xi-split, 0 one wave per SIMD
-WGRAD_VARIANT = int(os.environ.get("TNV3_WGRAD_VARIANT", "0"))     # 1: LDS-DMA staged kernels (parity-green, 8 % slower)
+# F(2x2) forward / data-gradient kernel (what runs where F(4x4) does not apply): -1 = the library's pick -- 6, the 128-channel form, where
+# Cout % 128 == 0, else 5, the streaming persistent kernel.
+WINO_VARIANT = _choice("TNV3_WINO_VARIANT", -1, {-1, 5, 6}, "tnv3_conv3x3_wino_forward")
+WGRAD_VARIANT = _choice("TNV3_WGRAD_VARIANT", 0, {0}, "tnv3_conv3x3_wgrad")      # the register-staged direct kernel (the LDS-DMA twin: the diagnostics library)
 # Winograd-form weight gradient of the plain layers (and the skip half of the decoder-entry layers): -1 = the library's pick -- the
 # F(4x4) kernel (8) where H % 4 == 0, else F(2x2) kernel 1 (5 for the stem); 8 the F(4x4) kernel (other heights fall back to -1);
-# 1-4 the role-split F(2x2) generations, 5 / 6 every wave streams and transforms, 0 the first kernel.
+# 1 the role-split F(2x2) kernel, 5 the one where every wave streams and transforms (any Cin).
 # Measured per call at batch 10 (profiles/r04_wgrad_wino43_ab.json): 8 is 1.45-1.51x faster than 1 on every plain shape (0.396 vs
 # 0.598 ms at 64 -> 64 @ 288x512), 2.56x on the stem (0.237 vs 0.605 ms: blocks of 32 input channels instead of 64); the training step
 # 26.11 -> 23.59 ms.  Its gradient is 2-4e-6 (max) / 3-6e-7 (rms) of max|dW| from the F(2x2) one.
-WGRAD_WINO_VARIANT = int(os.environ.get("TNV3_WGRAD_WINO_VARIANT", "-1"))
+WGRAD_WINO_VARIANT = _choice("TNV3_WGRAD_WINO_VARIANT", -1, {-1, 1, 5, 8}, "tnv3_conv3x3_wgrad_wino")
+
+
+# Data gradient of the decoder entries' upsampled halves: 2 = the 25-of-36 F(4x4) form on the 16x16x4 kernel (kernels/conv3x3_wino43s_mfma.h
+# MODE 2, round 5: 6.25 multiply-adds per low-resolution pixel; c0 % 64 == 0, else the next), 0 = the one-GEMM F(2x2) kernel (9; c0 % 128 == 0).
+DGRAD_UP2X_WINO_VARIANT = _choice("TNV3_DGRAD_UP2X_WINO_VARIANT", 2, {-1, 0, 1, 2}, "tnv3_dgrad_up2x_wino")
 
 
 # Weight gradient of the decoder entries' upsampled halves: -1 = the fastest form the shape allows -- 2, the 25-of-36 F(4x4) form
 # (kernels/wgrad_up2x_wino43_mfma.h, round 5: 6.25 multiply-adds per low-resolution pixel, any c0), else 1, the 9-GEMM F(2x2) form
 # (9; c0 % 128 == 0), else 0, four 2x2-window launches (16).  The weight gradient is a leaf: nothing amplifies its rounding.
-WGRAD_UP2X_VARIANT = int(os.environ.get("TNV3_WGRAD_UP2X_VARIANT", "-1"))
+WGRAD_UP2X_VARIANT = _choice("TNV3_WGRAD_UP2X_VARIANT", -1, {-1, 0, 1, 2}, "tnv3_conv3x3_wgrad_up2x (up_variant)")
 
 
 # Training: all Winograd filter panels that the optimiser step made stale are rebuilt by one launch at the start of the forward
@@ -185,8 +201,8 @@ UP2X_WINO = os.environ.get("TNV3_UP2X_WINO", "1") != "0"
 # ... and which Winograd form: 0 = 9 of the 16 F(2x2) GEMMs (kernels/conv_up2x_wino_mfma.h), 2 = 25 of the 36 F(4x4) products on the 16x16x4
 # kernel (kernels/conv3x3_wino43s_mfma.h MODE 1: Lavin's points, 1-5e-6 of the output scale from fp64 -- an addend of the skip half's launch).
 # The eval forward and the training forward choose separately (batch-statistics BatchNorm amplifies the forward's rounding).
-UP2X_WINO_VARIANT = int(os.environ.get("TNV3_UP2X_WINO_VARIANT", "2"))
-UP2X_WINO_VARIANT_TRAIN = int(os.environ.get("TNV3_UP2X_WINO_VARIANT_TRAIN", "0"))
+UP2X_WINO_VARIANT = _choice("TNV3_UP2X_WINO_VARIANT", 2, {-1, 0, 1, 2}, "tnv3_conv_up2x_wino_forward")
+UP2X_WINO_VARIANT_TRAIN = _choice("TNV3_UP2X_WINO_VARIANT_TRAIN", 0, {-1, 0, 1, 2}, "tnv3_conv_up2x_wino_forward")
 
 
 # BatchNorm + ReLU backward: the two per-channel sums of block L (sum g, sum g * xhat) taken in the epilogue of the Winograd data-gradient
