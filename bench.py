@@ -410,9 +410,11 @@ def bench_train(args, dev, rank, world):
 # ---- control plane of an N > 1 run.  The bench's OWN barriers and reductions of timings go through a gloo group (host tensors): they are
 #      measurement plumbing and must not depend on the transport under test.  RCCL is used where the product uses it -- the gradient
 #      all-reduce of the training step (tracknetv3_amd/parallel.py) -- after one watched first contact: if communicator set-up or the
-#      first all-reduce does not finish in RCCL_WATCHDOG_S seconds, the rank reports who hung (rank, device, NCCL_DEBUG tail), the training
-#      leg becomes {"error": ...}, the inference leg (no collective in its data path) is still measured, and the process leaves through
-#      os._exit (a thread stuck inside the communicator cannot be joined).  HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) is set for every
+#      first all-reduce does not finish in RCCL_WATCHDOG_S seconds, every rank reports who hung (rank, device, NCCL_DEBUG tail), rank 0 prints
+#      an {"error": ...} line and all ranks leave through os._exit at once -- WITHOUT synchronising the device, on which the hung collective's
+#      kernel may still spin (a later torch.cuda.synchronize would block until the process-group timeout).  A first contact that FAILS
+#      without hanging (an exception, a wrong sum) only turns the training leg into {"error": ...}; the inference leg (no collective in its
+#      data path) is still measured.  HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) is set for every
 #      rank: this host driver has no legacy IPC handles, and RCCL's intra-node transport fails without it (hipIpcGetMemHandle: invalid argument).
 RCCL_WATCHDOG_S = float(os.environ.get("TNV3_RCCL_WATCHDOG_S", "60"))
 _CTL = {"group": None, "rccl": None}
@@ -476,9 +478,9 @@ def rccl_first_contact(dev, rank, world, backend):
         res = {"ok": False, "error": f"no answer from the first {backend} all-reduce within {RCCL_WATCHDOG_S:.0f} s (communicator set-up or the collective hangs)",
                "hung": True}
     mine = 1.0 if res.get("ok") else 0.0
-    flags = torch.tensor([mine], dtype=torch.float64)
+    flags = torch.tensor([mine, 0.0 if res.get("hung") else 1.0], dtype=torch.float64)      # (ok, not hung) -- MIN over ranks, over the gloo control group
     dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=_CTL["group"])
-    out = {"ok": bool(flags.item() > 0.5), "backend": backend, "watchdog_s": RCCL_WATCHDOG_S}
+    out = {"ok": bool(flags[0].item() > 0.5), "backend": backend, "watchdog_s": RCCL_WATCHDOG_S, "any_hung": bool(flags[1].item() < 0.5)}
     if res.get("ok"):
         out["first_allreduce_ms"] = round(res["ms"], 2)
     if not out["ok"]:
@@ -662,6 +664,18 @@ def main():
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
         _CTL["group"] = dist.new_group(backend="gloo")       # the bench's own barriers / reductions: never the transport under test
         _CTL["rccl"] = rccl_first_contact(dev, rank, world, args.backend)
+        if not _CTL["rccl"]["ok"] and _CTL["rccl"].get("any_hung"):
+            # A collective that HANGS may have left a kernel spinning on this rank's device: every later torch.cuda.synchronize(dev) -- the
+            # barriers of the inference leg -- would block behind it until the process-group timeout kills the job.  Report now and leave:
+            # no device synchronisation, no teardown (a thread still sits inside the communicator).
+            if rank == 0:
+                print(json.dumps({"metric": "frames/sec (288x512, seq_len=8) TrackNet inference", "value": None, "unit": "frames/s", "n_gpus": world,
+                                  "error": "RCCL first contact hung: " + str(_CTL["rccl"].get("error")), "rccl": _CTL["rccl"],
+                                  "note": "nothing was measured: a hung collective can hold the device, so the ranks leave without synchronising it; "
+                                          "`python bench.py --gpus 1` measures the single-GPU legs"}), flush=True)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(3)
     n_gpus = world
 
     from tracknetv3_amd import _lib, ops

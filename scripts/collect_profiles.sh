@@ -2,7 +2,7 @@
 # Copies the summaries of the last scripts/gpu_session.sh evidence session (PARTS="host smoke pytest infer train ab fixed decoder profinfer proftrain pmc sq") from gpurun_out/ (scratch) into profiles/ (tracked).
 set -u
 cd "$(dirname "$0")/.."
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 O=gpurun_out
 P=profiles
 cp $O/bench.json $P/${R}_bench_n1.json
@@ -25,5 +25,11 @@ python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/co
 for f in wino43_variant_ab up2x_wino43_ab wino43s_timeline wgrad_wino43_ab; do fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
 for f in fullsize_train_parity_n2_f43fwd fullsize_train_parity_n2_f22fwd fullsize_train_parity_n10_default; do fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
 [ -f $O/infer_sq_summary.json ] && cp $O/infer_sq_summary.json $P/${R}_infer_sq_summary.json
+# round 5: the training step's counters (one stream), its stand-alone kernel times, the precision sweep and channel-plan tables, the new A/Bs
+fresh $O/train_sq_summary.json && cp $O/train_sq_summary.json $P/${R}_train_sq_summary.json
+for f in sq1 sq2 sq3 tcc fetch write; do fresh $O/pmc_train_$f.csv && cp $O/pmc_train_$f.csv $P/${R}_train_pmc_$f.csv; done
+fresh $O/prof_train1_kernel_stats.csv && cp $O/prof_train1_kernel_stats.csv $P/${R}_train_one_stream_kernel_stats.csv
+for f in precision_sweep_eval precision_sweep_train channel_plan_9to3 channel_plan_24to8 channel_plan_8to8 channel_plan_32to8 wgrad_up2x_wino43_ab dgrad_up2x_wino43_ab; do
+  fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
 cp $O/session.log $P/${R}_session_final.log
 echo "profiles/ refreshed from $O"

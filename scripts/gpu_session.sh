@@ -15,6 +15,8 @@
 #   proftrain rocprofv3 --kernel-trace --stats of the training bench
 #   pmc       FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only)
 #   sq        SQ / TCC counter passes (scripts/gpu_pmc_sq.sh)
+#   sqtrain   the same of the TRAINING step on one stream, plus FETCH_SIZE / WRITE_SIZE (-> train_sq_summary.json)
+#   proftrain1 rocprofv3 --kernel-trace --stats of the training bench on ONE stream (TNV3_WGRAD_OVERLAP=0: stand-alone kernel times)
 # Everything that must come back is written under gpurun_out/; scripts/collect_profiles.sh copies the summaries to profiles/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -62,13 +64,16 @@ if has profinfer; then echo "== rocprofv3 kernel trace (infer)" | tee -a $LOG
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_infer -o trace -- python $REPO/bench.py --steps 5 --warmup 2 --blocks 1 --no-cpu-baseline --overlap-streams 0 --infer-split 0 --train-steps 0 --extras 0 --layers-out $OUT/prof_infer_layers.json > $OUT/prof_infer.json 2> $OUT/prof_infer.err; echo "rocprof infer rc=$?" | tee -a $LOG; fi
 if has proftrain; then echo "== rocprofv3 kernel trace (train)" | tee -a $LOG
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_train -o trace -- python $REPO/bench.py --mode train --steps 3 --warmup 1 --strong-steps 0 --no-cpu-baseline > $OUT/prof_train.json 2> $OUT/prof_train.err; echo "rocprof train rc=$?" | tee -a $LOG; fi
+if has proftrain1; then echo "== rocprofv3 kernel trace (train, one stream)" | tee -a $LOG
+  TNV3_WGRAD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_train1 -o trace -- python $REPO/bench.py --mode train --steps 3 --warmup 1 --strong-steps 0 --no-cpu-baseline > $OUT/prof_train1.json 2> $OUT/prof_train1.err; echo "rocprof train (one stream) rc=$?" | tee -a $LOG; fi
 if has pmc; then echo "== rocprofv3 PMC passes (separate runs; counters only with --kernel-trace)" | tee -a $LOG
   for c in FETCH_SIZE WRITE_SIZE; do n=$(echo $c | cut -d_ -f1 | tr A-Z a-z)
     timeout 600 rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$n -o pmc -- python $REPO/bench.py --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline --overlap-streams 0 --infer-split 0 --train-steps 0 --extras 0 --layers-out /tmp/pmc_layers.json > /dev/null 2> $OUT/pmc_$n.err; echo "pmc $n rc=$?" | tee -a $LOG; done; fi
 cd $REPO
-for d in prof_infer prof_train pmc_fetch pmc_write; do
+for d in prof_infer prof_train prof_train1 pmc_fetch pmc_write; do
   for f in $(find $OUT/$d -name "*.db" 2>/dev/null); do python scripts/rocpd_summary.py $f $OUT/${d}_kernel_stats.csv >> $LOG 2>&1; python scripts/rocpd_pmc.py $f $OUT/${d}_pmc.csv >> $LOG 2>&1; done
 done
 if has sq; then echo "== SQ / TCC counter passes" | tee -a $LOG; bash scripts/gpu_pmc_sq.sh 2>&1 | tail -20 | tee -a $LOG; fi
+if has sqtrain; then echo "== SQ / TCC / FETCH / WRITE counter passes of the training step (one stream)" | tee -a $LOG; SQ_MODE=train bash scripts/gpu_pmc_sq.sh 2>&1 | tail -24 | tee -a $LOG; fi
 find $OUT -name "*.db" -size +15M -delete
 echo "== done" | tee -a $LOG

@@ -767,3 +767,18 @@ def test_wino_helpers_refuse_the_unresolved_variant(emu):
     v = lib.tnv3_conv3x3_wino_pick(64, 128)
     assert v == 6 and lib.tnv3_conv3x3_wino_layout(v) == 2 and lib.tnv3_conv3x3_wino_has_stats(v) == 1
     assert lib.tnv3_conv3x3_wino_stats_tiles(2, 8, 64, v) == 2 * 2 * 2 and lib.tnv3_conv3x3_wino_stats_tiles(2, 8, 64, 5) == 2 * 2 * 1
+
+
+def test_wino43_takes_bn_constants_at_any_4_byte_offset(emu):
+    """mean / scale / shift of the eval forward may be views at odd offsets (a flattened parameter buffer, a sliced state tensor):
+    the 16x16x4 kernel reads them as per-lane scalars, only 4-byte alignment is needed.  Same bits as with aligned copies."""
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = 1, 16, 64, 8, 64
+    x, wt = torch.relu(T((n, cin, h, w), 491)), T((cout, cin, 3, 3), 492, -0.3, 0.3)
+    flat = T((3 * cout + 8,), 493, 0.5, 1.5)
+    mean, scale, shift = flat[1:1 + cout], flat[2 + cout:2 + 2 * cout], flat[5 + 2 * cout:5 + 3 * cout]
+    assert mean.data_ptr() % 16 and scale.data_ptr() % 16 and shift.data_ptr() % 16
+    u = ops.pack_wino43_weights(wt)
+    got = ops.conv3x3_wino43(x, u, cout, mean=mean, scale=scale, shift=shift, relu=True)
+    want = ops.conv3x3_wino43(x, u, cout, mean=mean.clone(), scale=scale.clone(), shift=shift.clone(), relu=True)
+    assert torch.equal(got, want)

@@ -185,7 +185,8 @@ def test_bench_first_contact_watchdog_reports_instead_of_hanging(hang_rank):
         mp.spawn(_watchdog_worker, args=(world, port, out, hang_rank), nprocs=world, join=True)
         r0, r1 = dict(out[0]), dict(out[1])
     if hang_rank < 0:
-        assert r0["ok"] and r1["ok"] and r0["first_allreduce_ms"] > 0
+        assert r0["ok"] and r1["ok"] and r0["first_allreduce_ms"] > 0 and not r0["any_hung"]
     else:
         assert not r0["ok"] and not r1["ok"]
         assert "within 2 s" in r0["error"] and r1["hung_here"] and r0["watchdog_s"] == 2.0
+        assert r0["any_hung"] and r1["any_hung"]           # every rank learns that SOMEONE hung: all of them leave without a device synchronise

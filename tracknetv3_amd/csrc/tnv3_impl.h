@@ -658,8 +658,12 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
   if ((scale == nullptr) != (shift == nullptr) || (mean && !scale)) TNV3_FAIL(-1, "conv3x3_wino43: inconsistent affine arguments");
   if ((long)cin * h * w * 4 >= (1l << 31) || (long)Wino43Cfg::MB * h * w * 4 >= (1l << 31))
     TNV3_FAIL(-1, "conv3x3_wino43: one sample of the input / 64 output planes must stay below 2 GiB");
-  if ((((uintptr_t)u | (uintptr_t)src | (uintptr_t)dst | (uintptr_t)addend | (uintptr_t)mean | (uintptr_t)scale | (uintptr_t)shift) & 15) != 0)
-    TNV3_FAIL(-1, "conv3x3_wino43: pointers must be 16-byte aligned");
+  if ((((uintptr_t)u | (uintptr_t)src | (uintptr_t)dst | (uintptr_t)addend) & 15) != 0)
+    TNV3_FAIL(-1, "conv3x3_wino43: the panel, the input, the output and the addend must be 16-byte aligned");
+  // (the 16x16x4 kernel reads mean / scale / shift as per-lane scalars: views at odd offsets of a flattened parameter buffer are fine;
+  //  the 32x32x2 twin reads them as float4)
+  if ((((uintptr_t)mean | (uintptr_t)scale | (uintptr_t)shift) & (variant == 1 ? 15 : 3)) != 0)
+    TNV3_FAIL(-1, "conv3x3_wino43: mean / scale / shift must be 4-byte aligned");
   if (conv3x3_wino43_packed_floats_v(cin, cout, variant) * 4 >= (1ul << 31)) TNV3_FAIL(-1, "conv3x3_wino43: the filter panel must stay below 2 GiB");
   WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, nullptr, nullptr, pool_dst};
   if (variant != 1) {
