@@ -21,7 +21,7 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INS
 run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
 run sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES GRBM_GUI_ACTIVE
 run tcc TCC_HIT_sum TCC_MISS_sum
-if [ "$MODE" = train ]; then run fetch FETCH_SIZE; run write WRITE_SIZE; fi
+if [ "$MODE" = train ] && [ "${SQ_TRAIN_TRAFFIC:-1}" = 1 ]; then run fetch FETCH_SIZE; run write WRITE_SIZE; fi
 cd $REPO
 LIST="sq1 sq2 sq3 tcc"; [ "$MODE" = train ] && LIST="$LIST fetch write"
 for d in $LIST; do for f in $(find $OUT/pmc_$PFX$d -name "*.db" 2>/dev/null); do python scripts/rocpd_pmc.py $f $OUT/pmc_$PFX${d}.csv; python scripts/rocpd_summary.py $f $OUT/pmc_$PFX${d}_kernel_stats.csv; done; [ -f $OUT/pmc_$PFX$d.err ] && tail -3 $OUT/pmc_$PFX$d.err; done
