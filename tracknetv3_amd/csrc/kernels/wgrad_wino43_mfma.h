@@ -11,12 +11,9 @@
 // Mapping (the 16x16x4 structure of conv3x3_wino43s_mfma.h).  MFMA 16x16x4: M = 16 output channels, N = 16 input channels, K = 4 tiles
 // (a strip of 4 x 16 pixels = one STEP); a wave keeps all 36 xi of its 16 x 16 block of S: 144 accumulator registers, two waves per
 // SIMD.  Workgroup = 64 co x 32 ci (waves = 4 co blocks x 2 ci blocks) x a contiguous share of the strips (split-K); 512 threads.
-//   * Both operands are transformed per step and meet in LDS as 16-byte quads of four CONSECUTIVE xi = 6 i + j (quad q = xi 4 q .. 4 q + 3;
-//     round 5 -- before, a quad mixed rows i' and i' + 3, so that the two row-half threads of a patch each wrote HALF of every V quad: 8-byte
-//     stores 16 bytes apart, a 2-way bank conflict on every one of them, 23 % of the kernel's LDS cycles in profiles/r05_train_sq_summary.json.
-//     Now a row half owns xi 0-17 / 18-35 = four whole quads and half of quad 4: five stores per thread instead of nine) -- in MFMA lane
-//     order (lane = tile * 16 + channel): one ds_read_b128 per operand and quad = four MFMAs; two stages (the transform of step sigma + 1
-//     runs between the MFMAs of step sigma).
+//   * Both operands are transformed per step and meet in LDS as 16-byte quads of four xi -- quad q = 3 i' + m holds xi = (i', 2 m),
+//     (i', 2 m + 1), (i' + 3, 2 m), (i' + 3, 2 m + 1) -- in MFMA lane order (lane = tile * 16 + channel): one ds_read_b128 per operand
+//     and quad = four MFMAs; two stages (the transform of step sigma + 1 runs between the MFMAs of step sigma).
 //   * Yh = A dY A^T: waves 0-3, thread = (co, tile): the 4x4 tile of dZ comes STRAIGHT from global memory into registers (four
 //     16-byte loads, requested one step ahead), 100 operations, nine 16-byte stores.
 //   * V = B^T d B: waves 4-7, thread = (ci, tile, row half): the raw strip of X (32 channels x 6 rows x 20 columns from column
@@ -152,26 +149,23 @@ inline __global__ void __launch_bounds__(WgradWino43Cfg::NT) wgrad_wino43_kernel
       wino43_a6(dy[0][P], dy[1][P], dy[2][P], dy[3][P], z);
 #pragma unroll
       for (int i = 0; i < 6; ++i) ty[i][P] = z[i];
-    } else if constexpr (P < 7) {                       // second pass along rows 2 p, 2 p + 1 (xi 12 p .. 12 p + 11): quads 3 p .. 3 p + 2
-      constexpr int pp = P - 4;
+    } else if constexpr (P < 7) {                       // second pass along rows i' and i' + 3: quads 3 i' .. 3 i' + 2
+      constexpr int ip = P - 4;
       float za[6], zb[6];
-      wino43_a6(ty[2 * pp][0], ty[2 * pp][1], ty[2 * pp][2], ty[2 * pp][3], za);
-      wino43_a6(ty[2 * pp + 1][0], ty[2 * pp + 1][1], ty[2 * pp + 1][2], ty[2 * pp + 1][3], zb);
-      *reinterpret_cast<f32x4*>(dst + (3 * pp) * 1024) = f32x4{za[0], za[1], za[2], za[3]};
-      *reinterpret_cast<f32x4*>(dst + (3 * pp + 1) * 1024) = f32x4{za[4], za[5], zb[0], zb[1]};
-      *reinterpret_cast<f32x4*>(dst + (3 * pp + 2) * 1024) = f32x4{zb[2], zb[3], zb[4], zb[5]};
+      wino43_a6(ty[ip][0], ty[ip][1], ty[ip][2], ty[ip][3], za);
+      wino43_a6(ty[ip + 3][0], ty[ip + 3][1], ty[ip + 3][2], ty[ip + 3][3], zb);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) *reinterpret_cast<f32x4*>(dst + (3 * ip + m) * 1024) = f32x4{za[2 * m], za[2 * m + 1], zb[2 * m], zb[2 * m + 1]};
     }
   };
-
   // ---- group 1: thread = (ci block (swave - 4) & 1, ci = lane & 15; tile = lane >> 4; row half RH = (swave - 4) >> 1)
   const int v_ib = swave & 1, v_rh = (swave >> 1) & 1;
   const int v_t = lane >> 4, v_ci = 16 * v_ib + (lane & 15);
   const int v_src = v_ci * (Cfg::RPLANE * 4) + (v_rh * RQ + v_t) * 4;      // + row * 20 floats; second piece + 4
-  const int v_dst = v_ib * 256 + lane * 4;                                 // + quad * 512 (row half 0: quads 0-3 and floats 0, 1 of quad 4; half 1: floats 2, 3 of quad 4 and quads 5-8)
+  const int v_dst = v_ib * 256 + lane * 4 + 2 * v_rh;                      // + quad * 512
   f32x4 tq0[5];
   wf2 tq1[5];
   float tt[3][6];
-  float vhold[2] = {0.0f, 0.0f};                        // two values of a row until the next row completes their quad
   bool zl = false, zr = false, fix_corner = false;
   auto v_piece = [&](auto pc, const float* raw, float* dst, const Cur& c) {
     constexpr int P = decltype(pc)::value;
@@ -208,32 +202,12 @@ inline __global__ void __launch_bounds__(WgradWino43Cfg::NT) wgrad_wino43_kernel
         if constexpr (cc == 5) v = zr ? 0.0f : v;
         tt[r][cc] = v;
       }
-    } else if constexpr (P < 11) {                      // second pass along row 3 RH + r = xi 18 RH + 6 r .. + 5
+    } else if constexpr (P < 11) {                      // second pass along row 3 RH + r: quads 3 r .. 3 r + 2, floats 2 RH, 2 RH + 1
       constexpr int r = P - 8;
       float o[6];
       wino43_bt_full(tt[r], o);
-      // row half 0 (xi 0-17): r = 0 -> quad 0, (4, 5) held; r = 1 -> quad 1 = (held, 6, 7), quad 2 = 8-11; r = 2 -> quad 3 = 12-15, first half of quad 4
-      // row half 1 (xi 18-35): r = 0 -> second half of quad 4 = (18, 19), quad 5 = 20-23; r = 1 -> quad 6 = 24-27, (28, 29) held; r = 2 -> quad 7, quad 8
-      float* d0 = dst;
-      if (v_rh == 0) {
-        if constexpr (r == 0) { *reinterpret_cast<f32x4*>(d0) = f32x4{o[0], o[1], o[2], o[3]}; vhold[0] = o[4]; vhold[1] = o[5]; }
-        else if constexpr (r == 1) {
-          *reinterpret_cast<f32x4*>(d0 + 512) = f32x4{vhold[0], vhold[1], o[0], o[1]};
-          *reinterpret_cast<f32x4*>(d0 + 2 * 512) = f32x4{o[2], o[3], o[4], o[5]};
-        } else {
-          *reinterpret_cast<f32x4*>(d0 + 3 * 512) = f32x4{o[0], o[1], o[2], o[3]};
-          *reinterpret_cast<wf2*>(d0 + 4 * 512) = wf2{o[4], o[5]};
-        }
-      } else {
-        if constexpr (r == 0) {
-          *reinterpret_cast<wf2*>(d0 + 4 * 512 + 2) = wf2{o[0], o[1]};
-          *reinterpret_cast<f32x4*>(d0 + 5 * 512) = f32x4{o[2], o[3], o[4], o[5]};
-        } else if constexpr (r == 1) { *reinterpret_cast<f32x4*>(d0 + 6 * 512) = f32x4{o[0], o[1], o[2], o[3]}; vhold[0] = o[4]; vhold[1] = o[5]; }
-        else {
-          *reinterpret_cast<f32x4*>(d0 + 7 * 512) = f32x4{vhold[0], vhold[1], o[0], o[1]};
-          *reinterpret_cast<f32x4*>(d0 + 8 * 512) = f32x4{o[2], o[3], o[4], o[5]};
-        }
-      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) *reinterpret_cast<wf2*>(dst + (3 * r + m) * 512) = wf2{o[2 * m], o[2 * m + 1]};
     }
   };
   constexpr int NPIECE = GRP == 0 ? 7 : 11;
@@ -324,7 +298,7 @@ inline __global__ void __launch_bounds__(WgradWino43Cfg::NT) wgrad_wino43_kernel
   }
   (void)cM;
 
-  // ---- epilogue: dg = G^T S G per (co, ci); acc[6 i + j] = S[i][j]; the slab's tap planes
+  // ---- epilogue: dg = G^T S G per (co, ci); acc[4 q + e] = S[(q / 3) + 3 (e >> 1)][2 (q % 3) + (e & 1)]; the slab's tap planes
   {
     const int g = lane >> 4, ci = ci0 + 16 * ib + (lane & 15);
     float* slab = a.part + (size_t)ks * 9 * Cout * Cin;
@@ -336,7 +310,7 @@ inline __global__ void __launch_bounds__(WgradWino43Cfg::NT) wgrad_wino43_kernel
       for (int j = 0; j < 6; ++j) {
         float m[6], o[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) m[i] = nsteps > 0 ? acc[6 * i + j][r] : 0.0f;
+        for (int i = 0; i < 6; ++i) m[i] = nsteps > 0 ? acc[4 * (3 * (i % 3) + j / 2) + 2 * (i / 3) + (j & 1)][r] : 0.0f;
         wino43_gt3(m[0], m[1], m[2], m[3], m[4], m[5], o);
         p[0][j] = o[0]; p[1][j] = o[1]; p[2][j] = o[2];
       }
