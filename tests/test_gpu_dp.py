@@ -35,6 +35,11 @@ def _worker(rank, world, port, out, backend="gloo", batch=4, direct=True):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if world > 2:
+            # eight processes on one device oversubscribe its hardware queues: fewer queues per process -- the weight gradients on
+            # the main stream (the data-parallel semantics under test do not depend on which stream a gradient kernel runs on)
+            from tracknetv3_amd import autograd_ops
+            autograd_ops.set_wgrad_overlap(False)
         from tracknetv3_amd.parallel import TrackNetTrainer, shard_range
         from tracknetv3_amd.utils.general import get_model
         sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 13, calibrated=True)
