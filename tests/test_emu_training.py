@@ -193,6 +193,21 @@ def test_wgrad_wino43_with_lds_dma_landing_late(emu, monkeypatch):
     assert _wgrad_wino43_case((2, 27, 64, 8, 32), "cpu") <= 8e-6
 
 
+@pytest.mark.parametrize("lazy", ["0", "1"])
+@pytest.mark.parametrize("sw", [32, 512, 256, 256 + 32, 256 + 512])
+def test_wgrad_wino43_candidate_schedules_are_bit_identical(emu, monkeypatch, sw, lazy):
+    """The schedule switches of wgrad_wino43_body (WgradWino43Sw: the dY loads issued behind quad 3 / quad 1 instead of at the end of a step,
+    three raw stages with the DMA a step further ahead) change WHEN operands are requested, never what is summed in which order:
+    bit-identical to the product kernel, with the LDS-DMA landing at issue and as late as the waits allow, strips over images / tile rows /
+    columns, a partial block of input channels, long walks (few CUs)."""
+    from tracknetv3_amd import ops
+    monkeypatch.setenv("TNV3_EMU_LAZY_DMA", lazy)
+    for cus, (n, cin, cout, h, w) in ((2, (3, 64, 64, 8, 48)), (3, (2, 27, 64, 8, 32)), (256, (2, 64, 128, 8, 32)), (1, (1, 100, 64, 4, 16))):
+        monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+        x, dz = torch.relu(T((n, cin, h, w), 51)), T((n, cout, h, w), 52)
+        assert torch.equal(ops.conv3x3_wgrad_wino(x, dz, variant=8), ops.conv3x3_wgrad_wino(x, dz, variant=8000 + sw)), (sw, cus)
+
+
 def test_wgrad_wino43_refuses_heights_that_are_not_a_multiple_of_four(emu):
     from tracknetv3_amd import ops
     with pytest.raises(Exception, match="H % 4"):

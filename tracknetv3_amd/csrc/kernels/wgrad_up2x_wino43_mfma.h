@@ -64,9 +64,12 @@ __device__ __forceinline__ void wino43u_gt3(float m0, float m1, float me, float 
 }
 
 // part: [splitK][9 taps][Cout][C0]
+// Round 6: the step's bookkeeping follows wgrad_wino43_mfma.h's diet (every instruction of a step costs ~4.6 cycles beside 1600 cycles of MFMAs
+// per SIMD): the DMA slot's address is a per-lane constant + the strip's origin, the strip cursors advance by additions (no division, no
+// multiplication by the image number), the row half of the V transform is a compile-time parameter of the wave group's instantiation.
 inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino43_kernel(const WgradUp2xWinoArgs a) {
   using Cfg = WgradUp2xWino43Cfg;
-  constexpr int NT = Cfg::NT, RQ = Cfg::RQ, YH = Cfg::YH_STAGE, VS = Cfg::V_STAGE, RAW_STAGE = Cfg::RAW_STAGE, NQ = Cfg::NQ;
+  constexpr int RQ = Cfg::RQ, YH = Cfg::YH_STAGE, VS = Cfg::V_STAGE, RAW_STAGE = Cfg::RAW_STAGE, NQ = Cfg::NQ;
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   float* yh_s = lds;                                    // two stages
   float* v_s = lds + 2 * YH;
@@ -77,7 +80,7 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
   const int Hl = a.Hl, Wl = a.Wl, C0 = a.C0, Cout = a.Cout, LHW = Hl * Wl;
   const int H = 2 * Hl, W = 2 * Wl, HW = H * W;
   const int nIB = (C0 + Cfg::CB - 1) / Cfg::CB;
-  const int kW = W >> 4, kpi = (H >> 2) * kW;           // strips per tile row / per image
+  const int kW = W >> 4, nTR = H >> 2, kpi = nTR * kW;  // strips per tile row, tile rows, strips per image
   const long strips = (long)a.N * kpi;
   const int b = blockIdx.x;
   const int ks = b % a.splitK, bb = b / a.splitK, ibk = bb % nIB, mbk = bb / nIB;
@@ -88,49 +91,81 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
   const int cb = swave & 3, ib = swave >> 2;            // MFMA role: wave = (co block cb, ci block ib)
   const int a_lane = cb * 256 + lane * 4, b_lane = ib * 256 + lane * 4;      // + quad * 1024 / + quad * 512
   f32x4 acc[25];
-  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < 25; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   const int wbase = __builtin_amdgcn_readfirstlane(wave * 64);
 
-  struct Cur { int n, tr, kc; };
+  // strip cursor: `off` = 4 tr W + 16 kc (the strip's origin in a plane of dZ), `offl` = 2 tr Wl + 8 kc (in a plane of x_low), the images as
+  // running pointers, `left` = strips of the slice from this one on
+  struct Cur { int tr, kc, off, offl; const float* ximg; const float* zimg; int left; };
   auto cur_at = [&](long e) {
     Cur c;
-    c.n = (int)(e / kpi);
-    const int rem = (int)(e - (long)c.n * kpi);
+    const int n = (int)(e / kpi);
+    const int rem = (int)(e - (long)n * kpi);
     c.tr = rem / kW;
     c.kc = rem - c.tr * kW;
+    c.off = 4 * c.tr * W + 16 * c.kc;
+    c.offl = 2 * c.tr * Wl + 8 * c.kc;
+    c.ximg = a.x_low + (size_t)n * C0 * LHW;
+    c.zimg = a.dz + (size_t)n * Cout * HW;
+    c.left = nsteps;
     return c;
   };
   auto cur_next = [&](Cur& c) {
-    if (++c.kc >= kW) { c.kc = 0; if (++c.tr >= (H >> 2)) { c.tr = 0; ++c.n; } }
+    --c.left;
+    c.off += 16;
+    c.offl += 8;
+    if (++c.kc >= kW) {
+      TNV3_NO_IF_CONVERSION();
+      c.kc = 0;
+      c.off += 3 * W;                                   // (16 kW = W)
+      c.offl += Wl;                                     // (8 kW = Wl)
+      if (++c.tr >= nTR) { c.tr = 0; c.off = 0; c.offl = 0; c.ximg += (size_t)C0 * LHW; c.zimg += (size_t)Cout * HW; }
+    }
   };
 
-  // ---- x_low raw DMA: slot e = tid -> (channel c, low-resolution row r of 2 tr - 1 .. 2 tr + 2, piece q) of [32][RPLANE]
-  auto dma_x = [&](const Cur& c, int stage, bool live) {
+  // ---- x_low raw DMA (waves 0-6, one piece each): slot e = tid -> (channel ch, low-resolution row r of 2 tr - 1 .. 2 tr + 2, piece q) of [32][RPLANE]
+  unsigned dma_c = kDmaOob;
+  int dma_r = 7;
+  {
+    const int e = tid;
+    const int ch = e / Cfg::RPLANE, rem = e - ch * Cfg::RPLANE;
+    const int r = rem / RQ, q = rem - r * RQ;
+    if (e < Cfg::RAW_SLOTS && rem < 4 * RQ) {
+      dma_c = (unsigned)((ci0 + ch) * LHW + r * Wl + 4 * q) * 4u;      // (channels >= C0: beyond the descriptor's range = zeros)
+      dma_r = r;
+    }
+  }
+  auto dma_x = [&](const Cur& c, int stage) {
     if (swave < Cfg::DMA_WAVES) {
-      const tnv3_rsrc_t rx = tnv3_make_rsrc(a.x_low + (size_t)(live ? c.n : 0) * C0 * LHW, (unsigned)C0 * (unsigned)LHW * 4u);
-      int e = tid;
-      TNV3_OPAQUE_V(e);
-      const int ch = e / Cfg::RPLANE, rem = e - ch * Cfg::RPLANE;
-      const int r = rem / RQ, q = rem - r * RQ;
-      const int gh = 2 * c.tr - 1 + r, gw = 8 * c.kc - 1 + 4 * q;
-      const bool ok = live && e < Cfg::RAW_SLOTS && rem < 4 * RQ && gh >= 0 && gh < Hl;
-      const unsigned vo = ok ? (unsigned)((ci0 + ch) * LHW + gh * Wl + gw) * 4u : kDmaOob;      // (channels >= C0: beyond the descriptor's range = zeros)
+      const bool live = c.left > 0;
+      const tnv3_rsrc_t rx = tnv3_make_rsrc(c.ximg, (unsigned)C0 * (unsigned)LHW * 4u);
+      // origin: low-resolution row 2 tr - 1, column 8 kc - 1 (wrap-around arithmetic: what stays negative lands beyond the descriptor's range =
+      // zeros; a padding slot at 2^31 + origin stays out of range as well: wgrad_up2x_wino43_supported keeps an image 4 (Wl + 1) bytes below 2^31)
+      unsigned vo = dma_c + (unsigned)(c.offl - Wl - 1) * 4u;
+      if (c.tr == 0 || c.tr == nTR - 1 || !live) {
+        TNV3_NO_IF_CONVERSION();
+        if (!live || (c.tr == 0 && dma_r == 0) || (c.tr == nTR - 1 && dma_r == 3)) vo = kDmaOob;
+      }
       tnv3_buf_dma16(rx, raw_s + stage * RAW_STAGE + wbase * 4, vo);
     }
   };
 
-  Cur cM = cur_at(e0), cT = cM, cD = cM;                // M: the MFMAs' strip; T: the transforms' (one ahead); D: the loads' (two ahead)
-  int sT = 0, sD = 0;
+  Cur cT = cur_at(e0), cD = cT;                         // T: the transforms' strip (one ahead of the MFMAs'); D: the loads' (two ahead)
 
-  auto body = [&](auto grpc) {
-  constexpr int GRP = decltype(grpc)::value;
+  auto body = [&](auto grpc, auto rhc) {
+  constexpr int GRP = decltype(grpc)::value, RH = decltype(rhc)::value;
   // ---- group 0: thread = (co = co block `swave`, lane & 15; tile = lane >> 4)
   f32x4 dy[4];
-  auto load_dy = [&](const Cur& c, bool live) {
-    const tnv3_rsrc_t rz = tnv3_make_rsrc(a.dz + (size_t)(live ? c.n : 0) * Cout * HW, (unsigned)Cout * (unsigned)HW * 4u);
-    const unsigned vo = live ? (unsigned)((co0 + 16 * (swave & 3) + (lane & 15)) * HW + (4 * c.tr) * W + 16 * c.kc + 4 * (lane >> 4)) * 4u : kDmaOob;
+  const unsigned dy_c = (unsigned)((co0 + 16 * (swave & 3) + (lane & 15)) * HW + 4 * (lane >> 4)) * 4u;
+  auto load_dy = [&](const Cur& c) {
+    if constexpr (GRP == 0) {
+      const bool live = c.left > 0;                     // (past the end of the slice: any in-range tile; never multiplied)
+      const tnv3_rsrc_t rz = tnv3_make_rsrc(live ? c.zimg : a.dz, (unsigned)Cout * (unsigned)HW * 4u);
+      const unsigned so = live ? (unsigned)c.off * 4u : 0u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dy[r] = tnv3_buf_load_f4(rz, vo, (unsigned)(r * W) * 4u);
+      for (int r = 0; r < 4; ++r) dy[r] = tnv3_buf_load_f4(rz, dy_c, so + (unsigned)(r * W) * 4u);
+    }
   };
   float ty[5][4];
   float yv[25];
@@ -157,10 +192,10 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
       *reinterpret_cast<f32x4*>(dst + q * 1024) = f32x4{yv[4 * q], q < 6 ? yv[4 * q + 1] : 0.0f, q < 6 ? yv[4 * q + 2] : 0.0f, q < 6 ? yv[4 * q + 3] : 0.0f};
     }
   };
-  // ---- group 1: thread = (ci block (swave - 4) & 1, ci = lane & 15; tile = lane >> 4; row half RH = (swave - 4) >> 1)
-  const int v_ib = swave & 1, v_rh = (swave >> 1) & 1;
+  // ---- group 1: thread = (ci block swave & 1, ci = lane & 15; tile = lane >> 4; row half RH: a compile-time parameter of the instantiation)
+  const int v_ib = swave & 1;
   const int v_t = lane >> 4, v_ci = 16 * v_ib + (lane & 15);
-  const int v_src = v_ci * (Cfg::RPLANE * 4) + (v_rh * RQ) * 4 + 2 * v_t;      // + row * 12 floats; columns 2, 3 of the patch at + 2
+  const int v_src = v_ci * (Cfg::RPLANE * 4) + (RH * RQ) * 4 + 2 * v_t;         // + row * 12 floats; columns 2, 3 of the patch at + 2
   const int v_dst = v_ib * 256 + lane * 4;                                     // + quad * 512
   wf2 ulo[3], uhi[3];
   float uc[2][4], uw[2][4];
@@ -174,12 +209,13 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
         uhi[r] = *reinterpret_cast<const wf2*>(raw + r * (RQ * 4) + 2);
       }
       if (fix_corner) {                                 // the piece before the image's first element (channel 0, low-resolution row 0, columns -1 .. 2):
+        TNV3_NO_IF_CONVERSION();
         if ((lane & 15) == 0 && v_t < 2 && v_ib == 0) { // all of tile 0's row and the first half of tile 1's; row 0 is patch row 1 (half 0) / 0 (half 1)
-          const tnv3_rsrc_t ri = tnv3_make_rsrc(a.x_low + (size_t)c.n * C0 * LHW, (unsigned)C0 * (unsigned)LHW * 4u);
+          const tnv3_rsrc_t ri = tnv3_make_rsrc(c.ximg, (unsigned)C0 * (unsigned)LHW * 4u);
           const f32x4 x = tnv3_buf_load_f4(ri, 0u, 0u);
           const bool t0 = v_t == 0;
           const wf2 nlo = wf2{t0 ? 0.0f : x[1], t0 ? x[0] : x[2]};
-          if (v_rh) { ulo[0] = nlo; if (t0) uhi[0] = wf2{x[1], x[2]}; }
+          if constexpr (RH) { ulo[0] = nlo; if (t0) uhi[0] = wf2{x[1], x[2]}; }
           else { ulo[1] = nlo; if (t0) uhi[1] = wf2{x[1], x[2]}; }
         }
       }
@@ -188,8 +224,8 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
       for (int x = 0; x < 4; ++x) {
         const float r0 = x < 2 ? ulo[0][x & 1] : uhi[0][x & 1], r1 = x < 2 ? ulo[1][x & 1] : uhi[1][x & 1], r2 = x < 2 ? ulo[2][x & 1] : uhi[2][x & 1];
         float c0, c1;
-        if (v_rh == 0) { c0 = fmaf(kU43B, r0, fmaf(-kU43B1, r1, r2)); c1 = fmaf(-kU43B, r1, r2); }      // (a, b, c) -> B a - (1 + B) b + c,  c - B b
-        else { c0 = r0 - r1; c1 = fmaf(kU43B, r0, fmaf(-kU43B1, r1, r2)); }                              // (b, c, e) -> b - c,  B b - (1 + B) c + e
+        if constexpr (RH == 0) { c0 = fmaf(kU43B, r0, fmaf(-kU43B1, r1, r2)); c1 = fmaf(-kU43B, r1, r2); }      // (a, b, c) -> B a - (1 + B) b + c,  c - B b
+        else { c0 = r0 - r1; c1 = fmaf(kU43B, r0, fmaf(-kU43B1, r1, r2)); }                                      // (b, c, e) -> b - c,  B b - (1 + B) c + e
         if (x == 0) { c0 = zl ? 0.0f : c0; c1 = zl ? 0.0f : c1; }
         if (x == 3) { c0 = zr ? 0.0f : c0; c1 = zr ? 0.0f : c1; }
         uc[0][x] = c0; uc[1][x] = c1;
@@ -204,7 +240,7 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
     } else if constexpr (P == 4) {                      // xi = 5 i' + j'; j' = (0, 1, e, o, 5) -> the row pass's values (0, 1, 2, 2, 3)
       const float* r0 = uw[0];
       const float* r1 = uw[1];
-      if (v_rh == 0) {                                  // rows i' = 0 (xi 0-4) and 1 (xi 5-9): quads 0, 1 and the first half of quad 2
+      if constexpr (RH == 0) {                          // rows i' = 0 (xi 0-4) and 1 (xi 5-9): quads 0, 1 and the first half of quad 2
         *reinterpret_cast<f32x4*>(dst) = f32x4{r0[0], r0[1], r0[2], r0[2]};
         *reinterpret_cast<f32x4*>(dst + 512) = f32x4{r0[3], r1[0], r1[1], r1[2]};
         *reinterpret_cast<wf2*>(dst + 2 * 512) = wf2{r1[2], r1[3]};
@@ -218,17 +254,17 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
     }
   };
   constexpr int NPIECE = GRP == 0 ? 3 + NQ : 5;
-  auto set_v_flags = [&](const Cur& c, bool live, bool first_of_image_channel0) {
+  auto set_v_flags = [&](const Cur& c) {
     zl = c.kc == 0 && v_t == 0;
     zr = c.kc == kW - 1 && v_t == 3;
-    fix_corner = live && first_of_image_channel0;
+    fix_corner = c.left > 0 && c.off == 0 && ci0 == 0;
   };
-  auto transform_all = [&](int stage, int raw_stage, const Cur& c, bool live) {      // (prologue: not interleaved)
+  auto transform_all = [&](int stage, int raw_stage, const Cur& c) {      // (prologue: not interleaved)
     if constexpr (GRP == 0) {
       float* dst = yh_s + stage * YH + (swave & 3) * 256 + lane * 4;
       wino43s_for<0, NPIECE>([&](auto pc) { yh_piece(pc, dst); });
     } else {
-      set_v_flags(c, live, c.tr == 0 && c.kc == 0 && ci0 == 0);
+      set_v_flags(c);
       const float* raw = raw_s + raw_stage * RAW_STAGE + v_src;
       float* dst = v_s + stage * VS + v_dst;
       wino43s_for<0, NPIECE>([&](auto pc) { v_piece(pc, raw, dst, c); });
@@ -241,15 +277,15 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
   };
 
   // ---- prologue: operands of step 0 in stage 0, the loads of step 1 under way
-  dma_x(cD, 0, sD < nsteps);
-  if constexpr (GRP == 0) load_dy(cD, sD < nsteps);
+  dma_x(cD, 0);
+  load_dy(cD);
   full_barrier();
-  transform_all(0, 0, cT, sT < nsteps);
-  cur_next(cT); ++sT;
-  cur_next(cD); ++sD;
-  dma_x(cD, 1, sD < nsteps);
-  if constexpr (GRP == 0) load_dy(cD, sD < nsteps);
-  cur_next(cD); ++sD;
+  transform_all(0, 0, cT);
+  cur_next(cT);
+  cur_next(cD);
+  dma_x(cD, 1);
+  load_dy(cD);
+  cur_next(cD);
   full_barrier();
 
   // ---- steps
@@ -257,15 +293,14 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
     const int st = sg & 1, sn = st ^ 1;
     const float* A = yh_s + st * YH + a_lane;
     const float* B = v_s + st * VS + b_lane;
-    const bool liveT = sT < nsteps, liveD = sD < nsteps;
     const float* raw = raw_s + sn * RAW_STAGE + v_src;   // raw(sigma + 1): requested one step ago
     float* ydst = yh_s + sn * YH + (swave & 3) * 256 + lane * 4;
     float* vdst = v_s + sn * VS + v_dst;
-    if constexpr (GRP == 1) set_v_flags(cT, liveT, cT.tr == 0 && cT.kc == 0 && ci0 == 0);
+    if constexpr (GRP == 1) set_v_flags(cT);
     f32x4 aq[2], bq[2];
     aq[0] = *reinterpret_cast<const f32x4*>(A);
     bq[0] = *reinterpret_cast<const f32x4*>(B);
-    dma_x(cD, st, liveD);                               // raw(sigma + 2) -> the raw stage whose strip the transform of the previous step has consumed
+    dma_x(cD, st);                                      // raw(sigma + 2) -> the raw stage whose strip the transform of the previous step has consumed
     wino43s_for<0, NQ>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       if constexpr (q + 1 < NQ) {
@@ -276,7 +311,7 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (4 * q + e < 25)
-          acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q & 1][e], bq[q & 1][e], sg == 0 ? zero4 : acc[4 * q + e], 0, 0, 0);
+          acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q & 1][e], bq[q & 1][e], acc[4 * q + e], 0, 0, 0);
       // the transform of step sigma + 1 behind the quads: ten pieces (group 0) / five (group 1) over seven slots
       if constexpr (GRP == 0) {
         if constexpr (q < 3) {
@@ -292,7 +327,7 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
     });
     if constexpr (GRP == 0) {
       // this wave's x piece (older than the four dY loads requested now) has landed once at most four loads are in flight
-      load_dy(cD, liveD);
+      load_dy(cD);
       __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(4));
     } else {
       __builtin_amdgcn_s_waitcnt(tnv3_vmcnt_only(0));
@@ -300,10 +335,9 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
     __builtin_amdgcn_s_waitcnt(tnv3_lgkmcnt_only(0));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    cur_next(cT); ++sT;
-    cur_next(cD); ++sD;
+    cur_next(cT);
+    cur_next(cD);
   }
-  (void)cM;
 
   // ---- epilogue: dg = G'^T S G' per (co, ci); acc[5 i' + j'] = S[i'][j']; the slab's tap planes
   {
@@ -316,8 +350,7 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         float o[3];
-        wino43u_gt3(nsteps > 0 ? acc[j][r] : 0.0f, nsteps > 0 ? acc[5 + j][r] : 0.0f, nsteps > 0 ? acc[10 + j][r] : 0.0f,
-                    nsteps > 0 ? acc[15 + j][r] : 0.0f, nsteps > 0 ? acc[20 + j][r] : 0.0f, o);
+        wino43u_gt3(acc[j][r], acc[5 + j][r], acc[10 + j][r], acc[15 + j][r], acc[20 + j][r], o);
         p[0][j] = o[0]; p[1][j] = o[1]; p[2][j] = o[2];
       }
 #pragma unroll
@@ -332,7 +365,9 @@ inline __global__ void __launch_bounds__(WgradUp2xWino43Cfg::NT) wgrad_up2x_wino
     }
   }
   };
-  if (swave >> 2) body(std::integral_constant<int, 1>{}); else body(std::integral_constant<int, 0>{});
+  if (swave < 4) body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  else if (swave < 6) body(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  else body(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
 }
 
 }  // namespace tnv3

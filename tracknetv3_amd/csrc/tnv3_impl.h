@@ -26,6 +26,7 @@
 #include "kernels/wgrad3x3_mfma.h"
 #include "kernels/wgrad_wino_mfma.h"
 #include "kernels/wgrad_wino43_mfma.h"
+#include "kernels/wgrad_wino43_r5_mfma.h"
 #include "kernels/wgrad_up2x_wino43_mfma.h"
 
 namespace tnv3 {
@@ -1186,7 +1187,9 @@ inline int wgrad_wino_splitk(int n, int cin, int cout, int h, int w) {
 // ... and in F(4x4, 3x3) form (kernels/wgrad_wino43_mfma.h; kernel variant 8): 64 co x 32 ci per workgroup, a K unit = one strip of 4 x 16 pixels
 constexpr int kWgradWino43Variant = 8;
 inline bool wgrad_wino43_supported(int cin, int cout, int h, int w) {
-  return cin > 0 && cout > 0 && cout % 64 == 0 && h % 4 == 0 && w % 16 == 0 && (long)(cin > cout ? cin : cout) * h * w * 4 < (1l << 31);
+  // (an image of either operand stays 4 (W + 1) bytes below 2^31: the X DMA's padding slots sit at offset 2^31 + the strip origin, which may be
+  //  that far negative, and must stay beyond the descriptor's range)
+  return cin > 0 && cout > 0 && cout % 64 == 0 && h % 4 == 0 && w % 16 == 0 && (long)(cin > cout ? cin : cout) * h * w * 4 + 4l * (w + 1) + 16 < (1l << 31);
 }
 inline int wgrad_wino43_splitk(int n, int cin, int cout, int h, int w) {
   const int nb = (cout / WgradWino43Cfg::MB) * ((cin + WgradWino43Cfg::CB - 1) / WgradWino43Cfg::CB);
@@ -1284,6 +1287,34 @@ int conv3x3_wgrad_wino_impl(Launcher& L, const float* x, const float* dz, float*
     if ((rc = L.launch(wgrad_wino43_kernel, (cout / WgradWino43Cfg::MB) * ((cin + WgradWino43Cfg::CB - 1) / WgradWino43Cfg::CB) * sk43, WgradWino43Cfg::NT, a43))) return rc;
     return L.launch(wgrad_wino43_fold_kernel, grid_for((long)9 * cout * cin, 64, 8192), 256, (const float*)slabs, dw, cout, cin, sk43);
   }
+#ifdef TNV3_DIAG      // 8000 + switches: twins / candidate schedules of the F(4x4) kernel (WgradWino43Sw; the Timeline bit writes [wave 8][8] uint64 to the workspace's first KB)
+  if (variant >= 9000 && variant < 9000 + 1024) {      // round 5's schedule of the same kernel (kernels/wgrad_wino43_r5_mfma.h): the same-session A/B reference
+    if (!wgrad_wino43_supported(cin, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (F(4x4) twins): unsupported shape");
+    const int sk43 = wgrad_wino43_splitk(n, cin, cout, h, w);
+    WgradWinoArgs a43{x, dz, (const float*)ws, slabs, n, cin, cout, h, w, sk43};
+    const int grid = (cout / WgradWino43Cfg::MB) * ((cin + WgradWino43Cfg::CB - 1) / WgradWino43Cfg::CB) * sk43;
+    const int sw = variant - 9000;
+    if (sw == 0) { if ((rc = L.launch(wgrad_wino43_r5_twin_kernel<0>, grid, WgradWino43Cfg::NT, a43))) return rc; }
+    else if (sw == 64) { if ((rc = L.launch(wgrad_wino43_r5_twin_kernel<64>, grid, WgradWino43Cfg::NT, a43))) return rc; }
+    else TNV3_FAIL(-1, "conv3x3_wgrad_wino: no round-5 F(4x4) twin with switches %d", sw);
+    return L.launch(wgrad_wino43_fold_kernel, grid_for((long)9 * cout * cin, 64, 8192), 256, (const float*)slabs, dw, cout, cin, sk43);
+  }
+  if (variant >= 8000 && variant < 8000 + 1024) {
+    if (!wgrad_wino43_supported(cin, cout, h, w)) TNV3_FAIL(-1, "conv3x3_wgrad_wino (F(4x4) twins): unsupported shape");
+    const int sk43 = wgrad_wino43_splitk(n, cin, cout, h, w);
+    WgradWinoArgs a43{x, dz, (const float*)ws, slabs, n, cin, cout, h, w, sk43};
+    const int grid = (cout / WgradWino43Cfg::MB) * ((cin + WgradWino43Cfg::CB - 1) / WgradWino43Cfg::CB) * sk43;
+    const int sw = variant - 8000;
+#define TNV3_W43_TWIN(S) if (sw == (S)) { if ((rc = L.launch(wgrad_wino43_twin_kernel<(S)>, grid, WgradWino43Cfg::NT, a43))) return rc; } else
+    TNV3_W43_TWIN(0) TNV3_W43_TWIN(64) TNV3_W43_TWIN(1) TNV3_W43_TWIN(2) TNV3_W43_TWIN(3) TNV3_W43_TWIN(4) TNV3_W43_TWIN(8) TNV3_W43_TWIN(12) TNV3_W43_TWIN(16)
+    TNV3_W43_TWIN(128) TNV3_W43_TWIN(15) TNV3_W43_TWIN(143) TNV3_W43_TWIN(32) TNV3_W43_TWIN(512) TNV3_W43_TWIN(256) TNV3_W43_TWIN(256 + 32)
+    TNV3_W43_TWIN(256 + 512) TNV3_W43_TWIN(64 + 32) TNV3_W43_TWIN(64 + 512) TNV3_W43_TWIN(64 + 256) TNV3_W43_TWIN(64 + 256 + 512)
+    TNV3_W43_TWIN(256 + 512 + 4) TNV3_W43_TWIN(256 + 512 + 8) TNV3_W43_TWIN(256 + 512 + 12)
+    TNV3_FAIL(-1, "conv3x3_wgrad_wino: no F(4x4) twin with switches %d", sw);
+#undef TNV3_W43_TWIN
+    return L.launch(wgrad_wino43_fold_kernel, grid_for((long)9 * cout * cin, 64, 8192), 256, (const float*)slabs, dw, cout, cin, sk43);
+  }
+#endif
   const int sk = wgrad_wino_splitk(n, cin, cout, h, w);
   const bool zero_page = wgrad_wino_pick(cin, variant) == 0;                           // only the first kernel reads its borders from a zero page
   if (zero_page && (rc = L.launch(fill_zero_kernel, 1, 256, (float*)ws, (int)(kWgradZeroBytes / 4)))) return rc;
@@ -1300,7 +1331,7 @@ struct WgradUpLayout { size_t zp, d4, dwskip, slabs, total; WgradPlan up, skip; 
 // the upsampled half in the 25-of-36 F(4x4) form (kernels/wgrad_up2x_wino43_mfma.h): any c0, a K unit = one strip of 4 x 16 output pixels
 inline bool wgrad_up2x_wino43_supported(int c0, int cout, int hl, int wl) {
   return c0 > 0 && cout > 0 && cout % 64 == 0 && hl > 0 && hl % 2 == 0 && wl > 0 && wl % 8 == 0 &&
-         (long)(c0 > 4 * cout ? c0 : 4 * cout) * hl * wl * 4 < (1l << 31);
+         (long)(c0 > 4 * cout ? c0 : 4 * cout) * hl * wl * 4 + 4l * (wl + 1) + 16 < (1l << 31);      // (the DMA's padding slots: see wgrad_wino43_supported)
 }
 inline int wgrad_up2x_wino43_splitk(int n, int c0, int cout, int hl, int wl) {
   const int nb = (cout / WgradUp2xWino43Cfg::MB) * ((c0 + WgradUp2xWino43Cfg::CB - 1) / WgradUp2xWino43Cfg::CB);
