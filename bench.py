@@ -43,6 +43,17 @@ def lib_sha256():
             return hashlib.sha256(f.read()).hexdigest()
     except OSError:
         return None
+
+
+def src_sha256():
+    """Path-independent key of the build: sha256 of the kernel sources + compile flags (tracknetv3_amd/_build.source_sha256)."""
+    from tracknetv3_amd import _build
+    try:
+        return _build.source_sha256()
+    except OSError:
+        return None
+
+
 ALG_BYTES_PER_SAMPLE = 693.55e6    # SURVEY 8d: ideal-fusion fp32 bytes of one 27->8 forward
 
 
@@ -852,13 +863,16 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "conv_traffic.json")) as f:
                 tj = json.load(f)
-            sha = lib_sha256()
-            if (int(tj.get("conv_launches_per_step", -1)) == launches_per_step and tj.get("kernel_set") == KERNEL_SET and sha is not None
-                    and tj.get("lib_sha256") == sha):
+            sha, ssha = lib_sha256(), src_sha256()
+            # the counters belong to a BUILD: the same kernel sources + flags (path-independent), or -- for counter files
+            # written before that key existed -- the same library file
+            same_build = (ssha is not None and tj.get("src_sha256") == ssha) or (tj.get("src_sha256") is None and sha is not None and tj.get("lib_sha256") == sha)
+            if int(tj.get("conv_launches_per_step", -1)) == launches_per_step and tj.get("kernel_set") == KERNEL_SET and same_build:
                 traffic = float(tj["traffic_bytes_per_launch"])
                 traffic_src = {"file": "profiles/conv_traffic.json", "commit": tj.get("commit"), "taken_utc": tj.get("taken_utc"), "lib_sha": sha,
+                               "src_sha": ssha,
                                "note": "PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE over the conv launches of this same command, taken on "
-                                       "the library with this sha256 (the one loaded now); any other build reports null"}
+                                       "a build of the same kernel sources and flags (src_sha256); any other build reports null"}
         except (OSError, KeyError, ValueError, TypeError):
             pass
         to_ms = lambda sec: round(sec / args.steps * 1e3, 4)      # noqa: E731
@@ -887,7 +901,7 @@ def main():
                          "traffic_unit": "bytes per launch",
                          "kernel": f"conv3x3_wino43s_kernel<CBW 4 | 8, MODE 0 plain | 1 upsampled half> ({launches_per_step} launches/step for the 17 "
                                    f"conv layers, fp32 MFMA 16x16x4)",
-                         "lib_sha256": lib_sha256(),
+                         "lib_sha256": lib_sha256(), "src_sha256": src_sha256(),
                          "measured": "second pass of the same K-step blocks with the whole batch on ONE stream (model.no_infer_split) and HIP "
                                      "events around every conv launch: a launch's duration is its own, not stretched by the other half's "
                                      "co-running launches; per layer the MEDIAN over all timed steps; `single_stream_ms_per_step` is "

@@ -20,8 +20,9 @@ fresh() { [ -f "$1" ] && [ "$1" -nt $O/lib_sha256.txt ]; }
 for f in up2x_wino_ab dgrad_up2x_ab wgrad_up_sweep wgrad_wino_ab; do fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
 fresh $O/e2e_real_network_report.json && cp $O/e2e_real_network_report.json $P/${R}_e2e_real_network_report.json
 # (the library that ran on the GPU box is the one in the tree: the session ships the tree; its sha256 keys the counters to the build)
-python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json ${COMMIT:-$(git rev-parse --short HEAD)} $(cat $O/lib_sha256.txt 2>/dev/null || sha256sum tracknetv3_amd/libtnv3_hip.so | cut -d" " -f1)
+python scripts/conv_traffic.py $O/pmc_fetch_pmc.csv $O/pmc_write_pmc.csv 3 $P/conv_traffic.json ${COMMIT:-$(git rev-parse --short HEAD)} $(cat $O/lib_sha256.txt 2>/dev/null || sha256sum tracknetv3_amd/libtnv3_hip.so | cut -d" " -f1) $(cat $O/src_sha256.txt 2>/dev/null || python -c "from tracknetv3_amd import _build; print(_build.source_sha256())" | tail -1)
 [ -f $O/lib_sha256.txt ] && cp $O/lib_sha256.txt $P/${R}_lib_sha256.txt
+[ -f $O/src_sha256.txt ] && cp $O/src_sha256.txt $P/${R}_src_sha256.txt
 for f in wino43_variant_ab up2x_wino43_ab wino43s_timeline wgrad_wino43_ab; do fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
 for f in fullsize_train_parity_n2_f43fwd fullsize_train_parity_n2_f22fwd fullsize_train_parity_n10_default; do fresh $O/$f.json && cp $O/$f.json $P/${R}_$f.json; done
 [ -f $O/infer_sq_summary.json ] && cp $O/infer_sq_summary.json $P/${R}_infer_sq_summary.json

@@ -1,5 +1,5 @@
 """profiles/conv_traffic.json from the two PMC passes (rocpd_pmc.py CSVs of `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`).
-usage: conv_traffic.py <fetch_pmc.csv> <write_pmc.csv> <steps_in_the_profiled_run> <out.json> [commit] [sha256 of the library that ran]
+usage: conv_traffic.py <fetch_pmc.csv> <write_pmc.csv> <steps_in_the_profiled_run> <out.json> [commit] [sha256 of the library that ran] [sha256 of its sources: _build.source_sha256()]
 bench.py reports `roofline.traffic` from this file only when its launch list (`conv_launches_per_step`, `kernel_set`) matches
 the run, together with the commit / time recorded here."""
 import csv, json, sys, time
@@ -32,6 +32,7 @@ def main():
     json.dump({
         "commit": sys.argv[5] if len(sys.argv) > 5 else None, "taken_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
         "kernel_set": "wino43s+up2x_wino43s", "lib_sha256": sys.argv[6] if len(sys.argv) > 6 else None,
+        "src_sha256": sys.argv[7] if len(sys.argv) > 7 else None,      # path-independent key of the build: what bench.py matches
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
                   f"bench.py --steps {steps - 1} --warmup 1 --blocks 1 --overlap-streams 0 --infer-split 0, MI355X (raw per-kernel sums: "
                   "the two CSVs given on the command line; made by scripts/conv_traffic.py)",

@@ -30,6 +30,7 @@ LOG=$OUT/session.log
 : > $LOG
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 sha256sum tracknetv3_amd/libtnv3_hip.so | cut -d" " -f1 > $OUT/lib_sha256.txt      # which build this session measured
+python -c "from tracknetv3_amd import _build; print(_build.source_sha256())" 2>/dev/null | tail -1 > $OUT/src_sha256.txt      # ... and its path-independent key
 if has host; then
   python -c "import cv2; print('cv2', cv2.__version__)" > $OUT/cv2_probe.txt 2>&1
   nproc > $OUT/host.txt; grep -m1 "model name" /proc/cpuinfo >> $OUT/host.txt; rocm-smi --showproductname 2>/dev/null | head -20 >> $OUT/host.txt

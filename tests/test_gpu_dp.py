@@ -58,7 +58,7 @@ def _worker(rank, world, port, out, backend="gloo", batch=4, direct=True):
         # backward's kernels wrote every gradient into its all-reduce bucket (no copy); p.grad IS the bucket view
         assert tr.reducer.copies == (0 if direct else 53), tr.reducer.copies
         for p_ in net.parameters():
-            assert p_.grad.data_ptr() == tr.reducer.dest(p_).data_ptr()
+            assert p_.grad.data_ptr() == tr.reducer.view(p_).data_ptr()
         out[rank] = dict(loss=float(loss), overlap=tr.overlap_report(), params={k: v.detach().cpu() for k, v in net.named_parameters()},
                          grads={k: v.grad.detach().cpu() for k, v in net.named_parameters()},
                          bn={k: v.detach().cpu() for k, v in net.state_dict().items() if "running_" in k})

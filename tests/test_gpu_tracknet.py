@@ -146,8 +146,13 @@ def test_product_library_refuses_the_measurement_twins(gpu_device):
             ops.conv3x3_wgrad_wino(x, dz, variant=v)
     with pytest.raises(_lib.Tnv3Error, match="libtnv3_diag"):
         ops.conv3x3_wgrad(x, dz, variant=1)
-    for v in (5, 6 if False else 5, -1):                       # what stays: bit-identical streaming kernels, the library's pick
+    for v in (5, -1):                                          # what stays: the streaming kernel, the library's pick (5 again at 64 output channels)
         assert torch.equal(ops.conv3x3_wino(x, u5, 64, variant=5), ops.conv3x3_wino(x, ops.pack_wino_weights(wt, variant=v), 64, variant=v))
+    # ... and the 128-channel form (6) on a shape it takes: the same sums in the same order as kernel 5
+    w128 = (torch.rand(128, 64, 3, 3, device=x.device) - 0.5) * 0.1
+    y5 = ops.conv3x3_wino(x, ops.pack_wino_weights(w128, variant=5), 128, variant=5)
+    for v in (6, -1):
+        assert torch.equal(y5, ops.conv3x3_wino(x, ops.pack_wino_weights(w128, variant=v), 128, variant=v)), v
 
 
 def test_wino_pack_view(gpu_device):

@@ -112,7 +112,7 @@ def _worker8(rank, world, port, out):
                 if id(p) in checks:
                     other = [torch.empty_like(checks[id(p)]) for _ in range(world)]
                     dist.all_gather(other, checks[id(p)])
-                    assert torch.allclose(red.dest(p), sum(other) / world, atol=1e-6), "bucket average mismatch"
+                    assert torch.allclose(red.view(p), sum(other) / world, atol=1e-6), "bucket average mismatch"
         # a gradient that arrives somewhere else (a caller's own tensor) is still copied in -- and counted
         red.on_grad(order[0], torch.ones(order[0].shape))
         assert red.copies == 1
@@ -190,3 +190,24 @@ def test_bench_first_contact_watchdog_reports_instead_of_hanging(hang_rank):
         assert not r0["ok"] and not r1["ok"]
         assert "within 2 s" in r0["error"] and r1["hung_here"] and r0["watchdog_s"] == 2.0
         assert r0["any_hung"] and r1["any_hung"]           # every rank learns that SOMEONE hung: all of them leave without a device synchronise
+
+
+def test_destination_hook_steps_aside_when_a_gradient_is_already_accumulated_in_the_bucket():
+    """with the kernels writing into the bucket views, param.grad ALIASES the bucket after the first backward.  A second backward
+    without zero_grad(set_to_none=True) (gradient accumulation) must not be handed the same memory as its destination -- the kernel would
+    overwrite the accumulated gradient before autograd adds that memory to itself (2 x new instead of old + new).  dest() then answers None
+    ("write a fresh tensor"), and autograd's own accumulation into the view stays correct."""
+    from tracknetv3_amd import parallel
+    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
+    red = parallel.GradAllReducer(params, bucket_bytes=1 << 20)
+    for p in params:
+        v = red.dest(p)
+        assert v is not None and v.data_ptr() == red.view(p).data_ptr()
+        v.fill_(2.0)
+        p.grad = red.on_grad(p, v)                              # what autograd does with the hook's return value
+        assert red.dest(p) is None                              # a second backward now: fresh tensor + copy-free accumulation by autograd
+        fresh = torch.full(p.shape, 3.0)
+        p.grad.add_(fresh)                                      # AccumulateGrad
+        assert torch.equal(red.view(p), torch.full(p.shape, 5.0))
+        p.grad = None                                           # zero_grad(set_to_none=True)
+        assert red.dest(p) is not None

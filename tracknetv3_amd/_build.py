@@ -31,6 +31,22 @@ def _sources():
     return out
 
 
+def source_sha256():
+    """sha256 over what the library is built FROM: every file under csrc/ and the two C headers (relative path + bytes, sorted) and the compile
+    flags.  Unlike the sha256 of libtnv3_hip.so -- which embeds the build directory's path, so the same sources hash differently under /tmp
+    than under /root/repo -- this key is the same wherever the tree is built: bench.py replays profiled counters (profiles/conv_traffic.json)
+    for a build with the same sources, the profile scripts record it next to the library's own hash."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(PKG_DIR)
+    for path in sorted(os.path.realpath(p_) for p_ in _sources() if os.path.isfile(p_)):
+        h.update(os.path.relpath(path, os.path.realpath(root)).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(repr((FLAGS, sorted(FAMILY_FLAGS.items()), FAMILIES)).encode())
+    return h.hexdigest()
+
+
 def _newer_than(target, paths):
     if not os.path.exists(target):
         return True

@@ -330,7 +330,8 @@ class TrackNet(nn.Module):
             x = b.forward_eval(x)
         return blocks[-1].forward_eval(x, pool=pool)
 
-    def _forward_eval(self, x):
+    def _forward_eval(self, x, out=None):
+        """out: where the head writes the heat maps (a contiguous (n, out_dim, H, W) view, e.g. a batch slice of the caller's tensor)."""
         x1, p1 = self._chain_eval(self.down_block_1.blocks(), x, pool=True)
         x2, p2 = self._chain_eval(self.down_block_2.blocks(), p1, pool=True)
         x3, p3 = self._chain_eval(self.down_block_3.blocks(), p2, pool=True)
@@ -338,7 +339,7 @@ class TrackNet(nn.Module):
         x = self._chain_eval(self.up_block_1.blocks(), x, skip=x3, up=True)
         x = self._chain_eval(self.up_block_2.blocks(), x, skip=x2, up=True)
         x = self._chain_eval(self.up_block_3.blocks(), x, skip=x1, up=True)
-        return ops.head1x1_sigmoid(x, self.predictor.weight.detach(), self.predictor.bias.detach())
+        return ops.head1x1_sigmoid(x, self.predictor.weight.detach(), self.predictor.bias.detach(), out=out)
 
     def invalidate_caches(self):
         """Drop the cached packed operands of every block (needed after writes through `.data` / raw pointers, which bump no
@@ -410,7 +411,8 @@ class TrackNet(nn.Module):
         self.prepare_eval()                                  # cached operands are built on this stream, before the side streams read them
         ready = torch.cuda.Event()
         ready.record(main)                                   # x (and the caches) were produced on this stream
-        outs = [None] * len(parts)
+        # one output tensor, allocated on this stream; every part's head writes its batch slice (no concatenation pass)
+        y = torch.empty((n, self.out_dim, int(x.shape[2]), int(x.shape[3])), dtype=torch.float32, device=dev)
         sides = []
         for i in range(1, len(parts)):
             if cuts[i + 1] <= cuts[i]:
@@ -419,14 +421,11 @@ class TrackNet(nn.Module):
             sides.append(side)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                outs[i] = self._forward_eval(x[cuts[i]:cuts[i + 1]])
-        outs[0] = self._forward_eval(x[:cuts[1]])
+                self._forward_eval(x[cuts[i]:cuts[i + 1]], out=y[cuts[i]:cuts[i + 1]])
+        self._forward_eval(x[:cuts[1]], out=y[:cuts[1]])
         for side in sides:
-            main.wait_stream(side)
-        for y in outs[1:]:
-            if y is not None:
-                y.record_stream(main)                        # allocated on a side stream, consumed (and freed) on this one
-        return torch.cat([y for y in outs if y is not None], 0)
+            main.wait_stream(side)                           # (y lives on this stream and is handed on only after the join)
+        return y
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_dim:

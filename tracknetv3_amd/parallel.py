@@ -39,19 +39,19 @@ class GradAllReducer:
         for p in self.params:
             n = p.numel()
             if cur and (cur_n + n) * 4 > bucket_bytes:
-                self._close(cur, cur_n)
+                self._close(cur)
                 cur, cur_n = [], 0
             cur.append(p)
             cur_n += n
         if cur:
-            self._close(cur, cur_n)
+            self._close(cur)
         self.pending = []
         self.arrived = [0] * len(self.buckets)
         self.copies = 0                               # gradients that had to be copied into their bucket (0 when the kernels write there)
 
     SLOT_ALIGN = 64      # floats: every parameter's slot starts 256-byte aligned, so a kernel can write its gradient straight into it
 
-    def _close(self, plist, total):
+    def _close(self, plist):
         a = self.SLOT_ALIGN
         padded = sum((p.numel() + a - 1) // a * a for p in plist)
         flat = torch.zeros(padded, dtype=torch.float32, device=self.device)      # (the pad floats stay zero: they ride along in the all-reduce)
@@ -66,7 +66,18 @@ class GradAllReducer:
         return len(self.buckets)
 
     def dest(self, param):
-        """The parameter's view of its bucket: where backward's kernels write the gradient (autograd_ops' destination hook)."""
+        """The parameter's view of its bucket: where backward's kernels write the gradient (autograd_ops' destination hook).  None -- "write a
+        fresh tensor" -- when param.grad already lives in that slot: a second backward without zero_grad(set_to_none=True) (gradient
+        accumulation) would otherwise OVERWRITE the accumulated gradient before autograd adds the same memory to itself (2 x new instead
+        of old + new, silently); with a fresh tensor autograd accumulates into the bucket view as usual and on_grad sees the view again."""
+        view = self.view(param)
+        g = param.grad
+        if g is not None and g.data_ptr() == view.data_ptr():
+            return None
+        return view
+
+    def view(self, param):
+        """The parameter's slot of its flat bucket, shaped like the parameter."""
         b, off, n, shape = self.slot[id(param)]
         return self.buckets[b]["flat"][off:off + n].view(shape)
 

@@ -33,11 +33,22 @@ def save(configs, meta=None):
 
 
 def _choice(name, default, allowed, what):
-    """An integer kernel-variant knob from the environment, checked HERE against what the product library dispatches (ABI 6): a stale
-    value used to surface as 'unknown kernel variant' from inside the first launch, mid-forward or mid-backward."""
-    v = int(os.environ.get(name, str(default)))
+    """An integer kernel-variant knob from the environment, checked HERE against what the product library dispatches (ABI 6).  A stale value
+    (a twin that left the product library) used to surface as 'unknown kernel variant' from inside the first launch; raising at import
+    instead made the WHOLE package unimportable for it -- inference paths that never touch the knob included.  Now: a warning,
+    and the default."""
+    raw = os.environ.get(name)
+    if raw is None:
+        return default
+    try:
+        v = int(raw)
+    except ValueError:
+        v = None
     if v not in allowed:
-        raise ValueError(f"{name}={v}: {what} dispatches {sorted(allowed)} (the measured-and-rejected generations live in the diagnostics library; the scripts/ loader)")
+        import warnings
+        warnings.warn(f"{name}={raw!r} ignored: {what} dispatches {sorted(allowed)} (the measured-and-rejected generations live in the diagnostics "
+                      f"library; the scripts/ loader) -- using {default}", RuntimeWarning, stacklevel=2)
+        return default
     return v
 
 
