@@ -32,7 +32,7 @@ extern "C" {
 #define TNV3_OK 0
 #define TNV3_E_INVALID (-1)   /* bad argument / unsupported shape */
 #define TNV3_E_LAUNCH (-2)    /* HIP launch error */
-#define TNV3_ABI_VERSION 6   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
+#define TNV3_ABI_VERSION 7   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
                                  3: `variant` argument on the Winograd-form weight gradients;
                                  4: `sum_order` on tnv3_ensemble_frames (the reference's summation order, bit-exact); `variant` on the
                                     9-GEMM decoder kernels; the fused InpaintNet training entries; tnv3_conv3x3_wino_pick / _has_stats /
@@ -43,7 +43,9 @@ extern "C" {
                                     generations (tnv3_conv3x3_wino_forward 0 / 2 / 4, tnv3_conv3x3_wgrad_wino 0 / 3 / 4 / 6 / 7) left the
                                     product library: they are refused here and stay dispatchable in libtnv3_diag.so;
                                  6: `up_variant` on tnv3_conv3x3_wgrad_up2x (the upsampled half's 25-of-36 F(4x4) weight gradient), `variant` 2
-                                    on tnv3_dgrad_up2x_wino (its data gradient on the 16x16x4 kernel) */
+                                    on tnv3_dgrad_up2x_wino (its data gradient on the 16x16x4 kernel);
+                                 7: tnv3_conv3x3_wino43_dgrad_bnstats (the F(4x4) data gradient that takes the previous block's BatchNorm-backward
+                                    sums from its write-out) */
 
 typedef void* tnv3_stream_t;
 
@@ -165,6 +167,17 @@ int tnv3_conv3x3_wino43_forward(const float* src, const float* u, const float* a
 long tnv3_conv3x3_wino43_stats_tiles(int n, int h, int w, int variant);
 int tnv3_conv3x3_wino43_forward_stats(const float* src, const float* u, const float* addend, float* dst, double* tile_stats, int n, int cin,
                                       int cout, int h, int w, int variant, tnv3_stream_t stream);
+
+/* ABI 7.  The data gradient of a plain layer in that form -- da = conv3x3(dz, W^T flipped), u_t = the transposed, flipped panel
+ * (tnv3_conv3x3_wino43_pack with transpose_flip) -- that ALSO takes, from the registers it writes da from, the two sums of the PREVIOUS
+ * Conv2DBlock's BatchNorm + ReLU backward (autograd of model.py:9-10; train.py:95): tile_stats[cout][tiles][2] = per channel and pixel tile
+ * (tiles = tnv3_conv3x3_wino43_stats_tiles) sum g and sum g * xhat, g = da * [BN(z) > 0] with the forward's own expression, xhat = (z - mean) *
+ * invstd; bn_z = that block's raw convolution output [n][cout][h][w], bn_mean / bn_invstd = its saved batch statistics, bn_gamma / bn_beta its
+ * affine.  Feed da and the sums to tnv3_bn_relu_backward_tiles: the separate pass over (da, z) that tnv3_bn_relu_backward would make for the
+ * sums is gone.  The F(4x4) twin of tnv3_conv3x3_wino_dgrad_bnstats; da bit-identical to tnv3_conv3x3_wino43_forward's.  Variants 0 / 2. */
+int tnv3_conv3x3_wino43_dgrad_bnstats(const float* dz, const float* u_t, float* da, double* tile_stats, const float* bn_z, const float* bn_mean,
+                                      const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int n, int cin, int cout, int h, int w,
+                                      int variant, tnv3_stream_t stream);
 
 int tnv3_conv3x3_wino_forward(const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                               const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant,

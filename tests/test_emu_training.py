@@ -445,6 +445,43 @@ def test_bn_backward_sums_from_the_data_gradient_epilogue_emulated(emu, monkeypa
     _bn_bwd_epilogue_case(case, "cpu")
 
 
+# (n, cin = the next block's Cout, cout = this block's channels, h, w): 128 -> the 128-channel geometry, 64 -> the 64-channel one (two tile
+# rows per workgroup; h = 12: a half-empty last tile row), several tiles per workgroup
+BN_BWD_EPILOGUE43_CASES = [(2, 16, 128, 8, 64), (1, 32, 64, 12, 128), (2, 64, 64, 4, 64)]
+
+
+def _bn_bwd_epilogue43_case(case, device):
+    """VERDICT r5 #3 -- the F(4x4) twin: conv3x3_wino43_dgrad_bnstats + bn_relu_backward_tiles == conv3x3_wino43 + bn_relu_backward: the same dA
+    bits, the same mask expression, the same fp64 accumulation of the two sums in another order (per 4 x 64 pixel tile, then the tiles)."""
+    from tracknetv3_amd import ops
+    n, cin, cout, h, w = case
+    dz_next, wt = T((n, cin, h, w), 711).to(device), T((cin, cout, 3, 3), 712, -0.3, 0.3).to(device)   # weight of the NEXT block: [Cout_next = cin][cout]
+    z = T((n, cout, h, w), 713, -1.0, 1.0).to(device)
+    gamma, beta = T((cout,), 714, 0.5, 1.5).to(device), T((cout,), 715, -0.3, 0.3).to(device)
+    mean = z.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(z.var((0, 2, 3), unbiased=False) + 1e-5)
+    u_t = ops.pack_wino43_weights(wt, transpose_flip=True)
+    da_ref = ops.conv3x3_wino43(dz_next, u_t, cout)
+    dz_ref, dg_ref, db_ref = ops.bn_relu_backward(da_ref.clone(), None, z, gamma, mean, invstd, beta=beta)
+    da, st = ops.conv3x3_wino43_dgrad_bnstats(dz_next, u_t, cout, z, mean, invstd, gamma, beta)
+    assert torch.equal(da, da_ref)
+    assert tuple(st.shape) == (cout, n * (h // 4) * (w // 64), 2)
+    scale = max(da.abs().sum((0, 2, 3)).max().item(), 1.0)
+    assert (st.sum(1)[:, 0] - db_ref.double()).abs().max().item() <= 2e-6 * scale
+    assert (st.sum(1)[:, 1] - dg_ref.double()).abs().max().item() <= 2e-6 * scale
+    dz2, dg2, db2 = ops.bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, st)
+    assert rel_err(dg2, dg_ref) <= 1e-6 and rel_err(db2, db_ref) <= 1e-6 and rel_err(dz2, dz_ref) <= 1e-6
+    da3, st3 = ops.conv3x3_wino43_dgrad_bnstats(dz_next, u_t, cout, z, mean, invstd, gamma, beta)      # deterministic
+    assert torch.equal(da3, da_ref) and torch.equal(st3, st)                                           # (da itself was turned into dZ in place above)
+
+
+@pytest.mark.parametrize("cus", [8, 2])
+@pytest.mark.parametrize("case", BN_BWD_EPILOGUE43_CASES)
+def test_bn_backward_sums_from_the_f43_data_gradient_epilogue_emulated(emu, monkeypatch, case, cus):
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+    _bn_bwd_epilogue43_case(case, "cpu")
+
+
 def _inpaint_train_grads(net, coor, mask, gt):
     for p in net.parameters():
         p.grad = None

@@ -521,3 +521,12 @@ def test_bn_backward_sums_from_the_data_gradient_epilogue(gpu_device, case):
     """The data-gradient launch that also takes BatchNorm + ReLU backward's two sums (kernels 5 and 6) at small and network shapes."""
     from test_emu_training import _bn_bwd_epilogue_case
     _bn_bwd_epilogue_case(case, gpu_device)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 128, 8, 64), (1, 32, 64, 12, 128), (2, 64, 64, 288, 512), (2, 128, 128, 144, 256), (10, 256, 256, 72, 128),
+                                  (10, 512, 512, 36, 64)])
+def test_bn_backward_sums_from_the_f43_data_gradient_epilogue(gpu_device, case):
+    """the F(4x4) data-gradient launch that also takes the previous block's BatchNorm + ReLU backward sums from its write-out
+    (conv3x3_wino43s_kernel<.., STATS = 2>; the training default inside Double / Triple blocks) at small and network shapes, both geometries."""
+    from test_emu_training import _bn_bwd_epilogue43_case
+    _bn_bwd_epilogue43_case(case, gpu_device)

@@ -15,7 +15,7 @@ _c = ctypes
 _f32p = _c.c_void_p
 _lib = None
 _is_emulator = False
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Tnv3Error(RuntimeError):
@@ -69,6 +69,7 @@ def _declare(lib):
     sig("tnv3_conv3x3_wino43_forward", i, p, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino43_stats_tiles", lg, i, i, i, i)
     sig("tnv3_conv3x3_wino43_forward_stats", i, p, p, p, p, p, i, i, i, i, i, i, p)
+    sig("tnv3_conv3x3_wino43_dgrad_bnstats", i, p, p, p, p, p, p, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_forward", i, p, p, p, p, p, p, p, i, i, i, i, i, i, i, p)
     sig("tnv3_conv3x3_wino_stats_tiles", lg, i, i, i, i)
     sig("tnv3_conv3x3_wino_forward_stats", i, p, p, p, p, p, i, i, i, i, i, i, p)
@@ -150,7 +151,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_conv3x3_wino_stats_tiles", "tnv3_conv3x3_wino_forward_stats", "tnv3_bn_train_forward_tiles",
            "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_layout", "tnv3_conv3x3_wino_has_stats", "tnv3_conv3x3_wino_pick", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_pack_multi", "tnv3_conv3x3_wino_forward",
            "tnv3_conv3x3_wino43_supported", "tnv3_conv3x3_wino43_packed_floats", "tnv3_conv3x3_wino43_pack", "tnv3_conv3x3_wino43_forward",
-           "tnv3_conv3x3_wino43_stats_tiles", "tnv3_conv3x3_wino43_forward_stats"]
+           "tnv3_conv3x3_wino43_stats_tiles", "tnv3_conv3x3_wino43_forward_stats", "tnv3_conv3x3_wino43_dgrad_bnstats"]
 
 
 def library_path():

@@ -151,6 +151,7 @@ def _train_backward_body(ctx, dev, head_backward):
 
     side = wgrad_stream(dev)
     main = torch.cuda.current_stream(dev) if side is not None else None
+    side_results = []                                      # [(tensor made on the side stream, its completion event)]
     if dev.type == "cuda":
         _BACKWARD_STREAMS[dev.index if dev.index is not None else 0] = \
             [torch.cuda.current_stream(dev)] + ([side] if side is not None else [])
@@ -223,13 +224,29 @@ def _train_backward_body(ctx, dev, head_backward):
             else:
                 g_low, w_skip_t = blk.packed_dgrad_up2x(c0)
                 d_low = ops.dgrad_up2x(dz, g_low, c0)
-            if skip_wino and tuning.use_wino43_dgrad(blk.conv.out_dim, c1, int(h), int(w)):
-                d_skip = ops.conv3x3_wino43(dz, blk.packed_wino43_t(c0), c1)
-            elif skip_wino:
-                d_skip = ops.conv3x3_wino(dz, blk.packed_wino_t(c0), c1)
-            else:
+            def skip_dgrad():
+                if skip_wino and tuning.use_wino43_dgrad(blk.conv.out_dim, c1, int(h), int(w)):
+                    return ops.conv3x3_wino43(dz, blk.packed_wino43_t(c0), c1)
+                if skip_wino:
+                    return ops.conv3x3_wino(dz, blk.packed_wino_t(c0), c1)
                 cfg = tuning.conv_config(c1, blk.conv.out_dim, int(n), int(h), int(w))
-                d_skip, _ = ops.conv3x3_dgrad(dz, w_skip_t, c1, 0, cfg=cfg)
+                return ops.conv3x3_dgrad(dz, w_skip_t, c1, 0, cfg=cfg)[0]
+
+            if side is not None and tuning.DSKIP_SIDE:
+                # off the critical chain: the skip half's gradient is consumed by the max-pool backward of the matching down block, several
+                # layers later -- it runs on the side stream (behind this entry's weight gradient; dZ is kept alive for it like for that)
+                if skip_wino:                              # (the filter panel is built on the main stream, where the optimiser changed the weights)
+                    (blk.packed_wino43_t if tuning.use_wino43_dgrad(blk.conv.out_dim, c1, int(h), int(w)) else blk.packed_wino_t)(c0)
+                packed = torch.cuda.Event()
+                packed.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(packed)
+                    d_skip = skip_dgrad()
+                    done_ev = torch.cuda.Event()
+                    done_ev.record(side)
+                side_results.append((d_skip, done_ev))
+            else:
+                d_skip = skip_dgrad()
             return d_low, d_skip, None
         if c1 == 0 and not rec["up"] and tuning.use_winograd(blk.conv.out_dim, c0, int(h), int(w)):
             # plain layer: dX = conv3x3(dZ, W^T flipped) is itself a plain 3x3 convolution -> the Winograd kernel
@@ -240,6 +257,14 @@ def _train_backward_body(ctx, dev, head_backward):
                 dx, st = ops.conv3x3_wino_dgrad_bnstats(dz, blk.packed_wino_t(), c0, producer["z"], c4)
                 return dx, None, st
             if tuning.use_wino43_dgrad(blk.conv.out_dim, c0, int(h), int(w)):
+                if (producer is not None and tuning.BN_BWD_STATS_IN_DGRAD43 and bn_unchanged(producer) and producer["z"].shape[1] == c0
+                        and ops.wino43_variant(None) != 1):
+                    # round 6: this launch's write-out also takes the PRODUCER block's two BatchNorm-backward sums (it reads that block's z beside
+                    # the dA it writes): the separate sums pass over (dA, z) is gone, one pass (the apply) is left
+                    pb = producer["blk"].bn
+                    dx, st = ops.conv3x3_wino43_dgrad_bnstats(dz, blk.packed_wino43_t(), c0, producer["z"], producer["mean"], producer["invstd"],
+                                                              pb.weight.detach(), pb.bias.detach())
+                    return dx, None, st
                 return ops.conv3x3_wino43(dz, blk.packed_wino43_t(), c0), None, None
             return ops.conv3x3_wino(dz, blk.packed_wino_t(), c0), None, None
         if c1 == 0 and c0 % 64:
@@ -256,6 +281,17 @@ def _train_backward_body(ctx, dev, head_backward):
 
     x1, x2, x3 = ctx.skips
     idx = len(saved) - 1
+
+    def from_side(t):
+        """A tensor the side stream produced (a skip half's data gradient): the main stream waits for its event before reading it; the tensor was
+        allocated on the side stream's pool and is handed to main-stream work, so the allocator is told."""
+        for k, (ts, ev) in enumerate(side_results):
+            if ts is t:
+                main.wait_event(ev)
+                t.record_stream(main)
+                del side_results[k]
+                break
+        return t
 
     def chain_bwd(count, da, first_needs_dx=True):
         nonlocal idx
@@ -275,11 +311,11 @@ def _train_backward_body(ctx, dev, head_backward):
     da, d_x2 = chain_bwd(2, da)                        # up_block_2      low-resolution operand of nn.Upsample directly)
     da, d_x3 = chain_bwd(3, da)                        # up_block_1
     d_pool3, _ = chain_bwd(3, da)                      # bottleneck -> gradient of pool(x3)
-    da = ops.maxpool2x2_backward_add(x3, d_pool3, d_x3)
+    da = ops.maxpool2x2_backward_add(x3, d_pool3, from_side(d_x3))
     d_pool2, _ = chain_bwd(3, da)                      # down_block_3
-    da = ops.maxpool2x2_backward_add(x2, d_pool2, d_x2)
+    da = ops.maxpool2x2_backward_add(x2, d_pool2, from_side(d_x2))
     d_pool1, _ = chain_bwd(2, da)                      # down_block_2
-    da = ops.maxpool2x2_backward_add(x1, d_pool1, d_x1)
+    da = ops.maxpool2x2_backward_add(x1, d_pool1, from_side(d_x1))
     dx, _ = chain_bwd(2, da, first_needs_dx=ctx.need_dx)   # down_block_1
     if side is not None:
         main.wait_stream(side)                                   # every weight gradient is final for whoever comes next

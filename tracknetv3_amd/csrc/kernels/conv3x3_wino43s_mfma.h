@@ -315,6 +315,7 @@ template <int CBW, int STATS = 0, int GROW = 10, int TS = 10, int TL = 0, int DG
 __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const WinoArgs a) {
   using Cfg = Wino43SCfg<CBW, MODE>;
   static_assert(MODE == 0 || (STATS == 0 && POOL == 0), "the upsampled half (and its data gradient) write plain sums");
+  static_assert(STATS >= 0 && STATS <= 2 && (STATS != 2 || POOL == 0), "STATS: 0 none, 1 BatchNorm forward statistics, 2 BatchNorm backward sums (data gradient)");
   constexpr bool LOW = Cfg::LOW;
   constexpr int SC = Cfg::SC, KB = Cfg::KB, NP = Cfg::NP, NV = Cfg::NV, NSLOT = 2 * NP, PAIRS = Cfg::PAIRS, NXI = Cfg::NXI;
   constexpr int NT = Cfg::NT, MB = Cfg::MB, V_STAGE = Cfg::V_STAGE, RAW_STAGE = Cfg::RAW_STAGE, V_PAIR = Cfg::V_PAIR;
@@ -789,7 +790,13 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-    const tnv3_rsrc_t r_add = tnv3_make_rsrc(has_addend ? a.addend + plane0 : a.dst + plane0, planes_b);
+    // STATS == 2 (round 6): a DATA-GRADIENT launch whose outputs are dA, the gradient at the activation of the previous Conv2DBlock, and which also
+    // takes that block's two BatchNorm + ReLU backward sums (model.py:9-10) from the registers it writes dA from: bn_z = that block's raw
+    // convolution output (read here like an addend: four 16-byte rows per channel), per channel mean / invstd / gamma / beta in a.mean /
+    // a.scale / a.shift / a.bn_c4.  g = dA [BN(z) > 0] with the forward's own expression (bit-identical mask), xhat = (z - mean) invstd --
+    // bn_relu_bwd_partial_kernel's arithmetic, element for element; only the order of the fp64 sums differs (per tile, then the tiles in order).
+    constexpr bool BNB = STATS == 2;
+    const tnv3_rsrc_t r_add = tnv3_make_rsrc(BNB ? a.bn_z + plane0 : (has_addend ? a.addend + plane0 : a.dst + plane0), planes_b);
     const unsigned lane_off_b = oh < H ? (unsigned)((4 * g) * HW + oh * W + ow) * 4u : kDmaOob;      // (a tile row below the image: loads give 0, stores are dropped)
     // MaxPool2d(2, 2) of the block as a second output (the down blocks' last layers): a lane's 4x4 pixels are 2x2 pooled ones
     constexpr bool has_pool = POOL != 0;               // (its own instantiation: the descriptor and the kept row would cost the plain kernel spills)
@@ -822,6 +829,12 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         }
       };
       if constexpr (AFF) load_consts(0);
+      float b_mu_n = 0.0f, b_is_n = 0.0f, b_ga_n = 0.0f, b_be_n = 0.0f;      // STATS == 2: the previous block's BatchNorm constants, one channel ahead
+      auto load_bn_consts = [&](int r) {
+        const int ch = e_m0 + 4 * g + r;
+        b_mu_n = a.mean[ch]; b_is_n = a.scale[ch]; b_ga_n = a.shift[ch]; b_be_n = a.bn_c4[ch];
+      };
+      if constexpr (BNB) load_bn_consts(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const unsigned ch_b = (unsigned)r * (unsigned)HW * 4u;
@@ -829,8 +842,12 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         if constexpr (AFF) {
           if (r < 3) load_consts(r + 1);
         }
+        const float b_mu = b_mu_n, b_is = b_is_n, b_sc = (float)((double)b_ga_n * (double)b_is_n), b_be = b_be_n;      // (bn_scale: the forward's rounding)
+        if constexpr (BNB) {
+          if (r < 3) load_bn_consts(r + 1);
+        }
         f32x4 ad[4];
-        if (has_addend) {
+        if (BNB || has_addend) {
 #pragma unroll
           for (int ar = 0; ar < 4; ++ar) ad[ar] = tnv3_buf_load_f4(r_add, lane_off_b, ch_b + (unsigned)(ar * W) * 4u);
         }
@@ -848,7 +865,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
           float o[4];
           wino43s_at6(wv[ar][0], wv[ar][1], wv[ar][2], wv[ar][3], wv[ar][4], wv[ar][5], o);
           f32x4 v = {o[0], o[1], o[2], o[3]};
-          if (has_addend) {
+          if (!BNB && has_addend) {
             TNV3_NO_IF_CONVERSION();                     // a real scalar branch: as a select the four adds cost four more instructions per row
             v += ad[ar];
           }
@@ -858,9 +875,18 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
           }
           tnv3_buf_store_f4(r_dst, (DG & 32) ? kDmaOob : lane_off_b, ch_b + (unsigned)(ar * W) * 4u, v);
           if (has_pool) pool_store(ar, ch_b, v, pv);
-          if constexpr (STATS) {
+          if constexpr (STATS == 1) {
             s1 += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
             s2 += ((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1]) + ((double)v[2] * (double)v[2] + (double)v[3] * (double)v[3]);
+          }
+          if constexpr (BNB) {
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) {
+              const float zc = ad[ar][b2] - b_mu;
+              const float gk = fmaf(zc, b_sc, b_be) > 0.0f ? v[b2] : 0.0f;
+              s1 += (double)gk;
+              s2 += (double)gk * (double)(zc * b_is);
+            }
           }
         }
         if constexpr (STATS) {

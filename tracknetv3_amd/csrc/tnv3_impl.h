@@ -646,13 +646,20 @@ inline bool conv3x3_wino43s_wide(int cout, int variant) { return variant == 0 &&
 template <class Launcher>
 int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, const float* addend, const float* mean, const float* scale,
                                 const float* shift, float* dst, int n, int cin, int cout, int h, int w, int relu, int variant, double* stats = nullptr,
-                                float* pool_dst = nullptr) {
+                                float* pool_dst = nullptr, const float* bn_z = nullptr, const float* bn_beta = nullptr) {
+  // bn_z (round 6): the launch is a DATA GRADIENT that also takes the previous block's BatchNorm + ReLU backward sums from its write-out
+  // (conv3x3_wino43s_kernel<.., STATS = 2>): mean / scale / shift then carry that block's saved mean / invstd / gamma, bn_beta its beta.
   if (!src || !u || !dst || n <= 0) TNV3_FAIL(-1, "conv3x3_wino43: bad argument");
+  if (bn_z) {
+    if (!stats || !mean || !scale || !shift || !bn_beta || addend || pool_dst || relu || variant == 1)
+      TNV3_FAIL(-1, "conv3x3_wino43 (BatchNorm-backward sums): needs the sums' buffer, mean / invstd / gamma / beta, and no addend / pool / ReLU (kernel variants 0 / 2)");
+    if (((uintptr_t)bn_z & 15) || ((uintptr_t)bn_beta & 3)) TNV3_FAIL(-1, "conv3x3_wino43 (BatchNorm-backward sums): z must be 16-byte aligned, beta 4-byte");
+  }
   if (pool_dst && (variant == 1 || stats)) TNV3_FAIL(-1, "conv3x3_wino43: the pooled second output belongs to kernel variants 0 / 2 without statistics");
   if (pool_dst && (((uintptr_t)pool_dst) & 7)) TNV3_FAIL(-1, "conv3x3_wino43: the pooled output must be 8-byte aligned");
   if (variant < 0 || variant >= kWino43Variants) TNV3_FAIL(-1, "conv3x3_wino43: unknown kernel variant %d", variant);
   if (variant == 1 && !kTwins) TNV3_FAIL(-1, "conv3x3_wino43: kernel variant 1 (32x32x2) is a measurement twin of libtnv3_diag.so since ABI 6 (dispatchable: 0, 2)");
-  if (stats && (scale || shift || mean || relu)) TNV3_FAIL(-1, "conv3x3_wino43: the batch-statistics epilogue writes the raw convolution (no affine, no ReLU)");
+  if (stats && !bn_z && (scale || shift || mean || relu)) TNV3_FAIL(-1, "conv3x3_wino43: the batch-statistics epilogue writes the raw convolution (no affine, no ReLU)");
   if (stats && (((uintptr_t)stats) & 7)) TNV3_FAIL(-1, "conv3x3_wino43: statistics buffer must be 8-byte aligned");
   if (!conv3x3_wino43_supported(cin, cout, h, w))
     TNV3_FAIL(-1, "conv3x3_wino43: needs Cout %% 64 == 0, H %% 4 == 0, W %% 64 == 0 (got %d -> %d, %dx%d)", cin, cout, h, w);
@@ -666,12 +673,16 @@ int conv3x3_wino43_forward_impl(Launcher& L, const float* src, const float* u, c
   if ((((uintptr_t)mean | (uintptr_t)scale | (uintptr_t)shift) & (variant == 1 ? 15 : 3)) != 0)
     TNV3_FAIL(-1, "conv3x3_wino43: mean / scale / shift must be 4-byte aligned");
   if (conv3x3_wino43_packed_floats_v(cin, cout, variant) * 4 >= (1ul << 31)) TNV3_FAIL(-1, "conv3x3_wino43: the filter panel must stay below 2 GiB");
-  WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, nullptr, nullptr, pool_dst};
+  WinoArgs a{src, u, u, addend, mean, scale, shift, dst, n, cin, cout, h, w, relu ? 1 : 0, stats, bn_z, bn_beta, pool_dst};
   if (variant != 1) {
     const bool wide = conv3x3_wino43s_wide(cout, variant);
     const long npt = wide ? (long)n * (h / 4) * (w / 64) : (long)n * ((h + 7) / 8) * (w / 64);
     if (npt > (1l << 28)) TNV3_FAIL(-1, "conv3x3_wino43: too many pixel tiles");
     const int grid = wino_persistent_grid(conv_grid_blocks(cout / (wide ? 128 : 64), (int)npt));
+    if (bn_z) {
+      if (wide) return L.launch(conv3x3_wino43s_kernel<8, 2, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
+      return L.launch(conv3x3_wino43s_kernel<4, 2, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
+    }
     if (wide) {
       if (stats) return L.launch(conv3x3_wino43s_kernel<8, 1, kWino43SGrow, kWino43STs>, grid, Wino43SBase::NT, a);
       if (pool_dst) return L.launch(conv3x3_wino43s_kernel<8, 0, kWino43SGrow, kWino43STs, 0, 0, 1>, grid, Wino43SBase::NT, a);

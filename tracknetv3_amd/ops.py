@@ -706,6 +706,28 @@ def conv3x3_wino_dgrad_bnstats(dz, u, cout, bn_z, bn_c4, variant=None):
     return da, stats
 
 
+def conv3x3_wino43_dgrad_bnstats(dz, u_t, cout, bn_z, bn_mean, bn_invstd, bn_gamma, bn_beta, variant=None):
+    """The F(4x4) data gradient dA = conv3x3(dZ, W^T flipped) that ALSO takes, from its write-out's registers, the two sums of the previous
+    block's BatchNorm + ReLU backward (tnv3_conv3x3_wino43_dgrad_bnstats, ABI 7): returns (dA, tile_stats (cout, tiles, 2) float64) -- feed
+    them to bn_relu_backward_tiles.  bn_z: that block's raw convolution output (the shape of dA); bn_mean / bn_invstd: its saved batch
+    statistics; bn_gamma / bn_beta: its affine.  dA is bit-identical to conv3x3_wino43(dz, u_t, cout)."""
+    lib = _lib.load()
+    _f32(dz, u_t, bn_z, bn_mean, bn_invstd, bn_gamma, bn_beta)
+    _lib.dev_check(dz, u_t, bn_z, bn_mean, bn_invstd, bn_gamma, bn_beta)
+    n, cin, h, w = (int(v) for v in dz.shape)
+    variant = wino43_variant(variant)
+    tiles = int(lib.tnv3_conv3x3_wino43_stats_tiles(n, h, w, variant))
+    if (tiles <= 0 or variant == 1 or u_t.numel() != lib.tnv3_conv3x3_wino43_packed_floats(cin, int(cout), variant)
+            or tuple(bn_z.shape) != (n, int(cout), h, w) or any(int(t.numel()) != int(cout) for t in (bn_mean, bn_invstd, bn_gamma, bn_beta))):
+        raise _lib.Tnv3Error("conv3x3_wino43_dgrad_bnstats: unsupported shape, filter panel, z or per-channel constants mismatch")
+    da = torch.empty((n, int(cout), h, w), dtype=torch.float32, device=dz.device)
+    stats = torch.empty((int(cout), tiles, 2), dtype=torch.float64, device=dz.device)
+    _lib.check(lib.tnv3_conv3x3_wino43_dgrad_bnstats(_lib.ptr(dz), _lib.ptr(u_t), _lib.ptr(da), _lib.ptr(stats), _lib.ptr(bn_z), _lib.ptr(bn_mean),
+                                                     _lib.ptr(bn_invstd), _lib.ptr(bn_gamma), _lib.ptr(bn_beta), n, cin, int(cout), h, w, int(variant),
+                                                     _lib.stream_ptr(dz)))
+    return da, stats
+
+
 def bn_relu_backward_tiles(da, z, gamma, beta, mean, invstd, tile_stats, inplace=True, out=None):
     """bn_relu_backward with the two per-channel sums already taken per pixel tile by conv3x3_wino_dgrad_bnstats: one pass over (dA, z).
     out: (dgamma, dbeta) destinations."""
@@ -1071,7 +1093,7 @@ def conv1d_k3_wgrad(src0, dpre, src1=None, src_nlc=False):
 # The C ABI runs a call on its stream's device, but a tensor's *default* stream is the NULL stream (= "the calling thread's
 # current device"), and the stream-less workspace queries plan for the current device too.  Every op therefore runs with the
 # device of its first GPU tensor current (a no-op check when it already is, i.e. always in single-device processes).
-_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pack_wino_weights_multi", "pack_wino43_weights", "conv3x3_wino43", "conv3x3_wino43_stats", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
+_TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pack_wino_weights_multi", "pack_wino43_weights", "conv3x3_wino43", "conv3x3_wino43_stats", "conv3x3_wino43_dgrad_bnstats", "conv3x3_wino", "conv3x3_wino_stats", "pack_up2x_weights", "conv_up2x", "pack_up2x_wino_weights", "conv_up2x_wino", "pack_dgrad_up2x_wino_weights", "dgrad_up2x_wino",
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "bn_bwd_consts", "conv3x3_wino_dgrad_bnstats", "bn_relu_backward_tiles", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",

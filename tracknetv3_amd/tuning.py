@@ -94,7 +94,19 @@ def use_wino43_dgrad(cin, cout, h, w):
 WINO43_TRAIN = os.environ.get("TNV3_WINO43_TRAIN", "1") != "0"
 
 
+# ... and at WHICH resolution levels (rows of the layer's output): round 5 measured what the F(4x4) forward at one level only adds to the
+# training-mode heat-map error (1.4 / 1.1 / 1.0 / 0.4e-5 at 288 / 144 / 72 / 36 rows over F(2x2)'s 1.6e-5, gain 2.4); round 6 drew the Pareto of
+# error against milliseconds over all 16 subsets (tests/studies/train_precision_pareto.py, profiles/r06_train_precision_pareto.json) and the
+# default is the cheapest subset with a 2x margin under the 1e-4 bar at a trained-like logit range (<= 3.5e-5 at head gain 2.4, <= 5e-5 at 4).
+# TNV3_WINO43_TRAIN_LEVELS="288,144,72,36": everywhere (round 4 / 5's default); "": nowhere (= TNV3_WINO43_TRAIN=0).  Levels of other image
+# sizes (a 64x128 test network: 64 / 32 / 16 / 8 rows) are not in the set and take F(4x4) -- the set names where it is NOT trusted at full size.
+_ALL_LEVELS_288 = (288, 144, 72, 36)
+WINO43_TRAIN_LEVELS = frozenset(int(v) for v in os.environ.get("TNV3_WINO43_TRAIN_LEVELS", "288,144,72,36").split(",") if v.strip())
+
+
 def use_wino43_train(cin, cout, h, w):
+    if int(h) in _ALL_LEVELS_288 and int(h) not in WINO43_TRAIN_LEVELS:
+        return False
     return WINO43_TRAIN and BN_STATS_IN_EPILOGUE and use_wino43(cin, cout, h, w)
 
 
@@ -147,6 +159,11 @@ WGRAD_WINO_TAIL = int(os.environ.get("TNV3_WGRAD_WINO_TAIL", "0"))
 # stream's when CUs free up).  Measured (scripts/train_prio_ab.sh): 31.59 / 31.73 ms per step at 0, 31.75 / 31.59 at -1 -- no effect:
 # both streams are saturated (profiles/r03_train_timeline.json), priority only reorders who waits.
 WGRAD_STREAM_PRIORITY = int(os.environ.get("TNV3_WGRAD_STREAM_PRIORITY", "0"))
+# The data gradient of a decoder entry's SKIP half (d_x3 / d_x2 / d_x1) is not on backward's critical chain: its consumer is the max-pool
+# backward of the matching down block, three to nine layers later.  With the round-6 weight-gradient kernels the side stream has slack, so
+# these three launches (~0.9 ms of MFMA time at 288x512, batch 10) run there, behind the entry's weight gradient.  TNV3_DSKIP_SIDE=0: on the
+# main stream, as before.
+DSKIP_SIDE = os.environ.get("TNV3_DSKIP_SIDE", "1") != "0"
 
 
 # Kernel-family choices are per-call arguments of the C ABI (no process-wide state inside the library); these are the
@@ -224,6 +241,12 @@ UP2X_WINO_VARIANT_TRAIN = _choice("TNV3_UP2X_WINO_VARIANT_TRAIN", 0, {-1, 0, 1, 
 # MFMA kernel's epilogue (which nothing overlaps: one workgroup fills the CU) more than the HBM-bound pass they replace, which runs
 # beside the other stream's kernels.  Default OFF; TNV3_BN_BWD_STATS_IN_DGRAD=1 switches it on.
 BN_BWD_STATS_IN_DGRAD = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD", "0") == "1"
+# The same fusion on the F(4x4) 16x16x4 kernel (round 6; conv3x3_wino43s_kernel<.., STATS = 2>, tnv3_conv3x3_wino43_dgrad_bnstats): there the
+# write-out is per-lane register arithmetic (no LDS exchange), the z rows are read like an addend's, and since the round-6 weight gradients the
+# MAIN stream's chain (BatchNorm backward -> data gradient -> ...) is what bounds the step -- the sums pass sits on it, the epilogue's extra
+# vector work costs 1-3 % of a data-gradient launch from 128 channels up (13 % on the two 64-channel launches).  Applies to the 10 of the 17 layers
+# whose input is the previous layer's activation (inside a Double / Triple block).  TNV3_BN_BWD_STATS_IN_DGRAD43=0: the separate sums pass.
+BN_BWD_STATS_IN_DGRAD43 = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD43", "1") != "0"
 
 
 def wino_has_stats():
