@@ -260,36 +260,46 @@ def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
     """The training path recomputes the ReLU mask from z with the forward's gamma / beta; if a BN parameter was modified in
     place between forward and backward (version counter moved) it must take the mask from the saved activation instead.
     Both routes are bit-identical when the values did not change."""
-    from tracknetv3_amd import ops
+    from tracknetv3_amd import ops, tuning
     from tracknetv3_amd.utils.general import get_model
     from tracknetv3_amd.utils.metric import WBCELoss
     x = nets.synth_input((2, 9, 32, 64), 5).to(gpu_device)
     y = nets.disc_heatmaps(2, 3, 32, 64, 6).to(gpu_device)
     sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 21, calibrated=True)
-    grads, calls = [], []
-    real = ops.bn_relu_backward
+    real, real_tiles, real_fused = ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43
+    for fused in (False, True):      # the sums by their own pass / (round 6) from the F(4x4) data gradient's write-out where a layer's input is the previous activation
+        grads, calls, tiles = [], [], []
 
-    def spy(da, a, *args, **kw):
-        calls.append(a is None)
-        return real(da, a, *args, **kw)
+        def spy(da, a, *args, **kw):
+            calls.append(a is None)
+            return real(da, a, *args, **kw)
 
-    ops.bn_relu_backward = spy
-    try:
-        for bump in (False, True):
-            m = get_model("TrackNet", 3, "")
-            m.load_state_dict(sd, strict=True)
-            m = m.to(gpu_device).train()
-            loss = WBCELoss(m(x), y)
-            if bump:
-                with torch.no_grad():
-                    m.down_block_1.conv_1.bn.bias.add_(0.0)          # same values, new version
-            calls.clear()
-            loss.backward()
-            assert calls.count(False) == (1 if bump else 0) and len(calls) == 17
-            grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
-    finally:
-        ops.bn_relu_backward = real
-    assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
+        def spy_tiles(*args, **kw):
+            tiles.append(1)
+            return real_tiles(*args, **kw)
+
+        ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43 = spy, spy_tiles, fused
+        try:
+            for bump in (False, True):
+                m = get_model("TrackNet", 3, "")
+                m.load_state_dict(sd, strict=True)
+                m = m.to(gpu_device).train()
+                loss = WBCELoss(m(x), y)
+                if bump:
+                    with torch.no_grad():
+                        m.down_block_1.conv_1.bn.bias.add_(0.0)          # same values, new version
+                calls.clear(); tiles.clear()
+                loss.backward()
+                # a bumped block never takes the fused route (its mask could not be recomputed from z): it goes through the plain pass, mask from a
+                assert calls.count(False) == (1 if bump else 0) and len(calls) + len(tiles) == 17, (fused, bump, calls, len(tiles))
+                assert (len(tiles) > 0) == fused
+                grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+        finally:
+            ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43 = real, real_tiles, real_fused
+        if not fused:
+            assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
+        else:       # the bumped block's two sums are added in another fp64 order (its own pass instead of per-tile partials): equal to the last bits
+            assert max(rel_err(grads[1][k].cpu(), grads[0][k].cpu()) for k in grads[0]) <= 2e-6
 
 
 def test_mixup_with_reference_rng_protocol(gpu_device):

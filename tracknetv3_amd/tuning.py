@@ -161,9 +161,10 @@ WGRAD_WINO_TAIL = int(os.environ.get("TNV3_WGRAD_WINO_TAIL", "0"))
 WGRAD_STREAM_PRIORITY = int(os.environ.get("TNV3_WGRAD_STREAM_PRIORITY", "0"))
 # The data gradient of a decoder entry's SKIP half (d_x3 / d_x2 / d_x1) is not on backward's critical chain: its consumer is the max-pool
 # backward of the matching down block, three to nine layers later.  With the round-6 weight-gradient kernels the side stream has slack, so
-# these three launches (~0.9 ms of MFMA time at 288x512, batch 10) run there, behind the entry's weight gradient.  TNV3_DSKIP_SIDE=0: on the
-# main stream, as before.
-DSKIP_SIDE = os.environ.get("TNV3_DSKIP_SIDE", "1") != "0"
+# these three launches (~0.9 ms of MFMA time at 288x512, batch 10) CAN run there, behind the entry's weight gradient (TNV3_DSKIP_SIDE=1).
+# Measured and rejected as a default (profiles/r06_train_step_ab.txt, two repeats in one session): 22.04 / 22.60 ms with it, 21.81 / 21.91
+# without -- the side stream's MFMA kernels take CUs from the main chain's, and the chain does not get shorter by what moved.
+DSKIP_SIDE = os.environ.get("TNV3_DSKIP_SIDE", "0") == "1"
 
 
 # Kernel-family choices are per-call arguments of the C ABI (no process-wide state inside the library); these are the
