@@ -641,12 +641,13 @@ def main():
     args = ap.parse_args()
     if args.share_gpus:
         args.backend = "gloo"
-        # TEST MODE only: eight processes on one device oversubscribe its hardware queues, and on this image that faults intermittently
-        # (DESIGN 5e).  Fewer queues per process: the weight gradients run on the main stream here (the product default -- and every run with
-        # one process per GPU -- keeps them on their side stream).
-        if os.environ.get("TNV3_WGRAD_OVERLAP") is None and args.gpus and args.gpus > 2:
-            from tracknetv3_amd import autograd_ops
-            autograd_ops.set_wgrad_overlap(False)
+        # TEST MODE only: more than two processes sharing one device oversubscribe its hardware queues (per process: main, weight-gradient,
+        # reducer and gloo's copy streams), and with the queues time-sliced this image loses stores of kernels in flight / aborts with an HSA
+        # illegal-instruction error at ~0.13 % of the rank-steps (7 of 5 544) (reproducer scripts/dp_soak.py; 0 faults in 8192 rank-steps
+        # with two hardware queues per process).  So the ranks of this mode run the PRODUCT's stream topology on two hardware queues each
+        # (HIP multiplexes the streams onto them); one process per GPU -- every real run -- keeps the runtime's default.
+        if args.gpus and args.gpus > 2:
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")      # read when the HIP runtime initialises: before the first device call; inherited by spawned ranks
     elif args.backend == "gloo":
         raise SystemExit("--backend gloo is only meaningful with --share-gpus (the product's collective path is RCCL)")
 
@@ -890,7 +891,7 @@ def main():
                        "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
                        "backend": (args.backend if world > 1 else None),
                        "shared_gpus": (f"TEST MODE: {world} ranks on {torch.cuda.device_count()} GPU(s) over gloo -- not a scaling measurement"
-                                       + ("; weight gradients on the main stream (fewer hardware queues per process)" if world > 2 else "")
+                                       + (f"; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')} per process (hardware-queue oversubscription: DESIGN 5e)" if world > 2 else "")
                                        if args.share_gpus else None),
                        "launcher": ("torch.distributed.run" if launched else "single process"),
                        "schedule": ("the batch's images split 6 : 4 over two HIP streams (product default, tuning.INFER_SPLIT): the halves' "

@@ -28,6 +28,12 @@ def _worker(rank, world, port, out, backend="gloo", batch=4, direct=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 2 and backend != "nccl":
+        # more than two processes SHARING one device oversubscribe its hardware queues; with the queues time-sliced this image loses stores of
+        # kernels in flight at ~0.13 % of the rank-steps (7 of 5 544) (scripts/dp_soak.py reproduces it; 0 faults in 8192 rank-steps with
+        # two hardware queues per process).  The ranks keep the PRODUCT's stream topology (side-stream weight gradients, reducer stream) and
+        # let HIP multiplex it onto two hardware queues -- set before this process's first device call.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     dev = torch.device("cuda", rank if backend == "nccl" else 0)      # RCCL: one GPU per rank; gloo: both ranks share cuda:0
     if backend == "nccl":
         torch.cuda.set_device(dev)
@@ -35,11 +41,6 @@ def _worker(rank, world, port, out, backend="gloo", batch=4, direct=True):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        if world > 2:
-            # eight processes on one device oversubscribe its hardware queues: fewer queues per process -- the weight gradients on
-            # the main stream (the data-parallel semantics under test do not depend on which stream a gradient kernel runs on)
-            from tracknetv3_amd import autograd_ops
-            autograd_ops.set_wgrad_overlap(False)
         from tracknetv3_amd.parallel import TrackNetTrainer, shard_range
         from tracknetv3_amd.utils.general import get_model
         sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 13, calibrated=True)

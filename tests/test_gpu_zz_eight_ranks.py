@@ -1,13 +1,19 @@
 """GPU (-m gpu), LAST file of the suite on purpose: BASELINE configs[2]'s rank count -- eight -- rehearsed on a box with ONE MI355X.
 
-Eight processes with three to five HIP streams each oversubscribe the device's hardware queues, and on this image that is not free of
-faults of its own: in round 5, 2 of 9 `bench.py --gpus 8 --share-gpus` runs ended with one process aborted by the HSA runtime
-(`HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION ... code: 0x2a`, after a ~50 s stall), and 1 of 7 eight-rank training steps had ONE rank's loss 2e-4
-off its shard's.  Neither happens with one or two processes (every other session of the round), nor in scripts/multiproc_soak.py (eight
-processes, 1056 steps on main + weight-gradient streams only, every tensor bit-identical: profiles/r05_multiproc_soak_*.json); the kernels read
-no unwritten memory (profiles/r05_train_poison_probe.json).  Everything points at wave save / restore under queue oversubscription, which a
-deployment (one process per GPU) never sees.  So: each test gets up to three attempts, every failed attempt is REPORTED (warning + report file)
-instead of hidden, and the file runs after everything else so that `-x` cannot let this rehearsal cut the parity suite short.
+What round 5 ran into here (one rank's loss 2e-4 off in 1 of 7 eight-rank steps, an `HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION ... code: 0x2a`
+abort in 2 of 9 rehearsals) was taken apart in round 6 (reproducers scripts/dp_soak.py, dp_soak_stock.py, forward_soak.py,
+idle_first_kernel_probe.py; tables profiles/r06_eight_process_fault.json):
+  * it needs eight processes SHARING the device with the full data-parallel stream set (main, weight-gradient, reducer and gloo's copy
+    streams: ~40 HIP hardware queues for the device to time-slice); forward-only (63 241 rank-steps), single-kernel-after-idle
+    (60 336) and gloo-free (45 600) eight-process soaks are clean, and so is the same topology running stock kernels only (4 112);
+  * the damage is always the same: whole output tiles of the FIRST kernel a rank launches after waiting for the others still hold what
+    that memory held before (the workgroup's early stores are missing, its later ones arrived), at 0.13 % of the rank-steps (7 of 5 544), plus the
+    occasional HSA abort; re-running the layer at once gives the right bits;
+  * with two hardware queues per process (GPU_MAX_HW_QUEUES=2: HIP multiplexes the same streams) it does not happen: 0 of 8 192 rank-steps.
+So the ranks of these tests run the PRODUCT's stream topology (side-stream weight gradients writing into the all-reduce buckets) on two
+hardware queues each (tests/test_gpu_dp.py::_worker, bench.py --share-gpus).  A NUMERIC deviation fails the test at once -- no retry
+(ADVICE r5); only a process that dies (the HSA abort) is retried, once, and reported.  One process per GPU -- every deployment, every other
+test -- never oversubscribes the queues and keeps the runtime's default.
 """
 import json
 import os
@@ -25,7 +31,7 @@ from test_gpu_dp import _free_port, _worker
 
 pytestmark = pytest.mark.gpu
 
-ATTEMPTS = 3
+ATTEMPTS = 2            # for a rank that DIES (HSA abort under queue oversubscription); a wrong number is never retried
 
 
 def _note(name, attempts):
@@ -71,22 +77,22 @@ def test_eight_rank_train_step_equals_sequential_eight_shard_oracle(gpu_device):
         mine, ref = np.array(mine), np.array(ref)
         assert mine.max() <= 3 * ref.max() + 2e-4 and np.median(mine) <= 3 * np.median(ref) + 1e-4, (mine.max(), ref.max(), np.median(mine), np.median(ref))
 
-    attempts = []
+    attempts, res = [], None
     for k in range(ATTEMPTS):
         try:
             with mp.Manager() as mgr:
                 out = mgr.dict()
                 mp.spawn(_worker, args=(world, _free_port(), out, "gloo", batch), nprocs=world, join=True)
                 res = [out[r] for r in range(world)]
-            check(res)
             attempts.append({"ok": True})
             break
-        except Exception as e:  # noqa: BLE001 -- reported below; the last attempt's failure is raised
+        except Exception as e:  # noqa: BLE001 -- a rank died (or raised): reported; retried once
             attempts.append({"ok": False, "error": f"{type(e).__name__}: {str(e)[:600]}"})
             if k == ATTEMPTS - 1:
                 _note("eight_rank_train_step", attempts)
                 raise
     _note("eight_rank_train_step", attempts)
+    check(res)                                   # numbers are checked ONCE: a deviation is a failure, not a reason to run again
 
 
 def test_bench_eight_rank_dress_rehearsal(gpu_device):
@@ -121,14 +127,9 @@ def test_bench_eight_rank_dress_rehearsal(gpu_device):
     attempts = []
     for k in range(ATTEMPTS):
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
-        try:
-            check(r)
-            attempts.append({"ok": True})
-            break
-        except AssertionError as e:
-            attempts.append({"ok": False, "returncode": r.returncode, "hsa_illegal_instruction": "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" in r.stderr,
-                             "error": str(e)[:600]})
-            if k == ATTEMPTS - 1:
-                _note("bench_eight_rank_rehearsal", attempts)
-                raise
+        died = r.returncode != 0 and ("HSA_STATUS_ERROR" in r.stderr or r.returncode < 0)
+        attempts.append({"ok": not died, "returncode": r.returncode, "hsa_illegal_instruction": "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" in r.stderr})
+        if not died or k == ATTEMPTS - 1:
+            break                                # only a rank that died (HSA abort) is run again; anything else is judged as it is
     _note("bench_eight_rank_rehearsal", attempts)
+    check(r)
