@@ -32,7 +32,7 @@ def main():
     real = tuning.use_wino43_train
 
     def run(tag, levels, up_variant=0):
-        tuning.use_wino43_train = (lambda cin, cout, hh, ww: hh in levels and real(cin, cout, hh, ww))
+        tuning.use_wino43_train = (lambda cin, cout, hh, ww, layer=None: hh in levels and real(cin, cout, hh, ww))
         tuning.UP2X_WINO_VARIANT_TRAIN = up_variant
         m = TrackNet(in_dim, out_dim)
         m.load_state_dict(sd, strict=True)

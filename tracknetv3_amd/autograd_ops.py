@@ -91,8 +91,8 @@ def _train_forward_body(net, x):
         w = src0.shape[3] * (2 if up else 1)
         stats = None           # BatchNorm's batch statistics taken in the conv epilogue (Winograd kernels 3 / 4), else a pass over z
         if up and src1 is not None:
-            z, stats = blk.conv_up_skip(src0, src1, int(n), relu=False, affine=False, want_stats=True)
-        elif src1 is None and not up and tuning.use_wino43_train(blk.conv.in_dim, blk.conv.out_dim, int(h), int(w)):
+            z, stats = blk.conv_up_skip(src0, src1, int(n), relu=False, affine=False, want_stats=True, layer=len(saved))
+        elif src1 is None and not up and tuning.use_wino43_train(blk.conv.in_dim, blk.conv.out_dim, int(h), int(w), layer=len(saved)):
             z, stats = ops.conv3x3_wino43_stats(src0, blk.packed_wino43(), blk.conv.out_dim)      # F(4x4, 3x3) + statistics epilogue
         elif src1 is None and not up and tuning.use_winograd(blk.conv.in_dim, blk.conv.out_dim, int(h), int(w)):
             if tuning.wino_has_stats():

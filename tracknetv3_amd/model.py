@@ -180,7 +180,7 @@ class Conv2DBlock(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
-    def conv_up_skip(self, x_low, skip, n, relu, affine, want_stats=False):
+    def conv_up_skip(self, x_low, skip, n, relu, affine, want_stats=False, layer=None):
         """conv3x3(cat([upsample2x(x_low), skip], 1)) with the upsampled half computed at the low resolution.  want_stats (training
         forward, Winograd skip half): returns (z, tile_stats) -- BatchNorm's batch statistics from the kernel's epilogue."""
         c0, c1 = int(x_low.shape[1]), int(skip.shape[1])
@@ -207,7 +207,7 @@ class Conv2DBlock(nn.Module):
         if affine:
             return ops.conv3x3(skip, wskip, self.conv.out_dim, addend=part, mean=bn.running_mean, scale=self.eval_scale(),
                                shift=bn.bias.detach(), relu=relu, cfg=cfg)
-        if want_stats and c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_wino43_train(c1, self.conv.out_dim, h, w):   # training forward, F(4x4, 3x3)
+        if want_stats and c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_wino43_train(c1, self.conv.out_dim, h, w, layer=layer):   # training forward, F(4x4, 3x3)
             return ops.conv3x3_wino43_stats(skip, self.packed_wino43(c0), self.conv.out_dim, addend=part)
         if c1 >= tuning.WINOGRAD_MIN_SKIP and tuning.use_winograd(c1, self.conv.out_dim, h, w):   # training forward: raw sums
             if want_stats and tuning.wino_has_stats():

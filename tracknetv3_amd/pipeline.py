@@ -58,6 +58,8 @@ def _np_median0(frames):
 
 
 _SIDE_STREAMS = {}
+# uint8 source streams: resize lazily on the batches' streams (preprocess.LazyResizer) instead of everything up front.  TNV3_LAZY_RESIZE=0: up front.
+LAZY_RESIZE = __import__("os").environ.get("TNV3_LAZY_RESIZE", "1") != "0"
 
 
 def _side_streams(dev, n):
@@ -70,16 +72,20 @@ def _side_streams(dev, n):
     return have[:n]
 
 
-def _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, n_streams=2):
+def _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, n_streams=2, ensure=None):
     """Yields (window-index batch, heat maps) in order, keeping up to `n_streams` TrackNet forwards in flight on side
     HIP streams: windows are independent, so the next batch's launches fill the CUs that the 45/48 tail of every
     batch-sized conv launch leaves idle (+6 % measured), and they run while the host post-processes the previous batch.
     The consumer's stream waits on each batch's completion event before it reads the heat maps."""
     dev = frames.device
     starts = list(range(0, int(widx.shape[0]), batch_size))
+    # ensure(lo, hi): makes frames lo .. hi - 1 of `frames` valid on the current stream (preprocess.LazyResizer: the resize of a uint8 source
+    # stream, chunk by chunk, on the stream of the batch that needs it first)
     if dev.type != "cuda" or n_streams < 2 or len(starts) < 2:
         for s in starts:
             wi = widx[s:s + batch_size]
+            if ensure is not None:
+                ensure(int(wi.min()), int(wi.max()) + 1)
             yield wi, tracknet(_assemble(frames, median, wi, bg_mode))
         return
     main = torch.cuda.current_stream(dev)
@@ -95,6 +101,8 @@ def _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, n_str
         st = side[k % n_streams]
         with torch.cuda.stream(st), _no_infer_split():     # batches already overlap here: no second split inside each
             st.wait_event(ready)
+            if ensure is not None:
+                ensure(int(wi.min()), int(wi.max()) + 1)
             y = tracknet(_assemble(frames, median, wi, bg_mode))
             done = torch.cuda.Event()
             done.record(st)
@@ -122,11 +130,17 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
     with int() in the InpaintNet stage (the parity tests compare them with the oracle's before looking at the integers)."""
     if eval_mode not in ("nonoverlap", "average", "weight"):
         raise ValueError("Invalid mode")
+    ensure = None
     if frames.dtype == torch.uint8:                      # source-resolution (T, H, W, 3) stream: preprocess on the device
         from . import preprocess
         if img_shape is None:
             img_shape = (int(frames.shape[2]), int(frames.shape[1]))
-        frames, med = preprocess.preprocess_video(frames, bg_mode)
+        if bg_mode in ("", None, "concat") and frames.is_cuda and LAZY_RESIZE:
+            # the median up front; the bicubic resize per chunk of frames on the stream of the TrackNet batch that needs it first
+            lazy = preprocess.LazyResizer(frames, bg_mode)
+            frames, med, ensure = lazy.out, lazy.median, lazy.ensure
+        else:
+            frames, med = preprocess.preprocess_video(frames, bg_mode)
         if median is None:
             median = med
     t = int(frames.shape[0])
@@ -141,7 +155,7 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
 
     if eval_mode == "nonoverlap":
         widx = _windows(t, seq_len, seq_len, padding=True)
-        for wi, y in _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size):
+        for wi, y in _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, ensure=ensure):
             tmp = pp.predict(_index_tensor(wi), y_pred=y, img_scaler=img_scaler)
             for k in pred:
                 pred[k].extend(tmp[k])
@@ -150,7 +164,7 @@ def predict_video(frames, tracknet, inpaintnet=None, tracknet_seq_len=8, inpaint
         num_sample = int(widx.shape[0])
         stream = pp.EnsembleStream(seq_len, eval_mode, num_sample)
         frame_id = 0
-        for wi, y in _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size):
+        for wi, y in _tracknet_batches(tracknet, frames, median, widx, bg_mode, batch_size, ensure=ensure):
             ens = stream.push(y)                                                       # (n_frames, H, W), on device
             n = int(ens.shape[0])
             ids = torch.zeros((n, 1, 2), dtype=torch.long)

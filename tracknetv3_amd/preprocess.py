@@ -65,9 +65,10 @@ def _device_tables(h, w, oh, ow, device):
 
 
 @_lib.on_tensor_device
-def resize_frames(frames_u8, out_h=HEIGHT, out_w=WIDTH, want_f32=True, want_u8=False):
+def resize_frames(frames_u8, out_h=HEIGHT, out_w=WIDTH, want_f32=True, want_u8=False, out=None):
     """(F, H, W, C) uint8 -> fp32 (F, C, out_h, out_w) in [0, 1] (and/or uint8 (F, out_h, out_w, C)); bit-exact with
-    `np.moveaxis(np.array(Image.fromarray(img).resize((out_w, out_h))), -1, 0) / 255.`"""
+    `np.moveaxis(np.array(Image.fromarray(img).resize((out_w, out_h))), -1, 0) / 255.`  out: where the fp32 planes go (a contiguous
+    (F, C, out_h, out_w) fp32 tensor, e.g. a frame range of the caller's stream buffer)."""
     lib = _lib.load()
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
         raise _lib.Tnv3Error("resize_frames: expected a (F, H, W, C) uint8 tensor")
@@ -75,7 +76,9 @@ def resize_frames(frames_u8, out_h=HEIGHT, out_w=WIDTH, want_f32=True, want_u8=F
     f, h, w, c = (int(v) for v in frames_u8.shape)
     dev = frames_u8.device
     (xmin, xcnt, kkx), (ymin, ycnt, kky), lut = _device_tables(h, w, out_h, out_w, dev)
-    out_f = torch.empty((f, c, out_h, out_w), dtype=torch.float32, device=dev) if want_f32 else None
+    if out is not None and (not want_f32 or out.dtype != torch.float32 or tuple(out.shape) != (f, c, out_h, out_w) or not out.is_contiguous() or out.device != dev):
+        raise _lib.Tnv3Error("resize_frames: `out` must be a contiguous fp32 (F, C, out_h, out_w) tensor on the frames' device")
+    out_f = (out if out is not None else torch.empty((f, c, out_h, out_w), dtype=torch.float32, device=dev)) if want_f32 else None
     out_u = torch.empty((f, out_h, out_w, c), dtype=torch.uint8, device=dev) if want_u8 else None
     if f == 0:
         return (out_f, out_u) if (want_f32 and want_u8) else (out_f if want_f32 else out_u)
@@ -142,3 +145,38 @@ def preprocess_video(frames_u8, bg_mode="concat", median_u8=None, chunk=64):
             planes.append(resize_frames(difference_frames(part, med2)))
         outs.append(planes[0] if len(planes) == 1 else torch.cat(planes, 1))
     return torch.cat(outs, 0), med
+
+
+class LazyResizer:
+    """preprocess_video for bg_mode '' / 'concat' with the resize done ON DEMAND, a chunk of frames at a time, on whichever stream asks first:
+    `out` (T, 3, 288, 512) is allocated at once, `ensure(lo, hi)` makes frames lo .. hi - 1 of it valid for the CURRENT stream (resizing the
+    chunks nobody has resized yet there, waiting for the events of those another stream did).  pipeline.predict_video calls it from the side
+    stream of each TrackNet batch, so the HBM-bound resize of batch k + 1 runs beside the MFMA-bound network of batch k instead of in front of
+    everything (round 6: 1.8 of the 23 ms of a 256-frame nonoverlap run).  The temporal median (which every window needs) is taken up front.
+    Same kernels, same bits as preprocess_video."""
+
+    def __init__(self, frames_u8, bg_mode="concat", median_u8=None, chunk=64):
+        if bg_mode not in ("", None, "concat"):
+            raise ValueError("LazyResizer serves bg_mode '' / 'concat' (the difference-frame modes go through preprocess_video)")
+        self.src, self.chunk, self.t = frames_u8, int(chunk), int(frames_u8.shape[0])
+        self.median = None
+        if bg_mode == "concat":
+            if median_u8 is None:
+                median_u8 = median_background(frames_u8)
+            self.median = resize_frames(median_u8.unsqueeze(0))[0]
+        self.out = torch.empty((self.t, int(frames_u8.shape[3]), HEIGHT, WIDTH), dtype=torch.float32, device=frames_u8.device)
+        self.done = {}                                       # chunk -> event recorded behind its resize
+
+    def ensure(self, lo, hi):
+        cur = torch.cuda.current_stream(self.src.device) if self.src.is_cuda else None
+        for c in range(max(0, int(lo)) // self.chunk, (min(self.t, int(hi)) - 1) // self.chunk + 1):
+            ev = self.done.get(c)
+            if ev is None:
+                a, b = c * self.chunk, min(self.t, (c + 1) * self.chunk)
+                resize_frames(self.src[a:b], out=self.out[a:b])
+                if cur is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                self.done[c] = ev if ev is not None else True
+            elif cur is not None and ev is not True:
+                cur.wait_event(ev)

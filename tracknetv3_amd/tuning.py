@@ -104,8 +104,17 @@ _ALL_LEVELS_288 = (288, 144, 72, 36)
 WINO43_TRAIN_LEVELS = frozenset(int(v) for v in os.environ.get("TNV3_WINO43_TRAIN_LEVELS", "288,144,72,36").split(",") if v.strip())
 
 
-def use_wino43_train(cin, cout, h, w):
+# ... or per LAYER (forward order 0 .. 16: down_block_1.conv_1 = 0, ..., bottleneck = 7-9, ..., up_block_3.conv_2 = 16): the layers listed here run
+# their training forward in F(2x2) form whatever their level.  The error of the heat maps does not come from the levels evenly -- the last
+# layers in front of the head carry most of it (tests/studies/train_precision_layers.py, profiles/r06_train_precision_layers.json) -- so a
+# handful of layers buys the margin a whole level costs.  TNV3_WINO43_TRAIN_F22_LAYERS="": none.
+WINO43_TRAIN_F22_LAYERS = frozenset(int(v) for v in os.environ.get("TNV3_WINO43_TRAIN_F22_LAYERS", "").split(",") if v.strip())
+
+
+def use_wino43_train(cin, cout, h, w, layer=None):
     if int(h) in _ALL_LEVELS_288 and int(h) not in WINO43_TRAIN_LEVELS:
+        return False
+    if layer is not None and int(layer) in WINO43_TRAIN_F22_LAYERS:
         return False
     return WINO43_TRAIN and BN_STATS_IN_EPILOGUE and use_wino43(cin, cout, h, w)
 
