@@ -42,7 +42,7 @@ def _report(name, obj):
 # Regression thresholds of the training-mode heat maps (bar: 1e-4, BASELINE north_star).  Measured on MI355X, rounds 4-5: the default
 # F(4x4) training forward 4.5-4.6e-5 at N = 2 and N = 10, the F(2x2) forward 1.6e-5, torch-fp32 itself 1.7e-5 -- a kernel edit that
 # drifts past 1.3x of that is noticed here, long before the bar (tests/test_gpu_precision_sweep.py sweeps seeds and weight scales).
-HEAT_BOUND = {"f43": 6e-5, "f22": 2.5e-5}
+HEAT_BOUND = {"f43": 5.5e-5, "f22": 2.5e-5}      # (f43 = the default: since round 6 the first block in F(2x2), the rest F(4x4): 3.0-4.2e-5 measured)
 
 
 def _fullsize_train_step(gpu_device, n, tag):

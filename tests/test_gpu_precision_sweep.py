@@ -30,17 +30,19 @@ SEEDS = (31, 47, 59)
 GAINS = (1.0, 2.4, 4.0)
 VAR_RANGES = ((0.5, 2.0), (0.05, 0.5))
 
-# Bounds <= 1.5x the worst value of the round-5 sweep on MI355X (final library, all rows: profiles/r05_precision_sweep_eval_full18.json /
-# r05_precision_sweep_train_full9.json):
+# Bounds: eval -- <= 1.5x the worst value of the round-5 sweep on MI355X (profiles/r05_precision_sweep_eval_full18.json; the eval kernels did not
+# change in round 6); training -- <= 1.3x the worst of round 6's three-seed verification of the new default (first block F(2x2), the rest F(4x4),
+# upsampled halves 25-of-36: profiles/r06_train_precision_sets.json), NOT the bar:
 #   eval, max |logit| < 50 (9 of the 18 networks): heat maps 7e-8 .. 1.69e-6 (torch-fp32: 2e-8 .. 1.35e-6)
 #   eval, all 18: logits 3.3e-7 .. 6.3e-6 of their scale (torch-fp32: 4.9e-7 .. 4.2e-6; ours / torch <= 1.94)
-#   training: heat maps 1.6-1.9e-5 at gain 1, 4.0-4.5e-5 at 2.4 (torch-fp32: 1.4-1.7e-5), 6.0-6.7e-5 at 4; loss <= 4e-8;
+#   training: heat maps 1.6-1.9e-5 at gain 1, <= 4.2e-5 at 2.4 (torch-fp32: 1.4-1.7e-5), <= 5.7e-5 at 4 (2.6e-5), <= 8.3e-5 at 6 (4.2e-5: there the
+#             heat maps span [5e-7, 0.999993] and the bound IS north_star's bar); loss <= 4e-8;
 #             gradients: worst tensor 2.6-5.5e-2 of its scale (torch-fp32 2.8-3.7e-2), median 1.0-1.1e-2 (0.6-0.9e-2)
 EVAL_HEAT_ABS = 4e-6          # eval heat maps vs fp64 where the network is not saturated (max |logit| < EVAL_SANE_LOGIT)
 EVAL_SANE_LOGIT = 50.0
 EVAL_LOGIT_REL = 1.2e-5       # eval logits, relative to max |logit|, everywhere
 EVAL_LOGIT_VS_FP32 = 3.0      # ... and at most this many times torch-fp32's own distance
-TRAIN_HEAT_ABS = {1.0: 3e-5, 2.4: 6.5e-5, 4.0: 1e-4}      # training-mode heat maps by head gain; the last is north_star's bar itself (1.5x margin)
+TRAIN_HEAT_ABS = {1.0: 2.5e-5, 2.4: 5.5e-5, 4.0: 7.5e-5, 6.0: 1e-4}      # training-mode heat maps by head gain (1.3x the measured worst; gain 6: the bar itself)
 
 
 def _host_threads():
@@ -164,13 +166,13 @@ def _train_row(seed, gain, got, o64, o32=None):
     return row
 
 
-TRAIN_ROWS = [(31, 1.0), (31, 4.0), (47, 2.4), (47, 4.0), (59, 2.4), (59, 4.0)]      # (31, 2.4) is tests/test_gpu_fullsize_parity.py's network
+TRAIN_ROWS = [(31, 1.0), (31, 4.0), (31, 6.0), (47, 2.4), (47, 4.0), (59, 2.4), (59, 4.0)]      # (31, 2.4) is tests/test_gpu_fullsize_parity.py's network
 
 
 def test_precision_sweep_train_step_288x512(gpu_device):
     """Six networks through the default training forward (F(4x4) with the statistics epilogue; TNV3_SWEEP_FULL=1: all nine, with torch-fp32
     beside the gain-2.4 rows -- profiles/r05_precision_sweep_train.json): heat maps inside TRAIN_HEAT_ABS[gain] of the fp64 oracle, the loss
-    inside 1e-6, the worst gradient tensor inside 8e-2 of its own scale and the median inside 1.6e-2 (torch-fp32 itself: 2.8-3.7e-2 and
+    inside 1e-6, the worst gradient tensor inside 7e-2 of its own scale and the median inside 1.6e-2 (torch-fp32 itself: 2.8-3.7e-2 and
     0.6-0.9e-2 at gain 2.4; SURVEY 7: 2.5e-2 at batch 1)."""
     full = os.environ.get("TNV3_SWEEP_FULL") == "1"
     cfgs = [(s_, g_) for s_ in SEEDS for g_ in GAINS] if full else TRAIN_ROWS
@@ -191,12 +193,12 @@ def test_precision_sweep_train_step_288x512(gpu_device):
         for k in ("_mine", "_ref", "_names"):
             r.pop(k, None)
     worst = {k: max(r[k] for r in rows) for k in ("loss_abs_err", "grad_rel_err_max", "grad_rel_err_median")}
-    worst["heat_err_by_gain"] = {str(g): max(r["heat_err"] for r in rows if r["gain"] == g) for g in GAINS if any(r["gain"] == g for r in rows)}
+    worst["heat_err_by_gain"] = {str(g): max(r["heat_err"] for r in rows if r["gain"] == g) for g in sorted({r["gain"] for r in rows})}
     _report("precision_sweep_train.json", {"shape": [2, 27, H, W], "rows": rows, "worst": worst, "bounds": {"heat_abs_by_gain": {str(k): v for k, v in TRAIN_HEAT_ABS.items()}}})
     for r in rows:
         assert r["heat_err"] <= TRAIN_HEAT_ABS[r["gain"]], r
         assert r["loss_abs_err"] <= 1e-6, r
-        assert r["grad_rel_err_max"] <= 8e-2 and r["grad_rel_err_median"] <= 1.6e-2, r
+        assert r["grad_rel_err_max"] <= 7e-2 and r["grad_rel_err_median"] <= 1.6e-2, r
         if "heat_err_torch_fp32" in r:
             assert r["grad_rel_err_max"] <= 2 * r["grad_rel_err_max_torch_fp32"] + 2e-4, r
             assert r["grad_rel_err_median"] <= 2 * r["grad_rel_err_median_torch_fp32"] + 1e-4, r
@@ -236,7 +238,7 @@ def test_every_channel_plan_eval_and_train_step_288x512(gpu_device, plan):
         assert mine.max() <= 2 * ref.max() + 2e-4, (names[int(mine.argmax())], mine.max(), ref.max())
         assert np.median(mine) <= 2 * np.median(ref) + 1e-4, (np.median(mine), np.median(ref))
         for k, a, b in zip(names, mine, ref):              # (a ratio of two noisy numbers: 2.8-4.6 at the worst tensor over the five plans)
-            assert a <= 7 * b + 5e-4, (k, a, b)
+            assert a <= 5 * b + 5e-4, (k, a, b)
         # the stem's weight gradient alone, through the kernel the training step dispatches for this Cin
         x = nets.synth_input((2, in_dim, H, W), 77)
         dz = torch.from_numpy(nets.prng.uniform((2, 64, H, W), 78, -1.0, 1.0))

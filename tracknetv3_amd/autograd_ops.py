@@ -82,6 +82,7 @@ def _cfg(blk, n, h, w):
 def _train_forward_body(net, x):
     """conv -> BN(batch statistics) -> ReLU per Conv2DBlock up to the head's input; returns (saved records, head input, skips)."""
     saved = []          # per block: dict(x0, x1, up, z, a, mean, invstd)
+    bumped = []
     n = x.shape[0]
     if tuning.WINO_REPACK_MULTI:
         net.repack_wino_panels()        # the panels the optimiser step made stale, forward and backward ones, in one launch
@@ -104,7 +105,7 @@ def _train_forward_body(net, x):
         bn = blk.bn
         a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                bn.eps, bn.momentum, tile_stats=stats)
-        bn.num_batches_tracked.add_(1)
+        bumped.append(bn.num_batches_tracked)           # (+= 1 for all 17 layers in ONE launch behind the last layer: they were 17 launches on the chain)
         blk._cache.pop("aff", None)       # running_var was rewritten through a raw pointer: the folded eval scale is stale
         saved.append(dict(blk=blk, idx=len(saved), x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,
                           bn_ver=(bn.weight._version, bn.bias._version)))
@@ -124,6 +125,7 @@ def _train_forward_body(net, x):
     y = chain(u1, y, x3, True)
     y = chain(u2, y, x2, True)
     y = chain(u3, y, x1, True)
+    torch._foreach_add_(bumped, 1)
     return saved, y, (x1, x2, x3)
 
 

@@ -66,6 +66,21 @@ __device__ __forceinline__ float bn_scale(float gamma, float invstd) { return (f
 
 // mean / biased var -> (scale, shift) for the normalise pass, saved (mean, invstd) for backward, running-stat update
 // with the UNBIASED variance.  One thread per channel.
+__device__ __forceinline__ void bn_stats_finalize_channel(double s1, double s2, int c, const float* __restrict__ gamma, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float eps, float momentum, long count,
+                                                          float* __restrict__ scale, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const double n = (double)count;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)invstd;
+  scale[c] = bn_scale(gamma[c], save_invstd[c]);      // from the SAVED fp32 invstd: the backward pass recomputes exactly this value
+  const double unbiased = count > 1 ? var * (n / (n - 1.0)) : var;
+  running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+  running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+}
 inline __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, float* __restrict__ running_mean,
                                          float* __restrict__ running_var, float eps, float momentum, long count,
@@ -75,18 +90,41 @@ inline __global__ void bn_stats_finalize_kernel(const double* __restrict__ parti
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
   for (int s = 0; s < kRedSplit; ++s) { s1 += partial[((size_t)c * kRedSplit + s) * 2]; s2 += partial[((size_t)c * kRedSplit + s) * 2 + 1]; }
-  const double n = (double)count;
-  const double mean = s1 / n;
-  double var = s2 / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double invstd = 1.0 / sqrt(var + (double)eps);
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)invstd;
-  scale[c] = bn_scale(gamma[c], save_invstd[c]);      // from the SAVED fp32 invstd: the backward pass recomputes exactly this value
   (void)beta;
-  const double unbiased = count > 1 ? var * (n / (n - 1.0)) : var;
-  running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-  running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+  bn_stats_finalize_channel(s1, s2, c, gamma, running_mean, running_var, eps, momentum, count, scale, save_mean, save_invstd);
+}
+
+// Round 6: bn_tile_stats_reduce_kernel + a finalize kernel as ONE launch (a training step made 27 + 27 of these 5-us launches on its critical
+// chain).  grid = C, 1024 threads: wave w forms the partial sums of the slices s = w, w + 16, w + 32, w + 48 exactly as workgroup (s, c) of
+// bn_tile_stats_reduce_kernel does (same strides, same butterfly), thread 0 then adds the kRedSplit partials in order like the finalize
+// kernels: the same additions in the same order -- bit-identical to the two launches.  FIN: the per-channel epilogue.
+template <class FIN>
+__device__ __forceinline__ void bn_tile_stats_fold(const double* __restrict__ tile_stats, long n_tiles, FIN&& fin) {
+  __shared__ double part_s[kRedSplit * 2];
+  static_assert(kRedSplit == 64, "sixteen waves x four slices");
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double* src = tile_stats + (size_t)c * n_tiles * 2;
+  for (int s = wv; s < kRedSplit; s += 16) {
+    double s1 = 0.0, s2 = 0.0;
+    for (long t = (long)s * 64 + lane; t < n_tiles; t += (long)kRedSplit * 64) { s1 += src[2 * t]; s2 += src[2 * t + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+    if (lane == 0) { part_s[2 * s] = s1; part_s[2 * s + 1] = s2; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < kRedSplit; ++s) { s1 += part_s[2 * s]; s2 += part_s[2 * s + 1]; }
+    fin(s1, s2, c);
+  }
+}
+inline __global__ void __launch_bounds__(1024) bn_tile_stats_finalize_kernel(const double* __restrict__ tile_stats, long n_tiles, const float* __restrict__ gamma,
+                                                                      float* __restrict__ running_mean, float* __restrict__ running_var, float eps,
+                                                                      float momentum, long count, float* __restrict__ scale,
+                                                                      float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  bn_tile_stats_fold(tile_stats, n_tiles, [&](double s1, double s2, int c) {
+    bn_stats_finalize_channel(s1, s2, c, gamma, running_mean, running_var, eps, momentum, count, scale, save_mean, save_invstd);
+  });
 }
 
 // a = max((z - mean[c])*scale[c] + beta[c], 0)  -- subtract first, like the reference: no cancellation when |mean| >> std
@@ -161,6 +199,16 @@ inline __global__ void bn_bwd_consts_kernel(const float* __restrict__ mean, cons
 }
 
 // dbeta = sum g, dgamma = sum g*xhat; coefficients of the apply pass:  dZ = k0*g - k1 - k2*xhat
+__device__ __forceinline__ void bn_relu_bwd_finalize_channel(double s1, double s2, int c, int C, const float* __restrict__ gamma,
+                                                             const float* __restrict__ invstd, long count, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ coef) {
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  const double k0 = (double)gamma[c] * (double)invstd[c];
+  coef[c] = (float)k0;
+  coef[C + c] = (float)(k0 * s1 / (double)count);
+  coef[2 * C + c] = (float)(k0 * s2 / (double)count);
+}
 inline __global__ void bn_relu_bwd_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
                                             const float* __restrict__ invstd, long count, float* __restrict__ dgamma,
                                             float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */, int C) {
@@ -168,12 +216,15 @@ inline __global__ void bn_relu_bwd_finalize_kernel(const double* __restrict__ pa
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
   for (int s = 0; s < kRedSplit; ++s) { s1 += partial[((size_t)c * kRedSplit + s) * 2]; s2 += partial[((size_t)c * kRedSplit + s) * 2 + 1]; }
-  dbeta[c] = (float)s1;
-  dgamma[c] = (float)s2;
-  const double k0 = (double)gamma[c] * (double)invstd[c];
-  coef[c] = (float)k0;
-  coef[C + c] = (float)(k0 * s1 / (double)count);
-  coef[2 * C + c] = (float)(k0 * s2 / (double)count);
+  bn_relu_bwd_finalize_channel(s1, s2, c, C, gamma, invstd, count, dgamma, dbeta, coef);
+}
+// (the tile-statistics route: reduce + finalize in one launch, bit-identical -- see bn_tile_stats_fold)
+inline __global__ void __launch_bounds__(1024) bn_tile_stats_bwd_finalize_kernel(const double* __restrict__ tile_stats, long n_tiles, const float* __restrict__ gamma,
+                                                                          const float* __restrict__ invstd, long count, float* __restrict__ dgamma,
+                                                                          float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */, int C) {
+  bn_tile_stats_fold(tile_stats, n_tiles, [&](double s1, double s2, int c) {
+    bn_relu_bwd_finalize_channel(s1, s2, c, C, gamma, invstd, count, dgamma, dbeta, coef);
+  });
 }
 
 // dZ = k0*g - k1 - k2*xhat  (written over dA's buffer is allowed: dZ may alias dA)

@@ -443,9 +443,9 @@ int bn_train_forward_tiles_impl(Launcher& L, const float* z, const double* tile_
   double* partial = (double*)ws;
   float* scale = (float*)(partial + (size_t)c * kRedSplit * 2);
   int rc;
-  if ((rc = L.launch3(bn_tile_stats_reduce_kernel, kRedSplit, c, 1, 64, tile_stats, partial, n_tiles))) return rc;
-  if ((rc = L.launch(bn_stats_finalize_kernel, (c + 63) / 64, 64, (const double*)partial, gamma, beta, rm, rv, eps, momentum,
-                     (long)n * hw, scale, save_mean, save_invstd, c))) return rc;
+  // (one launch: the tiles' fixed-order sums and the finalize -- bit-identical to bn_tile_stats_reduce_kernel + bn_stats_finalize_kernel)
+  if ((rc = L.launch(bn_tile_stats_finalize_kernel, c, 1024, tile_stats, n_tiles, gamma, rm, rv, eps, momentum, (long)n * hw, scale, save_mean,
+                     save_invstd))) return rc;
   return L.launch(bn_apply_relu_kernel, grid_for((long)n * c * (hw / 4)), 256, z, (const float*)save_mean, (const float*)scale, beta, a,
                   (long)n * c, c, hw);
 }
@@ -487,9 +487,7 @@ int bn_relu_backward_tiles_impl(Launcher& L, const float* da, const float* z, co
   double* partial = (double*)ws;
   float* coef = (float*)(partial + (size_t)c * kRedSplit * 2);
   int rc;
-  if ((rc = L.launch3(bn_tile_stats_reduce_kernel, kRedSplit, c, 1, 64, tile_stats, partial, n_tiles))) return rc;
-  if ((rc = L.launch(bn_relu_bwd_finalize_kernel, (c + 63) / 64, 64, (const double*)partial, gamma, invstd, (long)n * hw, dgamma,
-                     dbeta, coef, c))) return rc;
+  if ((rc = L.launch(bn_tile_stats_bwd_finalize_kernel, c, 1024, tile_stats, n_tiles, gamma, invstd, (long)n * hw, dgamma, dbeta, coef, c))) return rc;
   return L.launch(bn_relu_bwd_apply_kernel<true>, grid_for((long)n * c * (hw / 4)), 256, da, (const float*)nullptr, z, gamma, beta, mean, invstd,
                   (const float*)coef, dz, (long)n * c, c, hw);
 }

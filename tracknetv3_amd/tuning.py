@@ -105,10 +105,16 @@ WINO43_TRAIN_LEVELS = frozenset(int(v) for v in os.environ.get("TNV3_WINO43_TRAI
 
 
 # ... or per LAYER (forward order 0 .. 16: down_block_1.conv_1 = 0, ..., bottleneck = 7-9, ..., up_block_3.conv_2 = 16): the layers listed here run
-# their training forward in F(2x2) form whatever their level.  The error of the heat maps does not come from the levels evenly -- the last
-# layers in front of the head carry most of it (tests/studies/train_precision_layers.py, profiles/r06_train_precision_layers.json) -- so a
-# handful of layers buys the margin a whole level costs.  TNV3_WINO43_TRAIN_F22_LAYERS="": none.
-WINO43_TRAIN_F22_LAYERS = frozenset(int(v) for v in os.environ.get("TNV3_WINO43_TRAIN_F22_LAYERS", "").split(",") if v.strip())
+# their training forward in F(2x2) form whatever their level.  The error of the heat maps does not come from the layers evenly -- switching the
+# stem or down_block_1.conv_2 alone removes 0.8-1.1e-5 of the 4.5e-5, no other single layer more than the seed-to-seed noise
+# (tests/studies/train_precision_layers.py, profiles/r06_train_precision_layers.json) -- so two layers buy what a whole level costs.  TNV3_WINO43_TRAIN_F22_LAYERS="": none.
+# Default since round 6: the first block (layers 0, 1 -- the un-normalised image planes and the first activation: positive data with a large
+# mean, where F(4x4)'s transforms cancel most) in F(2x2), everything else in F(4x4), the decoder entries' upsampled halves in the 25-of-36 form
+# (UP2X_WINO_VARIANT_TRAIN = 2): worst of 3 seeds 4.2e-5 / 5.7e-5 / 8.3e-5 at head gain 2.4 / 4 / 6 at +0.1 ms per step over round 5's default,
+# which measured 4.5e-5 / 6.7e-5 / 1.1e-4 (profiles/r06_train_precision_sets.json).  More margin costs time roughly linearly:
+# TNV3_WINO43_TRAIN_LEVELS=72,36 -> 2.7e-5 / 4.1e-5 / 5.9e-5 for +2.0 ms; TNV3_WINO43_TRAIN=0 (F(2x2) everywhere) -> 1.6e-5 / 2.8e-5 / 3.7e-5
+# (torch-fp32's own level) for +3.5 ms (profiles/r06_train_precision_pareto.json).
+WINO43_TRAIN_F22_LAYERS = frozenset(int(v) for v in os.environ.get("TNV3_WINO43_TRAIN_F22_LAYERS", "0,1").split(",") if v.strip())
 
 
 def use_wino43_train(cin, cout, h, w, layer=None):
@@ -240,7 +246,7 @@ UP2X_WINO = os.environ.get("TNV3_UP2X_WINO", "1") != "0"
 # kernel (kernels/conv3x3_wino43s_mfma.h MODE 1: Lavin's points, 1-5e-6 of the output scale from fp64 -- an addend of the skip half's launch).
 # The eval forward and the training forward choose separately (batch-statistics BatchNorm amplifies the forward's rounding).
 UP2X_WINO_VARIANT = _choice("TNV3_UP2X_WINO_VARIANT", 2, {-1, 0, 1, 2}, "tnv3_conv_up2x_wino_forward")
-UP2X_WINO_VARIANT_TRAIN = _choice("TNV3_UP2X_WINO_VARIANT_TRAIN", 0, {-1, 0, 1, 2}, "tnv3_conv_up2x_wino_forward")
+UP2X_WINO_VARIANT_TRAIN = _choice("TNV3_UP2X_WINO_VARIANT_TRAIN", 2, {-1, 0, 1, 2}, "tnv3_conv_up2x_wino_forward")
 
 
 # BatchNorm + ReLU backward: the two per-channel sums of block L (sum g, sum g * xhat) taken in the epilogue of the Winograd data-gradient
