@@ -253,7 +253,7 @@ def train_flops_executed_per_sample():
     pass the direct count times 9/36 (Winograd F(4x4,3x3), and the 9-GEMM forms of the upsampled halves), 16/36 (F(2x2,3x3)) or 1."""
     from tracknetv3_amd import tuning as t
     total = 0.0
-    for name, c0, c1, co, h, w, up in conv_layer_table((SEQ_LEN + 1) * 3, H, W):
+    for idx, (name, c0, c1, co, h, w, up) in enumerate(conv_layer_table((SEQ_LEN + 1) * 3, H, W)):      # idx: the layer's forward order (tuning.WINO43_TRAIN_F22_LAYERS)
         def frac(ci, use43):
             if use43:
                 return 9 / 36
@@ -274,11 +274,11 @@ def train_flops_executed_per_sample():
             f_wg = 6.25 / 36 if ((wv < 0 or wv == 2) and co % 64 == 0 and hl % 2 == 0 and wl % 8 == 0) else (9 / 36 if (wv != 0 and c0 % 128 == 0) else 16 / 36)
             upf = conv_flops(c0, 0, co, h, w) * (f_fwd + f_dg + f_wg)      # forward; data gradient; weight gradient (25-of-36 F(4x4) or 9-GEMM F(2x2) forms)
             sk = conv_flops(c1, 0, co, h, w)
-            skip = sk * (frac(c1, t.use_wino43_train(c1, co, h, w)) + frac(c1, t.use_wino43_dgrad(co, c1, h, w)) + wfrac(c1))
+            skip = sk * (frac(c1, t.use_wino43_train(c1, co, h, w, layer=idx)) + frac(c1, t.use_wino43_dgrad(co, c1, h, w)) + wfrac(c1))
             total += upf + skip
         else:
             fl = conv_flops(c0, 0, co, h, w)
-            total += fl * frac(c0, t.use_wino43_train(c0, co, h, w))                                # forward
+            total += fl * frac(c0, t.use_wino43_train(c0, co, h, w, layer=idx))                     # forward
             if name != "down_block_1.conv_1":
                 total += fl * frac(c0, t.use_wino43_dgrad(co, c0, h, w))                            # data gradient (none for the first layer)
             total += fl * wfrac(c0)                                                                 # weight gradient
@@ -345,6 +345,20 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
                     "bucket_copies": int(trainer.reducer.copies) if trainer.reducer is not None else None,
                     "note": "int64 checksums of the parameters' and Adam moments' bit patterns after the timed steps, equal on every rank; "
                             "bucket_copies: gradients that were copied into an all-reduce bucket instead of being written there by their kernel"}
+    # the same step with round 5's training-forward configuration (F(4x4) on every layer, the upsampled halves in the 9-GEMM F(2x2) form): what
+    # round 6's default -- first block in F(2x2), 25-of-36 upsampled halves: less heat-map error (tuning.WINO43_TRAIN_F22_LAYERS) -- costs
+    alt = None
+    if world == 1 and steps >= 4:
+        from tracknetv3_amd import tuning as _t
+        keep = (_t.WINO43_TRAIN_F22_LAYERS, _t.UP2X_WINO_VARIANT_TRAIN)
+        try:
+            _t.WINO43_TRAIN_F22_LAYERS, _t.UP2X_WINO_VARIANT_TRAIN = frozenset(), 0
+            adt, _ = timed_steps(x, y, steps, 2)
+            alt = {"ms_per_step": round(adt / steps * 1e3, 3),
+                   "config": "round 5's training forward: F(4x4) on all 17 layers, upsampled halves in the 9-GEMM F(2x2) form (heat maps 4.5e-5 / "
+                             "6.7e-5 / 1.1e-4 from fp64 at head gain 2.4 / 4 / 6; the default: 4.2e-5 / 5.7e-5 / 8.3e-5, profiles/r06_train_precision_sets.json)"}
+        finally:
+            _t.WINO43_TRAIN_F22_LAYERS, _t.UP2X_WINO_VARIANT_TRAIN = keep
     overlap = None
     if record_timing and world > 1:
         timed = TrackNetTrainer(model, opt, alpha=0.5, seed=14, record_timing=True)
@@ -397,7 +411,7 @@ def train_leg(dev, rank, world, batch, steps, warmup, record_timing=False, stron
                              "all three passes (forward with the statistics epilogue, data gradient, weight gradient) --, counted per layer "
                              "from the dispatch rules (train_flops_executed_per_sample: a knob that moves a pass to F(2x2) or the direct form "
                              "moves its count to 16/36 or 1)"},
-        "strong": strong, "dp_overlap": overlap, "replicas": replicas, "final_loss": round(float(loss.item()), 6)}
+        "strong": strong, "dp_overlap": overlap, "replicas": replicas, "round5_forward_config": alt, "final_loss": round(float(loss.item()), 6)}
 
 
 def bench_train(args, dev, rank, world):

@@ -527,6 +527,106 @@ __global__ void __launch_bounds__(256) head_backward_kernel(const float* __restr
   if (tid < L) out[L * kHeadC + tid] = accB;
 }
 
+// Round 6: the same three gradients on the matrix pipe (the kernel above took 0.47 ms of a training step's critical chain for 0.94 GB of traffic --
+// its 1024 multiply-adds per pixel went through LDS broadcasts).  MFMA 16x16x4 (fp32: an fmaf chain in k order, bitwise), NO LDS in the loop: a wave
+// owns groups of 16 pixels (HW % 16 == 0, C = 64, L <= 8):
+//   * dz[px][l] is formed ONCE per group in the weight gradient's operand layout -- lane (l = lane & 15 < L, pixel quarter kq = lane >> 4): a
+//     16-byte read of p (and of y / dP) = the four pixels 4 kq .. 4 kq + 3 of map l -- and handed to the data gradient's layout (lane = pixel,
+//     kq = map) by four ds_bpermute (no LDS allocation) + one select;
+//   * dA[px][c] = sum_l dz[px][l] w[l][c]: A = dz (M = pixel, K = map), B = w (loop-invariant registers), 4 channel blocks x <= 2 K steps; a lane's
+//     four accumulator registers are four CONSECUTIVE pixels of one channel: one 16-byte store (the same fmaf order over l as the kernel above);
+//   * dW[l][c] += sum_px dz[px][l] a[c][px]: A = dz (M = map, K = pixel), B = a read as 16 bytes along the pixels (K order = the read's
+//     component: any order, both operands agree), 4 channel blocks x 4 K steps, accumulators live across the wave's groups; db from the same dz.
+// The four waves' dW / db are folded in a fixed order into part[block] (then sum_partials_wave_kernel, as before).  Deterministic.
+template <bool FUSED_WBCE>
+__global__ void __launch_bounds__(256) head_backward_mfma_kernel(const float* __restrict__ dP, const float* __restrict__ p,
+                                                                 const float* __restrict__ a, const float* __restrict__ w,
+                                                                 float* __restrict__ dA, float* __restrict__ part /* [grid][L*C + L] */,
+                                                                 int N, int L, int HW, const float* __restrict__ upstream, int upstream_per_sample,
+                                                                 float inv_denom) {
+  __shared__ float red[4 * (8 * kHeadC + 8)];            // [wave][l 8][c 64] + [wave][l 8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int KS = (L + 3) >> 2;                           // K steps of the data gradient (maps in fours)
+  // B operand of the data gradient: w[l = 4 kk + kq][c = 16 cb + m] (zero beyond L)
+  float wB[4][2];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int l = 4 * kk + kq;
+      wB[cb][kk] = l < L ? w[l * kHeadC + 16 * cb + m] : 0.0f;
+    }
+  t_f32x4 accW[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) accW[cb] = t_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float accB = 0.0f;
+  const long gpi = HW >> 4;                              // groups per image
+  const long groups = (long)N * gpi;
+  const long stride = (long)gridDim.x * 4;
+  for (long g = (long)blockIdx.x * 4 + wave; g < groups; g += stride) {
+    const int n = (int)(g / gpi);
+    const int p0 = (int)(g - (long)n * gpi) << 4;
+    // ---- dz in the weight gradient's layout: lane (map m, pixels 4 kq .. 4 kq + 3)
+    t_f32x4 dzW = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (m < L) {
+      const size_t o = ((size_t)n * L + m) * HW + p0 + 4 * kq;
+      const t_f32x4 pv = *reinterpret_cast<const t_f32x4*>(p + o);
+      const t_f32x4 yv = *reinterpret_cast<const t_f32x4*>(dP + o);
+      const float up = FUSED_WBCE ? upstream[upstream_per_sample ? n : 0] : 1.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float dpv = FUSED_WBCE ? wbce_elem_grad(pv[t], yv[t]) * up * inv_denom : yv[t];      // (the kernel above's expression, product for product)
+        dzW[t] = dpv * pv[t] * (1.0f - pv[t]);
+      }
+      accB += (dzW[0] + dzW[1]) + (dzW[2] + dzW[3]);
+    }
+    // ---- the activation rows of the group: lane (channel 16 cb + m, pixels 4 kq .. 4 kq + 3)
+    t_f32x4 a4[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) a4[cb] = *reinterpret_cast<const t_f32x4*>(a + ((size_t)n * kHeadC + 16 * cb + m) * HW + p0 + 4 * kq);
+    // ---- data gradient: A[pixel m][map 4 kk + kq] = dzW of lane (map) + 16 (m >> 2), component m & 3
+    float dzA[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int src = (4 * kk + kq) + 16 * (m >> 2);
+      const float v0 = __shfl(dzW[0], src, 64), v1 = __shfl(dzW[1], src, 64), v2 = __shfl(dzW[2], src, 64), v3 = __shfl(dzW[3], src, 64);
+      const int t = m & 3;
+      dzA[kk] = t == 0 ? v0 : (t == 1 ? v1 : (t == 2 ? v2 : v3));
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      t_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dzA[0], wB[cb][0], acc, 0, 0, 0);
+      if (KS > 1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dzA[1], wB[cb][1], acc, 0, 0, 0);
+      // acc[r] = dA[pixel 4 kq + r][channel 16 cb + m]
+      *reinterpret_cast<t_f32x4*>(dA + ((size_t)n * kHeadC + 16 * cb + m) * HW + p0 + 4 * kq) = acc;
+    }
+    // ---- weight gradient: K step t = the t-th pixel of every lane's four
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) accW[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzW[t], a4[cb][t], accW[cb], 0, 0, 0);
+  }
+  // ---- fold: accW[cb][r] = dW[map 4 kq + r][channel 16 cb + m] of this wave; db: the four pixel quarters of map m
+  accB += __shfl_xor(accB, 16, 64);
+  accB += __shfl_xor(accB, 32, 64);
+  float* rw = red + wave * (8 * kHeadC + 8);
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int l = 4 * kq + r;
+      if (l < 8) rw[l * kHeadC + 16 * cb + m] = accW[cb][r];
+    }
+  if (lane < 8) rw[8 * kHeadC + lane] = accB;
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * (L * kHeadC + L);
+  constexpr int WS = 8 * kHeadC + 8;
+  for (int i = tid; i < L * kHeadC; i += 256) out[i] = ((red[i] + red[WS + i]) + red[2 * WS + i]) + red[3 * WS + i];
+  if (tid < L) out[L * kHeadC + tid] = ((red[8 * kHeadC + tid] + red[WS + 8 * kHeadC + tid]) + red[2 * WS + 8 * kHeadC + tid]) + red[3 * WS + 8 * kHeadC + tid];
+}
+
 // out[i] = sum_b part[b][i] in fixed order (double accumulate).  Used for head dW/db and the wgrad split-K slabs.
 inline __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nparts) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {

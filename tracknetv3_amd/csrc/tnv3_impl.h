@@ -1522,9 +1522,20 @@ int head_backward_impl(Launcher& L, const float* dp, const float* p, const float
   if (l > kHeadLMax) TNV3_FAIL(-1, "head_backward: at most %d output maps", kHeadLMax);
   if (ws_bytes < head_backward_workspace_bytes(l)) TNV3_FAIL(-1, "head_backward: workspace too small");
   const long nTiles = (long)n * ((hw + kHeadP - 1) / kHeadP);
-  const int grid = (int)(nTiles < kHeadGrid ? nTiles : kHeadGrid);
+  int grid = (int)(nTiles < kHeadGrid ? nTiles : kHeadGrid);
   int rc;
-  if (upstream) {
+  // the matrix-pipe form (round 6): groups of 16 pixels per wave, 16-byte rows of p / dp / a / dA
+  const bool mfma = l <= 8 && hw % 16 == 0 && ((((uintptr_t)dp | (uintptr_t)p | (uintptr_t)a | (uintptr_t)da) & 15) == 0);
+  if (mfma) {
+    const long wave_groups = ((long)n * (hw / 16) + 3) / 4;
+    grid = (int)(wave_groups < kHeadGrid ? wave_groups : kHeadGrid);
+    if (upstream) {
+      const float inv = reduce ? (float)(1.0 / ((double)n * (double)l * (double)hw)) : (float)(1.0 / ((double)l * (double)hw));
+      rc = L.launch(head_backward_mfma_kernel<true>, grid, 256, dp, p, a, w, da, (float*)ws, n, l, hw, upstream, reduce ? 0 : 1, inv);
+    } else {
+      rc = L.launch(head_backward_mfma_kernel<false>, grid, 256, dp, p, a, w, da, (float*)ws, n, l, hw, (const float*)nullptr, 0, 1.0f);
+    }
+  } else if (upstream) {
     const float inv = reduce ? (float)(1.0 / ((double)n * (double)l * (double)hw)) : (float)(1.0 / ((double)l * (double)hw));
     rc = L.launch(head_backward_kernel<true>, grid, 256, dp, p, a, w, da, (float*)ws, n, l, hw, upstream, reduce ? 0 : 1, inv);
   } else {
