@@ -625,6 +625,20 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   // (a chunk beyond the panel's last -- the second half of a 16-channel step when Cin % 16 <= 8 -- must read zeros: through the LANE offset,
   //  the scalar offset of a buffer access is not range-checked)
   auto a_lane_of = [&](int k, int q) -> unsigned { return (KB == 1 || q < PAIRS || k * KB + 1 < nCh8) ? a_lane_b : kDmaOob; };
+  // Quad q of a step's panel slice sits 1024 q bytes behind the slice's start.  Round 6: (q & 3) * 1024 rides in the instruction's immediate
+  // offset (the compiler folds a constant added to the lane offset; an out-of-range lane offset 2^31 stays out of range with it) and only
+  // (q >> 2) * 4096 goes through the scalar offset -- 9 scalar adds per step instead of 36 (every instruction of a step costs ~4.6 cycles,
+  // DESIGN 3.1k).  TNV3_A_IMM_OFFSETS=0 (an A/B build): one scalar offset per quad as before.
+#ifndef TNV3_A_IMM_OFFSETS
+#define TNV3_A_IMM_OFFSETS 1
+#endif
+  // (the 128-channel instantiations with a statistics epilogue -- training forward, data gradient + BatchNorm sums -- sit at exactly 256 registers: there the immediate form costs two spilled
+  //  registers -- and a spill inside a counted-vmcnt region is a wrong result, 3.1g -- so those two keep the scalar form)
+  constexpr bool A_IMM = TNV3_A_IMM_OFFSETS != 0 && !(CBW == 8 && STATS != 0);
+  auto a_load = [&](unsigned lane_off, unsigned so_base, int q) -> f32x4 {
+    if constexpr (A_IMM) return tnv3_buf_load_f4(r_panel, lane_off + (unsigned)(q & 3) * 1024u, so_base + (unsigned)(q >> 2) * 4096u);
+    else return tnv3_buf_load_f4(r_panel, lane_off, so_base + (unsigned)q * 1024u);
+  };
   auto next_mb = [&]() -> int {                          // the channel block of the tile after M's (the walk's rule)
     int mb = wM.mb + wM.d_mb;
     if (mb >= nMB) mb -= nMB;
@@ -656,7 +670,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   {
     const unsigned s0 = a_base(wM.mb, 0);
 #pragma unroll
-    for (int q = 0; q < GROW; ++q) aq[q] = tnv3_buf_load_f4(r_panel, a_lane_of(0, q), s0 + (unsigned)q * 1024u);
+    for (int q = 0; q < GROW; ++q) aq[q] = a_load(a_lane_of(0, q), s0, q);
   }
   full_barrier();
   if constexpr (B_ACROSS) {
@@ -691,7 +705,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
         constexpr int qb = q + Cfg::B_DIST, qa = q + A_DIST;
         if constexpr ((DG & 8) == 0 && (qb < NP || B_ACROSS))
           bq[qb % Cfg::B_RING] = *reinterpret_cast<const f32x4*>((qb < NP ? bM : bN) + (qb % NP) * V_PAIR);
-        if constexpr ((DG & 4) == 0 && qa >= GROW && qa < NP) aq[qa] = tnv3_buf_load_f4(r_panel, qa < PAIRS ? a_lane_b : a_lane_hi, soM + (unsigned)qa * 1024u);
+        if constexpr ((DG & 4) == 0 && qa >= GROW && qa < NP) aq[qa] = a_load(qa < PAIRS ? a_lane_b : a_lane_hi, soM, qa);
         __builtin_amdgcn_sched_barrier(0);
       }
       const f32x4& av = aq[q];
@@ -708,7 +722,7 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
       if constexpr (IDX >= TS && IDX - TS < T_PIECES) { if constexpr ((DG & 2) == 0) t_piece(std::integral_constant<int, IDX - TS>{}); }
       if constexpr (IDX >= GS && (DG & 4) == 0) {
 #pragma unroll
-        for (int j = (IDX - GS) * GPS; j < (IDX - GS + 1) * GPS && j < GROW; ++j) aq[j] = tnv3_buf_load_f4(r_panel, a_lane_of(kA, j), soA + (unsigned)j * 1024u);
+        for (int j = (IDX - GS) * GPS; j < (IDX - GS + 1) * GPS && j < GROW; ++j) aq[j] = a_load(a_lane_of(kA, j), soA, j);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
