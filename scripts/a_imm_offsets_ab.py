@@ -1,12 +1,13 @@
-"""A/B of the F(4x4) kernel's filter-operand addressing (round 6): the product library (quads' (q & 3) * 1024 bytes in the load's immediate
-offset: 9 scalar adds per step) against the same sources built with -DTNV3_A_IMM_OFFSETS=0 (one scalar offset per quad: 36 adds) on
-TrackNet's plain-layer shapes at batch 10, eval-mode epilogue, both geometries, and MODE 1 / MODE 2 through the decoder-entry calls.
-  python scripts/a_imm_offsets_ab.py build      (in the build container: writes scripts/libtnv3_hip_scalar_a_offsets.so)
+"""A/B of the F(4x4) kernel's filter-operand addressing (round 6): one scalar offset per quad (36 scalar adds per step: the product) against
+the quads' (q & 3) * 1024 bytes in the load's immediate offset (-DTNV3_A_IMM_OFFSETS=1: 9 adds per step) on TrackNet's plain-layer shapes
+at batch 10, eval-mode epilogue, both geometries.  Result (profiles/r06_a_imm_offsets_ab.json, recorded when the immediate form was the
+product build and the scalar one the alternative): 0.0 to +2 % per launch for the immediate form -- not adopted.
+  python scripts/a_imm_offsets_ab.py build      (in the build container: writes scripts/libtnv3_hip_alt_a_offsets.so with the immediate form)
   python scripts/a_imm_offsets_ab.py            (on the GPU box)"""
 import json, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 HERE = os.path.dirname(os.path.abspath(__file__))
-ALT = os.path.join(HERE, "libtnv3_hip_scalar_a_offsets.so")
+ALT = os.path.join(HERE, "libtnv3_hip_alt_a_offsets.so")
 SHAPES = ((27, 64, 288, 512), (64, 64, 288, 512), (64, 128, 144, 256), (128, 128, 144, 256), (128, 256, 72, 128), (256, 256, 72, 128), (256, 512, 36, 64),
           (512, 512, 36, 64))
 
@@ -19,7 +20,7 @@ def build():
     procs = []
     for fam in _build.FAMILIES:
         obj = f"/tmp/alt_build/tnv3_{fam.lower()}.o"
-        cmd = [hipcc] + _build.FLAGS + _build.FAMILY_FLAGS.get(fam, []) + [f"-DTNV3_TU_{fam}", "-DTNV3_A_IMM_OFFSETS=0", "-c", _build.SRC, "-o", obj]
+        cmd = [hipcc] + _build.FLAGS + _build.FAMILY_FLAGS.get(fam, []) + [f"-DTNV3_TU_{fam}", "-DTNV3_A_IMM_OFFSETS=1", "-c", _build.SRC, "-o", obj]
         procs.append(subprocess.Popen(cmd))
         objs.append(obj)
     assert all(p.wait() == 0 for p in procs)
@@ -44,7 +45,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    libs = {"imm": _lib.library_path(), "scalar": ALT}
+    libs = {"scalar": _lib.library_path(), "imm": ALT}
     out = {}
     for cin, cout, h, w in SHAPES:
         x = torch.relu(torch.randn(10, cin, h, w, device=dev))
@@ -62,7 +63,7 @@ def main():
         row["bit_identical"] = all(torch.equal(ys[("imm", v)], ys[("scalar", v)]) for (t, v) in ys if t == "imm")
         out[f"{cin}->{cout}@{h}x{w}"] = {k: (min(v) if isinstance(v, list) else v) for k, v in row.items()}
         print(f"{cin}->{cout}@{h}x{w}", json.dumps(out[f"{cin}->{cout}@{h}x{w}"]), flush=True)
-    _lib.use_library(libs["imm"])
+    _lib.use_library(libs["scalar"])
     od = os.path.join(os.path.dirname(HERE), "gpurun_out")
     os.makedirs(od, exist_ok=True)
     json.dump(out, open(os.path.join(od, "a_imm_offsets_ab.json"), "w"), indent=1)

@@ -625,15 +625,15 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
   // (a chunk beyond the panel's last -- the second half of a 16-channel step when Cin % 16 <= 8 -- must read zeros: through the LANE offset,
   //  the scalar offset of a buffer access is not range-checked)
   auto a_lane_of = [&](int k, int q) -> unsigned { return (KB == 1 || q < PAIRS || k * KB + 1 < nCh8) ? a_lane_b : kDmaOob; };
-  // Quad q of a step's panel slice sits 1024 q bytes behind the slice's start.  Round 6: (q & 3) * 1024 rides in the instruction's immediate
-  // offset (the compiler folds a constant added to the lane offset; an out-of-range lane offset 2^31 stays out of range with it) and only
-  // (q >> 2) * 4096 goes through the scalar offset -- 9 scalar adds per step instead of 36 (every instruction of a step costs ~4.6 cycles,
-  // DESIGN 3.1k).  TNV3_A_IMM_OFFSETS=0 (an A/B build): one scalar offset per quad as before.
+  // Quad q of a step's panel slice sits 1024 q bytes behind the slice's start: one scalar offset per quad (36 scalar adds per step).
+  // Round 6 measured the alternative -- (q & 3) * 1024 in the instruction's immediate offset, only (q >> 2) * 4096 through the scalar offset:
+  // 9 adds per step -- and found nothing (profiles/r06_a_imm_offsets_ab.json: 0.0 to +2 % per launch over the eight plain-layer shapes,
+  // bit-identical; the weight-gradient kernel's per-instruction cost, DESIGN 3.1k, does not carry over: here the scalar adds sit in the shadow
+  // of the MFMAs they are interleaved with), and the 128-channel instantiations with a statistics epilogue lose two registers to it (they
+  // sit at exactly 256: a spill, and a spill inside a counted-vmcnt region is a wrong result, 3.1g).  Kept as a build switch for the record.
 #ifndef TNV3_A_IMM_OFFSETS
-#define TNV3_A_IMM_OFFSETS 1
+#define TNV3_A_IMM_OFFSETS 0
 #endif
-  // (the 128-channel instantiations with a statistics epilogue -- training forward, data gradient + BatchNorm sums -- sit at exactly 256 registers: there the immediate form costs two spilled
-  //  registers -- and a spill inside a counted-vmcnt region is a wrong result, 3.1g -- so those two keep the scalar form)
   constexpr bool A_IMM = TNV3_A_IMM_OFFSETS != 0 && !(CBW == 8 && STATS != 0);
   auto a_load = [&](unsigned lane_off, unsigned so_base, int q) -> f32x4 {
     if constexpr (A_IMM) return tnv3_buf_load_f4(r_panel, lane_off + (unsigned)(q & 3) * 1024u, so_base + (unsigned)(q >> 2) * 4096u);
