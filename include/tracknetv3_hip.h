@@ -32,7 +32,7 @@ extern "C" {
 #define TNV3_OK 0
 #define TNV3_E_INVALID (-1)   /* bad argument / unsupported shape */
 #define TNV3_E_LAUNCH (-2)    /* HIP launch error */
-#define TNV3_ABI_VERSION 7   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
+#define TNV3_ABI_VERSION 8   /* 2: per-call kernel variants instead of process-wide knobs; diagnostics moved to libtnv3_diag.so;
                                  3: `variant` argument on the Winograd-form weight gradients;
                                  4: `sum_order` on tnv3_ensemble_frames (the reference's summation order, bit-exact); `variant` on the
                                     9-GEMM decoder kernels; the fused InpaintNet training entries; tnv3_conv3x3_wino_pick / _has_stats /
@@ -45,7 +45,8 @@ extern "C" {
                                  6: `up_variant` on tnv3_conv3x3_wgrad_up2x (the upsampled half's 25-of-36 F(4x4) weight gradient), `variant` 2
                                     on tnv3_dgrad_up2x_wino (its data gradient on the 16x16x4 kernel);
                                  7: tnv3_conv3x3_wino43_dgrad_bnstats (the F(4x4) data gradient that takes the previous block's BatchNorm-backward
-                                    sums from its write-out) */
+                                    sums from its write-out);
+                                 8: tnv3_maxpool2x2_backward_add_bnstats (the max-pool backward + skip add that takes them the same way) */
 
 typedef void* tnv3_stream_t;
 
@@ -456,6 +457,16 @@ int tnv3_head_wbce_backward(const float* y, const float* p, const float* a, cons
 /* MaxPool2d(2,2) backward fused with the skip-connection gradient add: dx = dskip + route(dpool). dskip may be NULL. */
 int tnv3_maxpool2x2_backward_add(const float* x, const float* dpool, const float* dskip, float* dx, long nc, int h,
                                  int w, tnv3_stream_t stream);
+/* ABI 8.  The same routing where the pooled tensor is a = ReLU(BatchNorm(z)) of a block normalised in this step (model.py:9-10 in front of
+ * model.py:48,51,54) -- the launch ALSO takes that block's two BatchNorm + ReLU backward sums of the dx it writes (autograd of model.py:9-10:
+ * dbeta = sum g, dgamma = sum g * zhat, g = dx where a > 0): tile_stats [c][slices][2] doubles, slices = tnv3_maxpool2x2_bn_stats_tiles(n, h, w)
+ * (0: shape not supported -- needs h % 2 == 0, w % 4 == 0), to be fed with dx to tnv3_bn_relu_backward_tiles.  It reads z, not a: a is
+ * recomputed with the forward's expression (same bits, so the same first maximum per window), bn_* are that block's saved mean / invstd
+ * and its affine parameters as the forward used them.  z / dskip / dx 16-byte aligned.  dskip may be NULL. */
+int tnv3_maxpool2x2_bn_stats_tiles(int n, int h, int w);
+int tnv3_maxpool2x2_backward_add_bnstats(const float* z, const float* dpool, const float* dskip, float* dx, const float* bn_mean,
+                                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, double* tile_stats, int n, int c, int h,
+                                         int w, tnv3_stream_t stream);
 /* nn.Upsample(scale_factor=2) backward: d_lo = 2x2 block sums of d_hi [nc][2*hl][2*wl]. */
 int tnv3_upsample2x_backward(const float* d_hi, float* d_lo, long nc, int hl, int wl, tnv3_stream_t stream);
 /* Sample mixup (train.py:32-40): out[n] = x[n]*lam[n] + x[perm[n]]*(1-lam[n]); per_sample % 4 == 0. */

@@ -2,7 +2,7 @@
 # Copies the summaries of the last scripts/gpu_session.sh evidence session (PARTS="host smoke pytest infer train ab fixed decoder profinfer proftrain pmc sq") from gpurun_out/ (scratch) into profiles/ (tracked).
 set -u
 cd "$(dirname "$0")/.."
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 O=gpurun_out
 P=profiles
 cp $O/bench.json $P/${R}_bench_n1.json

@@ -21,7 +21,7 @@ def test_capi_library_builds_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/tracknetv3_hip.h but not exported"
     lib.tnv3_abi_version.restype = ctypes.c_int
-    assert lib.tnv3_abi_version() == 7
+    assert lib.tnv3_abi_version() == 8
     lib.tnv3_conv3x3_num_configs.restype = ctypes.c_int
     assert lib.tnv3_conv3x3_num_configs() >= 1
     from tracknetv3_amd import _lib

@@ -482,6 +482,44 @@ def test_bn_backward_sums_from_the_f43_data_gradient_epilogue_emulated(emu, monk
     _bn_bwd_epilogue43_case(case, "cpu")
 
 
+POOL_BNSUMS_CASES = [(2, 3, 8, 12, True), (3, 5, 4, 8, False), (1, 2, 6, 260, True), (10, 4, 16, 64, True)]
+
+
+def _pool_bnsums_case(case, device):
+    """maxpool2x2_backward_add_bnstats + bn_relu_backward_tiles == bn_train_forward's a -> maxpool2x2_backward_add -> bn_relu_backward: the same dx
+    bits (the activation is recomputed from z with the forward's expression: the same first maximum per window, ties at zero behind the ReLU
+    included), the same mask, the two sums accumulated in fp64 in another order."""
+    from tracknetv3_amd import ops
+    n, c, h, w, skip = case
+    z = T((n, c, h, w), 721, -1.0, 1.0).to(device)
+    z[:, :, ::2, ::4] = z[:, :, 1::2, 1::4]                 # ties inside windows, above and below zero
+    gamma, beta = T((c,), 722, 0.5, 1.5).to(device), T((c,), 723, -0.3, 0.3).to(device)
+    rm, rv = torch.zeros(c, device=device), torch.ones(c, device=device)
+    a, mean, invstd = ops.bn_train_forward(z, gamma, beta, rm, rv, 1e-5, 0.1)
+    dpool = T((n, c, h // 2, w // 2), 724).to(device)
+    dskip = T((n, c, h, w), 725).to(device) if skip else None
+    dx_ref = ops.maxpool2x2_backward_add(a, dpool, dskip)
+    dz_ref, dg_ref, db_ref = ops.bn_relu_backward(dx_ref.clone(), None, z, gamma, mean, invstd, beta=beta)
+    assert ops.maxpool2x2_bnstats_supported(n, h, w)
+    dx, st = ops.maxpool2x2_backward_add_bnstats(z, dpool, dskip, mean, invstd, gamma, beta)
+    assert torch.equal(dx, dx_ref) and st.shape[0] == c and st.shape[2] == 2
+    scale = max(dx.abs().sum((0, 2, 3)).max().item(), 1.0)
+    assert (st.sum(1)[:, 0] - db_ref.double()).abs().max().item() <= 2e-6 * scale
+    assert (st.sum(1)[:, 1] - dg_ref.double()).abs().max().item() <= 2e-6 * scale
+    dz2, dg2, db2 = ops.bn_relu_backward_tiles(dx, z, gamma, beta, mean, invstd, st)
+    assert rel_err(dg2, dg_ref) <= 1e-6 and rel_err(db2, db_ref) <= 1e-6 and rel_err(dz2, dz_ref) <= 1e-6
+    dx3, st3 = ops.maxpool2x2_backward_add_bnstats(z, dpool, dskip, mean, invstd, gamma, beta)          # deterministic
+    assert torch.equal(dx3, dx_ref) and torch.equal(st3, st)
+    assert not ops.maxpool2x2_bnstats_supported(n, h, w + 2)
+    with pytest.raises(Exception):
+        ops.maxpool2x2_backward_add_bnstats(z[:, :, :, :w - 2].contiguous(), dpool[:, :, :, :w // 2 - 1].contiguous(), None, mean, invstd, gamma, beta)
+
+
+@pytest.mark.parametrize("case", POOL_BNSUMS_CASES)
+def test_bn_backward_sums_from_the_max_pool_backward_emulated(emu, case):
+    _pool_bnsums_case(case, "cpu")
+
+
 def _inpaint_train_grads(net, coor, mask, gt):
     for p in net.parameters():
         p.grad = None

@@ -266,8 +266,9 @@ def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
     x = nets.synth_input((2, 9, 32, 64), 5).to(gpu_device)
     y = nets.disc_heatmaps(2, 3, 32, 64, 6).to(gpu_device)
     sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 21, calibrated=True)
-    real, real_tiles, real_fused = ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43
-    for fused in (False, True):      # the sums by their own pass / (round 6) from the F(4x4) data gradient's write-out where a layer's input is the previous activation
+    real, real_tiles, real_fused, real_pool = ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43, tuning.BN_BWD_STATS_IN_POOL
+    for fused in (False, True):      # the sums by their own pass / (round 6) from the pass that produces dA: the F(4x4) data gradient's write-out where a
+                                     # layer's input is the previous activation, the max-pool backward for the last layer of a down block
         grads, calls, tiles = [], [], []
 
         def spy(da, a, *args, **kw):
@@ -278,7 +279,7 @@ def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
             tiles.append(1)
             return real_tiles(*args, **kw)
 
-        ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43 = spy, spy_tiles, fused
+        ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43, tuning.BN_BWD_STATS_IN_POOL = spy, spy_tiles, fused, fused
         try:
             for bump in (False, True):
                 m = get_model("TrackNet", 3, "")
@@ -292,10 +293,10 @@ def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
                 loss.backward()
                 # a bumped block never takes the fused route (its mask could not be recomputed from z): it goes through the plain pass, mask from a
                 assert calls.count(False) == (1 if bump else 0) and len(calls) + len(tiles) == 17, (fused, bump, calls, len(tiles))
-                assert (len(tiles) > 0) == fused
+                assert (len(tiles) >= 3) if fused else (len(tiles) == 0), (fused, bump, len(tiles))      # the three pools + the layers inside blocks whose shape the F(4x4) data gradient takes
                 grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
         finally:
-            ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43 = real, real_tiles, real_fused
+            ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43, tuning.BN_BWD_STATS_IN_POOL = real, real_tiles, real_fused, real_pool
         if not fused:
             assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
         else:       # the bumped block's two sums are added in another fp64 order (its own pass instead of per-tile partials): equal to the last bits
@@ -540,3 +541,35 @@ def test_bn_backward_sums_from_the_f43_data_gradient_epilogue(gpu_device, case):
     (conv3x3_wino43s_kernel<.., STATS = 2>; the training default inside Double / Triple blocks) at small and network shapes, both geometries."""
     from test_emu_training import _bn_bwd_epilogue43_case
     _bn_bwd_epilogue43_case(case, gpu_device)
+
+
+@pytest.mark.parametrize("case", [(2, 3, 8, 12, True), (1, 2, 6, 260, False), (10, 64, 288, 512, True), (10, 128, 144, 256, True), (10, 256, 72, 128, True)])
+def test_bn_backward_sums_from_the_max_pool_backward(gpu_device, case):
+    """Round 6: the max-pool backward + skip add that also takes the down block's last BatchNorm + ReLU backward sums (it reads z instead of a), at small
+    shapes and at the three network shapes."""
+    from test_emu_training import _pool_bnsums_case
+    _pool_bnsums_case(case, gpu_device)
+
+
+def test_train_step_with_and_without_the_pool_route(gpu_device):
+    """tuning.BN_BWD_STATS_IN_POOL on / off: the same loss bits, every gradient within the distance of two fp64 summation orders."""
+    from tracknetv3_amd import tuning
+    from tracknetv3_amd.utils.general import get_model
+    from tracknetv3_amd.utils.metric import WBCELoss
+    x = nets.synth_input((2, 9, 64, 128), 15).to(gpu_device)
+    y = nets.disc_heatmaps(2, 3, 64, 128, 16).to(gpu_device)
+    sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 22, calibrated=True)
+    real, res = tuning.BN_BWD_STATS_IN_POOL, {}
+    try:
+        for flag in (True, False):
+            tuning.BN_BWD_STATS_IN_POOL = flag
+            m = get_model("TrackNet", 3, "")
+            m.load_state_dict(sd, strict=True)
+            m = m.to(gpu_device).train()
+            loss = WBCELoss(m(x), y)
+            loss.backward()
+            res[flag] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        tuning.BN_BWD_STATS_IN_POOL = real
+    assert res[True][0] == res[False][0]
+    assert max(rel_err(res[True][1][k].cpu(), res[False][1][k].cpu()) for k in res[True][1]) <= 2e-6

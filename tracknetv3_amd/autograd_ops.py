@@ -295,9 +295,9 @@ def _train_backward_body(ctx, dev, head_backward):
                 break
         return t
 
-    def chain_bwd(count, da, first_needs_dx=True):
+    def chain_bwd(count, da, first_needs_dx=True, stats=None):
         nonlocal idx
-        d_skip, stats = None, None
+        d_skip = None
         for k in range(count):
             rec = saved[idx]
             idx -= 1
@@ -312,13 +312,23 @@ def _train_backward_body(ctx, dev, head_backward):
     da, d_x1 = chain_bwd(2, da)                        # (the first block of each chain returns the gradient of the
     da, d_x2 = chain_bwd(2, da)                        # up_block_2      low-resolution operand of nn.Upsample directly)
     da, d_x3 = chain_bwd(3, da)                        # up_block_1
+    def pool_bwd(x, d_pool, d_skip):
+        """Gradient of a down block's output x = ReLU(BN(z)) (pooled below, concatenated into the decoder): the routed pool gradient + the skip
+        half's.  Round 6: the pass also takes the block's last layer's BatchNorm-backward sums (it reads that layer's z instead of x)."""
+        rec = saved[idx]                                   # the down block's last layer
+        n, _, h, w = (int(v) for v in x.shape)
+        if (tuning.BN_BWD_STATS_IN_POOL and bn_unchanged(rec) and rec["a"] is x and ops.maxpool2x2_bnstats_supported(n, h, w)):
+            bn = rec["blk"].bn
+            return ops.maxpool2x2_backward_add_bnstats(rec["z"], d_pool, d_skip, rec["mean"], rec["invstd"], bn.weight.detach(), bn.bias.detach())
+        return ops.maxpool2x2_backward_add(x, d_pool, d_skip), None
+
     d_pool3, _ = chain_bwd(3, da)                      # bottleneck -> gradient of pool(x3)
-    da = ops.maxpool2x2_backward_add(x3, d_pool3, from_side(d_x3))
-    d_pool2, _ = chain_bwd(3, da)                      # down_block_3
-    da = ops.maxpool2x2_backward_add(x2, d_pool2, from_side(d_x2))
-    d_pool1, _ = chain_bwd(2, da)                      # down_block_2
-    da = ops.maxpool2x2_backward_add(x1, d_pool1, from_side(d_x1))
-    dx, _ = chain_bwd(2, da, first_needs_dx=ctx.need_dx)   # down_block_1
+    da, st = pool_bwd(x3, d_pool3, from_side(d_x3))
+    d_pool2, _ = chain_bwd(3, da, stats=st)            # down_block_3
+    da, st = pool_bwd(x2, d_pool2, from_side(d_x2))
+    d_pool1, _ = chain_bwd(2, da, stats=st)            # down_block_2
+    da, st = pool_bwd(x1, d_pool1, from_side(d_x1))
+    dx, _ = chain_bwd(2, da, first_needs_dx=ctx.need_dx, stats=st)   # down_block_1
     if side is not None:
         main.wait_stream(side)                                   # every weight gradient is final for whoever comes next
     keep.clear()

@@ -12,6 +12,7 @@
 namespace tnv3 {
 
 typedef float t_f32x4 __attribute__((ext_vector_type(4)));
+typedef float t_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kRedSplit = 64;   // partial sums per channel / per sample
 
@@ -715,6 +716,71 @@ inline __global__ void __launch_bounds__(256) maxpool2x2_bwd_add_kernel(const fl
     dx[i00 + W] = (has ? dskip[i00 + W] : 0.0f) + (am == 2 ? g : 0.0f);
     dx[i00 + W + 1] = (has ? dskip[i00 + W + 1] : 0.0f) + (am == 3 ? g : 0.0f);
   }
+}
+
+// Round 6: the same routing, for a pooled tensor that is a = ReLU(BN(z)) of a block this step normalised (model.py:9-10 in front of model.py:48,
+// 51, 54), which ALSO takes that block's two BatchNorm + ReLU backward sums of the gradient it writes: tile_stats[c][s] = (sum g, sum g * zhat)
+// over slice s of channel c, g = dx where a > 0 (bn_tile_stats_bwd_finalize_kernel's input: the separate sums pass over (dA, z) is gone).  a is
+// recomputed from z with the forward's own expression (bn_apply_relu_kernel: bit-identical, so the first maximum is the same one) -- the pass
+// reads z instead of a: the sums cost no HBM traffic.  grid = (n_slices, C), 256 threads; a thread = two windows (2 rows x 4 columns).
+// Needs W % 4 == 0, H % 2 == 0, 16-byte aligned z / dskip / dx, 8-byte aligned dpool.
+inline __global__ void __launch_bounds__(256) maxpool2x2_bwd_add_bnsums_kernel(const float* __restrict__ z, const float* __restrict__ dpool,
+                                                                        const float* __restrict__ dskip, float* __restrict__ dx,
+                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                        double* __restrict__ tile_stats, int N, int C, int H, int W) {
+  __shared__ double red[4];
+  const int c = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+  const int Ho = H >> 1, W4 = W >> 2, Wo = W >> 1;
+  const int per_n = Ho * W4;
+  const long total = (long)N * per_n;
+  const float mu = mean[c], is = invstd[c], sc = bn_scale(gamma[c], is), sh = beta[c];
+  const bool has = dskip != nullptr;
+  double s1 = 0.0, s2 = 0.0;
+  for (long t = (long)s * 256 + threadIdx.x; t < total; t += (long)S * 256) {
+    const int n = (int)(t / per_n);
+    const int r = (int)(t - (long)n * per_n);
+    const int oh = r / W4, q = r - oh * W4;
+    const size_t plane = (size_t)n * C + c;
+    const size_t i0 = (plane * H + 2 * oh) * W + 4 * q;
+    const t_f32x4 z0 = *reinterpret_cast<const t_f32x4*>(z + i0), z1 = *reinterpret_cast<const t_f32x4*>(z + i0 + W);
+    const t_f32x2 gp = *reinterpret_cast<const t_f32x2*>(dpool + (plane * Ho + oh) * Wo + 2 * q);
+    t_f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (has) { d0 = *reinterpret_cast<const t_f32x4*>(dskip + i0); d1 = *reinterpret_cast<const t_f32x4*>(dskip + i0 + W); }
+    t_f32x4 a0, a1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float y0 = fmaf(z0[k] - mu, sc, sh), y1 = fmaf(z1[k] - mu, sc, sh);
+      a0[k] = y0 > 0.0f ? y0 : 0.0f;
+      a1[k] = y1 > 0.0f ? y1 : 0.0f;
+    }
+#pragma unroll
+    for (int wnd = 0; wnd < 2; ++wnd) {
+      const float v0 = a0[2 * wnd], v1 = a0[2 * wnd + 1], v2 = a1[2 * wnd], v3 = a1[2 * wnd + 1];
+      int am = 0; float m = v0;                           // (a is never NaN here: a NaN y fails y > 0)
+      if (v1 > m) { m = v1; am = 1; }
+      if (v2 > m) { m = v2; am = 2; }
+      if (v3 > m) { m = v3; am = 3; }
+      const float g = gp[wnd];
+      d0[2 * wnd] += am == 0 ? g : 0.0f;
+      d0[2 * wnd + 1] += am == 1 ? g : 0.0f;
+      d1[2 * wnd] += am == 2 ? g : 0.0f;
+      d1[2 * wnd + 1] += am == 3 ? g : 0.0f;
+    }
+    *reinterpret_cast<t_f32x4*>(dx + i0) = d0;
+    *reinterpret_cast<t_f32x4*>(dx + i0 + W) = d1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g0 = a0[k] > 0.0f ? d0[k] : 0.0f, g1 = a1[k] > 0.0f ? d1[k] : 0.0f;
+      s1 += (double)g0;
+      s2 += (double)g0 * (double)((z0[k] - mu) * is);
+      s1 += (double)g1;
+      s2 += (double)g1 * (double)((z1[k] - mu) * is);
+    }
+  }
+  const double r1 = block_sum_256(s1, red);
+  const double r2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) { tile_stats[((size_t)c * S + s) * 2] = r1; tile_stats[((size_t)c * S + s) * 2 + 1] = r2; }
 }
 
 // nearest 2x upsample backward: d_lo[h][w] = sum of the 2x2 block of d_hi

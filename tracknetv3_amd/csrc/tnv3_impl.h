@@ -1555,6 +1555,27 @@ int maxpool2x2_backward_add_impl(Launcher& L, const float* x, const float* dpool
   return L.launch(maxpool2x2_bwd_add_kernel, grid_for(nc * (h / 2) * (w / 2)), 256, x, dpool, dskip, dx, nc, h, w);
 }
 
+// Slices per channel of the sums maxpool2x2_backward_add_bnstats leaves (its tile_stats is [c][slices][2] doubles): a workgroup of 256
+// threads walks a slice, a thread takes 2 x 4 pixels per iteration -- about four iterations per thread, at most kRedSplit slices.
+inline int maxpool2x2_bnstats_slices(int n, int h, int w) {
+  if (n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 3)) return 0;
+  const long units = (long)n * (h / 2) * (w / 4);
+  const long s = (units + 1023) / 1024;
+  return (int)(s < 1 ? 1 : (s > kRedSplit ? kRedSplit : s));
+}
+template <class Launcher>
+int maxpool2x2_backward_add_bnstats_impl(Launcher& L, const float* z, const float* dpool, const float* dskip, float* dx, const float* mean,
+                                         const float* invstd, const float* gamma, const float* beta, double* tile_stats, int n, int c, int h, int w) {
+  if (!z || !dpool || !dx || !mean || !invstd || !gamma || !beta || !tile_stats || n <= 0 || c <= 0)
+    TNV3_FAIL(-1, "maxpool2x2_backward_add_bnstats: bad argument");
+  const int slices = maxpool2x2_bnstats_slices(n, h, w);
+  if (!slices) TNV3_FAIL(-1, "maxpool2x2_backward_add_bnstats: needs H %% 2 == 0 and W %% 4 == 0 (got %dx%d)", h, w);
+  if ((((uintptr_t)z | (uintptr_t)dskip | (uintptr_t)dx) & 15) || (((uintptr_t)dpool | (uintptr_t)tile_stats) & 7))
+    TNV3_FAIL(-1, "maxpool2x2_backward_add_bnstats: z / dskip / dx must be 16-byte aligned, dpool and the sums 8-byte");
+  if (c > 65535) TNV3_FAIL(-1, "maxpool2x2_backward_add_bnstats: too many channels");
+  return L.launch3(maxpool2x2_bwd_add_bnsums_kernel, slices, c, 1, 256, z, dpool, dskip, dx, mean, invstd, gamma, beta, tile_stats, n, c, h, w);
+}
+
 template <class Launcher>
 int upsample2x_backward_impl(Launcher& L, const float* d_hi, float* d_lo, long nc, int hl, int wl) {
   if (!d_hi || !d_lo || nc <= 0 || hl <= 0 || wl <= 0) TNV3_FAIL(-1, "upsample2x_backward: bad argument");

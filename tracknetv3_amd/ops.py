@@ -933,6 +933,32 @@ def maxpool2x2_backward_add(x, dpool, dskip=None):
     return dx
 
 
+def maxpool2x2_bnstats_supported(n, h, w):
+    return _lib.load().tnv3_maxpool2x2_bn_stats_tiles(int(n), int(h), int(w)) > 0
+
+
+def maxpool2x2_backward_add_bnstats(z, dpool, dskip, mean, invstd, gamma, beta):
+    """maxpool2x2_backward_add for a pooled tensor that is ReLU(BatchNorm(z)) of a block normalised in this step: returns (dx, tile_stats) --
+    tile_stats [C][slices][2] float64, that block's two BatchNorm-backward sums of dx, for bn_relu_backward_tiles (autograd of model.py:9-10
+    behind model.py:48,51,54)."""
+    lib = _lib.load()
+    _f32(z, dpool, dskip, mean, invstd, gamma, beta)
+    _lib.dev_check(z, dpool, dskip, mean, invstd, gamma, beta)
+    n, c, h, w = (int(v) for v in z.shape)
+    if tuple(dpool.shape) != (n, c, h // 2, w // 2) or (dskip is not None and dskip.shape != z.shape):
+        raise _lib.Tnv3Error("maxpool2x2_backward_add_bnstats: shape mismatch")
+    if not (z.is_contiguous() and dpool.is_contiguous() and (dskip is None or dskip.is_contiguous())):
+        raise _lib.Tnv3Error("maxpool2x2_backward_add_bnstats: contiguous tensors required")
+    slices = lib.tnv3_maxpool2x2_bn_stats_tiles(n, h, w)
+    if slices <= 0:
+        raise _lib.Tnv3Error(f"maxpool2x2_backward_add_bnstats: needs H % 2 == 0 and W % 4 == 0 (got {h}x{w})")
+    dx = torch.empty_like(z)
+    st = torch.empty((c, slices, 2), dtype=torch.float64, device=z.device)
+    _lib.check(lib.tnv3_maxpool2x2_backward_add_bnstats(_lib.ptr(z), _lib.ptr(dpool), _lib.ptr(dskip), _lib.ptr(dx), _lib.ptr(mean), _lib.ptr(invstd),
+                                                        _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(st), n, c, h, w, _lib.stream_ptr(z)))
+    return dx, st
+
+
 def upsample2x_backward(d_hi):
     lib = _lib.load()
     _f32(d_hi)
@@ -1097,7 +1123,7 @@ _TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pa
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "bn_bwd_consts", "conv3x3_wino_dgrad_bnstats", "bn_relu_backward_tiles", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
-               "maxpool2x2_backward_add", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad",
+               "maxpool2x2_backward_add", "maxpool2x2_backward_add_bnstats", "maxpool2x2_bnstats_supported", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad",
                "grad_norm", "adam_step", "sgd_step", "inpaintnet_pack", "inpaintnet_pack_t", "inpaintnet_fused_train_forward", "inpaintnet_fused_backward"]          # list-of-tensor ops: the guard looks inside the lists
 for _name in _TENSOR_OPS:
     globals()[_name] = _lib.on_tensor_device(globals()[_name])

@@ -263,6 +263,10 @@ BN_BWD_STATS_IN_DGRAD = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD", "0") == "1"
 # vector work costs 1-3 % of a data-gradient launch from 128 channels up (13 % on the two 64-channel launches).  Applies to the 10 of the 17 layers
 # whose input is the previous layer's activation (inside a Double / Triple block).  TNV3_BN_BWD_STATS_IN_DGRAD43=0: the separate sums pass.
 BN_BWD_STATS_IN_DGRAD43 = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD43", "1") != "0"
+# Round 6: ... and for the last layer of each down block (its gradient comes out of the max-pool backward + skip add, not out of a data
+# gradient) from that pass (ops.maxpool2x2_backward_add_bnstats: it reads z instead of a, the sums cost no traffic).
+# TNV3_BN_BWD_STATS_IN_POOL=0: the separate sums pass.
+BN_BWD_STATS_IN_POOL = os.environ.get("TNV3_BN_BWD_STATS_IN_POOL", "1") != "0"
 
 
 def wino_has_stats():
