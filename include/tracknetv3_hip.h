@@ -46,7 +46,8 @@ extern "C" {
                                     on tnv3_dgrad_up2x_wino (its data gradient on the 16x16x4 kernel);
                                  7: tnv3_conv3x3_wino43_dgrad_bnstats (the F(4x4) data gradient that takes the previous block's BatchNorm-backward
                                     sums from its write-out);
-                                 8: tnv3_maxpool2x2_backward_add_bnstats (the max-pool backward + skip add that takes them the same way) */
+                                 8: tnv3_maxpool2x2_backward_add_bnstats (the max-pool backward + skip add that takes them the same way);
+                                    tnv3_bn_train_forward_tiles_pool (the normalise + ReLU pass that also writes the pooled tensor) */
 
 typedef void* tnv3_stream_t;
 
@@ -387,6 +388,12 @@ int tnv3_bn_train_forward(const float* z, const float* gamma, const float* beta,
 int tnv3_bn_train_forward_tiles(const float* z, const double* tile_stats, long n_tiles, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float eps, float momentum, float* a, float* save_mean,
                                 float* save_invstd, void* workspace, size_t workspace_bytes, int n, int c, int hw, tnv3_stream_t stream);
+
+/* ABI 8.  ... for a block whose output is pooled next (a down block's last layer, model.py:47-48, 50-51, 53-54): the normalise + ReLU pass also
+ * writes pooled = MaxPool2d(2, 2)(a) [n][c][h / 2][w / 2] -- the separate pooling pass and its read of a are gone.  h % 2 == 0, w % 4 == 0. */
+int tnv3_bn_train_forward_tiles_pool(const float* z, const double* tile_stats, long n_tiles, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float eps, float momentum, float* a, float* pooled, float* save_mean,
+                                     float* save_invstd, void* workspace, size_t workspace_bytes, int n, int c, int h, int w, tnv3_stream_t stream);
 
 /* Backward of the same: given dA (gradient w.r.t. a), z and the saved statistics, writes dZ (may alias dA),
  * dgamma[C], dbeta[C].  The ReLU mask comes from `a` when it is given; with a == NULL it is recomputed from z, gamma, beta

@@ -482,6 +482,28 @@ def test_bn_backward_sums_from_the_f43_data_gradient_epilogue_emulated(emu, monk
     _bn_bwd_epilogue43_case(case, "cpu")
 
 
+def _bn_apply_pool_case(case, device):
+    """bn_train_forward(pool=True) == bn_train_forward + maxpool2x2, bit for bit (a, the saved statistics, the running statistics, the pooled tensor)."""
+    from tracknetv3_amd import ops
+    n, c, h, w = case
+    z = T((n, c, h, w), 731, -1.0, 1.0).to(device)
+    gamma, beta = T((c,), 732, 0.5, 1.5).to(device), T((c,), 733, -0.3, 0.3).to(device)
+    st = torch.stack([z.double().sum((0, 2, 3)), (z.double() ** 2).sum((0, 2, 3))], 1).reshape(c, 1, 2).contiguous()
+    rm0, rv0 = torch.zeros(c, device=device), torch.ones(c, device=device)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    a0, m0, i0 = ops.bn_train_forward(z, gamma, beta, rm0, rv0, 1e-5, 0.1, tile_stats=st)
+    a1, m1, i1, p1 = ops.bn_train_forward(z, gamma, beta, rm1, rv1, 1e-5, 0.1, tile_stats=st, pool=True)
+    assert torch.equal(a0, a1) and torch.equal(m0, m1) and torch.equal(i0, i1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+    assert torch.equal(p1, ops.maxpool2x2(a0)) and torch.equal(p1.cpu(), F.max_pool2d(a0.cpu(), 2, 2))
+    a2, _, _, p2 = ops.bn_train_forward(z, gamma, beta, rm1.clone(), rv1.clone(), 1e-5, 0.1, pool=True)      # (no tile statistics: the two-pass fallback)
+    assert torch.equal(p2, ops.maxpool2x2(a2))
+
+
+@pytest.mark.parametrize("case", [(2, 3, 8, 12), (1, 5, 2, 4), (3, 2, 6, 260)])
+def test_bn_apply_that_also_writes_the_pooled_tensor_emulated(emu, case):
+    _bn_apply_pool_case(case, "cpu")
+
+
 POOL_BNSUMS_CASES = [(2, 3, 8, 12, True), (3, 5, 4, 8, False), (1, 2, 6, 260, True), (10, 4, 16, 64, True)]
 
 

@@ -573,3 +573,10 @@ def test_train_step_with_and_without_the_pool_route(gpu_device):
         tuning.BN_BWD_STATS_IN_POOL = real
     assert res[True][0] == res[False][0]
     assert max(rel_err(res[True][1][k].cpu(), res[False][1][k].cpu()) for k in res[True][1]) <= 2e-6
+
+
+@pytest.mark.parametrize("case", [(2, 3, 8, 12), (10, 64, 288, 512), (10, 128, 144, 256), (10, 256, 72, 128)])
+def test_bn_apply_that_also_writes_the_pooled_tensor(gpu_device, case):
+    """Round 6: the normalise + ReLU pass of a down block's last layer also writes MaxPool2d(2, 2) of its output (tnv3_bn_train_forward_tiles_pool)."""
+    from test_emu_training import _bn_apply_pool_case
+    _bn_apply_pool_case(case, gpu_device)

@@ -74,6 +74,7 @@ def _declare(lib):
     sig("tnv3_conv3x3_wino_stats_tiles", lg, i, i, i, i)
     sig("tnv3_conv3x3_wino_forward_stats", i, p, p, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_bn_train_forward_tiles", i, p, p, lg, p, p, p, p, f, f, p, p, p, p, sz, i, i, i, p)
+    sig("tnv3_bn_train_forward_tiles_pool", i, p, p, lg, p, p, p, p, f, f, p, p, p, p, p, sz, i, i, i, i, p)
     sig("tnv3_conv3x3_wgrad_wino_supported", i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad_wino_workspace_bytes", sz, i, i, i, i, i)
     sig("tnv3_conv3x3_wgrad_wino", i, p, p, p, p, sz, i, i, i, i, i, i, p)
@@ -150,7 +151,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_dgrad_up2x_wino_pack", "tnv3_dgrad_up2x_wino", "tnv3_dgrad_up2x_packed_floats", "tnv3_pack_dgrad_up2x_weights",
            "tnv3_dgrad_up2x", "tnv3_conv3x3_wgrad_up2x_workspace_bytes", "tnv3_conv3x3_wgrad_up2x",
            "tnv3_conv3x3_wgrad_wino_supported", "tnv3_conv3x3_wgrad_wino_workspace_bytes", "tnv3_conv3x3_wgrad_wino",
-           "tnv3_conv3x3_wino_stats_tiles", "tnv3_conv3x3_wino_forward_stats", "tnv3_bn_train_forward_tiles",
+           "tnv3_conv3x3_wino_stats_tiles", "tnv3_conv3x3_wino_forward_stats", "tnv3_bn_train_forward_tiles", "tnv3_bn_train_forward_tiles_pool",
            "tnv3_conv3x3_wino_packed_floats", "tnv3_conv3x3_wino_layout", "tnv3_conv3x3_wino_has_stats", "tnv3_conv3x3_wino_pick", "tnv3_conv3x3_wino_supported", "tnv3_conv3x3_wino_pack", "tnv3_conv3x3_wino_pack_view", "tnv3_conv3x3_wino_pack_multi", "tnv3_conv3x3_wino_forward",
            "tnv3_conv3x3_wino43_supported", "tnv3_conv3x3_wino43_packed_floats", "tnv3_conv3x3_wino43_pack", "tnv3_conv3x3_wino43_forward",
            "tnv3_conv3x3_wino43_stats_tiles", "tnv3_conv3x3_wino43_forward_stats", "tnv3_conv3x3_wino43_dgrad_bnstats"]

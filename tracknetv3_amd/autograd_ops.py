@@ -87,7 +87,9 @@ def _train_forward_body(net, x):
     if tuning.WINO_REPACK_MULTI:
         net.repack_wino_panels()        # the panels the optimiser step made stale, forward and backward ones, in one launch
 
-    def block_fwd(blk, src0, src1=None, up=False):
+    pooled_of = {}         # id(a) -> MaxPool2d(2, 2)(a), written by the BatchNorm + ReLU pass of a down block's last layer
+
+    def block_fwd(blk, src0, src1=None, up=False, pool=False):
         h = src0.shape[2] * (2 if up else 1)
         w = src0.shape[3] * (2 if up else 1)
         stats = None           # BatchNorm's batch statistics taken in the conv epilogue (Winograd kernels 3 / 4), else a pass over z
@@ -103,25 +105,32 @@ def _train_forward_body(net, x):
         else:
             z = ops.conv3x3(src0, blk.packed_weight(), blk.conv.out_dim, src1=src1, up0=up, relu=False, cfg=_cfg(blk, n, h, w))
         bn = blk.bn
-        a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                               bn.eps, bn.momentum, tile_stats=stats)
+        if pool and tuning.POOL_IN_BN_APPLY:
+            a, mean, invstd, pooled_of["y"] = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                                   bn.eps, bn.momentum, tile_stats=stats, pool=True)
+        else:
+            a, mean, invstd = ops.bn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                   bn.eps, bn.momentum, tile_stats=stats)
+            if pool:
+                pooled_of["y"] = ops.maxpool2x2(a)
         bumped.append(bn.num_batches_tracked)           # (+= 1 for all 17 layers in ONE launch behind the last layer: they were 17 launches on the chain)
         blk._cache.pop("aff", None)       # running_var was rewritten through a raw pointer: the folded eval scale is stale
         saved.append(dict(blk=blk, idx=len(saved), x0=src0, x1=src1, up=up, z=z, a=a, mean=mean, invstd=invstd,
                           bn_ver=(bn.weight._version, bn.bias._version)))
         return a
 
-    def chain(blks, src0, src1=None, up=False):
-        y = block_fwd(blks[0], src0, src1, up)
-        for b in blks[1:]:
-            y = block_fwd(b, y)
-        return y
+    def chain(blks, src0, src1=None, up=False, pool=False):
+        """pool: the chain's output is pooled next -- returns (y, MaxPool2d(2, 2)(y))"""
+        y = block_fwd(blks[0], src0, src1, up, pool=pool and len(blks) == 1)
+        for k, b in enumerate(blks[1:]):
+            y = block_fwd(b, y, pool=pool and k == len(blks) - 2)
+        return (y, pooled_of.pop("y")) if pool else y
 
     d1, d2, d3, bt, u1, u2, u3 = _blocks(net)
-    x1 = chain(d1, x)
-    x2 = chain(d2, ops.maxpool2x2(x1))
-    x3 = chain(d3, ops.maxpool2x2(x2))
-    y = chain(bt, ops.maxpool2x2(x3))
+    x1, p1 = chain(d1, x, pool=True)
+    x2, p2 = chain(d2, p1, pool=True)
+    x3, p3 = chain(d3, p2, pool=True)
+    y = chain(bt, p3)
     y = chain(u1, y, x3, True)
     y = chain(u2, y, x2, True)
     y = chain(u3, y, x1, True)

@@ -145,6 +145,38 @@ inline __global__ void __launch_bounds__(256) bn_apply_relu_kernel(const float* 
   }
 }
 
+// The same pass for a block whose output is pooled next (model.py:47-48, 50-51, 53-54: a down block's last layer): it also writes
+// MaxPool2d(2, 2) of the a it forms -- pointwise.h's maxpool2x2_kernel without its read of a.  Thread = two windows (2 rows x 4 columns).
+// a is never NaN here (a NaN y fails y > 0), so the window maximum needs no order.  Needs W % 4 == 0, H % 2 == 0.
+inline __global__ void __launch_bounds__(256) bn_apply_relu_pool_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 float* __restrict__ a, float* __restrict__ pooled, long NC, int C, int H, int W) {
+  const int Ho = H >> 1, W4 = W >> 2, Wo = W >> 1;
+  const long total = NC * Ho * W4;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(t % W4);
+    const long u = t / W4;
+    const int oh = (int)(u % Ho);
+    const long nc = u / Ho;
+    const int c = (int)(nc % C);
+    const float mu = mean[c], sc = scale[c], sh = shift[c];
+    const size_t i0 = ((size_t)nc * H + 2 * oh) * W + 4 * q;
+    t_f32x4 v0 = *reinterpret_cast<const t_f32x4*>(z + i0), v1 = *reinterpret_cast<const t_f32x4*>(z + i0 + W);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float y0 = fmaf(v0[k] - mu, sc, sh), y1 = fmaf(v1[k] - mu, sc, sh);
+      v0[k] = y0 > 0.0f ? y0 : 0.0f;
+      v1[k] = y1 > 0.0f ? y1 : 0.0f;
+    }
+    *reinterpret_cast<t_f32x4*>(a + i0) = v0;
+    *reinterpret_cast<t_f32x4*>(a + i0 + W) = v1;
+    t_f32x2 o;
+    o[0] = fmaxf(fmaxf(v0[0], v0[1]), fmaxf(v1[0], v1[1]));
+    o[1] = fmaxf(fmaxf(v0[2], v0[3]), fmaxf(v1[2], v1[3]));
+    *reinterpret_cast<t_f32x2*>(pooled + ((size_t)nc * Ho + oh) * Wo + 2 * q) = o;
+  }
+}
+
 // ---- BatchNorm + ReLU backward ---------------------------------------------------------------------------------
 // g = dA * (a > 0);  partial[c][s] = (sum g, sum g*xhat), xhat = (z - mean) * invstd.      grid = (kRedSplit, C)
 // FROM_Z: the mask is recomputed from z with the forward's own expression (bit-identical to a > 0) instead of reading a:

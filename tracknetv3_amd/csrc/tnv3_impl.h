@@ -435,10 +435,13 @@ inline long conv3x3_wino_stats_tiles(int n, int h, int w, int variant = 5) {
 template <class Launcher>
 int bn_train_forward_tiles_impl(Launcher& L, const float* z, const double* tile_stats, long n_tiles, const float* gamma, const float* beta,
                                 float* rm, float* rv, float eps, float momentum, float* a, float* save_mean, float* save_invstd, void* ws,
-                                size_t ws_bytes, int n, int c, int hw) {
+                                size_t ws_bytes, int n, int c, int hw, float* pooled = nullptr, int h = 0, int w = 0) {
+  // pooled (round 6, tnv3_bn_train_forward_tiles_pool): MaxPool2d(2, 2) of a [n][c][h / 2][w / 2], written by the normalise + ReLU pass itself
   if (!z || !tile_stats || !gamma || !beta || !rm || !rv || !a || !save_mean || !save_invstd || !ws || n <= 0 || c <= 0 || hw <= 0 || n_tiles <= 0)
     TNV3_FAIL(-1, "bn_train_forward_tiles: bad argument");
   if (hw % 4) TNV3_FAIL(-1, "bn_train_forward_tiles: H*W must be a multiple of 4");
+  if (pooled && (h <= 0 || w <= 0 || (h & 1) || (w & 3) || (long)h * w != hw || (((uintptr_t)pooled) & 7) || (((uintptr_t)z | (uintptr_t)a) & 15)))
+    TNV3_FAIL(-1, "bn_train_forward_tiles_pool: needs H %% 2 == 0, W %% 4 == 0, 16-byte aligned z / a and an 8-byte aligned pooled output");
   if (ws_bytes < bn_workspace_bytes(c) || (((uintptr_t)ws) & 7)) TNV3_FAIL(-1, "bn_train_forward_tiles: workspace too small / misaligned");
   double* partial = (double*)ws;
   float* scale = (float*)(partial + (size_t)c * kRedSplit * 2);
@@ -446,6 +449,9 @@ int bn_train_forward_tiles_impl(Launcher& L, const float* z, const double* tile_
   // (one launch: the tiles' fixed-order sums and the finalize -- bit-identical to bn_tile_stats_reduce_kernel + bn_stats_finalize_kernel)
   if ((rc = L.launch(bn_tile_stats_finalize_kernel, c, 1024, tile_stats, n_tiles, gamma, rm, rv, eps, momentum, (long)n * hw, scale, save_mean,
                      save_invstd))) return rc;
+  if (pooled)
+    return L.launch(bn_apply_relu_pool_kernel, grid_for((long)n * c * (hw / 8)), 256, z, (const float*)save_mean, (const float*)scale, beta, a, pooled,
+                    (long)n * c, c, h, w);
   return L.launch(bn_apply_relu_kernel, grid_for((long)n * c * (hw / 4)), 256, z, (const float*)save_mean, (const float*)scale, beta, a,
                   (long)n * c, c, hw);
 }

@@ -630,10 +630,31 @@ def _grad_out(shape, device, out, what):
     return out.view(shape)
 
 
-def bn_train_forward(z, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=0.1, tile_stats=None):
+def bn_train_forward(z, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=0.1, tile_stats=None, pool=False):
     """Training-mode BatchNorm2d + ReLU on the raw conv output; updates running stats in place.
     Returns (a, save_mean, save_invstd).  tile_stats: the (C, tiles, 2) float64 sums the producing convolution's epilogue left
-    (conv3x3_wino_stats) -- the statistics pass over z is then skipped."""
+    (conv3x3_wino_stats) -- the statistics pass over z is then skipped.  pool=True: returns (a, save_mean, save_invstd, MaxPool2d(2, 2)(a)) --
+    written by the normalise + ReLU pass itself where the shape allows (tile_stats given, H % 2 == 0, W % 4 == 0), else by maxpool2x2."""
+    if pool:
+        n, c, h, w = (int(v) for v in z.shape)
+        if tile_stats is None or (h & 1) or (w & 3):
+            a, mean, invstd = bn_train_forward(z, gamma, beta, running_mean, running_var, eps, momentum, tile_stats)
+            return a, mean, invstd, maxpool2x2(a)
+        lib = _lib.load()
+        _f32(z, gamma, beta, running_mean, running_var)
+        _lib.dev_check(z, gamma, beta, running_mean, running_var, tile_stats)
+        if tile_stats.dtype != torch.float64 or tile_stats.dim() != 3 or int(tile_stats.shape[0]) != c or int(tile_stats.shape[2]) != 2:
+            raise _lib.Tnv3Error("bn_train_forward: tile_stats must be float64 (C, tiles, 2)")
+        a = torch.empty_like(z)
+        pooled = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=z.device)
+        mean = torch.empty(c, dtype=torch.float32, device=z.device)
+        invstd = torch.empty_like(mean)
+        ws = _workspace(lib.tnv3_bn_workspace_bytes(c), z.device)
+        _lib.check(lib.tnv3_bn_train_forward_tiles_pool(_lib.ptr(z), _lib.ptr(tile_stats), int(tile_stats.shape[1]), _lib.ptr(gamma), _lib.ptr(beta),
+                                                        _lib.ptr(running_mean), _lib.ptr(running_var), float(eps), float(momentum), _lib.ptr(a),
+                                                        _lib.ptr(pooled), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(ws), ws.numel() * 8, n, c, h, w,
+                                                        _lib.stream_ptr(z)))
+        return a, mean, invstd, pooled
     lib = _lib.load()
     _f32(z, gamma, beta, running_mean, running_var)
     _lib.dev_check(z, gamma, beta, running_mean, running_var, tile_stats)

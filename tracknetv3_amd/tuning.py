@@ -267,6 +267,9 @@ BN_BWD_STATS_IN_DGRAD43 = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD43", "1") !=
 # gradient) from that pass (ops.maxpool2x2_backward_add_bnstats: it reads z instead of a, the sums cost no traffic).
 # TNV3_BN_BWD_STATS_IN_POOL=0: the separate sums pass.
 BN_BWD_STATS_IN_POOL = os.environ.get("TNV3_BN_BWD_STATS_IN_POOL", "1") != "0"
+# Round 6: the forward twin -- the BatchNorm + ReLU pass of a down block's last layer also writes the pooled tensor (no separate pooling pass,
+# no second read of a).  TNV3_POOL_IN_BN_APPLY=0: ops.maxpool2x2 behind it.
+POOL_IN_BN_APPLY = os.environ.get("TNV3_POOL_IN_BN_APPLY", "1") != "0"
 
 
 def wino_has_stats():
