@@ -47,7 +47,8 @@ extern "C" {
                                  7: tnv3_conv3x3_wino43_dgrad_bnstats (the F(4x4) data gradient that takes the previous block's BatchNorm-backward
                                     sums from its write-out);
                                  8: tnv3_maxpool2x2_backward_add_bnstats (the max-pool backward + skip add that takes them the same way);
-                                    tnv3_bn_train_forward_tiles_pool (the normalise + ReLU pass that also writes the pooled tensor) */
+                                    tnv3_bn_train_forward_tiles_pool (the normalise + ReLU pass that also writes the pooled tensor);
+                                    tnv3_dgrad_up2x_wino_bnstats (the upsampled half's data gradient that takes those sums) */
 
 typedef void* tnv3_stream_t;
 
@@ -250,6 +251,13 @@ size_t tnv3_dgrad_up2x_wino_packed_floats(int c0, int cout, int variant);
 int tnv3_dgrad_up2x_wino_pack(const float* w, float* u, int cout, int cin, int c0, int variant, tnv3_stream_t stream);
 int tnv3_dgrad_up2x_wino(const float* dz, const float* u, float* dx_low, int n, int c0, int cout, int h_low, int w_low, int variant,
                          tnv3_stream_t stream);
+/* ABI 8.  Variant 2's launch that also takes the BatchNorm + ReLU backward sums of the block whose activation the decoder entry upsamples
+ * (model.py:64-69: dx_low IS that block's dA, nothing else reads its activation): bn_z = that block's raw convolution output [n][c0][h_low][w_low],
+ * bn_* its saved mean / invstd and the affine parameters as its forward used them; tile_stats [c0][n * (h_low / 2) * (w_low / 32)][2] doubles, to be
+ * fed with dx_low to tnv3_bn_relu_backward_tiles (autograd of model.py:9-10).  The same dx_low bits as tnv3_dgrad_up2x_wino(variant 2). */
+int tnv3_dgrad_up2x_wino_bnstats(const float* dz, const float* u, float* dx_low, double* tile_stats, const float* bn_z, const float* bn_mean,
+                                 const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int n, int c0, int cout, int h_low, int w_low,
+                                 int variant, tnv3_stream_t stream);
 
 /* Weight gradient of a plain layer (single source, no upsampling) in Winograd form: dw[cout][cin][3][3] =
  * G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- per (co, ci) 36 multiply-adds per 4x4 tile in F(4x4, 3x3) form (2.25 per pixel), 16

@@ -482,6 +482,40 @@ def test_bn_backward_sums_from_the_f43_data_gradient_epilogue_emulated(emu, monk
     _bn_bwd_epilogue43_case(case, "cpu")
 
 
+DGRAD_UP2X_BNSUMS_CASES = [(1, 128, 16, 2, 32), (2, 64, 24, 6, 32), (1, 192, 9, 2, 64)]
+
+
+def _dgrad_up2x_bnsums_case(case, device):
+    """dgrad_up2x_wino_bnstats + bn_relu_backward_tiles == dgrad_up2x_wino(variant 2) + bn_relu_backward: the same d_low bits, the same mask expression,
+    the two sums accumulated in fp64 per tile row of 2 x 32 low-resolution pixels (both geometries; a half-empty last tile row)."""
+    from tracknetv3_amd import ops
+    n, c0, cout, hl, wl = case
+    dz, wt = T((n, cout, 2 * hl, 2 * wl), 741).to(device), T((cout, c0 + 8, 3, 3), 742, -0.3, 0.3).to(device)
+    z = T((n, c0, hl, wl), 743, -1.0, 1.0).to(device)
+    gamma, beta = T((c0,), 744, 0.5, 1.5).to(device), T((c0,), 745, -0.3, 0.3).to(device)
+    mean = z.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(z.var((0, 2, 3), unbiased=False) + 1e-5)
+    u = ops.pack_dgrad_up2x_wino_weights(wt, c0, variant=2)
+    d_ref = ops.dgrad_up2x_wino(dz, u, c0, variant=2)
+    dz_ref, dg_ref, db_ref = ops.bn_relu_backward(d_ref.clone(), None, z, gamma, mean, invstd, beta=beta)
+    d, st = ops.dgrad_up2x_wino_bnstats(dz, u, c0, z, mean, invstd, gamma, beta)
+    assert torch.equal(d, d_ref) and tuple(st.shape) == (c0, n * (hl // 2) * (wl // 32), 2)
+    scale = max(d.abs().sum((0, 2, 3)).max().item(), 1.0)
+    assert (st.sum(1)[:, 0] - db_ref.double()).abs().max().item() <= 2e-6 * scale
+    assert (st.sum(1)[:, 1] - dg_ref.double()).abs().max().item() <= 2e-6 * scale
+    dz2, dg2, db2 = ops.bn_relu_backward_tiles(d, z, gamma, beta, mean, invstd, st)
+    assert rel_err(dg2, dg_ref) <= 1e-6 and rel_err(db2, db_ref) <= 1e-6 and rel_err(dz2, dz_ref) <= 1e-6
+    d3, st3 = ops.dgrad_up2x_wino_bnstats(dz, u, c0, z, mean, invstd, gamma, beta)                # deterministic
+    assert torch.equal(d3, d_ref) and torch.equal(st3, st)
+
+
+@pytest.mark.parametrize("cus", [8, 2])
+@pytest.mark.parametrize("case", DGRAD_UP2X_BNSUMS_CASES)
+def test_bn_backward_sums_from_the_upsampled_half_data_gradient_emulated(emu, monkeypatch, case, cus):
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+    _dgrad_up2x_bnsums_case(case, "cpu")
+
+
 def _bn_apply_pool_case(case, device):
     """bn_train_forward(pool=True) == bn_train_forward + maxpool2x2, bit for bit (a, the saved statistics, the running statistics, the pooled tensor)."""
     from tracknetv3_amd import ops

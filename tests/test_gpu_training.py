@@ -266,7 +266,8 @@ def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
     x = nets.synth_input((2, 9, 32, 64), 5).to(gpu_device)
     y = nets.disc_heatmaps(2, 3, 32, 64, 6).to(gpu_device)
     sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 21, calibrated=True)
-    real, real_tiles, real_fused, real_pool = ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43, tuning.BN_BWD_STATS_IN_POOL
+    real, real_tiles, real_fused, real_pool, real_up = (ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43, tuning.BN_BWD_STATS_IN_POOL,
+                                                        tuning.BN_BWD_STATS_IN_DGRAD_UP2X)
     for fused in (False, True):      # the sums by their own pass / (round 6) from the pass that produces dA: the F(4x4) data gradient's write-out where a
                                      # layer's input is the previous activation, the max-pool backward for the last layer of a down block
         grads, calls, tiles = [], [], []
@@ -279,7 +280,8 @@ def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
             tiles.append(1)
             return real_tiles(*args, **kw)
 
-        ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43, tuning.BN_BWD_STATS_IN_POOL = spy, spy_tiles, fused, fused
+        ops.bn_relu_backward, ops.bn_relu_backward_tiles = spy, spy_tiles
+        tuning.BN_BWD_STATS_IN_DGRAD43 = tuning.BN_BWD_STATS_IN_POOL = tuning.BN_BWD_STATS_IN_DGRAD_UP2X = fused
         try:
             for bump in (False, True):
                 m = get_model("TrackNet", 3, "")
@@ -297,6 +299,7 @@ def test_bn_backward_mask_source_follows_parameter_versions(gpu_device):
                 grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
         finally:
             ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD43, tuning.BN_BWD_STATS_IN_POOL = real, real_tiles, real_fused, real_pool
+            tuning.BN_BWD_STATS_IN_DGRAD_UP2X = real_up
         if not fused:
             assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
         else:       # the bumped block's two sums are added in another fp64 order (its own pass instead of per-tile partials): equal to the last bits
@@ -580,3 +583,42 @@ def test_bn_apply_that_also_writes_the_pooled_tensor(gpu_device, case):
     """Round 6: the normalise + ReLU pass of a down block's last layer also writes MaxPool2d(2, 2) of its output (tnv3_bn_train_forward_tiles_pool)."""
     from test_emu_training import _bn_apply_pool_case
     _bn_apply_pool_case(case, gpu_device)
+
+
+@pytest.mark.parametrize("case", [(1, 128, 16, 2, 32), (2, 64, 24, 6, 32), (10, 512, 256, 36, 64), (10, 256, 128, 72, 128), (10, 128, 64, 144, 256)])
+def test_bn_backward_sums_from_the_upsampled_half_data_gradient(gpu_device, case):
+    """Round 6: the decoder entries' low-resolution data gradient (25-of-36 F(4x4) form) that also takes the BatchNorm + ReLU backward sums of the block
+    it writes the gradient of, at small shapes and at the three network shapes."""
+    from test_emu_training import _dgrad_up2x_bnsums_case
+    _dgrad_up2x_bnsums_case(case, gpu_device)
+
+
+def test_which_blocks_keep_a_separate_bn_backward_sums_pass(gpu_device):
+    """At a size every F(4x4) kernel takes (32 x 512: 4 x 64 at the bottleneck): with the round-6 defaults 13 of the 17 blocks get their BatchNorm-backward sums from the pass that
+    produces their dA (data gradient inside blocks, max-pool backward); the head's input layer and the three blocks in front of the decoder entries
+    keep the separate pass -- with TNV3_BN_BWD_STATS_IN_DGRAD_UP2X (measured slower, off) only the head's input layer does.  Same loss bits, gradients
+    within two fp64 summation orders."""
+    from tracknetv3_amd import ops, tuning
+    from tracknetv3_amd.utils.general import get_model
+    from tracknetv3_amd.utils.metric import WBCELoss
+    x = nets.synth_input((2, 9, 32, 512), 15).to(gpu_device)
+    y = nets.disc_heatmaps(2, 3, 32, 512, 16).to(gpu_device)
+    sd = nets.synth_state(nets.tracknet_state_shapes(9, 3), 23, calibrated=True)
+    real, real_tiles, real_up, res = ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD_UP2X, {}
+    try:
+        for up in (False, True):
+            plain, tiles = [], []
+            ops.bn_relu_backward = lambda *a, **k: (plain.append(1), real(*a, **k))[1]
+            ops.bn_relu_backward_tiles = lambda *a, **k: (tiles.append(1), real_tiles(*a, **k))[1]
+            tuning.BN_BWD_STATS_IN_DGRAD_UP2X = up
+            m = get_model("TrackNet", 3, "")
+            m.load_state_dict(sd, strict=True)
+            m = m.to(gpu_device).train()
+            loss = WBCELoss(m(x), y)
+            loss.backward()
+            assert (len(plain), len(tiles)) == ((1, 16) if up else (4, 13)), (up, len(plain), len(tiles))
+            res[up] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        ops.bn_relu_backward, ops.bn_relu_backward_tiles, tuning.BN_BWD_STATS_IN_DGRAD_UP2X = real, real_tiles, real_up
+    assert res[True][0] == res[False][0]
+    assert max(rel_err(res[True][1][k].cpu(), res[False][1][k].cpu()) for k in res[True][1]) <= 2e-6

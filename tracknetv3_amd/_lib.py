@@ -50,6 +50,7 @@ def _declare(lib):
     sig("tnv3_dgrad_up2x_wino_packed_floats", sz, i, i, i)
     sig("tnv3_dgrad_up2x_wino_pack", i, p, p, i, i, i, i, p)
     sig("tnv3_dgrad_up2x_wino", i, p, p, p, i, i, i, i, i, i, p)
+    sig("tnv3_dgrad_up2x_wino_bnstats", i, p, p, p, p, p, p, p, p, p, i, i, i, i, i, i, p)
     sig("tnv3_dgrad_up2x_packed_floats", sz, i, i)
     sig("tnv3_pack_dgrad_up2x_weights", i, p, p, i, i, i, p)
     sig("tnv3_dgrad_up2x", i, p, p, p, i, i, i, i, i, p)
@@ -142,7 +143,7 @@ EXPORTS = ["tnv3_abi_version", "tnv3_last_error", "tnv3_conv3x3_num_configs", "t
            "tnv3_bn_relu_backward", "tnv3_bn_bwd_consts", "tnv3_conv3x3_wino_dgrad_bnstats", "tnv3_bn_relu_backward_tiles", "tnv3_conv3x3_dgrad", "tnv3_conv3x3_wgrad_workspace_bytes", "tnv3_conv3x3_wgrad",
            "tnv3_wbce_workspace_bytes", "tnv3_wbce_forward", "tnv3_wbce_backward", "tnv3_head_backward_workspace_bytes",
            "tnv3_head_backward", "tnv3_head_wbce_workspace_bytes", "tnv3_head1x1_sigmoid_wbce", "tnv3_head_wbce_backward",
-           "tnv3_maxpool2x2_backward_add", "tnv3_maxpool2x2_bn_stats_tiles", "tnv3_maxpool2x2_backward_add_bnstats", "tnv3_upsample2x_backward", "tnv3_mixup",
+           "tnv3_maxpool2x2_backward_add", "tnv3_maxpool2x2_bn_stats_tiles", "tnv3_maxpool2x2_backward_add_bnstats", "tnv3_dgrad_up2x_wino_bnstats", "tnv3_upsample2x_backward", "tnv3_mixup",
            "tnv3_grad_norm_workspace_bytes", "tnv3_grad_norm", "tnv3_adam_step", "tnv3_sgd_step", "tnv3_mixup_draw",
            "tnv3_resample_bicubic_u8", "tnv3_median_u8", "tnv3_absdiff_sum_u8", "tnv3_conv1d_act_backward", "tnv3_conv1d_k3_dgrad", "tnv3_conv1d_k3_wgrad_workspace_bytes", "tnv3_conv1d_k3_wgrad",
            "tnv3_heatmap_box_max", "tnv3_conv3x3_forward_add", "tnv3_conv_up2x_packed_floats",

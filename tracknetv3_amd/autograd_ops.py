@@ -224,12 +224,20 @@ def _train_backward_body(ctx, dev, head_backward):
             # correlation of dZ, 4/9 of the MACs, no full-resolution intermediate), the skip half as a plain 3x3 dgrad
             skip_wino = tuning.use_winograd(blk.conv.out_dim, c1, int(h), int(w))
             w_skip_t = None
+            low_stats = None
             dv = ops.dgrad_up2x_wino_variant()
             if dv == 2 and not ops.dgrad_up2x_wino_supported(c0, blk.conv.out_dim, int(h) // 2, int(w) // 2, 2):
                 dv = 0
             if tuning.UP2X_WINO and ops.dgrad_up2x_wino_supported(c0, blk.conv.out_dim, int(h) // 2, int(w) // 2, dv):
                 # 25 of the 36 F(4x4) products (variant 2), or one GEMM with K = 9 * Cout
-                d_low = ops.dgrad_up2x_wino(dz, blk.packed_dgrad_up2x_wino(c0, dv), c0, variant=dv)
+                if (dv == 2 and producer is not None and tuning.BN_BWD_STATS_IN_DGRAD_UP2X and bn_unchanged(producer)
+                        and producer["a"] is rec["x0"]):
+                    # round 6: d_low IS the producer block's dA -- the launch takes its BatchNorm-backward sums from the write-out
+                    pb = producer["blk"].bn
+                    d_low, low_stats = ops.dgrad_up2x_wino_bnstats(dz, blk.packed_dgrad_up2x_wino(c0, dv), c0, producer["z"], producer["mean"],
+                                                                   producer["invstd"], pb.weight.detach(), pb.bias.detach())
+                else:
+                    d_low = ops.dgrad_up2x_wino(dz, blk.packed_dgrad_up2x_wino(c0, dv), c0, variant=dv)
                 if not skip_wino:
                     w_skip_t = blk.packed_dgrad_up2x(c0)[1]
             else:
@@ -258,7 +266,7 @@ def _train_backward_body(ctx, dev, head_backward):
                 side_results.append((d_skip, done_ev))
             else:
                 d_skip = skip_dgrad()
-            return d_low, d_skip, None
+            return d_low, d_skip, low_stats
         if c1 == 0 and not rec["up"] and tuning.use_winograd(blk.conv.out_dim, c0, int(h), int(w)):
             # plain layer: dX = conv3x3(dZ, W^T flipped) is itself a plain 3x3 convolution -> the Winograd kernel
             if (producer is not None and tuning.BN_BWD_STATS_IN_DGRAD and tuning.wino_has_stats() and bn_unchanged(producer)
@@ -304,17 +312,24 @@ def _train_backward_body(ctx, dev, head_backward):
                 break
         return t
 
+    carried = {"stats": None}        # the sums a chain's LAST data gradient took for the block in front of the chain (decoder entries)
+
     def chain_bwd(count, da, first_needs_dx=True, stats=None):
         nonlocal idx
         d_skip = None
+        if stats is None:
+            stats, carried["stats"] = carried["stats"], None
         for k in range(count):
             rec = saved[idx]
             idx -= 1
             last = (k == count - 1)
             # inside a Double / Triple block the next record is the producer of this block's input: its BatchNorm-backward sums
             # come out of this block's data-gradient epilogue
+            # ... and the record in front of a decoder entry (the previous chain's last block) is the producer of the entry's upsampled operand
+            entry = last and rec["up"] and rec["x1"] is not None and idx >= 0
             da, d_skip, stats = block_bwd(rec, da, need_dx=(first_needs_dx or not last), da_stats=stats,
-                                          producer=(None if last else saved[idx]))
+                                          producer=(saved[idx] if (not last or entry) else None))
+        carried["stats"] = stats
         return da, d_skip
 
     # up_block_3 (2) -> dUp(128ch, full res), dSkip(x1)

@@ -314,7 +314,8 @@ __device__ __forceinline__ void wino43s_at6(float m0, float m1, float m2, float 
 template <int CBW, int STATS = 0, int GROW = 10, int TS = 10, int TL = 0, int DG = 0, int POOL = 0, int MODE = 0>
 __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const WinoArgs a) {
   using Cfg = Wino43SCfg<CBW, MODE>;
-  static_assert(MODE == 0 || (STATS == 0 && POOL == 0), "the upsampled half (and its data gradient) write plain sums");
+  static_assert(MODE == 0 || (POOL == 0 && (STATS == 0 || (MODE == 2 && STATS == 2))),
+                "the upsampled half (and its data gradient) write plain sums; the data gradient may take the BatchNorm-backward sums of what it writes");
   static_assert(STATS >= 0 && STATS <= 2 && (STATS != 2 || POOL == 0), "STATS: 0 none, 1 BatchNorm forward statistics, 2 BatchNorm backward sums (data gradient)");
   constexpr bool LOW = Cfg::LOW;
   constexpr int SC = Cfg::SC, KB = Cfg::KB, NP = Cfg::NP, NV = Cfg::NV, NSLOT = 2 * NP, PAIRS = Cfg::PAIRS, NXI = Cfg::NXI;
@@ -754,6 +755,18 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
       const int LW = W >> 1, LHW = HW >> 2;
       const tnv3_rsrc_t r_low = tnv3_make_rsrc(a.dst + ((size_t)wM.n * Cout + e_m0) * LHW, 16u * (unsigned)LHW * 4u);
       const unsigned lane_off_l = oh < H ? (unsigned)((4 * g) * LHW + (oh >> 1) * LW + (ow >> 1)) * 4u : kDmaOob;
+      // STATS == 2 (round 6): dX_low IS dA of the block whose activation the decoder entry upsamples (model.py:64-69: nothing else reads it), so this
+      // write-out takes that block's two BatchNorm + ReLU backward sums exactly as the plain data gradient's does below: bn_z = its raw convolution
+      // output at the LOW resolution (two 8-byte rows per channel and lane), constants in a.mean / a.scale / a.shift / a.bn_c4; one statistics tile
+      // = this wave's tile row = 2 x 32 low-resolution pixels, a.N * (H / 4) * tilesW of them per channel.
+      constexpr bool BNB2 = STATS == 2;
+      const tnv3_rsrc_t r_zl = tnv3_make_rsrc((BNB2 ? a.bn_z : a.dst) + ((size_t)wM.n * Cout + e_m0) * LHW, 16u * (unsigned)LHW * 4u);
+      float c_mu_n = 0.0f, c_is_n = 0.0f, c_ga_n = 0.0f, c_be_n = 0.0f;
+      auto load_c = [&](int r) {
+        const int ch = e_m0 + 4 * g + r;
+        c_mu_n = a.mean[ch]; c_is_n = a.scale[ch]; c_ga_n = a.shift[ch]; c_be_n = a.bn_c4[ch];
+      };
+      if constexpr (BNB2) load_c(0);
       auto q2 = [](float q0, float q1, float qb, float qm, float q5, float (&o)[2]) {
         const float sb = qb + qm;
         o[0] = (q0 + q1) + sb;
@@ -768,11 +781,41 @@ __global__ void __launch_bounds__(Wino43SBase::NT) conv3x3_wino43s_kernel(const 
           q2(acc[2 * j][r], acc[2 * j + 1][r], acc[10 + 2 * j][r], acc[11 + 2 * j][r], acc[20 + j][r], o);
           wv[0][j] = o[0]; wv[1][j] = o[1];
         }
+        const float c_mu = c_mu_n, c_is = c_is_n, c_sc = (float)((double)c_ga_n * (double)c_is_n), c_be = c_be_n;      // (bn_scale: the forward's rounding)
+        wf2 zr[2] = {wf2{0.0f, 0.0f}, wf2{0.0f, 0.0f}};
+        if constexpr (BNB2) {
+          if (r < 3) load_c(r + 1);
+#pragma unroll
+          for (int ar = 0; ar < 2; ++ar) zr[ar] = tnv3_buf_load_f2(r_zl, lane_off_l, (unsigned)r * (unsigned)LHW * 4u + (unsigned)(ar * LW) * 4u);
+        }
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int ar = 0; ar < 2; ++ar) {
           float o[2];
           q2(wv[ar][0], wv[ar][1], wv[ar][2], wv[ar][3], wv[ar][4], o);
           tnv3_buf_store_f2(r_low, (DG & 32) ? kDmaOob : lane_off_l, (unsigned)r * (unsigned)LHW * 4u + (unsigned)(ar * LW) * 4u, wf2{o[0], o[1]});
+          if constexpr (BNB2) {
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+              const float zc = zr[ar][b2] - c_mu;
+              const float gk = fmaf(zc, c_sc, c_be) > 0.0f ? o[b2] : 0.0f;
+              s1 += (double)gk;
+              s2 += (double)gk * (double)(zc * c_is);
+            }
+          }
+        }
+        if constexpr (BNB2) {
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+          }
+          if (tc == 0 && oh < H) {
+            const long st_tile = ((long)wM.n * (H >> 2) + (oh >> 2)) * tilesW + wM.tcol;
+            double* o = a.stats + ((size_t)(e_m0 + 4 * g + r) * ((size_t)a.N * (H >> 2) * tilesW) + st_tile) * 2;
+            o[0] = s1;
+            o[1] = s2;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -1147,14 +1147,24 @@ int dgrad_up2x_wino43_pack_launch(Launcher& L, const float* w, float* u, int cou
   return L.launch(dgrad_up2x_wino43_pack_kernel, (int)((items + 255) / 256 > 65535 ? 65535 : (items + 255) / 256), 256, w, u, cout, cin, c0);
 }
 template <class Launcher>
-int dgrad_up2x_wino43_launch(Launcher& L, const float* dz, const float* u, float* dst, int n, int c0, int cout, int hl, int wl) {
+int dgrad_up2x_wino43_launch(Launcher& L, const float* dz, const float* u, float* dst, int n, int c0, int cout, int hl, int wl, double* stats = nullptr,
+                             const float* bn_z = nullptr, const float* bn_mean = nullptr, const float* bn_invstd = nullptr, const float* bn_gamma = nullptr,
+                             const float* bn_beta = nullptr) {
   if ((((uintptr_t)dst) & 7) || (((uintptr_t)u) & 15) || (((uintptr_t)dz) & 3)) TNV3_FAIL(-1, "dgrad_up2x_wino: misaligned pointer");
+  // stats (round 6): the launch also takes the BatchNorm + ReLU backward sums of the block whose activation is upsampled (bn_z: its raw output
+  // [n][c0][hl][wl]), per tile row of 2 x 32 low-resolution pixels: [c0][n * (hl / 2) * (wl / 32)][2] doubles
+  if (stats && (!bn_z || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta || (((uintptr_t)stats | (uintptr_t)bn_z) & 7)))
+    TNV3_FAIL(-1, "dgrad_up2x_wino (BatchNorm-backward sums): needs z (8-byte aligned), mean / invstd / gamma / beta and an 8-byte aligned sums buffer");
   // the kernel's "input" is dZ (cout channels at the full resolution), its "output channels" are the layer's c0 upsampled input channels
-  WinoArgs a{dz, u, u, nullptr, nullptr, nullptr, nullptr, dst, n, cout, c0, 2 * hl, 2 * wl, 0, nullptr, nullptr, nullptr, nullptr};
+  WinoArgs a{dz, u, u, nullptr, bn_mean, bn_invstd, bn_gamma, dst, n, cout, c0, 2 * hl, 2 * wl, 0, stats, bn_z, bn_beta, nullptr};
   const bool wide = c0 % 128 == 0;
   const long npt = wide ? (long)n * (hl / 2) * (wl / 32) : (long)n * ((hl + 3) / 4) * (wl / 32);
   if (npt > (1l << 28)) TNV3_FAIL(-1, "dgrad_up2x_wino: too many tiles");
   const int grid = wino_persistent_grid(conv_grid_blocks(c0 / (wide ? 128 : 64), (int)npt));
+  if (stats) {
+    if (wide) return L.launch(conv3x3_wino43s_kernel<8, 2, kWino43UGrow, kWino43UTs, 0, 0, 0, 2>, grid, Wino43SBase::NT, a);
+    return L.launch(conv3x3_wino43s_kernel<4, 2, kWino43UGrow, kWino43UTs, 0, 0, 0, 2>, grid, Wino43SBase::NT, a);
+  }
   if (wide) return L.launch(conv3x3_wino43s_kernel<8, 0, kWino43UGrow, kWino43UTs, 0, 0, 0, 2>, grid, Wino43SBase::NT, a);
   return L.launch(conv3x3_wino43s_kernel<4, 0, kWino43UGrow, kWino43UTs, 0, 0, 0, 2>, grid, Wino43SBase::NT, a);
 }

@@ -367,6 +367,28 @@ def dgrad_up2x_wino(dz, u, c0, variant=None):
     return out
 
 
+def dgrad_up2x_wino_bnstats(dz, u, c0, z, mean, invstd, gamma, beta):
+    """dgrad_up2x_wino(variant 2) that also takes the two BatchNorm + ReLU backward sums of the block whose activation is upsampled (z: its raw
+    output at the low resolution): returns (d_low, tile_stats [C0][N * (H_low / 2) * (W_low / 32)][2] float64) for bn_relu_backward_tiles."""
+    lib = _lib.load()
+    _f32(dz, u, z, mean, invstd, gamma, beta)
+    _lib.dev_check(dz, u, z, mean, invstd, gamma, beta)
+    n, cout, h, w = (int(v_) for v_ in dz.shape)
+    c0 = int(c0)
+    if (h | w) & 1 or u.numel() != lib.tnv3_dgrad_up2x_wino_packed_floats(c0, cout, 2):
+        raise _lib.Tnv3Error("dgrad_up2x_wino_bnstats: odd output size or filter buffer / channel mismatch (the panel of variant 2 is required)")
+    hl, wl = h // 2, w // 2
+    if tuple(z.shape) != (n, c0, hl, wl) or not z.is_contiguous() or not dz.is_contiguous():
+        raise _lib.Tnv3Error("dgrad_up2x_wino_bnstats: z must be the contiguous (N, C0, H / 2, W / 2) raw output of the upsampled block")
+    if not lib.tnv3_dgrad_up2x_wino_supported(c0, cout, hl, wl, 2):
+        raise _lib.Tnv3Error(f"dgrad_up2x_wino_bnstats: unsupported shape {c0} <- {cout}, {hl}x{wl}")
+    out = torch.empty((n, c0, hl, wl), dtype=torch.float32, device=dz.device)
+    st = torch.empty((c0, n * (hl // 2) * (wl // 32), 2), dtype=torch.float64, device=dz.device)
+    _lib.check(lib.tnv3_dgrad_up2x_wino_bnstats(_lib.ptr(dz), _lib.ptr(u), _lib.ptr(out), _lib.ptr(st), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(invstd),
+                                                _lib.ptr(gamma), _lib.ptr(beta), n, c0, cout, hl, wl, 2, _lib.stream_ptr(dz)))
+    return out, st
+
+
 def pack_dgrad_up2x_weights(weight, c0):
     """nn.Conv2d weight (Cout, Cin, 3, 3) -> the 4x4 stride-2 filters of the low-resolution data gradient (first c0 inputs)."""
     lib = _lib.load()
@@ -1144,7 +1166,7 @@ _TENSOR_OPS = ["pack_conv3x3_weights", "bn_eval_scale", "pack_wino_weights", "pa
                "pack_dgrad_up2x_weights", "dgrad_up2x", "conv3x3", "head1x1_sigmoid", "maxpool2x2", "conv1d_k3", "inpaintnet_fused", "ensemble_frames",
                "heatmap_peakfind", "heatmap_box_max", "bn_train_forward", "bn_relu_backward", "bn_bwd_consts", "conv3x3_wino_dgrad_bnstats", "bn_relu_backward_tiles", "conv3x3_dgrad", "conv3x3_wgrad",
                "conv3x3_wgrad_wino", "conv3x3_wgrad_up2x", "wbce_forward", "wbce_backward", "head_backward", "head1x1_sigmoid_wbce", "head_wbce_backward",
-               "maxpool2x2_backward_add", "maxpool2x2_backward_add_bnstats", "maxpool2x2_bnstats_supported", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad",
+               "maxpool2x2_backward_add", "maxpool2x2_backward_add_bnstats", "dgrad_up2x_wino_bnstats", "maxpool2x2_bnstats_supported", "upsample2x_backward", "mixup", "conv1d_act_backward", "conv1d_k3_dgrad", "conv1d_k3_wgrad",
                "grad_norm", "adam_step", "sgd_step", "inpaintnet_pack", "inpaintnet_pack_t", "inpaintnet_fused_train_forward", "inpaintnet_fused_backward"]          # list-of-tensor ops: the guard looks inside the lists
 for _name in _TENSOR_OPS:
     globals()[_name] = _lib.on_tensor_device(globals()[_name])

@@ -267,6 +267,11 @@ BN_BWD_STATS_IN_DGRAD43 = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD43", "1") !=
 # gradient) from that pass (ops.maxpool2x2_backward_add_bnstats: it reads z instead of a, the sums cost no traffic).
 # TNV3_BN_BWD_STATS_IN_POOL=0: the separate sums pass.
 BN_BWD_STATS_IN_POOL = os.environ.get("TNV3_BN_BWD_STATS_IN_POOL", "1") != "0"
+# ... and for the block in front of a decoder entry (the bottleneck's and the first two up blocks' last layers) from the upsampled half's data
+# gradient (kernel variant 2 only: ops.dgrad_up2x_wino_bnstats) -- built, measured, OFF: these three blocks sit at the low resolutions, their
+# separate sums passes are the cheap ones (~0.1 ms together), and the epilogue costs the 25-of-36 kernel more than that: 21.99 / 21.90 ms per
+# step with it against 21.84 / 21.75 without (profiles/r06_train_step_ab.txt).  TNV3_BN_BWD_STATS_IN_DGRAD_UP2X=1 turns it on.
+BN_BWD_STATS_IN_DGRAD_UP2X = os.environ.get("TNV3_BN_BWD_STATS_IN_DGRAD_UP2X", "0") == "1"
 # Round 6: the forward twin -- the BatchNorm + ReLU pass of a down block's last layer also writes the pooled tensor (no separate pooling pass,
 # no second read of a).  TNV3_POOL_IN_BN_APPLY=0: ops.maxpool2x2 behind it.
 POOL_IN_BN_APPLY = os.environ.get("TNV3_POOL_IN_BN_APPLY", "1") != "0"
