@@ -47,12 +47,13 @@ def main():
         ws = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=dev)
         dw = torch.empty_like(ref)
         row = {"product_ms": round(timeit(lambda: ops.conv3x3_wgrad_wino(x, dz, variant=8)), 4)}
-        for rep in range(2):
+        for rep in range(int(os.environ.get("W43_REPS", "2"))):      # (interleaved repetitions; the last one's time is kept, all of them are listed)
             for sw in SWITCHES:
                 call(x, dz, dw, ws, sw)
                 d = {"ms": round(timeit(lambda: call(x, dz, dw, ws, sw)), 4)}
                 if not ((sw % 1000) & (1 | 2 | 4 | 8 | 16 | 128)):
                     d["bit_identical_to_product"] = bool(torch.equal(dw, ref))
+                d["all_ms"] = row.get(f"sw{sw}", {}).get("all_ms", []) + [d["ms"]]
                 row[f"sw{sw}"] = d
         for sw in TIMELINES:
             ws[:128].zero_()
