@@ -609,7 +609,7 @@ def e2e_leg(dev, t_frames=256):
         predict_video(src, tn, net, SEQ_LEN, 16, BG_MODE, mode, 16)      # warm-up: allocator pools of both streams
         torch.cuda.synchronize(dev)
         ts = []
-        for _ in range(3 if mode == "nonoverlap" else 2):
+        for _ in range(3):                         # (median of three: one slow run of two moved the 256-frame `weight` figure by 30 % once)
             t0 = time.perf_counter()
             pd = predict_video(src, tn, net, SEQ_LEN, 16, BG_MODE, mode, 16)
             torch.cuda.synchronize(dev)

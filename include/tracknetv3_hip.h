@@ -545,6 +545,7 @@ int tnv3_conv1d_k3_wgrad(const float* src0, const float* src1, const float* dpre
  *   dst_u8 [frames][oh][ow][c]                     (either may be NULL)
  *   tmp: frames*h*ow*c bytes of scratch (the horizontally resized intermediate)
  *   xmin/xcnt/kkx[ow][ksize_x], ymin/ycnt/kky[oh][ksize_y]: Pillow's precompute_coeffs + normalize_coeffs_8bpc tables
+ *   (ABI 8: every coefficient must fit 24 bits, |k| < 2^23 -- Pillow's are <= 1.13 * 2^22: the products are formed by full-rate 24-bit multiplies)
  *   (int32, device memory) for the two axes; they depend only on (w, ow) and (h, oh). */
 int tnv3_resample_bicubic_u8(const unsigned char* src, unsigned char* tmp, float* dst_f32, unsigned char* dst_u8,
                              const int32_t* xmin, const int32_t* xcnt, const int32_t* kkx, int ksize_x,

@@ -49,6 +49,25 @@ def test_resize_and_median_emulated_vs_oracle(emu):
         assert np.array_equal(m2.astype(np.float64) / 2, np.median(fr, 0)), t
 
 
+@pytest.mark.parametrize("cus", [1, 2])
+def test_resize_persistent_horizontal_pass_walks_many_row_groups_emulated(emu, monkeypatch, cus):
+    """Round 6's horizontal pass is a persistent workgroup (coefficients in registers, the next group of four source rows fetched while the current
+    one is computed, two LDS stages): with 1 / 2 emulated CUs (3 / 6 workgroups) every workgroup walks several row groups, the last group is
+    partial (rows % 4 != 0), and 40 output columns leave most threads of the second column set idle.  Bit-exact against Pillow's algorithm."""
+    from tracknetv3_amd import preprocess as pre
+    monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
+    rng = np.random.RandomState(7)
+    for (f, h, w, oh, ow) in ((3, 54, 96, 16, 32), (2, 23, 64, 9, 40), (1, 37, 160, 10, 300)):
+        fr = rng.randint(0, 256, (f, h, w, 3)).astype(np.uint8)
+        fr[0, :5] = 255
+        fr[-1, -3:] = 0
+        f32, u8 = pre.resize_frames(torch.from_numpy(fr), oh, ow, want_f32=True, want_u8=True)
+        for k in range(f):
+            want = opre.resize_bicubic_u8(fr[k], ow, oh)
+            assert np.array_equal(u8[k].numpy(), want), (f, h, w, oh, ow, k)
+            assert np.array_equal(f32[k].numpy(), opre.normalise_u8(np.moveaxis(want, -1, 0)))
+
+
 def test_preprocess_video_matches_reference_dataset_layout(emu):
     """median first for 'concat', frame channels RGB-major, /255 -- vs the oracle's restatement of dataset.py:427-461."""
     from tracknetv3_amd import preprocess as pre

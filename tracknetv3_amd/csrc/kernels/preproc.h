@@ -13,6 +13,18 @@ namespace tnv3 {
 
 constexpr int kResampleBits = 22;
 constexpr int kResampleMaxRowBytes = 32 * 1024;     // one source row (W*C bytes) staged in LDS
+constexpr int kResamplePersistRowBytes = 6144;             // one staged row of the persistent horizontal pass
+
+// pixel (8 bits) x coefficient (Pillow's are <= 2^22 in magnitude: normalised weights scaled by 2^22; the contract of the tables is |k| < 2^23) as
+// a 24-bit multiply: v_mad_i32_i24 runs at full rate, the 32-bit v_mul_lo_u32 the compiler must otherwise emit at a quarter of it -- the
+// horizontal pass was 245 of those per thread and row group (round 6; the pass did not get faster by it alone: it is not bound by its arithmetic).  Same integers.
+__device__ __forceinline__ int resample_mul24(int pixel, int coeff) {
+#ifdef TNV3_EMU
+  return pixel * coeff;
+#else
+  return __mul24(pixel, coeff);
+#endif
+}
 
 __device__ __forceinline__ unsigned char resample_clip8(int acc) {
   const int v = acc >> kResampleBits;
@@ -34,7 +46,7 @@ inline __global__ void __launch_bounds__(256) resample_h_u8_kernel(const unsigne
     const int x0 = xmin[xx], n = xcnt[xx];
     const int* k = kk + (size_t)xx * ksize;
     int acc = 1 << (kResampleBits - 1);
-    for (int x = 0; x < n; ++x) acc += (int)row_s[(x0 + x) * C + c] * k[x];
+    for (int x = 0; x < n; ++x) acc += resample_mul24((int)row_s[(x0 + x) * C + c], k[x]);
     d[o] = resample_clip8(acc);
   }
 }
@@ -50,7 +62,7 @@ inline __global__ void __launch_bounds__(256) resample_v_u8_kernel(const unsigne
   const unsigned char* s = src + ((size_t)f * H + y0) * OW * C;
   for (int o = threadIdx.x; o < OW * C; o += 256) {
     int acc = 1 << (kResampleBits - 1);
-    for (int y = 0; y < n; ++y) acc += (int)s[(size_t)y * OW * C + o] * k[y];
+    for (int y = 0; y < n; ++y) acc += resample_mul24((int)s[(size_t)y * OW * C + o], k[y]);
     const unsigned char v = resample_clip8(acc);
     const int xx = o / C, c = o - xx * C;
     if (dst_u8) dst_u8[((size_t)f * OH + yy) * OW * C + o] = v;
@@ -89,13 +101,100 @@ __global__ void __launch_bounds__(256) resample_h_rgb_kernel(const unsigned char
       int a0 = 1 << (kResampleBits - 1), a1 = a0, a2 = a0;
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) {                             // taps beyond n carry a zero coefficient (reads stay inside the slack)
-        a0 += (int)p[j * C] * k[j];
-        a1 += (int)p[j * C + 1] * k[j];
-        a2 += (int)p[j * C + 2] * k[j];
+        a0 += resample_mul24((int)p[j * C], k[j]);
+        a1 += resample_mul24((int)p[j * C + 1], k[j]);
+        a2 += resample_mul24((int)p[j * C + 2], k[j]);
       }
       unsigned char* d = dst + ((r0 + r) * (size_t)OW + xx) * C;
       d[0] = resample_clip8(a0); d[1] = resample_clip8(a1); d[2] = resample_clip8(a2);
     }
+  }
+}
+
+// Round 6: the same pass as a PERSISTENT workgroup (grid = a few per CU, each walks many groups of RPB source rows): a thread keeps the
+// coefficients of its NXC output columns in registers for the kernel's lifetime (the kernel above re-fetches 20 table entries per column and row
+// group), and the next group's rows are fetched into registers BEFORE the current group is computed and stored into the other half of a
+// double-buffered LDS stage behind it.  Measured on 256 frames of 1080p -> 512 columns: 1222 us (kernel above) -> 1059 us; what was tried on top
+// and did not move it: 24-bit multiplies with or without SDWA byte selects (1076 / 1120), dword stores packed from four lanes through a shuffle
+// (1720), two instead of four rows per group = six instead of three workgroups per CU (1059 vs 1076) -- the pass moves its 2.0 GB at 1.9 TB/s like
+// the vertical pass (2.1) and the median (2.1), neither its arithmetic (~0.45 ms), its LDS reads nor its occupancy set that.
+// OW <= 256 * NXC.  Same arithmetic, same bits.
+template <int KMAX, int RPB, int NXC>
+__global__ void __launch_bounds__(256) resample_h_rgb_persist_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                                     const int* __restrict__ xmin, const int* __restrict__ xcnt,
+                                                                     const int* __restrict__ kk, int ksize, long rows, int W, int OW) {
+  constexpr int C = 3;
+  constexpr int kRowStride = kResamplePersistRowBytes;             // bytes reserved per staged row (incl. tail slack): 1080p RGB rows are 5760
+  constexpr int kStage = kRowStride * RPB;                         // bytes per LDS stage (two stages)
+  constexpr int NV = (kStage / 16 + 255) / 256;                    // 16-byte vectors per thread and stage (upper bound)
+  __shared__ __attribute__((aligned(16))) unsigned char row_s[2 * kStage];
+  const int rowb = W * C;                                          // host guarantees rowb % 16 == 0, rowb + KMAX*C <= kRowStride
+  const int vec_per_row = rowb / 16, nvec = RPB * vec_per_row;
+  const long groups = (rows + RPB - 1) / RPB;
+  int x0[NXC], k[NXC][KMAX];
+#pragma unroll
+  for (int c = 0; c < NXC; ++c) {
+    const int xx = threadIdx.x + 256 * c;
+    const bool on = xx < OW;
+    x0[c] = on ? xmin[xx] : 0;
+    const int n = on ? xcnt[xx] : 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) k[c][j] = j < n ? kk[(size_t)xx * ksize + j] : 0;
+  }
+  uint4 nxt[NV];
+  auto fetch = [&](long g) {                                      // rows of group g -> registers (rows beyond the last: zeros, never stored)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      const int r = e / vec_per_row, v = e - r * vec_per_row;
+      nxt[i] = (e < nvec && g * RPB + r < rows) ? *reinterpret_cast<const uint4*>(src + (g * RPB + r) * (size_t)rowb + 16 * v) : uint4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stash = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      const int r = e / vec_per_row, v = e - r * vec_per_row;
+      if (e < nvec) *reinterpret_cast<uint4*>(row_s + stage * kStage + r * kRowStride + 16 * v) = nxt[i];
+    }
+  };
+  long g = blockIdx.x;
+  if (g >= groups) return;
+  fetch(g);
+  stash(0);
+  __syncthreads();
+  int cur = 0;
+  for (; g < groups; g += gridDim.x) {
+    const long gn = g + gridDim.x;
+    if (gn < groups) fetch(gn);
+    const long r0 = g * RPB;
+#pragma unroll
+    for (int c = 0; c < NXC; ++c) {
+      const int xx = threadIdx.x + 256 * c;
+#pragma unroll
+      for (int r = 0; r < RPB; ++r) {
+        const bool on = xx < OW && r0 + r < rows;
+        unsigned v = 0u;
+        if (on) {
+          const unsigned char* p = row_s + cur * kStage + r * kRowStride + x0[c] * C;
+          int a0 = 1 << (kResampleBits - 1), a1 = a0, a2 = a0;
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j) {                         // taps beyond the column's count carry a zero coefficient (reads stay inside the slack)
+            a0 += resample_mul24((int)p[j * C], k[c][j]);
+            a1 += resample_mul24((int)p[j * C + 1], k[c][j]);
+            a2 += resample_mul24((int)p[j * C + 2], k[c][j]);
+          }
+          v = (unsigned)resample_clip8(a0) | ((unsigned)resample_clip8(a1) << 8) | ((unsigned)resample_clip8(a2) << 16);
+        }
+        if (on) {                                                  // (byte stores: packing four lanes' bytes into dword stores through a lane shuffle measured SLOWER, 1076 -> 1720 us)
+          unsigned char* d = dst + ((r0 + r) * (size_t)OW + xx) * C;
+          d[0] = (unsigned char)(v & 255u); d[1] = (unsigned char)((v >> 8) & 255u); d[2] = (unsigned char)(v >> 16);
+        }
+      }
+    }
+    if (gn < groups) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
 }
 
@@ -114,7 +213,8 @@ inline __global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsig
     for (int y = 0; y < n; ++y) {
       const unsigned v = *reinterpret_cast<const unsigned int*>(s + (size_t)y * rowb + 4 * q);
       const int ky = k[y];
-      a0 += (int)(v & 255u) * ky; a1 += (int)((v >> 8) & 255u) * ky; a2 += (int)((v >> 16) & 255u) * ky; a3 += (int)(v >> 24) * ky;
+      a0 += resample_mul24((int)(v & 255u), ky); a1 += resample_mul24((int)((v >> 8) & 255u), ky);
+      a2 += resample_mul24((int)((v >> 16) & 255u), ky); a3 += resample_mul24((int)(v >> 24), ky);
     }
     const unsigned char o[4] = {resample_clip8(a0), resample_clip8(a1), resample_clip8(a2), resample_clip8(a3)};
     if (dst_u8)

@@ -1714,7 +1714,14 @@ int resample_bicubic_u8_impl(Launcher& L, const unsigned char* src, unsigned cha
   const long rows = (long)frames * h;
   const bool fast_h = c == 3 && ksx <= KMAX && (w * c) % 16 == 0 && w * c + KMAX * 3 <= kResampleMaxRowBytes / RPB &&
                       (((uintptr_t)src) & 15) == 0;
-  if (fast_h) rc = L.launch(resample_h_rgb_kernel<KMAX, RPB>, (int)((rows + RPB - 1) / RPB), 256, src, tmp, xmin, xcnt, kkx, ksx, rows, w, ow);
+  // (round 6) up to 512 output columns: the persistent form -- coefficients live in registers, rows are double-buffered
+  const bool persist_h = fast_h && ow <= 512 && w * c + KMAX * 3 <= kResamplePersistRowBytes;
+  if (persist_h) {
+    constexpr int PR = 2;                              // rows per group: 2 x 2 x 6 KB of LDS -> six resident workgroups per CU
+    const long groups = (rows + PR - 1) / PR;
+    const long cap = 6l * num_cus();
+    rc = L.launch(resample_h_rgb_persist_kernel<KMAX, PR, 2>, (int)(groups < cap ? groups : cap), 256, src, tmp, xmin, xcnt, kkx, ksx, rows, w, ow);
+  } else if (fast_h) rc = L.launch(resample_h_rgb_kernel<KMAX, RPB>, (int)((rows + RPB - 1) / RPB), 256, src, tmp, xmin, xcnt, kkx, ksx, rows, w, ow);
   else rc = L.launch(resample_h_u8_kernel, frames * h, 256, src, tmp, xmin, xcnt, kkx, ksx, h, w, c, ow);
   if (rc) return rc;
   if ((ow * c) % 4 == 0 && (((uintptr_t)tmp | (uintptr_t)dst_u8) & 3) == 0)

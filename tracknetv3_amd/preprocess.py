@@ -57,8 +57,13 @@ _tables = {}
 def _device_tables(h, w, oh, ow, device):
     key = (h, w, oh, ow, str(device))
     if key not in _tables:
-        xs = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in resample_coeffs(w, ow)]
-        ys = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in resample_coeffs(h, oh)]
+        cx, cy = resample_coeffs(w, ow), resample_coeffs(h, oh)
+        # the kernels multiply pixel x coefficient as 24-bit integers (full-rate v_mad_i32_i24): Pillow's normalised weights stay below 1.13 * 2^22
+        # (measured over size pairs from 1 to 1920); a table beyond 2^23 would be a different filter, and a wrong result
+        if max(int(np.abs(cx[2]).max()), int(np.abs(cy[2]).max())) >= (1 << 23):
+            raise _lib.Tnv3Error("resize_frames: a resampling coefficient does not fit 24 bits")
+        xs = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in cx]
+        ys = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in cy]
         lut = torch.from_numpy((np.arange(256, dtype=np.float64) / 255.0).astype(np.float32)).to(device)   # `/= 255.` then .float()
         _tables[key] = (xs, ys, lut)
     return _tables[key]
