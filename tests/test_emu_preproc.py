@@ -57,7 +57,7 @@ def test_resize_persistent_horizontal_pass_walks_many_row_groups_emulated(emu, m
     from tracknetv3_amd import preprocess as pre
     monkeypatch.setenv("TNV3_EMU_CUS", str(cus))
     rng = np.random.RandomState(7)
-    for (f, h, w, oh, ow) in ((3, 54, 96, 16, 32), (2, 23, 64, 9, 40), (1, 37, 160, 10, 300)):
+    for (f, h, w, oh, ow) in ((3, 54, 96, 16, 32), (2, 23, 64, 9, 40), (1, 37, 160, 10, 300), (2, 61, 64, 7, 48), (1, 9, 32, 20, 16)):      # (9 -> 20 rows: up-scaling, five taps)
         fr = rng.randint(0, 256, (f, h, w, 3)).astype(np.uint8)
         fr[0, :5] = 255
         fr[-1, -3:] = 0

@@ -26,6 +26,21 @@ __device__ __forceinline__ int resample_mul24(int pixel, int coeff) {
 #endif
 }
 
+// a volatile 32-bit view of LDS that stays an LDS pointer (a volatile access through a generic pointer is a flat load)
+#ifdef TNV3_EMU
+typedef const volatile unsigned* resample_lds_cvu_p;
+#else
+typedef const volatile __attribute__((address_space(3))) unsigned* resample_lds_cvu_p;
+#endif
+// ({hi, lo} >> 8 s) as 32 bits, s = 0 .. 3: v_alignbyte_b32
+__device__ __forceinline__ unsigned resample_alignbyte(unsigned hi, unsigned lo, unsigned s) {
+#ifdef TNV3_EMU
+  return (unsigned)(((((unsigned long long)hi) << 32) | (unsigned long long)lo) >> (8u * (s & 3u)));
+#else
+  return __builtin_amdgcn_alignbyte(hi, lo, s);
+#endif
+}
+
 __device__ __forceinline__ unsigned char resample_clip8(int acc) {
   const int v = acc >> kResampleBits;
   return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
@@ -176,13 +191,25 @@ __global__ void __launch_bounds__(256) resample_h_rgb_persist_kernel(const unsig
         const bool on = xx < OW && r0 + r < rows;
         unsigned v = 0u;
         if (on) {
-          const unsigned char* p = row_s + cur * kStage + r * kRowStride + x0[c] * C;
+          // The window's 3 KMAX bytes start at byte 3 x0 of the row: ANY alignment.  Read through a byte pointer the compiler merges them into
+          // ds_read_b128 / _b96 at that address -- and a DS access wider than 32 bits off its natural alignment is replayed at 64 cycles per
+          // wave-instruction (hardware guide, guideline 17): that, not arithmetic or HBM, was this pass's time.  So: 32-bit reads of the aligned
+          // dwords around the window (volatile: not to be merged again), realigned in registers with v_alignbyte_b32.
+          const unsigned b0 = (unsigned)(x0[c] * C);
+          const resample_lds_cvu_p pw = (resample_lds_cvu_p)(row_s + cur * kStage + r * kRowStride + (b0 & ~3u));
+          constexpr int NW = (KMAX * C + 3) / 4;                   // dwords of the window
+          unsigned dd[NW + 1], ww[NW];
+#pragma unroll
+          for (int i = 0; i <= NW; ++i) dd[i] = pw[i];
+#pragma unroll
+          for (int i = 0; i < NW; ++i) ww[i] = resample_alignbyte(dd[i + 1], dd[i], b0 & 3u);
           int a0 = 1 << (kResampleBits - 1), a1 = a0, a2 = a0;
 #pragma unroll
           for (int j = 0; j < KMAX; ++j) {                         // taps beyond the column's count carry a zero coefficient (reads stay inside the slack)
-            a0 += resample_mul24((int)p[j * C], k[c][j]);
-            a1 += resample_mul24((int)p[j * C + 1], k[c][j]);
-            a2 += resample_mul24((int)p[j * C + 2], k[c][j]);
+            const int t0 = j * C, t1 = j * C + 1, t2 = j * C + 2;
+            a0 += resample_mul24((int)((ww[t0 >> 2] >> (8 * (t0 & 3))) & 255u), k[c][j]);
+            a1 += resample_mul24((int)((ww[t1 >> 2] >> (8 * (t1 & 3))) & 255u), k[c][j]);
+            a2 += resample_mul24((int)((ww[t2 >> 2] >> (8 * (t2 & 3))) & 255u), k[c][j]);
           }
           v = (unsigned)resample_clip8(a0) | ((unsigned)resample_clip8(a1) << 8) | ((unsigned)resample_clip8(a2) << 16);
         }
@@ -229,6 +256,11 @@ inline __global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsig
     }
   }
 }
+
+// (Round 6 built two more forms of the vertical pass and measured both on 256 frames of 1080p -> 288 x 512: the support rows staged in LDS with 16-byte
+//  loads and one 16-byte store per thread into a colour plane instead of four scattered 4-byte stores: 439 us against this kernel's 442; the same with
+//  eight adjacent output rows per workgroup from one staged window, so that a source row is fetched once instead of ~4 times: 667 us.  Neither the
+//  stores' shape nor the re-reads are what its time is; the kernel above stays.)
 
 // Median over T frames of P bytes each: frames [T][P] u8 -> med [P] u8 = floor((v[(T-1)/2] + v[T/2]) / 2).
 // 128 threads x 256 32-bit bins = 128 KB of LDS; bin-major layout keeps the 32 lanes of a half-wave on 32 banks.

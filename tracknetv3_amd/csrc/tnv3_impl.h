@@ -1715,9 +1715,9 @@ int resample_bicubic_u8_impl(Launcher& L, const unsigned char* src, unsigned cha
   const bool fast_h = c == 3 && ksx <= KMAX && (w * c) % 16 == 0 && w * c + KMAX * 3 <= kResampleMaxRowBytes / RPB &&
                       (((uintptr_t)src) & 15) == 0;
   // (round 6) up to 512 output columns: the persistent form -- coefficients live in registers, rows are double-buffered
-  const bool persist_h = fast_h && ow <= 512 && w * c + KMAX * 3 <= kResamplePersistRowBytes;
+  const bool persist_h = fast_h && ow <= 512 && w * c + KMAX * 3 + 8 <= kResamplePersistRowBytes;      // (+ 8: the aligned dwords around the last window)
   if (persist_h) {
-    constexpr int PR = 2;                              // rows per group: 2 x 2 x 6 KB of LDS -> six resident workgroups per CU
+    constexpr int PR = 2;                              // rows per group: 2 x 2 x 6 KB of LDS -> six resident workgroups per CU (four rows: 713 vs 659 us)
     const long groups = (rows + PR - 1) / PR;
     const long cap = 6l * num_cus();
     rc = L.launch(resample_h_rgb_persist_kernel<KMAX, PR, 2>, (int)(groups < cap ? groups : cap), 256, src, tmp, xmin, xcnt, kkx, ksx, rows, w, ow);
