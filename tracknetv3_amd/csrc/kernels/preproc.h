@@ -226,11 +226,8 @@ __global__ void __launch_bounds__(256) resample_h_rgb_persist_kernel(const unsig
 }
 
 // Vertical pass, four consecutive output bytes per thread (32-bit loads of the intermediate rows); (OW*C) % 4 == 0.
-// KYMAX > 0 (round 6; needs ksize <= KYMAX): the loads of ALL support rows are issued before the first multiply -- rows beyond the support
-// re-read its last row against a zero coefficient.  The loop form (KYMAX = 0) waits one memory latency per support row: with ~15 rows per output
-// row that wait, not traffic or arithmetic, was the pass's 0.44 ms per 256 frames of 1080p.
-template <int KYMAX>
-__global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst_f32,
+// (Round 6 also tried this loop with the loads of all support rows issued ahead of the first multiply: 437 us against 442 -- not its limiter either.)
+inline __global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst_f32,
                                                               unsigned char* __restrict__ dst_u8, const int* __restrict__ ymin,
                                                               const int* __restrict__ ycnt, const int* __restrict__ kk, int ksize,
                                                               const float* __restrict__ lut, int H, int OW, int C, int OH) {
@@ -241,24 +238,11 @@ __global__ void __launch_bounds__(256) resample_v_u8x4_kernel(const unsigned cha
   const unsigned char* s = src + ((size_t)f * H + y0) * rowb;
   for (int q = threadIdx.x; q < rowb / 4; q += 256) {
     int a0 = 1 << (kResampleBits - 1), a1 = a0, a2 = a0, a3 = a0;
-    if constexpr (KYMAX > 0) {
-      unsigned vv[KYMAX];
-#pragma unroll
-      for (int y = 0; y < KYMAX; ++y) vv[y] = *reinterpret_cast<const unsigned int*>(s + (size_t)(y < n ? y : (n > 0 ? n - 1 : 0)) * rowb + 4 * q);
-#pragma unroll
-      for (int y = 0; y < KYMAX; ++y) {
-        const int ky = y < n ? k[y < ksize ? y : ksize - 1] : 0;
-        const unsigned v = vv[y];
-        a0 += resample_mul24((int)(v & 255u), ky); a1 += resample_mul24((int)((v >> 8) & 255u), ky);
-        a2 += resample_mul24((int)((v >> 16) & 255u), ky); a3 += resample_mul24((int)(v >> 24), ky);
-      }
-    } else {
-      for (int y = 0; y < n; ++y) {
-        const unsigned v = *reinterpret_cast<const unsigned int*>(s + (size_t)y * rowb + 4 * q);
-        const int ky = k[y];
-        a0 += resample_mul24((int)(v & 255u), ky); a1 += resample_mul24((int)((v >> 8) & 255u), ky);
-        a2 += resample_mul24((int)((v >> 16) & 255u), ky); a3 += resample_mul24((int)(v >> 24), ky);
-      }
+    for (int y = 0; y < n; ++y) {
+      const unsigned v = *reinterpret_cast<const unsigned int*>(s + (size_t)y * rowb + 4 * q);
+      const int ky = k[y];
+      a0 += resample_mul24((int)(v & 255u), ky); a1 += resample_mul24((int)((v >> 8) & 255u), ky);
+      a2 += resample_mul24((int)((v >> 16) & 255u), ky); a3 += resample_mul24((int)(v >> 24), ky);
     }
     const unsigned char o[4] = {resample_clip8(a0), resample_clip8(a1), resample_clip8(a2), resample_clip8(a3)};
     if (dst_u8)

@@ -1724,11 +1724,8 @@ int resample_bicubic_u8_impl(Launcher& L, const unsigned char* src, unsigned cha
   } else if (fast_h) rc = L.launch(resample_h_rgb_kernel<KMAX, RPB>, (int)((rows + RPB - 1) / RPB), 256, src, tmp, xmin, xcnt, kkx, ksx, rows, w, ow);
   else rc = L.launch(resample_h_u8_kernel, frames * h, 256, src, tmp, xmin, xcnt, kkx, ksx, h, w, c, ow);
   if (rc) return rc;
-  if ((ow * c) % 4 == 0 && (((uintptr_t)tmp | (uintptr_t)dst_u8) & 3) == 0) {
-    if (ksy <= 20)                                     // (every down-scale up to 4.5x: all support rows' loads in flight at once)
-      return L.launch(resample_v_u8x4_kernel<20>, frames * oh, 256, (const unsigned char*)tmp, dst_f32, dst_u8, ymin, ycnt, kky, ksy, lut, h, ow, c, oh);
-    return L.launch(resample_v_u8x4_kernel<0>, frames * oh, 256, (const unsigned char*)tmp, dst_f32, dst_u8, ymin, ycnt, kky, ksy, lut, h, ow, c, oh);
-  }
+  if ((ow * c) % 4 == 0 && (((uintptr_t)tmp | (uintptr_t)dst_u8) & 3) == 0)
+    return L.launch(resample_v_u8x4_kernel, frames * oh, 256, (const unsigned char*)tmp, dst_f32, dst_u8, ymin, ycnt, kky, ksy, lut, h, ow, c, oh);
   return L.launch(resample_v_u8_kernel, frames * oh, 256, (const unsigned char*)tmp, dst_f32, dst_u8, ymin, ycnt, kky, ksy, lut, h, ow, c, oh);
 }
 
